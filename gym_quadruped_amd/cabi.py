@@ -1,0 +1,118 @@
+"""ctypes mirror of ``include/gq.h`` (the C-ABI boundary) and the ModelDesc -> GqModelDesc marshaller.
+
+The reference reaches its physics through the ``mujoco`` pybind API (SURVEY.md §8b lower boundary); this
+module is the equivalent binding layer for ``libgq.so``: plain pointers and sizes, no torch types.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .mjcf import ModelDesc
+
+GQ_NLEG = 4
+
+_I = C.POINTER(C.c_int32)
+_D = C.POINTER(C.c_double)
+
+
+class GqModelDesc(C.Structure):
+    _fields_ = [
+        ('nq', C.c_int32), ('nv', C.c_int32), ('nu', C.c_int32), ('nbody', C.c_int32), ('njnt', C.c_int32),
+        ('ngeom', C.c_int32), ('ncloud', C.c_int32), ('nvert', C.c_int32),
+        ('timestep', C.c_double), ('gravity', C.c_double * 3), ('cone', C.c_int32), ('impratio', C.c_double),
+        ('integrator', C.c_int32),
+        ('body_parentid', _I), ('body_pos', _D), ('body_quat', _D), ('body_ipos', _D), ('body_iquat', _D),
+        ('body_mass', _D), ('body_inertia', _D), ('body_jntadr', _I), ('body_jntnum', _I), ('body_invweight0', _D),
+        ('jnt_type', _I), ('jnt_bodyid', _I), ('jnt_qposadr', _I), ('jnt_dofadr', _I), ('jnt_pos', _D),
+        ('jnt_axis', _D), ('jnt_limited', _I), ('jnt_range', _D), ('jnt_margin', _D), ('jnt_solref', _D),
+        ('jnt_solimp', _D), ('jnt_actfrclimited', _I), ('jnt_actfrcrange', _D), ('qpos0', _D),
+        ('dof_bodyid', _I), ('dof_jntid', _I), ('dof_parentid', _I), ('dof_damping', _D), ('dof_armature', _D),
+        ('dof_frictionloss', _D), ('dof_solref', _D), ('dof_solimp', _D), ('dof_invweight0', _D),
+        ('geom_bodyid', _I), ('geom_pos', _D), ('geom_quat', _D), ('geom_cloudid', _I), ('geom_friction', _D),
+        ('geom_margin', _D), ('geom_gap', _D), ('geom_condim', _I), ('geom_priority', _I), ('geom_solref', _D),
+        ('geom_solimp', _D), ('geom_solmix', _D), ('geom_rbound', _D),
+        ('cloud_vertadr', _I), ('cloud_vertnum', _I), ('cloud_radius', _D), ('vert_pos', _D),
+        ('actuator_trnid', _I), ('actuator_gear', _D), ('actuator_ctrllimited', _I), ('actuator_ctrlrange', _D),
+        ('actuator_forcelimited', _I), ('actuator_forcerange', _D),
+        ('floor_friction', C.c_double * 3), ('floor_margin', C.c_double), ('floor_gap', C.c_double),
+        ('floor_solmix', C.c_double), ('floor_solref', C.c_double * 2), ('floor_solimp', C.c_double * 5),
+        ('floor_condim', C.c_int32), ('floor_priority', C.c_int32),
+        ('feet_geomid', C.c_int32 * GQ_NLEG), ('terrain_limits', C.c_double * 4), ('meaninertia', C.c_double),
+        ('solver', C.c_int32), ('iterations', C.c_int32), ('tolerance', C.c_double),
+    ]
+
+
+class GqState(C.Structure):
+    _fields_ = [('qpos', C.c_void_p), ('qvel', C.c_void_p), ('qacc', C.c_void_p), ('qacc_warmstart', C.c_void_p),
+                ('qfrc_applied', C.c_void_p), ('time', C.c_void_p), ('friction', C.c_void_p), ('cmd', C.c_void_p)]
+
+
+class GqObsOut(C.Structure):
+    _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('terminated', C.c_void_p), ('truncated', C.c_void_p),
+                ('invalid_contact', C.c_void_p), ('step_num', C.c_void_p)]
+
+
+# index into QuadrupedEnv.ALL_OBS (reference quadruped_env.py:35-66,81) == enum GqObsId
+ALL_OBS = [
+    'base_pos', 'base_lin_vel', 'base_lin_vel_err', 'base_lin_acc', 'base_ang_vel', 'base_ang_vel_err',
+    'base_ori_euler_xyz', 'base_ori_quat_wxyz', 'base_ori_SO3', 'gravity_vector:base',
+    'base_lin_vel:base', 'base_lin_vel_err:base', 'base_lin_acc:base', 'base_ang_vel:base', 'base_ang_vel_err:base',
+    'qpos', 'qvel', 'tau_ctrl_setpoint', 'qpos_js', 'qvel_js', 'kinetic_energy', 'work',
+    'feet_pos', 'feet_pos:base', 'feet_vel', 'feet_vel_rel', 'feet_vel:base', 'feet_vel_rel:base',
+    'contact_state', 'contact_forces', 'contact_forces:base',
+]
+OBS_DIMS = [3, 3, 3, 3, 3, 3, 3, 4, 9, 3, 3, 3, 3, 3, 3, 19, 18, 12, 12, 12, 1, 1, 12, 12, 12, 12, 12, 12, 4, 12, 12]
+LEG_NAMES = ['FL', 'FR', 'RL', 'RR']
+
+SOLVER_PGS, SOLVER_NEWTON = 0, 1
+
+
+class MarshalledModel:
+    """Owns the numpy buffers a GqModelDesc points into (keep alive for as long as the struct is in use)."""
+
+    def __init__(self, md: ModelDesc, *, qpos0=None, feet_geom_names=None, terrain_limits=(1e4, -1e4, 1e4, -1e4),
+                 timestep=None, solver=SOLVER_PGS, iterations=100, tolerance=1e-8, floor=None):
+        self.md = md
+        self._keep = []
+        d = GqModelDesc()
+        nvert = int(md.vert_pos.shape[0])
+        for k in ('nq', 'nv', 'nu', 'nbody', 'njnt', 'ngeom'):
+            setattr(d, k, int(getattr(md, k)))
+        d.ncloud, d.nvert = int(len(md.cloud_vertnum)), nvert
+        d.timestep = float(md.timestep if timestep is None else timestep)
+        d.gravity = (C.c_double * 3)(*md.gravity)
+        d.cone, d.impratio, d.integrator = int(md.cone), float(md.impratio), int(md.integrator)
+        q0 = np.array(md.qpos0 if qpos0 is None else qpos0, dtype=np.float64)
+        for name, ctype in GqModelDesc._fields_:
+            if ctype in (_I, _D):
+                src = q0 if name == 'qpos0' else getattr(md, name)
+                arr = np.ascontiguousarray(src, dtype=np.int32 if ctype is _I else np.float64)
+                if arr.size == 0:
+                    arr = np.zeros(1, dtype=arr.dtype)
+                self._keep.append(arr)
+                setattr(d, name, arr.ctypes.data_as(ctype))
+        fl = dict(friction=(1.0, 0.005, 0.0001), margin=0.0, gap=0.0, solmix=1.0, solref=(0.02, 1.0),
+                  solimp=(0.9, 0.95, 0.001, 0.5, 2.0), condim=3, priority=0)
+        fl.update(floor or {})
+        d.floor_friction = (C.c_double * 3)(*fl['friction'])
+        d.floor_margin, d.floor_gap, d.floor_solmix = fl['margin'], fl['gap'], fl['solmix']
+        d.floor_solref = (C.c_double * 2)(*fl['solref'])
+        d.floor_solimp = (C.c_double * 5)(*fl['solimp'])
+        d.floor_condim, d.floor_priority = fl['condim'], fl['priority']
+        names = feet_geom_names or {k: k for k in LEG_NAMES}
+        d.feet_geomid = (C.c_int32 * 4)(*[md.geom_names.index(names[k]) for k in LEG_NAMES])
+        d.terrain_limits = (C.c_double * 4)(*terrain_limits)
+        d.meaninertia = float(md.meaninertia)
+        d.solver, d.iterations, d.tolerance = int(solver), int(iterations), float(tolerance)
+        self.desc = d
+
+
+def obs_ids_from_names(names):
+    ids = []
+    for n in names:
+        if n not in ALL_OBS:
+            raise ValueError(f'Invalid observation name: {n}, available obs: {ALL_OBS}')
+        ids.append(ALL_OBS.index(n))
+    return ids

@@ -1,0 +1,218 @@
+/*
+ * gq.h - C-ABI of libgq, the MI355X-native batched replacement for the MuJoCo
+ * calls on gym-quadruped's QuadrupedEnv.step() hot path.
+ *
+ * Every entry point names the reference interface it replaces.  Reference
+ * paths are relative to the gym-quadruped repository (iit-DLSLab/gym-quadruped
+ * v1.1.5); "mujoco.*" is the third-party pybind API the reference calls.
+ *
+ *   reference call site                                   replaced by
+ *   ----------------------------------------------------  --------------------
+ *   mujoco.MjModel.from_xml_path   quadruped_env.py:170    gq_model_create
+ *   mujoco.MjData(model)           quadruped_env.py:178    gq_batch_create
+ *   mujoco.mj_step                 quadruped_env.py:271    gq_step  (+ the
+ *     _get_obs / _check_* epilogue quadruped_env.py:277-285, :1146-1257)
+ *   mujoco.mj_step1                quadruped_env.py:376    gq_reset (lift loop)
+ *   mj_resetDataKeyframe + reset   quadruped_env.py:343-397 gq_reset
+ *   mujoco.mj_jac                  quadruped_env.py:728    gq_step obs epilogue
+ *   mujoco.mj_contactForce         quadruped_env.py:852    gq_step obs epilogue
+ *   mujoco.mj_fullM                quadruped_env.py:940    gq_step obs epilogue
+ *
+ * Conventions
+ *  - plain C, no exceptions cross the boundary; every function returns 0 on
+ *    success or a negative GQ_E* code, text via gq_last_error().
+ *  - all batch tensors are CALLER-owned device memory (PyTorch-ROCm
+ *    allocations), passed as raw pointers; the library owns only the opaque
+ *    GqModel / GqBatch handles (model constants + debug scratch on device).
+ *  - batch layout: one array per field, env-major rows:  field[env][dim].
+ *    One wavefront owns one env, so each row is read/written by consecutive
+ *    lanes = one coalesced <=128 B segment per access (DESIGN.md "HBM layout").
+ *  - every launch is asynchronous on the hipStream_t passed in (as void*);
+ *    no hidden synchronisation.  Handles are not thread-safe.
+ */
+#ifndef GQ_H_
+#define GQ_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GQ_OK 0
+#define GQ_EINVAL (-1)   /* bad argument / unsupported model feature */
+#define GQ_ENOMEM (-2)
+#define GQ_EDEVICE (-3)  /* HIP runtime error */
+#define GQ_ENODEVICE (-4)
+
+#define GQ_NLEG 4
+#define GQ_MAX_NV 18
+#define GQ_MAX_NBODY 14
+
+/* ---- model description: flat host arrays produced by the MJCF compiler -------------
+ * (gym_quadruped_amd/mjcf.py; field names follow mujoco.MjModel).  All pointers are
+ * host memory, read during gq_model_create only. */
+typedef struct GqModelDesc {
+  /* sizes */
+  int32_t nq, nv, nu, nbody, njnt, ngeom, ncloud, nvert;
+  /* options (mjOption) */
+  double timestep;
+  double gravity[3];
+  int32_t cone;        /* 0 pyramidal, 1 elliptic */
+  double impratio;
+  int32_t integrator;  /* 0 Euler (3 = implicitfast is run as Euler + implicit joint damping) */
+  /* bodies */
+  const int32_t* body_parentid; /* [nbody] */
+  const double* body_pos;       /* [nbody][3] */
+  const double* body_quat;      /* [nbody][4] wxyz */
+  const double* body_ipos;      /* [nbody][3] */
+  const double* body_iquat;     /* [nbody][4] */
+  const double* body_mass;      /* [nbody] */
+  const double* body_inertia;   /* [nbody][3] */
+  const int32_t* body_jntadr;   /* [nbody] */
+  const int32_t* body_jntnum;   /* [nbody] */
+  const double* body_invweight0;/* [nbody][2] */
+  /* joints */
+  const int32_t* jnt_type;      /* [njnt] 0 free, 3 hinge */
+  const int32_t* jnt_bodyid;
+  const int32_t* jnt_qposadr;
+  const int32_t* jnt_dofadr;
+  const double* jnt_pos;        /* [njnt][3] */
+  const double* jnt_axis;       /* [njnt][3] */
+  const int32_t* jnt_limited;
+  const double* jnt_range;      /* [njnt][2] */
+  const double* jnt_margin;
+  const double* jnt_solref;     /* [njnt][2] limit */
+  const double* jnt_solimp;     /* [njnt][5] limit */
+  const int32_t* jnt_actfrclimited;
+  const double* jnt_actfrcrange;/* [njnt][2] */
+  const double* qpos0;          /* [nq] AFTER the registry's qpos0_js override (robot_cfgs.py:39, quadruped_env.py:171-173) */
+  /* dofs */
+  const int32_t* dof_bodyid;    /* [nv] */
+  const int32_t* dof_jntid;
+  const int32_t* dof_parentid;
+  const double* dof_damping;
+  const double* dof_armature;
+  const double* dof_frictionloss;
+  const double* dof_solref;     /* [nv][2] friction loss */
+  const double* dof_solimp;     /* [nv][5] */
+  const double* dof_invweight0;
+  /* robot collision geoms lowered to vertex clouds (geoms of body 0 are excluded) */
+  const int32_t* geom_bodyid;   /* [ngeom] */
+  const double* geom_pos;       /* [ngeom][3] body frame */
+  const double* geom_quat;      /* [ngeom][4] */
+  const int32_t* geom_cloudid;  /* [ngeom] -1 = does not collide */
+  const double* geom_friction;  /* [ngeom][3] */
+  const double* geom_margin;
+  const double* geom_gap;
+  const int32_t* geom_condim;
+  const int32_t* geom_priority;
+  const double* geom_solref;    /* [ngeom][2] */
+  const double* geom_solimp;    /* [ngeom][5] */
+  const double* geom_solmix;
+  const double* geom_rbound;
+  const int32_t* cloud_vertadr; /* [ncloud] */
+  const int32_t* cloud_vertnum;
+  const double* cloud_radius;
+  const double* vert_pos;       /* [nvert][3] geom frame */
+  /* actuators (torque motors) */
+  const int32_t* actuator_trnid;   /* [nu] joint id */
+  const double* actuator_gear;
+  const int32_t* actuator_ctrllimited;
+  const double* actuator_ctrlrange;/* [nu][2] */
+  const int32_t* actuator_forcelimited;
+  const double* actuator_forcerange;
+  /* scene: ground plane z = 0 named "floor" (utils/mujoco/assets/scene_flat.xml:31) */
+  double floor_friction[3];
+  double floor_margin, floor_gap, floor_solmix;
+  double floor_solref[2];
+  double floor_solimp[5];
+  int32_t floor_condim, floor_priority;
+  /* env-level constants */
+  int32_t feet_geomid[GQ_NLEG];  /* FL FR RL RR (robot_cfgs.py:15) */
+  double terrain_limits[4];      /* max_x min_x max_y min_y (terrain.py:359) */
+  double meaninertia;
+  /* solver */
+  int32_t solver;                /* 0 PGS (north-star), 1 Newton (MuJoCo default; oracle only in this round) */
+  int32_t iterations;
+  double tolerance;
+} GqModelDesc;
+
+typedef struct GqModel GqModel;
+typedef struct GqBatch GqBatch;
+
+/* ---- per-env state, device pointers, env-major rows --------------------------------- */
+typedef struct GqState {
+  double* qpos;            /* [N][19] f64: base xyz must survive |xy| ~ 1e4 m (terrain.py:359)      */
+  float* qvel;             /* [N][18]                                                               */
+  float* qacc;             /* [N][18] out: mjData.qacc of the last forward pass                     */
+  float* qacc_warmstart;   /* [N][18] in/out                                                        */
+  float* qfrc_applied;     /* [N][18] in: external disturbance wrench (quadruped_env.py:305)        */
+  float* time;             /* [N] in/out                                                            */
+  float* friction;         /* [N] tangential coeff. of floor + feet (quadruped_env.py:1277-1298)    */
+  float* cmd;              /* [N][4] ref_base_lin_vel_H[3], ref_base_ang_yaw_dot (:1046-1072)       */
+} GqState;
+
+/* ---- observation outputs: one contiguous row per env -------------------------------- */
+typedef struct GqObsOut {
+  float* obs;              /* [N][obs_dim] concatenation in the order of obs_ids                    */
+  float* reward;           /* [N]   (_compute_reward: constant 0, quadruped_env.py:1141)            */
+  uint8_t* terminated;     /* [N]   invalid contact | out of terrain bounds (:283-285)              */
+  uint8_t* truncated;      /* [N]   always 0 (:286)                                                 */
+  uint8_t* invalid_contact;/* [N]   info['invalid_contacts'] non-empty (:1228-1248)                 */
+  int32_t* step_num;       /* [N]   in/out                                                          */
+} GqObsOut;
+
+/* observable ids = index into QuadrupedEnv.ALL_OBS (quadruped_env.py:35-66,81) */
+enum GqObsId {
+  GQ_OBS_BASE_POS = 0, GQ_OBS_BASE_LIN_VEL, GQ_OBS_BASE_LIN_VEL_ERR, GQ_OBS_BASE_LIN_ACC, GQ_OBS_BASE_ANG_VEL,
+  GQ_OBS_BASE_ANG_VEL_ERR, GQ_OBS_BASE_ORI_EULER_XYZ, GQ_OBS_BASE_ORI_QUAT_WXYZ, GQ_OBS_BASE_ORI_SO3,
+  GQ_OBS_GRAVITY_VECTOR_B,
+  GQ_OBS_BASE_LIN_VEL_B, GQ_OBS_BASE_LIN_VEL_ERR_B, GQ_OBS_BASE_LIN_ACC_B, GQ_OBS_BASE_ANG_VEL_B,
+  GQ_OBS_BASE_ANG_VEL_ERR_B,
+  GQ_OBS_QPOS, GQ_OBS_QVEL, GQ_OBS_TAU_CTRL_SETPOINT, GQ_OBS_QPOS_JS, GQ_OBS_QVEL_JS, GQ_OBS_KINETIC_ENERGY,
+  GQ_OBS_WORK,
+  GQ_OBS_FEET_POS, GQ_OBS_FEET_POS_B, GQ_OBS_FEET_VEL, GQ_OBS_FEET_VEL_REL, GQ_OBS_FEET_VEL_B,
+  GQ_OBS_FEET_VEL_REL_B, GQ_OBS_CONTACT_STATE, GQ_OBS_CONTACT_FORCES, GQ_OBS_CONTACT_FORCES_B,
+  GQ_OBS_COUNT
+};
+
+const char* gq_last_error(void);
+int gq_version(void);
+
+/* dimension of observable `id` (19,18,12,... as configure_observation_space, quadruped_utils.py:235-325) */
+int gq_obs_dim(int obs_id);
+
+/* mujoco.MjModel.from_xml_path (quadruped_env.py:170): uploads model constants to `device` */
+int gq_model_create(const GqModelDesc* desc, int device, GqModel** out);
+int gq_model_destroy(GqModel* m);
+
+/* mujoco.MjData (quadruped_env.py:178): per-batch launch geometry + debug scratch.
+ * obs_ids/n_obs = state_obs_names; legs_order = permutation of {0:FL,1:FR,2:RL,3:RR} (quadruped_env.py:95) */
+int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, const int32_t* legs_order,
+                    GqBatch** out);
+int gq_batch_destroy(GqBatch* b);
+int gq_batch_obs_dim(const GqBatch* b);
+
+/* QuadrupedEnv.step body (quadruped_env.py:270-290): ctrl <- action; mj_step; _get_obs; reward; termination.
+ * ctrl: device [N][nu] f32.  mask: device [N] u8 or NULL - envs with mask==0 are left untouched
+ * (used by reset(), which ends with one mj_step for the envs being reset, quadruped_env.py:397). */
+int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, void* hip_stream);
+
+/* QuadrupedEnv.reset state write (quadruped_env.py:332-395) for envs with mask!=0: copies the candidate
+ * qpos/qvel, zeroes time/qacc/qacc_warmstart/qfrc_applied/step_num, and - when lift != 0 - runs the
+ * mj_step1 + "lift until no foot contact" loop (:376-388; <=100 iterations, +1.1*max|dist| each).
+ * lift_failed: device [N] u8 out (RuntimeError condition, :387-388), may be NULL. */
+int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new, int lift,
+             GqState st, GqObsOut out, uint8_t* lift_failed, void* hip_stream);
+
+/* debug / inspection: last forward pass internals of env `env` copied to host (doubles).
+ * name in {"M","qfrc_bias","qfrc_smooth","qacc_smooth","qfrc_constraint","efc_J","efc_aref","efc_R","efc_b",
+ * "efc_force","efc_type","contact_dist","contact_geom","xpos","xmat","geom_xpos"}; returns count written. */
+int gq_debug_enable(GqBatch* b, int enable);
+int gq_debug_get(GqBatch* b, int env, const char* name, double* out, int max_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GQ_H_ */

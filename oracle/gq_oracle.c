@@ -1,0 +1,1183 @@
+/*
+ * gq_oracle.c - CPU fp64 single-env restatement of the physics step on the
+ * QuadrupedEnv.step() hot path.  TEST INFRASTRUCTURE ONLY: nothing in the
+ * product path (gym_quadruped_amd/) may link, load or call this file; it is
+ * used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ *
+ * PARITY UNPINNED for the mj_step part: the reference delegates the whole
+ * step to the third-party dependency `mujoco` (pyproject.toml:30,
+ * "mujoco>=3.10.0", unpinned; call site gym_quadruped/quadruped_env.py:271),
+ * which is neither vendored under the reference tree nor installable here, and
+ * the reference's own test (tests/env_test.py:35-46) pins shapes only.  This
+ * file therefore restates MuJoCo's published algorithm (documentation chapter
+ * "Computation" + the open-source engine's function structure), function by
+ * function:
+ *
+ *   mj_kinematics / mj_comPos          -> gqo_kinematics, gqo_com_pos
+ *   mj_crb / mj_factorM / mj_solveM    -> gqo_crb, gqo_factor_m, gqo_solve_m
+ *   mj_comVel / mj_rne / mj_passive    -> gqo_com_vel, gqo_rne, passive in gqo_fwd_velocity
+ *   mj_fwdActuation                    -> gqo_fwd_actuation
+ *   mj_collision (plane vs robot geom) -> gqo_collision
+ *   mj_makeConstraint + mj_makeImpedance + mj_diagApprox -> gqo_make_constraint
+ *   mj_solNewton / mj_solPGS           -> gqo_sol_newton, gqo_sol_pgs
+ *   mj_Euler / mj_integratePos         -> gqo_euler
+ *   mj_jac, mj_contactForce, mj_fullM  -> gqo_jac, gqo_contact_force, M[][]
+ *
+ * It is pinned instead by physical invariants (tests/test_oracle_invariants.py)
+ * and, for the observation layer above it, by golden vectors captured from the
+ * importable numpy part of the reference (tests/golden/).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gq.h"
+
+#define NQ 19
+#define NV 18
+#define NU 12
+#define NB 14
+#define NJ 13
+#define NG 96
+#define NCON 48
+#define NEFC 512
+#define MINVAL 1e-15
+#define MINIMP 0.0001
+#define MAXIMP 0.9999
+
+enum { EFC_FRICTION_DOF = 0, EFC_LIMIT_JOINT = 1, EFC_CONTACT_FRICTIONLESS = 2, EFC_CONTACT_PYRAMIDAL = 3,
+       EFC_CONTACT_ELLIPTIC = 4 };
+
+typedef struct {
+  double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
+  int geom, body, dim, efc_address;
+} Contact;
+
+typedef struct GqOracle {
+  GqModelDesc d;
+  void* owned[64];
+  int nowned;
+  /* state (mjData) */
+  double qpos[NQ], qvel[NV], qacc[NV], qacc_warmstart[NV], ctrl[NU], qfrc_applied[NV], time;
+  double friction; /* <0: XML frictions; >=0: floor+feet tangential coefficient (quadruped_env.py:1277-1298) */
+  /* position stage */
+  double xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3], ximat[NB][9];
+  double xanchor[NJ][3], xaxis[NJ][3], subtree_com[NB][3];
+  double cinert[NB][10], crb[NB][10], cdof[NV][6];
+  double M[NV][NV], LD[NV][NV];
+  double geom_xpos[NG][3], geom_xmat[NG][9];
+  /* velocity stage */
+  double cvel[NB][6], cdof_dot[NV][6], cacc[NB][6], cfrc[NB][6];
+  double qfrc_bias[NV], qfrc_passive[NV], qfrc_actuator[NV], qfrc_smooth[NV], qacc_smooth[NV], qfrc_constraint[NV];
+  /* contacts + constraints */
+  int ncon, nefc;
+  Contact contact[NCON];
+  int efc_type[NEFC], efc_id[NEFC];
+  double efc_J[NEFC][NV], efc_pos[NEFC], efc_margin[NEFC], efc_frictionloss[NEFC], efc_diagApprox[NEFC];
+  double efc_R[NEFC], efc_D[NEFC], efc_vel[NEFC], efc_aref[NEFC], efc_b[NEFC], efc_force[NEFC];
+  double efc_solref[NEFC][2], efc_solimp[NEFC][5];
+  int solver_niter;
+  int warning; /* bad qpos/qvel/qacc seen (mj_checkPos/Vel/Acc) */
+} GqOracle;
+
+/* ------------------------------------------------------------------ small vector helpers */
+static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void mulmatvec3(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+         z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void mulmatTvec3(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2],
+         z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void mulmat3(double* r, const double* a, const double* b) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  memcpy(r, t, sizeof t);
+}
+static void quat_mul(double* r, const double* a, const double* b) {
+  double t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                 a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+  memcpy(r, t, sizeof t);
+}
+static void quat_normalize(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  for (int i = 0; i < 4; i++) q[i] /= n;
+}
+static void quat2mat(double* m, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[4] = w * w - x * x + y * y - z * z; m[8] = w * w - x * x - y * y + z * z;
+  m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y); m[3] = 2 * (x * y + w * z);
+  m[5] = 2 * (y * z - w * x); m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x);
+}
+static void axis_angle2quat(double* q, const double* axis, double angle) {
+  double s = sin(0.5 * angle);
+  q[0] = cos(0.5 * angle); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+/* spatial motion cross product  res = vel x_m v   (mju_crossMotion) */
+static void cross_motion(double* res, const double* vel, const double* v) {
+  double a[3], b[3];
+  cross3(res, vel, v);
+  cross3(a, vel, v + 3); cross3(b, vel + 3, v);
+  res[3] = a[0] + b[0]; res[4] = a[1] + b[1]; res[5] = a[2] + b[2];
+}
+/* spatial force cross product  res = vel x_f f   (mju_crossForce) */
+static void cross_force(double* res, const double* vel, const double* f) {
+  double a[3], b[3];
+  cross3(a, vel, f); cross3(b, vel + 3, f + 3);
+  res[0] = a[0] + b[0]; res[1] = a[1] + b[1]; res[2] = a[2] + b[2];
+  cross3(res + 3, vel, f + 3);
+}
+/* res = I * v, I = [Ixx Iyy Izz Ixy Ixz Iyz | m*c (3) | m]   (mju_mulInertVec) */
+static void mul_inert_vec(double* res, const double* i, const double* v) {
+  res[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  res[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  res[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  res[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  res[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  res[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+
+/* ------------------------------------------------------------------ model copy */
+static void* own(GqOracle* o, const void* src, size_t bytes) {
+  if (!src || !bytes) return NULL;
+  void* p = malloc(bytes);
+  memcpy(p, src, bytes);
+  o->owned[o->nowned++] = p;
+  return p;
+}
+#define OWN(field, count) o->d.field = own(o, desc->field, sizeof(*desc->field) * (size_t)(count))
+
+static char g_err[256];
+const char* gqo_last_error(void) { return g_err; }
+
+int gqo_create(const GqModelDesc* desc, GqOracle** out) {
+  if (desc->nq != NQ || desc->nv != NV || desc->nu > NU || desc->nbody > NB || desc->njnt > NJ || desc->ngeom > NG) {
+    snprintf(g_err, sizeof g_err, "oracle: unsupported sizes nq=%d nv=%d nu=%d nbody=%d ngeom=%d", desc->nq, desc->nv,
+             desc->nu, desc->nbody, desc->ngeom);
+    return GQ_EINVAL;
+  }
+  GqOracle* o = calloc(1, sizeof(GqOracle));
+  if (!o) return GQ_ENOMEM;
+  o->d = *desc;
+  int nb = desc->nbody, nj = desc->njnt, nv = desc->nv, ng = desc->ngeom, nu = desc->nu;
+  OWN(body_parentid, nb); OWN(body_pos, 3 * nb); OWN(body_quat, 4 * nb); OWN(body_ipos, 3 * nb); OWN(body_iquat, 4 * nb);
+  OWN(body_mass, nb); OWN(body_inertia, 3 * nb); OWN(body_jntadr, nb); OWN(body_jntnum, nb); OWN(body_invweight0, 2 * nb);
+  OWN(jnt_type, nj); OWN(jnt_bodyid, nj); OWN(jnt_qposadr, nj); OWN(jnt_dofadr, nj); OWN(jnt_pos, 3 * nj); OWN(jnt_axis, 3 * nj);
+  OWN(jnt_limited, nj); OWN(jnt_range, 2 * nj); OWN(jnt_margin, nj); OWN(jnt_solref, 2 * nj); OWN(jnt_solimp, 5 * nj);
+  OWN(jnt_actfrclimited, nj); OWN(jnt_actfrcrange, 2 * nj); OWN(qpos0, desc->nq);
+  OWN(dof_bodyid, nv); OWN(dof_jntid, nv); OWN(dof_parentid, nv); OWN(dof_damping, nv); OWN(dof_armature, nv);
+  OWN(dof_frictionloss, nv); OWN(dof_solref, 2 * nv); OWN(dof_solimp, 5 * nv); OWN(dof_invweight0, nv);
+  OWN(geom_bodyid, ng); OWN(geom_pos, 3 * ng); OWN(geom_quat, 4 * ng); OWN(geom_cloudid, ng); OWN(geom_friction, 3 * ng);
+  OWN(geom_margin, ng); OWN(geom_gap, ng); OWN(geom_condim, ng); OWN(geom_priority, ng); OWN(geom_solref, 2 * ng);
+  OWN(geom_solimp, 5 * ng); OWN(geom_solmix, ng); OWN(geom_rbound, ng);
+  OWN(cloud_vertadr, desc->ncloud); OWN(cloud_vertnum, desc->ncloud); OWN(cloud_radius, desc->ncloud);
+  OWN(vert_pos, 3 * desc->nvert);
+  OWN(actuator_trnid, nu); OWN(actuator_gear, nu); OWN(actuator_ctrllimited, nu); OWN(actuator_ctrlrange, 2 * nu);
+  OWN(actuator_forcelimited, nu); OWN(actuator_forcerange, 2 * nu);
+  memcpy(o->qpos, o->d.qpos0, sizeof(double) * NQ);
+  o->friction = -1.0;
+  *out = o;
+  return GQ_OK;
+}
+
+void gqo_destroy(GqOracle* o) {
+  if (!o) return;
+  for (int i = 0; i < o->nowned; i++) free(o->owned[i]);
+  free(o);
+}
+
+/* ------------------------------------------------------------------ mj_kinematics */
+static void gqo_kinematics(GqOracle* o) {
+  const GqModelDesc* m = &o->d;
+  memset(o->xpos[0], 0, sizeof o->xpos[0]);
+  o->xquat[0][0] = 1; o->xquat[0][1] = o->xquat[0][2] = o->xquat[0][3] = 0;
+  quat2mat(o->xmat[0], o->xquat[0]);
+  memset(o->xipos[0], 0, sizeof o->xipos[0]);
+  quat2mat(o->ximat[0], o->xquat[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parentid[b];
+    double pos[3], quat[4], tmp[3];
+    mulmatvec3(tmp, o->xmat[p], m->body_pos + 3 * b);
+    for (int k = 0; k < 3; k++) pos[k] = o->xpos[p][k] + tmp[k];
+    quat_mul(quat, o->xquat[p], m->body_quat + 4 * b);
+    for (int j = m->body_jntadr[b]; j >= 0 && j < m->body_jntadr[b] + m->body_jntnum[b]; j++) {
+      int qa = m->jnt_qposadr[j];
+      if (m->jnt_type[j] == 0) { /* free: pose straight from qpos, quaternion normalised */
+        memcpy(pos, o->qpos + qa, sizeof pos);
+        memcpy(quat, o->qpos + qa + 3, sizeof quat);
+        quat_normalize(quat);
+        memcpy(o->xanchor[j], pos, sizeof pos);
+        o->xaxis[j][0] = 0; o->xaxis[j][1] = 0; o->xaxis[j][2] = 1;
+      } else { /* hinge: anchor/axis in the frame BEFORE this joint's rotation, angle relative to qpos0 */
+        double R[9], ql[4], a[3];
+        quat2mat(R, quat);
+        mulmatvec3(a, R, m->jnt_pos + 3 * j);
+        for (int k = 0; k < 3; k++) o->xanchor[j][k] = pos[k] + a[k];
+        mulmatvec3(o->xaxis[j], R, m->jnt_axis + 3 * j);
+        axis_angle2quat(ql, m->jnt_axis + 3 * j, o->qpos[qa] - m->qpos0[qa]);
+        quat_mul(quat, quat, ql);
+        /* off-centre rotation correction: keep the anchor fixed */
+        quat2mat(R, quat);
+        mulmatvec3(a, R, m->jnt_pos + 3 * j);
+        for (int k = 0; k < 3; k++) pos[k] = o->xanchor[j][k] - a[k];
+      }
+    }
+    quat_normalize(quat);
+    memcpy(o->xpos[b], pos, sizeof pos);
+    memcpy(o->xquat[b], quat, sizeof quat);
+    quat2mat(o->xmat[b], quat);
+    mulmatvec3(tmp, o->xmat[b], m->body_ipos + 3 * b);
+    for (int k = 0; k < 3; k++) o->xipos[b][k] = pos[k] + tmp[k];
+    double qi[4];
+    quat_mul(qi, quat, m->body_iquat + 4 * b);
+    quat2mat(o->ximat[b], qi);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_bodyid[g];
+    double tmp[3], q[4];
+    mulmatvec3(tmp, o->xmat[b], m->geom_pos + 3 * g);
+    for (int k = 0; k < 3; k++) o->geom_xpos[g][k] = o->xpos[b][k] + tmp[k];
+    quat_mul(q, o->xquat[b], m->geom_quat + 4 * g);
+    quat2mat(o->geom_xmat[g], q);
+  }
+}
+
+/* ------------------------------------------------------------------ mj_comPos */
+static void gqo_com_pos(GqOracle* o) {
+  const GqModelDesc* m = &o->d;
+  double mass[NB];
+  for (int b = 0; b < m->nbody; b++) {
+    mass[b] = m->body_mass[b];
+    for (int k = 0; k < 3; k++) o->subtree_com[b][k] = m->body_mass[b] * o->xipos[b][k];
+  }
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    mass[p] += mass[b];
+    for (int k = 0; k < 3; k++) o->subtree_com[p][k] += o->subtree_com[b][k];
+  }
+  for (int b = 0; b < m->nbody; b++)
+    for (int k = 0; k < 3; k++) o->subtree_com[b][k] = mass[b] > MINVAL ? o->subtree_com[b][k] / mass[b] : o->xipos[b][k];
+  /* every robot body has root body 1 (the floating base): com-based frame origin = subtree_com[1] */
+  const double* O = o->subtree_com[1];
+  memset(o->cinert[0], 0, sizeof o->cinert[0]);
+  for (int b = 1; b < m->nbody; b++) { /* mju_inertCom */
+    double d[3], tmp[9], I[9], mb = m->body_mass[b];
+    for (int k = 0; k < 3; k++) d[k] = o->xipos[b][k] - O[k];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) tmp[3 * i + j] = o->ximat[b][3 * i + j] * m->body_inertia[3 * b + j];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += tmp[3 * i + k] * o->ximat[b][3 * j + k];
+        I[3 * i + j] = s;
+      }
+    double dd = dot3(d, d);
+    double* c = o->cinert[b];
+    c[0] = I[0] + mb * (dd - d[0] * d[0]); c[1] = I[4] + mb * (dd - d[1] * d[1]); c[2] = I[8] + mb * (dd - d[2] * d[2]);
+    c[3] = I[1] - mb * d[0] * d[1]; c[4] = I[2] - mb * d[0] * d[2]; c[5] = I[5] - mb * d[1] * d[2];
+    c[6] = mb * d[0]; c[7] = mb * d[1]; c[8] = mb * d[2]; c[9] = mb;
+  }
+  for (int j = 0; j < m->njnt; j++) { /* cdof = [axis ; axis x (O - anchor)]  (mju_dofCom) */
+    int b = m->jnt_bodyid[j], d = m->jnt_dofadr[j];
+    double off[3];
+    for (int k = 0; k < 3; k++) off[k] = O[k] - o->xanchor[j][k];
+    if (m->jnt_type[j] == 0) {
+      for (int k = 0; k < 3; k++) {
+        memset(o->cdof[d + k], 0, sizeof o->cdof[0]);
+        o->cdof[d + k][3 + k] = 1;
+        double ax[3] = {o->xmat[b][k], o->xmat[b][3 + k], o->xmat[b][6 + k]};
+        memcpy(o->cdof[d + 3 + k], ax, sizeof ax);
+        cross3(o->cdof[d + 3 + k] + 3, ax, off);
+      }
+    } else {
+      memcpy(o->cdof[d], o->xaxis[j], sizeof o->xaxis[j]);
+      cross3(o->cdof[d] + 3, o->xaxis[j], off);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ mj_crb + mj_factorM */
+static void gqo_crb(GqOracle* o) {
+  const GqModelDesc* m = &o->d;
+  memcpy(o->crb, o->cinert, sizeof o->crb);
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    if (p > 0)
+      for (int k = 0; k < 10; k++) o->crb[p][k] += o->crb[b][k];
+  }
+  memset(o->M, 0, sizeof o->M);
+  for (int i = 0; i < m->nv; i++) {
+    double buf[6];
+    mul_inert_vec(buf, o->crb[m->dof_bodyid[i]], o->cdof[i]);
+    o->M[i][i] = m->dof_armature[i];
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += o->cdof[j][k] * buf[k];
+      if (j == i) o->M[i][i] += s; else { o->M[i][j] = s; o->M[j][i] = s; }
+    }
+  }
+}
+
+/* L'DL factorisation exploiting the dof tree (mj_factorI): LD holds L below the diagonal (unit diagonal implied)
+ * and D on the diagonal. */
+static void factor_ld(const GqModelDesc* m, double LD[NV][NV]) {
+  for (int k = m->nv - 1; k >= 0; k--) {
+    for (int i = m->dof_parentid[k]; i >= 0; i = m->dof_parentid[i]) {
+      double tmp = LD[k][i] / LD[k][k];
+      for (int j = i; j >= 0; j = m->dof_parentid[j]) LD[i][j] -= LD[k][j] * tmp;
+      LD[k][i] = tmp;
+    }
+  }
+}
+static void solve_ld(const GqModelDesc* m, double LD[NV][NV], double* x) {
+  for (int k = m->nv - 1; k >= 0; k--)
+    for (int i = m->dof_parentid[k]; i >= 0; i = m->dof_parentid[i]) x[i] -= LD[k][i] * x[k];
+  for (int k = 0; k < m->nv; k++) x[k] /= LD[k][k];
+  for (int k = 0; k < m->nv; k++)
+    for (int i = m->dof_parentid[k]; i >= 0; i = m->dof_parentid[i]) x[k] -= LD[k][i] * x[i];
+}
+static void gqo_factor_m(GqOracle* o) {
+  for (int i = 0; i < NV; i++)
+    for (int j = 0; j < NV; j++) o->LD[i][j] = j <= i ? o->M[i][j] : 0.0;
+  factor_ld(&o->d, o->LD);
+}
+static void gqo_solve_m(GqOracle* o, double* x) { solve_ld(&o->d, o->LD, x); }
+
+/* ------------------------------------------------------------------ mj_jac: translational/rotational Jacobian of a
+ * world point attached to `body` */
+static void gqo_jac(const GqOracle* o, double jacp[3][NV], double jacr[3][NV], const double* point, int body) {
+  const GqModelDesc* m = &o->d;
+  double off[3];
+  for (int k = 0; k < 3; k++) off[k] = point[k] - o->subtree_com[1][k];
+  if (jacp) memset(jacp, 0, sizeof(double) * 3 * NV);
+  if (jacr) memset(jacr, 0, sizeof(double) * 3 * NV);
+  if (body <= 0) return;
+  /* last dof of the body (bodies without joints do not occur in these models) */
+  int j = m->body_jntadr[body] + m->body_jntnum[body] - 1;
+  int i = m->jnt_dofadr[j] + (m->jnt_type[j] == 0 ? 5 : 0);
+  for (; i >= 0; i = m->dof_parentid[i]) {
+    double t[3];
+    cross3(t, o->cdof[i], off);
+    for (int k = 0; k < 3; k++) {
+      if (jacr) jacr[k][i] = o->cdof[i][k];
+      if (jacp) jacp[k][i] = o->cdof[i][3 + k] + t[k];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ mj_collision: floor plane (z = 0) vs robot geoms.
+ * plane-sphere is exact (mjc_PlaneSphere).  Other robot geoms are vertex clouds (+radius); this round keeps ONE
+ * contact per geom at its deepest vertex, where MuJoCo's plane-box / plane-capsule / plane-mesh routines may
+ * return several (documented deviation). */
+static void make_frame(double* f) { /* mju_makeFrame with only the x axis given */
+  double n = sqrt(dot3(f, f));
+  for (int k = 0; k < 3; k++) f[k] /= n;
+  f[3] = f[4] = f[5] = 0;
+  if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+  double t = dot3(f, f + 3);
+  for (int k = 0; k < 3; k++) f[3 + k] -= t * f[k];
+  n = sqrt(dot3(f + 3, f + 3));
+  for (int k = 0; k < 3; k++) f[3 + k] /= n;
+  cross3(f + 6, f, f + 3);
+}
+
+static int is_foot(const GqModelDesc* m, int g) {
+  for (int l = 0; l < GQ_NLEG; l++)
+    if (m->feet_geomid[l] == g) return 1;
+  return 0;
+}
+
+/* mj_contactParam: mix floor (geom 1) and robot geom (geom 2) */
+static void contact_param(const GqOracle* o, int g, Contact* c) {
+  const GqModelDesc* m = &o->d;
+  double f1[3], f2[3];
+  memcpy(f1, m->floor_friction, sizeof f1);
+  memcpy(f2, m->geom_friction + 3 * g, sizeof f2);
+  if (o->friction >= 0) { /* _set_ground_friction (quadruped_env.py:1292-1296): floor + feet = [mu, 0.005, 0.0] */
+    f1[0] = o->friction; f1[1] = 0.005; f1[2] = 0.0;
+    if (is_foot(m, g)) { f2[0] = o->friction; f2[1] = 0.005; f2[2] = 0.0; }
+  }
+  int p1 = m->floor_priority, p2 = m->geom_priority[g];
+  double fri[3];
+  if (p1 == p2) {
+    c->dim = m->floor_condim > m->geom_condim[g] ? m->floor_condim : m->geom_condim[g];
+    for (int k = 0; k < 3; k++) fri[k] = f1[k] > f2[k] ? f1[k] : f2[k];
+    double s1 = m->floor_solmix, s2 = m->geom_solmix[g], mix;
+    if (s1 >= MINVAL && s2 >= MINVAL) mix = s1 / (s1 + s2);
+    else if (s1 < MINVAL && s2 < MINVAL) mix = 0.5;
+    else mix = s1 < MINVAL ? 0.0 : 1.0;
+    const double* r1 = m->floor_solref; const double* r2 = m->geom_solref + 2 * g;
+    if (r1[0] > 0 && r2[0] > 0)
+      for (int k = 0; k < 2; k++) c->solref[k] = mix * r1[k] + (1 - mix) * r2[k];
+    else
+      for (int k = 0; k < 2; k++) c->solref[k] = r1[k] < r2[k] ? r1[k] : r2[k];
+    for (int k = 0; k < 5; k++) c->solimp[k] = mix * m->floor_solimp[k] + (1 - mix) * m->geom_solimp[5 * g + k];
+  } else {
+    int floor_wins = p1 > p2;
+    c->dim = floor_wins ? m->floor_condim : m->geom_condim[g];
+    memcpy(fri, floor_wins ? f1 : f2, sizeof fri);
+    memcpy(c->solref, floor_wins ? m->floor_solref : m->geom_solref + 2 * g, sizeof c->solref);
+    memcpy(c->solimp, floor_wins ? m->floor_solimp : m->geom_solimp + 5 * g, sizeof c->solimp);
+  }
+  c->friction[0] = c->friction[1] = fri[0]; c->friction[2] = fri[1]; c->friction[3] = c->friction[4] = fri[2];
+  double margin = m->floor_margin > m->geom_margin[g] ? m->floor_margin : m->geom_margin[g];
+  double gap = m->floor_gap > m->geom_gap[g] ? m->floor_gap : m->geom_gap[g];
+  c->includemargin = margin - gap;
+  c->mu = 0;
+}
+
+static void gqo_collision(GqOracle* o) {
+  const GqModelDesc* m = &o->d;
+  o->ncon = 0;
+  const double normal[3] = {0, 0, 1};
+  for (int g = 0; g < m->ngeom && o->ncon < NCON; g++) {
+    int cl = m->geom_cloudid[g];
+    if (cl < 0 || m->geom_bodyid[g] == 0) continue;
+    double margin = m->floor_margin > m->geom_margin[g] ? m->floor_margin : m->geom_margin[g];
+    double r = m->cloud_radius[cl];
+    /* bounding-sphere cull (mj broadphase equivalent for a plane) */
+    if (o->geom_xpos[g][2] - m->geom_rbound[g] > margin) continue;
+    double best = 1e300, bv[3] = {0, 0, 0};
+    for (int v = 0; v < m->cloud_vertnum[cl]; v++) {
+      double w[3];
+      mulmatvec3(w, o->geom_xmat[g], m->vert_pos + 3 * (m->cloud_vertadr[cl] + v));
+      for (int k = 0; k < 3; k++) w[k] += o->geom_xpos[g][k];
+      double dist = w[2] - r;
+      if (dist < best) { best = dist; memcpy(bv, w, sizeof bv); }
+    }
+    if (best >= margin) continue;
+    Contact* c = &o->contact[o->ncon++];
+    c->geom = g; c->body = m->geom_bodyid[g];
+    c->dist = best;
+    /* contact point midway between the surfaces: (vertex - r*n) - n*dist/2 */
+    for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - normal[k] * (r + 0.5 * best);
+    memcpy(c->frame, normal, sizeof normal);
+    make_frame(c->frame);
+    contact_param(o, g, c);
+  }
+}
+
+/* ------------------------------------------------------------------ constraint construction */
+static void get_impedance(const double* solimp, double pos, double margin, double* imp) {
+  double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  dmin = fmin(fmax(dmin, MINIMP), MAXIMP); dmax = fmin(fmax(dmax, MINIMP), MAXIMP);
+  width = fmax(MINVAL, width); mid = fmin(fmax(mid, MINIMP), MAXIMP); power = fmax(1, power);
+  if (dmin == dmax || width <= MINVAL) { *imp = 0.5 * (dmin + dmax); return; }
+  double x = fabs(pos - margin) / width;
+  if (x >= 1) { *imp = dmax; return; }
+  if (x <= 0) { *imp = dmin; return; }
+  double y;
+  if (power == 1) y = x;
+  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  *imp = dmin + y * (dmax - dmin);
+}
+
+static int add_row(GqOracle* o, int type, int id, double pos, double margin, double floss, const double* solref,
+                   const double* solimp, double diag) {
+  int i = o->nefc++;
+  o->efc_type[i] = type; o->efc_id[i] = id; o->efc_pos[i] = pos; o->efc_margin[i] = margin;
+  o->efc_frictionloss[i] = floss; o->efc_diagApprox[i] = diag;
+  memcpy(o->efc_solref[i], solref, sizeof(double) * 2);
+  memcpy(o->efc_solimp[i], solimp, sizeof(double) * 5);
+  memset(o->efc_J[i], 0, sizeof o->efc_J[i]);
+  return i;
+}
+
+static void gqo_make_constraint(GqOracle* o) {
+  const GqModelDesc* m = &o->d;
+  o->nefc = 0;
+  /* 1. dof friction loss (mj_instantiateFriction) */
+  for (int i = 0; i < m->nv; i++)
+    if (m->dof_frictionloss[i] > 0) {
+      int r = add_row(o, EFC_FRICTION_DOF, i, 0, 0, m->dof_frictionloss[i], m->dof_solref + 2 * i, m->dof_solimp + 5 * i,
+                      m->dof_invweight0[i]);
+      o->efc_J[r][i] = 1;
+    }
+  /* 2. joint limits (mj_instantiateLimit, hinge) */
+  for (int j = 0; j < m->njnt; j++)
+    if (m->jnt_limited[j] && m->jnt_type[j] == 3) {
+      double value = o->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
+      int d = m->jnt_dofadr[j];
+      for (int side = -1; side <= 1; side += 2) {
+        double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - value);
+        if (dist < margin) {
+          int r = add_row(o, EFC_LIMIT_JOINT, j, dist, margin, 0, m->jnt_solref + 2 * j, m->jnt_solimp + 5 * j,
+                          m->dof_invweight0[d]);
+          o->efc_J[r][d] = -side;
+        }
+      }
+    }
+  /* 3. contacts (mj_instantiateContact), pyramidal cone */
+  for (int c = 0; c < o->ncon; c++) {
+    Contact* con = &o->contact[c];
+    double jp[3][NV], jr[3][NV], Jc[6][NV];
+    gqo_jac(o, jp, jr, con->pos, con->body);
+    for (int k = 0; k < 3; k++)
+      for (int i = 0; i < NV; i++) {
+        Jc[k][i] = con->frame[3 * k] * jp[0][i] + con->frame[3 * k + 1] * jp[1][i] + con->frame[3 * k + 2] * jp[2][i];
+        Jc[3 + k][i] = con->frame[3 * k] * jr[0][i] + con->frame[3 * k + 1] * jr[1][i] + con->frame[3 * k + 2] * jr[2][i];
+      }
+    double tran = m->body_invweight0[2 * con->body], rot = m->body_invweight0[2 * con->body + 1];
+    con->efc_address = o->nefc;
+    con->mu = con->friction[0] / sqrt(m->impratio);
+    if (con->dim == 1) {
+      int r = add_row(o, EFC_CONTACT_FRICTIONLESS, c, con->dist, con->includemargin, 0, con->solref, con->solimp, tran);
+      memcpy(o->efc_J[r], Jc[0], sizeof Jc[0]);
+    } else { /* pyramidal: 2*(dim-1) edges  Jn +- mu_k * Jt_k */
+      for (int k = 1; k < con->dim; k++)
+        for (int s = 0; s < 2; s++) {
+          int e = 2 * (k - 1) + s;
+          double fri = con->friction[e / 2];
+          double diag = tran + fri * fri * (e < 4 ? tran : rot);
+          int r = add_row(o, EFC_CONTACT_PYRAMIDAL, c, con->dist, con->includemargin, 0, con->solref, con->solimp, diag);
+          for (int i = 0; i < NV; i++) o->efc_J[r][i] = Jc[0][i] + (s ? -1.0 : 1.0) * con->friction[k - 1] * Jc[k][i];
+        }
+    }
+  }
+  /* mj_makeImpedance: R, D, aref */
+  double timestep = m->timestep;
+  for (int i = 0; i < o->nefc; i++) {
+    double imp;
+    get_impedance(o->efc_solimp[i], o->efc_pos[i], o->efc_margin[i], &imp);
+    o->efc_R[i] = fmax(MINVAL, (1 - imp) * o->efc_diagApprox[i] / imp);
+    double dmax = fmin(fmax(o->efc_solimp[i][1], MINIMP), MAXIMP), K, B;
+    const double* sr = o->efc_solref[i];
+    if (sr[0] > 0) {
+      double tc = fmax(sr[0], 2 * timestep), dr = sr[1];
+      K = 1 / fmax(MINVAL, dmax * dmax * tc * tc * dr * dr);
+      B = 2 / fmax(MINVAL, dmax * tc);
+    } else { K = -sr[0] / fmax(MINVAL, dmax * dmax); B = -sr[1] / fmax(MINVAL, dmax); }
+    double vel = 0;
+    for (int k = 0; k < NV; k++) vel += o->efc_J[i][k] * o->qvel[k];
+    o->efc_vel[i] = vel;
+    o->efc_aref[i] = -B * vel - K * imp * (o->efc_pos[i] - o->efc_margin[i]);
+  }
+  /* friction-adjusted R of pyramid edges: Rpy = 2 mu^2 R(first edge) for every edge of the contact */
+  for (int c = 0; c < o->ncon; c++) {
+    Contact* con = &o->contact[c];
+    if (con->dim > 1) {
+      int a = con->efc_address;
+      double Rpy = 2 * con->mu * con->mu * o->efc_R[a];
+      for (int e = 0; e < 2 * (con->dim - 1); e++) o->efc_R[a + e] = fmax(MINVAL, Rpy);
+    }
+  }
+  for (int i = 0; i < o->nefc; i++) o->efc_D[i] = 1 / o->efc_R[i];
+}
+
+/* ------------------------------------------------------------------ velocity / actuation stages */
+static void gqo_com_vel(GqOracle* o) {
+  const GqModelDesc* m = &o->d;
+  memset(o->cvel[0], 0, sizeof o->cvel[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    double v[6];
+    memcpy(v, o->cvel[m->body_parentid[b]], sizeof v);
+    for (int j = m->body_jntadr[b]; j < m->body_jntadr[b] + m->body_jntnum[b]; j++) {
+      int d = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == 0) {
+        for (int k = 0; k < 3; k++) { /* translations: world-fixed axes, cdof_dot = 0 */
+          memset(o->cdof_dot[d + k], 0, sizeof o->cdof_dot[0]);
+          for (int c = 0; c < 6; c++) v[c] += o->cdof[d + k][c] * o->qvel[d + k];
+        }
+        for (int k = 3; k < 6; k++) cross_motion(o->cdof_dot[d + k], v, o->cdof[d + k]);
+        for (int k = 3; k < 6; k++)
+          for (int c = 0; c < 6; c++) v[c] += o->cdof[d + k][c] * o->qvel[d + k];
+      } else {
+        cross_motion(o->cdof_dot[d], v, o->cdof[d]);
+        for (int c = 0; c < 6; c++) v[c] += o->cdof[d][c] * o->qvel[d];
+      }
+    }
+    memcpy(o->cvel[b], v, sizeof v);
+  }
+}
+
+/* mj_rne with flg_acc = 0: Coriolis + centrifugal + gravity */
+static void gqo_rne(GqOracle* o, double* res) {
+  const GqModelDesc* m = &o->d;
+  memset(o->cacc[0], 0, sizeof o->cacc[0]);
+  for (int k = 0; k < 3; k++) o->cacc[0][3 + k] = -m->gravity[k];
+  memset(o->cfrc[0], 0, sizeof o->cfrc[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    double a[6], t1[6], t2[6];
+    memcpy(a, o->cacc[m->body_parentid[b]], sizeof a);
+    for (int j = m->body_jntadr[b]; j < m->body_jntadr[b] + m->body_jntnum[b]; j++) {
+      int d = m->jnt_dofadr[j], n = m->jnt_type[j] == 0 ? 6 : 1;
+      for (int k = 0; k < n; k++)
+        for (int c = 0; c < 6; c++) a[c] += o->cdof_dot[d + k][c] * o->qvel[d + k];
+    }
+    memcpy(o->cacc[b], a, sizeof a);
+    mul_inert_vec(t1, o->cinert[b], a);
+    mul_inert_vec(t2, o->cinert[b], o->cvel[b]);
+    cross_force(o->cfrc[b], o->cvel[b], t2);
+    for (int c = 0; c < 6; c++) o->cfrc[b][c] += t1[c];
+  }
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    if (p > 0)
+      for (int c = 0; c < 6; c++) o->cfrc[p][c] += o->cfrc[b][c];
+  }
+  for (int i = 0; i < m->nv; i++) {
+    double s = 0;
+    for (int c = 0; c < 6; c++) s += o->cdof[i][c] * o->cfrc[m->dof_bodyid[i]][c];
+    res[i] = s;
+  }
+}
+
+static void gqo_fwd_position(GqOracle* o) {
+  gqo_kinematics(o);
+  gqo_com_pos(o);
+  gqo_crb(o);
+  gqo_factor_m(o);
+  gqo_collision(o);
+  gqo_make_constraint(o);
+}
+
+static void gqo_fwd_velocity(GqOracle* o) {
+  gqo_com_vel(o);
+  for (int i = 0; i < NV; i++) o->qfrc_passive[i] = -o->d.dof_damping[i] * o->qvel[i];
+  gqo_rne(o, o->qfrc_bias);
+  /* efc_vel / aref depend on qvel: recompute (make_constraint above already used the current qvel) */
+}
+
+static void gqo_fwd_actuation(GqOracle* o) {
+  const GqModelDesc* m = &o->d;
+  memset(o->qfrc_actuator, 0, sizeof o->qfrc_actuator);
+  for (int u = 0; u < m->nu; u++) {
+    double c = o->ctrl[u];
+    if (m->actuator_ctrllimited[u]) c = fmin(fmax(c, m->actuator_ctrlrange[2 * u]), m->actuator_ctrlrange[2 * u + 1]);
+    double f = c; /* motor: gain 1, no bias */
+    if (m->actuator_forcelimited[u]) f = fmin(fmax(f, m->actuator_forcerange[2 * u]), m->actuator_forcerange[2 * u + 1]);
+    o->qfrc_actuator[m->jnt_dofadr[m->actuator_trnid[u]]] += m->actuator_gear[u] * f;
+  }
+  for (int j = 0; j < m->njnt; j++)
+    if (m->jnt_actfrclimited[j] && m->jnt_type[j] == 3) {
+      int d = m->jnt_dofadr[j];
+      o->qfrc_actuator[d] = fmin(fmax(o->qfrc_actuator[d], m->jnt_actfrcrange[2 * j]), m->jnt_actfrcrange[2 * j + 1]);
+    }
+}
+
+static void gqo_fwd_acceleration(GqOracle* o) {
+  for (int i = 0; i < NV; i++)
+    o->qfrc_smooth[i] = o->qfrc_passive[i] - o->qfrc_bias[i] + o->qfrc_actuator[i] + o->qfrc_applied[i];
+  memcpy(o->qacc_smooth, o->qfrc_smooth, sizeof o->qacc_smooth);
+  gqo_solve_m(o, o->qacc_smooth);
+}
+
+/* ------------------------------------------------------------------ constraint force law (mj_constraintUpdate):
+ * force and cost of every row given jar = J*qacc - aref.  Returns the constraint cost. */
+static double constraint_update(GqOracle* o, const double* jar, double* force, int* active) {
+  double cost = 0;
+  for (int i = 0; i < o->nefc; i++) {
+    double R = o->efc_R[i], D = o->efc_D[i], x = jar[i];
+    int act = 1;
+    if (o->efc_type[i] == EFC_FRICTION_DOF) {
+      double f = o->efc_frictionloss[i];
+      if (x <= -R * f) { force[i] = f; cost += -0.5 * R * f * f - f * x; act = 0; }
+      else if (x >= R * f) { force[i] = -f; cost += -0.5 * R * f * f + f * x; act = 0; }
+      else { force[i] = -D * x; cost += 0.5 * D * x * x; }
+    } else { /* limit, frictionless / pyramidal contact: one-sided quadratic */
+      if (x < 0) { force[i] = -D * x; cost += 0.5 * D * x * x; }
+      else { force[i] = 0; act = 0; }
+    }
+    if (active) active[i] = act;
+  }
+  return cost;
+}
+
+/* ------------------------------------------------------------------ mj_solNewton (primal, exact line search) */
+typedef struct { double a; double c0, c1, c2; } Breakpt; /* at alpha >= a add (c0,c1,c2) to the quadratic */
+static int cmp_bp(const void* x, const void* y) {
+  double a = ((const Breakpt*)x)->a, b = ((const Breakpt*)y)->a;
+  return a < b ? -1 : a > b;
+}
+
+static double primal_cost(GqOracle* o, const double* qacc, double* force) {
+  double jar[NEFC], Ma[NV], cost = 0;
+  for (int i = 0; i < o->nefc; i++) {
+    double s = -o->efc_aref[i];
+    for (int k = 0; k < NV; k++) s += o->efc_J[i][k] * qacc[k];
+    jar[i] = s;
+  }
+  for (int i = 0; i < NV; i++) {
+    double s = 0;
+    for (int k = 0; k < NV; k++) s += o->M[i][k] * (qacc[k] - o->qacc_smooth[k]);
+    Ma[i] = s;
+  }
+  for (int i = 0; i < NV; i++) cost += 0.5 * Ma[i] * (qacc[i] - o->qacc_smooth[i]);
+  double tmp[NEFC];
+  return cost + constraint_update(o, jar, force ? force : tmp, NULL);
+}
+
+static void gqo_sol_newton(GqOracle* o, int maxiter, double tol) {
+  const int nefc = o->nefc;
+  double qacc[NV], jar[NEFC], grad[NV], search[NV], jv[NEFC], Mv[NV], H[NV][NV];
+  int active[NEFC];
+  /* warm start: whichever of qacc_warmstart / qacc_smooth has the lower cost */
+  double cw = primal_cost(o, o->qacc_warmstart, NULL), cs = primal_cost(o, o->qacc_smooth, NULL);
+  memcpy(qacc, cw < cs ? o->qacc_warmstart : o->qacc_smooth, sizeof qacc);
+  double scale = 1.0 / (o->d.meaninertia * NV);
+  int iter = 0;
+  for (; iter < maxiter; iter++) {
+    for (int i = 0; i < nefc; i++) {
+      double s = -o->efc_aref[i];
+      for (int k = 0; k < NV; k++) s += o->efc_J[i][k] * qacc[k];
+      jar[i] = s;
+    }
+    constraint_update(o, jar, o->efc_force, active);
+    /* gradient = M (qacc - qacc_smooth) - J' f */
+    for (int i = 0; i < NV; i++) {
+      double s = 0;
+      for (int k = 0; k < NV; k++) s += o->M[i][k] * (qacc[k] - o->qacc_smooth[k]);
+      for (int r = 0; r < nefc; r++) s -= o->efc_J[r][i] * o->efc_force[r];
+      grad[i] = s;
+    }
+    double gn = 0;
+    for (int i = 0; i < NV; i++) gn += grad[i] * grad[i];
+    if (scale * sqrt(gn) < tol) break;
+    /* Hessian = M + J' diag(D active) J ; dense Cholesky */
+    for (int i = 0; i < NV; i++)
+      for (int j = 0; j < NV; j++) H[i][j] = o->M[i][j];
+    for (int r = 0; r < nefc; r++)
+      if (active[r])
+        for (int i = 0; i < NV; i++) {
+          double a = o->efc_J[r][i] * o->efc_D[r];
+          if (a != 0)
+            for (int j = 0; j < NV; j++) H[i][j] += a * o->efc_J[r][j];
+        }
+    for (int j = 0; j < NV; j++) {
+      for (int k = 0; k < j; k++)
+        for (int i = j; i < NV; i++) H[i][j] -= H[i][k] * H[j][k];
+      double dj = sqrt(fmax(H[j][j], MINVAL));
+      for (int i = j; i < NV; i++) H[i][j] /= dj;
+    }
+    for (int i = 0; i < NV; i++) search[i] = -grad[i];
+    for (int i = 0; i < NV; i++) {
+      for (int k = 0; k < i; k++) search[i] -= H[i][k] * search[k];
+      search[i] /= H[i][i];
+    }
+    for (int i = NV - 1; i >= 0; i--) {
+      for (int k = i + 1; k < NV; k++) search[i] -= H[k][i] * search[k];
+      search[i] /= H[i][i];
+    }
+    /* exact line search on phi(alpha) = cost(qacc + alpha*search): convex piecewise quadratic.
+     * Gauss part: q0 + q1 a + q2 a^2 with q1 = search.(M(qacc-qs)), q2 = 0.5 search.M.search */
+    for (int i = 0; i < NV; i++) {
+      double s = 0;
+      for (int k = 0; k < NV; k++) s += o->M[i][k] * search[k];
+      Mv[i] = s;
+    }
+    for (int r = 0; r < nefc; r++) {
+      double s = 0;
+      for (int k = 0; k < NV; k++) s += o->efc_J[r][k] * search[k];
+      jv[r] = s;
+    }
+    double q1 = 0, q2 = 0;
+    for (int i = 0; i < NV; i++) {
+      double s = 0;
+      for (int k = 0; k < NV; k++) s += o->M[i][k] * (qacc[k] - o->qacc_smooth[k]);
+      q1 += search[i] * s;
+      q2 += 0.5 * search[i] * Mv[i];
+    }
+    /* derivative phi'(a) = d1 + 2*d2*a, accumulate row pieces valid at a = 0+, then sweep breakpoints */
+    static Breakpt bp[2 * NEFC];
+    int nbp = 0;
+    double d1 = q1, d2 = q2;
+    for (int r = 0; r < nefc; r++) {
+      double x = jar[r], v = jv[r], D = o->efc_D[r], R = o->efc_R[r];
+      if (v == 0) { /* constant piece: contributes nothing to the derivative */ continue; }
+      if (o->efc_type[r] == EFC_FRICTION_DOF) {
+        double f = o->efc_frictionloss[r], lo = -R * f, hi = R * f;
+        /* pieces along alpha: x + alpha v crosses lo and hi */
+        double a_lo = (lo - x) / v, a_hi = (hi - x) / v;
+        double a1 = fmin(a_lo, a_hi), a2 = fmax(a_lo, a_hi);
+        /* zone slopes: below lo: cost' = -f v ; quad: D (x+av) v ; above hi: +f v */
+        double s_first = v > 0 ? -f * v : f * v; /* zone entered from alpha -> -inf */
+        /* piece functions of derivative: linear zone -> (c1 = s, c2 = 0); quad zone -> (c1 = D x v, 2 c2 = D v v) */
+        double quad1 = D * x * v, quad2 = 0.5 * D * v * v, s_last = -s_first;
+        if (0 < a1) { d1 += s_first; bp[nbp++] = (Breakpt){a1, 0, quad1 - s_first, quad2};
+                      bp[nbp++] = (Breakpt){a2, 0, s_last - quad1, -quad2}; }
+        else if (0 < a2) { d1 += quad1; d2 += quad2; bp[nbp++] = (Breakpt){a2, 0, s_last - quad1, -quad2}; }
+        else { d1 += s_last; }
+      } else {
+        double a0 = -x / v; /* x + a v = 0 */
+        double quad1 = D * x * v, quad2 = 0.5 * D * v * v;
+        if (v > 0) { /* active (x<0) before a0, inactive after */
+          if (0 < a0) { d1 += quad1; d2 += quad2; bp[nbp++] = (Breakpt){a0, 0, -quad1, -quad2}; }
+        } else {     /* inactive before a0, active after */
+          if (0 < a0) bp[nbp++] = (Breakpt){a0, 0, quad1, quad2};
+          else { d1 += quad1; d2 += quad2; }
+        }
+      }
+    }
+    qsort(bp, nbp, sizeof(Breakpt), cmp_bp);
+    double alpha = 0;
+    int found = 0;
+    if (d1 >= 0) { alpha = 0; found = 1; }
+    for (int k = 0; k <= nbp && !found; k++) {
+      double hi = k < nbp ? bp[k].a : 1e300;
+      /* root of d1 + 2 d2 a in the current segment */
+      if (d2 > 0) {
+        double a = -d1 / (2 * d2);
+        if (a <= hi) { alpha = a; found = 1; break; }
+      }
+      if (k < nbp) { d1 += bp[k].c1; d2 += bp[k].c2;
+        if (d1 + 2 * d2 * hi >= 0) { alpha = hi; found = 1; break; } }
+    }
+    if (!found || alpha <= 0) break;
+    for (int i = 0; i < NV; i++) qacc[i] += alpha * search[i];
+  }
+  o->solver_niter = iter;
+  for (int i = 0; i < nefc; i++) {
+    double s = -o->efc_aref[i];
+    for (int k = 0; k < NV; k++) s += o->efc_J[i][k] * qacc[k];
+    jar[i] = s;
+  }
+  constraint_update(o, jar, o->efc_force, NULL);
+  memcpy(o->qacc, qacc, sizeof qacc);
+}
+
+/* ------------------------------------------------------------------ mj_solPGS (dual) */
+static double g_AR[NEFC][NEFC]; /* not re-entrant: PGS leg of the oracle is single-threaded */
+static void gqo_sol_pgs(GqOracle* o, int maxiter, double tol) {
+  const int nefc = o->nefc;
+  static double B[NEFC][NV];
+  for (int i = 0; i < nefc; i++) {
+    memcpy(B[i], o->efc_J[i], sizeof B[i]);
+    gqo_solve_m(o, B[i]);
+  }
+  for (int i = 0; i < nefc; i++)
+    for (int j = 0; j < nefc; j++) {
+      double s = 0;
+      for (int k = 0; k < NV; k++) s += o->efc_J[i][k] * B[j][k];
+      g_AR[i][j] = s + (i == j ? o->efc_R[i] : 0);
+    }
+  for (int i = 0; i < nefc; i++) {
+    double s = -o->efc_aref[i];
+    for (int k = 0; k < NV; k++) s += o->efc_J[i][k] * o->qacc_smooth[k];
+    o->efc_b[i] = s;
+  }
+  /* warm start: forces from the primal force law at qacc_warmstart; keep only if the dual cost is negative */
+  double jar[NEFC], *f = o->efc_force;
+  for (int i = 0; i < nefc; i++) {
+    double s = -o->efc_aref[i];
+    for (int k = 0; k < NV; k++) s += o->efc_J[i][k] * o->qacc_warmstart[k];
+    jar[i] = s;
+  }
+  constraint_update(o, jar, f, NULL);
+  double cost = 0;
+  for (int i = 0; i < nefc; i++) {
+    double s = 0;
+    for (int j = 0; j < nefc; j++) s += g_AR[i][j] * f[j];
+    cost += 0.5 * f[i] * s + f[i] * o->efc_b[i];
+  }
+  if (cost > 0) memset(f, 0, sizeof(double) * nefc);
+  double scale = 1.0 / (o->d.meaninertia * NV);
+  int iter = 0;
+  for (; iter < maxiter; iter++) {
+    double improvement = 0;
+    for (int i = 0; i < nefc; i++) {
+      double res = o->efc_b[i];
+      for (int j = 0; j < nefc; j++) res += g_AR[i][j] * f[j];
+      double old = f[i], x = old - res / g_AR[i][i];
+      if (o->efc_type[i] == EFC_FRICTION_DOF) { double fl = o->efc_frictionloss[i]; x = fmin(fmax(x, -fl), fl); }
+      else x = fmax(0, x);
+      double delta = x - old;
+      f[i] = x;
+      improvement -= 0.5 * delta * delta * g_AR[i][i] + delta * res;
+    }
+    if (improvement * scale < tol) { iter++; break; }
+  }
+  o->solver_niter = iter;
+  double qc[NV];
+  memset(qc, 0, sizeof qc);
+  for (int i = 0; i < nefc; i++)
+    for (int k = 0; k < NV; k++) qc[k] += o->efc_J[i][k] * f[i];
+  gqo_solve_m(o, qc);
+  for (int k = 0; k < NV; k++) o->qacc[k] = o->qacc_smooth[k] + qc[k];
+}
+
+static void gqo_fwd_constraint(GqOracle* o) {
+  if (o->nefc == 0) {
+    memcpy(o->qacc, o->qacc_smooth, sizeof o->qacc);
+    memset(o->qfrc_constraint, 0, sizeof o->qfrc_constraint);
+    o->solver_niter = 0;
+    return;
+  }
+  if (o->d.solver == 1) gqo_sol_newton(o, o->d.iterations, o->d.tolerance);
+  else gqo_sol_pgs(o, o->d.iterations, o->d.tolerance);
+  memset(o->qfrc_constraint, 0, sizeof o->qfrc_constraint);
+  for (int i = 0; i < o->nefc; i++)
+    for (int k = 0; k < NV; k++) o->qfrc_constraint[k] += o->efc_J[i][k] * o->efc_force[i];
+}
+
+/* ------------------------------------------------------------------ mj_Euler */
+static void gqo_euler(GqOracle* o) {
+  const GqModelDesc* m = &o->d;
+  double h = m->timestep, qacc[NV];
+  int damped = 0;
+  for (int i = 0; i < NV; i++) damped |= m->dof_damping[i] > 0;
+  if (damped) { /* (M + h*diag(damping)) qacc' = qfrc_smooth + qfrc_constraint */
+    double LD[NV][NV];
+    for (int i = 0; i < NV; i++)
+      for (int j = 0; j < NV; j++) LD[i][j] = j <= i ? o->M[i][j] : 0.0;
+    for (int i = 0; i < NV; i++) LD[i][i] += h * m->dof_damping[i];
+    factor_ld(m, LD);
+    for (int i = 0; i < NV; i++) qacc[i] = o->qfrc_smooth[i] + o->qfrc_constraint[i];
+    solve_ld(m, LD, qacc);
+  } else memcpy(qacc, o->qacc, sizeof qacc);
+  for (int i = 0; i < NV; i++) o->qvel[i] += h * qacc[i];
+  /* mj_integratePos */
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], d = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == 0) {
+      for (int k = 0; k < 3; k++) o->qpos[qa + k] += h * o->qvel[d + k];
+      double w[3] = {o->qvel[d + 3], o->qvel[d + 4], o->qvel[d + 5]};
+      double n = sqrt(dot3(w, w));
+      if (n > MINVAL) {
+        double ax[3] = {w[0] / n, w[1] / n, w[2] / n}, qr[4];
+        axis_angle2quat(qr, ax, h * n);
+        quat_mul(o->qpos + qa + 3, o->qpos + qa + 3, qr);
+      }
+      quat_normalize(o->qpos + qa + 3);
+    } else o->qpos[qa] += h * o->qvel[d];
+  }
+  o->time += h;
+  memcpy(o->qacc_warmstart, o->qacc, sizeof o->qacc);
+}
+
+/* ------------------------------------------------------------------ public stepping API */
+static int bad(const double* x, int n, double lim) {
+  for (int i = 0; i < n; i++)
+    if (!(fabs(x[i]) < lim)) return 1;
+  return 0;
+}
+
+/* mj_forward; stage 1 = position + velocity only (what mj_step1 evaluates, quadruped_env.py:376) */
+int gqo_forward(GqOracle* o, const double* ctrl, int stage) {
+  if (ctrl) memcpy(o->ctrl, ctrl, sizeof(double) * o->d.nu);
+  gqo_fwd_position(o);
+  gqo_fwd_velocity(o);
+  if (stage == 1) return GQ_OK;
+  gqo_fwd_actuation(o);
+  gqo_fwd_acceleration(o);
+  gqo_fwd_constraint(o);
+  return GQ_OK;
+}
+
+int gqo_step(GqOracle* o, const double* ctrl) {
+  o->warning = bad(o->qpos, NQ, 1e10) | bad(o->qvel, NV, 1e10);
+  gqo_forward(o, ctrl, 0);
+  o->warning |= bad(o->qacc, NV, 1e10);
+  gqo_euler(o);
+  return GQ_OK;
+}
+
+int gqo_set_state(GqOracle* o, const double* qpos, const double* qvel, const double* qacc_warmstart,
+                  const double* qfrc_applied, double time, double friction) {
+  if (qpos) memcpy(o->qpos, qpos, sizeof o->qpos);
+  if (qvel) memcpy(o->qvel, qvel, sizeof o->qvel);
+  if (qacc_warmstart) memcpy(o->qacc_warmstart, qacc_warmstart, sizeof o->qacc_warmstart);
+  if (qfrc_applied) memcpy(o->qfrc_applied, qfrc_applied, sizeof o->qfrc_applied);
+  o->time = time;
+  o->friction = friction;
+  return GQ_OK;
+}
+
+int gqo_set_solver(GqOracle* o, int solver, int iterations, double tolerance) {
+  o->d.solver = solver; o->d.iterations = iterations; o->d.tolerance = tolerance;
+  return GQ_OK;
+}
+
+/* mj_contactForce: normal/tangent force of contact c in the contact frame (mju_decodePyramid) */
+static void gqo_contact_force(const GqOracle* o, int c, double* out6) {
+  const Contact* con = &o->contact[c];
+  memset(out6, 0, sizeof(double) * 6);
+  const double* f = o->efc_force + con->efc_address;
+  if (con->dim == 1) { out6[0] = f[0]; return; }
+  for (int e = 0; e < 2 * (con->dim - 1); e++) out6[0] += f[e];
+  for (int k = 0; k < con->dim - 1; k++) out6[k + 1] = (f[2 * k] - f[2 * k + 1]) * con->friction[k];
+}
+
+#define GET(nm, ptr, count)                                  \
+  if (!strcmp(name, nm)) {                                   \
+    int n = (count);                                         \
+    if (n > max_n) n = max_n;                                \
+    memcpy(out, (ptr), sizeof(double) * (size_t)n);          \
+    return n;                                                \
+  }
+
+int gqo_get(const GqOracle* o, const char* name, double* out, int max_n) {
+  const GqModelDesc* m = &o->d;
+  GET("qpos", o->qpos, NQ) GET("qvel", o->qvel, NV) GET("qacc", o->qacc, NV) GET("qacc_warmstart", o->qacc_warmstart, NV)
+  GET("ctrl", o->ctrl, m->nu) GET("qfrc_applied", o->qfrc_applied, NV) GET("time", &o->time, 1)
+  GET("xpos", o->xpos, 3 * m->nbody) GET("xquat", o->xquat, 4 * m->nbody) GET("xmat", o->xmat, 9 * m->nbody)
+  GET("xipos", o->xipos, 3 * m->nbody) GET("subtree_com", o->subtree_com, 3 * m->nbody)
+  GET("geom_xpos", o->geom_xpos, 3 * m->ngeom) GET("geom_xmat", o->geom_xmat, 9 * m->ngeom)
+  GET("M", o->M, NV * NV) GET("qfrc_bias", o->qfrc_bias, NV) GET("qfrc_passive", o->qfrc_passive, NV)
+  GET("qfrc_actuator", o->qfrc_actuator, NV) GET("qfrc_smooth", o->qfrc_smooth, NV) GET("qacc_smooth", o->qacc_smooth, NV)
+  GET("qfrc_constraint", o->qfrc_constraint, NV) GET("cvel", o->cvel, 6 * m->nbody)
+  GET("efc_pos", o->efc_pos, o->nefc) GET("efc_margin", o->efc_margin, o->nefc) GET("efc_R", o->efc_R, o->nefc)
+  GET("efc_D", o->efc_D, o->nefc) GET("efc_aref", o->efc_aref, o->nefc) GET("efc_vel", o->efc_vel, o->nefc)
+  GET("efc_force", o->efc_force, o->nefc) GET("efc_frictionloss", o->efc_frictionloss, o->nefc)
+  GET("efc_diagApprox", o->efc_diagApprox, o->nefc) GET("efc_b", o->efc_b, o->nefc)
+  if (!strcmp(name, "efc_J")) {
+    int n = o->nefc * NV; if (n > max_n) n = max_n;
+    for (int i = 0; i < n; i++) out[i] = o->efc_J[i / NV][i % NV];
+    return n;
+  }
+  if (!strcmp(name, "efc_type")) { int n = o->nefc < max_n ? o->nefc : max_n; for (int i = 0; i < n; i++) out[i] = o->efc_type[i]; return n; }
+  if (!strcmp(name, "nefc")) { out[0] = o->nefc; return 1; }
+  if (!strcmp(name, "ncon")) { out[0] = o->ncon; return 1; }
+  if (!strcmp(name, "solver_niter")) { out[0] = o->solver_niter; return 1; }
+  if (!strcmp(name, "warning")) { out[0] = o->warning; return 1; }
+  if (!strcmp(name, "contact_dist")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].dist; return n; }
+  if (!strcmp(name, "contact_geom")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].geom; return n; }
+  if (!strcmp(name, "contact_body")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].body; return n; }
+  if (!strcmp(name, "contact_pos")) { int n = 3 * o->ncon < max_n ? 3 * o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i / 3].pos[i % 3]; return n; }
+  if (!strcmp(name, "contact_frame")) { int n = 9 * o->ncon < max_n ? 9 * o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i / 9].frame[i % 9]; return n; }
+  if (!strcmp(name, "contact_force")) { /* mj_contactForce for every contact, 6 each */
+    int n = 6 * o->ncon < max_n ? 6 * o->ncon : max_n; double f[6];
+    for (int c = 0; c * 6 < n; c++) { gqo_contact_force(o, c, f); for (int k = 0; k < 6 && 6 * c + k < n; k++) out[6 * c + k] = f[k]; }
+    return n;
+  }
+  snprintf(g_err, sizeof g_err, "gqo_get: unknown field %s", name);
+  return GQ_EINVAL;
+}
+
+/* mj_jac wrapper for tests / observation oracle: point in world coords, body id; jacp/jacr 3 x nv row-major */
+int gqo_jac_point(const GqOracle* o, const double* point, int body, double* jacp, double* jacr) {
+  double jp[3][NV], jr[3][NV];
+  gqo_jac(o, jp, jr, point, body);
+  if (jacp) memcpy(jacp, jp, sizeof jp);
+  if (jacr) memcpy(jacr, jr, sizeof jr);
+  return GQ_OK;
+}
+
+/* ------------------------------------------------------------------ observation + termination assembly in C
+ * (restates quadruped_env.py:1146-1257 on top of the oracle's mjData-equivalent; used for the cpu_baseline timing
+ * and cross-checked against oracle/obs_oracle.py, which is pinned by the reference-generated golden vectors) */
+static void euler_xyz_from_mat(const double* R, double* e) { /* scipy Rotation.as_euler('xyz'), extrinsic */
+  double sy = -R[6];
+  if (sy > 1) sy = 1; if (sy < -1) sy = -1;
+  e[1] = asin(sy);
+  if (fabs(sy) < 1 - 1e-12) { e[0] = atan2(R[7], R[8]); e[2] = atan2(R[3], R[0]); }
+  else { e[0] = 0; e[2] = atan2(-R[1], R[4]); } /* gimbal lock: scipy sets the third angle to zero */
+}
+
+int gqo_get_obs(const GqOracle* o, const double* cmd /*[4]*/, const int* legs_order /*[4]*/, const int* obs_ids,
+                int n_obs, double* out, int* terminated, int* invalid_contact) {
+  const GqModelDesc* m = &o->d;
+  double q[4], R[9], e[3], Rh[9];
+  memcpy(q, o->qpos + 3, sizeof q);
+  quat_normalize(q); /* scipy Rotation.from_quat normalises */
+  quat2mat(R, q);
+  euler_xyz_from_mat(R, e);
+  double cy = cos(e[2]), sy = sin(e[2]);
+  double Rh_[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1};
+  memcpy(Rh, Rh_, sizeof Rh);
+  double tl[3], ta[3] = {0, 0, cmd[3]};
+  mulmatvec3(tl, Rh, cmd);
+  /* feet quantities from the (stale) position stage */
+  double fpos[4][3], fvel[4][3], fvel_rel[4][3], cf[4][3];
+  int cstate[4] = {0, 0, 0, 0};
+  for (int l = 0; l < 4; l++) {
+    int g = m->feet_geomid[l], b = m->geom_bodyid[g];
+    memcpy(fpos[l], o->geom_xpos[g], sizeof fpos[l]);
+    double jp[3][NV];
+    gqo_jac(o, jp, NULL, fpos[l], b);
+    for (int k = 0; k < 3; k++) {
+      double s = 0;
+      for (int i = 0; i < NV; i++) s += jp[k][i] * o->qvel[i];
+      fvel[l][k] = s;
+    }
+    double d[3], cr[3];
+    for (int k = 0; k < 3; k++) d[k] = fpos[l][k] - o->qpos[k];
+    cross3(cr, o->qvel + 3, d); /* quirk B4: body-frame omega used as if world-frame (quadruped_env.py:659,669) */
+    for (int k = 0; k < 3; k++) fvel_rel[l][k] = fvel[l][k] - o->qvel[k] - cr[k];
+    cf[l][0] = cf[l][1] = cf[l][2] = 0;
+  }
+  *invalid_contact = 0;
+  for (int c = 0; c < o->ncon; c++) {
+    int g = o->contact[c].geom, b = m->geom_bodyid[g], leg = -1;
+    for (int l = 0; l < 4; l++)
+      if (m->geom_bodyid[m->feet_geomid[l]] == b) leg = l;
+    if (leg < 0) { *invalid_contact = 1; continue; }
+    cstate[leg] = 1;
+    double f6[6], fw[3];
+    gqo_contact_force(o, c, f6);
+    mulmatTvec3(fw, o->contact[c].frame, f6);
+    for (int k = 0; k < 3; k++) cf[leg][k] += fw[k];
+  }
+  *terminated = *invalid_contact || o->qpos[0] > m->terrain_limits[0] || o->qpos[0] < m->terrain_limits[1] ||
+                o->qpos[1] > m->terrain_limits[2] || o->qpos[1] < m->terrain_limits[3];
+  double Mv[NV], Ma[NV], ke = 0, work = 0;
+  for (int i = 0; i < NV; i++) {
+    double s = 0, t = 0;
+    for (int k = 0; k < NV; k++) { s += o->M[i][k] * o->qvel[k]; t += o->M[i][k] * o->qacc[k]; }
+    Mv[i] = s; Ma[i] = t;
+  }
+  for (int i = 0; i < NV; i++) { ke += 0.5 * o->qvel[i] * Mv[i]; work += Ma[i] * o->qvel[i]; }
+  double* p = out;
+  double tmp[3], tmp2[3];
+#define PUT3(v) { p[0] = (v)[0]; p[1] = (v)[1]; p[2] = (v)[2]; p += 3; }
+  for (int n = 0; n < n_obs; n++) {
+    switch (obs_ids[n]) {
+      case GQ_OBS_BASE_POS: PUT3(o->qpos) break;
+      case GQ_OBS_BASE_LIN_VEL: PUT3(o->qvel) break;
+      case GQ_OBS_BASE_LIN_VEL_ERR: for (int k = 0; k < 3; k++) tmp[k] = tl[k] - o->qvel[k]; PUT3(tmp) break;
+      case GQ_OBS_BASE_LIN_ACC: PUT3(o->qacc) break;
+      case GQ_OBS_BASE_ANG_VEL: mulmatvec3(tmp, R, o->qvel + 3); PUT3(tmp) break;
+      case GQ_OBS_BASE_ANG_VEL_ERR: mulmatvec3(tmp, R, o->qvel + 3); for (int k = 0; k < 3; k++) tmp[k] = ta[k] - tmp[k]; PUT3(tmp) break;
+      case GQ_OBS_BASE_ORI_EULER_XYZ: PUT3(e) break;
+      case GQ_OBS_BASE_ORI_QUAT_WXYZ: memcpy(p, o->qpos + 3, 4 * sizeof(double)); p += 4; break;
+      case GQ_OBS_BASE_ORI_SO3: memcpy(p, R, sizeof R); p += 9; break;
+      case GQ_OBS_GRAVITY_VECTOR_B: { double g[3] = {0, 0, -1}; mulmatTvec3(tmp, R, g); PUT3(tmp) } break;
+      case GQ_OBS_BASE_LIN_VEL_B: mulmatTvec3(tmp, R, o->qvel); PUT3(tmp) break;
+      case GQ_OBS_BASE_LIN_VEL_ERR_B: mulmatTvec3(tmp, R, tl); mulmatTvec3(tmp2, R, o->qvel); for (int k = 0; k < 3; k++) tmp[k] -= tmp2[k]; PUT3(tmp) break;
+      case GQ_OBS_BASE_LIN_ACC_B: mulmatTvec3(tmp, R, o->qacc); PUT3(tmp) break;
+      case GQ_OBS_BASE_ANG_VEL_B: PUT3(o->qvel + 3) break;
+      case GQ_OBS_BASE_ANG_VEL_ERR_B: mulmatTvec3(tmp, R, ta); for (int k = 0; k < 3; k++) tmp[k] -= o->qvel[3 + k]; PUT3(tmp) break;
+      case GQ_OBS_QPOS: memcpy(p, o->qpos, sizeof o->qpos); p += NQ; break;
+      case GQ_OBS_QVEL: memcpy(p, o->qvel, sizeof o->qvel); p += NV; break;
+      case GQ_OBS_TAU_CTRL_SETPOINT: memcpy(p, o->ctrl, sizeof(double) * m->nu); p += m->nu; break;
+      case GQ_OBS_QPOS_JS: memcpy(p, o->qpos + 7, sizeof(double) * 12); p += 12; break;
+      case GQ_OBS_QVEL_JS: memcpy(p, o->qvel + 6, sizeof(double) * 12); p += 12; break;
+      case GQ_OBS_KINETIC_ENERGY: *p++ = ke; break;
+      case GQ_OBS_WORK: *p++ = work; break;
+      case GQ_OBS_FEET_POS: for (int l = 0; l < 4; l++) PUT3(fpos[legs_order[l]]) break;
+      case GQ_OBS_FEET_POS_B: for (int l = 0; l < 4; l++) { for (int k = 0; k < 3; k++) tmp2[k] = fpos[legs_order[l]][k] - o->qpos[k]; mulmatTvec3(tmp, R, tmp2); PUT3(tmp) } break;
+      case GQ_OBS_FEET_VEL: for (int l = 0; l < 4; l++) PUT3(fvel[legs_order[l]]) break;
+      case GQ_OBS_FEET_VEL_REL: for (int l = 0; l < 4; l++) PUT3(fvel_rel[legs_order[l]]) break;
+      case GQ_OBS_FEET_VEL_B: for (int l = 0; l < 4; l++) { mulmatTvec3(tmp, R, fvel[legs_order[l]]); PUT3(tmp) } break;
+      case GQ_OBS_FEET_VEL_REL_B: for (int l = 0; l < 4; l++) { mulmatTvec3(tmp, R, fvel_rel[legs_order[l]]); PUT3(tmp) } break;
+      case GQ_OBS_CONTACT_STATE: for (int l = 0; l < 4; l++) *p++ = cstate[l]; break; /* quirk B5: always FL FR RL RR */
+      case GQ_OBS_CONTACT_FORCES: for (int l = 0; l < 4; l++) PUT3(cf[legs_order[l]]) break;
+      case GQ_OBS_CONTACT_FORCES_B: for (int l = 0; l < 4; l++) { mulmatTvec3(tmp, R, cf[legs_order[l]]); PUT3(tmp) } break;
+      default: snprintf(g_err, sizeof g_err, "gqo_get_obs: bad obs id %d", obs_ids[n]); return GQ_EINVAL;
+    }
+  }
+  return (int)(p - out);
+}
+
+/* cpu_baseline helper: run `nsteps` steps with the given control sequence [nsteps][nu] and assemble obs each step */
+int gqo_rollout(GqOracle* o, const double* ctrl_seq, int nsteps, const double* cmd, const int* legs_order,
+                const int* obs_ids, int n_obs, double* obs_last) {
+  static double buf[512];
+  int term, inv, nterm = 0;
+  for (int s = 0; s < nsteps; s++) {
+    gqo_step(o, ctrl_seq + (size_t)s * o->d.nu);
+    gqo_get_obs(o, cmd, legs_order, obs_ids, n_obs, obs_last ? obs_last : buf, &term, &inv);
+    nterm += term;
+  }
+  return nterm;
+}
