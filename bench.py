@@ -1,0 +1,161 @@
+"""bench.py - headline benchmark: batched QuadrupedEnv.step() throughput (env-steps/sec).
+
+Workload (BASELINE.json configs[1]): mini_cheetah on the flat scene, 4096 envs per GPU, random-action rollout
+(50 * N(0,1) torques, what the reference's ``action_space.sample() * 50`` produces), ALL_OBS observations (227
+scalars), masked auto-reset on termination, sim_dt = 0.002, PGS with MuJoCo's default iteration cap / tolerance
+(100 / 1e-8).  One "step" = one ``env.step(action)`` over the whole batch, exactly what the reference's ``step``
+does for one env: mj_step + observation/termination assembly.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Every rank owns an independent shard of 4096 envs (weak scaling, no data-path collective; the process group only
+provides the start/stop barrier and the max-over-ranks time).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ENVS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_env_step(obs_dim: int) -> int:
+    """HBM bytes one env-step must move (DESIGN.md "Roofline accounting"): state rows in, state + obs rows out."""
+    reads = 19 * 8 + 18 * 4 + 12 * 4 + 18 * 4 + 18 * 4 + 4 + 4 + 16 + 4      # qpos f64, qvel, ctrl, warm, applied, time, friction, cmd, step_num
+    writes = 19 * 8 + 18 * 4 + 18 * 4 + 18 * 4 + 4 + 4 * obs_dim + 4 + 3 + 4  # qpos, qvel, qacc, warm, time, obs, reward, 3 flags, step_num
+    return reads + writes
+
+
+def cpu_baseline(seconds_budget: float = 15.0):
+    """Single-env CPU fp64 restatement of the reference step (oracle, MuJoCo's default Newton solver), 1 core."""
+    from gym_quadruped_amd.cabi import ALL_OBS
+    from oracle.oracle import Oracle
+    from tests.helpers import marshalled
+
+    mm = marshalled('mini_cheetah', solver=1, iterations=100, tolerance=1e-8)
+    o = Oracle(mm)
+    q = mm.md.key_qpos[0].copy()
+    q[2] = 0.3
+    o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18), 0.0, -1.0)
+    rng = np.random.default_rng(0)
+    chunk, done, t_used = 20000, 0, 0.0
+    while t_used < seconds_budget:
+        ctrl = rng.normal(0, 1, (chunk, 12)).astype(np.float32).astype(np.float64) * 50
+        t0 = time.perf_counter()
+        o.rollout(ctrl, ALL_OBS)
+        t_used += time.perf_counter() - t0
+        done += chunk
+    return {'value': done / t_used, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{done} steps of 1 mini_cheetah env on flat, 50*N(0,1) torques, ALL_OBS assembled each step, '
+                      f'reset to the start state on termination; C fp64 restatement of mj_step with the Newton solver '
+                      f'(MuJoCo itself is not installable here), {os.cpu_count()} host cores present, 1 used'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+    ap.add_argument('--obs', choices=['all', 'default'], default='all')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-auto-reset', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} != WORLD_SIZE {world}')
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device(f'cuda:{local_rank}'))
+    device = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(device)
+
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+
+    obs_names = tuple(QuadrupedEnv.ALL_OBS) if args.obs == 'all' else QuadrupedEnv._DEFAULT_OBS
+    n = args.envs_per_gpu
+    env = QuadrupedEnv('mini_cheetah', state_obs_names=obs_names, scene='flat', num_envs=n, device=device,
+                       auto_reset=not args.no_auto_reset, solver_iterations=100, solver_tolerance=1e-8,
+                       seed=1000 + rank)  # env shards draw from disjoint RNG keys
+    env.reset(random=True)
+    g = torch.Generator(device=device).manual_seed(rank)
+    pool = [torch.randn(n, 12, generator=g, device=device) * 50 for _ in range(64)]
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        env.step(pool[i % 64])
+    # timed region: exactly K steps bracketed by barrier + synchronize
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    env._profile_events = None
+    barrier()
+    t0 = time.perf_counter()
+    nterm = 0
+    for i in range(args.steps):
+        env._profile_events = ev[i]  # HIP events around the step-kernel launch on the launch stream
+        env.step(pool[i % 64])
+    env._profile_events = None
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    finite = bool(torch.isfinite(env.qpos).all() and torch.isfinite(env.qvel).all())
+
+    if rank == 0:
+        total_envs = n * world
+        value = total_envs * args.steps / dt
+        bytes_step = algorithmic_bytes_per_env_step(env._obs_dim)
+        achieved = n * bytes_step / (kernel_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'env-steps/sec (batched)', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'mini_cheetah flat, {n} envs/GPU, random-action rollout (50*N(0,1) torques), '
+                                   f'{"ALL_OBS" if args.obs == "all" else "_DEFAULT_OBS"} ({env._obs_dim} scalars), '
+                                   f'auto-reset on termination, sim_dt 0.002, PGS <=100 it tol 1e-8',
+                       'envs_per_gpu': n, 'total_envs': total_envs, 'parallelism': f'env-shards x{world} (no collectives)',
+                       'state_finite': finite},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'gq::step_kernel',
+                         'kernel_ms': kernel_ms, 'bytes_per_env_step': bytes_step,
+                         'note': 'algorithmic bytes / HIP-event kernel time; the step is latency/VALU bound, not HBM bound'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,48 @@
+"""Loader of the HIP extension ``libgq.so`` (C-ABI of include/gq.h).  There is NO fallback: if the library is
+missing or cannot be loaded the product path raises - it never routes through the CPU oracle."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+from .cabi import GqModelDesc, GqObsOut, GqResetCfg, GqState
+
+_LIB = None
+LIB_PATH = Path(__file__).parent / 'libgq.so'
+
+EXPORTS = ['gq_last_error', 'gq_version', 'gq_obs_dim', 'gq_model_create', 'gq_model_destroy', 'gq_batch_create',
+           'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get']
+
+
+class GqError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not LIB_PATH.exists():
+        raise GqError(f'{LIB_PATH} not found: build the HIP extension first (python -c "import __graft_entry__ as g; '
+                      f'g.build()" or make -C gym_quadruped_amd/csrc). There is no CPU fallback.')
+    L = C.CDLL(str(LIB_PATH))
+    L.gq_last_error.restype = C.c_char_p
+    L.gq_model_create.argtypes = [C.POINTER(GqModelDesc), C.c_int, C.POINTER(C.c_void_p)]
+    L.gq_model_destroy.argtypes = [C.c_void_p]
+    L.gq_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.gq_batch_destroy.argtypes = [C.c_void_p]
+    L.gq_batch_obs_dim.argtypes = [C.c_void_p]
+    L.gq_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, GqState, GqObsOut, C.c_void_p]
+    L.gq_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GqResetCfg), GqState, GqObsOut,
+                           C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gq_debug_enable.argtypes = [C.c_void_p, C.c_int]
+    L.gq_debug_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int]
+    L.gq_obs_dim.argtypes = [C.c_int]
+    _LIB = L
+    return L
+
+
+def check(rc, what):
+    if rc < 0:
+        raise GqError(f'{what} failed ({rc}): {lib().gq_last_error().decode()}')
+    return rc

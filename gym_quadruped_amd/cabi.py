@@ -40,6 +40,7 @@ class GqModelDesc(C.Structure):
         ('floor_solmix', C.c_double), ('floor_solref', C.c_double * 2), ('floor_solimp', C.c_double * 5),
         ('floor_condim', C.c_int32), ('floor_priority', C.c_int32),
         ('feet_geomid', C.c_int32 * GQ_NLEG), ('terrain_limits', C.c_double * 4), ('meaninertia', C.c_double),
+        ('key_qpos', C.c_double * 19),
         ('solver', C.c_int32), ('iterations', C.c_int32), ('tolerance', C.c_double),
     ]
 
@@ -47,6 +48,13 @@ class GqModelDesc(C.Structure):
 class GqState(C.Structure):
     _fields_ = [('qpos', C.c_void_p), ('qvel', C.c_void_p), ('qacc', C.c_void_p), ('qacc_warmstart', C.c_void_p),
                 ('qfrc_applied', C.c_void_p), ('time', C.c_void_p), ('friction', C.c_void_p), ('cmd', C.c_void_p)]
+
+
+class GqResetCfg(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('random', C.c_int32), ('q_pos_amp', C.c_float), ('q_vel_amp', C.c_float),
+                ('roll_sweep', C.c_float), ('pitch_sweep', C.c_float), ('hip_height', C.c_float),
+                ('lin_vel_range', C.c_float * 2), ('ang_vel_range', C.c_float * 2), ('friction_range', C.c_float * 2),
+                ('cmd_forward', C.c_int32), ('cmd_random', C.c_int32), ('cmd_rotate', C.c_int32), ('cmd_human', C.c_int32)]
 
 
 class GqObsOut(C.Structure):
@@ -105,6 +113,8 @@ class MarshalledModel:
         d.feet_geomid = (C.c_int32 * 4)(*[md.geom_names.index(names[k]) for k in LEG_NAMES])
         d.terrain_limits = (C.c_double * 4)(*terrain_limits)
         d.meaninertia = float(md.meaninertia)
+        kq = md.key_qpos[0] if len(md.key_qpos) else q0
+        d.key_qpos = (C.c_double * 19)(*[float(v) for v in kq])
         d.solver, d.iterations, d.tolerance = int(solver), int(iterations), float(tolerance)
         self.desc = d
 

@@ -1,0 +1,200 @@
+/*
+ * gq_api.hip - the C-ABI of libgq (include/gq.h): handle management, model upload, launches.
+ * No torch types, no hidden synchronisation; every tensor is a caller-owned device pointer.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gq.h"
+#include "gq_host_model.h"
+#include <gq_device.h>
+#include "gq_step_kernel.h"
+#include "gq_step_body.h"
+
+extern "C" void gq_launch_step(const gq::StepArgs* a, int n_envs, hipStream_t stream);
+extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream);
+
+static thread_local char g_err[512] = "";
+#define SET_ERR(...) std::snprintf(g_err, sizeof g_err, __VA_ARGS__)
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) { SET_ERR("%s: %s", #expr, hipGetErrorString(e_)); return GQ_EDEVICE; } \
+  } while (0)
+
+struct GqModel {
+  int device;
+  GqDevModel host;
+  GqDevModel* dev;
+  float *vx, *vy, *vz;
+  int nvert;
+};
+struct GqBatch {
+  GqModel* model;
+  GqDevBatch host;
+  GqDevBatch* dev;
+  float* debug;       /* device, debug_envs * GQ_DBG_SIZE floats (lazily allocated) */
+  float* friction_next; /* device [N]: friction drawn by reset, committed after the reset step */
+  int debug_cap;
+};
+
+extern "C" {
+
+const char* gq_last_error(void) { return g_err; }
+int gq_version(void) { return 100; }
+int gq_obs_dim(int obs_id) { return gq_obs_dim_host(obs_id); }
+
+int gq_model_create(const GqModelDesc* desc, int device, GqModel** out) {
+  if (!desc || !out) { SET_ERR("gq_model_create: null argument"); return GQ_EINVAL; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { SET_ERR("no HIP device visible"); return GQ_ENODEVICE; }
+  if (device < 0 || device >= ndev) { SET_ERR("device %d out of range (have %d)", device, ndev); return GQ_EINVAL; }
+  GqModel* m = new (std::nothrow) GqModel();
+  if (!m) return GQ_ENOMEM;
+  std::vector<float> vx, vy, vz;
+  if (gq_build_dev_model(desc, &m->host, &vx, &vy, &vz, g_err, sizeof g_err)) { delete m; return GQ_EINVAL; }
+  m->device = device; m->nvert = (int)vx.size();
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMalloc(&m->dev, sizeof(GqDevModel)));
+  HIP_TRY(hipMemcpy(m->dev, &m->host, sizeof(GqDevModel), hipMemcpyHostToDevice));
+  size_t vb = vx.size() * sizeof(float);
+  HIP_TRY(hipMalloc(&m->vx, vb)); HIP_TRY(hipMalloc(&m->vy, vb)); HIP_TRY(hipMalloc(&m->vz, vb));
+  HIP_TRY(hipMemcpy(m->vx, vx.data(), vb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->vy, vy.data(), vb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->vz, vz.data(), vb, hipMemcpyHostToDevice));
+  *out = m;
+  return GQ_OK;
+}
+
+int gq_model_destroy(GqModel* m) {
+  if (!m) return GQ_OK;
+  hipSetDevice(m->device);
+  hipFree(m->dev); hipFree(m->vx); hipFree(m->vy); hipFree(m->vz);
+  delete m;
+  return GQ_OK;
+}
+
+int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, const int32_t* legs_order, GqBatch** out) {
+  if (!m || !out || n_envs <= 0) { SET_ERR("gq_batch_create: bad argument"); return GQ_EINVAL; }
+  GqBatch* b = new (std::nothrow) GqBatch();
+  if (!b) return GQ_ENOMEM;
+  b->model = m; b->debug = nullptr; b->debug_cap = 0;
+  if (gq_build_dev_batch(n_envs, obs_ids, n_obs, legs_order, &b->host, g_err, sizeof g_err)) { delete b; return GQ_EINVAL; }
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMalloc(&b->dev, sizeof(GqDevBatch)));
+  HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->friction_next, sizeof(float) * (size_t)n_envs));
+  HIP_TRY(hipMemset(b->friction_next, 0, sizeof(float) * (size_t)n_envs));
+  *out = b;
+  return GQ_OK;
+}
+
+int gq_batch_destroy(GqBatch* b) {
+  if (!b) return GQ_OK;
+  hipSetDevice(b->model->device);
+  hipFree(b->dev); hipFree(b->friction_next);
+  if (b->debug) hipFree(b->debug);
+  delete b;
+  return GQ_OK;
+}
+
+int gq_batch_obs_dim(const GqBatch* b) { return b ? b->host.obs_dim : GQ_EINVAL; }
+
+int gq_debug_enable(GqBatch* b, int n_debug_envs) {
+  if (!b) return GQ_EINVAL;
+  if (n_debug_envs > b->host.n_envs) n_debug_envs = b->host.n_envs;
+  HIP_TRY(hipSetDevice(b->model->device));
+  if (n_debug_envs > b->debug_cap) {
+    if (b->debug) hipFree(b->debug);
+    HIP_TRY(hipMalloc(&b->debug, (size_t)n_debug_envs * GQ_DBG_SIZE * sizeof(float)));
+    HIP_TRY(hipMemset(b->debug, 0, (size_t)n_debug_envs * GQ_DBG_SIZE * sizeof(float)));
+    b->debug_cap = n_debug_envs;
+  }
+  b->host.debug_envs = n_debug_envs;
+  HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
+  return GQ_OK;
+}
+
+int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, void* hip_stream) {
+  if (!b || !ctrl || !st.qpos || !st.qvel || !st.qacc || !st.qacc_warmstart || !st.time || !out.obs || !out.reward ||
+      !out.terminated || !out.truncated || !out.invalid_contact || !out.step_num) {
+    SET_ERR("gq_step: null tensor"); return GQ_EINVAL;
+  }
+  gq::StepArgs a{};
+  GqModel* m = b->model;
+  a.model = m->dev; a.batch = b->dev; a.vx = m->vx; a.vy = m->vy; a.vz = m->vz;
+  a.ctrl = ctrl; a.mask = mask; a.qpos = st.qpos; a.qvel = st.qvel; a.qacc = st.qacc; a.warm = st.qacc_warmstart;
+  a.applied = st.qfrc_applied; a.time = st.time; a.friction = st.friction; a.cmd = st.cmd;
+  a.obs = out.obs; a.reward = out.reward; a.terminated = out.terminated; a.truncated = out.truncated;
+  a.invalid_contact = out.invalid_contact; a.step_num = out.step_num;
+  a.debug = b->host.debug_envs > 0 ? b->debug : nullptr; a.n_envs = b->host.n_envs;
+  gq_launch_step(&a, b->host.n_envs, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  return GQ_OK;
+}
+
+int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new, const GqResetCfg* cfg,
+             GqState st, GqObsOut out, int32_t* episode, uint8_t* lift_failed, void* hip_stream) {
+  if (!b || !cfg || !st.qpos || !st.qvel || !st.qacc || !st.qacc_warmstart || !st.time || !out.step_num || !out.obs ||
+      !out.reward || !out.terminated || !out.truncated || !out.invalid_contact) {
+    SET_ERR("gq_reset: null tensor"); return GQ_EINVAL;
+  }
+  if ((qpos_new == nullptr) != (qvel_new == nullptr)) { SET_ERR("gq_reset: qpos_new and qvel_new must be given together"); return GQ_EINVAL; }
+  GqModel* m = b->model;
+  gq::ResetArgs a{};
+  a.model = m->dev; a.vx = m->vx; a.vy = m->vy; a.vz = m->vz; a.mask = mask; a.qpos_new = qpos_new; a.qvel_new = qvel_new;
+  a.qpos = st.qpos; a.qvel = st.qvel; a.qacc = st.qacc; a.warm = st.qacc_warmstart; a.applied = st.qfrc_applied;
+  a.time = st.time; a.cmd = st.cmd; a.friction_next = st.friction ? b->friction_next : nullptr;
+  a.step_num = out.step_num; a.episode = episode; a.lift_failed = lift_failed;
+  a.cfg.seed_lo = (uint32_t)(cfg->seed & 0xffffffffu); a.cfg.seed_hi = (uint32_t)(cfg->seed >> 32);
+  a.cfg.random = cfg->random; a.cfg.q_pos_amp = cfg->q_pos_amp; a.cfg.q_vel_amp = cfg->q_vel_amp;
+  a.cfg.roll_sweep = cfg->roll_sweep; a.cfg.pitch_sweep = cfg->pitch_sweep; a.cfg.hip_height = cfg->hip_height;
+  for (int k = 0; k < 2; k++) { a.cfg.lin_vel_range[k] = cfg->lin_vel_range[k]; a.cfg.ang_vel_range[k] = cfg->ang_vel_range[k]; a.cfg.friction_range[k] = cfg->friction_range[k]; }
+  a.cfg.cmd_forward = cfg->cmd_forward; a.cfg.cmd_random = cfg->cmd_random; a.cfg.cmd_rotate = cfg->cmd_rotate; a.cfg.cmd_human = cfg->cmd_human;
+  gq_launch_reset(&a, b->host.n_envs, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */
+  gq::StepArgs s{};
+  s.model = m->dev; s.batch = b->dev; s.vx = m->vx; s.vy = m->vy; s.vz = m->vz;
+  s.ctrl = nullptr; s.mask = mask; s.qpos = st.qpos; s.qvel = st.qvel; s.qacc = st.qacc; s.warm = st.qacc_warmstart;
+  s.applied = st.qfrc_applied; s.time = st.time; s.friction = st.friction; s.cmd = st.cmd;
+  s.friction_commit = st.friction ? b->friction_next : nullptr;
+  s.obs = out.obs; s.reward = out.reward; s.terminated = out.terminated; s.truncated = out.truncated;
+  s.invalid_contact = out.invalid_contact; s.step_num = out.step_num;
+  s.debug = nullptr; s.n_envs = b->host.n_envs;
+  gq_launch_step(&s, b->host.n_envs, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  return GQ_OK;
+}
+
+static const struct { const char* name; int off, n; } kDbg[] = {
+    {"M", GQ_DBG_M, 324}, {"qfrc_bias", GQ_DBG_BIAS, 18}, {"qfrc_smooth", GQ_DBG_SMOOTH, 18},
+    {"qacc_smooth", GQ_DBG_QACC_SMOOTH, 18}, {"qfrc_constraint", GQ_DBG_QFRC_C, 18}, {"xpos", GQ_DBG_XPOS, 39},
+    {"xmat", GQ_DBG_XMAT, 117}, {"nefc", GQ_DBG_NEFC, 1}, {"ncon", GQ_DBG_NCON, 1}, {"niter", GQ_DBG_NITER, 1},
+    {"efc_J", GQ_DBG_EFC_J, 64 * 18}, {"efc_aref", GQ_DBG_EFC_AREF, 64}, {"efc_R", GQ_DBG_EFC_R, 64},
+    {"efc_b", GQ_DBG_EFC_B, 64}, {"efc_force", GQ_DBG_EFC_FORCE, 64}, {"efc_type", GQ_DBG_EFC_TYPE, 64},
+    {"contact_dist", GQ_DBG_CON_DIST, GQ_MAXCON}, {"contact_geom", GQ_DBG_CON_GEOM, GQ_MAXCON},
+    {"foot_pos", GQ_DBG_FOOT_POS, 12}, {"qacc", GQ_DBG_QACC, 18}, {"record", 0, GQ_DBG_SIZE}};
+
+int gq_debug_get(GqBatch* b, int env, const char* name, double* out, int max_n) {
+  if (!b || !name || !out || env < 0 || env >= b->host.debug_envs || !b->debug) { SET_ERR("gq_debug_get: bad argument / debug not enabled"); return GQ_EINVAL; }
+  for (const auto& f : kDbg)
+    if (!std::strcmp(f.name, name)) {
+      int n = f.n < max_n ? f.n : max_n;
+      std::vector<float> tmp((size_t)n);
+      HIP_TRY(hipSetDevice(b->model->device));
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemcpy(tmp.data(), b->debug + (size_t)env * GQ_DBG_SIZE + f.off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; i++) out[i] = tmp[(size_t)i];
+      return n;
+    }
+  SET_ERR("gq_debug_get: unknown field %s", name);
+  return GQ_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+/*
+ * gq_device.h - wave-level primitives for the gfx950 kernels (one env per 64-lane wavefront, one wavefront
+ * per workgroup).  Cross-lane primitives must be called from wave-uniform control flow.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GQ_WAVE 64
+
+namespace gq {
+
+__device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
+
+/* LDS hand-off between lanes of the single wavefront of this workgroup.  With a 64-thread workgroup the
+ * s_barrier degenerates (LLVM drops it for single-wave groups) and what remains is the lgkmcnt wait + the
+ * compiler-level ordering of LDS accesses. */
+__device__ __forceinline__ void wave_barrier() { __syncthreads(); }
+
+/* broadcast lane `src` (wave-uniform index) - v_readlane_b32 */
+__device__ __forceinline__ float bcast(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+template <int SRC>
+__device__ __forceinline__ float readlane(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), SRC));
+}
+
+/* butterfly exchange: DPP within rows of 16 / quad perms, ds_swizzle / permlane for the wider strides */
+__device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, GQ_WAVE); }
+__device__ __forceinline__ int shfl_xor(int v, int m) { return __shfl_xor(v, m, GQ_WAVE); }
+
+__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+/* full-wave reductions, result in every lane.  row_shr / row_bcast DPP ladder + readlane(63). */
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_mov<0x111>(v);  /* row_shr:1 */
+  v += dpp_mov<0x112>(v);  /* row_shr:2 */
+  v += dpp_mov<0x114>(v);  /* row_shr:4 */
+  v += dpp_mov<0x118>(v);  /* row_shr:8  -> lane 15 of each row holds the row sum */
+  /* combine the four row sums held in lanes 15, 31, 47, 63 */
+  float r0 = readlane<15>(v), r1 = readlane<31>(v), r2 = readlane<47>(v), r3 = readlane<63>(v);
+  return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_min(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v = fminf(v, shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+  return v;
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
+}  // namespace gq

@@ -1,0 +1,217 @@
+/*
+ * gq_host_model.cpp - host-side lowering of the MuJoCo-style model tables (GqModelDesc, include/gq.h) into the
+ * fp32 device constant block (GqDevModel).  Pure C++ (no HIP): validates that the model has the topology the
+ * kernels are specialised for and pre-mixes the per-geom contact parameters with the floor (mj_contactParam).
+ */
+#include "gq_host_model.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+void quat2mat(const double* q, double* m) {
+  double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  m[0] = w * w + x * x - y * y - z * z; m[4] = w * w - x * x + y * y - z * z; m[8] = w * w - x * x - y * y + z * z;
+  m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y); m[3] = 2 * (x * y + w * z);
+  m[5] = 2 * (y * z - w * x); m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x);
+}
+
+struct Mixed { int dim, rule; double margin, includemargin, solref[2], solimp[5]; };
+
+/* mj_contactParam between the floor plane and robot geom g (friction itself is mixed at run time because
+ * _set_ground_friction rewrites it per env) */
+Mixed mix_with_floor(const GqModelDesc* d, int g) {
+  Mixed r;
+  int p1 = d->floor_priority, p2 = d->geom_priority[g];
+  if (p1 == p2) {
+    r.rule = 0;
+    r.dim = d->floor_condim > d->geom_condim[g] ? d->floor_condim : d->geom_condim[g];
+    double s1 = d->floor_solmix, s2 = d->geom_solmix[g], mix;
+    if (s1 >= 1e-15 && s2 >= 1e-15) mix = s1 / (s1 + s2);
+    else if (s1 < 1e-15 && s2 < 1e-15) mix = 0.5;
+    else mix = s1 < 1e-15 ? 0.0 : 1.0;
+    const double* r1 = d->floor_solref; const double* r2 = d->geom_solref + 2 * g;
+    for (int k = 0; k < 2; k++)
+      r.solref[k] = (r1[0] > 0 && r2[0] > 0) ? mix * r1[k] + (1 - mix) * r2[k] : (r1[k] < r2[k] ? r1[k] : r2[k]);
+    for (int k = 0; k < 5; k++) r.solimp[k] = mix * d->floor_solimp[k] + (1 - mix) * d->geom_solimp[5 * g + k];
+  } else {
+    bool floor_wins = p1 > p2;
+    r.rule = floor_wins ? 1 : 2;
+    r.dim = floor_wins ? d->floor_condim : d->geom_condim[g];
+    std::memcpy(r.solref, floor_wins ? d->floor_solref : d->geom_solref + 2 * g, sizeof r.solref);
+    std::memcpy(r.solimp, floor_wins ? d->floor_solimp : d->geom_solimp + 5 * g, sizeof r.solimp);
+  }
+  r.margin = d->floor_margin > d->geom_margin[g] ? d->floor_margin : d->geom_margin[g];
+  double gap = d->floor_gap > d->geom_gap[g] ? d->floor_gap : d->geom_gap[g];
+  r.includemargin = r.margin - gap;
+  return r;
+}
+
+}  // namespace
+
+#define FAIL(...) do { std::snprintf(err, errlen, __VA_ARGS__); return -1; } while (0)
+
+int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>* vx, std::vector<float>* vy,
+                       std::vector<float>* vz, char* err, size_t errlen) {
+  GqDevModel& M = *out;
+  std::memset(&M, 0, sizeof M);
+  if (d->nq != 19 || d->nv != 18 || d->nbody != 14 || d->njnt != 13 || d->nu > 12)
+    FAIL("model must be a floating base + 12 hinges (nq=19 nv=18 nbody=14), got nq=%d nv=%d nbody=%d njnt=%d nu=%d",
+         d->nq, d->nv, d->nbody, d->njnt, d->nu);
+  if (d->jnt_type[0] != 0 || d->jnt_bodyid[0] != 1) FAIL("joint 0 must be the free joint of body 1");
+  for (int b = 2; b < 14; b++) {
+    int link = (b - 2) % 3, expect = link == 0 ? 1 : b - 1;
+    if (d->body_parentid[b] != expect) FAIL("body %d: parent %d, expected %d (4 x hip-thigh-calf chains)", b, d->body_parentid[b], expect);
+    if (d->body_jntnum[b] != 1 || d->jnt_type[d->body_jntadr[b]] != 3 || d->body_jntadr[b] != b - 1)
+      FAIL("body %d must carry exactly one hinge joint (joint %d)", b, b - 1);
+  }
+  if (d->cone != 0) FAIL("elliptic friction cones are not supported by the HIP path yet (pyramidal only)");
+  if (d->solver != 0) FAIL("HIP path implements the PGS solver only (solver=0)");
+  if (d->gravity[0] != 0 || d->gravity[1] != 0) FAIL("gravity must be along z");
+  M.timestep = (float)d->timestep; M.gravity_z = (float)d->gravity[2]; M.impratio = (float)d->impratio;
+  M.meaninertia = (float)d->meaninertia; M.tolerance = (float)d->tolerance; M.iterations = d->iterations; M.cone = d->cone;
+  for (int b = 0; b < GQ_NB; b++) {
+    int s = b + 1;
+    for (int k = 0; k < 3; k++) { M.body_pos[b][k] = (float)d->body_pos[3 * s + k]; M.body_ipos[b][k] = (float)d->body_ipos[3 * s + k]; }
+    for (int k = 0; k < 4; k++) M.body_quat[b][k] = (float)d->body_quat[4 * s + k];
+    M.body_mass[b] = (float)d->body_mass[s];
+    double R[9], I[9];
+    quat2mat(d->body_iquat + 4 * s, R);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double v = 0;
+        for (int k = 0; k < 3; k++) v += R[3 * i + k] * d->body_inertia[3 * s + k] * R[3 * j + k];
+        I[3 * i + j] = v;
+      }
+    M.body_I[b][0] = (float)I[0]; M.body_I[b][1] = (float)I[4]; M.body_I[b][2] = (float)I[8];
+    M.body_I[b][3] = (float)I[1]; M.body_I[b][4] = (float)I[2]; M.body_I[b][5] = (float)I[5];
+    M.body_invweight0[b][0] = (float)d->body_invweight0[2 * s]; M.body_invweight0[b][1] = (float)d->body_invweight0[2 * s + 1];
+  }
+  for (int j = 0; j < GQ_NJ; j++) {
+    int s = j + 1;
+    if (d->jnt_qposadr[s] != 7 + j || d->jnt_dofadr[s] != 6 + j) FAIL("joint %d has unexpected qpos/dof address", s);
+    for (int k = 0; k < 3; k++) { M.jnt_pos[j][k] = (float)d->jnt_pos[3 * s + k]; M.jnt_axis[j][k] = (float)d->jnt_axis[3 * s + k]; }
+    M.qpos0[j] = (float)d->qpos0[7 + j];
+    M.jnt_limited[j] = d->jnt_limited[s];
+    M.jnt_range[j][0] = (float)d->jnt_range[2 * s]; M.jnt_range[j][1] = (float)d->jnt_range[2 * s + 1];
+    M.jnt_margin[j] = (float)d->jnt_margin[s];
+    for (int k = 0; k < 2; k++) M.jnt_solref[j][k] = (float)d->jnt_solref[2 * s + k];
+    for (int k = 0; k < 5; k++) M.jnt_solimp[j][k] = (float)d->jnt_solimp[5 * s + k];
+    M.jnt_actfrclimited[j] = d->jnt_actfrclimited[s];
+    M.jnt_actfrcrange[j][0] = (float)d->jnt_actfrcrange[2 * s]; M.jnt_actfrcrange[j][1] = (float)d->jnt_actfrcrange[2 * s + 1];
+    M.act_of_jnt[j] = -1;
+  }
+  M.nfl = 0;
+  for (int i = 0; i < GQ_NVD; i++) {
+    M.dof_damping[i] = (float)d->dof_damping[i]; M.dof_armature[i] = (float)d->dof_armature[i];
+    M.dof_frictionloss[i] = (float)d->dof_frictionloss[i]; M.dof_invweight0[i] = (float)d->dof_invweight0[i];
+    for (int k = 0; k < 2; k++) M.dof_solref[i][k] = (float)d->dof_solref[2 * i + k];
+    for (int k = 0; k < 5; k++) M.dof_solimp[i][k] = (float)d->dof_solimp[5 * i + k];
+    if (d->dof_frictionloss[i] > 0) M.fl_dof[M.nfl++] = i;
+  }
+  for (int u = 0; u < d->nu; u++) {
+    int j = d->actuator_trnid[u] - 1;
+    if (j < 0 || j >= GQ_NJ) FAIL("actuator %d drives joint %d (must be a leg hinge)", u, d->actuator_trnid[u]);
+    if (M.act_of_jnt[j] >= 0) FAIL("joint %d has more than one actuator", j + 1);
+    M.act_of_jnt[j] = u; M.act_gear[j] = (float)d->actuator_gear[u];
+    M.act_ctrllimited[j] = d->actuator_ctrllimited[u]; M.act_forcelimited[j] = d->actuator_forcelimited[u];
+    for (int k = 0; k < 2; k++) { M.act_ctrlrange[j][k] = (float)d->actuator_ctrlrange[2 * u + k]; M.act_forcerange[j][k] = (float)d->actuator_forcerange[2 * u + k]; }
+  }
+  for (int k = 0; k < 3; k++) M.floor_friction[k] = (float)d->floor_friction[k];
+  for (int k = 0; k < 4; k++) M.terrain_limits[k] = d->terrain_limits[k];
+  for (int k = 0; k < 19; k++) M.key_qpos[k] = (float)d->key_qpos[k];
+  /* feet */
+  bool is_foot[1024] = {false};
+  for (int k = 0; k < 4; k++) {
+    int g = d->feet_geomid[k];
+    if (g < 0 || g >= d->ngeom || g >= 1024) FAIL("bad foot geom id %d", g);
+    int cl = d->geom_cloudid[g], b = d->geom_bodyid[g];
+    if (cl < 0 || d->cloud_vertnum[cl] != 1) FAIL("foot geom %d must be a sphere", g);
+    if (b < 2 || (b - 2) % 3 != 2) FAIL("foot geom %d must be attached to a calf body (got body %d)", g, b);
+    is_foot[g] = true;
+    M.foot_leg[k] = (b - 2) / 3;
+    const double* v = d->vert_pos + 3 * d->cloud_vertadr[cl];
+    double R[9]; quat2mat(d->geom_quat + 4 * g, R);
+    for (int i = 0; i < 3; i++) M.foot_pos[k][i] = (float)(d->geom_pos[3 * g + i] + R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2]);
+    M.foot_radius[k] = (float)d->cloud_radius[cl];
+    Mixed mx = mix_with_floor(d, g);
+    if (mx.dim != 1 && mx.dim != 3) FAIL("foot contact dimension %d not supported (1 or 3)", mx.dim);
+    M.foot_dim[k] = mx.dim; M.foot_fric_rule[k] = mx.rule; M.foot_margin[k] = (float)mx.margin; M.foot_includemargin[k] = (float)mx.includemargin;
+    for (int i = 0; i < 3; i++) M.foot_friction[k][i] = (float)d->geom_friction[3 * g + i];
+    for (int i = 0; i < 2; i++) M.foot_solref[k][i] = (float)mx.solref[i];
+    for (int i = 0; i < 5; i++) M.foot_solimp[k][i] = (float)mx.solimp[i];
+  }
+  /* link geoms + shared vertex clouds (SoA) */
+  vx->clear(); vy->clear(); vz->clear();
+  for (int i = 0; i < d->nvert; i++) { vx->push_back((float)d->vert_pos[3 * i]); vy->push_back((float)d->vert_pos[3 * i + 1]); vz->push_back((float)d->vert_pos[3 * i + 2]); }
+  if (vx->empty()) { vx->push_back(0); vy->push_back(0); vz->push_back(0); }
+  M.nlg = 0;
+  int nitem = 0;
+  for (int g = 0; g < d->ngeom; g++) {
+    int cl = d->geom_cloudid[g], b = d->geom_bodyid[g];
+    if (g < 1024 && is_foot[g]) {
+      for (int k = 0; k < 4; k++)
+        if (d->feet_geomid[k] == g) M.con_order[nitem++] = k;
+      continue;
+    }
+    if (cl < 0 || b == 0) continue;
+    if (M.nlg < GQ_MAXLG) M.con_order[nitem++] = 4 + M.nlg;
+    if (M.nlg >= GQ_MAXLG) FAIL("more than %d link collision geoms", GQ_MAXLG);
+    GqDevGeom& G = M.lg[M.nlg++];
+    G.body = b - 1; G.cloud_adr = d->cloud_vertadr[cl]; G.cloud_num = d->cloud_vertnum[cl]; G.radius = (float)d->cloud_radius[cl];
+    double R[9]; quat2mat(d->geom_quat + 4 * g, R);
+    for (int i = 0; i < 3; i++) G.pos[i] = (float)d->geom_pos[3 * g + i];
+    for (int i = 0; i < 9; i++) G.mat[i] = (float)R[i];
+    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+    for (int v = 0; v < G.cloud_num; v++)
+      for (int i = 0; i < 3; i++) {
+        double c = d->vert_pos[3 * (G.cloud_adr + v) + i];
+        if (c < lo[i]) lo[i] = c;
+        if (c > hi[i]) hi[i] = c;
+      }
+    for (int i = 0; i < 3; i++) { G.aabb_c[i] = (float)(0.5 * (lo[i] + hi[i])); G.aabb_h[i] = (float)(0.5 * (hi[i] - lo[i]) * 1.0001 + 1e-7); }
+    Mixed mx = mix_with_floor(d, g);
+    if (mx.dim != 1 && mx.dim != 3) FAIL("contact dimension %d of geom %d not supported (1 or 3)", mx.dim, g);
+    G.dim = mx.dim; G.fric_rule = mx.rule; G.margin = (float)mx.margin; G.includemargin = (float)mx.includemargin;
+    for (int i = 0; i < 3; i++) G.friction[i] = (float)d->geom_friction[3 * g + i];
+    for (int i = 0; i < 2; i++) G.solref[i] = (float)mx.solref[i];
+    for (int i = 0; i < 5; i++) G.solimp[i] = (float)mx.solimp[i];
+  }
+  return 0;
+}
+
+static const int kObsDims[GQ_OBS_COUNT] = {3, 3, 3, 3, 3, 3, 3, 4, 9, 3, 3, 3, 3, 3, 3, 19, 18, 12, 12, 12, 1, 1,
+                                           12, 12, 12, 12, 12, 12, 4, 12, 12};
+
+int gq_obs_dim_host(int id) { return (id < 0 || id >= GQ_OBS_COUNT) ? -1 : kObsDims[id]; }
+
+int gq_build_dev_batch(int n_envs, const int32_t* obs_ids, int n_obs, const int32_t* legs_order, GqDevBatch* out,
+                       char* err, size_t errlen) {
+  std::memset(out, 0, sizeof *out);
+  out->n_envs = n_envs;
+  int offs[GQ_OBS_COUNT], o = 0;
+  for (int i = 0; i < GQ_OBS_COUNT; i++) { offs[i] = o; o += kObsDims[i]; }
+  int k = 0;
+  for (int n = 0; n < n_obs; n++) {
+    int id = obs_ids[n];
+    if (id < 0 || id >= GQ_OBS_COUNT) FAIL("bad observation id %d", id);
+    if (k + kObsDims[id] > 256) FAIL("observation row wider than 256 scalars");
+    /* leg-ordered observables honour legs_order (to_list(order=self.legs_order), quadruped_env.py:1184-1198);
+     * contact_state does not (quirk B5, :1194-1195) */
+    bool per_leg = id >= GQ_OBS_FEET_POS && id <= GQ_OBS_CONTACT_FORCES_B && id != GQ_OBS_CONTACT_STATE;
+    for (int c = 0; c < kObsDims[id]; c++) {
+      int src = c;
+      if (per_leg) {
+        int leg = legs_order ? legs_order[c / 3] : c / 3;
+        if (leg < 0 || leg > 3) FAIL("bad legs_order entry %d", leg);
+        src = 3 * leg + c % 3;
+      }
+      out->obs_map[k++] = offs[id] + src;
+    }
+  }
+  out->obs_dim = k;
+  return 0;
+}

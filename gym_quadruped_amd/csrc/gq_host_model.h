@@ -1,0 +1,13 @@
+/* gq_host_model.h - GqModelDesc -> GqDevModel / GqDevBatch lowering (host, no HIP). */
+#pragma once
+#include <cstddef>
+#include <vector>
+
+#include "gq.h"
+#include "gq_model_dev.h"
+
+int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>* vx, std::vector<float>* vy,
+                       std::vector<float>* vz, char* err, size_t errlen);
+int gq_build_dev_batch(int n_envs, const int32_t* obs_ids, int n_obs, const int32_t* legs_order, GqDevBatch* out,
+                       char* err, size_t errlen);
+int gq_obs_dim_host(int id);

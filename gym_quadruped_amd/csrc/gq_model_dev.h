@@ -1,0 +1,99 @@
+/*
+ * gq_model_dev.h - fp32 model constants as laid out in device memory (one struct, read through the scalar /
+ * L1 path by every wavefront) and the launch parameter block.  Built on the host by gq_api.cpp from the
+ * GqModelDesc tables (include/gq.h).  The kernels are specialised for the topology every registry robot
+ * shares: floating base + 4 legs x (hip, thigh, calf) hinge chains,
+ * nq = 19, nv = 18, nu = 12, 13 moving bodies.
+ */
+#pragma once
+#include <stdint.h>
+
+#define GQ_NB 13        /* moving bodies: 0 = base, 1 + 3*leg + link */
+#define GQ_NVD 18       /* dofs: 0..5 base, 6 + 3*leg + link */
+#define GQ_NJ 12        /* hinge joints */
+#define GQ_MAXLG 28     /* max link (non-foot) collision geoms */
+#define GQ_MAXCON 12    /* max simultaneous contacts fed to the solver */
+#define GQ_MAXEFC 63    /* constraint rows: one per lane, lane 63 carries the smooth-force solve */
+#define GQ_NOBS_ALL 227 /* scalars in QuadrupedEnv.ALL_OBS */
+
+struct GqDevGeom {          /* a robot collision geom that is not a foot sphere */
+  int32_t body;             /* 0..12 */
+  int32_t cloud_adr, cloud_num;
+  float radius;             /* inflation (capsule) */
+  float pos[3];             /* geom frame in body frame */
+  float mat[9];
+  float aabb_c[3], aabb_h[3]; /* AABB of the cloud in the geom frame */
+  /* contact parameters pre-mixed with the floor (mj_contactParam) */
+  int32_t dim;              /* 1 or 3 */
+  int32_t fric_rule;        /* 0: element-wise max with floor, 1: floor wins, 2: geom wins */
+  float friction[3];        /* geom's own */
+  float margin;             /* detection margin = max(floor, geom) */
+  float includemargin;      /* margin - gap */
+  float solref[2], solimp[5];
+};
+
+struct GqDevModel {
+  float timestep, gravity_z, impratio, meaninertia, tolerance;
+  int32_t iterations, cone, nlg, nfl;
+  /* bodies */
+  float body_pos[GQ_NB][3], body_quat[GQ_NB][4], body_ipos[GQ_NB][3], body_mass[GQ_NB];
+  float body_I[GQ_NB][6];        /* inertia tensor in the BODY frame: xx yy zz xy xz yz */
+  float body_invweight0[GQ_NB][2];
+  /* hinges */
+  float jnt_pos[GQ_NJ][3], jnt_axis[GQ_NJ][3], qpos0[GQ_NJ];
+  int32_t jnt_limited[GQ_NJ];
+  float jnt_range[GQ_NJ][2], jnt_margin[GQ_NJ], jnt_solref[GQ_NJ][2], jnt_solimp[GQ_NJ][5];
+  int32_t jnt_actfrclimited[GQ_NJ];
+  float jnt_actfrcrange[GQ_NJ][2];
+  /* dofs */
+  float dof_damping[GQ_NVD], dof_armature[GQ_NVD], dof_frictionloss[GQ_NVD], dof_invweight0[GQ_NVD];
+  float dof_solref[GQ_NVD][2], dof_solimp[GQ_NVD][5];
+  int32_t fl_dof[GQ_NVD];        /* dofs that own a friction-loss row, compacted; nfl of them */
+  /* motors, one per hinge dof slot (index = hinge 0..11), 0 gear if the joint is unactuated */
+  int32_t act_of_jnt[GQ_NJ];     /* ctrl index driving hinge j, -1 none */
+  float act_gear[GQ_NJ];
+  int32_t act_ctrllimited[GQ_NJ], act_forcelimited[GQ_NJ];
+  float act_ctrlrange[GQ_NJ][2], act_forcerange[GQ_NJ][2];
+  /* feet (FL FR RL RR): sphere on the calf of leg foot_leg[k] */
+  int32_t foot_leg[4];           /* kinematic leg index (body order) of foot k */
+  float foot_pos[4][3], foot_radius[4];
+  int32_t foot_dim[4], foot_fric_rule[4];
+  float foot_friction[4][3], foot_margin[4], foot_includemargin[4], foot_solref[4][2], foot_solimp[4][5];
+  /* floor */
+  float floor_friction[3];
+  /* link geoms */
+  GqDevGeom lg[GQ_MAXLG];
+  int32_t con_order[4 + GQ_MAXLG]; /* collision items by increasing geom id: k<4 foot k, else 4 + link geom */
+  /* env */
+  double terrain_limits[4];
+  float key_qpos[19];            /* keyframe 0 */
+};
+
+struct GqDevBatch {            /* per-batch constants */
+  int32_t n_envs, obs_dim;
+  int32_t obs_map[256];        /* output column -> canonical ALL_OBS scalar index */
+  int32_t debug_envs;          /* number of leading envs whose internals are dumped */
+};
+
+/* debug dump record (floats) per env, see gq_debug_get */
+#define GQ_DBG_M 0
+#define GQ_DBG_BIAS (GQ_DBG_M + 324)
+#define GQ_DBG_SMOOTH (GQ_DBG_BIAS + 18)
+#define GQ_DBG_QACC_SMOOTH (GQ_DBG_SMOOTH + 18)
+#define GQ_DBG_QFRC_C (GQ_DBG_QACC_SMOOTH + 18)
+#define GQ_DBG_XPOS (GQ_DBG_QFRC_C + 18)
+#define GQ_DBG_XMAT (GQ_DBG_XPOS + 39)
+#define GQ_DBG_NEFC (GQ_DBG_XMAT + 117)
+#define GQ_DBG_NCON (GQ_DBG_NEFC + 1)
+#define GQ_DBG_NITER (GQ_DBG_NCON + 1)
+#define GQ_DBG_EFC_J (GQ_DBG_NITER + 1)
+#define GQ_DBG_EFC_AREF (GQ_DBG_EFC_J + 64 * 18)
+#define GQ_DBG_EFC_R (GQ_DBG_EFC_AREF + 64)
+#define GQ_DBG_EFC_B (GQ_DBG_EFC_R + 64)
+#define GQ_DBG_EFC_FORCE (GQ_DBG_EFC_B + 64)
+#define GQ_DBG_EFC_TYPE (GQ_DBG_EFC_FORCE + 64)
+#define GQ_DBG_CON_DIST (GQ_DBG_EFC_TYPE + 64)
+#define GQ_DBG_CON_GEOM (GQ_DBG_CON_DIST + GQ_MAXCON)
+#define GQ_DBG_FOOT_POS (GQ_DBG_CON_GEOM + GQ_MAXCON)
+#define GQ_DBG_QACC (GQ_DBG_FOOT_POS + 12)
+#define GQ_DBG_SIZE (GQ_DBG_QACC + 18)

@@ -1,0 +1,824 @@
+/*
+ * gq_step_body.h - body of the fused step kernel (see gq_step_kernel.h for the stage map and the reference
+ * lines each stage replaces).  Everything runs in one wavefront; `wave_barrier()` separates producer and
+ * consumer lanes of an LDS hand-off.
+ */
+#pragma once
+#include "gq_step_kernel.h"
+
+namespace gq {
+
+/* S1 (mj_kinematics): lanes 0-3 walk the leg chains; returns the normalised base quaternion (all lanes) */
+__device__ inline Q4 stage_kinematics(WaveMem& W, const GqDevModel& m) {
+  const int lane = lane_id();
+  Q4 qbase = {W.qb[0], W.qb[1], W.qb[2], W.qb[3]};
+  qbase = qnormalize(qbase);
+  if (lane == 0) {
+    W.xpos[0][0] = 0.0f; W.xpos[0][1] = 0.0f; W.xpos[0][2] = W.basez;
+    q2mat(W.xmat[0], qbase);
+  }
+  if (lane < 4) {
+    float Rp[9];
+    q2mat(Rp, qbase);
+    V3 pp = v3(0.0f, 0.0f, W.basez);
+    Q4 pq = qbase;
+    for (int i = 0; i < 3; i++) {
+      const int b = 1 + 3 * lane + i, j = 3 * lane + i;
+      Q4 bq = {m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2], m.body_quat[b][3]};
+      V3 pos = pp + matvec(Rp, ld3(m.body_pos[b]));
+      Q4 q = qmul(pq, bq);
+      float R0[9];
+      q2mat(R0, q);
+      V3 jp = ld3(m.jnt_pos[j]), ax = ld3(m.jnt_axis[j]);
+      V3 anchor = pos + matvec(R0, jp);
+      st3(W.anchor[j], anchor);
+      st3(W.axis[j], matvec(R0, ax));
+      float ang = W.qj[j] - m.qpos0[j];
+      float s = sinf(0.5f * ang), c = cosf(0.5f * ang);
+      Q4 ql = {c, ax.x * s, ax.y * s, ax.z * s};
+      q = qnormalize(qmul(q, ql));
+      q2mat(Rp, q);
+      pos = anchor - matvec(Rp, jp);
+      st3(W.xpos[b], pos);
+#pragma unroll
+      for (int k = 0; k < 9; k++) W.xmat[b][k] = Rp[k];
+      pp = pos; pq = q;
+    }
+  }
+  wave_barrier();
+
+  return qbase;
+}
+
+/* S6 (mj_collision, floor plane z = 0): foot sphere centres and, per link geom, the deepest cloud vertex.
+ * calf_only restricts the scan to geoms of the calf bodies (reset lift loop, quadruped_env.py:376-388). */
+__device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, const float* vx, const float* vy, const float* vz,
+                                            bool calf_only) {
+  const int lane = lane_id();
+  if (lane < 4) { /* feet: exact plane-sphere */
+    const int leg = m.foot_leg[lane], b = 3 + 3 * leg;
+    V3 c = ld3(W.xpos[b]) + matvec(W.xmat[b], ld3(m.foot_pos[lane]));
+    st3(W.foot_world[lane], c);
+  }
+  /* link geoms: wave-wide scan of the vertex cloud, OBB lower bound first */
+  const int nlg = m.nlg;
+  for (int g = 0; g < nlg; g++) {
+    const GqDevGeom& G = m.lg[g];
+    if (calf_only && !(G.body > 0 && (G.body - 1) % 3 == 2)) { if (lane == 0) W.lg_dist[g] = 1e30f; continue; }
+    const float* Rb = W.xmat[G.body];
+    /* plane normal in the geom frame: n_g = Rg' Rb' n, n = (0,0,1) */
+    V3 nb = v3(Rb[6], Rb[7], Rb[8]);
+    V3 ng = matTvec(G.mat, nb);
+    float d0 = W.xpos[G.body][2] + dot(nb, ld3(G.pos));
+    float lower = d0 + dot(ng, ld3(G.aabb_c)) - (fabsf(ng.x) * G.aabb_h[0] + fabsf(ng.y) * G.aabb_h[1] + fabsf(ng.z) * G.aabb_h[2]) - G.radius;
+    float best = 1e30f;
+    int bi = 0;
+    if (lower < G.margin) { /* wave-uniform */
+      for (int v = lane; v < G.cloud_num; v += GQ_WAVE) {
+        int idx = G.cloud_adr + v;
+        float dv = ng.x * vx[idx] + ng.y * vy[idx] + ng.z * vz[idx];
+        if (dv < best) { best = dv; bi = idx; }
+      }
+      float wmin = wave_min(best);
+      uint64_t who = ballot(best == wmin);
+      int src = 0;
+      while (!((who >> src) & 1)) src++;
+      bi = bcast(bi, src);
+      best = wmin + d0 - G.radius;
+      if (lane == 0) {
+        W.lg_dist[g] = best;
+        V3 vl = v3(vx[bi], vy[bi], vz[bi]);
+        V3 vb = ld3(G.pos) + matvec(G.mat, vl);
+        st3(W.lg_pt[g], ld3(W.xpos[G.body]) + matvec(Rb, vb));
+      }
+    } else if (lane == 0) W.lg_dist[g] = 1e30f;
+  }
+  wave_barrier();
+}
+
+__device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]) {
+  const int lane = lane_id();
+  const int env = (int)blockIdx.x;
+  const GqDevModel& m = *a.model;
+  const float h = m.timestep;
+
+  /* ================================================================ S0: load the env's state rows */
+  /* base x,y stay in f64 (uniform: every lane reads the same two words) and never enter fp32 arithmetic */
+  const double bx_d = a.qpos[(size_t)env * 19 + 0], by_d = a.qpos[(size_t)env * 19 + 1];
+  if (lane < 19) {
+    double q = a.qpos[(size_t)env * 19 + lane];
+    if (lane < 2) { }
+    else if (lane == 2) W.basez = (float)q;
+    else if (lane < 7) W.qb[lane - 3] = (float)q;
+    else W.qj[lane - 7] = (float)q;
+  }
+  if (lane < 18) {
+    W.qvel[lane] = a.qvel[(size_t)env * 18 + lane];
+    W.warm[lane] = a.warm[(size_t)env * 18 + lane];
+    W.applied[lane] = a.applied ? a.applied[(size_t)env * 18 + lane] : 0.0f;
+  }
+  if (lane < 12) W.ctrl[lane] = a.ctrl ? a.ctrl[(size_t)env * 12 + lane] : 0.0f;
+  if (lane < 4) W.cmd[lane] = a.cmd ? a.cmd[(size_t)env * 4 + lane] : 0.0f;
+  const float mu_env = a.friction ? a.friction[env] : -1.0f;
+  wave_barrier();
+
+  const Q4 qbase = stage_kinematics(W, m);
+
+  /* ================================================================ S2: spatial inertias about O = base origin */
+  const V3 O = v3(0.0f, 0.0f, W.basez);
+  if (lane < GQ_NB) {
+    const int b = lane;
+    const float* R = W.xmat[b];
+    V3 d = ld3(W.xpos[b]) + matvec(R, ld3(m.body_ipos[b])) - O;
+    /* I_w = R Ib R' */
+    const float* Ib = m.body_I[b];
+    float A[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]}, T[9], Iw[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) T[3 * r + c] = R[3 * r] * A[c] + R[3 * r + 1] * A[3 + c] + R[3 * r + 2] * A[6 + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Iw[3 * r + c] = T[3 * r] * R[3 * c] + T[3 * r + 1] * R[3 * c + 1] + T[3 * r + 2] * R[3 * c + 2];
+    float mb = m.body_mass[b], dd = dot(d, d);
+    float* ci = W.cinert[b];
+    ci[0] = Iw[0] + mb * (dd - d.x * d.x); ci[1] = Iw[4] + mb * (dd - d.y * d.y); ci[2] = Iw[8] + mb * (dd - d.z * d.z);
+    ci[3] = Iw[1] - mb * d.x * d.y; ci[4] = Iw[2] - mb * d.x * d.z; ci[5] = Iw[5] - mb * d.y * d.z;
+    ci[6] = mb * d.x; ci[7] = mb * d.y; ci[8] = mb * d.z; ci[9] = mb;
+  }
+  /* motion subspaces */
+  if (lane < GQ_NVD) {
+    float* s = W.cdof[lane];
+    if (lane < 3) { s[0] = s[1] = s[2] = 0.0f; s[3] = lane == 0; s[4] = lane == 1; s[5] = lane == 2; }
+    else if (lane < 6) { /* body-fixed rotation axes through O: linear part vanishes */
+      const float* R = W.xmat[0];
+      s[0] = R[lane - 3]; s[1] = R[3 + lane - 3]; s[2] = R[6 + lane - 3]; s[3] = s[4] = s[5] = 0.0f;
+    }
+  }
+  wave_barrier();
+  if (lane >= 6 && lane < GQ_NVD) {
+    const int j = lane - 6;
+    V3 ax = ld3(W.axis[j]);
+    st3(W.cdof[lane], ax);
+    st3(W.cdof[lane] + 3, cross(ax, O - ld3(W.anchor[j])));
+  }
+  /* composite inertias: everything is about the same point in the same axes, so they are plain sums */
+  if (lane < 40) {
+    const int leg = lane / 10, k = lane % 10, b0 = 1 + 3 * leg;
+    float c2 = W.cinert[b0 + 2][k], c1 = W.cinert[b0 + 1][k] + c2, c0 = W.cinert[b0][k] + c1;
+    W.crb[b0 + 2][k] = c2; W.crb[b0 + 1][k] = c1; W.crb[b0][k] = c0;
+  }
+  wave_barrier();
+  if (lane < 10) W.crb[0][lane] = W.cinert[0][lane] + W.crb[1][lane] + W.crb[4][lane] + W.crb[7][lane] + W.crb[10][lane];
+  wave_barrier();
+
+  /* ================================================================ S3: joint-space inertia */
+  if (lane < GQ_NVD) {
+    float buf[6];
+    mul_inert(buf, W.crb[dof_body(lane)], W.cdof[lane]);
+    for (int j = lane; j >= 0; j = dof_parent(j)) {
+      const float* s = W.cdof[j];
+      float v = s[0] * buf[0] + s[1] * buf[1] + s[2] * buf[2] + s[3] * buf[3] + s[4] * buf[4] + s[5] * buf[5];
+      if (j == lane) v += m.dof_armature[lane];
+      W.M[lane][j] = v; W.M[j][lane] = v;
+    }
+    /* entries between different legs are structurally zero */
+    for (int j = 6; j < GQ_NVD; j++)
+      if (lane >= 6 && (j - 6) / 3 != (lane - 6) / 3) W.M[lane][j] = 0.0f;
+  }
+  wave_barrier();
+
+  /* ================================================================ S4: factorise M and M + h*D */
+  {
+    float zero18[GQ_NVD], hd[GQ_NVD];
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) { zero18[k] = 0.0f; hd[k] = h * m.dof_damping[k]; }
+    factor_tree(W, 0, zero18, acc);
+    factor_tree(W, 1, hd, acc);
+  }
+
+  /* ================================================================ S5: velocity stage (mj_comVel, mj_rne) */
+  if (lane < 4) {
+    /* base velocity and bias acceleration, recomputed per leg lane */
+    float vb[6], ab[6];
+    {
+      const float* R = W.xmat[0];
+      V3 wl = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
+      V3 ww = matvec(R, wl), vl = v3(W.qvel[0], W.qvel[1], W.qvel[2]);
+      st3(vb, ww); st3(vb + 3, vl);
+      V3 al = cross(vl, ww);
+      ab[0] = ab[1] = ab[2] = 0.0f; ab[3] = al.x; ab[4] = al.y; ab[5] = al.z - m.gravity_z;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) { W.cvel[0][k] = vb[k]; W.cacc[0][k] = ab[k]; }
+      }
+    }
+    for (int i = 0; i < 3; i++) {
+      const int b = 1 + 3 * lane + i, d = 6 + 3 * lane + i;
+      float cd[6];
+      cross_motion(cd, vb, W.cdof[d]);
+      float qd = W.qvel[d];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { vb[k] += W.cdof[d][k] * qd; ab[k] += cd[k] * qd; W.cvel[b][k] = vb[k]; W.cacc[b][k] = ab[k]; }
+    }
+  }
+  wave_barrier();
+  if (lane < GQ_NB) {
+    float t1[6], t2[6], f[6];
+    mul_inert(t1, W.cinert[lane], W.cacc[lane]);
+    mul_inert(t2, W.cinert[lane], W.cvel[lane]);
+    cross_force(f, W.cvel[lane], t2);
+#pragma unroll
+    for (int k = 0; k < 6; k++) W.cfrc[lane][k] = f[k] + t1[k];
+  }
+  wave_barrier();
+  if (lane < 24) { /* accumulate up the legs */
+    const int leg = lane / 6, k = lane % 6, b0 = 1 + 3 * leg;
+    float f2 = W.cfrc[b0 + 2][k], f1 = W.cfrc[b0 + 1][k] + f2, f0 = W.cfrc[b0][k] + f1;
+    W.cfrc[b0 + 1][k] = f1; W.cfrc[b0][k] = f0;
+  }
+  wave_barrier();
+  if (lane < 6) W.cfrc[0][lane] += W.cfrc[1][lane] + W.cfrc[4][lane] + W.cfrc[7][lane] + W.cfrc[10][lane];
+  wave_barrier();
+  if (lane < GQ_NVD) {
+    const float* s = W.cdof[lane];
+    const float* f = W.cfrc[dof_body(lane)];
+    float bias = s[0] * f[0] + s[1] * f[1] + s[2] * f[2] + s[3] * f[3] + s[4] * f[4] + s[5] * f[5];
+    W.bias[lane] = bias;
+    /* actuation (mj_fwdActuation): torque motors */
+    float act = 0.0f;
+    if (lane >= 6) {
+      const int j = lane - 6, u = m.act_of_jnt[j];
+      if (u >= 0) {
+        float c = W.ctrl[u];
+        if (m.act_ctrllimited[j]) c = fminf(fmaxf(c, m.act_ctrlrange[j][0]), m.act_ctrlrange[j][1]);
+        if (m.act_forcelimited[j]) c = fminf(fmaxf(c, m.act_forcerange[j][0]), m.act_forcerange[j][1]);
+        act = m.act_gear[j] * c;
+      }
+      if (m.jnt_actfrclimited[j]) act = fminf(fmaxf(act, m.jnt_actfrcrange[j][0]), m.jnt_actfrcrange[j][1]);
+    }
+    W.act[lane] = act;
+    W.smooth[lane] = -m.dof_damping[lane] * W.qvel[lane] - bias + act + W.applied[lane];
+  }
+
+  /* ================================================================ S6: collision with the floor (z = 0) */
+  const int nlg = m.nlg;
+  stage_collision_scan(W, m, a.vx, a.vy, a.vz, false);
+  /* contact list in MuJoCo's order (increasing geom id; con_order interleaves feet and link geoms), capped */
+  if (lane == 0) {
+    int nc = 0, invalid = 0;
+    for (int k = 0; k < 4; k++) W.foot_touch[k] = 0;
+    for (int k = 0; k < 4; k++) W.foot_con[k] = -1;
+    for (int it = 0; it < 4 + nlg; it++) {
+      const int code = m.con_order[it];
+      if (code < 4) {
+      const int k = code;
+      float dist = W.foot_world[k][2] - m.foot_radius[k];
+      if (dist < m.foot_margin[k]) W.foot_touch[k] = 1;
+      if (dist < m.foot_margin[k] && nc < GQ_MAXCON) {
+        W.foot_con[k] = nc;
+        W.con_geom[nc] = k; W.con_body[nc] = 3 + 3 * m.foot_leg[k]; W.con_dim[nc] = m.foot_dim[k];
+        W.con_dist[nc] = dist; W.con_inc[nc] = m.foot_includemargin[k];
+        W.con_pos[nc][0] = W.foot_world[k][0]; W.con_pos[nc][1] = W.foot_world[k][1];
+        W.con_pos[nc][2] = W.foot_world[k][2] - (m.foot_radius[k] + 0.5f * dist);
+        /* friction mixing; _set_ground_friction overrides floor and feet with [mu, 0.005, 0] (quadruped_env.py:1292) */
+        float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0], fg = mu_env >= 0.0f ? mu_env : m.foot_friction[k][0];
+        int rule = m.foot_fric_rule[k];
+        W.con_mu[nc] = rule == 0 ? fmaxf(ff, fg) : (rule == 1 ? ff : fg);
+        W.con_solref[nc][0] = m.foot_solref[k][0]; W.con_solref[nc][1] = m.foot_solref[k][1];
+        for (int q = 0; q < 5; q++) W.con_solimp[nc][q] = m.foot_solimp[k][q];
+        nc++;
+      }
+      } else {
+      const int g = code - 4;
+      const GqDevGeom& G = m.lg[g];
+      float dist = W.lg_dist[g];
+      if (dist < G.margin) { /* _check_for_invalid_contacts (quadruped_env.py:1228-1248): body-level test */
+        const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
+        if (!calf) invalid = 1;
+        else for (int k = 0; k < 4; k++) if (3 + 3 * m.foot_leg[k] == G.body) W.foot_touch[k] = 1;
+      }
+      if (dist < G.margin && nc < GQ_MAXCON) {
+        W.con_geom[nc] = 4 + g; W.con_body[nc] = G.body; W.con_dim[nc] = G.dim;
+        W.con_dist[nc] = dist; W.con_inc[nc] = G.includemargin;
+        W.con_pos[nc][0] = W.lg_pt[g][0]; W.con_pos[nc][1] = W.lg_pt[g][1];
+        W.con_pos[nc][2] = W.lg_pt[g][2] - (G.radius + 0.5f * dist);
+        float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0], fg = G.friction[0];
+        W.con_mu[nc] = G.fric_rule == 0 ? fmaxf(ff, fg) : (G.fric_rule == 1 ? ff : fg);
+        W.con_solref[nc][0] = G.solref[0]; W.con_solref[nc][1] = G.solref[1];
+        for (int q = 0; q < 5; q++) W.con_solimp[nc][q] = G.solimp[q];
+        nc++;
+      }
+      }
+    }
+    /* joint limits */
+    int nl = 0;
+    for (int j = 0; j < GQ_NJ; j++)
+      if (m.jnt_limited[j]) {
+        float q = W.qj[j];
+        float dlo = q - m.jnt_range[j][0], dhi = m.jnt_range[j][1] - q;
+        if (dlo < m.jnt_margin[j]) { W.lim_jnt[nl] = j; W.lim_side[nl] = 1.0f; W.lim_dist[nl] = dlo; nl++; }
+        if (dhi < m.jnt_margin[j] && nl < GQ_NJ) { W.lim_jnt[nl] = j; W.lim_side[nl] = -1.0f; W.lim_dist[nl] = dhi; nl++; }
+      }
+    /* row budget: friction rows, limit rows, then whole contacts while they fit */
+    int rows = m.nfl + nl, ncfit = 0;
+    for (int c = 0; c < nc; c++) {
+      int need = W.con_dim[c] == 1 ? 1 : 2 * (W.con_dim[c] - 1);
+      if (rows + need > GQ_MAXEFC) break;
+      W.con_row[c] = rows; rows += need; ncfit++;
+    }
+    for (int k = 0; k < 4; k++)
+      if (W.foot_con[k] >= ncfit) W.foot_con[k] = -1;
+    W.ncon = ncfit; W.nlim = nl; W.nefc = rows; W.invalid = invalid;
+  }
+  wave_barrier();
+  const int nefc = W.nefc, ncon = W.ncon, nlim = W.nlim, nfl = m.nfl;
+
+  /* ================================================================ S7: constraint rows, lane = row */
+  float J[GQ_NVD];
+#pragma unroll
+  for (int k = 0; k < GQ_NVD; k++) J[k] = 0.0f;
+  int rtype = ROW_NONE;
+  float rpos = 0.0f, rmargin = 0.0f, rfloss = 0.0f, rdiag = 0.0f, rmu = 0.0f, rdiag_first = 0.0f;
+  const float* rsolref = m.dof_solref[0];
+  const float* rsolimp = m.dof_solimp[0];
+  if (lane < nfl) {
+    const int d = m.fl_dof[lane];
+    rtype = ROW_FRICTION; rfloss = m.dof_frictionloss[d]; rdiag = m.dof_invweight0[d];
+    rsolref = m.dof_solref[d]; rsolimp = m.dof_solimp[d];
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) J[k] = (k == d) ? 1.0f : 0.0f;
+  } else if (lane < nfl + nlim) {
+    const int r = lane - nfl, j = W.lim_jnt[r], d = 6 + j;
+    rtype = ROW_LIMIT; rpos = W.lim_dist[r]; rmargin = m.jnt_margin[j]; rdiag = m.dof_invweight0[d];
+    rsolref = m.jnt_solref[j]; rsolimp = m.jnt_solimp[j];
+    const float sgn = W.lim_side[r];
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) J[k] = (k == d) ? sgn : 0.0f;
+  } else if (lane < nefc) {
+    int c = 0;
+    for (int q = 1; q < ncon; q++)
+      if (lane >= W.con_row[q]) c = q;
+    const int e = lane - W.con_row[c], dim = W.con_dim[c], body = W.con_body[c];
+    const float mu = W.con_mu[c];
+    rpos = W.con_dist[c]; rmargin = W.con_inc[c]; rsolref = W.con_solref[c]; rsolimp = W.con_solimp[c];
+    const float tran = m.body_invweight0[body][0];
+    /* contact frame of a horizontal floor (mju_makeFrame): n = z, t1 = y, t2 = -x */
+    V3 dir = v3(0.0f, 0.0f, 1.0f);
+    if (dim == 1) { rtype = ROW_CONTACT1; rdiag = tran; }
+    else {
+      rtype = ROW_PYRAMID;
+      const float sgn = (e & 1) ? -mu : mu;
+      if ((e >> 1) == 0) dir.y = sgn; else dir.x = -sgn;
+      rdiag = tran + mu * mu * tran;
+      rdiag_first = rdiag;
+      rmu = mu / sqrtf(m.impratio);
+    }
+    V3 p = ld3(W.con_pos[c]) - O;
+    V3 w = cross(p, dir);
+    /* J[d] = cdof[d] . [p x dir ; dir] for the dofs on the chain of `body` */
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const float* s = W.cdof[k];
+      J[k] = s[0] * w.x + s[1] * w.y + s[2] * w.z + s[3] * dir.x + s[4] * dir.y + s[5] * dir.z;
+    }
+    if (body > 0) {
+      const int leg = (body - 1) / 3, depth = (body - 1) % 3;
+#pragma unroll
+      for (int k = 6; k < GQ_NVD; k++) {
+        const float* s = W.cdof[k];
+        float v = s[0] * w.x + s[1] * w.y + s[2] * w.z + s[3] * dir.x + s[4] * dir.y + s[5] * dir.z;
+        J[k] = ((k - 6) / 3 == leg && (k - 6) % 3 <= depth) ? v : 0.0f;
+      }
+    }
+  }
+  float rR = 1.0f, raref = 0.0f;
+  if (rtype != ROW_NONE) {
+    float imp = impedance(rsolimp, rpos, rmargin);
+    rR = fmaxf(1e-15f, (1.0f - imp) * rdiag / imp);
+    float dmax = fminf(fmaxf(rsolimp[1], 0.0001f), 0.9999f), K, B;
+    if (rsolref[0] > 0.0f) {
+      float tc = fmaxf(rsolref[0], 2.0f * h), dr = rsolref[1];
+      K = 1.0f / fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr);
+      B = 2.0f / fmaxf(1e-15f, dmax * tc);
+    } else { K = -rsolref[0] / fmaxf(1e-15f, dmax * dmax); B = -rsolref[1] / fmaxf(1e-15f, dmax); }
+    float vel = 0.0f;
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) vel += J[k] * W.qvel[k];
+    raref = -B * vel - K * imp * (rpos - rmargin);
+    if (rtype == ROW_PYRAMID) { /* Rpy = 2 mu^2 R(first edge); all edges of a condim-3 contact share diagApprox */
+      float Rfirst = fmaxf(1e-15f, (1.0f - imp) * rdiag_first / imp);
+      rR = fmaxf(1e-15f, 2.0f * rmu * rmu * Rfirst);
+    }
+  }
+
+  /* ================================================================ S8: B = M^-1 J' (lane-parallel), A = J B' + R */
+  float x[GQ_NVD];
+#pragma unroll
+  for (int k = 0; k < GQ_NVD; k++) x[k] = (lane == 63) ? W.smooth[k] : J[k];
+  solve_tree(W, 0, x);
+  float diag = 0.0f; /* A_ii = J_i . B_i */
+#pragma unroll
+  for (int k = 0; k < GQ_NVD; k++) { W.JB[lane][k] = x[k]; diag += J[k] * x[k]; }
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) W.qacc_smooth[k] = x[k];
+  }
+  wave_barrier();
+  float A[GQ_MAXEFC];
+#pragma unroll
+  for (int j = 0; j < GQ_MAXEFC; j++) {
+    float s = 0.0f;
+    if (j < nefc) {
+#pragma unroll
+      for (int k = 0; k < GQ_NVD; k++) s += J[k] * W.JB[j][k];
+    }
+    A[j] = s;
+  }
+  float b_i = -raref, jar_w = -raref;
+#pragma unroll
+  for (int k = 0; k < GQ_NVD; k++) { b_i += J[k] * W.qacc_smooth[k]; jar_w += J[k] * W.warm[k]; }
+  wave_barrier();
+  /* J rows replace B in LDS (needed for J' f and the debug dump) */
+#pragma unroll
+  for (int k = 0; k < GQ_NVD; k++) W.JB[lane][k] = (lane < nefc) ? J[k] : 0.0f;
+
+  /* ================================================================ S9: PGS on  min 1/2 f'(A+R)f + f'b */
+  const bool active = lane < nefc;
+  float lo = 0.0f, hi = 3.0e38f;
+  if (rtype == ROW_FRICTION) { lo = -rfloss; hi = rfloss; }
+  if (!active) { lo = 0.0f; hi = 0.0f; }
+  const float ARii = active ? diag + rR : 1.0f;
+  const float invd = 1.0f / ARii;
+  /* warm start: primal force law at qacc_warmstart (mj_constraintUpdate) */
+  float f = 0.0f;
+  if (active) {
+    if (rtype == ROW_FRICTION) f = med3(-jar_w / rR, -rfloss, rfloss);
+    else f = jar_w < 0.0f ? -jar_w / rR : 0.0f;
+  }
+  /* residual r = (A+R) f + b ; dual cost decides whether the warm start is kept */
+  float r = b_i + rR * f;
+#pragma unroll
+  for (int j = 0; j < GQ_MAXEFC; j++) {
+    if (j < nefc) r += A[j] * bcast(f, j);
+  }
+  {
+    float cost = wave_sum(active ? 0.5f * f * (r - b_i) + f * b_i : 0.0f);
+    if (cost > 0.0f) { f = 0.0f; r = b_i; }
+  }
+  if (!active) r = 0.0f;
+  const float scale = 1.0f / (m.meaninertia * 18.0f);
+  int iter = 0;
+  for (; iter < m.iterations; iter++) {
+    float imp_acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < GQ_MAXEFC; i++) {
+      if (i < nefc) { /* wave-uniform */
+        float fn = med3(f - r * invd, lo, hi);
+        float delta = fn - f;
+        float dcost = delta * (0.5f * delta * ARii + r);
+        const bool mine = lane == i;
+        f = mine ? fn : f;
+        imp_acc = mine ? imp_acc - dcost : imp_acc;
+        float d_i = bcast(delta, i);
+        r += (mine ? ARii : A[i]) * d_i;
+      }
+    }
+    float improvement = wave_sum(imp_acc);
+    if (improvement * scale < m.tolerance) { iter++; break; }
+  }
+  W.force[lane] = active ? f : 0.0f;
+  wave_barrier();
+
+  /* ================================================================ S10: accelerations and integration */
+  if (lane < GQ_NVD) {
+    float s = 0.0f;
+    for (int i = 0; i < nefc; i++) s += W.JB[i][lane] * W.force[i];
+    W.qfrc_c[lane] = s;
+  }
+  wave_barrier();
+  {
+    const int which = lane & 1;
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) x[k] = W.qfrc_c[k] + (which ? W.smooth[k] : 0.0f);
+    solve_tree(W, which, x);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < GQ_NVD; k++) W.qacc[k] = W.qacc_smooth[k] + x[k];
+    }
+    if (lane == 1) {
+#pragma unroll
+      for (int k = 0; k < GQ_NVD; k++) W.qacc_int[k] = x[k];
+    }
+  }
+  wave_barrier();
+
+  if (a.debug && env < a.batch->debug_envs) {
+    float* D = a.debug + (size_t)env * GQ_DBG_SIZE;
+    for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = W.M[k / 18][k % 18];
+    if (lane < 18) {
+      D[GQ_DBG_BIAS + lane] = W.bias[lane]; D[GQ_DBG_SMOOTH + lane] = W.smooth[lane];
+      D[GQ_DBG_QACC_SMOOTH + lane] = W.qacc_smooth[lane]; D[GQ_DBG_QFRC_C + lane] = W.qfrc_c[lane];
+      D[GQ_DBG_QACC + lane] = W.qacc[lane];
+    }
+    if (lane < 39) D[GQ_DBG_XPOS + lane] = W.xpos[lane / 3][lane % 3];
+    for (int k = lane; k < 117; k += GQ_WAVE) D[GQ_DBG_XMAT + k] = W.xmat[k / 9][k % 9];
+    if (lane == 0) { D[GQ_DBG_NEFC] = (float)nefc; D[GQ_DBG_NCON] = (float)ncon; D[GQ_DBG_NITER] = (float)iter; }
+    for (int k = 0; k < GQ_NVD; k++) D[GQ_DBG_EFC_J + lane * 18 + k] = W.JB[lane][k];
+    D[GQ_DBG_EFC_AREF + lane] = raref; D[GQ_DBG_EFC_R + lane] = rR; D[GQ_DBG_EFC_B + lane] = b_i;
+    D[GQ_DBG_EFC_FORCE + lane] = W.force[lane]; D[GQ_DBG_EFC_TYPE + lane] = (float)rtype;
+    if (lane < GQ_MAXCON) { D[GQ_DBG_CON_DIST + lane] = lane < ncon ? W.con_dist[lane] : 0.0f; D[GQ_DBG_CON_GEOM + lane] = lane < ncon ? (float)W.con_geom[lane] : -1.0f; }
+    if (lane < 12) D[GQ_DBG_FOOT_POS + lane] = W.foot_world[lane / 3][lane % 3];
+  }
+
+  /* semi-implicit Euler (mj_Euler): velocity with the damped system, then positions with the new velocity */
+  float vnew = 0.0f;
+  if (lane < GQ_NVD) {
+    vnew = W.qvel[lane] + h * W.qacc_int[lane];
+    a.qvel[(size_t)env * 18 + lane] = vnew;
+    a.qacc[(size_t)env * 18 + lane] = W.qacc[lane];
+    a.warm[(size_t)env * 18 + lane] = W.qacc[lane];
+  }
+  wave_barrier();
+  if (lane < GQ_NVD) W.qvel[lane] = vnew; /* new qvel; old one is not needed any more */
+  wave_barrier();
+  /* positions */
+  const double bxn_d = bx_d + (double)h * (double)W.qvel[0], byn_d = by_d + (double)h * (double)W.qvel[1];
+  if (lane == 0) a.qpos[(size_t)env * 19 + 0] = bxn_d;
+  if (lane == 1) a.qpos[(size_t)env * 19 + 1] = byn_d;
+  const float znew = W.basez + h * W.qvel[2];
+  Q4 qn;
+  {
+    V3 w = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
+    float n = sqrtf(dot(w, w));
+    qn = qbase;
+    /* mju_quatIntegrate starts from the raw (un-normalised) qpos quaternion; it was normalised above, the
+     * difference is removed by the normalisation that follows */
+    if (n > 1e-15f) {
+      float ang = h * n, s = sinf(0.5f * ang) / n, c = cosf(0.5f * ang);
+      Q4 qr = {c, w.x * s, w.y * s, w.z * s};
+      qn = qmul(qbase, qr);
+    }
+    qn = qnormalize(qn);
+  }
+  if (lane == 2) a.qpos[(size_t)env * 19 + 2] = (double)znew;
+  if (lane >= 3 && lane < 7) {
+    float qc = lane == 3 ? qn.w : (lane == 4 ? qn.x : (lane == 5 ? qn.y : qn.z));
+    a.qpos[(size_t)env * 19 + lane] = (double)qc;
+  }
+  float qjn = 0.0f;
+  if (lane >= 7 && lane < 19) {
+    qjn = W.qj[lane - 7] + h * W.qvel[lane - 1];
+    a.qpos[(size_t)env * 19 + lane] = (double)qjn;
+  }
+  float tnew = 0.0f;
+  if (lane == 0) { tnew = a.time[env] + h; a.time[env] = tnew; }
+
+  /* ================================================================ S11: observations (new qpos/qvel, old kinematics) */
+  float Rn[9];
+  q2mat(Rn, qn);
+  /* scipy as_euler('xyz') of the new orientation */
+  float sy = fminf(fmaxf(-Rn[6], -1.0f), 1.0f);
+  float e0, e1 = asinf(sy), e2;
+  if (fabsf(sy) < 0.9999999f) { e0 = atan2f(Rn[7], Rn[8]); e2 = atan2f(Rn[3], Rn[0]); }
+  else { e0 = 0.0f; e2 = atan2f(-Rn[1], Rn[4]); }
+  const float cyaw = cosf(e2), syaw = sinf(e2);
+  V3 cmdl = v3(W.cmd[0], W.cmd[1], W.cmd[2]);
+  V3 tl = v3(cyaw * cmdl.x - syaw * cmdl.y, syaw * cmdl.x + cyaw * cmdl.y, cmdl.z);
+  V3 ta = v3(0.0f, 0.0f, W.cmd[3]);
+  V3 vlin = v3(W.qvel[0], W.qvel[1], W.qvel[2]), wloc = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
+  V3 acc3 = v3(W.qacc[0], W.qacc[1], W.qacc[2]);
+  float* ob = W.obs;
+  if (lane == 0) {
+    ob[OB_BASE_POS] = (float)bxn_d; ob[OB_BASE_POS + 1] = (float)byn_d; ob[OB_BASE_POS + 2] = znew;
+    ob[OB_QPOS] = (float)bxn_d; ob[OB_QPOS + 1] = (float)byn_d; ob[OB_QPOS + 2] = znew;
+    st3(ob + OB_LIN_VEL, vlin); st3(ob + OB_LIN_VEL_ERR, tl - vlin); st3(ob + OB_LIN_ACC, acc3);
+    V3 ww = matvec(Rn, wloc);
+    st3(ob + OB_ANG_VEL, ww); st3(ob + OB_ANG_VEL_ERR, ta - ww);
+    ob[OB_EULER] = e0; ob[OB_EULER + 1] = e1; ob[OB_EULER + 2] = e2;
+    ob[OB_QUAT] = qn.w; ob[OB_QUAT + 1] = qn.x; ob[OB_QUAT + 2] = qn.y; ob[OB_QUAT + 3] = qn.z;
+    ob[OB_QPOS + 3] = qn.w; ob[OB_QPOS + 4] = qn.x; ob[OB_QPOS + 5] = qn.y; ob[OB_QPOS + 6] = qn.z;
+#pragma unroll
+    for (int k = 0; k < 9; k++) ob[OB_SO3 + k] = Rn[k];
+    st3(ob + OB_GRAV_B, matTvec(Rn, v3(0.0f, 0.0f, -1.0f)));
+    V3 vb = matTvec(Rn, vlin);
+    st3(ob + OB_LIN_VEL_B, vb); st3(ob + OB_LIN_VEL_ERR_B, matTvec(Rn, tl) - vb); st3(ob + OB_LIN_ACC_B, matTvec(Rn, acc3));
+    st3(ob + OB_ANG_VEL_B, wloc); st3(ob + OB_ANG_VEL_ERR_B, matTvec(Rn, ta) - wloc);
+  }
+  if (lane < GQ_NVD) ob[OB_QVEL + lane] = W.qvel[lane];
+  if (lane < 12) { ob[OB_TAU + lane] = W.ctrl[lane]; ob[OB_QVEL_JS + lane] = W.qvel[6 + lane]; }
+  if (lane >= 7 && lane < 19) { ob[OB_QPOS + lane] = qjn; ob[OB_QPOS_JS + lane - 7] = qjn; }
+  /* kinetic energy 1/2 v'Mv and work (M qacc).v with the OLD mass matrix, NEW velocity, qacc of this step */
+  float ke_part = 0.0f, wk_part = 0.0f;
+  if (lane < GQ_NVD) {
+    float mv = 0.0f, ma = 0.0f;
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) { mv += W.M[lane][k] * W.qvel[k]; ma += W.M[lane][k] * W.qacc[k]; }
+    ke_part = 0.5f * W.qvel[lane] * mv; wk_part = ma * W.qvel[lane];
+  }
+  float ke = wave_sum(ke_part), wk = wave_sum(wk_part);
+  if (lane == 0) { ob[OB_KE] = ke; ob[OB_WORK] = wk; }
+  /* feet: lane k < 4 = foot k in FL FR RL RR order */
+  if (lane < 4) {
+    const int leg = m.foot_leg[lane], body = 3 + 3 * leg;
+    V3 pw = ld3(W.foot_world[lane]); /* relative to the OLD base x/y */
+    /* spatial velocity of the calf with old cdof and new qvel (J_old * qvel_new) */
+    float sv[6] = {0, 0, 0, 0, 0, 0};
+    for (int d = 0; d < 6; d++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) sv[k] += W.cdof[d][k] * W.qvel[d];
+    for (int d = 6 + 3 * leg; d < 9 + 3 * leg; d++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) sv[k] += W.cdof[d][k] * W.qvel[d];
+    V3 fv = ld3(sv + 3) + cross(ld3(sv), pw - O);
+    /* world position of the foot: old base x/y + relative.  feet_pos:base uses the NEW base pose (quirk B3) */
+    V3 pworld = v3((float)(bx_d + (double)pw.x), (float)(by_d + (double)pw.y), pw.z);
+    V3 prel_new = v3(pw.x - h * W.qvel[0], pw.y - h * W.qvel[1], pw.z - znew);
+    V3 fvr = fv - vlin - cross(wloc, prel_new); /* quirk B4: body-frame omega used as world-frame */
+    /* feet_contact_state (quadruped_env.py:836-855): every world contact of the foot's BODY (the calf: foot sphere
+     * and calf link geom alike) sets the state and adds its force */
+    V3 cf = v3(0.0f, 0.0f, 0.0f);
+    float cs = 0.0f;
+    for (int c = 0; c < ncon; c++) {
+      if (W.con_body[c] != body) continue;
+      cs = 1.0f;
+      const int r0 = W.con_row[c];
+      if (W.con_dim[c] == 1) cf.z += W.force[r0];
+      else {
+        float f0 = W.force[r0], f1 = W.force[r0 + 1], f2 = W.force[r0 + 2], f3 = W.force[r0 + 3], mu = W.con_mu[c];
+        /* mju_decodePyramid, then frame' * f with n = z, t1 = y, t2 = -x */
+        float fn = f0 + f1 + f2 + f3, ft1 = mu * (f0 - f1), ft2 = mu * (f2 - f3);
+        cf = cf + v3(-ft2, ft1, fn);
+      }
+    }
+    if (W.foot_touch[lane]) cs = 1.0f; /* contact detected but dropped by the row budget */
+    /* slot of this foot in legs_order-dependent observables is resolved by obs_map; canonical order = FL FR RL RR */
+    st3(ob + OB_FEET_POS + 3 * lane, pworld);
+    st3(ob + OB_FEET_POS_B + 3 * lane, matTvec(Rn, prel_new));
+    st3(ob + OB_FEET_VEL + 3 * lane, fv);
+    st3(ob + OB_FEET_VEL_REL + 3 * lane, fvr);
+    st3(ob + OB_FEET_VEL_B + 3 * lane, matTvec(Rn, fv));
+    st3(ob + OB_FEET_VEL_REL_B + 3 * lane, matTvec(Rn, fvr));
+    ob[OB_CONTACT_STATE + lane] = cs;
+    st3(ob + OB_CONTACT_F + 3 * lane, cf);
+    st3(ob + OB_CONTACT_F_B + 3 * lane, matTvec(Rn, cf));
+  }
+  wave_barrier();
+  /* termination (quadruped_env.py:283-285): non-foot contact with the ground, or base outside the terrain */
+  {
+    const bool oob = bxn_d > m.terrain_limits[0] || bxn_d < m.terrain_limits[1] || byn_d > m.terrain_limits[2] ||
+                     byn_d < m.terrain_limits[3];
+    if (lane == 0) {
+      const int invalid = W.invalid;
+      a.invalid_contact[env] = (uint8_t)invalid;
+      a.terminated[env] = (uint8_t)(invalid || oob);
+      a.truncated[env] = 0;
+      a.reward[env] = 0.0f;
+      a.step_num[env] += 1;
+      if (a.friction_commit) const_cast<float*>(a.friction)[env] = a.friction_commit[env];
+    }
+  }
+  /* gather to the requested observation layout: coalesced row write */
+  {
+    const int od = a.batch->obs_dim;
+    for (int k = lane; k < od; k += GQ_WAVE) a.obs[(size_t)env * od + k] = ob[a.batch->obs_map[k]];
+  }
+}
+
+
+/* ------------------------------------------------------------------ reset: state write + lift loop
+ * QuadrupedEnv.reset (quadruped_env.py:332-395) for one env.  Random draws come from a counter-based generator
+ * (Philox4x32-10, key = seed, counter = (draw/4, episode, env, 0x5eed)); the reference uses numpy's global
+ * MT19937, which a batch cannot reproduce - draw ORDER and distributions are kept, the stream is documented in
+ * DESIGN.md and restated in tests/philox_ref.py.  On the flat floor a pure z shift moves every distance by the
+ * same amount, so the lift loop runs on the distances of one kinematics pass. */
+struct ResetCfgDev {
+  uint32_t seed_lo, seed_hi;
+  int32_t random;
+  float q_pos_amp, q_vel_amp, roll_sweep, pitch_sweep, hip_height;
+  float lin_vel_range[2], ang_vel_range[2], friction_range[2];
+  int32_t cmd_forward, cmd_random, cmd_rotate, cmd_human;
+};
+struct ResetArgs {
+  const GqDevModel* model;
+  const float* vx; const float* vy; const float* vz;
+  const uint8_t* mask; const double* qpos_new; const float* qvel_new;
+  double* qpos; float* qvel; float* qacc; float* warm; float* applied; float* time; float* cmd; float* friction_next;
+  int32_t* step_num; int32_t* episode;
+  uint8_t* lift_failed;
+  ResetCfgDev cfg;
+};
+
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+/* Philox4x32-10 (Salmon et al. 2011); returns component `which` of the output block */
+__device__ inline uint32_t philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int which) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return which == 0 ? c0 : (which == 1 ? c1 : (which == 2 ? c2 : c3));
+}
+
+/* draw indices */
+enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH = 27, RN_VNORM = 28, RN_HEADING = 29,
+       RN_YAWDOT = 30, RN_FRICTION = 31 };
+
+__device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
+  const int lane = lane_id();
+  const int env = (int)blockIdx.x;
+  const GqDevModel& m = *a.model;
+  const ResetCfgDev& c = a.cfg;
+  const int episode = a.episode ? a.episode[env] : 0;
+  /* one uniform in [0,1) per lane < 32 */
+  float u = 0.0f;
+  if (lane < 32) {
+    uint32_t x = philox4x32((uint32_t)(lane >> 2), (uint32_t)episode, (uint32_t)env, 0x5eedu, c.seed_lo, c.seed_hi, lane & 3);
+    u = (float)(x >> 8) * (1.0f / 16777216.0f);
+  }
+  W.obs[lane] = u; /* scratch: publish the draws */
+  wave_barrier();
+  const bool explicit_state = a.qpos_new != nullptr;
+  double q = 0.0;
+  float qv = 0.0f;
+  if (explicit_state) {
+    if (lane < 19) q = a.qpos_new[(size_t)env * 19 + lane];
+    if (lane < 18) qv = a.qvel_new[(size_t)env * 18 + lane];
+  } else {
+    if (lane < 19) q = (double)m.key_qpos[lane];
+    if (c.random) {
+      if (lane >= 7 && lane < 19) q += (double)((2.0f * W.obs[RN_QPOS + lane - 7] - 1.0f) * c.q_pos_amp);
+      if (lane >= 6 && lane < 18) qv = (2.0f * W.obs[RN_QVEL + lane - 6] - 1.0f) * c.q_vel_amp;
+      /* xy ~ U(terrain_limits[0], [1]) x U([2], [3]) (np.random.uniform(low, high) = low + (high-low) u) */
+      const double x = m.terrain_limits[0] + (m.terrain_limits[1] - m.terrain_limits[0]) * (double)W.obs[RN_X];
+      const double y = m.terrain_limits[2] + (m.terrain_limits[3] - m.terrain_limits[2]) * (double)W.obs[RN_Y];
+      const float roll = (2.0f * W.obs[RN_ROLL] - 1.0f) * c.roll_sweep, pitch = (2.0f * W.obs[RN_PITCH] - 1.0f) * c.pitch_sweep;
+      const float yaw = (float)atan2(-y, -x); /* heading towards the origin (math_utils.py:37-51) */
+      const float cr = cosf(0.5f * roll), sr = sinf(0.5f * roll), cp = cosf(0.5f * pitch), sp = sinf(0.5f * pitch);
+      const float cy = cosf(0.5f * yaw), sy = sinf(0.5f * yaw);
+      if (lane == 0) q = x;
+      if (lane == 1) q = y;
+      if (lane == 2) q = (double)c.hip_height;
+      /* Rotation.from_euler('xyz', [roll, pitch, yaw]).as_quat(scalar_first=True) */
+      if (lane == 3) q = (double)(cr * cp * cy + sr * sp * sy);
+      if (lane == 4) q = (double)(sr * cp * cy - cr * sp * sy);
+      if (lane == 5) q = (double)(cr * sp * cy + sr * cp * sy);
+      if (lane == 6) q = (double)(cr * cp * sy - sr * sp * cy);
+    }
+  }
+  if (lane == 2) W.basez = (float)q;
+  else if (lane >= 3 && lane < 7) W.qb[lane - 3] = (float)q;
+  else if (lane >= 7 && lane < 19) W.qj[lane - 7] = (float)q;
+  wave_barrier();
+  float dz = 0.0f;
+  int failed = 0;
+  if (!explicit_state) {
+    stage_kinematics(W, m);
+    wave_barrier();
+    stage_collision_scan(W, m, a.vx, a.vy, a.vz, true);
+    /* distances and margins of everything attached to a calf body (feet_contact_state is body-level) */
+    float dist = 1e30f, margin = 0.0f;
+    if (lane < 4) { dist = W.foot_world[lane][2] - m.foot_radius[lane]; margin = m.foot_margin[lane]; }
+    else if (lane - 4 < m.nlg) { dist = W.lg_dist[lane - 4]; margin = m.lg[lane - 4].margin; }
+    for (int it = 0; it < 100; it++) {
+      const bool touching = dist + dz < margin;
+      if (ballot(touching) == 0) break;
+      float pen = wave_max(touching ? fabsf(dist + dz) : 0.0f);
+      dz += 1.1f * pen;
+    }
+    failed = ballot(dist + dz < margin) != 0;
+  }
+  if (lane < 19) a.qpos[(size_t)env * 19 + lane] = lane == 2 ? q + (double)dz : q;
+  if (lane < 18) {
+    a.qvel[(size_t)env * 18 + lane] = qv;
+    a.qacc[(size_t)env * 18 + lane] = 0.0f;
+    a.warm[(size_t)env * 18 + lane] = 0.0f;
+    if (a.applied) a.applied[(size_t)env * 18 + lane] = 0.0f;
+  }
+  if (lane == 0) {
+    a.time[env] = 0.0f;
+    a.step_num[env] = -1; /* the reset's own mj_step brings it to 0 (:332, :397) */
+    if (a.episode) a.episode[env] = episode + 1;
+    if (a.lift_failed) a.lift_failed[env] = (uint8_t)failed;
+    /* _sample_ref_vel (:1046-1072) */
+    if (a.cmd) {
+      float norm = 0.0f, heading = 0.0f, yaw_dot = 0.0f;
+      if (c.cmd_forward) norm = c.lin_vel_range[0] + (c.lin_vel_range[1] - c.lin_vel_range[0]) * W.obs[RN_VNORM];
+      else if (c.cmd_random) {
+        norm = c.lin_vel_range[0] + (c.lin_vel_range[1] - c.lin_vel_range[0]) * W.obs[RN_VNORM];
+        heading = (2.0f * W.obs[RN_HEADING] - 1.0f) * 3.14159265358979f;
+      }
+      if (c.cmd_rotate) yaw_dot = c.ang_vel_range[0] + (c.ang_vel_range[1] - c.ang_vel_range[0]) * W.obs[RN_YAWDOT];
+      a.cmd[(size_t)env * 4 + 0] = norm * cosf(heading); a.cmd[(size_t)env * 4 + 1] = norm * sinf(heading);
+      a.cmd[(size_t)env * 4 + 2] = 0.0f; a.cmd[(size_t)env * 4 + 3] = yaw_dot;
+    }
+    if (a.friction_next)
+      a.friction_next[env] = c.friction_range[0] + (c.friction_range[1] - c.friction_range[0]) * W.obs[RN_FRICTION];
+  }
+}
+
+}  // namespace gq

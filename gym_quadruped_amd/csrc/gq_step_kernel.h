@@ -1,0 +1,295 @@
+/*
+ * gq_step_kernel.h - the fused batched physics step for gfx950: one environment per 64-lane wavefront,
+ * one wavefront per workgroup, per-env working set in LDS, state/obs rows streamed coalesced from/to HBM.
+ *
+ * Replaces, for a batch of envs, what the reference does per env in QuadrupedEnv.step()
+ * (gym_quadruped/quadruped_env.py:270-290): mjData.ctrl = action; mujoco.mj_step; _get_obs; reward;
+ * termination checks.  The stages follow MuJoCo's mj_step (restated on the CPU in oracle/gq_oracle.c):
+ *
+ *   S1 kinematics          lanes 0-3 walk the 4 leg chains              (mj_kinematics)
+ *   S2 spatial inertias    lane = body; composite = plain sums          (mj_comPos, mj_crb)
+ *   S3 mass matrix         lane = dof                                   (mj_crb)
+ *   S4 L'DL factorisation  lanes 0-3 = legs, then the 6x6 base block    (mj_factorM), M and M + h*D
+ *   S5 bias forces         RNE, lanes 0-3 chains / lane = body          (mj_comVel, mj_rne, mj_passive)
+ *   S6 collision           feet spheres + link vertex clouds vs floor   (mj_collision)
+ *   S7 constraint rows     lane = row: J row, impedance, R, aref        (mj_makeConstraint, mj_makeImpedance)
+ *   S8 dual operator       lane i solves M x = J_i' and owns row i of A = J M^-1 J' + R   (mj_projectConstraint)
+ *   S9 PGS                 sequential rows, residual vector kept in lanes (mj_solPGS)
+ *   S10 integration        semi-implicit Euler with implicit damping    (mj_Euler)
+ *   S11 observations       ALL_OBS scalars assembled in LDS, gathered to the requested layout (_get_obs, _check_*)
+ *
+ * Spatial quantities are expressed in world-aligned axes about O = base-body origin (MuJoCo uses the subtree
+ * centre of mass; M, bias forces and Jacobians are independent of that choice) and base x/y are removed from
+ * all fp32 arithmetic so that spawning 10 km from the origin (terrain.py:359) costs no precision.
+ */
+#pragma once
+#include <gq_device.h> /* angle brackets: the include path decides (csrc/ for the product, tests/simt_emu/ for the emulator) */
+#include "gq_model_dev.h"
+
+namespace gq {
+
+struct StepArgs {
+  const GqDevModel* model;
+  const GqDevBatch* batch;
+  const float* vx; const float* vy; const float* vz; /* cloud vertices SoA */
+  const float* ctrl; const uint8_t* mask;
+  double* qpos; float* qvel; float* qacc; float* warm; const float* applied; float* time; const float* friction;
+  const float* cmd;
+  const float* friction_commit; /* non-NULL: friction[env] <- friction_commit[env] after the step (reset, :403-404) */
+  float* obs; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* invalid_contact; int32_t* step_num;
+  float* debug;
+  int32_t n_envs;
+  int32_t forward_only; /* 1: stop after the position stage bookkeeping (unused by step) */
+};
+
+/* canonical ALL_OBS scalar offsets (order of QuadrupedEnv.ALL_OBS, quadruped_env.py:35-66,81) */
+enum {
+  OB_BASE_POS = 0, OB_LIN_VEL = 3, OB_LIN_VEL_ERR = 6, OB_LIN_ACC = 9, OB_ANG_VEL = 12, OB_ANG_VEL_ERR = 15,
+  OB_EULER = 18, OB_QUAT = 21, OB_SO3 = 25, OB_GRAV_B = 34, OB_LIN_VEL_B = 37, OB_LIN_VEL_ERR_B = 40,
+  OB_LIN_ACC_B = 43, OB_ANG_VEL_B = 46, OB_ANG_VEL_ERR_B = 49, OB_QPOS = 52, OB_QVEL = 71, OB_TAU = 89,
+  OB_QPOS_JS = 101, OB_QVEL_JS = 113, OB_KE = 125, OB_WORK = 126, OB_FEET_POS = 127, OB_FEET_POS_B = 139,
+  OB_FEET_VEL = 151, OB_FEET_VEL_REL = 163, OB_FEET_VEL_B = 175, OB_FEET_VEL_REL_B = 187, OB_CONTACT_STATE = 199,
+  OB_CONTACT_F = 203, OB_CONTACT_F_B = 215
+};
+
+enum { ROW_NONE = 0, ROW_FRICTION = 1, ROW_LIMIT = 2, ROW_CONTACT1 = 3, ROW_PYRAMID = 4 };
+
+/* ------------------------------------------------------------------ per-wave LDS working set */
+struct WaveMem {
+  float qj[12], qb[4], basez, qvel[18], ctrl[12], warm[18], applied[18], cmd[4];
+  float xpos[GQ_NB][3], xmat[GQ_NB][9];
+  float anchor[GQ_NJ][3], axis[GQ_NJ][3];
+  float cinert[GQ_NB][10], crb[GQ_NB][10];
+  float cdof[GQ_NVD][6];
+  float cvel[GQ_NB][6], cacc[GQ_NB][6], cfrc[GQ_NB][6];
+  float M[GQ_NVD][GQ_NVD];
+  float L[2][GQ_NVD][GQ_NVD], Dinv[2][GQ_NVD];      /* [0]: M, [1]: M + h*diag(damping) */
+  float bias[18], act[18], smooth[18], qacc_smooth[18], qfrc_c[18], qacc[18], qacc_int[18];
+  /* contacts */
+  int32_t ncon, nefc, nlim, invalid;
+  int32_t foot_touch[4];
+  int32_t con_geom[GQ_MAXCON], con_body[GQ_MAXCON], con_dim[GQ_MAXCON], con_row[GQ_MAXCON];
+  float con_dist[GQ_MAXCON], con_pos[GQ_MAXCON][3], con_mu[GQ_MAXCON], con_inc[GQ_MAXCON];
+  float con_solref[GQ_MAXCON][2], con_solimp[GQ_MAXCON][5];
+  int32_t foot_con[4];                                  /* contact index of foot k or -1 */
+  float foot_world[4][3];
+  int32_t lim_jnt[GQ_NJ]; float lim_side[GQ_NJ], lim_dist[GQ_NJ];
+  float lg_dist[GQ_MAXLG], lg_pt[GQ_MAXLG][3];
+  /* rows */
+  float JB[GQ_MAXEFC + 1][GQ_NVD];                      /* B = M^-1 J' while A is built, then J */
+  float force[64];
+  float obs[256];
+};
+
+/* ------------------------------------------------------------------ small math */
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+__device__ __forceinline__ V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3 matvec(const float* m, V3 v) {
+  return v3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+__device__ __forceinline__ V3 matTvec(const float* m, V3 v) {
+  return v3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z);
+}
+struct Q4 { float w, x, y, z; };
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  Q4 r = {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+  return r;
+}
+__device__ __forceinline__ Q4 qnormalize(Q4 q) {
+  float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  if (n2 < 1e-30f) { Q4 i = {1, 0, 0, 0}; return i; }
+  float s = 1.0f / sqrtf(n2);
+  Q4 r = {q.w * s, q.x * s, q.y * s, q.z * s};
+  return r;
+}
+__device__ __forceinline__ void q2mat(float* m, Q4 q) {
+  float w = q.w, x = q.x, y = q.y, z = q.z;
+  m[0] = w * w + x * x - y * y - z * z; m[4] = w * w - x * x + y * y - z * z; m[8] = w * w - x * x - y * y + z * z;
+  m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y); m[3] = 2 * (x * y + w * z);
+  m[5] = 2 * (y * z - w * x); m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x);
+}
+/* spatial vectors [ang(3); lin(3)] */
+__device__ __forceinline__ void cross_motion(float* r, const float* v, const float* s) {
+  V3 w = ld3(v), l = ld3(v + 3), sa = ld3(s), sl = ld3(s + 3);
+  st3(r, cross(w, sa));
+  st3(r + 3, cross(w, sl) + cross(l, sa));
+}
+__device__ __forceinline__ void cross_force(float* r, const float* v, const float* f) {
+  V3 w = ld3(v), l = ld3(v + 3), fa = ld3(f), fl = ld3(f + 3);
+  st3(r, cross(w, fa) + cross(l, fl));
+  st3(r + 3, cross(w, fl));
+}
+__device__ __forceinline__ void mul_inert(float* r, const float* i, const float* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+
+/* dof tree of the fixed topology: parent of dof d */
+__device__ __forceinline__ int dof_parent(int d) { return d < 6 ? d - 1 : ((d - 6) % 3 == 0 ? 5 : d - 1); }
+__device__ __forceinline__ int dof_body(int d) { return d < 6 ? 0 : d - 5; }
+
+/* solimp impedance (mj_makeImpedance::getimpedance) */
+__device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
+  float dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f), dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
+  float width = fmaxf(1e-15f, solimp[2]), mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f), power = fmaxf(1.0f, solimp[4]);
+  if (dmin == dmax || width <= 1e-15f) return 0.5f * (dmin + dmax);
+  float x = fabsf(pos - margin) / width;
+  if (x >= 1.0f) return dmax;
+  if (x <= 0.0f) return dmin;
+  float y;
+  if (power == 1.0f) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.0f);
+  else y = 1.0f - powf(1.0f - x, power) / powf(1.0f - mid, power - 1.0f);
+  return dmin + y * (dmax - dmin);
+}
+
+/* L'DL of a matrix with the robot's dof-tree sparsity (mj_factorI).  src: dense symmetric in LDS, diag_add: added
+ * to the diagonal (h*damping for the Euler system).  Lanes 0-3 eliminate their leg's three dofs in registers and
+ * emit their Schur contribution to the 6x6 base block; lane 0 then factors the base block. */
+__device__ inline void factor_tree(WaveMem& W, int which, const float* diag_add, float (*acc)[21]) {
+  const int lane = lane_id();
+  float(*L)[GQ_NVD] = W.L[which];
+  if (lane < 4) {
+    const int h = 6 + 3 * lane, t = h + 1, c = h + 2;
+    /* rows over columns [b0..b5, h, t, c] */
+    float rc[9], rt[8], rh[7], bb[21];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { rc[j] = W.M[c][j]; rt[j] = W.M[t][j]; rh[j] = W.M[h][j]; }
+    rc[6] = W.M[c][h]; rc[7] = W.M[c][t]; rc[8] = W.M[c][c] + diag_add[c];
+    rt[6] = W.M[t][h]; rt[7] = W.M[t][t] + diag_add[t];
+    rh[6] = W.M[h][h] + diag_add[h];
+#pragma unroll
+    for (int k = 0; k < 21; k++) bb[k] = 0.0f;
+    /* eliminate calf: ancestors t(7), h(6), b5..b0 */
+    {
+      float inv = 1.0f / rc[8], tmp;
+      tmp = rc[7] * inv;
+#pragma unroll
+      for (int j = 0; j <= 7; j++) rt[j] -= rc[j] * tmp;
+      rc[7] = tmp;
+      tmp = rc[6] * inv;
+#pragma unroll
+      for (int j = 0; j <= 6; j++) rh[j] -= rc[j] * tmp;
+      rc[6] = tmp;
+#pragma unroll
+      for (int i = 5; i >= 0; i--) {
+        tmp = rc[i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rc[j] * tmp;
+        rc[i] = tmp;
+      }
+    }
+    { /* thigh: ancestors h(6), b5..b0 */
+      float inv = 1.0f / rt[7], tmp;
+      tmp = rt[6] * inv;
+#pragma unroll
+      for (int j = 0; j <= 6; j++) rh[j] -= rt[j] * tmp;
+      rt[6] = tmp;
+#pragma unroll
+      for (int i = 5; i >= 0; i--) {
+        tmp = rt[i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rt[j] * tmp;
+        rt[i] = tmp;
+      }
+    }
+    { /* hip: ancestors b5..b0 */
+      float inv = 1.0f / rh[6], tmp;
+#pragma unroll
+      for (int i = 5; i >= 0; i--) {
+        tmp = rh[i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rh[j] * tmp;
+        rh[i] = tmp;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) { L[c][j] = rc[j]; L[t][j] = rt[j]; L[h][j] = rh[j]; }
+    L[c][h] = rc[6]; L[c][t] = rc[7]; L[t][h] = rt[6];
+    W.Dinv[which][c] = 1.0f / rc[8]; W.Dinv[which][t] = 1.0f / rt[7]; W.Dinv[which][h] = 1.0f / rh[6];
+#pragma unroll
+    for (int k = 0; k < 21; k++) acc[lane][k] = bb[k];
+  }
+  wave_barrier();
+  if (lane == 0) {
+    float b[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        int k = i * (i + 1) / 2 + j;
+        b[i][j] = W.M[i][j] + (i == j ? diag_add[i] : 0.0f) + acc[0][k] + acc[1][k] + acc[2][k] + acc[3][k];
+      }
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+      float inv = 1.0f / b[k][k];
+#pragma unroll
+      for (int i = k - 1; i >= 0; i--) {
+        float tmp = b[k][i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; j++) b[i][j] -= b[k][j] * tmp;
+        b[k][i] = tmp;
+      }
+      W.Dinv[which][k] = inv;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < i; j++) L[i][j] = b[i][j];
+  }
+  wave_barrier();
+}
+
+/* x <- (L' D L)^-1 x on 18 registers per lane; L and Dinv are wave-uniform LDS reads (mj_solveLD) */
+__device__ __forceinline__ void solve_tree(const WaveMem& W, int which, float* x) {
+  const float(*L)[GQ_NVD] = W.L[which];
+  const float* Dinv = W.Dinv[which];
+#pragma unroll
+  for (int leg = 3; leg >= 0; leg--) {
+    const int h = 6 + 3 * leg, t = h + 1, c = h + 2;
+    x[t] -= L[c][t] * x[c]; x[h] -= L[c][h] * x[c];
+#pragma unroll
+    for (int j = 0; j < 6; j++) x[j] -= L[c][j] * x[c];
+    x[h] -= L[t][h] * x[t];
+#pragma unroll
+    for (int j = 0; j < 6; j++) x[j] -= L[t][j] * x[t];
+#pragma unroll
+    for (int j = 0; j < 6; j++) x[j] -= L[h][j] * x[h];
+  }
+#pragma unroll
+  for (int k = 5; k >= 1; k--)
+#pragma unroll
+    for (int j = 0; j < k; j++) x[j] -= L[k][j] * x[k];
+#pragma unroll
+  for (int k = 0; k < 18; k++) x[k] *= Dinv[k];
+#pragma unroll
+  for (int k = 1; k < 6; k++)
+#pragma unroll
+    for (int j = 0; j < k; j++) x[k] -= L[k][j] * x[j];
+#pragma unroll
+  for (int leg = 0; leg < 4; leg++) {
+    const int h = 6 + 3 * leg, t = h + 1, c = h + 2;
+#pragma unroll
+    for (int j = 0; j < 6; j++) x[h] -= L[h][j] * x[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) x[t] -= L[t][j] * x[j];
+    x[t] -= L[t][h] * x[h];
+#pragma unroll
+    for (int j = 0; j < 6; j++) x[c] -= L[c][j] * x[j];
+    x[c] -= L[c][h] * x[h]; x[c] -= L[c][t] * x[t];
+  }
+}
+
+}  // namespace gq

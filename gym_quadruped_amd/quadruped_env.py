@@ -1,0 +1,467 @@
+"""Batched ``QuadrupedEnv`` - MI355X-native drop-in for the reference's ``gym_quadruped.quadruped_env.QuadrupedEnv``.
+
+Same constructor arguments, method names, observable names (``ALL_OBS``) and return structure as the reference
+(``gym_quadruped/quadruped_env.py:71-406``); every array gains a leading env axis ``N = num_envs`` and lives on the
+GPU as a ``torch`` tensor.  Where the reference advances ONE MuJoCo env with ``mujoco.mj_step`` (:271) and assembles
+observations in Python (:277-285), this class makes ONE call into ``libgq.so`` (``gq_step``, include/gq.h) that
+advances all ``N`` envs, one env per wavefront, and writes observations / termination flags on the device.
+
+PyTorch is plumbing here: it owns the device memory and the stream; all physics, observation, termination and
+reset-randomisation arithmetic runs in the hand-written HIP kernels.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import logging
+import math
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import _lib
+from .cabi import ALL_OBS as _ALL_OBS
+from .cabi import LEG_NAMES, OBS_DIMS, GqObsOut, GqResetCfg, GqState, MarshalledModel, obs_ids_from_names
+from .mjcf import ModelDesc, compile_mjcf, load_compiled
+from .robot_cfgs import RobotConfig, get_robot_config
+from .terrain import generate_terrain
+from .utils.math_utils import _process_range
+from .utils.quadruped_utils import LegsAttr, configure_observation_space, extract_mj_joint_info, spaces
+
+log = logging.getLogger(__name__)
+
+BASE_OBS = _ALL_OBS[0:10]
+BASE_OBS_BASE_FRAME = _ALL_OBS[10:15]
+GEN_COORDS_OBS = _ALL_OBS[15:22]
+FEET_OBS = _ALL_OBS[22:31]
+
+
+class _Info(dict):
+    """``info`` dict of ``step``: 'time', 'step_num' (value before this step's increment, as the reference reports
+    it, quadruped_env.py:288-290) and 'invalid_contacts' (bool mask instead of a dict of MjContact objects)."""
+
+    def __init__(self, env):
+        super().__init__()
+        self._env = env
+        dict.__setitem__(self, 'time', env._time)
+        dict.__setitem__(self, 'invalid_contacts', env._invalid_b)
+
+    def __getitem__(self, k):
+        if k == 'step_num':
+            return self._env._step_num - 1
+        return dict.__getitem__(self, k)
+
+    def keys(self):
+        return ['time', 'step_num', 'invalid_contacts']
+
+    def __contains__(self, k):
+        return k in ('time', 'step_num', 'invalid_contacts')
+
+
+class QuadrupedEnv:
+    """Batched quadruped environment (see module docstring).  Single-env semantics follow the reference class of the
+    same name; ``num_envs`` / ``device`` / ``auto_reset`` / solver knobs are the only additions."""
+
+    _DEFAULT_OBS = ('qpos', 'qvel', 'tau_ctrl_setpoint', 'feet_pos:base', 'feet_vel:base')
+    ALL_OBS = list(_ALL_OBS)
+    metadata = {'render.modes': [], 'version': 0}
+
+    def __init__(
+        self,
+        robot: str,
+        state_obs_names: tuple[str, ...] = _DEFAULT_OBS,
+        scene: str = 'flat',
+        sim_dt: float = 0.002,
+        base_vel_command_type: str = 'forward',
+        ref_base_lin_vel: tuple[float, float] | float = 0.5,
+        ref_base_ang_vel: tuple[float, float] | float = 0.0,
+        ground_friction_coeff: tuple[float, float] | float = 1.0,
+        legs_order: tuple[str, str, str, str] = ('FL', 'FR', 'RL', 'RR'),
+        sensors: tuple = None,
+        sensors_kwargs: tuple[dict[str, Any]] = None,
+        external_disturbances_kwargs: dict[str, Any] = None,
+        *,
+        num_envs: int = 1,
+        device: str | torch.device = 'cuda:0',
+        auto_reset: bool = False,
+        solver_iterations: int = 100,
+        solver_tolerance: float = 1e-8,
+        seed: int | None = None,
+        mjcf_path: str | None = None,
+    ):
+        self._save_hyperparameters(constructor_params=locals().copy())
+        log.info(f'Initializing {robot} environment with scene {scene}.')
+        self.robot_name = robot
+        self.robot_cfg: RobotConfig = get_robot_config(robot_name=robot)
+        self.base_vel_command_type = base_vel_command_type
+        self.base_lin_vel_range = _process_range(ref_base_lin_vel)
+        self.base_ang_vel_range = _process_range(ref_base_ang_vel)
+        self.ground_friction_coeff_range = _process_range(ground_friction_coeff)
+        self.legs_order = tuple(legs_order)
+        self.num_envs = int(num_envs)
+        self.auto_reset = bool(auto_reset)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.GqError('QuadrupedEnv runs on a ROCm GPU only (device must be cuda:N); there is no CPU path')
+        if sensors:
+            raise NotImplementedError('sensor plug-ins (IMU / HeightMap) are not available on the batched path yet')
+
+        # scene + model (reference :150-183)
+        self.scene_desc, self.terrain_limits = generate_terrain(scene, self.robot_cfg.hip_height, seed=10)
+        self.mjModel: ModelDesc = (compile_mjcf(mjcf_path) if mjcf_path
+                                   else load_compiled(Path(self.robot_cfg.mjcf_filename).stem))
+        qpos0 = self.mjModel.qpos0.copy()
+        if self.robot_cfg.qpos0_js is not None:
+            qpos0[7:] = np.asarray(self.robot_cfg.qpos0_js, dtype=np.float64)
+        self.mjModel.qpos0 = qpos0
+        self._mm = MarshalledModel(self.mjModel, qpos0=qpos0, feet_geom_names=self.robot_cfg.feet_geom_names,
+                                   terrain_limits=self.terrain_limits, timestep=sim_dt, solver=0,
+                                   iterations=solver_iterations, tolerance=solver_tolerance,
+                                   floor=self.scene_desc.get('floor'))
+        self._sim_dt = float(sim_dt)
+
+        # leg index maps (reference :189-212)
+        self.joint_info = extract_mj_joint_info(self.mjModel)
+        self.legs_qpos_idx = LegsAttr(None, None, None, None)
+        self.legs_qvel_idx = LegsAttr(None, None, None, None)
+        self.legs_tau_idx = LegsAttr(None, None, None, None)
+        for leg in ['FR', 'FL', 'RR', 'RL']:
+            qi, vi, ti = [], [], []
+            for jn in self.robot_cfg.leg_joints[leg]:
+                assert jn in self.joint_info, f'Joint {jn} not found in {list(self.joint_info.keys())}'
+                qi.extend(self.joint_info[jn].qpos_idx); vi.extend(self.joint_info[jn].qvel_idx); ti.extend(self.joint_info[jn].tau_idx)
+            self.legs_qpos_idx[leg], self.legs_qvel_idx[leg], self.legs_tau_idx[leg] = qi, vi, ti
+        self._feet_geom_id = LegsAttr(None, None, None, None)
+        self._feet_body_id = LegsAttr(None, None, None, None)
+        for leg in ['FR', 'FL', 'RR', 'RL']:
+            g = self.mjModel.geom_names.index(self.robot_cfg.feet_geom_names[leg])
+            self._feet_geom_id[leg] = g
+            self._feet_body_id[leg] = int(self.mjModel.geom_bodyid[g])
+
+        # spaces (reference :215-230; the action Box is unbounded there because of the truthiness slip, quirk B2)
+        nu = self.mjModel.nu
+        self.action_space = spaces.Box(shape=(nu,), low=np.full(nu, -np.inf), high=np.full(nu, np.inf), dtype=np.float32)
+        self.state_obs_names = tuple(state_obs_names)
+        self.observation_space = configure_observation_space(mj_model=self.mjModel, obs_names=self.state_obs_names)
+        self._obs_ids = obs_ids_from_names(self.state_obs_names)
+
+        # device state: one tensor per field, env-major rows
+        N, dev = self.num_envs, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._qpos = torch.zeros(N, 19, dtype=torch.float64, device=dev)
+        self._qvel = torch.zeros(N, 18, **f32)
+        self._qacc = torch.zeros(N, 18, **f32)
+        self._warm = torch.zeros(N, 18, **f32)
+        self._applied = torch.zeros(N, 18, **f32)
+        self._time = torch.zeros(N, **f32)
+        self._friction = torch.full((N,), -1.0, **f32)   # < 0: XML frictions until the first reset sets it
+        self._cmd = torch.zeros(N, 4, **f32)
+        self._ctrl = torch.zeros(N, nu, **f32)
+        self._zero_ctrl = torch.zeros(N, nu, **f32)
+        self._obs_dim = int(sum(OBS_DIMS[i] for i in self._obs_ids))
+        self._obs_buf = torch.zeros(N, self._obs_dim, **f32)
+        self._reward = torch.zeros(N, **f32)
+        self._terminated = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._truncated = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._invalid = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._terminated_b = self._terminated.view(torch.bool)
+        self._truncated_b = self._truncated.view(torch.bool)
+        self._invalid_b = self._invalid.view(torch.bool)
+        self._step_num = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._lift_failed = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._mask_all = torch.ones(N, dtype=torch.uint8, device=dev)
+        self._steps_after_vel = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._steps_before_vel = torch.full((N,), 1 << 30, dtype=torch.int32, device=dev)
+        self._steps_after_dist = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._steps_before_dist = torch.full((N,), 1 << 30, dtype=torch.int32, device=dev)
+        self._ext_dist = torch.zeros(N, 6, **f32)
+        self._has_cmd = False
+        self._obs_views, k = {}, 0
+        for name, i in zip(self.state_obs_names, self._obs_ids):
+            self._obs_views[name] = self._obs_buf[:, k:k + OBS_DIMS[i]]
+            k += OBS_DIMS[i]
+        self._key_qpos = torch.as_tensor(self.mjModel.key_qpos[0] if len(self.mjModel.key_qpos) else qpos0, dtype=torch.float64, device=dev)
+        self._gen = torch.Generator(device=dev)
+        self._gen.manual_seed(0 if seed is None else int(seed))
+
+        # C-ABI handles
+        L = _lib.lib()
+        self._L = L
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._hmodel = C.c_void_p()
+        _lib.check(L.gq_model_create(C.byref(self._mm.desc), int(dev_index), C.byref(self._hmodel)), 'gq_model_create')
+        ids = np.asarray(self._obs_ids, dtype=np.int32)
+        lo = np.asarray([LEG_NAMES.index(l) for l in self.legs_order], dtype=np.int32)
+        self._hbatch = C.c_void_p()
+        _lib.check(L.gq_batch_create(self._hmodel, N, ids.ctypes.data, len(ids), lo.ctypes.data, C.byref(self._hbatch)), 'gq_batch_create')
+        assert L.gq_batch_obs_dim(self._hbatch) == self._obs_dim
+        self._st = GqState(self._qpos.data_ptr(), self._qvel.data_ptr(), self._qacc.data_ptr(), self._warm.data_ptr(),
+                           self._applied.data_ptr(), self._time.data_ptr(), self._friction.data_ptr(), self._cmd.data_ptr())
+        self._out = GqObsOut(self._obs_buf.data_ptr(), self._reward.data_ptr(), self._terminated.data_ptr(),
+                             self._truncated.data_ptr(), self._invalid.data_ptr(), self._step_num.data_ptr())
+        self._info = _Info(self)
+        self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
+        t = self.base_vel_command_type
+        if not any(k in t for k in ('forward', 'random', 'human')):
+            raise ValueError(f'Invalid base linear velocity command type: {t}')
+        self._seed = 0 if seed is None else int(seed)
+        self._reset_cfg = GqResetCfg(
+            seed=self._seed, random=1, q_pos_amp=20 * math.pi / 180, q_vel_amp=0.5, roll_sweep=10 * math.pi / 180,
+            pitch_sweep=10 * math.pi / 180, hip_height=float(self.robot_cfg.hip_height),
+            lin_vel_range=(C.c_float * 2)(*map(float, self.base_lin_vel_range)),
+            ang_vel_range=(C.c_float * 2)(*map(float, self.base_ang_vel_range)),
+            friction_range=(C.c_float * 2)(*map(float, self.ground_friction_coeff_range)),
+            cmd_forward=int('forward' in t), cmd_random=int('forward' not in t and 'random' in t),
+            cmd_rotate=int('rotate' in t), cmd_human=int('human' in t))
+
+        self.external_disturbances_kwargs = external_disturbances_kwargs
+        if self.external_disturbances_kwargs is not None:
+            self._sample_external_disturbances(self._mask_all.view(torch.bool))
+        self.viewer = None
+        self.sensors = []
+        self._profile_events = None  # optional (start, end) torch.cuda.Event pair recorded around the gq_step launch
+
+    # ------------------------------------------------------------------ core API
+    def step(self, action):
+        """Advance every env by one ``sim_dt`` (reference ``step`` :251-307).
+
+        action: ``[N, nu]`` joint torques (tensor / array; ``[nu]`` is broadcast when N == 1).
+        Returns ``(obs, reward, terminated, truncated, info)`` with obs a dict ``name -> [N, dim]`` float32 tensor
+        (views of one persistent buffer, overwritten by the next call), reward ``[N]``, terminated/truncated ``[N]``
+        bool and info {'time' [N], 'step_num' [N], 'invalid_contacts' [N] bool}.
+        """
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+        if a.dim() == 1:
+            a = a.unsqueeze(0).expand(self.num_envs, -1)
+        if a.shape != self._ctrl.shape:
+            raise ValueError(f'action must have shape {tuple(self._ctrl.shape)}, got {tuple(a.shape)}')
+        self._ctrl.copy_(a)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        ev = self._profile_events
+        if ev is not None:
+            ev[0].record()
+        _lib.check(self._L.gq_step(self._hbatch, self._ctrl.data_ptr(), None, self._st, self._out, stream), 'gq_step')
+        if ev is not None:
+            ev[1].record()
+
+        if 'reset' in self.base_vel_command_type:  # reference :293-296
+            self._steps_after_vel += 1
+            due = self._steps_after_vel >= self._steps_before_vel
+            self._sample_ref_vel(due)
+        if self.external_disturbances_kwargs is not None and self.external_disturbances_kwargs['type'] == 'reset':
+            self._steps_after_dist += 1
+            due = self._steps_after_dist >= self._steps_before_dist
+            self._sample_external_disturbances(due)
+            self._applied[:, :6] = self._ext_dist  # acts from the NEXT step on (reference :305, quirk B9)
+        if self.auto_reset:
+            self._reset_masked(self._terminated, random=True, options=None)
+        return self._obs_views, self._reward, self._terminated_b, self._truncated_b, self._info
+
+    def reset(self, qpos=None, qvel=None, seed: int | None = None, random: bool = True,
+              options: dict[str, Any] | None = None, env_ids=None):
+        """Reset (reference ``reset`` :309-406); ``env_ids`` (index tensor / bool mask) restricts it to a subset.
+        Returns the observation dict only, like the reference (quirk B7)."""
+        if seed is not None:  # reference: np.random.seed(seed) (:338-339); here: re-key the device generators
+            self._gen.manual_seed(int(seed))
+            self._seed = int(seed)
+            self._reset_cfg.seed = self._seed
+            self._episode.zero_()
+        N = self.num_envs
+        if env_ids is None:
+            mask = self._mask_all
+        else:
+            idx = torch.as_tensor(env_ids, device=self.device)
+            if idx.dtype == torch.bool:
+                mask = idx.to(torch.uint8)
+            else:
+                mask = torch.zeros(N, dtype=torch.uint8, device=self.device)
+                mask[idx.long()] = 1
+        if qpos is None and qvel is None:
+            self._reset_masked(mask, random=random, options=options)
+        else:
+            qp = torch.as_tensor(qpos, dtype=torch.float64, device=self.device).reshape(-1, 19).expand(N, 19).contiguous()
+            qv = torch.as_tensor(qvel, dtype=torch.float32, device=self.device).reshape(-1, 18).expand(N, 18).contiguous()
+            self._reset_masked(mask, random=False, options=options, qpos=qp, qvel=qv)
+        return self._obs_views
+
+    def _reset_masked(self, mask, random, options, qpos=None, qvel=None):
+        """One ``gq_reset`` call = state write (+ lift loop) and the reset's own ``mj_step`` for the masked envs."""
+        options = {} if options is None else options
+        cfg = self._reset_cfg
+        cfg.random = int(bool(random))
+        cfg.q_pos_amp = float(options.get('angle_sweep', 20 * math.pi / 180))
+        cfg.roll_sweep = float(options.get('roll_sweep', 10 * math.pi / 180))
+        cfg.pitch_sweep = float(options.get('pitch_sweep', 10 * math.pi / 180))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._L.gq_reset(self._hbatch, mask.data_ptr(), None if qpos is None else qpos.data_ptr(),
+                                    None if qvel is None else qvel.data_ptr(), C.byref(cfg), self._st, self._out,
+                                    self._episode.data_ptr(), self._lift_failed.data_ptr(), stream), 'gq_reset')
+        if 'reset' in self.base_vel_command_type:
+            mb = mask.view(torch.bool)
+            nxt = torch.randint(1000, 3000, (self.num_envs,), generator=self._gen, device=self.device, dtype=torch.int32)
+            self._steps_before_vel = torch.where(mb, nxt, self._steps_before_vel)
+            self._steps_after_vel = torch.where(mb, torch.zeros_like(nxt), self._steps_after_vel)
+
+    # ------------------------------------------------------------------ command / disturbance sampling
+    def _sample_ref_vel(self, mask):
+        """Per-env redraw of the velocity command for envs in ``mask`` (reference ``_sample_ref_vel`` :1046-1072)."""
+        N, dev, g = self.num_envs, self.device, self._gen
+        t = self.base_vel_command_type
+        lo, hi = self.base_lin_vel_range
+        if 'forward' in t:
+            norm = lo + (hi - lo) * torch.rand(N, generator=g, device=dev)
+            heading = torch.zeros(N, device=dev)
+        elif 'random' in t:
+            norm = lo + (hi - lo) * torch.rand(N, generator=g, device=dev)
+            heading = (torch.rand(N, generator=g, device=dev) * 2 - 1) * math.pi
+        elif 'human' in t:
+            norm = torch.zeros(N, device=dev)
+            heading = torch.zeros(N, device=dev)
+        else:
+            raise ValueError(f'Invalid base linear velocity command type: {t}')
+        if 'rotate' in t:
+            alo, ahi = self.base_ang_vel_range
+            yaw_dot = alo + (ahi - alo) * torch.rand(N, generator=g, device=dev)
+        else:
+            yaw_dot = torch.zeros(N, device=dev)
+        new = torch.stack([norm * torch.cos(heading), norm * torch.sin(heading), torch.zeros(N, device=dev), yaw_dot], 1)
+        self._cmd.copy_(torch.where(mask.unsqueeze(1), new, self._cmd))
+        if 'reset' in t:
+            nxt = torch.randint(1000, 3000, (N,), generator=g, device=dev, dtype=torch.int32)
+            self._steps_before_vel = torch.where(mask, nxt, self._steps_before_vel)
+            self._steps_after_vel = torch.where(mask, torch.zeros_like(nxt), self._steps_after_vel)
+        self._has_cmd = True
+
+    def _sample_external_disturbances(self, mask):
+        """Per-env redraw of the base wrench (reference ``_sample_external_disturbances`` :1074-1139)."""
+        N, dev, g = self.num_envs, self.device, self._gen
+        kw = self.external_disturbances_kwargs
+        cols = []
+        for key in ('x', 'y', 'z', 'roll', 'pitch', 'yaw'):
+            r = kw.get(key)
+            if r is None or len(r) == 0:
+                cols.append(torch.zeros(N, device=dev))
+            elif len(r) == 1:
+                cols.append(torch.full((N,), float(r[0]), device=dev))
+            else:
+                cols.append(float(r[0]) + (float(r[1]) - float(r[0])) * torch.rand(N, generator=g, device=dev))
+        new = torch.stack(cols, 1)
+        self._ext_dist = torch.where(mask.unsqueeze(1), new, self._ext_dist)
+        nxt = torch.randint(1000, 3000, (N,), generator=g, device=dev, dtype=torch.int32)
+        self._steps_before_dist = torch.where(mask, nxt, self._steps_before_dist)
+        self._steps_after_dist = torch.where(mask, torch.zeros_like(nxt), self._steps_after_dist)
+
+    # ------------------------------------------------------------------ accessors (reference names)
+    @property
+    def qpos(self):
+        return self._qpos
+
+    @property
+    def qvel(self):
+        return self._qvel
+
+    @property
+    def base_pos(self):
+        return self._qpos[:, 0:3]
+
+    @property
+    def joint_space_state(self):
+        return self._qpos[:, 7:], self._qvel[:, 6:]
+
+    @property
+    def torque_ctrl_setpoint(self):
+        return self._ctrl
+
+    @property
+    def simulation_dt(self):
+        return self._sim_dt
+
+    @property
+    def simulation_time(self):
+        return self._time
+
+    @property
+    def step_num(self):
+        return self._step_num
+
+    @property
+    def robot_model(self):
+        return self.mjModel
+
+    @property
+    def lift_failed(self):
+        """Per-env flag of the reset RuntimeError condition (reference :387-388)."""
+        return self._lift_failed.view(torch.bool)
+
+    def target_base_vel(self):
+        """Reference command in the heading frame ``[N,3]`` and yaw rate ``[N]`` (reference :488-499 inputs)."""
+        return self._cmd[:, 0:3], self._cmd[:, 3]
+
+    def state_dict(self):
+        """Checkpoint: everything needed to resume a rollout bit-for-bit."""
+        keys = ['_qpos', '_qvel', '_qacc', '_warm', '_applied', '_time', '_friction', '_cmd', '_step_num', '_episode',
+                '_steps_after_vel', '_steps_before_vel', '_steps_after_dist', '_steps_before_dist', '_ext_dist']
+        d = {k: getattr(self, k).clone() for k in keys}
+        d['rng'] = self._gen.get_state()
+        return d
+
+    def load_state_dict(self, d):
+        for k, v in d.items():
+            if k == 'rng':
+                self._gen.set_state(v)
+            elif k == '_ext_dist':
+                self._ext_dist = v.to(self.device).clone()
+            else:
+                getattr(self, k).copy_(v)
+
+    def debug_internals(self, n_envs: int, names):
+        """Copy solver / dynamics internals of the LAST step for the first ``n_envs`` envs (must be enabled before
+        the step with ``enable_debug``)."""
+        out = []
+        for e in range(n_envs):
+            rec = {}
+            for nm in names:
+                buf = np.zeros(64 * 18, dtype=np.float64)
+                n = _lib.check(self._L.gq_debug_get(self._hbatch, e, nm.encode(), buf.ctypes.data, buf.size), 'gq_debug_get')
+                rec[nm] = buf[:n].copy()
+            out.append(rec)
+        return out
+
+    def enable_debug(self, n_envs: int):
+        _lib.check(self._L.gq_debug_enable(self._hbatch, int(n_envs)), 'gq_debug_enable')
+
+    def render(self, *a, **k):
+        raise NotImplementedError('interactive MuJoCo viewer rendering is out of scope of the batched GPU path')
+
+    def close(self):
+        if getattr(self, '_hbatch', None):
+            self._L.gq_batch_destroy(self._hbatch)
+            self._hbatch = None
+        if getattr(self, '_hmodel', None):
+            self._L.gq_model_destroy(self._hmodel)
+            self._hmodel = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _save_hyperparameters(self, constructor_params):
+        self._init_args = constructor_params
+        for k in ['self', '__class__']:
+            self._init_args.pop(k, None)
+
+    def get_hyperparameters(self):
+        """Constructor arguments (reference :1356-1358)."""
+        return copy.copy(self._init_args)
+
+    def __str__(self):
+        msg = f'robot={self._init_args["robot"]} terrain={self._init_args["scene"]} task={self.base_vel_command_type} num_envs={self.num_envs}'
+        if self.base_vel_command_type != 'human':
+            msg += (f' lin_vel_range=({self.base_lin_vel_range[0]:.3f}, {self.base_lin_vel_range[1]:.3f})'
+                    f' ang_vel_range=({self.base_ang_vel_range[0]:.3f}, {self.base_ang_vel_range[1]:.3f})'
+                    f' lat_friction_range=({self.ground_friction_coeff_range[0]:.1e}, {self.ground_friction_coeff_range[1]:.1e})')
+        return msg

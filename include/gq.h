@@ -132,6 +132,7 @@ typedef struct GqModelDesc {
   int32_t feet_geomid[GQ_NLEG];  /* FL FR RL RR (robot_cfgs.py:15) */
   double terrain_limits[4];      /* max_x min_x max_y min_y (terrain.py:359) */
   double meaninertia;
+  double key_qpos[19];           /* keyframe 0 (mj_resetDataKeyframe, quadruped_env.py:343) */
   /* solver */
   int32_t solver;                /* 0 PGS (north-star), 1 Newton (MuJoCo default; oracle only in this round) */
   int32_t iterations;
@@ -149,7 +150,7 @@ typedef struct GqState {
   float* qacc_warmstart;   /* [N][18] in/out                                                        */
   float* qfrc_applied;     /* [N][18] in: external disturbance wrench (quadruped_env.py:305)        */
   float* time;             /* [N] in/out                                                            */
-  float* friction;         /* [N] tangential coeff. of floor + feet (quadruped_env.py:1277-1298)    */
+  float* friction;         /* [N] tangential coeff. of floor + feet (quadruped_env.py:1277-1298); < 0 = XML values */
   float* cmd;              /* [N][4] ref_base_lin_vel_H[3], ref_base_ang_yaw_dot (:1046-1072)       */
 } GqState;
 
@@ -199,12 +200,33 @@ int gq_batch_obs_dim(const GqBatch* b);
  * (used by reset(), which ends with one mj_step for the envs being reset, quadruped_env.py:397). */
 int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, void* hip_stream);
 
-/* QuadrupedEnv.reset state write (quadruped_env.py:332-395) for envs with mask!=0: copies the candidate
- * qpos/qvel, zeroes time/qacc/qacc_warmstart/qfrc_applied/step_num, and - when lift != 0 - runs the
- * mj_step1 + "lift until no foot contact" loop (:376-388; <=100 iterations, +1.1*max|dist| each).
- * lift_failed: device [N] u8 out (RuntimeError condition, :387-388), may be NULL. */
-int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new, int lift,
-             GqState st, GqObsOut out, uint8_t* lift_failed, void* hip_stream);
+/* reset configuration: the knobs of QuadrupedEnv.reset / _sample_ref_vel / _set_ground_friction */
+typedef struct GqResetCfg {
+  uint64_t seed;            /* key of the counter-based device RNG (Philox4x32-10; counter = draw, episode, env) */
+  int32_t random;           /* reset(random=...) (quadruped_env.py:314,346) */
+  float q_pos_amp;          /* joint angle noise amplitude, default 20 deg (:347) */
+  float q_vel_amp;          /* joint velocity noise amplitude 0.5 (:348) */
+  float roll_sweep, pitch_sweep; /* default 10 deg (:362-363) */
+  float hip_height;         /* RobotConfig.hip_height: spawn height before the lift loop (:359) */
+  float lin_vel_range[2];   /* ref_base_lin_vel (min,max) (:141) */
+  float ang_vel_range[2];   /* ref_base_ang_vel (min,max) (:142) */
+  float friction_range[2];  /* ground_friction_coeff (min,max) (:143) */
+  int32_t cmd_forward, cmd_random, cmd_rotate, cmd_human; /* substrings of base_vel_command_type (:1049-1066) */
+} GqResetCfg;
+
+/* QuadrupedEnv.reset (quadruped_env.py:309-406) for the envs with mask != 0 (mask NULL = all), two launches:
+ *  1. state write: explicit qpos_new/qvel_new when given (:389-391), otherwise keyframe 0 (+ joint noise, random
+ *     xy inside terrain_limits, z = hip_height, random roll/pitch, yaw facing the origin when cfg->random, :343-373)
+ *     followed by the mj_step1 + "lift until no foot-body contact" loop (:376-388; <= 100 iterations, z += 1.1 *
+ *     max|dist|); zero time / qacc / qacc_warmstart / qfrc_applied / step_num (:332-335, :394-395); draw the velocity
+ *     command (:400) and the next friction coefficient.
+ *  2. one masked mj_step with zero control (:397) that also produces the observation rows (:406); the new
+ *     friction coefficient is committed after it (:403-404).
+ * episode: device [N] int32 in/out, incremented per reset env (RNG counter).  lift_failed: device [N] u8 out
+ * (the reference's RuntimeError condition, :387-388), may be NULL.  qpos_new/qvel_new: device [N][19] f64 /
+ * [N][18] f32 or both NULL. */
+int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new, const GqResetCfg* cfg,
+             GqState st, GqObsOut out, int32_t* episode, uint8_t* lift_failed, void* hip_stream);
 
 /* debug / inspection: last forward pass internals of env `env` copied to host (doubles).
  * name in {"M","qfrc_bias","qfrc_smooth","qacc_smooth","qfrc_constraint","efc_J","efc_aref","efc_R","efc_b",

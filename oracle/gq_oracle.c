@@ -1169,15 +1169,23 @@ int gqo_get_obs(const GqOracle* o, const double* cmd /*[4]*/, const int* legs_or
   return (int)(p - out);
 }
 
-/* cpu_baseline helper: run `nsteps` steps with the given control sequence [nsteps][nu] and assemble obs each step */
+/* cpu_baseline helper: run `nsteps` steps with the given control sequence [nsteps][nu], assembling the observation
+ * row every step as QuadrupedEnv.step does; when reset_on_term != 0 a terminated env is put back to the state the
+ * rollout started from (stand-in for the user's env.reset()).  Returns the number of terminated steps. */
 int gqo_rollout(GqOracle* o, const double* ctrl_seq, int nsteps, const double* cmd, const int* legs_order,
-                const int* obs_ids, int n_obs, double* obs_last) {
+                const int* obs_ids, int n_obs, double* obs_last, int reset_on_term) {
   static double buf[512];
+  double q0[NQ], v0[NV];
+  memcpy(q0, o->qpos, sizeof q0); memcpy(v0, o->qvel, sizeof v0);
   int term, inv, nterm = 0;
   for (int s = 0; s < nsteps; s++) {
     gqo_step(o, ctrl_seq + (size_t)s * o->d.nu);
     gqo_get_obs(o, cmd, legs_order, obs_ids, n_obs, obs_last ? obs_last : buf, &term, &inv);
     nterm += term;
+    if (term && reset_on_term) {
+      memcpy(o->qpos, q0, sizeof q0); memcpy(o->qvel, v0, sizeof v0);
+      memset(o->qacc_warmstart, 0, sizeof o->qacc_warmstart);
+    }
   }
   return nterm;
 }

@@ -40,7 +40,7 @@ def lib():
         L.gqo_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.gqo_jac_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.gqo_get_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.gqo_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.gqo_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.gqo_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
@@ -134,9 +134,9 @@ class Oracle:
             k += OBS_DIMS[i]
         return res, bool(term.value), bool(inv.value)
 
-    def rollout(self, ctrl_seq, obs_names, cmd=(0, 0, 0, 0), legs_order=(0, 1, 2, 3)):
+    def rollout(self, ctrl_seq, obs_names, cmd=(0, 0, 0, 0), legs_order=(0, 1, 2, 3), reset_on_term=True):
         ids = np.asarray(obs_ids_from_names(obs_names), dtype=np.int32)
         seq = np.ascontiguousarray(ctrl_seq, dtype=np.float64)
         cmd = np.asarray(cmd, dtype=np.float64)
         lo = np.asarray(legs_order, dtype=np.int32)
-        return self.L.gqo_rollout(self.h, _p(seq), seq.shape[0], _p(cmd), _p(lo), _p(ids), len(ids), None)
+        return self.L.gqo_rollout(self.h, _p(seq), seq.shape[0], _p(cmd), _p(lo), _p(ids), len(ids), None, int(reset_on_term))

@@ -1,0 +1,113 @@
+"""Shared test helpers: model marshalling, oracle construction, the host SIMT emulator binding and the
+debug-record layout of the kernel.  TEST INFRASTRUCTURE."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+from gym_quadruped_amd.cabi import ALL_OBS, OBS_DIMS, GqModelDesc, MarshalledModel, obs_ids_from_names  # noqa: E402
+from gym_quadruped_amd.mjcf import load_compiled  # noqa: E402
+from gym_quadruped_amd.robot_cfgs import get_robot_config  # noqa: E402
+
+# debug record layout (csrc/gq_model_dev.h GQ_DBG_*)
+DBG = {}
+_o = 0
+for _name, _n in [('M', 324), ('qfrc_bias', 18), ('qfrc_smooth', 18), ('qacc_smooth', 18), ('qfrc_constraint', 18),
+                  ('xpos', 39), ('xmat', 117), ('nefc', 1), ('ncon', 1), ('niter', 1), ('efc_J', 64 * 18),
+                  ('efc_aref', 64), ('efc_R', 64), ('efc_b', 64), ('efc_force', 64), ('efc_type', 64),
+                  ('contact_dist', 12), ('contact_geom', 12), ('foot_pos', 12), ('qacc', 18)]:
+    DBG[_name] = (_o, _n)
+    _o += _n
+DBG_SIZE = _o
+
+
+def marshalled(robot='mini_cheetah', solver=0, iterations=100, tolerance=1e-8, timestep=0.002,
+               terrain_limits=(1e4, -1e4, 1e4, -1e4)):
+    cfg = get_robot_config(robot)
+    md = load_compiled(Path(cfg.mjcf_filename).stem)
+    qpos0 = md.qpos0.copy()
+    if cfg.qpos0_js is not None:
+        qpos0[7:] = np.asarray(cfg.qpos0_js, dtype=np.float64)
+    return MarshalledModel(md, qpos0=qpos0, feet_geom_names=cfg.feet_geom_names, terrain_limits=terrain_limits,
+                           timestep=timestep, solver=solver, iterations=iterations, tolerance=tolerance)
+
+
+def random_states(md, n, rng, z_range=(0.18, 0.45), contact_bias=True):
+    """Reference-reset-like random states (quadruped_env.py:343-373) without the lift loop: keyframe + joint noise,
+    random roll/pitch/yaw, heights spanning flight and ground contact."""
+    from scipy.spatial.transform import Rotation
+    qpos = np.tile(md.key_qpos[0], (n, 1))
+    qpos[:, 7:] += rng.uniform(-0.35, 0.35, (n, 12))
+    qpos[:, 0:2] = rng.uniform(-5, 5, (n, 2))
+    qpos[:, 2] = rng.uniform(*z_range, n)
+    eul = np.stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-np.pi, np.pi, n)], 1)
+    qpos[:, 3:7] = Rotation.from_euler('xyz', eul).as_quat(scalar_first=True)
+    qvel = rng.normal(0, 1.0, (n, 18))
+    qvel[:, 0:3] *= 0.5
+    return qpos, qvel
+
+
+_EMU = None
+
+
+def emu_lib():
+    global _EMU
+    if _EMU is None:
+        d = ROOT / 'tests' / 'simt_emu'
+        subprocess.run(['make', '-s', '-C', str(d)], check=True, capture_output=True)
+        _EMU = C.CDLL(str(d / 'libgq_emu.so'))
+    return _EMU
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=None, cmd=None, obs_names=ALL_OBS,
+             legs_order=(0, 1, 2, 3), mask=None, debug_envs=0):
+    """Run the kernel body under the emulator. Arrays are updated in place like the device tensors would be."""
+    L = emu_lib()
+    n = qpos.shape[0]
+    ids = np.asarray(obs_ids_from_names(obs_names), dtype=np.int32)
+    od = int(sum(OBS_DIMS[i] for i in ids))
+    f32 = lambda a, shape: np.zeros(shape, np.float32) if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    st = dict(
+        ctrl=f32(ctrl, (n, 12)), qpos=np.ascontiguousarray(qpos, dtype=np.float64), qvel=f32(qvel, (n, 18)),
+        qacc=np.zeros((n, 18), np.float32), warm=f32(warm, (n, 18)), applied=f32(applied, (n, 18)),
+        time=f32(time, (n,)), friction=np.full(n, -1, np.float32) if friction is None else f32(friction, (n,)),
+        cmd=f32(cmd, (n, 4)), obs=np.zeros((n, od), np.float32), reward=np.zeros(n, np.float32),
+        terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8), invalid=np.zeros(n, np.uint8),
+        step_num=np.zeros(n, np.int32), debug=np.zeros((max(debug_envs, 1), DBG_SIZE), np.float32))
+    lo = np.asarray(legs_order, dtype=np.int32)
+    err = C.create_string_buffer(512)
+    m8 = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    rc = L.emu_step(C.byref(mm.desc), n, _p(ids), len(ids), _p(lo), _p(st['ctrl']), _p(m8), _p(st['qpos']), _p(st['qvel']),
+                    _p(st['qacc']), _p(st['warm']), _p(st['applied']), _p(st['time']), _p(st['friction']), _p(st['cmd']),
+                    _p(st['obs']), _p(st['reward']), _p(st['terminated']), _p(st['truncated']), _p(st['invalid']),
+                    _p(st['step_num']), _p(st['debug']), debug_envs, err, 512)
+    if rc < 0:
+        raise RuntimeError(err.value.decode())
+    st['obs_names'] = list(obs_names)
+    return st
+
+
+def dbg(rec, name):
+    o, n = DBG[name]
+    return rec[o:o + n]
+
+
+def split_obs(row, obs_names):
+    out, k = {}, 0
+    for nme in obs_names:
+        d = OBS_DIMS[ALL_OBS.index(nme)]
+        out[nme] = row[k:k + d]
+        k += d
+    return out

@@ -1,0 +1,38 @@
+/* TEST INFRASTRUCTURE - runs the unmodified step kernel body (csrc/gq_step_body.h) under the host SIMT emulator.
+ * Exposes a C entry point with the same tensors as gq_step, operating on host memory. */
+#include <functional>
+#include <vector>
+#include <cstdio>
+
+#include "gq_device.h"          /* the emulator shim (this directory comes first on the include path) */
+#include "gq_step_body.h"
+#include "gq_host_model.h"
+
+void emu_run_wave(unsigned block, unsigned nblocks, const std::function<void()>& body);
+
+extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_ids, int n_obs, const int32_t* legs_order,
+                        const float* ctrl, const uint8_t* mask, double* qpos, float* qvel, float* qacc, float* warm,
+                        const float* applied, float* time, const float* friction, const float* cmd, float* obs,
+                        float* reward, uint8_t* terminated, uint8_t* truncated, uint8_t* invalid_contact,
+                        int32_t* step_num, float* debug, int debug_envs, char* err, int errlen) {
+  static GqDevModel M;
+  static GqDevBatch B;
+  std::vector<float> vx, vy, vz;
+  if (gq_build_dev_model(desc, &M, &vx, &vy, &vz, err, (size_t)errlen)) return -1;
+  if (gq_build_dev_batch(n_envs, obs_ids, n_obs, legs_order, &B, err, (size_t)errlen)) return -1;
+  B.debug_envs = debug_envs;
+  gq::StepArgs a{};
+  a.model = &M; a.batch = &B; a.vx = vx.data(); a.vy = vy.data(); a.vz = vz.data();
+  a.ctrl = ctrl; a.mask = mask; a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied;
+  a.time = time; a.friction = friction; a.cmd = cmd; a.obs = obs; a.reward = reward; a.terminated = terminated;
+  a.truncated = truncated; a.invalid_contact = invalid_contact; a.step_num = step_num; a.debug = debug; a.n_envs = n_envs;
+  for (int e = 0; e < n_envs; e++) {
+    if (mask && !mask[e]) continue;
+    emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
+      __shared__ gq::WaveMem W;
+      __shared__ float acc[4][21];
+      gq::step_wave(a, W, acc);
+    });
+  }
+  return B.obs_dim;
+}

@@ -1,0 +1,57 @@
+/*
+ * TEST INFRASTRUCTURE - host SIMT emulator shim.
+ *
+ * tests/simt_emu/ compiles the UNMODIFIED kernel sources of gym_quadruped_amd/csrc/ with g++ and runs one
+ * 64-lane "wavefront" as 64 ucontext coroutines, so kernel logic can be checked against the oracle in the
+ * GPU-less container.  This header shadows csrc/gq_device.h (it is found first on the include path of the
+ * emulator build only) and provides the handful of wave primitives the kernels use.  Cross-lane primitives
+ * rendezvous all 64 lanes, therefore kernels must call them from wave-uniform control flow only - the same
+ * discipline the hardware versions need for full-wave semantics.  The product never builds or loads this.
+ */
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <algorithm>
+
+#define GQ_WAVE 64
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline
+#define __restrict__
+#define __launch_bounds__(...)
+
+struct EmuDim3 { unsigned x, y, z; };
+extern EmuDim3 threadIdx, blockIdx, blockDim, gridDim;
+void emu_yield();                 /* switch to the next lane */
+extern uint32_t emu_slot[2][GQ_WAVE];
+extern int emu_phase[GQ_WAVE];
+
+namespace gq {
+static inline int lane_id() { return (int)threadIdx.x; }
+static inline void wave_barrier() { emu_yield(); }
+
+/* deposit a 32-bit value, rendezvous, return pointer to the 64 deposited values (valid until next primitive) */
+static inline const uint32_t* exchange(uint32_t v) {
+  int l = lane_id();
+  int ph = emu_phase[l] ^= 1;
+  emu_slot[ph][l] = v;
+  emu_yield();
+  return emu_slot[ph];
+}
+static inline float bcast(float v, int src) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r; memcpy(&r, &s[src & 63], 4); return r; }
+static inline int bcast(int v, int src) { const uint32_t* s = exchange((uint32_t)v); return (int)s[src & 63]; }
+template <int SRC> static inline float readlane(float v) { return bcast(v, SRC); }
+static inline float shfl_xor(float v, int m) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r; memcpy(&r, &s[lane_id() ^ m], 4); return r; }
+static inline int shfl_xor(int v, int m) { const uint32_t* s = exchange((uint32_t)v); return (int)s[lane_id() ^ m]; }
+static inline uint64_t ballot(bool p) { const uint32_t* s = exchange(p ? 1u : 0u); uint64_t m = 0; for (int i = 0; i < 64; i++) m |= (uint64_t)(s[i] & 1) << i; return m; }
+static inline float wave_sum(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = 0; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r += t; } return r; }
+static inline float wave_min(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::min(r, t); } return r; }
+static inline float wave_max(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = -INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::max(r, t); } return r; }
+static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+static inline float fast_rcp(float x) { return 1.0f / x; }
+static inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
+static inline float med3(float x, float lo, float hi) { return std::min(std::max(x, lo), hi); }
+}  // namespace gq

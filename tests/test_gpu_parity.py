@@ -1,0 +1,148 @@
+"""GPU parity: the HIP path (through the C-ABI / QuadrupedEnv) against the CPU fp64 oracle on identical
+qpos / qvel / ctrl.  Tolerances are fp32-vs-fp64 with the same PGS iteration count:
+  stage internals (M, bias, J, aref, R) rel 1e-4; constraint forces 2e-3 of the largest force;
+  qacc 1e-3 * max|qacc| ; one-step qvel 1e-4 + 1e-5*|.| ; qpos 1e-6 ; observations 2e-3 * max(1, |obs|).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ALL_OBS, marshalled, random_states, split_obs
+
+pytestmark = pytest.mark.gpu
+
+N = 256
+
+
+def _make_env(n, obs=ALL_OBS, iters=50, tol=0.0, **kw):
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    return QuadrupedEnv('mini_cheetah', state_obs_names=tuple(obs), num_envs=n, device='cuda:0',
+                        solver_iterations=iters, solver_tolerance=tol, seed=0, **kw)
+
+
+def _oracle(env):
+    from oracle.oracle import Oracle
+    return Oracle(env._mm)
+
+
+def test_loaded_native_lib():
+    from gym_quadruped_amd import _lib
+    assert _lib.LIB_PATH.exists()
+    _lib.lib()
+
+
+def test_step_matches_oracle_stagewise():
+    env = _make_env(N)
+    rng = np.random.default_rng(0)
+    qpos, qvel = random_states(env.mjModel, N, rng)
+    warm = rng.normal(0, 5, (N, 18)).astype(np.float32)
+    ctrl = (rng.normal(0, 1, (N, 12)) * 30).astype(np.float32)
+    cmd = np.tile(np.array([0.5, 0.1, 0.0, 0.3], np.float32), (N, 1))
+    env.reset(qpos=qpos, qvel=qvel.astype(np.float32))   # explicit-state reset performs one step; overwrite after
+    env._qpos.copy_(torch.as_tensor(qpos)); env._qvel.copy_(torch.as_tensor(qvel.astype(np.float32)))
+    env._warm.copy_(torch.as_tensor(warm)); env._cmd.copy_(torch.as_tensor(cmd)); env._time.zero_()
+    env._friction.fill_(-1.0)
+    ndbg = 32
+    env.enable_debug(ndbg)
+    obs, rew, term, trunc, info = env.step(torch.as_tensor(ctrl))
+    torch.cuda.synchronize()
+    names = ['M', 'qfrc_bias', 'qfrc_smooth', 'qacc_smooth', 'nefc', 'ncon', 'efc_J', 'efc_aref', 'efc_R', 'efc_force', 'qacc']
+    dbg = env.debug_internals(ndbg, names)
+    o = _oracle(env)
+    qpos_g, qvel_g = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
+    obs_g = env._obs_buf.cpu().numpy()
+    term_g, inv_g = term.cpu().numpy(), info['invalid_contacts'].cpu().numpy()
+    n_contact = 0
+    for e in range(N):
+        o.set_state(qpos[e], qvel[e].astype(np.float32), warm[e], np.zeros(18), 0.0, -1.0)
+        o.step(ctrl[e].astype(np.float64))
+        if e < ndbg:
+            d = dbg[e]
+            assert int(d['nefc'][0]) == o.nefc and int(d['ncon'][0]) == o.ncon
+            ne = o.nefc
+            np.testing.assert_allclose(d['M'].reshape(18, 18), o.M, rtol=1e-4, atol=2e-5)
+            np.testing.assert_allclose(d['qfrc_bias'], o.qfrc_bias, rtol=1e-4, atol=2e-3)
+            np.testing.assert_allclose(d['efc_J'].reshape(64, 18)[:ne], o.efc_J, rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(d['efc_aref'][:ne], o.efc_aref, rtol=2e-4, atol=2e-2)
+            np.testing.assert_allclose(d['efc_R'][:ne], o.efc_R, rtol=1e-4)
+            fmax = max(1.0, np.abs(o.efc_force).max())
+            assert np.abs(d['efc_force'][:ne] - o.efc_force).max() < 2e-3 * fmax
+            amax = max(1.0, np.abs(o.qacc).max())
+            assert np.abs(d['qacc'] - o.qacc).max() < 1e-3 * amax
+        n_contact += o.ncon > 0
+        assert np.abs(qpos_g[e] - o.qpos).max() < 1e-6 + 2e-6 * np.abs(o.qpos).max()
+        assert np.abs(qvel_g[e] - o.qvel).max() < 1e-4 + 1e-5 * np.abs(o.qvel).max()
+        ref, t, inv = o.get_obs(ALL_OBS, cmd[e])
+        got = split_obs(obs_g[e], ALL_OBS)
+        for k in ALL_OBS:
+            tol = 2e-3 * max(1.0, np.abs(ref[k]).max())
+            assert np.abs(got[k] - ref[k]).max() < tol, (e, k, got[k], ref[k])
+        assert bool(term_g[e]) == t and bool(inv_g[e]) == inv
+    assert n_contact > N // 4, 'test states must exercise contacts'
+
+
+def test_rollout_tracks_oracle():
+    """20 steps from reset states: trajectories stay within solver/fp32 tolerance of the oracle."""
+    n = 32
+    env = _make_env(n, obs=('qpos', 'qvel'), iters=50)
+    env.reset(random=True)
+    torch.cuda.synchronize()
+    from oracle.oracle import Oracle
+    orc = [Oracle(env._mm) for _ in range(n)]
+    for e, o in enumerate(orc):
+        o.set_state(env.qpos[e].cpu().numpy(), env.qvel[e].cpu().numpy().astype(np.float64),
+                    env._warm[e].cpu().numpy().astype(np.float64), np.zeros(18), float(env._time[e]), float(env._friction[e]))
+    g = torch.Generator(device='cuda:0').manual_seed(3)
+    for s in range(20):
+        act = torch.randn(n, 12, generator=g, device='cuda:0') * 10
+        env.step(act)
+        qp, qv = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
+        for e, o in enumerate(orc):
+            o.step(act[e].cpu().numpy().astype(np.float64))
+            assert np.abs(qp[e] - o.qpos).max() < 5e-4, (s, e)
+            assert np.abs(qv[e] - o.qvel).max() < 5e-2, (s, e)
+
+
+def test_reset_contract_and_shapes():
+    """The reference's own test (tests/env_test.py:14-53) re-expressed for the batch: three resets, shapes, 10 steps."""
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    n = 64
+    env = QuadrupedEnv(robot='mini_cheetah', scene='flat', ref_base_lin_vel=(0.5, 1.0), ground_friction_coeff=(0.2, 1.5),
+                       base_vel_command_type='forward+rotate', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n)
+    state = env.reset()
+    qpos, qvel = state['qpos'].clone(), state['qvel'].clone()
+    state = env.reset(random=True)
+    state = env.reset(qpos=env.qpos.clone(), qvel=env.qvel.clone())
+    for name in QuadrupedEnv.ALL_OBS:
+        assert tuple(state[name].shape) == (n,) + tuple(env.observation_space[name].shape)
+    assert not bool(env.lift_failed.any())
+    fr = env._friction.cpu().numpy()
+    assert np.all(fr >= 0.2) and np.all(fr <= 1.5)
+    cmd = env._cmd.cpu().numpy()
+    assert np.all(cmd[:, 0] >= 0.5) and np.all(cmd[:, 0] <= 1.0) and np.all(cmd[:, 1] == 0)
+    for _ in range(10):
+        action = torch.as_tensor(np.stack([env.action_space.sample() for _ in range(n)])) * 50
+        state, reward, term, trunc, info = env.step(action)
+    torch.cuda.synchronize()
+    assert torch.isfinite(state['qpos']).all() and torch.isfinite(state['qvel']).all()
+    assert int(info['step_num'][0]) == 9 and abs(float(info['time'][0]) - 11 * 0.002) < 1e-6
+
+
+def test_full_size_invariants():
+    """4096 envs (BASELINE config 2): finite state, unit quaternions, no feet below the floor by more than the
+    soft-contact depth, energy bounded; auto-reset keeps every env alive over a 200-step random rollout."""
+    n = 4096
+    env = _make_env(n, obs=('qpos', 'qvel', 'feet_pos', 'kinetic_energy'), iters=50, tol=1e-8, auto_reset=True)
+    env.reset(random=True)
+    g = torch.Generator(device='cuda:0').manual_seed(0)
+    nterm = 0
+    for _ in range(200):
+        obs, rew, term, trunc, info = env.step(torch.randn(n, 12, generator=g, device='cuda:0') * 50)
+        nterm += int(term.sum())
+    torch.cuda.synchronize()
+    q = env.qpos
+    assert torch.isfinite(q).all() and torch.isfinite(env.qvel).all()
+    assert (q[:, 3:7].norm(dim=1) - 1).abs().max() < 1e-5
+    assert obs['feet_pos'].reshape(n, 4, 3)[:, :, 2].min() > -0.02
+    assert obs['kinetic_energy'].max() < 1e4
+    assert nterm > 0, 'random +-50 Nm actions must terminate some envs'
