@@ -25,6 +25,7 @@ def lib():
     if not LIB_PATH.exists():
         raise GqError(f'{LIB_PATH} not found: build the HIP extension first (python -c "import __graft_entry__ as g; '
                       f'g.build()" or make -C gym_quadruped_amd/csrc). There is no CPU fallback.')
+    import torch  # noqa: F401  - load torch's HIP runtime first so libgq.so binds to the same one
     L = C.CDLL(str(LIB_PATH))
     L.gq_last_error.restype = C.c_char_p
     L.gq_model_create.argtypes = [C.POINTER(GqModelDesc), C.c_int, C.POINTER(C.c_void_p)]

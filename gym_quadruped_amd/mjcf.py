@@ -146,11 +146,24 @@ def _load_mesh_vertices(path: Path) -> np.ndarray:
     raise ValueError(f'unsupported mesh format {path}')
 
 
+HULL_MERGE_TOL = 1e-4  # [m] hull vertices closer than this are merged (a tenth of the usual 1 mm contact margin)
+
+
 def _hull_vertices(v: np.ndarray) -> np.ndarray:
-    from scipy.spatial import ConvexHull
+    """Convex-hull vertices of a mesh, with near-duplicate hull vertices (scan artefacts of the OBJ/STL files,
+    some only micrometres apart) merged greedily within HULL_MERGE_TOL."""
+    from scipy.spatial import ConvexHull, cKDTree
 
     v = np.unique(np.round(v, 9), axis=0)
-    return v[np.sort(ConvexHull(v).vertices)]
+    h = v[np.sort(ConvexHull(v).vertices)]
+    tree = cKDTree(h)
+    keep = np.ones(len(h), dtype=bool)
+    for i in range(len(h)):
+        if keep[i]:
+            for j in tree.query_ball_point(h[i], HULL_MERGE_TOL):
+                if j > i:
+                    keep[j] = False
+    return h[keep]
 
 
 # ----------------------------------------------------------------------------- model description

@@ -51,6 +51,7 @@ enum { EFC_FRICTION_DOF = 0, EFC_LIMIT_JOINT = 1, EFC_CONTACT_FRICTIONLESS = 2, 
 
 typedef struct {
   double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
+  double tiegap; /* depth gap to the second deepest vertex of the geom's cloud (test diagnostics) */
   int geom, body, dim, efc_address;
 } Contact;
 
@@ -447,18 +448,20 @@ static void gqo_collision(GqOracle* o) {
     double r = m->cloud_radius[cl];
     /* bounding-sphere cull (mj broadphase equivalent for a plane) */
     if (o->geom_xpos[g][2] - m->geom_rbound[g] > margin) continue;
-    double best = 1e300, bv[3] = {0, 0, 0};
+    double best = 1e300, second = 1e300, bv[3] = {0, 0, 0};
     for (int v = 0; v < m->cloud_vertnum[cl]; v++) {
       double w[3];
       mulmatvec3(w, o->geom_xmat[g], m->vert_pos + 3 * (m->cloud_vertadr[cl] + v));
       for (int k = 0; k < 3; k++) w[k] += o->geom_xpos[g][k];
       double dist = w[2] - r;
-      if (dist < best) { best = dist; memcpy(bv, w, sizeof bv); }
+      if (dist < best) { second = best; best = dist; memcpy(bv, w, sizeof bv); }
+      else if (dist < second) second = dist;
     }
     if (best >= margin) continue;
     Contact* c = &o->contact[o->ncon++];
     c->geom = g; c->body = m->geom_bodyid[g];
     c->dist = best;
+    c->tiegap = second - best;
     /* contact point midway between the surfaces: (vertex - r*n) - n*dist/2 */
     for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - normal[k] * (r + 0.5 * best);
     memcpy(c->frame, normal, sizeof normal);
@@ -1041,6 +1044,7 @@ int gqo_get(const GqOracle* o, const char* name, double* out, int max_n) {
   if (!strcmp(name, "solver_niter")) { out[0] = o->solver_niter; return 1; }
   if (!strcmp(name, "warning")) { out[0] = o->warning; return 1; }
   if (!strcmp(name, "contact_dist")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].dist; return n; }
+  if (!strcmp(name, "contact_tiegap")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].tiegap; return n; }
   if (!strcmp(name, "contact_geom")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].geom; return n; }
   if (!strcmp(name, "contact_body")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].body; return n; }
   if (!strcmp(name, "contact_pos")) { int n = 3 * o->ncon < max_n ? 3 * o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i / 3].pos[i % 3]; return n; }

@@ -52,10 +52,16 @@ def test_step_matches_oracle_stagewise():
     qpos_g, qvel_g = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
     obs_g = env._obs_buf.cpu().numpy()
     term_g, inv_g = term.cpu().numpy(), info['invalid_contacts'].cpu().numpy()
-    n_contact = 0
+    n_contact, n_tie = 0, 0
     for e in range(N):
         o.set_state(qpos[e], qvel[e].astype(np.float32), warm[e], np.zeros(18), 0.0, -1.0)
         o.step(ctrl[e].astype(np.float64))
+        # a link geom resting on two hull vertices of (numerically) equal depth has no unique "deepest vertex":
+        # fp32 and fp64 may legitimately pick different ones.  Such envs are only checked for sanity.
+        if o.ncon and o.get('contact_tiegap').min() < 3e-7:
+            n_tie += 1
+            assert np.all(np.isfinite(qvel_g[e])) and np.abs(qvel_g[e] - o.qvel).max() < 0.05
+            continue
         if e < ndbg:
             d = dbg[e]
             assert int(d['nefc'][0]) == o.nefc and int(d['ncon'][0]) == o.ncon
@@ -79,6 +85,7 @@ def test_step_matches_oracle_stagewise():
             assert np.abs(got[k] - ref[k]).max() < tol, (e, k, got[k], ref[k])
         assert bool(term_g[e]) == t and bool(inv_g[e]) == inv
     assert n_contact > N // 4, 'test states must exercise contacts'
+    assert n_tie < N // 10
 
 
 def test_rollout_tracks_oracle():
