@@ -111,3 +111,32 @@ def split_obs(row, obs_names):
         out[nme] = row[k:k + d]
         k += d
     return out
+
+
+def emu_reset(mm, n, cfg, qpos_new=None, qvel_new=None, mask=None, episode=None):
+    """Run the reset kernel body under the emulator; returns dict of host arrays."""
+    L = emu_lib()
+    st = dict(qpos=np.zeros((n, 19)), qvel=np.zeros((n, 18), np.float32), qacc=np.ones((n, 18), np.float32),
+              warm=np.ones((n, 18), np.float32), applied=np.ones((n, 18), np.float32), time=np.ones(n, np.float32),
+              cmd=np.zeros((n, 4), np.float32), friction_next=np.zeros(n, np.float32), step_num=np.full(n, 7, np.int32),
+              episode=np.zeros(n, np.int32) if episode is None else np.ascontiguousarray(episode, dtype=np.int32),
+              lift_failed=np.zeros(n, np.uint8))
+    err = C.create_string_buffer(512)
+    m8 = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    qn = None if qpos_new is None else np.ascontiguousarray(qpos_new, dtype=np.float64)
+    vn = None if qvel_new is None else np.ascontiguousarray(qvel_new, dtype=np.float32)
+    rc = L.emu_reset(C.byref(mm.desc), n, _p(m8), _p(qn), _p(vn), C.byref(cfg), _p(st['qpos']), _p(st['qvel']), _p(st['qacc']),
+                     _p(st['warm']), _p(st['applied']), _p(st['time']), _p(st['cmd']), _p(st['friction_next']),
+                     _p(st['step_num']), _p(st['episode']), _p(st['lift_failed']), err, 512)
+    if rc < 0:
+        raise RuntimeError(err.value.decode())
+    return st
+
+
+def default_reset_cfg(seed=0, random=1, hip_height=0.225, lin=(0.5, 0.5), ang=(0.0, 0.0), fric=(1.0, 1.0), cmd='forward'):
+    from gym_quadruped_amd.cabi import GqResetCfg
+    return GqResetCfg(seed=seed, random=random, q_pos_amp=20 * np.pi / 180, q_vel_amp=0.5, roll_sweep=10 * np.pi / 180,
+                      pitch_sweep=10 * np.pi / 180, hip_height=hip_height, lin_vel_range=(C.c_float * 2)(*lin),
+                      ang_vel_range=(C.c_float * 2)(*ang), friction_range=(C.c_float * 2)(*fric),
+                      cmd_forward=int('forward' in cmd), cmd_random=int('forward' not in cmd and 'random' in cmd),
+                      cmd_rotate=int('rotate' in cmd), cmd_human=int('human' in cmd))

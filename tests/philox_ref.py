@@ -1,0 +1,27 @@
+"""numpy restatement of the device RNG stream used by the reset kernel (csrc/gq_step_body.h): Philox4x32-10,
+key = (seed_lo, seed_hi), counter = (draw >> 2, episode, env, 0x5eed), uniform = (word >> 8) * 2^-24.
+Draw indices: 0-11 joint angle noise, 12-23 joint velocity noise, 24 x, 25 y, 26 roll, 27 pitch, 28 |v| command,
+29 heading, 30 yaw rate, 31 friction."""
+import numpy as np
+
+M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32(counter, key):
+    c = [int(x) & 0xffffffff for x in counter]
+    k = [int(x) & 0xffffffff for x in key]
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+        k = [(k[0] + W0) & 0xffffffff, (k[1] + W1) & 0xffffffff]
+    return c
+
+
+def draws(seed, env, episode):
+    """The 32 float32 uniforms of one reset."""
+    u = np.zeros(32, dtype=np.float32)
+    for blk in range(8):
+        w = philox4x32((blk, episode, env, 0x5eed), (seed & 0xffffffff, seed >> 32))
+        for j in range(4):
+            u[4 * blk + j] = np.float32(w[j] >> 8) * np.float32(1.0 / 16777216.0)
+    return u

@@ -36,3 +36,29 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
   }
   return B.obs_dim;
 }
+
+extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mask, const double* qpos_new, const float* qvel_new,
+                         const GqResetCfg* cfg, double* qpos, float* qvel, float* qacc, float* warm, float* applied,
+                         float* time, float* cmd, float* friction_next, int32_t* step_num, int32_t* episode,
+                         uint8_t* lift_failed, char* err, int errlen) {
+  static GqDevModel M;
+  std::vector<float> vx, vy, vz;
+  if (gq_build_dev_model(desc, &M, &vx, &vy, &vz, err, (size_t)errlen)) return -1;
+  gq::ResetArgs a{};
+  a.model = &M; a.vx = vx.data(); a.vy = vy.data(); a.vz = vz.data(); a.mask = mask; a.qpos_new = qpos_new; a.qvel_new = qvel_new;
+  a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied; a.time = time; a.cmd = cmd;
+  a.friction_next = friction_next; a.step_num = step_num; a.episode = episode; a.lift_failed = lift_failed;
+  a.cfg.seed_lo = (uint32_t)(cfg->seed & 0xffffffffu); a.cfg.seed_hi = (uint32_t)(cfg->seed >> 32);
+  a.cfg.random = cfg->random; a.cfg.q_pos_amp = cfg->q_pos_amp; a.cfg.q_vel_amp = cfg->q_vel_amp;
+  a.cfg.roll_sweep = cfg->roll_sweep; a.cfg.pitch_sweep = cfg->pitch_sweep; a.cfg.hip_height = cfg->hip_height;
+  for (int k = 0; k < 2; k++) { a.cfg.lin_vel_range[k] = cfg->lin_vel_range[k]; a.cfg.ang_vel_range[k] = cfg->ang_vel_range[k]; a.cfg.friction_range[k] = cfg->friction_range[k]; }
+  a.cfg.cmd_forward = cfg->cmd_forward; a.cfg.cmd_random = cfg->cmd_random; a.cfg.cmd_rotate = cfg->cmd_rotate; a.cfg.cmd_human = cfg->cmd_human;
+  for (int e = 0; e < n_envs; e++) {
+    if (mask && !mask[e]) continue;
+    emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
+      __shared__ gq::WaveMem W;
+      gq::reset_wave(a, W);
+    });
+  }
+  return 0;
+}

@@ -1,0 +1,100 @@
+"""The UNMODIFIED HIP kernel bodies (csrc/gq_step_body.h) executed by the host SIMT emulator (tests/simt_emu) against
+the CPU oracle: same parity contract as tests/test_gpu_parity.py, runnable without a GPU."""
+import numpy as np
+import pytest
+
+from helpers import ALL_OBS, dbg, default_reset_cfg, emu_reset, emu_step, marshalled, random_states, split_obs
+from oracle.oracle import Oracle
+from philox_ref import draws
+
+
+def test_step_stagewise_and_obs():
+    n = 24
+    mm = marshalled('mini_cheetah', solver=0, iterations=30, tolerance=0.0)
+    rng = np.random.default_rng(11)
+    qpos, qvel = random_states(mm.md, n, rng)
+    qvel = qvel.astype(np.float32)
+    warm = rng.normal(0, 5, (n, 18)).astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 40).astype(np.float32)   # beyond ctrlrange: exercises the clamp
+    cmd = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    fric = np.where(np.arange(n) % 2 == 0, -1.0, 0.55).astype(np.float32)
+    lo = (2, 0, 3, 1)
+    st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), warm=warm.copy(), cmd=cmd, friction=fric, legs_order=lo, debug_envs=n)
+    o = Oracle(mm)
+    ncon_total = 0
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e], warm[e], np.zeros(18), 0.0, float(fric[e]))
+        o.step(ctrl[e].astype(np.float64))
+        if o.ncon and o.get('contact_tiegap').min() < 3e-7:
+            continue
+        rec = st['debug'][e]
+        ne = o.nefc
+        ncon_total += o.ncon
+        assert int(dbg(rec, 'nefc')[0]) == ne and int(dbg(rec, 'ncon')[0]) == o.ncon
+        np.testing.assert_allclose(dbg(rec, 'M').reshape(18, 18), o.M, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(dbg(rec, 'qfrc_bias'), o.qfrc_bias, rtol=1e-5, atol=5e-4)
+        np.testing.assert_allclose(dbg(rec, 'efc_J').reshape(64, 18)[:ne], o.efc_J, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(dbg(rec, 'efc_R')[:ne], o.efc_R, rtol=1e-5)
+        np.testing.assert_allclose(dbg(rec, 'efc_aref')[:ne], o.efc_aref, rtol=1e-4, atol=1e-2)
+        fmax = max(1.0, np.abs(o.efc_force).max())
+        assert np.abs(dbg(rec, 'efc_force')[:ne] - o.efc_force).max() < 1e-4 * fmax
+        assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 2e-5 * max(1.0, np.abs(o.qacc).max())
+        assert np.abs(st['qvel'][e] - o.qvel).max() < 5e-5
+        assert np.abs(st['qpos'][e] - o.qpos).max() < 1e-6
+        ref, term, inv = o.get_obs(ALL_OBS, cmd[e], lo)
+        got = split_obs(st['obs'][e], ALL_OBS)
+        for k in ALL_OBS:
+            assert np.abs(got[k] - ref[k]).max() < 2e-4 * max(1.0, np.abs(ref[k]).max()), (e, k)
+        assert bool(st['terminated'][e]) == term and bool(st['invalid'][e]) == inv
+        assert st['step_num'][e] == 1 and abs(st['time'][e] - 0.002) < 1e-9 and st['reward'][e] == 0
+    assert ncon_total > 30
+
+
+def test_mask_leaves_other_envs_untouched():
+    mm = marshalled('mini_cheetah', iterations=5)
+    rng = np.random.default_rng(2)
+    qpos, qvel = random_states(mm.md, 4, rng)
+    q0, v0 = qpos.copy(), qvel.astype(np.float32).copy()
+    st = emu_step(mm, np.zeros((4, 12)), qpos, qvel, mask=[1, 0, 0, 1])
+    assert np.array_equal(st['qpos'][1], q0[1]) and np.array_equal(st['qvel'][2], v0[2])
+    assert not np.array_equal(st['qpos'][0], q0[0]) and st['step_num'].tolist() == [1, 0, 0, 1]
+
+
+def test_out_of_bounds_terminates_far_from_origin_in_f64():
+    """Base x/y are carried in f64: 1 mm steps at |x| = 9999.9995 m are resolved and the terrain limit trips."""
+    mm = marshalled('mini_cheetah', iterations=5)
+    q = np.tile(mm.md.key_qpos[0], (2, 1)); q[:, 2] = 1.0
+    q[0, 0] = 9999.9995; q[1, 0] = 9999.0
+    v = np.zeros((2, 18), np.float32); v[:, 0] = 0.5
+    st = emu_step(mm, np.zeros((2, 12)), q, v)
+    assert abs(st['qpos'][0, 0] - (9999.9995 + 0.002 * 0.5)) < 1e-9
+    assert st['terminated'].tolist() == [1, 0]
+
+
+def test_reset_kernel_stream_lift_and_bookkeeping():
+    mm = marshalled('mini_cheetah', terrain_limits=(5, -5, 5, -5))
+    seed = 987654321987
+    cfg = default_reset_cfg(seed=seed, lin=(0.5, 1.0), ang=(-0.3, 0.3), fric=(0.2, 1.5), cmd='random+rotate')
+    n = 6
+    st = emu_reset(mm, n, cfg, episode=np.arange(n))
+    o = Oracle(mm)
+    key = mm.md.key_qpos[0]
+    for e in range(n):
+        u = draws(seed, e, e)
+        np.testing.assert_allclose(st['qpos'][e, 7:], key[7:] + (2 * u[0:12] - 1) * np.float32(20 * np.pi / 180), atol=1e-6)
+        np.testing.assert_allclose(st['qvel'][e, 6:], (2 * u[12:24] - 1) * 0.5, atol=1e-6)
+        assert abs(st['qpos'][e, 0] - (5 - 10 * float(u[24]))) < 1e-9 and abs(st['qpos'][e, 1] - (5 - 10 * float(u[25]))) < 1e-9
+        norm, head = 0.5 + 0.5 * u[28], (2 * u[29] - 1) * np.pi
+        np.testing.assert_allclose(st['cmd'][e], [norm * np.cos(head), norm * np.sin(head), 0, -0.3 + 0.6 * u[30]], atol=1e-5)
+        assert abs(st['friction_next'][e] - (0.2 + 1.3 * u[31])) < 1e-6
+        assert st['episode'][e] == e + 1 and st['step_num'][e] == -1 and st['time'][e] == 0 and not st['lift_failed'][e]
+        assert not st['qacc'][e].any() and not st['warm'][e].any() and not st['applied'][e].any()
+        # lift loop: no foot-body contact at the final height, and the base was raised above hip_height
+        o.set_state(st['qpos'][e], st['qvel'][e].astype(np.float64), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12), stage=1)
+        calf = [b for b in o.get('contact_body')] if o.ncon else []
+        assert all((int(b) - 2) % 3 != 2 for b in calf), 'a calf body still touches the floor'
+        assert st['qpos'][e, 2] >= 0.225 - 1e-6
+    # explicit state: copied verbatim, no lift
+    qn = np.tile(key, (2, 1)); qn[:, 2] = 0.05
+    st2 = emu_reset(mm, 2, cfg, qpos_new=qn, qvel_new=np.ones((2, 18), np.float32))
+    assert np.array_equal(st2['qpos'], qn) and np.all(st2['qvel'] == 1)
