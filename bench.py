@@ -97,7 +97,7 @@ def main():
     n = args.envs_per_gpu
     env = QuadrupedEnv('mini_cheetah', state_obs_names=obs_names, scene='flat', num_envs=n, device=device,
                        auto_reset=not args.no_auto_reset, solver_iterations=100, solver_tolerance=1e-8,
-                       seed=1000 + rank)  # env shards draw from disjoint RNG keys
+                       seed=1000, env_id_offset=rank * n)  # shards: disjoint global env ids -> disjoint RNG counters
     env.reset(random=True)
     g = torch.Generator(device=device).manual_seed(rank)
     pool = [torch.randn(n, 12, generator=g, device=device) * 50 for _ in range(64)]

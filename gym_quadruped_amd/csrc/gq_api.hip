@@ -155,7 +155,7 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   a.cfg.random = cfg->random; a.cfg.q_pos_amp = cfg->q_pos_amp; a.cfg.q_vel_amp = cfg->q_vel_amp;
   a.cfg.roll_sweep = cfg->roll_sweep; a.cfg.pitch_sweep = cfg->pitch_sweep; a.cfg.hip_height = cfg->hip_height;
   for (int k = 0; k < 2; k++) { a.cfg.lin_vel_range[k] = cfg->lin_vel_range[k]; a.cfg.ang_vel_range[k] = cfg->ang_vel_range[k]; a.cfg.friction_range[k] = cfg->friction_range[k]; }
-  a.cfg.cmd_forward = cfg->cmd_forward; a.cfg.cmd_random = cfg->cmd_random; a.cfg.cmd_rotate = cfg->cmd_rotate; a.cfg.cmd_human = cfg->cmd_human;
+  a.cfg.cmd_forward = cfg->cmd_forward; a.cfg.cmd_random = cfg->cmd_random; a.cfg.cmd_rotate = cfg->cmd_rotate; a.cfg.cmd_human = cfg->cmd_human; a.cfg.env_id_offset = cfg->env_id_offset;
   gq_launch_reset(&a, b->host.n_envs, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */

@@ -698,7 +698,7 @@ struct ResetCfgDev {
   int32_t random;
   float q_pos_amp, q_vel_amp, roll_sweep, pitch_sweep, hip_height;
   float lin_vel_range[2], ang_vel_range[2], friction_range[2];
-  int32_t cmd_forward, cmd_random, cmd_rotate, cmd_human;
+  int32_t cmd_forward, cmd_random, cmd_rotate, cmd_human, env_id_offset;
 };
 struct ResetArgs {
   const GqDevModel* model;
@@ -737,7 +737,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   /* one uniform in [0,1) per lane < 32 */
   float u = 0.0f;
   if (lane < 32) {
-    uint32_t x = philox4x32((uint32_t)(lane >> 2), (uint32_t)episode, (uint32_t)env, 0x5eedu, c.seed_lo, c.seed_hi, lane & 3);
+    uint32_t x = philox4x32((uint32_t)(lane >> 2), (uint32_t)episode, (uint32_t)(env + c.env_id_offset), 0x5eedu, c.seed_lo, c.seed_hi, lane & 3);
     u = (float)(x >> 8) * (1.0f / 16777216.0f);
   }
   W.obs[lane] = u; /* scratch: publish the draws */

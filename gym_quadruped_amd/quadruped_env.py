@@ -90,6 +90,7 @@ class QuadrupedEnv:
         solver_tolerance: float = 1e-8,
         seed: int | None = None,
         mjcf_path: str | None = None,
+        env_id_offset: int = 0,
     ):
         self._save_hyperparameters(constructor_params=locals().copy())
         log.info(f'Initializing {robot} environment with scene {scene}.')
@@ -214,7 +215,7 @@ class QuadrupedEnv:
             ang_vel_range=(C.c_float * 2)(*map(float, self.base_ang_vel_range)),
             friction_range=(C.c_float * 2)(*map(float, self.ground_friction_coeff_range)),
             cmd_forward=int('forward' in t), cmd_random=int('forward' not in t and 'random' in t),
-            cmd_rotate=int('rotate' in t), cmd_human=int('human' in t))
+            cmd_rotate=int('rotate' in t), cmd_human=int('human' in t), env_id_offset=int(env_id_offset))
 
         self.external_disturbances_kwargs = external_disturbances_kwargs
         if self.external_disturbances_kwargs is not None:

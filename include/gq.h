@@ -212,6 +212,7 @@ typedef struct GqResetCfg {
   float ang_vel_range[2];   /* ref_base_ang_vel (min,max) (:142) */
   float friction_range[2];  /* ground_friction_coeff (min,max) (:143) */
   int32_t cmd_forward, cmd_random, cmd_rotate, cmd_human; /* substrings of base_vel_command_type (:1049-1066) */
+  int32_t env_id_offset;    /* global id of env 0 of this batch (multi-GPU shards draw from disjoint counters) */
 } GqResetCfg;
 
 /* QuadrupedEnv.reset (quadruped_env.py:309-406) for the envs with mask != 0 (mask NULL = all), two launches:
