@@ -33,7 +33,8 @@ def lib():
     L.gq_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.gq_batch_destroy.argtypes = [C.c_void_p]
     L.gq_batch_obs_dim.argtypes = [C.c_void_p]
-    L.gq_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, GqState, GqObsOut, C.c_void_p]
+    L.gq_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, GqState, GqObsOut, C.POINTER(GqResetCfg), C.c_void_p,
+                          C.c_void_p, C.c_void_p]
     L.gq_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GqResetCfg), GqState, GqObsOut,
                            C.c_void_p, C.c_void_p, C.c_void_p]
     L.gq_debug_enable.argtypes = [C.c_void_p, C.c_int]

@@ -16,7 +16,7 @@
 #include "gq_step_kernel.h"
 #include "gq_step_body.h"
 
-extern "C" void gq_launch_step(const gq::StepArgs* a, int n_envs, hipStream_t stream);
+extern "C" void gq_launch_step(const gq::FusedArgs* a, int n_envs, hipStream_t stream);
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream);
 
 static thread_local char g_err[512] = "";
@@ -120,19 +120,44 @@ int gq_debug_enable(GqBatch* b, int n_debug_envs) {
   return GQ_OK;
 }
 
-int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, void* hip_stream) {
+static void fill_reset_cfg(gq::ResetCfgDev* d, const GqResetCfg* cfg) {
+  d->seed_lo = (uint32_t)(cfg->seed & 0xffffffffu); d->seed_hi = (uint32_t)(cfg->seed >> 32);
+  d->random = cfg->random; d->q_pos_amp = cfg->q_pos_amp; d->q_vel_amp = cfg->q_vel_amp;
+  d->roll_sweep = cfg->roll_sweep; d->pitch_sweep = cfg->pitch_sweep; d->hip_height = cfg->hip_height;
+  for (int k = 0; k < 2; k++) { d->lin_vel_range[k] = cfg->lin_vel_range[k]; d->ang_vel_range[k] = cfg->ang_vel_range[k]; d->friction_range[k] = cfg->friction_range[k]; }
+  d->cmd_forward = cfg->cmd_forward; d->cmd_random = cfg->cmd_random; d->cmd_rotate = cfg->cmd_rotate; d->cmd_human = cfg->cmd_human;
+  d->env_id_offset = cfg->env_id_offset;
+}
+static void fill_step_args(gq::StepArgs* a, GqBatch* b, const float* ctrl, const uint8_t* mask, const GqState& st, const GqObsOut& out) {
+  GqModel* m = b->model;
+  a->model = m->dev; a->batch = b->dev; a->vx = m->vx; a->vy = m->vy; a->vz = m->vz;
+  a->ctrl = ctrl; a->mask = mask; a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart;
+  a->applied = st.qfrc_applied; a->time = st.time; a->friction = st.friction; a->cmd = st.cmd;
+  a->friction_next = b->friction_next;
+  a->obs = out.obs; a->reward = out.reward; a->terminated = out.terminated; a->truncated = out.truncated;
+  a->invalid_contact = out.invalid_contact; a->step_num = out.step_num;
+  a->debug = b->host.debug_envs > 0 ? b->debug : nullptr; a->n_envs = b->host.n_envs;
+}
+static void fill_reset_args(gq::ResetArgs* a, GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new,
+                            const GqResetCfg* cfg, const GqState& st, const GqObsOut& out, int32_t* episode, uint8_t* lift_failed) {
+  GqModel* m = b->model;
+  a->model = m->dev; a->vx = m->vx; a->vy = m->vy; a->vz = m->vz; a->mask = mask; a->qpos_new = qpos_new; a->qvel_new = qvel_new;
+  a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart; a->applied = st.qfrc_applied;
+  a->time = st.time; a->cmd = st.cmd; a->friction_next = st.friction ? b->friction_next : nullptr;
+  a->step_num = out.step_num; a->episode = episode; a->lift_failed = lift_failed;
+  fill_reset_cfg(&a->cfg, cfg);
+}
+
+int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
+            int32_t* episode, uint8_t* lift_failed, void* hip_stream) {
   if (!b || !ctrl || !st.qpos || !st.qvel || !st.qacc || !st.qacc_warmstart || !st.time || !out.obs || !out.reward ||
       !out.terminated || !out.truncated || !out.invalid_contact || !out.step_num) {
     SET_ERR("gq_step: null tensor"); return GQ_EINVAL;
   }
-  gq::StepArgs a{};
-  GqModel* m = b->model;
-  a.model = m->dev; a.batch = b->dev; a.vx = m->vx; a.vy = m->vy; a.vz = m->vz;
-  a.ctrl = ctrl; a.mask = mask; a.qpos = st.qpos; a.qvel = st.qvel; a.qacc = st.qacc; a.warm = st.qacc_warmstart;
-  a.applied = st.qfrc_applied; a.time = st.time; a.friction = st.friction; a.cmd = st.cmd;
-  a.obs = out.obs; a.reward = out.reward; a.terminated = out.terminated; a.truncated = out.truncated;
-  a.invalid_contact = out.invalid_contact; a.step_num = out.step_num;
-  a.debug = b->host.debug_envs > 0 ? b->debug : nullptr; a.n_envs = b->host.n_envs;
+  gq::FusedArgs a{};
+  fill_step_args(&a.s, b, ctrl, mask, st, out);
+  a.auto_reset = auto_reset != nullptr; a.first_pass = 0;
+  if (auto_reset) fill_reset_args(&a.r, b, nullptr, nullptr, nullptr, auto_reset, st, out, episode, lift_failed);
   gq_launch_step(&a, b->host.n_envs, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
@@ -145,29 +170,17 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
     SET_ERR("gq_reset: null tensor"); return GQ_EINVAL;
   }
   if ((qpos_new == nullptr) != (qvel_new == nullptr)) { SET_ERR("gq_reset: qpos_new and qvel_new must be given together"); return GQ_EINVAL; }
-  GqModel* m = b->model;
-  gq::ResetArgs a{};
-  a.model = m->dev; a.vx = m->vx; a.vy = m->vy; a.vz = m->vz; a.mask = mask; a.qpos_new = qpos_new; a.qvel_new = qvel_new;
-  a.qpos = st.qpos; a.qvel = st.qvel; a.qacc = st.qacc; a.warm = st.qacc_warmstart; a.applied = st.qfrc_applied;
-  a.time = st.time; a.cmd = st.cmd; a.friction_next = st.friction ? b->friction_next : nullptr;
-  a.step_num = out.step_num; a.episode = episode; a.lift_failed = lift_failed;
-  a.cfg.seed_lo = (uint32_t)(cfg->seed & 0xffffffffu); a.cfg.seed_hi = (uint32_t)(cfg->seed >> 32);
-  a.cfg.random = cfg->random; a.cfg.q_pos_amp = cfg->q_pos_amp; a.cfg.q_vel_amp = cfg->q_vel_amp;
-  a.cfg.roll_sweep = cfg->roll_sweep; a.cfg.pitch_sweep = cfg->pitch_sweep; a.cfg.hip_height = cfg->hip_height;
-  for (int k = 0; k < 2; k++) { a.cfg.lin_vel_range[k] = cfg->lin_vel_range[k]; a.cfg.ang_vel_range[k] = cfg->ang_vel_range[k]; a.cfg.friction_range[k] = cfg->friction_range[k]; }
-  a.cfg.cmd_forward = cfg->cmd_forward; a.cfg.cmd_random = cfg->cmd_random; a.cfg.cmd_rotate = cfg->cmd_rotate; a.cfg.cmd_human = cfg->cmd_human; a.cfg.env_id_offset = cfg->env_id_offset;
-  gq_launch_reset(&a, b->host.n_envs, (hipStream_t)hip_stream);
+  gq::ResetArgs r{};
+  fill_reset_args(&r, b, mask, qpos_new, qvel_new, cfg, st, out, episode, lift_failed);
+  r.clear_terminated = out.terminated; r.clear_truncated = out.truncated; r.clear_invalid = out.invalid_contact;
+  gq_launch_reset(&r, b->host.n_envs, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */
-  gq::StepArgs s{};
-  s.model = m->dev; s.batch = b->dev; s.vx = m->vx; s.vy = m->vy; s.vz = m->vz;
-  s.ctrl = nullptr; s.mask = mask; s.qpos = st.qpos; s.qvel = st.qvel; s.qacc = st.qacc; s.warm = st.qacc_warmstart;
-  s.applied = st.qfrc_applied; s.time = st.time; s.friction = st.friction; s.cmd = st.cmd;
-  s.friction_commit = st.friction ? b->friction_next : nullptr;
-  s.obs = out.obs; s.reward = out.reward; s.terminated = out.terminated; s.truncated = out.truncated;
-  s.invalid_contact = out.invalid_contact; s.step_num = out.step_num;
-  s.debug = nullptr; s.n_envs = b->host.n_envs;
-  gq_launch_step(&s, b->host.n_envs, (hipStream_t)hip_stream);
+  gq::FusedArgs a{};
+  fill_step_args(&a.s, b, nullptr, mask, st, out);
+  a.s.debug = nullptr;
+  a.auto_reset = 0; a.first_pass = 1;
+  gq_launch_step(&a, b->host.n_envs, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

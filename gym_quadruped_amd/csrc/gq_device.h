@@ -10,7 +10,13 @@
 
 namespace gq {
 
-__device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
+/* The lane index is deliberately opaque to the optimiser (empty asm volatile): per-lane address arithmetic then stays
+ * next to its use instead of being hoisted to the kernel prologue and kept live (or spilled) across the whole step. */
+__device__ __forceinline__ int lane_id() {
+  int l = (int)threadIdx.x;
+  asm volatile("" : "+v"(l));
+  return l;
+}
 
 /* LDS hand-off between lanes of the single wavefront of this workgroup.  With a 64-thread workgroup the
  * s_barrier degenerates (LLVM drops it for single-wave groups) and what remains is the lgkmcnt wait + the
@@ -57,6 +63,13 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
   return v;
 }
+
+/* optimisation barrier: the value becomes opaque to the compiler (no code is emitted) */
+__device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); } /* wave-uniform value */
+
+/* instruction-scheduling fence: nothing moves across it */
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }

@@ -8,6 +8,15 @@
 
 namespace gq {
 
+/* entry (i,j) of the joint-space inertia from its tree-sparse storage */
+__device__ __forceinline__ float m_entry(const WaveMem& W, int i, int j) {
+  if (i < j) { int t = i; i = j; j = t; }
+  if (i < 6) return W.Mb[i][j];
+  if (j < 6) return W.Mc[i - 6][j];
+  if ((i - 6) / 3 != (j - 6) / 3) return 0.0f;
+  return W.Mc[i - 6][6 + (j - 6) % 3];
+}
+
 /* S1 (mj_kinematics): lanes 0-3 walk the leg chains; returns the normalised base quaternion (all lanes) */
 __device__ inline Q4 stage_kinematics(WaveMem& W, const GqDevModel& m) {
   const int lane = lane_id();
@@ -31,8 +40,8 @@ __device__ inline Q4 stage_kinematics(WaveMem& W, const GqDevModel& m) {
       q2mat(R0, q);
       V3 jp = ld3(m.jnt_pos[j]), ax = ld3(m.jnt_axis[j]);
       V3 anchor = pos + matvec(R0, jp);
-      st3(W.anchor[j], anchor);
-      st3(W.axis[j], matvec(R0, ax));
+      st3(W.u.dyn.anchor[j], anchor);
+      st3(W.u.dyn.axis[j], matvec(R0, ax));
       float ang = W.qj[j] - m.qpos0[j];
       float s = sinf(0.5f * ang), c = cosf(0.5f * ang);
       Q4 ql = {c, ax.x * s, ax.y * s, ax.z * s};
@@ -96,15 +105,18 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
   wave_barrier();
 }
 
-__device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]) {
-  const int lane = lane_id();
-  const int env = (int)blockIdx.x;
+/* One mj_step + observation epilogue for this wave's env.  pass 0: the user's step.  pass 1: the reset's own step
+ * (zero control, friction committed afterwards, termination flags of pass 0 are kept).  Returns `terminated`. */
+__device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
+  /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
+   * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
+  int lane_o = lane_id(), env_o = (int)blockIdx.x;
+  opaque(lane_o); opaque_s(env_o);
+  const int lane = lane_o, env = env_o;
   const GqDevModel& m = *a.model;
   const float h = m.timestep;
 
   /* ================================================================ S0: load the env's state rows */
-  /* base x,y stay in f64 (uniform: every lane reads the same two words) and never enter fp32 arithmetic */
-  const double bx_d = a.qpos[(size_t)env * 19 + 0], by_d = a.qpos[(size_t)env * 19 + 1];
   if (lane < 19) {
     double q = a.qpos[(size_t)env * 19 + lane];
     if (lane < 2) { }
@@ -117,12 +129,12 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
     W.warm[lane] = a.warm[(size_t)env * 18 + lane];
     W.applied[lane] = a.applied ? a.applied[(size_t)env * 18 + lane] : 0.0f;
   }
-  if (lane < 12) W.ctrl[lane] = a.ctrl ? a.ctrl[(size_t)env * 12 + lane] : 0.0f;
+  if (lane < 12) W.ctrl[lane] = (a.ctrl && pass == 0) ? a.ctrl[(size_t)env * 12 + lane] : 0.0f;
   if (lane < 4) W.cmd[lane] = a.cmd ? a.cmd[(size_t)env * 4 + lane] : 0.0f;
   const float mu_env = a.friction ? a.friction[env] : -1.0f;
   wave_barrier();
 
-  const Q4 qbase = stage_kinematics(W, m);
+  stage_kinematics(W, m);
 
   /* ================================================================ S2: spatial inertias about O = base origin */
   const V3 O = v3(0.0f, 0.0f, W.basez);
@@ -142,7 +154,7 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
 #pragma unroll
       for (int c = 0; c < 3; c++) Iw[3 * r + c] = T[3 * r] * R[3 * c] + T[3 * r + 1] * R[3 * c + 1] + T[3 * r + 2] * R[3 * c + 2];
     float mb = m.body_mass[b], dd = dot(d, d);
-    float* ci = W.cinert[b];
+    float* ci = W.u.dyn.cinert[b];
     ci[0] = Iw[0] + mb * (dd - d.x * d.x); ci[1] = Iw[4] + mb * (dd - d.y * d.y); ci[2] = Iw[8] + mb * (dd - d.z * d.z);
     ci[3] = Iw[1] - mb * d.x * d.y; ci[4] = Iw[2] - mb * d.x * d.z; ci[5] = Iw[5] - mb * d.y * d.z;
     ci[6] = mb * d.x; ci[7] = mb * d.y; ci[8] = mb * d.z; ci[9] = mb;
@@ -159,44 +171,37 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   wave_barrier();
   if (lane >= 6 && lane < GQ_NVD) {
     const int j = lane - 6;
-    V3 ax = ld3(W.axis[j]);
+    V3 ax = ld3(W.u.dyn.axis[j]);
     st3(W.cdof[lane], ax);
-    st3(W.cdof[lane] + 3, cross(ax, O - ld3(W.anchor[j])));
+    st3(W.cdof[lane] + 3, cross(ax, O - ld3(W.u.dyn.anchor[j])));
   }
   /* composite inertias: everything is about the same point in the same axes, so they are plain sums */
   if (lane < 40) {
     const int leg = lane / 10, k = lane % 10, b0 = 1 + 3 * leg;
-    float c2 = W.cinert[b0 + 2][k], c1 = W.cinert[b0 + 1][k] + c2, c0 = W.cinert[b0][k] + c1;
-    W.crb[b0 + 2][k] = c2; W.crb[b0 + 1][k] = c1; W.crb[b0][k] = c0;
+    float c2 = W.u.dyn.cinert[b0 + 2][k], c1 = W.u.dyn.cinert[b0 + 1][k] + c2, c0 = W.u.dyn.cinert[b0][k] + c1;
+    W.u.dyn.crb[b0 + 2][k] = c2; W.u.dyn.crb[b0 + 1][k] = c1; W.u.dyn.crb[b0][k] = c0;
   }
   wave_barrier();
-  if (lane < 10) W.crb[0][lane] = W.cinert[0][lane] + W.crb[1][lane] + W.crb[4][lane] + W.crb[7][lane] + W.crb[10][lane];
+  if (lane < 10) W.u.dyn.crb[0][lane] = W.u.dyn.cinert[0][lane] + W.u.dyn.crb[1][lane] + W.u.dyn.crb[4][lane] + W.u.dyn.crb[7][lane] + W.u.dyn.crb[10][lane];
   wave_barrier();
 
   /* ================================================================ S3: joint-space inertia */
   if (lane < GQ_NVD) {
     float buf[6];
-    mul_inert(buf, W.crb[dof_body(lane)], W.cdof[lane]);
+    mul_inert(buf, W.u.dyn.crb[dof_body(lane)], W.cdof[lane]);
     for (int j = lane; j >= 0; j = dof_parent(j)) {
       const float* s = W.cdof[j];
       float v = s[0] * buf[0] + s[1] * buf[1] + s[2] * buf[2] + s[3] * buf[3] + s[4] * buf[4] + s[5] * buf[5];
       if (j == lane) v += m.dof_armature[lane];
-      W.M[lane][j] = v; W.M[j][lane] = v;
+      if (lane < 6) { W.Mb[lane][j] = v; W.Mb[j][lane] = v; }
+      else W.Mc[lane - 6][j < 6 ? j : 6 + (j - 6) % 3] = v;
     }
-    /* entries between different legs are structurally zero */
-    for (int j = 6; j < GQ_NVD; j++)
-      if (lane >= 6 && (j - 6) / 3 != (lane - 6) / 3) W.M[lane][j] = 0.0f;
   }
   wave_barrier();
 
   /* ================================================================ S4: factorise M and M + h*D */
-  {
-    float zero18[GQ_NVD], hd[GQ_NVD];
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) { zero18[k] = 0.0f; hd[k] = h * m.dof_damping[k]; }
-    factor_tree(W, 0, zero18, acc);
-    factor_tree(W, 1, hd, acc);
-  }
+  factor_tree(W, 0, m.dof_damping, 0.0f);
+  factor_tree(W, 1, m.dof_damping, h);
 
   /* ================================================================ S5: velocity stage (mj_comVel, mj_rne) */
   if (lane < 4) {
@@ -211,7 +216,7 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
       ab[0] = ab[1] = ab[2] = 0.0f; ab[3] = al.x; ab[4] = al.y; ab[5] = al.z - m.gravity_z;
       if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) { W.cvel[0][k] = vb[k]; W.cacc[0][k] = ab[k]; }
+        for (int k = 0; k < 6; k++) { W.u.dyn.cvel[0][k] = vb[k]; W.u.dyn.cacc[0][k] = ab[k]; }
       }
     }
     for (int i = 0; i < 3; i++) {
@@ -220,30 +225,30 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
       cross_motion(cd, vb, W.cdof[d]);
       float qd = W.qvel[d];
 #pragma unroll
-      for (int k = 0; k < 6; k++) { vb[k] += W.cdof[d][k] * qd; ab[k] += cd[k] * qd; W.cvel[b][k] = vb[k]; W.cacc[b][k] = ab[k]; }
+      for (int k = 0; k < 6; k++) { vb[k] += W.cdof[d][k] * qd; ab[k] += cd[k] * qd; W.u.dyn.cvel[b][k] = vb[k]; W.u.dyn.cacc[b][k] = ab[k]; }
     }
   }
   wave_barrier();
   if (lane < GQ_NB) {
     float t1[6], t2[6], f[6];
-    mul_inert(t1, W.cinert[lane], W.cacc[lane]);
-    mul_inert(t2, W.cinert[lane], W.cvel[lane]);
-    cross_force(f, W.cvel[lane], t2);
+    mul_inert(t1, W.u.dyn.cinert[lane], W.u.dyn.cacc[lane]);
+    mul_inert(t2, W.u.dyn.cinert[lane], W.u.dyn.cvel[lane]);
+    cross_force(f, W.u.dyn.cvel[lane], t2);
 #pragma unroll
-    for (int k = 0; k < 6; k++) W.cfrc[lane][k] = f[k] + t1[k];
+    for (int k = 0; k < 6; k++) W.u.dyn.cfrc[lane][k] = f[k] + t1[k];
   }
   wave_barrier();
   if (lane < 24) { /* accumulate up the legs */
     const int leg = lane / 6, k = lane % 6, b0 = 1 + 3 * leg;
-    float f2 = W.cfrc[b0 + 2][k], f1 = W.cfrc[b0 + 1][k] + f2, f0 = W.cfrc[b0][k] + f1;
-    W.cfrc[b0 + 1][k] = f1; W.cfrc[b0][k] = f0;
+    float f2 = W.u.dyn.cfrc[b0 + 2][k], f1 = W.u.dyn.cfrc[b0 + 1][k] + f2, f0 = W.u.dyn.cfrc[b0][k] + f1;
+    W.u.dyn.cfrc[b0 + 1][k] = f1; W.u.dyn.cfrc[b0][k] = f0;
   }
   wave_barrier();
-  if (lane < 6) W.cfrc[0][lane] += W.cfrc[1][lane] + W.cfrc[4][lane] + W.cfrc[7][lane] + W.cfrc[10][lane];
+  if (lane < 6) W.u.dyn.cfrc[0][lane] += W.u.dyn.cfrc[1][lane] + W.u.dyn.cfrc[4][lane] + W.u.dyn.cfrc[7][lane] + W.u.dyn.cfrc[10][lane];
   wave_barrier();
   if (lane < GQ_NVD) {
     const float* s = W.cdof[lane];
-    const float* f = W.cfrc[dof_body(lane)];
+    const float* f = W.u.dyn.cfrc[dof_body(lane)];
     float bias = s[0] * f[0] + s[1] * f[1] + s[2] * f[2] + s[3] * f[3] + s[4] * f[4] + s[5] * f[5];
     W.bias[lane] = bias;
     /* actuation (mj_fwdActuation): torque motors */
@@ -414,35 +419,42 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   }
 
   /* ================================================================ S8: B = M^-1 J' (lane-parallel), A = J B' + R */
-  float x[GQ_NVD];
-#pragma unroll
-  for (int k = 0; k < GQ_NVD; k++) x[k] = (lane == 63) ? W.smooth[k] : J[k];
-  solve_tree(W, 0, x);
-  float diag = 0.0f; /* A_ii = J_i . B_i */
-#pragma unroll
-  for (int k = 0; k < GQ_NVD; k++) { W.JB[lane][k] = x[k]; diag += J[k] * x[k]; }
-  if (lane == 63) {
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) W.qacc_smooth[k] = x[k];
-  }
-  wave_barrier();
   float A[GQ_MAXEFC];
+  float diag = 0.0f; /* A_ii = J_i . B_i */
+  {
+    float x[GQ_NVD];
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) x[k] = (lane == 63) ? W.smooth[k] : J[k];
+    solve_tree(W, 0, x);
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) diag += J[k] * x[k];
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < GQ_NVD; k++) W.qacc_smooth[k] = x[k];
+    }
+    /* rows of B are exchanged through LDS (they overlay the spatial-dynamics scratch, dead by now) */
+    wave_barrier();
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) W.u.B[lane][k] = x[k];
+    wave_barrier();
+  }
 #pragma unroll
   for (int j = 0; j < GQ_MAXEFC; j++) {
-    float s = 0.0f;
-    if (j < nefc) {
+    float sacc = 0.0f;
+    if (j < nefc) { /* wave-uniform */
 #pragma unroll
-      for (int k = 0; k < GQ_NVD; k++) s += J[k] * W.JB[j][k];
+      for (int k = 0; k < GQ_NVD; k++) sacc += J[k] * W.u.B[j][k];
     }
-    A[j] = s;
+    A[j] = sacc;
+    sched_fence(); /* one row of B in flight at a time: keeps the register pressure of the unrolled loop flat */
   }
   float b_i = -raref, jar_w = -raref;
 #pragma unroll
   for (int k = 0; k < GQ_NVD; k++) { b_i += J[k] * W.qacc_smooth[k]; jar_w += J[k] * W.warm[k]; }
+  /* J rows take B's place in LDS (needed again for J'f); their registers are free during the PGS sweeps */
   wave_barrier();
-  /* J rows replace B in LDS (needed for J' f and the debug dump) */
 #pragma unroll
-  for (int k = 0; k < GQ_NVD; k++) W.JB[lane][k] = (lane < nefc) ? J[k] : 0.0f;
+  for (int k = 0; k < GQ_NVD; k++) W.u.B[lane][k] = (lane < nefc) ? J[k] : 0.0f;
 
   /* ================================================================ S9: PGS on  min 1/2 f'(A+R)f + f'b */
   const bool active = lane < nefc;
@@ -469,20 +481,28 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   }
   if (!active) r = 0.0f;
   const float scale = 1.0f / (m.meaninertia * 18.0f);
+  /* fold R into the diagonal: lane i's own column entry becomes (A+R)_ii, so the residual update below is one
+   * uniform FMA for every lane */
+#pragma unroll
+  for (int j = 0; j < GQ_MAXEFC; j++) A[j] = (j == lane) ? ARii : A[j];
   int iter = 0;
   for (; iter < m.iterations; iter++) {
     float imp_acc = 0.0f;
+    int lane_s = lane;
+    opaque(lane_s); /* keeps the 63 (lane == i) predicates from being hoisted out of the sweep loop as live masks */
 #pragma unroll
-    for (int i = 0; i < GQ_MAXEFC; i++) {
-      if (i < nefc) { /* wave-uniform */
-        float fn = med3(f - r * invd, lo, hi);
-        float delta = fn - f;
-        float dcost = delta * (0.5f * delta * ARii + r);
-        const bool mine = lane == i;
-        f = mine ? fn : f;
-        imp_acc = mine ? imp_acc - dcost : imp_acc;
-        float d_i = bcast(delta, i);
-        r += (mine ? ARii : A[i]) * d_i;
+    for (int i0 = 0; i0 < GQ_MAXEFC + 1; i0 += 4) {
+      if (i0 < nefc) { /* wave-uniform; rows past nefc inside a group are inert (lo = hi = 0, f = 0) */
+#pragma unroll
+        for (int i = i0; i < i0 + 4 && i < GQ_MAXEFC; i++) {
+          const float fn = med3(f - r * invd, lo, hi);
+          const float delta = fn - f;
+          if (lane_s == i) {
+            imp_acc -= delta * (0.5f * delta * ARii + r);
+            f = fn;
+          }
+          r += A[i] * bcast(delta, i);
+        }
       }
     }
     float improvement = wave_sum(imp_acc);
@@ -492,13 +512,14 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   wave_barrier();
 
   /* ================================================================ S10: accelerations and integration */
-  if (lane < GQ_NVD) {
-    float s = 0.0f;
-    for (int i = 0; i < nefc; i++) s += W.JB[i][lane] * W.force[i];
-    W.qfrc_c[lane] = s;
+  if (lane < GQ_NVD) { /* qfrc_constraint = J' f */
+    float sacc = 0.0f;
+    for (int i = 0; i < nefc; i++) sacc += W.u.B[i][lane] * W.force[i];
+    W.qfrc_c[lane] = sacc;
   }
   wave_barrier();
   {
+    float x[GQ_NVD];
     const int which = lane & 1;
 #pragma unroll
     for (int k = 0; k < GQ_NVD; k++) x[k] = W.qfrc_c[k] + (which ? W.smooth[k] : 0.0f);
@@ -514,9 +535,9 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   }
   wave_barrier();
 
-  if (a.debug && env < a.batch->debug_envs) {
+  if (a.debug && pass == 0 && env < a.batch->debug_envs) {
     float* D = a.debug + (size_t)env * GQ_DBG_SIZE;
-    for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = W.M[k / 18][k % 18];
+    for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = m_entry(W, k / 18, k % 18);
     if (lane < 18) {
       D[GQ_DBG_BIAS + lane] = W.bias[lane]; D[GQ_DBG_SMOOTH + lane] = W.smooth[lane];
       D[GQ_DBG_QACC_SMOOTH + lane] = W.qacc_smooth[lane]; D[GQ_DBG_QFRC_C + lane] = W.qfrc_c[lane];
@@ -525,7 +546,7 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
     if (lane < 39) D[GQ_DBG_XPOS + lane] = W.xpos[lane / 3][lane % 3];
     for (int k = lane; k < 117; k += GQ_WAVE) D[GQ_DBG_XMAT + k] = W.xmat[k / 9][k % 9];
     if (lane == 0) { D[GQ_DBG_NEFC] = (float)nefc; D[GQ_DBG_NCON] = (float)ncon; D[GQ_DBG_NITER] = (float)iter; }
-    for (int k = 0; k < GQ_NVD; k++) D[GQ_DBG_EFC_J + lane * 18 + k] = W.JB[lane][k];
+    for (int k = 0; k < GQ_NVD; k++) D[GQ_DBG_EFC_J + lane * 18 + k] = W.u.B[lane][k];
     D[GQ_DBG_EFC_AREF + lane] = raref; D[GQ_DBG_EFC_R + lane] = rR; D[GQ_DBG_EFC_B + lane] = b_i;
     D[GQ_DBG_EFC_FORCE + lane] = W.force[lane]; D[GQ_DBG_EFC_TYPE + lane] = (float)rtype;
     if (lane < GQ_MAXCON) { D[GQ_DBG_CON_DIST + lane] = lane < ncon ? W.con_dist[lane] : 0.0f; D[GQ_DBG_CON_GEOM + lane] = lane < ncon ? (float)W.con_geom[lane] : -1.0f; }
@@ -544,6 +565,9 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   if (lane < GQ_NVD) W.qvel[lane] = vnew; /* new qvel; old one is not needed any more */
   wave_barrier();
   /* positions */
+  /* base x,y stay in f64 (uniform: every lane reads the same two words) and never enter fp32 arithmetic; they are
+   * read here, not at the top, so they do not occupy registers across the solver */
+  const double bx_d = a.qpos[(size_t)env * 19 + 0], by_d = a.qpos[(size_t)env * 19 + 1];
   const double bxn_d = bx_d + (double)h * (double)W.qvel[0], byn_d = by_d + (double)h * (double)W.qvel[1];
   if (lane == 0) a.qpos[(size_t)env * 19 + 0] = bxn_d;
   if (lane == 1) a.qpos[(size_t)env * 19 + 1] = byn_d;
@@ -552,6 +576,8 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   {
     V3 w = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
     float n = sqrtf(dot(w, w));
+    Q4 qraw = {W.qb[0], W.qb[1], W.qb[2], W.qb[3]};
+    const Q4 qbase = qnormalize(qraw);
     qn = qbase;
     /* mju_quatIntegrate starts from the raw (un-normalised) qpos quaternion; it was normalised above, the
      * difference is removed by the normalisation that follows */
@@ -589,7 +615,7 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   V3 ta = v3(0.0f, 0.0f, W.cmd[3]);
   V3 vlin = v3(W.qvel[0], W.qvel[1], W.qvel[2]), wloc = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
   V3 acc3 = v3(W.qacc[0], W.qacc[1], W.qacc[2]);
-  float* ob = W.obs;
+  float* ob = W.u.obs;
   if (lane == 0) {
     ob[OB_BASE_POS] = (float)bxn_d; ob[OB_BASE_POS + 1] = (float)byn_d; ob[OB_BASE_POS + 2] = znew;
     ob[OB_QPOS] = (float)bxn_d; ob[OB_QPOS + 1] = (float)byn_d; ob[OB_QPOS + 2] = znew;
@@ -613,8 +639,7 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   float ke_part = 0.0f, wk_part = 0.0f;
   if (lane < GQ_NVD) {
     float mv = 0.0f, ma = 0.0f;
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) { mv += W.M[lane][k] * W.qvel[k]; ma += W.M[lane][k] * W.qacc[k]; }
+    for (int k = 0; k < GQ_NVD; k++) { const float mk = m_entry(W, lane, k); mv += mk * W.qvel[k]; ma += mk * W.qacc[k]; }
     ke_part = 0.5f * W.qvel[lane] * mv; wk_part = ma * W.qvel[lane];
   }
   float ke = wave_sum(ke_part), wk = wave_sum(wk_part);
@@ -666,17 +691,20 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
   }
   wave_barrier();
   /* termination (quadruped_env.py:283-285): non-foot contact with the ground, or base outside the terrain */
+  int terminated = 0;
   {
     const bool oob = bxn_d > m.terrain_limits[0] || bxn_d < m.terrain_limits[1] || byn_d > m.terrain_limits[2] ||
                      byn_d < m.terrain_limits[3];
+    terminated = W.invalid || oob;
     if (lane == 0) {
-      const int invalid = W.invalid;
-      a.invalid_contact[env] = (uint8_t)invalid;
-      a.terminated[env] = (uint8_t)(invalid || oob);
-      a.truncated[env] = 0;
+      if (pass == 0) { /* the flags of the user's step survive an in-kernel auto-reset */
+        a.invalid_contact[env] = (uint8_t)W.invalid;
+        a.terminated[env] = (uint8_t)terminated;
+        a.truncated[env] = 0;
+      }
       a.reward[env] = 0.0f;
       a.step_num[env] += 1;
-      if (a.friction_commit) const_cast<float*>(a.friction)[env] = a.friction_commit[env];
+      if (pass == 1 && a.friction && a.friction_next) const_cast<float*>(a.friction)[env] = a.friction_next[env];
     }
   }
   /* gather to the requested observation layout: coalesced row write */
@@ -684,6 +712,8 @@ __device__ inline void step_wave(const StepArgs& a, WaveMem& W, float (*acc)[21]
     const int od = a.batch->obs_dim;
     for (int k = lane; k < od; k += GQ_WAVE) a.obs[(size_t)env * od + k] = ob[a.batch->obs_map[k]];
   }
+  wave_barrier(); /* the obs row overlays u: finish reading it before a second pass reuses the region */
+  return terminated;
 }
 
 
@@ -707,6 +737,7 @@ struct ResetArgs {
   double* qpos; float* qvel; float* qacc; float* warm; float* applied; float* time; float* cmd; float* friction_next;
   int32_t* step_num; int32_t* episode;
   uint8_t* lift_failed;
+  uint8_t* clear_terminated; uint8_t* clear_truncated; uint8_t* clear_invalid; /* explicit reset(): flags zeroed; NULL inside a fused auto-reset */
   ResetCfgDev cfg;
 };
 
@@ -729,8 +760,9 @@ enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH =
        RN_YAWDOT = 30, RN_FRICTION = 31 };
 
 __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
-  const int lane = lane_id();
-  const int env = (int)blockIdx.x;
+  int lane_o = lane_id(), env_o = (int)blockIdx.x;
+  opaque(lane_o); opaque_s(env_o); /* see step_wave: no address arithmetic may be hoisted to the kernel prologue */
+  const int lane = lane_o, env = env_o;
   const GqDevModel& m = *a.model;
   const ResetCfgDev& c = a.cfg;
   const int episode = a.episode ? a.episode[env] : 0;
@@ -740,8 +772,10 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
     uint32_t x = philox4x32((uint32_t)(lane >> 2), (uint32_t)episode, (uint32_t)(env + c.env_id_offset), 0x5eedu, c.seed_lo, c.seed_hi, lane & 3);
     u = (float)(x >> 8) * (1.0f / 16777216.0f);
   }
-  W.obs[lane] = u; /* scratch: publish the draws */
+  W.u.obs[lane] = u; /* scratch: publish the draws */
   wave_barrier();
+  /* draws needed after the kinematics pass (which reuses the union) */
+  const float u_vnorm = W.u.obs[RN_VNORM], u_heading = W.u.obs[RN_HEADING], u_yawdot = W.u.obs[RN_YAWDOT], u_fric = W.u.obs[RN_FRICTION];
   const bool explicit_state = a.qpos_new != nullptr;
   double q = 0.0;
   float qv = 0.0f;
@@ -751,12 +785,12 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   } else {
     if (lane < 19) q = (double)m.key_qpos[lane];
     if (c.random) {
-      if (lane >= 7 && lane < 19) q += (double)((2.0f * W.obs[RN_QPOS + lane - 7] - 1.0f) * c.q_pos_amp);
-      if (lane >= 6 && lane < 18) qv = (2.0f * W.obs[RN_QVEL + lane - 6] - 1.0f) * c.q_vel_amp;
+      if (lane >= 7 && lane < 19) q += (double)((2.0f * W.u.obs[RN_QPOS + lane - 7] - 1.0f) * c.q_pos_amp);
+      if (lane >= 6 && lane < 18) qv = (2.0f * W.u.obs[RN_QVEL + lane - 6] - 1.0f) * c.q_vel_amp;
       /* xy ~ U(terrain_limits[0], [1]) x U([2], [3]) (np.random.uniform(low, high) = low + (high-low) u) */
-      const double x = m.terrain_limits[0] + (m.terrain_limits[1] - m.terrain_limits[0]) * (double)W.obs[RN_X];
-      const double y = m.terrain_limits[2] + (m.terrain_limits[3] - m.terrain_limits[2]) * (double)W.obs[RN_Y];
-      const float roll = (2.0f * W.obs[RN_ROLL] - 1.0f) * c.roll_sweep, pitch = (2.0f * W.obs[RN_PITCH] - 1.0f) * c.pitch_sweep;
+      const double x = m.terrain_limits[0] + (m.terrain_limits[1] - m.terrain_limits[0]) * (double)W.u.obs[RN_X];
+      const double y = m.terrain_limits[2] + (m.terrain_limits[3] - m.terrain_limits[2]) * (double)W.u.obs[RN_Y];
+      const float roll = (2.0f * W.u.obs[RN_ROLL] - 1.0f) * c.roll_sweep, pitch = (2.0f * W.u.obs[RN_PITCH] - 1.0f) * c.pitch_sweep;
       const float yaw = (float)atan2(-y, -x); /* heading towards the origin (math_utils.py:37-51) */
       const float cr = cosf(0.5f * roll), sr = sinf(0.5f * roll), cp = cosf(0.5f * pitch), sp = sinf(0.5f * pitch);
       const float cy = cosf(0.5f * yaw), sy = sinf(0.5f * yaw);
@@ -804,21 +838,30 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
     a.step_num[env] = -1; /* the reset's own mj_step brings it to 0 (:332, :397) */
     if (a.episode) a.episode[env] = episode + 1;
     if (a.lift_failed) a.lift_failed[env] = (uint8_t)failed;
+    if (a.clear_terminated) { a.clear_terminated[env] = 0; a.clear_truncated[env] = 0; a.clear_invalid[env] = 0; }
     /* _sample_ref_vel (:1046-1072) */
     if (a.cmd) {
       float norm = 0.0f, heading = 0.0f, yaw_dot = 0.0f;
-      if (c.cmd_forward) norm = c.lin_vel_range[0] + (c.lin_vel_range[1] - c.lin_vel_range[0]) * W.obs[RN_VNORM];
+      if (c.cmd_forward) norm = c.lin_vel_range[0] + (c.lin_vel_range[1] - c.lin_vel_range[0]) * u_vnorm;
       else if (c.cmd_random) {
-        norm = c.lin_vel_range[0] + (c.lin_vel_range[1] - c.lin_vel_range[0]) * W.obs[RN_VNORM];
-        heading = (2.0f * W.obs[RN_HEADING] - 1.0f) * 3.14159265358979f;
+        norm = c.lin_vel_range[0] + (c.lin_vel_range[1] - c.lin_vel_range[0]) * u_vnorm;
+        heading = (2.0f * u_heading - 1.0f) * 3.14159265358979f;
       }
-      if (c.cmd_rotate) yaw_dot = c.ang_vel_range[0] + (c.ang_vel_range[1] - c.ang_vel_range[0]) * W.obs[RN_YAWDOT];
+      if (c.cmd_rotate) yaw_dot = c.ang_vel_range[0] + (c.ang_vel_range[1] - c.ang_vel_range[0]) * u_yawdot;
       a.cmd[(size_t)env * 4 + 0] = norm * cosf(heading); a.cmd[(size_t)env * 4 + 1] = norm * sinf(heading);
       a.cmd[(size_t)env * 4 + 2] = 0.0f; a.cmd[(size_t)env * 4 + 3] = yaw_dot;
     }
     if (a.friction_next)
-      a.friction_next[env] = c.friction_range[0] + (c.friction_range[1] - c.friction_range[0]) * W.obs[RN_FRICTION];
+      a.friction_next[env] = c.friction_range[0] + (c.friction_range[1] - c.friction_range[0]) * u_fric;
   }
 }
+
+
+struct FusedArgs {
+  StepArgs s;
+  ResetArgs r;          /* used when auto_reset != 0 */
+  int32_t auto_reset;
+  int32_t first_pass;   /* 0: user step; 1: the reset's own step (gq_reset) */
+};
 
 }  // namespace gq

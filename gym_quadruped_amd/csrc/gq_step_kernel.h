@@ -35,7 +35,7 @@ struct StepArgs {
   const float* ctrl; const uint8_t* mask;
   double* qpos; float* qvel; float* qacc; float* warm; const float* applied; float* time; const float* friction;
   const float* cmd;
-  const float* friction_commit; /* non-NULL: friction[env] <- friction_commit[env] after the step (reset, :403-404) */
+  float* friction_next;   /* library scratch [N]: friction drawn at reset, committed after the reset's own step (:403-404) */
   float* obs; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* invalid_contact; int32_t* step_num;
   float* debug;
   int32_t n_envs;
@@ -54,16 +54,25 @@ enum {
 
 enum { ROW_NONE = 0, ROW_FRICTION = 1, ROW_LIMIT = 2, ROW_CONTACT1 = 3, ROW_PYRAMID = 4 };
 
-/* ------------------------------------------------------------------ per-wave LDS working set */
+/* ------------------------------------------------------------------ per-wave LDS working set (8.5 KB: 16+ waves per CU)
+ * `u` overlays three regions with disjoint lifetimes: the spatial-dynamics scratch (S1-S5), the half-batch of
+ * B = M^-1 J' rows while the dual operator is built (S8), and the observation row (S11). */
+struct WaveDyn {
+  float anchor[GQ_NJ][3], axis[GQ_NJ][3];
+  float cinert[GQ_NB][10];
+  union { float crb[GQ_NB][10]; float acc[4][21]; };    /* acc: per-leg Schur updates of the base block (S4, crb is dead) */
+  float cvel[GQ_NB][6], cacc[GQ_NB][6], cfrc[GQ_NB][6];
+};
 struct WaveMem {
   float qj[12], qb[4], basez, qvel[18], ctrl[12], warm[18], applied[18], cmd[4];
   float xpos[GQ_NB][3], xmat[GQ_NB][9];
-  float anchor[GQ_NJ][3], axis[GQ_NJ][3];
-  float cinert[GQ_NB][10], crb[GQ_NB][10];
   float cdof[GQ_NVD][6];
-  float cvel[GQ_NB][6], cacc[GQ_NB][6], cfrc[GQ_NB][6];
-  float M[GQ_NVD][GQ_NVD];
-  float L[2][GQ_NVD][GQ_NVD], Dinv[2][GQ_NVD];      /* [0]: M, [1]: M + h*diag(damping) */
+  /* joint-space inertia, tree-sparse: leg dof 6+j keeps [b0..b5, hip, thigh, calf] of its own leg (lower part incl.
+   * the diagonal), the base block is a full symmetric 6x6 */
+  float Mc[GQ_NJ][9], Mb[6][6];
+  /* L'DL factors, tree-sparse storage: leg dof k >= 6 keeps [b0..b5, hip, thigh] (8 floats), base rows 6x6 lower.
+   * [0]: M, [1]: M + h*diag(damping) */
+  float Lc[2][GQ_NJ][8], Lb[2][6][6], Dinv[2][GQ_NVD];
   float bias[18], act[18], smooth[18], qacc_smooth[18], qfrc_c[18], qacc[18], qacc_int[18];
   /* contacts */
   int32_t ncon, nefc, nlim, invalid;
@@ -75,10 +84,12 @@ struct WaveMem {
   float foot_world[4][3];
   int32_t lim_jnt[GQ_NJ]; float lim_side[GQ_NJ], lim_dist[GQ_NJ];
   float lg_dist[GQ_MAXLG], lg_pt[GQ_MAXLG][3];
-  /* rows */
-  float JB[GQ_MAXEFC + 1][GQ_NVD];                      /* B = M^-1 J' while A is built, then J */
   float force[64];
-  float obs[256];
+  union {
+    WaveDyn dyn;
+    float B[64][GQ_NVD];                                /* rows of M^-1 J' while A is built (S8) */
+    float obs[256];
+  } u;
 };
 
 /* ------------------------------------------------------------------ small math */
@@ -158,18 +169,21 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 /* L'DL of a matrix with the robot's dof-tree sparsity (mj_factorI).  src: dense symmetric in LDS, diag_add: added
  * to the diagonal (h*damping for the Euler system).  Lanes 0-3 eliminate their leg's three dofs in registers and
  * emit their Schur contribution to the 6x6 base block; lane 0 then factors the base block. */
-__device__ inline void factor_tree(WaveMem& W, int which, const float* diag_add, float (*acc)[21]) {
+/* hscale * damping[dof] is added to the diagonal: h for the Euler system M + h*D, 0 for M itself */
+__device__ inline void factor_tree(WaveMem& W, int which, const float* damping, const float hscale) {
   const int lane = lane_id();
-  float(*L)[GQ_NVD] = W.L[which];
+  float(*Lc)[8] = W.Lc[which];
+  float(*Lb)[6] = W.Lb[which];
+  float(*acc)[21] = W.u.dyn.acc;
   if (lane < 4) {
     const int h = 6 + 3 * lane, t = h + 1, c = h + 2;
     /* rows over columns [b0..b5, h, t, c] */
     float rc[9], rt[8], rh[7], bb[21];
 #pragma unroll
-    for (int j = 0; j < 6; j++) { rc[j] = W.M[c][j]; rt[j] = W.M[t][j]; rh[j] = W.M[h][j]; }
-    rc[6] = W.M[c][h]; rc[7] = W.M[c][t]; rc[8] = W.M[c][c] + diag_add[c];
-    rt[6] = W.M[t][h]; rt[7] = W.M[t][t] + diag_add[t];
-    rh[6] = W.M[h][h] + diag_add[h];
+    for (int j = 0; j < 6; j++) { rc[j] = W.Mc[c - 6][j]; rt[j] = W.Mc[t - 6][j]; rh[j] = W.Mc[h - 6][j]; }
+    rc[6] = W.Mc[c - 6][6]; rc[7] = W.Mc[c - 6][7]; rc[8] = W.Mc[c - 6][8] + hscale * damping[c];
+    rt[6] = W.Mc[t - 6][6]; rt[7] = W.Mc[t - 6][7] + hscale * damping[t];
+    rh[6] = W.Mc[h - 6][6] + hscale * damping[h];
 #pragma unroll
     for (int k = 0; k < 21; k++) bb[k] = 0.0f;
     /* eliminate calf: ancestors t(7), h(6), b5..b0 */
@@ -216,13 +230,15 @@ __device__ inline void factor_tree(WaveMem& W, int which, const float* diag_add,
       }
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) { L[c][j] = rc[j]; L[t][j] = rt[j]; L[h][j] = rh[j]; }
-    L[c][h] = rc[6]; L[c][t] = rc[7]; L[t][h] = rt[6];
+    for (int j = 0; j < 6; j++) { Lc[c - 6][j] = rc[j]; Lc[t - 6][j] = rt[j]; Lc[h - 6][j] = rh[j]; }
+    Lc[c - 6][6] = rc[6]; Lc[c - 6][7] = rc[7]; Lc[t - 6][6] = rt[6];
     W.Dinv[which][c] = 1.0f / rc[8]; W.Dinv[which][t] = 1.0f / rt[7]; W.Dinv[which][h] = 1.0f / rh[6];
 #pragma unroll
     for (int k = 0; k < 21; k++) acc[lane][k] = bb[k];
   }
   wave_barrier();
+  /* NOTE: acc overlays dyn.crb, which S3 has finished with; the first barrier of the SECOND factor call also
+   * separates lane 0's reads of acc from the legs' next writes */
   if (lane == 0) {
     float b[6][6];
 #pragma unroll
@@ -230,7 +246,7 @@ __device__ inline void factor_tree(WaveMem& W, int which, const float* diag_add,
 #pragma unroll
       for (int j = 0; j <= i; j++) {
         int k = i * (i + 1) / 2 + j;
-        b[i][j] = W.M[i][j] + (i == j ? diag_add[i] : 0.0f) + acc[0][k] + acc[1][k] + acc[2][k] + acc[3][k];
+        b[i][j] = W.Mb[i][j] + (i == j ? hscale * damping[i] : 0.0f) + acc[0][k] + acc[1][k] + acc[2][k] + acc[3][k];
       }
 #pragma unroll
     for (int k = 5; k >= 0; k--) {
@@ -247,48 +263,49 @@ __device__ inline void factor_tree(WaveMem& W, int which, const float* diag_add,
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-      for (int j = 0; j < i; j++) L[i][j] = b[i][j];
+      for (int j = 0; j < i; j++) Lb[i][j] = b[i][j];
   }
   wave_barrier();
 }
 
 /* x <- (L' D L)^-1 x on 18 registers per lane; L and Dinv are wave-uniform LDS reads (mj_solveLD) */
 __device__ __forceinline__ void solve_tree(const WaveMem& W, int which, float* x) {
-  const float(*L)[GQ_NVD] = W.L[which];
+  const float(*Lc)[8] = W.Lc[which];
+  const float(*Lb)[6] = W.Lb[which];
   const float* Dinv = W.Dinv[which];
 #pragma unroll
   for (int leg = 3; leg >= 0; leg--) {
     const int h = 6 + 3 * leg, t = h + 1, c = h + 2;
-    x[t] -= L[c][t] * x[c]; x[h] -= L[c][h] * x[c];
+    x[t] -= Lc[c - 6][7] * x[c]; x[h] -= Lc[c - 6][6] * x[c];
 #pragma unroll
-    for (int j = 0; j < 6; j++) x[j] -= L[c][j] * x[c];
-    x[h] -= L[t][h] * x[t];
+    for (int j = 0; j < 6; j++) x[j] -= Lc[c - 6][j] * x[c];
+    x[h] -= Lc[t - 6][6] * x[t];
 #pragma unroll
-    for (int j = 0; j < 6; j++) x[j] -= L[t][j] * x[t];
+    for (int j = 0; j < 6; j++) x[j] -= Lc[t - 6][j] * x[t];
 #pragma unroll
-    for (int j = 0; j < 6; j++) x[j] -= L[h][j] * x[h];
+    for (int j = 0; j < 6; j++) x[j] -= Lc[h - 6][j] * x[h];
   }
 #pragma unroll
   for (int k = 5; k >= 1; k--)
 #pragma unroll
-    for (int j = 0; j < k; j++) x[j] -= L[k][j] * x[k];
+    for (int j = 0; j < k; j++) x[j] -= Lb[k][j] * x[k];
 #pragma unroll
   for (int k = 0; k < 18; k++) x[k] *= Dinv[k];
 #pragma unroll
   for (int k = 1; k < 6; k++)
 #pragma unroll
-    for (int j = 0; j < k; j++) x[k] -= L[k][j] * x[j];
+    for (int j = 0; j < k; j++) x[k] -= Lb[k][j] * x[j];
 #pragma unroll
   for (int leg = 0; leg < 4; leg++) {
     const int h = 6 + 3 * leg, t = h + 1, c = h + 2;
 #pragma unroll
-    for (int j = 0; j < 6; j++) x[h] -= L[h][j] * x[j];
+    for (int j = 0; j < 6; j++) x[h] -= Lc[h - 6][j] * x[j];
 #pragma unroll
-    for (int j = 0; j < 6; j++) x[t] -= L[t][j] * x[j];
-    x[t] -= L[t][h] * x[h];
+    for (int j = 0; j < 6; j++) x[t] -= Lc[t - 6][j] * x[j];
+    x[t] -= Lc[t - 6][6] * x[h];
 #pragma unroll
-    for (int j = 0; j < 6; j++) x[c] -= L[c][j] * x[j];
-    x[c] -= L[c][h] * x[h]; x[c] -= L[c][t] * x[t];
+    for (int j = 0; j < 6; j++) x[c] -= Lc[c - 6][j] * x[j];
+    x[c] -= Lc[c - 6][6] * x[h]; x[c] -= Lc[c - 6][7] * x[t];
   }
 }
 

@@ -216,6 +216,9 @@ class QuadrupedEnv:
             friction_range=(C.c_float * 2)(*map(float, self.ground_friction_coeff_range)),
             cmd_forward=int('forward' in t), cmd_random=int('forward' not in t and 'random' in t),
             cmd_rotate=int('rotate' in t), cmd_human=int('human' in t), env_id_offset=int(env_id_offset))
+        # auto-reset happens inside the step kernel (terminated envs take a second pass); None = off
+        self._auto_cfg_struct = GqResetCfg.from_buffer_copy(self._reset_cfg)  # user reset() options never leak into it
+        self._auto_cfg = C.pointer(self._auto_cfg_struct) if self.auto_reset else None
 
         self.external_disturbances_kwargs = external_disturbances_kwargs
         if self.external_disturbances_kwargs is not None:
@@ -243,11 +246,14 @@ class QuadrupedEnv:
         ev = self._profile_events
         if ev is not None:
             ev[0].record()
-        _lib.check(self._L.gq_step(self._hbatch, self._ctrl.data_ptr(), None, self._st, self._out, stream), 'gq_step')
+        _lib.check(self._L.gq_step(self._hbatch, self._ctrl.data_ptr(), None, self._st, self._out, self._auto_cfg,
+                                   self._episode.data_ptr(), self._lift_failed.data_ptr(), stream), 'gq_step')
         if ev is not None:
             ev[1].record()
 
         if 'reset' in self.base_vel_command_type:  # reference :293-296
+            if self.auto_reset:  # envs re-spawned inside the kernel restart their command interval (reference :1068-1070)
+                self._steps_after_vel.masked_fill_(self._terminated_b, 0)
             self._steps_after_vel += 1
             due = self._steps_after_vel >= self._steps_before_vel
             self._sample_ref_vel(due)
@@ -256,8 +262,6 @@ class QuadrupedEnv:
             due = self._steps_after_dist >= self._steps_before_dist
             self._sample_external_disturbances(due)
             self._applied[:, :6] = self._ext_dist  # acts from the NEXT step on (reference :305, quirk B9)
-        if self.auto_reset:
-            self._reset_masked(self._terminated, random=True, options=None)
         return self._obs_views, self._reward, self._terminated_b, self._truncated_b, self._info
 
     def reset(self, qpos=None, qvel=None, seed: int | None = None, random: bool = True,
@@ -268,6 +272,7 @@ class QuadrupedEnv:
             self._gen.manual_seed(int(seed))
             self._seed = int(seed)
             self._reset_cfg.seed = self._seed
+            self._auto_cfg_struct.seed = self._seed
             self._episode.zero_()
         N = self.num_envs
         if env_ids is None:

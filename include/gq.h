@@ -195,11 +195,6 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
 int gq_batch_destroy(GqBatch* b);
 int gq_batch_obs_dim(const GqBatch* b);
 
-/* QuadrupedEnv.step body (quadruped_env.py:270-290): ctrl <- action; mj_step; _get_obs; reward; termination.
- * ctrl: device [N][nu] f32.  mask: device [N] u8 or NULL - envs with mask==0 are left untouched
- * (used by reset(), which ends with one mj_step for the envs being reset, quadruped_env.py:397). */
-int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, void* hip_stream);
-
 /* reset configuration: the knobs of QuadrupedEnv.reset / _sample_ref_vel / _set_ground_friction */
 typedef struct GqResetCfg {
   uint64_t seed;            /* key of the counter-based device RNG (Philox4x32-10; counter = draw, episode, env) */
@@ -214,6 +209,16 @@ typedef struct GqResetCfg {
   int32_t cmd_forward, cmd_random, cmd_rotate, cmd_human; /* substrings of base_vel_command_type (:1049-1066) */
   int32_t env_id_offset;    /* global id of env 0 of this batch (multi-GPU shards draw from disjoint counters) */
 } GqResetCfg;
+
+/* QuadrupedEnv.step body (quadruped_env.py:270-290): ctrl <- action; mj_step; _get_obs; reward; termination.
+ * ctrl: device [N][nu] f32.  mask: device [N] u8 or NULL - envs with mask==0 are left untouched
+ * (used by reset(), which ends with one mj_step for the envs being reset, quadruped_env.py:397).
+ * auto_reset != NULL: an env whose step terminates is re-spawned INSIDE the same launch (the batched stand-in for the
+ * user's `if terminated: env.reset()` loop): reset state write + lift loop + the reset's own mj_step, exactly as
+ * gq_reset does; its `terminated` flag stays set and its observation row is the first one of the new episode.
+ * episode / lift_failed as in gq_reset (may be NULL when auto_reset is NULL). */
+int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out,
+            const GqResetCfg* auto_reset, int32_t* episode, uint8_t* lift_failed, void* hip_stream);
 
 /* QuadrupedEnv.reset (quadruped_env.py:309-406) for the envs with mask != 0 (mask NULL = all), two launches:
  *  1. state write: explicit qpos_new/qvel_new when given (:389-391), otherwise keyframe 0 (+ joint noise, random

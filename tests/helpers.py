@@ -72,7 +72,7 @@ def _p(a):
 
 
 def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=None, cmd=None, obs_names=ALL_OBS,
-             legs_order=(0, 1, 2, 3), mask=None, debug_envs=0):
+             legs_order=(0, 1, 2, 3), mask=None, debug_envs=0, auto_reset=None, episode=None, first_pass=0):
     """Run the kernel body under the emulator. Arrays are updated in place like the device tensors would be."""
     L = emu_lib()
     n = qpos.shape[0]
@@ -85,14 +85,17 @@ def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=
         time=f32(time, (n,)), friction=np.full(n, -1, np.float32) if friction is None else f32(friction, (n,)),
         cmd=f32(cmd, (n, 4)), obs=np.zeros((n, od), np.float32), reward=np.zeros(n, np.float32),
         terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8), invalid=np.zeros(n, np.uint8),
-        step_num=np.zeros(n, np.int32), debug=np.zeros((max(debug_envs, 1), DBG_SIZE), np.float32))
+        step_num=np.zeros(n, np.int32), debug=np.zeros((max(debug_envs, 1), DBG_SIZE), np.float32),
+        episode=np.zeros(n, np.int32) if episode is None else np.ascontiguousarray(episode, dtype=np.int32),
+        lift_failed=np.zeros(n, np.uint8), friction_next=np.zeros(n, np.float32))
     lo = np.asarray(legs_order, dtype=np.int32)
     err = C.create_string_buffer(512)
     m8 = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
     rc = L.emu_step(C.byref(mm.desc), n, _p(ids), len(ids), _p(lo), _p(st['ctrl']), _p(m8), _p(st['qpos']), _p(st['qvel']),
                     _p(st['qacc']), _p(st['warm']), _p(st['applied']), _p(st['time']), _p(st['friction']), _p(st['cmd']),
                     _p(st['obs']), _p(st['reward']), _p(st['terminated']), _p(st['truncated']), _p(st['invalid']),
-                    _p(st['step_num']), _p(st['debug']), debug_envs, err, 512)
+                    _p(st['step_num']), _p(st['debug']), debug_envs, None if auto_reset is None else C.byref(auto_reset),
+                    _p(st['episode']), _p(st['lift_failed']), _p(st['friction_next']), int(first_pass), err, 512)
     if rc < 0:
         raise RuntimeError(err.value.decode())
     st['obs_names'] = list(obs_names)

@@ -10,28 +10,54 @@
 
 void emu_run_wave(unsigned block, unsigned nblocks, const std::function<void()>& body);
 
+static void emu_fill_cfg(gq::ResetCfgDev* d, const GqResetCfg* cfg) {
+  d->seed_lo = (uint32_t)(cfg->seed & 0xffffffffu); d->seed_hi = (uint32_t)(cfg->seed >> 32);
+  d->random = cfg->random; d->q_pos_amp = cfg->q_pos_amp; d->q_vel_amp = cfg->q_vel_amp;
+  d->roll_sweep = cfg->roll_sweep; d->pitch_sweep = cfg->pitch_sweep; d->hip_height = cfg->hip_height;
+  for (int k = 0; k < 2; k++) { d->lin_vel_range[k] = cfg->lin_vel_range[k]; d->ang_vel_range[k] = cfg->ang_vel_range[k]; d->friction_range[k] = cfg->friction_range[k]; }
+  d->cmd_forward = cfg->cmd_forward; d->cmd_random = cfg->cmd_random; d->cmd_rotate = cfg->cmd_rotate; d->cmd_human = cfg->cmd_human;
+  d->env_id_offset = cfg->env_id_offset;
+}
+
+/* same control flow as gq::step_kernel (csrc/gq_kernels.hip) */
 extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_ids, int n_obs, const int32_t* legs_order,
                         const float* ctrl, const uint8_t* mask, double* qpos, float* qvel, float* qacc, float* warm,
-                        const float* applied, float* time, const float* friction, const float* cmd, float* obs,
+                        float* applied, float* time, float* friction, float* cmd, float* obs,
                         float* reward, uint8_t* terminated, uint8_t* truncated, uint8_t* invalid_contact,
-                        int32_t* step_num, float* debug, int debug_envs, char* err, int errlen) {
+                        int32_t* step_num, float* debug, int debug_envs, const GqResetCfg* auto_reset, int32_t* episode,
+                        uint8_t* lift_failed, float* friction_next, int first_pass, char* err, int errlen) {
   static GqDevModel M;
   static GqDevBatch B;
   std::vector<float> vx, vy, vz;
   if (gq_build_dev_model(desc, &M, &vx, &vy, &vz, err, (size_t)errlen)) return -1;
   if (gq_build_dev_batch(n_envs, obs_ids, n_obs, legs_order, &B, err, (size_t)errlen)) return -1;
   B.debug_envs = debug_envs;
-  gq::StepArgs a{};
+  gq::FusedArgs f{};
+  gq::StepArgs& a = f.s;
   a.model = &M; a.batch = &B; a.vx = vx.data(); a.vy = vy.data(); a.vz = vz.data();
   a.ctrl = ctrl; a.mask = mask; a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied;
-  a.time = time; a.friction = friction; a.cmd = cmd; a.obs = obs; a.reward = reward; a.terminated = terminated;
-  a.truncated = truncated; a.invalid_contact = invalid_contact; a.step_num = step_num; a.debug = debug; a.n_envs = n_envs;
+  a.time = time; a.friction = friction; a.cmd = cmd; a.friction_next = friction_next; a.obs = obs; a.reward = reward;
+  a.terminated = terminated; a.truncated = truncated; a.invalid_contact = invalid_contact; a.step_num = step_num;
+  a.debug = debug; a.n_envs = n_envs;
+  f.auto_reset = auto_reset != nullptr; f.first_pass = first_pass;
+  if (auto_reset) {
+    gq::ResetArgs& r = f.r;
+    r.model = &M; r.vx = vx.data(); r.vy = vy.data(); r.vz = vz.data();
+    r.qpos = qpos; r.qvel = qvel; r.qacc = qacc; r.warm = warm; r.applied = applied; r.time = time; r.cmd = cmd;
+    r.friction_next = friction_next; r.step_num = step_num; r.episode = episode; r.lift_failed = lift_failed;
+    emu_fill_cfg(&r.cfg, auto_reset);
+  }
   for (int e = 0; e < n_envs; e++) {
     if (mask && !mask[e]) continue;
     emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
       __shared__ gq::WaveMem W;
-      __shared__ float acc[4][21];
-      gq::step_wave(a, W, acc);
+      int pass = f.first_pass;
+      for (;;) {
+        const int term = gq::step_wave(f.s, W, pass);
+        if (pass == 1 || !f.auto_reset || !term) break;
+        gq::reset_wave(f.r, W);
+        pass = 1;
+      }
     });
   }
   return B.obs_dim;
@@ -48,11 +74,7 @@ extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mas
   a.model = &M; a.vx = vx.data(); a.vy = vy.data(); a.vz = vz.data(); a.mask = mask; a.qpos_new = qpos_new; a.qvel_new = qvel_new;
   a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied; a.time = time; a.cmd = cmd;
   a.friction_next = friction_next; a.step_num = step_num; a.episode = episode; a.lift_failed = lift_failed;
-  a.cfg.seed_lo = (uint32_t)(cfg->seed & 0xffffffffu); a.cfg.seed_hi = (uint32_t)(cfg->seed >> 32);
-  a.cfg.random = cfg->random; a.cfg.q_pos_amp = cfg->q_pos_amp; a.cfg.q_vel_amp = cfg->q_vel_amp;
-  a.cfg.roll_sweep = cfg->roll_sweep; a.cfg.pitch_sweep = cfg->pitch_sweep; a.cfg.hip_height = cfg->hip_height;
-  for (int k = 0; k < 2; k++) { a.cfg.lin_vel_range[k] = cfg->lin_vel_range[k]; a.cfg.ang_vel_range[k] = cfg->ang_vel_range[k]; a.cfg.friction_range[k] = cfg->friction_range[k]; }
-  a.cfg.cmd_forward = cfg->cmd_forward; a.cfg.cmd_random = cfg->cmd_random; a.cfg.cmd_rotate = cfg->cmd_rotate; a.cfg.cmd_human = cfg->cmd_human; a.cfg.env_id_offset = cfg->env_id_offset;
+  emu_fill_cfg(&a.cfg, cfg);
   for (int e = 0; e < n_envs; e++) {
     if (mask && !mask[e]) continue;
     emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {

@@ -51,6 +51,9 @@ static inline float wave_sum(float v) { uint32_t u; memcpy(&u, &v, 4); const uin
 static inline float wave_min(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::min(r, t); } return r; }
 static inline float wave_max(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = -INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::max(r, t); } return r; }
 static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+static inline void opaque(int&) {}
+static inline void opaque_s(int&) {}
+static inline void sched_fence() {}
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 static inline float med3(float x, float lo, float hi) { return std::min(std::max(x, lo), hi); }
