@@ -561,13 +561,13 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     a.qacc[(size_t)env * 18 + lane] = W.qacc[lane];
     a.warm[(size_t)env * 18 + lane] = W.qacc[lane];
   }
+  /* base x,y stay in f64 (uniform: every lane reads the same two words) and never enter fp32 arithmetic; they are
+   * read here, not at the top, so they do not occupy registers across the solver */
+  const double bx_d = a.qpos[(size_t)env * 19 + 0], by_d = a.qpos[(size_t)env * 19 + 1];
   wave_barrier();
   if (lane < GQ_NVD) W.qvel[lane] = vnew; /* new qvel; old one is not needed any more */
   wave_barrier();
   /* positions */
-  /* base x,y stay in f64 (uniform: every lane reads the same two words) and never enter fp32 arithmetic; they are
-   * read here, not at the top, so they do not occupy registers across the solver */
-  const double bx_d = a.qpos[(size_t)env * 19 + 0], by_d = a.qpos[(size_t)env * 19 + 1];
   const double bxn_d = bx_d + (double)h * (double)W.qvel[0], byn_d = by_d + (double)h * (double)W.qvel[1];
   if (lane == 0) a.qpos[(size_t)env * 19 + 0] = bxn_d;
   if (lane == 1) a.qpos[(size_t)env * 19 + 1] = byn_d;

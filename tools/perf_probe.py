@@ -1,0 +1,35 @@
+"""Kernel-time probe: step kernel duration (HIP events) vs PGS iteration cap and batch size."""
+import sys, time
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
+from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+
+def run(n, iters, tol, steps=300, auto=True, obs='all'):
+    names = tuple(QuadrupedEnv.ALL_OBS) if obs == 'all' else QuadrupedEnv._DEFAULT_OBS
+    env = QuadrupedEnv('mini_cheetah', state_obs_names=names, num_envs=n, auto_reset=auto, solver_iterations=iters, solver_tolerance=tol, seed=1)
+    env.reset()
+    g = torch.Generator(device='cuda').manual_seed(0)
+    pool = [torch.randn(n, 12, generator=g, device='cuda') * 50 for _ in range(16)]
+    for i in range(50): env.step(pool[i % 16])
+    env.enable_debug(min(n, 256))
+    env.step(pool[0]); torch.cuda.synchronize()
+    nit = np.mean([d['niter'][0] for d in env.debug_internals(min(n, 256), ['niter'])])
+    nefc = np.mean([d['nefc'][0] for d in env.debug_internals(min(n, 256), ['nefc'])])
+    env.enable_debug(0)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); s.record()
+    nterm = 0
+    for i in range(steps):
+        o, r, term, tr, info = env.step(pool[i % 16])
+    e.record(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
+    ms = s.elapsed_time(e) / steps
+    print(f'n={n:5d} iters={iters:3d} tol={tol:g} auto={auto} obs={obs}: {ms*1e3:7.1f} us/step (gpu) {wall/steps*1e6:7.1f} us/step (wall)  {n/ms/1e3:6.2f} M env-steps/s  mean niter {nit:.1f} nefc {nefc:.1f} term/step {float(term.float().mean()):.4f}')
+
+if __name__ == '__main__':
+    for it, tol in [(0, 0), (10, 0), (50, 0), (100, 1e-8)]:
+        run(4096, it, tol)
+    run(4096, 100, 1e-8, auto=False)
+    run(4096, 100, 1e-8, obs='default')
+    for n in (1024, 2048, 8192, 16384):
+        run(n, 100, 1e-8)
