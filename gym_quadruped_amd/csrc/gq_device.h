@@ -68,6 +68,9 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); } /* wave-uniform value */
 
+/* shader clock (s_memtime) for the stage timers of the debug record */
+__device__ __forceinline__ long long cycles() { return (long long)__builtin_readcyclecounter(); }
+
 /* instruction-scheduling fence: nothing moves across it */
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

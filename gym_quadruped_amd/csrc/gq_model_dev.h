@@ -96,4 +96,5 @@ struct GqDevBatch {            /* per-batch constants */
 #define GQ_DBG_CON_GEOM (GQ_DBG_CON_DIST + GQ_MAXCON)
 #define GQ_DBG_FOOT_POS (GQ_DBG_CON_GEOM + GQ_MAXCON)
 #define GQ_DBG_QACC (GQ_DBG_FOOT_POS + 12)
-#define GQ_DBG_SIZE (GQ_DBG_QACC + 18)
+#define GQ_DBG_TIMER (GQ_DBG_QACC + 18) /* 16 stage time stamps, shader cycles relative to kernel entry */
+#define GQ_DBG_SIZE (GQ_DBG_TIMER + 16)

@@ -115,6 +115,9 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   const int lane = lane_o, env = env_o;
   const GqDevModel& m = *a.model;
   const float h = m.timestep;
+  const bool timing = a.debug && pass == 0 && env < a.batch->debug_envs;
+  const long long t_start = timing ? cycles() : 0;
+#define GQ_TICK(i) do { if (timing && lane == 0) a.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); } while (0)
 
   /* ================================================================ S0: load the env's state rows */
   if (lane < 19) {
@@ -136,6 +139,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
 
   stage_kinematics(W, m);
 
+  GQ_TICK(1);
   /* ================================================================ S2: spatial inertias about O = base origin */
   const V3 O = v3(0.0f, 0.0f, W.basez);
   if (lane < GQ_NB) {
@@ -185,6 +189,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   if (lane < 10) W.u.dyn.crb[0][lane] = W.u.dyn.cinert[0][lane] + W.u.dyn.crb[1][lane] + W.u.dyn.crb[4][lane] + W.u.dyn.crb[7][lane] + W.u.dyn.crb[10][lane];
   wave_barrier();
 
+  GQ_TICK(2);
   /* ================================================================ S3: joint-space inertia */
   if (lane < GQ_NVD) {
     float buf[6];
@@ -199,10 +204,12 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   }
   wave_barrier();
 
+  GQ_TICK(3);
   /* ================================================================ S4: factorise M and M + h*D */
   factor_tree(W, 0, m.dof_damping, 0.0f);
   factor_tree(W, 1, m.dof_damping, h);
 
+  GQ_TICK(4);
   /* ================================================================ S5: velocity stage (mj_comVel, mj_rne) */
   if (lane < 4) {
     /* base velocity and bias acceleration, recomputed per leg lane */
@@ -267,9 +274,11 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     W.smooth[lane] = -m.dof_damping[lane] * W.qvel[lane] - bias + act + W.applied[lane];
   }
 
+  GQ_TICK(5);
   /* ================================================================ S6: collision with the floor (z = 0) */
   const int nlg = m.nlg;
   stage_collision_scan(W, m, a.vx, a.vy, a.vz, false);
+  GQ_TICK(14);
   /* contact list in MuJoCo's order (increasing geom id; con_order interleaves feet and link geoms), capped */
   if (lane == 0) {
     int nc = 0, invalid = 0;
@@ -340,6 +349,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   wave_barrier();
   const int nefc = W.nefc, ncon = W.ncon, nlim = W.nlim, nfl = m.nfl;
 
+  GQ_TICK(6);
   /* ================================================================ S7: constraint rows, lane = row */
   float J[GQ_NVD];
 #pragma unroll
@@ -418,6 +428,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     }
   }
 
+  GQ_TICK(7);
   /* ================================================================ S8: B = M^-1 J' (lane-parallel), A = J B' + R */
   float A[GQ_MAXEFC];
   float diag = 0.0f; /* A_ii = J_i . B_i */
@@ -456,6 +467,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
 #pragma unroll
   for (int k = 0; k < GQ_NVD; k++) W.u.B[lane][k] = (lane < nefc) ? J[k] : 0.0f;
 
+  GQ_TICK(8);
   /* ================================================================ S9: PGS on  min 1/2 f'(A+R)f + f'b */
   const bool active = lane < nefc;
   float lo = 0.0f, hi = 3.0e38f;
@@ -511,6 +523,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   W.force[lane] = active ? f : 0.0f;
   wave_barrier();
 
+  GQ_TICK(9);
   /* ================================================================ S10: accelerations and integration */
   if (lane < GQ_NVD) { /* qfrc_constraint = J' f */
     float sacc = 0.0f;
@@ -553,6 +566,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     if (lane < 12) D[GQ_DBG_FOOT_POS + lane] = W.foot_world[lane / 3][lane % 3];
   }
 
+  GQ_TICK(10);
   /* semi-implicit Euler (mj_Euler): velocity with the damped system, then positions with the new velocity */
   float vnew = 0.0f;
   if (lane < GQ_NVD) {
@@ -601,6 +615,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   float tnew = 0.0f;
   if (lane == 0) { tnew = a.time[env] + h; a.time[env] = tnew; }
 
+  GQ_TICK(11);
   /* ================================================================ S11: observations (new qpos/qvel, old kinematics) */
   float Rn[9];
   q2mat(Rn, qn);
@@ -707,12 +722,15 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
       if (pass == 1 && a.friction && a.friction_next) const_cast<float*>(a.friction)[env] = a.friction_next[env];
     }
   }
+  GQ_TICK(12);
   /* gather to the requested observation layout: coalesced row write */
   {
     const int od = a.batch->obs_dim;
     for (int k = lane; k < od; k += GQ_WAVE) a.obs[(size_t)env * od + k] = ob[a.batch->obs_map[k]];
   }
   wave_barrier(); /* the obs row overlays u: finish reading it before a second pass reuses the region */
+  GQ_TICK(13);
+#undef GQ_TICK
   return terminated;
 }
 

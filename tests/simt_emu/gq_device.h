@@ -54,6 +54,7 @@ static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline void opaque(int&) {}
 static inline void opaque_s(int&) {}
 static inline void sched_fence() {}
+static inline long long cycles() { return 0; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 static inline float med3(float x, float lo, float hi) { return std::min(std::max(x, lo), hi); }

@@ -26,10 +26,33 @@ def run(n, iters, tol, steps=300, auto=True, obs='all'):
     ms = s.elapsed_time(e) / steps
     print(f'n={n:5d} iters={iters:3d} tol={tol:g} auto={auto} obs={obs}: {ms*1e3:7.1f} us/step (gpu) {wall/steps*1e6:7.1f} us/step (wall)  {n/ms/1e3:6.2f} M env-steps/s  mean niter {nit:.1f} nefc {nefc:.1f} term/step {float(term.float().mean()):.4f}')
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     for it, tol in [(0, 0), (10, 0), (50, 0), (100, 1e-8)]:
         run(4096, it, tol)
     run(4096, 100, 1e-8, auto=False)
     run(4096, 100, 1e-8, obs='default')
     for n in (1024, 2048, 8192, 16384):
         run(n, 100, 1e-8)
+
+
+def stage_times(n=4096, iters=100, tol=1e-8):
+    env = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset=True, solver_iterations=iters, solver_tolerance=tol, seed=1)
+    env.reset()
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for i in range(60): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)
+    env.enable_debug(n)
+    env.step(torch.randn(n, 12, generator=g, device='cuda') * 50); torch.cuda.synchronize()
+    d = env.debug_internals(n, ['timer', 'niter', 'nefc'])
+    T = np.stack([x['timer'] for x in d]); nit = np.array([x['niter'][0] for x in d]); ne = np.array([x['nefc'][0] for x in d])
+    names = ['S0 load', 'S1 kin', 'S2 inert', 'S3 M', 'S4 factor', 'S5 rne', 'S6a scan', 'S6b list', 'S7 rows', 'S8 dual', 'S9 pgs', 'S10 acc', 'S10 int', 'S11 obs', 'gather']
+    order = [1, 2, 3, 4, 5, 14, 6, 7, 8, 9, 10, 11, 12, 13]
+    prev = np.zeros(n)
+    print(f'stage times in shader cycles (mean / p95 / max over {n} envs); niter mean {nit.mean():.1f} p95 {np.percentile(nit,95):.0f} max {nit.max():.0f}; nefc mean {ne.mean():.1f} max {ne.max():.0f}')
+    for nm, k in zip(names, order):
+        dt = T[:, k] - prev; prev = T[:, k]
+        print(f'  {nm:10s} {dt.mean():9.0f} {np.percentile(dt,95):9.0f} {dt.max():9.0f}')
+    print(f'  total      {T[:,13].mean():9.0f} {np.percentile(T[:,13],95):9.0f} {T[:,13].max():9.0f}')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'stages':
+    stage_times()
