@@ -206,8 +206,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
 
   GQ_TICK(3);
   /* ================================================================ S4: factorise M and M + h*D */
-  factor_tree(W, 0, m.dof_damping, 0.0f);
-  factor_tree(W, 1, m.dof_damping, h);
+  factor_tree_both(W, m.dof_damping, h);
 
   GQ_TICK(4);
   /* ================================================================ S5: velocity stage (mj_comVel, mj_rne) */
@@ -279,72 +278,86 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   const int nlg = m.nlg;
   stage_collision_scan(W, m, a.vx, a.vy, a.vz, false);
   GQ_TICK(14);
-  /* contact list in MuJoCo's order (increasing geom id; con_order interleaves feet and link geoms), capped */
-  if (lane == 0) {
-    int nc = 0, invalid = 0;
-    for (int k = 0; k < 4; k++) W.foot_touch[k] = 0;
-    for (int k = 0; k < 4; k++) W.foot_con[k] = -1;
-    for (int it = 0; it < 4 + nlg; it++) {
-      const int code = m.con_order[it];
+  /* contact list in MuJoCo's order (increasing geom id; con_order interleaves feet and link geoms), capped.
+   * Lane `it` evaluates collision item `it`; ranks and row offsets come from ballots (no serial section). */
+  {
+    const int nitem = 4 + nlg;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    bool touching = false, calf = false;
+    int code = 0, body = 0, dim = 3;
+    float dist = 0.0f, inc = 0.0f, mu = 0.0f, px = 0.0f, py = 0.0f, pz = 0.0f;
+    const float* solref = m.foot_solref[0];
+    const float* solimp = m.foot_solimp[0];
+    if (lane < nitem) {
+      code = m.con_order[lane];
+      const float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0];
       if (code < 4) {
-      const int k = code;
-      float dist = W.foot_world[k][2] - m.foot_radius[k];
-      if (dist < m.foot_margin[k]) W.foot_touch[k] = 1;
-      if (dist < m.foot_margin[k] && nc < GQ_MAXCON) {
-        W.foot_con[k] = nc;
-        W.con_geom[nc] = k; W.con_body[nc] = 3 + 3 * m.foot_leg[k]; W.con_dim[nc] = m.foot_dim[k];
-        W.con_dist[nc] = dist; W.con_inc[nc] = m.foot_includemargin[k];
-        W.con_pos[nc][0] = W.foot_world[k][0]; W.con_pos[nc][1] = W.foot_world[k][1];
-        W.con_pos[nc][2] = W.foot_world[k][2] - (m.foot_radius[k] + 0.5f * dist);
+        const int k = code;
+        dist = W.foot_world[k][2] - m.foot_radius[k];
+        touching = dist < m.foot_margin[k];
+        body = 3 + 3 * m.foot_leg[k]; dim = m.foot_dim[k]; inc = m.foot_includemargin[k]; calf = true;
+        px = W.foot_world[k][0]; py = W.foot_world[k][1]; pz = W.foot_world[k][2] - (m.foot_radius[k] + 0.5f * dist);
         /* friction mixing; _set_ground_friction overrides floor and feet with [mu, 0.005, 0] (quadruped_env.py:1292) */
-        float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0], fg = mu_env >= 0.0f ? mu_env : m.foot_friction[k][0];
-        int rule = m.foot_fric_rule[k];
-        W.con_mu[nc] = rule == 0 ? fmaxf(ff, fg) : (rule == 1 ? ff : fg);
-        W.con_solref[nc][0] = m.foot_solref[k][0]; W.con_solref[nc][1] = m.foot_solref[k][1];
-        for (int q = 0; q < 5; q++) W.con_solimp[nc][q] = m.foot_solimp[k][q];
-        nc++;
-      }
+        const float fg = mu_env >= 0.0f ? mu_env : m.foot_friction[k][0];
+        const int rule = m.foot_fric_rule[k];
+        mu = rule == 0 ? fmaxf(ff, fg) : (rule == 1 ? ff : fg);
+        solref = m.foot_solref[k]; solimp = m.foot_solimp[k];
       } else {
-      const int g = code - 4;
-      const GqDevGeom& G = m.lg[g];
-      float dist = W.lg_dist[g];
-      if (dist < G.margin) { /* _check_for_invalid_contacts (quadruped_env.py:1228-1248): body-level test */
-        const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
-        if (!calf) invalid = 1;
-        else for (int k = 0; k < 4; k++) if (3 + 3 * m.foot_leg[k] == G.body) W.foot_touch[k] = 1;
-      }
-      if (dist < G.margin && nc < GQ_MAXCON) {
-        W.con_geom[nc] = 4 + g; W.con_body[nc] = G.body; W.con_dim[nc] = G.dim;
-        W.con_dist[nc] = dist; W.con_inc[nc] = G.includemargin;
-        W.con_pos[nc][0] = W.lg_pt[g][0]; W.con_pos[nc][1] = W.lg_pt[g][1];
-        W.con_pos[nc][2] = W.lg_pt[g][2] - (G.radius + 0.5f * dist);
-        float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0], fg = G.friction[0];
-        W.con_mu[nc] = G.fric_rule == 0 ? fmaxf(ff, fg) : (G.fric_rule == 1 ? ff : fg);
-        W.con_solref[nc][0] = G.solref[0]; W.con_solref[nc][1] = G.solref[1];
-        for (int q = 0; q < 5; q++) W.con_solimp[nc][q] = G.solimp[q];
-        nc++;
-      }
+        const int g = code - 4;
+        const GqDevGeom& G = m.lg[g];
+        dist = W.lg_dist[g];
+        touching = dist < G.margin;
+        body = G.body; dim = G.dim; inc = G.includemargin; calf = G.body > 0 && (G.body - 1) % 3 == 2;
+        px = W.lg_pt[g][0]; py = W.lg_pt[g][1]; pz = W.lg_pt[g][2] - (G.radius + 0.5f * dist);
+        const float fg = G.friction[0];
+        mu = G.fric_rule == 0 ? fmaxf(ff, fg) : (G.fric_rule == 1 ? ff : fg);
+        solref = G.solref; solimp = G.solimp;
       }
     }
-    /* joint limits */
-    int nl = 0;
-    for (int j = 0; j < GQ_NJ; j++)
-      if (m.jnt_limited[j]) {
-        float q = W.qj[j];
-        float dlo = q - m.jnt_range[j][0], dhi = m.jnt_range[j][1] - q;
-        if (dlo < m.jnt_margin[j]) { W.lim_jnt[nl] = j; W.lim_side[nl] = 1.0f; W.lim_dist[nl] = dlo; nl++; }
-        if (dhi < m.jnt_margin[j] && nl < GQ_NJ) { W.lim_jnt[nl] = j; W.lim_side[nl] = -1.0f; W.lim_dist[nl] = dhi; nl++; }
-      }
-    /* row budget: friction rows, limit rows, then whole contacts while they fit */
-    int rows = m.nfl + nl, ncfit = 0;
-    for (int c = 0; c < nc; c++) {
-      int need = W.con_dim[c] == 1 ? 1 : 2 * (W.con_dim[c] - 1);
-      if (rows + need > GQ_MAXEFC) break;
-      W.con_row[c] = rows; rows += need; ncfit++;
+    const uint64_t touch_mask = ballot(touching);
+    /* _check_for_invalid_contacts (quadruped_env.py:1228-1248): body-level test, before any capping */
+    const int invalid = ballot(touching && !calf) != 0;
+    int ft[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ft[k] = ballot(touching && body == 3 + 3 * m.foot_leg[k]) != 0;
+    /* joint limits: lane j < 12 owns hinge j (lower side first, then upper) */
+    bool lim_lo = false, lim_hi = false;
+    float dlo = 0.0f, dhi = 0.0f;
+    if (lane < GQ_NJ && m.jnt_limited[lane]) {
+      const float q = W.qj[lane];
+      dlo = q - m.jnt_range[lane][0]; dhi = m.jnt_range[lane][1] - q;
+      lim_lo = dlo < m.jnt_margin[lane]; lim_hi = dhi < m.jnt_margin[lane];
     }
-    for (int k = 0; k < 4; k++)
-      if (W.foot_con[k] >= ncfit) W.foot_con[k] = -1;
-    W.ncon = ncfit; W.nlim = nl; W.nefc = rows; W.invalid = invalid;
+    const uint64_t mlo = ballot(lim_lo), mhi = ballot(lim_hi);
+    int nl = popc64(mlo) + popc64(mhi);
+    {
+      int at = popc64(mlo & lt) + popc64(mhi & lt);
+      if (lim_lo && at < GQ_NJ) { W.lim_jnt[at] = lane; W.lim_side[at] = 1.0f; W.lim_dist[at] = dlo; at++; }
+      if (lim_hi && at < GQ_NJ) { W.lim_jnt[at] = lane; W.lim_side[at] = -1.0f; W.lim_dist[at] = dhi; }
+      if (nl > GQ_NJ) nl = GQ_NJ;
+    }
+    /* row budget: friction rows, limit rows, then whole contacts in order while they fit (a prefix of the list) */
+    const int idx = popc64(touch_mask & lt);
+    const bool kept = touching && idx < GQ_MAXCON;
+    const int need = dim == 1 ? 1 : 2 * (dim - 1);
+    const uint64_t m1 = ballot(kept && need == 1), m4 = ballot(kept && need == 4);
+    const int row0 = m.nfl + nl + popc64(m1 & lt) + 4 * popc64(m4 & lt);
+    const bool fits = kept && row0 + need <= GQ_MAXEFC;
+    const uint64_t fit_mask = ballot(fits);
+    const uint64_t f1 = ballot(fits && need == 1), f4 = ballot(fits && need == 4);
+    if (fits) {
+      W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
+      W.con_dist[idx] = dist; W.con_inc[idx] = inc; W.con_mu[idx] = mu;
+      W.con_pos[idx][0] = px; W.con_pos[idx][1] = py; W.con_pos[idx][2] = pz;
+      W.con_solref[idx][0] = solref[0]; W.con_solref[idx][1] = solref[1];
+#pragma unroll
+      for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = solimp[q];
+    }
+    if (lane == 0) {
+      W.ncon = popc64(fit_mask); W.nlim = nl; W.nefc = m.nfl + nl + popc64(f1) + 4 * popc64(f4); W.invalid = invalid;
+#pragma unroll
+      for (int k = 0; k < 4; k++) W.foot_touch[k] = ft[k];
+    }
   }
   wave_barrier();
   const int nefc = W.nefc, ncon = W.ncon, nlim = W.nlim, nfl = m.nfl;
@@ -525,25 +538,30 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
 
   GQ_TICK(9);
   /* ================================================================ S10: accelerations and integration */
-  if (lane < GQ_NVD) { /* qfrc_constraint = J' f */
-    float sacc = 0.0f;
-    for (int i = 0; i < nefc; i++) sacc += W.u.B[i][lane] * W.force[i];
-    W.qfrc_c[lane] = sacc;
+  if (lane < GQ_NVD) { /* qfrc_constraint = J' f: four independent partial sums keep the LDS reads pipelined */
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int i = 0;
+    for (; i + 4 <= nefc; i += 4) {
+      s0 += W.u.B[i][lane] * W.force[i]; s1 += W.u.B[i + 1][lane] * W.force[i + 1];
+      s2 += W.u.B[i + 2][lane] * W.force[i + 2]; s3 += W.u.B[i + 3][lane] * W.force[i + 3];
+    }
+    for (; i < nefc; i++) s0 += W.u.B[i][lane] * W.force[i];
+    W.qfrc_c[lane] = (s0 + s1) + (s2 + s3);
   }
   wave_barrier();
-  {
-    float x[GQ_NVD];
-    const int which = lane & 1;
+  { /* qacc = qacc_smooth + M^-1 qfrc_c ;  Euler: (M + h D) qacc_int = qfrc_smooth + qfrc_c.  Even lanes solve the
+     * first system, odd lanes the second: one pass over each factor, every lane busy */
+    float x[GQ_NVD], y[GQ_NVD];
 #pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) x[k] = W.qfrc_c[k] + (which ? W.smooth[k] : 0.0f);
-    solve_tree(W, which, x);
-    if (lane == 0) {
+    for (int k = 0; k < GQ_NVD; k++) { x[k] = W.qfrc_c[k]; y[k] = x[k] + W.smooth[k]; }
+    solve_tree(W, 0, x);
+    solve_tree(W, 1, y);
+    if (lane < GQ_NVD) {
+      float qa = 0.0f, qi = 0.0f;
 #pragma unroll
-      for (int k = 0; k < GQ_NVD; k++) W.qacc[k] = W.qacc_smooth[k] + x[k];
-    }
-    if (lane == 1) {
-#pragma unroll
-      for (int k = 0; k < GQ_NVD; k++) W.qacc_int[k] = x[k];
+      for (int k = 0; k < GQ_NVD; k++) { qa = (k == lane) ? x[k] : qa; qi = (k == lane) ? y[k] : qi; }
+      W.qacc[lane] = W.qacc_smooth[lane] + qa;
+      W.qacc_int[lane] = qi;
     }
   }
   wave_barrier();

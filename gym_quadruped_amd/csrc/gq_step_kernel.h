@@ -52,6 +52,12 @@ enum {
   OB_CONTACT_F = 203, OB_CONTACT_F_B = 215
 };
 
+/* flat layout of one tree-sparse L'DL factor in LDS */
+#define GQ_F_LC(k, j) ((k) * 8 + (j))          /* leg dof 6+k, column j: 0-5 base, 6 hip, 7 thigh */
+#define GQ_F_LB(i, j) (96 + (i) * 6 + (j))     /* base block, lower */
+#define GQ_F_DINV(k) (132 + (k))
+#define GQ_FACTOR_SIZE 150
+
 enum { ROW_NONE = 0, ROW_FRICTION = 1, ROW_LIMIT = 2, ROW_CONTACT1 = 3, ROW_PYRAMID = 4 };
 
 /* ------------------------------------------------------------------ per-wave LDS working set (8.5 KB: 16+ waves per CU)
@@ -60,7 +66,7 @@ enum { ROW_NONE = 0, ROW_FRICTION = 1, ROW_LIMIT = 2, ROW_CONTACT1 = 3, ROW_PYRA
 struct WaveDyn {
   float anchor[GQ_NJ][3], axis[GQ_NJ][3];
   float cinert[GQ_NB][10];
-  union { float crb[GQ_NB][10]; float acc[4][21]; };    /* acc: per-leg Schur updates of the base block (S4, crb is dead) */
+  union { float crb[GQ_NB][10]; float acc[8][21]; };    /* acc: per-leg Schur updates of the base block (S4, crb is dead) */
   float cvel[GQ_NB][6], cacc[GQ_NB][6], cfrc[GQ_NB][6];
 };
 struct WaveMem {
@@ -72,7 +78,7 @@ struct WaveMem {
   float Mc[GQ_NJ][9], Mb[6][6];
   /* L'DL factors, tree-sparse storage: leg dof k >= 6 keeps [b0..b5, hip, thigh] (8 floats), base rows 6x6 lower.
    * [0]: M, [1]: M + h*diag(damping) */
-  float Lc[2][GQ_NJ][8], Lb[2][6][6], Dinv[2][GQ_NVD];
+  float F[2][GQ_FACTOR_SIZE];  /* per factor: Lc[12][8] | Lb[6][6] | Dinv[18], see the GQ_F_* offsets */
   float bias[18], act[18], smooth[18], qacc_smooth[18], qfrc_c[18], qacc[18], qacc_int[18];
   /* contacts */
   int32_t ncon, nefc, nlim, invalid;
@@ -166,147 +172,171 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   return dmin + y * (dmax - dmin);
 }
 
-/* L'DL of a matrix with the robot's dof-tree sparsity (mj_factorI).  src: dense symmetric in LDS, diag_add: added
- * to the diagonal (h*damping for the Euler system).  Lanes 0-3 eliminate their leg's three dofs in registers and
- * emit their Schur contribution to the 6x6 base block; lane 0 then factors the base block. */
-/* hscale * damping[dof] is added to the diagonal: h for the Euler system M + h*D, 0 for M itself */
-__device__ inline void factor_tree(WaveMem& W, int which, const float* damping, const float hscale) {
+/* L'DL of M (factor 0) and of M + h*diag(damping) (factor 1, the Euler system) with the robot's dof-tree sparsity
+ * (mj_factorI), both at once: lanes 0-3 eliminate the three dofs of their leg for factor 0 in registers, lanes 4-7 do
+ * the same for factor 1, each emitting its Schur contribution to the 6x6 base block; lanes 0 and 4 then factor the
+ * two base blocks.  Reciprocals use v_rcp_f32 (1 ulp). */
+__device__ inline void factor_tree_both(WaveMem& W, const float* damping, const float h) {
   const int lane = lane_id();
-  float(*Lc)[8] = W.Lc[which];
-  float(*Lb)[6] = W.Lb[which];
+  const int which = (lane >> 2) & 1, leg = lane & 3;
+  const float hscale = which ? h : 0.0f;
+  float* F = W.F[which];
   float(*acc)[21] = W.u.dyn.acc;
-  if (lane < 4) {
-    const int h = 6 + 3 * lane, t = h + 1, c = h + 2;
+  if (lane < 8) {
+    const int hh = 6 + 3 * leg, t = hh + 1, c = hh + 2;
     /* rows over columns [b0..b5, h, t, c] */
     float rc[9], rt[8], rh[7], bb[21];
 #pragma unroll
-    for (int j = 0; j < 6; j++) { rc[j] = W.Mc[c - 6][j]; rt[j] = W.Mc[t - 6][j]; rh[j] = W.Mc[h - 6][j]; }
+    for (int j = 0; j < 6; j++) { rc[j] = W.Mc[c - 6][j]; rt[j] = W.Mc[t - 6][j]; rh[j] = W.Mc[hh - 6][j]; }
     rc[6] = W.Mc[c - 6][6]; rc[7] = W.Mc[c - 6][7]; rc[8] = W.Mc[c - 6][8] + hscale * damping[c];
     rt[6] = W.Mc[t - 6][6]; rt[7] = W.Mc[t - 6][7] + hscale * damping[t];
-    rh[6] = W.Mc[h - 6][6] + hscale * damping[h];
+    rh[6] = W.Mc[hh - 6][6] + hscale * damping[hh];
 #pragma unroll
-    for (int k = 0; k < 21; k++) bb[k] = 0.0f;
-    /* eliminate calf: ancestors t(7), h(6), b5..b0 */
-    {
-      float inv = 1.0f / rc[8], tmp;
-      tmp = rc[7] * inv;
+    for (int q = 0; q < 21; q++) bb[q] = 0.0f;
+    const float ic = fast_rcp(rc[8]);
+    { /* eliminate calf: ancestors t(7), h(6), b5..b0 */
+      float tmp = rc[7] * ic;
 #pragma unroll
       for (int j = 0; j <= 7; j++) rt[j] -= rc[j] * tmp;
       rc[7] = tmp;
-      tmp = rc[6] * inv;
+      tmp = rc[6] * ic;
 #pragma unroll
       for (int j = 0; j <= 6; j++) rh[j] -= rc[j] * tmp;
       rc[6] = tmp;
 #pragma unroll
       for (int i = 5; i >= 0; i--) {
-        tmp = rc[i] * inv;
+        tmp = rc[i] * ic;
 #pragma unroll
         for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rc[j] * tmp;
         rc[i] = tmp;
       }
     }
+    const float it = fast_rcp(rt[7]);
     { /* thigh: ancestors h(6), b5..b0 */
-      float inv = 1.0f / rt[7], tmp;
-      tmp = rt[6] * inv;
+      float tmp = rt[6] * it;
 #pragma unroll
       for (int j = 0; j <= 6; j++) rh[j] -= rt[j] * tmp;
       rt[6] = tmp;
 #pragma unroll
       for (int i = 5; i >= 0; i--) {
-        tmp = rt[i] * inv;
+        tmp = rt[i] * it;
 #pragma unroll
         for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rt[j] * tmp;
         rt[i] = tmp;
       }
     }
+    const float ih = fast_rcp(rh[6]);
     { /* hip: ancestors b5..b0 */
-      float inv = 1.0f / rh[6], tmp;
 #pragma unroll
       for (int i = 5; i >= 0; i--) {
-        tmp = rh[i] * inv;
+        const float tmp = rh[i] * ih;
 #pragma unroll
         for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rh[j] * tmp;
         rh[i] = tmp;
       }
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) { Lc[c - 6][j] = rc[j]; Lc[t - 6][j] = rt[j]; Lc[h - 6][j] = rh[j]; }
-    Lc[c - 6][6] = rc[6]; Lc[c - 6][7] = rc[7]; Lc[t - 6][6] = rt[6];
-    W.Dinv[which][c] = 1.0f / rc[8]; W.Dinv[which][t] = 1.0f / rt[7]; W.Dinv[which][h] = 1.0f / rh[6];
+    for (int j = 0; j < 6; j++) { F[GQ_F_LC(c - 6, j)] = rc[j]; F[GQ_F_LC(t - 6, j)] = rt[j]; F[GQ_F_LC(hh - 6, j)] = rh[j]; }
+    F[GQ_F_LC(c - 6, 6)] = rc[6]; F[GQ_F_LC(c - 6, 7)] = rc[7]; F[GQ_F_LC(t - 6, 6)] = rt[6];
+    F[GQ_F_DINV(c)] = ic; F[GQ_F_DINV(t)] = it; F[GQ_F_DINV(hh)] = ih;
 #pragma unroll
-    for (int k = 0; k < 21; k++) acc[lane][k] = bb[k];
+    for (int q = 0; q < 21; q++) acc[lane][q] = bb[q];
   }
   wave_barrier();
-  /* NOTE: acc overlays dyn.crb, which S3 has finished with; the first barrier of the SECOND factor call also
-   * separates lane 0's reads of acc from the legs' next writes */
-  if (lane == 0) {
+  if (lane == 0 || lane == 4) {
     float b[6][6];
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
       for (int j = 0; j <= i; j++) {
-        int k = i * (i + 1) / 2 + j;
-        b[i][j] = W.Mb[i][j] + (i == j ? hscale * damping[i] : 0.0f) + acc[0][k] + acc[1][k] + acc[2][k] + acc[3][k];
+        const int q = i * (i + 1) / 2 + j;
+        b[i][j] = W.Mb[i][j] + (i == j ? hscale * damping[i] : 0.0f) + acc[lane][q] + acc[lane + 1][q] + acc[lane + 2][q] + acc[lane + 3][q];
       }
 #pragma unroll
     for (int k = 5; k >= 0; k--) {
-      float inv = 1.0f / b[k][k];
+      const float inv = fast_rcp(b[k][k]);
 #pragma unroll
       for (int i = k - 1; i >= 0; i--) {
-        float tmp = b[k][i] * inv;
+        const float tmp = b[k][i] * inv;
 #pragma unroll
         for (int j = 0; j <= i; j++) b[i][j] -= b[k][j] * tmp;
         b[k][i] = tmp;
       }
-      W.Dinv[which][k] = inv;
+      F[GQ_F_DINV(k)] = inv;
     }
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-      for (int j = 0; j < i; j++) Lb[i][j] = b[i][j];
+      for (int j = 0; j < i; j++) F[GQ_F_LB(i, j)] = b[i][j];
   }
   wave_barrier();
 }
 
-/* x <- (L' D L)^-1 x on 18 registers per lane; L and Dinv are wave-uniform LDS reads (mj_solveLD) */
-__device__ __forceinline__ void solve_tree(const WaveMem& W, int which, float* x) {
-  const float(*Lc)[8] = W.Lc[which];
-  const float(*Lb)[6] = W.Lb[which];
-  const float* Dinv = W.Dinv[which];
-#pragma unroll
-  for (int leg = 3; leg >= 0; leg--) {
-    const int h = 6 + 3 * leg, t = h + 1, c = h + 2;
-    x[t] -= Lc[c - 6][7] * x[c]; x[h] -= Lc[c - 6][6] * x[c];
-#pragma unroll
-    for (int j = 0; j < 6; j++) x[j] -= Lc[c - 6][j] * x[c];
-    x[h] -= Lc[t - 6][6] * x[t];
-#pragma unroll
-    for (int j = 0; j < 6; j++) x[j] -= Lc[t - 6][j] * x[t];
-#pragma unroll
-    for (int j = 0; j < 6; j++) x[j] -= Lc[h - 6][j] * x[h];
-  }
-#pragma unroll
-  for (int k = 5; k >= 1; k--)
-#pragma unroll
-    for (int j = 0; j < k; j++) x[j] -= Lb[k][j] * x[k];
-#pragma unroll
-  for (int k = 0; k < 18; k++) x[k] *= Dinv[k];
-#pragma unroll
-  for (int k = 1; k < 6; k++)
-#pragma unroll
-    for (int j = 0; j < k; j++) x[k] -= Lb[k][j] * x[j];
-#pragma unroll
-  for (int leg = 0; leg < 4; leg++) {
-    const int h = 6 + 3 * leg, t = h + 1, c = h + 2;
-#pragma unroll
-    for (int j = 0; j < 6; j++) x[h] -= Lc[h - 6][j] * x[j];
-#pragma unroll
-    for (int j = 0; j < 6; j++) x[t] -= Lc[t - 6][j] * x[j];
-    x[t] -= Lc[t - 6][6] * x[h];
-#pragma unroll
-    for (int j = 0; j < 6; j++) x[c] -= Lc[c - 6][j] * x[j];
-    x[c] -= Lc[c - 6][6] * x[h]; x[c] -= Lc[c - 6][7] * x[t];
-  }
+/* x <- (L' D L)^-1 x on 18 registers per lane (mj_solveLD).  The 150 factor words are fetched from LDS once,
+ * coalesced (3 words per lane), and every coefficient is then broadcast with v_readlane_b32 into the scalar operand
+ * of the FMA - no LDS latency inside the dependent chains.  All lanes run the solve, each on its own right-hand side. */
+struct FactorRegs { float f0, f1, f2; };
+__device__ __forceinline__ FactorRegs load_factor(const WaveMem& W, int which) {
+  const int lane = lane_id();
+  FactorRegs r;
+  r.f0 = W.F[which][lane];
+  r.f1 = W.F[which][64 + lane];
+  r.f2 = lane < GQ_FACTOR_SIZE - 128 ? W.F[which][128 + lane] : 0.0f;
+  return r;
 }
+template <int E>
+__device__ __forceinline__ float fcoef(const FactorRegs& r) {
+  return readlane<(E & 63)>(E < 64 ? r.f0 : (E < 128 ? r.f1 : r.f2));
+}
+#define LCF(k, j) fcoef<GQ_F_LC(k, j)>(fr)
+#define LBF(i, j) fcoef<GQ_F_LB(i, j)>(fr)
+#define DIF(k) fcoef<GQ_F_DINV(k)>(fr)
+
+template <int LEG>
+__device__ __forceinline__ void solve_back_leg(const FactorRegs& fr, float* x) {
+  constexpr int h = 6 + 3 * LEG, t = h + 1, c = h + 2;
+  x[t] -= LCF(c - 6, 7) * x[c]; x[h] -= LCF(c - 6, 6) * x[c];
+  x[0] -= LCF(c - 6, 0) * x[c]; x[1] -= LCF(c - 6, 1) * x[c]; x[2] -= LCF(c - 6, 2) * x[c];
+  x[3] -= LCF(c - 6, 3) * x[c]; x[4] -= LCF(c - 6, 4) * x[c]; x[5] -= LCF(c - 6, 5) * x[c];
+  x[h] -= LCF(t - 6, 6) * x[t];
+  x[0] -= LCF(t - 6, 0) * x[t]; x[1] -= LCF(t - 6, 1) * x[t]; x[2] -= LCF(t - 6, 2) * x[t];
+  x[3] -= LCF(t - 6, 3) * x[t]; x[4] -= LCF(t - 6, 4) * x[t]; x[5] -= LCF(t - 6, 5) * x[t];
+  x[0] -= LCF(h - 6, 0) * x[h]; x[1] -= LCF(h - 6, 1) * x[h]; x[2] -= LCF(h - 6, 2) * x[h];
+  x[3] -= LCF(h - 6, 3) * x[h]; x[4] -= LCF(h - 6, 4) * x[h]; x[5] -= LCF(h - 6, 5) * x[h];
+}
+template <int LEG>
+__device__ __forceinline__ void solve_fwd_leg(const FactorRegs& fr, float* x) {
+  constexpr int h = 6 + 3 * LEG, t = h + 1, c = h + 2;
+  x[h] -= LCF(h - 6, 0) * x[0] + LCF(h - 6, 1) * x[1] + LCF(h - 6, 2) * x[2] + LCF(h - 6, 3) * x[3] + LCF(h - 6, 4) * x[4] + LCF(h - 6, 5) * x[5];
+  x[t] -= LCF(t - 6, 0) * x[0] + LCF(t - 6, 1) * x[1] + LCF(t - 6, 2) * x[2] + LCF(t - 6, 3) * x[3] + LCF(t - 6, 4) * x[4] + LCF(t - 6, 5) * x[5] + LCF(t - 6, 6) * x[h];
+  x[c] -= LCF(c - 6, 0) * x[0] + LCF(c - 6, 1) * x[1] + LCF(c - 6, 2) * x[2] + LCF(c - 6, 3) * x[3] + LCF(c - 6, 4) * x[4] + LCF(c - 6, 5) * x[5] + LCF(c - 6, 6) * x[h] + LCF(c - 6, 7) * x[t];
+}
+
+__device__ __forceinline__ void solve_tree(const WaveMem& W, int which, float* x) {
+  const FactorRegs fr = load_factor(W, which);
+  solve_back_leg<3>(fr, x); sched_fence(); solve_back_leg<2>(fr, x); sched_fence();
+  solve_back_leg<1>(fr, x); sched_fence(); solve_back_leg<0>(fr, x); sched_fence();
+  x[0] -= LBF(5, 0) * x[5]; x[1] -= LBF(5, 1) * x[5]; x[2] -= LBF(5, 2) * x[5]; x[3] -= LBF(5, 3) * x[5]; x[4] -= LBF(5, 4) * x[5];
+  x[0] -= LBF(4, 0) * x[4]; x[1] -= LBF(4, 1) * x[4]; x[2] -= LBF(4, 2) * x[4]; x[3] -= LBF(4, 3) * x[4];
+  x[0] -= LBF(3, 0) * x[3]; x[1] -= LBF(3, 1) * x[3]; x[2] -= LBF(3, 2) * x[3];
+  x[0] -= LBF(2, 0) * x[2]; x[1] -= LBF(2, 1) * x[2];
+  x[0] -= LBF(1, 0) * x[1];
+  sched_fence();
+  x[0] *= DIF(0); x[1] *= DIF(1); x[2] *= DIF(2); x[3] *= DIF(3); x[4] *= DIF(4); x[5] *= DIF(5);
+  x[6] *= DIF(6); x[7] *= DIF(7); x[8] *= DIF(8); x[9] *= DIF(9); x[10] *= DIF(10); x[11] *= DIF(11);
+  x[12] *= DIF(12); x[13] *= DIF(13); x[14] *= DIF(14); x[15] *= DIF(15); x[16] *= DIF(16); x[17] *= DIF(17);
+  sched_fence();
+  x[1] -= LBF(1, 0) * x[0];
+  x[2] -= LBF(2, 0) * x[0] + LBF(2, 1) * x[1];
+  x[3] -= LBF(3, 0) * x[0] + LBF(3, 1) * x[1] + LBF(3, 2) * x[2];
+  x[4] -= LBF(4, 0) * x[0] + LBF(4, 1) * x[1] + LBF(4, 2) * x[2] + LBF(4, 3) * x[3];
+  x[5] -= LBF(5, 0) * x[0] + LBF(5, 1) * x[1] + LBF(5, 2) * x[2] + LBF(5, 3) * x[3] + LBF(5, 4) * x[4];
+  sched_fence();
+  solve_fwd_leg<0>(fr, x); sched_fence(); solve_fwd_leg<1>(fr, x); sched_fence();
+  solve_fwd_leg<2>(fr, x); sched_fence(); solve_fwd_leg<3>(fr, x); sched_fence();
+}
+#undef LCF
+#undef LBF
+#undef DIF
 
 }  // namespace gq

@@ -44,7 +44,7 @@ def stage_times(n=4096, iters=100, tol=1e-8):
     env.step(torch.randn(n, 12, generator=g, device='cuda') * 50); torch.cuda.synchronize()
     d = env.debug_internals(n, ['timer', 'niter', 'nefc'])
     T = np.stack([x['timer'] for x in d]); nit = np.array([x['niter'][0] for x in d]); ne = np.array([x['nefc'][0] for x in d])
-    names = ['S0 load', 'S1 kin', 'S2 inert', 'S3 M', 'S4 factor', 'S5 rne', 'S6a scan', 'S6b list', 'S7 rows', 'S8 dual', 'S9 pgs', 'S10 acc', 'S10 int', 'S11 obs', 'gather']
+    names = ['S0+S1 kin', 'S2 inert', 'S3 M', 'S4 factor', 'S5 rne', 'S6a scan', 'S6b list', 'S7 rows', 'S8 dual', 'S9 pgs', 'S10 acc', 'dump+euler', 'S11 obs', 'gather']
     order = [1, 2, 3, 4, 5, 14, 6, 7, 8, 9, 10, 11, 12, 13]
     prev = np.zeros(n)
     print(f'stage times in shader cycles (mean / p95 / max over {n} envs); niter mean {nit.mean():.1f} p95 {np.percentile(nit,95):.0f} max {nit.max():.0f}; nefc mean {ne.mean():.1f} max {ne.max():.0f}')
@@ -55,4 +55,5 @@ def stage_times(n=4096, iters=100, tol=1e-8):
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'stages':
-    stage_times()
+    for n in (int(x) for x in (sys.argv[2:] or ['4096'])):
+        stage_times(n)
