@@ -16,7 +16,7 @@
 #include "gq_step_kernel.h"
 #include "gq_step_body.h"
 
-extern "C" void gq_launch_step(const gq::FusedArgs* a, int n_envs, hipStream_t stream);
+extern "C" void gq_launch_step(const gq::FusedArgs* a, int n_envs, int solver, hipStream_t stream);
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream);
 
 static thread_local char g_err[512] = "";
@@ -158,7 +158,7 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
   fill_step_args(&a.s, b, ctrl, mask, st, out);
   a.auto_reset = auto_reset != nullptr; a.first_pass = 0;
   if (auto_reset) fill_reset_args(&a.r, b, nullptr, nullptr, nullptr, auto_reset, st, out, episode, lift_failed);
-  gq_launch_step(&a, b->host.n_envs, (hipStream_t)hip_stream);
+  gq_launch_step(&a, b->host.n_envs, b->model->host.solver, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }
@@ -180,7 +180,7 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   fill_step_args(&a.s, b, nullptr, mask, st, out);
   a.s.debug = nullptr;
   a.auto_reset = 0; a.first_pass = 1;
-  gq_launch_step(&a, b->host.n_envs, (hipStream_t)hip_stream);
+  gq_launch_step(&a, b->host.n_envs, b->model->host.solver, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

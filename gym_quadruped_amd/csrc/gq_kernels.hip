@@ -12,12 +12,13 @@ namespace gq {
 /* step (+ in-kernel auto-reset): a terminated env is re-spawned by the same wavefront - reset_wave, then the reset's
  * own mj_step as a second pass through step_wave - so auto-reset costs no extra launches and only the few
  * terminated envs pay for the second pass. */
+template <int SOLVER>
 __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(FusedArgs a) {
   if (a.s.mask && !a.s.mask[blockIdx.x]) return; /* wave-uniform */
   __shared__ WaveMem W;
   int pass = a.first_pass;
   for (;;) {
-    const int term = step_wave(a.s, W, pass);
+    const int term = step_wave<SOLVER>(a.s, W, pass);
     if (pass == 1 || !a.auto_reset || !term) break;
     reset_wave(a.r, W);
     pass = 1;
@@ -32,8 +33,9 @@ __global__ void __launch_bounds__(GQ_WAVE) reset_kernel(ResetArgs a) {
 
 }  // namespace gq
 
-extern "C" void gq_launch_step(const gq::FusedArgs* a, int n_envs, hipStream_t stream) {
-  hipLaunchKernelGGL(gq::step_kernel, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
+extern "C" void gq_launch_step(const gq::FusedArgs* a, int n_envs, int solver, hipStream_t stream) {
+  if (solver == 1) hipLaunchKernelGGL(gq::step_kernel<1>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
+  else hipLaunchKernelGGL(gq::step_kernel<0>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
 }
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream) {
   hipLaunchKernelGGL(gq::reset_kernel, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);

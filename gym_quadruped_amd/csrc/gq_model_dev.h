@@ -34,7 +34,7 @@ struct GqDevGeom {          /* a robot collision geom that is not a foot sphere 
 
 struct GqDevModel {
   float timestep, gravity_z, impratio, meaninertia, tolerance;
-  int32_t iterations, cone, nlg, nfl;
+  int32_t iterations, cone, nlg, nfl, solver;
   /* bodies */
   float body_pos[GQ_NB][3], body_quat[GQ_NB][4], body_ipos[GQ_NB][3], body_mass[GQ_NB];
   float body_I[GQ_NB][6];        /* inertia tensor in the BODY frame: xx yy zz xy xz yz */

@@ -1,0 +1,331 @@
+/*
+ * gq_newton.h - primal Newton solver of the constraint problem (MuJoCo's default solver, mj_solNewton), one env per
+ * wavefront.  Restated on the CPU in oracle/gq_oracle.c::gqo_sol_newton.
+ *
+ *   minimise over qacc:  1/2 (qacc - qacc_smooth)' M (qacc - qacc_smooth) + sum_i s_i(J_i qacc - aref_i)
+ *
+ * lane = constraint row (J row, R, aref, bounds in registers), lane = dof for the 18-vectors, lanes 0-3 = legs for
+ * the tree-sparse factorisation.  The Hessian H = M + J' diag(D active) J has exactly M's tree sparsity (every row
+ * of J touches the base and at most one leg), so it reuses the L'DL machinery; no nefc x nefc dual operator is
+ * ever formed.
+ */
+#pragma once
+#include "gq_step_kernel.h"
+
+namespace gq {
+
+/* out[d] = sum_k M[d][k] v[k], lane d < 18, v and out in LDS (tree-sparse M) */
+__device__ __forceinline__ float mul_m_row(const WaveMem& W, const float* v, int d) {
+  float s = 0.0f;
+  if (d < 6) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += W.Mb[d][k] * v[k];
+#pragma unroll
+    for (int j = 0; j < GQ_NJ; j++) s += W.Mc[j][d] * v[6 + j];
+  } else {
+    const int j = d - 6, l0 = 3 * (j / 3), dep = j % 3;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += W.Mc[j][k] * v[k];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { /* same-leg block, symmetric: entry (max, min) */
+      const int hi = q > dep ? q : dep, lo = q > dep ? dep : q;
+      s += W.Mc[l0 + hi][6 + lo] * v[6 + l0 + q];
+    }
+  }
+  return s;
+}
+
+/* L'DL of one tree-sparse system given in the Mc/Mb layout -> F (lanes 0-3 legs, lane 0 base block) */
+__device__ inline void factor_tree_one(WaveMem& W, const float (*Sc)[9], const float (*Sb)[6], float* F) {
+  const int lane = lane_id();
+  float(*acc)[21] = W.acc2;
+  if (lane < 4) {
+    const int hh = 6 + 3 * lane, t = hh + 1, c = hh + 2;
+    float rc[9], rt[8], rh[7], bb[21];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { rc[j] = Sc[c - 6][j]; rt[j] = Sc[t - 6][j]; rh[j] = Sc[hh - 6][j]; }
+    rc[6] = Sc[c - 6][6]; rc[7] = Sc[c - 6][7]; rc[8] = Sc[c - 6][8];
+    rt[6] = Sc[t - 6][6]; rt[7] = Sc[t - 6][7];
+    rh[6] = Sc[hh - 6][6];
+#pragma unroll
+    for (int q = 0; q < 21; q++) bb[q] = 0.0f;
+    const float ic = fast_rcp(rc[8]);
+    {
+      float tmp = rc[7] * ic;
+#pragma unroll
+      for (int j = 0; j <= 7; j++) rt[j] -= rc[j] * tmp;
+      rc[7] = tmp;
+      tmp = rc[6] * ic;
+#pragma unroll
+      for (int j = 0; j <= 6; j++) rh[j] -= rc[j] * tmp;
+      rc[6] = tmp;
+#pragma unroll
+      for (int i = 5; i >= 0; i--) {
+        tmp = rc[i] * ic;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rc[j] * tmp;
+        rc[i] = tmp;
+      }
+    }
+    const float it = fast_rcp(rt[7]);
+    {
+      float tmp = rt[6] * it;
+#pragma unroll
+      for (int j = 0; j <= 6; j++) rh[j] -= rt[j] * tmp;
+      rt[6] = tmp;
+#pragma unroll
+      for (int i = 5; i >= 0; i--) {
+        tmp = rt[i] * it;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rt[j] * tmp;
+        rt[i] = tmp;
+      }
+    }
+    const float ih = fast_rcp(rh[6]);
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+      const float tmp = rh[i] * ih;
+#pragma unroll
+      for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rh[j] * tmp;
+      rh[i] = tmp;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) { F[GQ_F_LC(c - 6, j)] = rc[j]; F[GQ_F_LC(t - 6, j)] = rt[j]; F[GQ_F_LC(hh - 6, j)] = rh[j]; }
+    F[GQ_F_LC(c - 6, 6)] = rc[6]; F[GQ_F_LC(c - 6, 7)] = rc[7]; F[GQ_F_LC(t - 6, 6)] = rt[6];
+    F[GQ_F_DINV(c)] = ic; F[GQ_F_DINV(t)] = it; F[GQ_F_DINV(hh)] = ih;
+#pragma unroll
+    for (int q = 0; q < 21; q++) acc[lane][q] = bb[q];
+  }
+  wave_barrier();
+  if (lane == 0) {
+    float b[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        const int q = i * (i + 1) / 2 + j;
+        b[i][j] = Sb[i][j] + acc[0][q] + acc[1][q] + acc[2][q] + acc[3][q];
+      }
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+      const float inv = fast_rcp(b[k][k]);
+#pragma unroll
+      for (int i = k - 1; i >= 0; i--) {
+        const float tmp = b[k][i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; j++) b[i][j] -= b[k][j] * tmp;
+        b[k][i] = tmp;
+      }
+      F[GQ_F_DINV(k)] = inv;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < i; j++) F[GQ_F_LB(i, j)] = b[i][j];
+  }
+  wave_barrier();
+}
+
+/* single right-hand side solve, leg-parallel: out <- (L'DL)^-1 g ; g, out: LDS [18] (may alias) */
+__device__ inline void solve_tree_one(WaveMem& W, const float* F, const float* g, float* out) {
+  const int lane = lane_id();
+  float(*acc)[21] = W.acc2;
+  float xc = 0.0f, xt = 0.0f, xh = 0.0f;
+  const int hh = 6 + 3 * (lane & 3), t = hh + 1, c = hh + 2;
+  if (lane < 4) { /* backward substitution inside the leg, contributions to the base collected per leg */
+    xc = g[c];
+    xt = g[t] - F[GQ_F_LC(c - 6, 7)] * xc;
+    xh = g[hh] - F[GQ_F_LC(c - 6, 6)] * xc - F[GQ_F_LC(t - 6, 6)] * xt;
+#pragma unroll
+    for (int j = 0; j < 6; j++) acc[lane][j] = F[GQ_F_LC(c - 6, j)] * xc + F[GQ_F_LC(t - 6, j)] * xt + F[GQ_F_LC(hh - 6, j)] * xh;
+  }
+  wave_barrier();
+  if (lane == 0) {
+    float xb[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) xb[j] = g[j] - (acc[0][j] + acc[1][j] + acc[2][j] + acc[3][j]);
+#pragma unroll
+    for (int k = 5; k >= 1; k--)
+#pragma unroll
+      for (int j = 0; j < k; j++) xb[j] -= F[GQ_F_LB(k, j)] * xb[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) xb[k] *= F[GQ_F_DINV(k)];
+#pragma unroll
+    for (int k = 1; k < 6; k++)
+#pragma unroll
+      for (int j = 0; j < k; j++) xb[k] -= F[GQ_F_LB(k, j)] * xb[j];
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc[4][k] = xb[k];
+  }
+  wave_barrier();
+  if (lane < 4) {
+    float xb[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) xb[j] = acc[4][j];
+    xh *= F[GQ_F_DINV(hh)]; xt *= F[GQ_F_DINV(t)]; xc *= F[GQ_F_DINV(c)];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { xh -= F[GQ_F_LC(hh - 6, j)] * xb[j]; xt -= F[GQ_F_LC(t - 6, j)] * xb[j]; xc -= F[GQ_F_LC(c - 6, j)] * xb[j]; }
+    xt -= F[GQ_F_LC(t - 6, 6)] * xh;
+    xc -= F[GQ_F_LC(c - 6, 6)] * xh + F[GQ_F_LC(c - 6, 7)] * xt;
+    out[hh] = xh; out[t] = xt; out[c] = xc;
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) out[j] = xb[j];
+    }
+  }
+  wave_barrier();
+}
+
+/* force law + cost of one row at residual y = J qacc - aref (mj_constraintUpdate); returns force, sets cost/active */
+__device__ __forceinline__ float row_law(int rtype, float y, float R, float D, float floss, float& cost, float& wact) {
+  float f = 0.0f;
+  cost = 0.0f; wact = 0.0f;
+  if (rtype == ROW_FRICTION) {
+    if (y <= -R * floss) { f = floss; cost = -0.5f * R * floss * floss - floss * y; }
+    else if (y >= R * floss) { f = -floss; cost = -0.5f * R * floss * floss + floss * y; }
+    else { f = -D * y; cost = 0.5f * D * y * y; wact = D; }
+  } else if (rtype != ROW_NONE) {
+    if (y < 0.0f) { f = -D * y; cost = 0.5f * D * y * y; wact = D; }
+  }
+  return f;
+}
+
+/* derivative pieces of one row along the search direction (first and second derivative of s_i(y + alpha*v)) */
+__device__ __forceinline__ void row_dd(int rtype, float y, float v, float R, float D, float floss, float& d1, float& d2) {
+  d1 = 0.0f; d2 = 0.0f;
+  if (rtype == ROW_FRICTION) {
+    if (y <= -R * floss) d1 = -floss * v;
+    else if (y >= R * floss) d1 = floss * v;
+    else { d1 = D * y * v; d2 = D * v * v; }
+  } else if (rtype != ROW_NONE) {
+    if (y < 0.0f) { d1 = D * y * v; d2 = D * v * v; }
+  }
+}
+
+/* Newton iterations.  In: row data in registers, qacc_smooth / warm / Mc / Mb in LDS, J rows in W.u.B.
+ * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
+__device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, const float* J, int rtype, float rR, float raref,
+                                     float rfloss, int nefc, int& niter) {
+  const int lane = lane_id();
+  const float rD = 1.0f / rR;
+  const float scale = 1.0f / (m.meaninertia * 18.0f);
+  float* dq = W.qacc_int;       /* scratch 18-vectors: free until S10 */
+  float* Mdq = W.qfrc_c;
+  float* grad = W.act;
+  float* search = W.u2.n.nw[0];
+  float* Ms = W.u2.n.nw[1];
+  /* ---- warm start: qacc_warmstart unless qacc_smooth is cheaper (mj_fwdConstraint) */
+  float cost_w, cost_s;
+  {
+    float yw = -raref, ys = -raref;
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) { yw += J[k] * W.warm[k]; ys += J[k] * W.qacc_smooth[k]; }
+    float cw, cs, tmp;
+    row_law(rtype, yw, rR, rD, rfloss, cw, tmp);
+    row_law(rtype, ys, rR, rD, rfloss, cs, tmp);
+    if (lane < GQ_NVD) dq[lane] = W.warm[lane] - W.qacc_smooth[lane];
+    wave_barrier();
+    float g = 0.0f;
+    if (lane < GQ_NVD) g = 0.5f * dq[lane] * mul_m_row(W, dq, lane);
+    cost_w = wave_sum(cw + g);
+    cost_s = wave_sum(cs);
+    wave_barrier();
+    if (lane < GQ_NVD) W.qacc[lane] = cost_w < cost_s ? W.warm[lane] : W.qacc_smooth[lane];
+    wave_barrier();
+  }
+  float f = 0.0f, oldcost = 0.0f;
+  int iter = 0;
+  for (;; iter++) {
+    /* ---- constraint state at the current iterate */
+    float y = -raref;
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) y += J[k] * W.qacc[k];
+    float ci, wact;
+    f = row_law(rtype, y, rR, rD, rfloss, ci, wact);
+    if (lane < GQ_NVD) dq[lane] = W.qacc[lane] - W.qacc_smooth[lane];
+    W.force[lane] = wact; /* Hessian weights of the rows */
+    wave_barrier();
+    float md = 0.0f;
+    if (lane < GQ_NVD) { md = mul_m_row(W, dq, lane); Mdq[lane] = md; }
+    const float cost = wave_sum(ci + (lane < GQ_NVD ? 0.5f * dq[lane] * md : 0.0f));
+    if (iter > 0 && scale * (oldcost - cost) < m.tolerance) break;
+    if (iter >= m.iterations) break;
+    oldcost = cost;
+    /* ---- gradient = M dq - J' f */
+    float gd = 0.0f;
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) {
+      const float jf = wave_sum(f * J[k]);
+      gd = (lane == k) ? md - jf : gd;
+    }
+    const float gnorm2 = wave_sum(lane < GQ_NVD ? gd * gd : 0.0f);
+    if (scale * sqrtf(gnorm2) < m.tolerance) break;
+    if (lane < GQ_NVD) grad[lane] = -gd; /* right-hand side of H search = -grad */
+    /* ---- Hessian in M's tree-sparse layout: H = M + sum_r w_r J_r' J_r */
+#pragma unroll
+    for (int pass = 0; pass < 3; pass++) {
+      const int e = pass * 64 + lane;
+      if (e < 144) {
+        int da, db, valid = 1;
+        float base;
+        if (e < 108) {
+          const int j = e / 9, col = e % 9;
+          da = 6 + j;
+          db = col < 6 ? col : 6 + 3 * (j / 3) + (col - 6);
+          valid = col < 6 || (col - 6) <= j % 3;
+          base = W.Mc[j][col];
+        } else {
+          da = (e - 108) / 6; db = (e - 108) % 6;
+          base = W.Mb[da][db];
+        }
+        float s0 = 0.0f, s1 = 0.0f;
+        if (valid) {
+          int r = 0;
+          for (; r + 2 <= nefc; r += 2) {
+            s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
+            s1 += W.force[r + 1] * W.u.B[r + 1][da] * W.u.B[r + 1][db];
+          }
+          if (r < nefc) s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
+        }
+        const float hv = base + s0 + s1;
+        if (e < 108) W.u2.n.Hc[e / 9][e % 9] = hv; else W.u2.n.Hb[da][db] = hv;
+      }
+    }
+    wave_barrier();
+    factor_tree_one(W, W.u2.n.Hc, W.u2.n.Hb, W.F[0]);
+    solve_tree_one(W, W.F[0], grad, search);
+    /* ---- exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on phi' */
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) v += J[k] * search[k];
+    float ms = 0.0f;
+    if (lane < GQ_NVD) { ms = mul_m_row(W, search, lane); Ms[lane] = ms; }
+    const float q1 = wave_sum(lane < GQ_NVD ? search[lane] * md : 0.0f);
+    const float q2 = wave_sum(lane < GQ_NVD ? 0.5f * search[lane] * ms : 0.0f);
+    float alpha = 0.0f, lo = 0.0f, hi = -1.0f; /* hi < 0: no upper bracket yet */
+    float d1, d2;
+    row_dd(rtype, y, v, rR, rD, rfloss, d1, d2);
+    const float g0 = q1 + wave_sum(d1);
+    float h0 = 2.0f * q2 + wave_sum(d2);
+    if (!(g0 < 0.0f)) break; /* not a descent direction: converged to working precision */
+    alpha = -g0 / h0;
+    for (int ls = 0; ls < 16; ls++) {
+      row_dd(rtype, y + alpha * v, v, rR, rD, rfloss, d1, d2);
+      const float ga = q1 + 2.0f * q2 * alpha + wave_sum(d1);
+      const float ha = 2.0f * q2 + wave_sum(d2);
+      if (fabsf(ga) <= 1e-5f * fabsf(g0)) break;
+      if (ga < 0.0f) lo = alpha; else hi = alpha;
+      float an = alpha - ga / ha;
+      if (!(an > lo) || (hi > 0.0f && !(an < hi))) an = hi > 0.0f ? 0.5f * (lo + hi) : 2.0f * alpha;
+      alpha = an;
+    }
+    wave_barrier();
+    if (lane < GQ_NVD) W.qacc[lane] += alpha * search[lane];
+    wave_barrier();
+  }
+  niter = iter;
+  wave_barrier();
+  return f;
+}
+
+}  // namespace gq

@@ -5,6 +5,7 @@
  */
 #pragma once
 #include "gq_step_kernel.h"
+#include "gq_newton.h"
 
 namespace gq {
 
@@ -73,7 +74,7 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
   const int nlg = m.nlg;
   for (int g = 0; g < nlg; g++) {
     const GqDevGeom& G = m.lg[g];
-    if (calf_only && !(G.body > 0 && (G.body - 1) % 3 == 2)) { if (lane == 0) W.lg_dist[g] = 1e30f; continue; }
+    if (calf_only && !(G.body > 0 && (G.body - 1) % 3 == 2)) { if (lane == 0) W.u2.c.lg_dist[g] = 1e30f; continue; }
     const float* Rb = W.xmat[G.body];
     /* plane normal in the geom frame: n_g = Rg' Rb' n, n = (0,0,1) */
     V3 nb = v3(Rb[6], Rb[7], Rb[8]);
@@ -95,18 +96,19 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
       bi = bcast(bi, src);
       best = wmin + d0 - G.radius;
       if (lane == 0) {
-        W.lg_dist[g] = best;
+        W.u2.c.lg_dist[g] = best;
         V3 vl = v3(vx[bi], vy[bi], vz[bi]);
         V3 vb = ld3(G.pos) + matvec(G.mat, vl);
-        st3(W.lg_pt[g], ld3(W.xpos[G.body]) + matvec(Rb, vb));
+        st3(W.u2.c.lg_pt[g], ld3(W.xpos[G.body]) + matvec(Rb, vb));
       }
-    } else if (lane == 0) W.lg_dist[g] = 1e30f;
+    } else if (lane == 0) W.u2.c.lg_dist[g] = 1e30f;
   }
   wave_barrier();
 }
 
 /* One mj_step + observation epilogue for this wave's env.  pass 0: the user's step.  pass 1: the reset's own step
  * (zero control, friction committed afterwards, termination flags of pass 0 are kept).  Returns `terminated`. */
+template <int SOLVER> /* 0: PGS (mj_solPGS), 1: Newton (mj_solNewton, MuJoCo's default) */
 __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
@@ -305,10 +307,10 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
       } else {
         const int g = code - 4;
         const GqDevGeom& G = m.lg[g];
-        dist = W.lg_dist[g];
+        dist = W.u2.c.lg_dist[g];
         touching = dist < G.margin;
         body = G.body; dim = G.dim; inc = G.includemargin; calf = G.body > 0 && (G.body - 1) % 3 == 2;
-        px = W.lg_pt[g][0]; py = W.lg_pt[g][1]; pz = W.lg_pt[g][2] - (G.radius + 0.5f * dist);
+        px = W.u2.c.lg_pt[g][0]; py = W.u2.c.lg_pt[g][1]; pz = W.u2.c.lg_pt[g][2] - (G.radius + 0.5f * dist);
         const float fg = G.friction[0];
         mu = G.fric_rule == 0 ? fmaxf(ff, fg) : (G.fric_rule == 1 ? ff : fg);
         solref = G.solref; solimp = G.solimp;
@@ -332,8 +334,8 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     int nl = popc64(mlo) + popc64(mhi);
     {
       int at = popc64(mlo & lt) + popc64(mhi & lt);
-      if (lim_lo && at < GQ_NJ) { W.lim_jnt[at] = lane; W.lim_side[at] = 1.0f; W.lim_dist[at] = dlo; at++; }
-      if (lim_hi && at < GQ_NJ) { W.lim_jnt[at] = lane; W.lim_side[at] = -1.0f; W.lim_dist[at] = dhi; }
+      if (lim_lo && at < GQ_NJ) { W.u2.c.lim_jnt[at] = lane; W.u2.c.lim_side[at] = 1.0f; W.u2.c.lim_dist[at] = dlo; at++; }
+      if (lim_hi && at < GQ_NJ) { W.u2.c.lim_jnt[at] = lane; W.u2.c.lim_side[at] = -1.0f; W.u2.c.lim_dist[at] = dhi; }
       if (nl > GQ_NJ) nl = GQ_NJ;
     }
     /* row budget: friction rows, limit rows, then whole contacts in order while they fit (a prefix of the list) */
@@ -361,6 +363,11 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   }
   wave_barrier();
   const int nefc = W.nefc, ncon = W.ncon, nlim = W.nlim, nfl = m.nfl;
+  if (timing) { /* body poses go to the debug record now: xmat's LDS is reused by the Newton solver */
+    float* D = a.debug + (size_t)env * GQ_DBG_SIZE;
+    if (lane < 39) D[GQ_DBG_XPOS + lane] = W.xpos[lane / 3][lane % 3];
+    for (int k = lane; k < 117; k += GQ_WAVE) D[GQ_DBG_XMAT + k] = W.xmat[k / 9][k % 9];
+  }
 
   GQ_TICK(6);
   /* ================================================================ S7: constraint rows, lane = row */
@@ -378,10 +385,10 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
 #pragma unroll
     for (int k = 0; k < GQ_NVD; k++) J[k] = (k == d) ? 1.0f : 0.0f;
   } else if (lane < nfl + nlim) {
-    const int r = lane - nfl, j = W.lim_jnt[r], d = 6 + j;
-    rtype = ROW_LIMIT; rpos = W.lim_dist[r]; rmargin = m.jnt_margin[j]; rdiag = m.dof_invweight0[d];
+    const int r = lane - nfl, j = W.u2.c.lim_jnt[r], d = 6 + j;
+    rtype = ROW_LIMIT; rpos = W.u2.c.lim_dist[r]; rmargin = m.jnt_margin[j]; rdiag = m.dof_invweight0[d];
     rsolref = m.jnt_solref[j]; rsolimp = m.jnt_solimp[j];
-    const float sgn = W.lim_side[r];
+    const float sgn = W.u2.c.lim_side[r];
 #pragma unroll
     for (int k = 0; k < GQ_NVD; k++) J[k] = (k == d) ? sgn : 0.0f;
   } else if (lane < nefc) {
@@ -442,6 +449,23 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   }
 
   GQ_TICK(7);
+  const bool active = lane < nefc;
+  float b_i = 0.0f;
+  int iter = 0;
+  if constexpr (SOLVER == 1) {
+    /* ================================================================ S8/S9 (Newton): primal solve, no dual operator */
+    wave_barrier(); /* u.dyn is dead: J rows go to LDS for the Hessian assembly */
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) W.u.B[lane][k] = active ? J[k] : 0.0f;
+    solve_tree_one(W, W.F[0], W.smooth, W.qacc_smooth);
+    b_i = -raref;
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) b_i += J[k] * W.qacc_smooth[k];
+    GQ_TICK(8);
+    const float fN = newton_solve(W, m, J, rtype, rR, raref, rfloss, nefc, iter);
+    W.force[lane] = active ? fN : 0.0f;
+    wave_barrier();
+  } else {
   /* ================================================================ S8: B = M^-1 J' (lane-parallel), A = J B' + R */
   float A[GQ_MAXEFC];
   float diag = 0.0f; /* A_ii = J_i . B_i */
@@ -472,7 +496,8 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     A[j] = sacc;
     sched_fence(); /* one row of B in flight at a time: keeps the register pressure of the unrolled loop flat */
   }
-  float b_i = -raref, jar_w = -raref;
+  b_i = -raref;
+  float jar_w = -raref;
 #pragma unroll
   for (int k = 0; k < GQ_NVD; k++) { b_i += J[k] * W.qacc_smooth[k]; jar_w += J[k] * W.warm[k]; }
   /* J rows take B's place in LDS (needed again for J'f); their registers are free during the PGS sweeps */
@@ -482,7 +507,6 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
 
   GQ_TICK(8);
   /* ================================================================ S9: PGS on  min 1/2 f'(A+R)f + f'b */
-  const bool active = lane < nefc;
   float lo = 0.0f, hi = 3.0e38f;
   if (rtype == ROW_FRICTION) { lo = -rfloss; hi = rfloss; }
   if (!active) { lo = 0.0f; hi = 0.0f; }
@@ -510,7 +534,6 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
    * uniform FMA for every lane */
 #pragma unroll
   for (int j = 0; j < GQ_MAXEFC; j++) A[j] = (j == lane) ? ARii : A[j];
-  int iter = 0;
   for (; iter < m.iterations; iter++) {
     float imp_acc = 0.0f;
     int lane_s = lane;
@@ -537,7 +560,15 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   wave_barrier();
 
   GQ_TICK(9);
+  }
   /* ================================================================ S10: accelerations and integration */
+  if constexpr (SOLVER == 1) {
+    /* qacc and qfrc_constraint (= M (qacc - qacc_smooth)) come out of the Newton solve; only the Euler system
+     * (M + h D) qacc_int = qfrc_smooth + qfrc_constraint is left */
+    if (lane < GQ_NVD) W.act[lane] = W.smooth[lane] + W.qfrc_c[lane];
+    wave_barrier();
+    solve_tree_one(W, W.F[1], W.act, W.qacc_int);
+  } else {
   if (lane < GQ_NVD) { /* qfrc_constraint = J' f: four independent partial sums keep the LDS reads pipelined */
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     int i = 0;
@@ -566,6 +597,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   }
   wave_barrier();
 
+  }
   if (a.debug && pass == 0 && env < a.batch->debug_envs) {
     float* D = a.debug + (size_t)env * GQ_DBG_SIZE;
     for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = m_entry(W, k / 18, k % 18);
@@ -574,8 +606,6 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
       D[GQ_DBG_QACC_SMOOTH + lane] = W.qacc_smooth[lane]; D[GQ_DBG_QFRC_C + lane] = W.qfrc_c[lane];
       D[GQ_DBG_QACC + lane] = W.qacc[lane];
     }
-    if (lane < 39) D[GQ_DBG_XPOS + lane] = W.xpos[lane / 3][lane % 3];
-    for (int k = lane; k < 117; k += GQ_WAVE) D[GQ_DBG_XMAT + k] = W.xmat[k / 9][k % 9];
     if (lane == 0) { D[GQ_DBG_NEFC] = (float)nefc; D[GQ_DBG_NCON] = (float)ncon; D[GQ_DBG_NITER] = (float)iter; }
     for (int k = 0; k < GQ_NVD; k++) D[GQ_DBG_EFC_J + lane * 18 + k] = W.u.B[lane][k];
     D[GQ_DBG_EFC_AREF + lane] = raref; D[GQ_DBG_EFC_R + lane] = rR; D[GQ_DBG_EFC_B + lane] = b_i;
@@ -853,7 +883,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
     /* distances and margins of everything attached to a calf body (feet_contact_state is body-level) */
     float dist = 1e30f, margin = 0.0f;
     if (lane < 4) { dist = W.foot_world[lane][2] - m.foot_radius[lane]; margin = m.foot_margin[lane]; }
-    else if (lane - 4 < m.nlg) { dist = W.lg_dist[lane - 4]; margin = m.lg[lane - 4].margin; }
+    else if (lane - 4 < m.nlg) { dist = W.u2.c.lg_dist[lane - 4]; margin = m.lg[lane - 4].margin; }
     for (int it = 0; it < 100; it++) {
       const bool touching = dist + dz < margin;
       if (ballot(touching) == 0) break;

@@ -71,7 +71,8 @@ struct WaveDyn {
 };
 struct WaveMem {
   float qj[12], qb[4], basez, qvel[18], ctrl[12], warm[18], applied[18], cmd[4];
-  float xpos[GQ_NB][3], xmat[GQ_NB][9];
+  float xpos[GQ_NB][3];
+  union { float xmat[GQ_NB][9]; float acc2[5][21]; };   /* acc2: Newton factor/solve exchange (xmat is dead after S6) */
   float cdof[GQ_NVD][6];
   /* joint-space inertia, tree-sparse: leg dof 6+j keeps [b0..b5, hip, thigh, calf] of its own leg (lower part incl.
    * the diagonal), the base block is a full symmetric 6x6 */
@@ -86,10 +87,11 @@ struct WaveMem {
   int32_t con_geom[GQ_MAXCON], con_body[GQ_MAXCON], con_dim[GQ_MAXCON], con_row[GQ_MAXCON];
   float con_dist[GQ_MAXCON], con_pos[GQ_MAXCON][3], con_mu[GQ_MAXCON], con_inc[GQ_MAXCON];
   float con_solref[GQ_MAXCON][2], con_solimp[GQ_MAXCON][5];
-  int32_t foot_con[4];                                  /* contact index of foot k or -1 */
   float foot_world[4][3];
-  int32_t lim_jnt[GQ_NJ]; float lim_side[GQ_NJ], lim_dist[GQ_NJ];
-  float lg_dist[GQ_MAXLG], lg_pt[GQ_MAXLG][3];
+  union {                                               /* collision / limit scratch (S6-S7)  |  Newton scratch (S9) */
+    struct { int32_t lim_jnt[GQ_NJ]; float lim_side[GQ_NJ], lim_dist[GQ_NJ]; float lg_dist[GQ_MAXLG], lg_pt[GQ_MAXLG][3]; } c;
+    struct { float Hc[GQ_NJ][9], Hb[6][6], nw[2][GQ_NVD]; } n;
+  } u2;
   float force[64];
   union {
     WaveDyn dyn;

@@ -86,6 +86,7 @@ class QuadrupedEnv:
         num_envs: int = 1,
         device: str | torch.device = 'cuda:0',
         auto_reset: bool = False,
+        solver: str = 'newton',
         solver_iterations: int = 100,
         solver_tolerance: float = 1e-8,
         seed: int | None = None,
@@ -118,7 +119,7 @@ class QuadrupedEnv:
             qpos0[7:] = np.asarray(self.robot_cfg.qpos0_js, dtype=np.float64)
         self.mjModel.qpos0 = qpos0
         self._mm = MarshalledModel(self.mjModel, qpos0=qpos0, feet_geom_names=self.robot_cfg.feet_geom_names,
-                                   terrain_limits=self.terrain_limits, timestep=sim_dt, solver=0,
+                                   terrain_limits=self.terrain_limits, timestep=sim_dt, solver={'pgs': 0, 'newton': 1}[solver],
                                    iterations=solver_iterations, tolerance=solver_tolerance,
                                    floor=self.scene_desc.get('floor'))
         self._sim_dt = float(sim_dt)

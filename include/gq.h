@@ -134,7 +134,7 @@ typedef struct GqModelDesc {
   double meaninertia;
   double key_qpos[19];           /* keyframe 0 (mj_resetDataKeyframe, quadruped_env.py:343) */
   /* solver */
-  int32_t solver;                /* 0 PGS (north-star), 1 Newton (MuJoCo default; oracle only in this round) */
+  int32_t solver;                /* 0 PGS (mj_solPGS, named by the north-star), 1 Newton (mj_solNewton, MuJoCo's default) */
   int32_t iterations;
   double tolerance;
 } GqModelDesc;

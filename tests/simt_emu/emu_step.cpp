@@ -53,7 +53,7 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
       __shared__ gq::WaveMem W;
       int pass = f.first_pass;
       for (;;) {
-        const int term = gq::step_wave(f.s, W, pass);
+        const int term = M.solver == 1 ? gq::step_wave<1>(f.s, W, pass) : gq::step_wave<0>(f.s, W, pass);
         if (pass == 1 || !f.auto_reset || !term) break;
         gq::reset_wave(f.r, W);
         pass = 1;

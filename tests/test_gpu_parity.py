@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 N = 256
 
 
-def _make_env(n, obs=ALL_OBS, iters=50, tol=0.0, **kw):
+def _make_env(n, obs=ALL_OBS, iters=50, tol=0.0, solver='pgs', **kw):
     from gym_quadruped_amd.quadruped_env import QuadrupedEnv
     return QuadrupedEnv('mini_cheetah', state_obs_names=tuple(obs), num_envs=n, device='cuda:0',
-                        solver_iterations=iters, solver_tolerance=tol, seed=0, **kw)
+                        solver=solver, solver_iterations=iters, solver_tolerance=tol, seed=0, **kw)
 
 
 def _oracle(env):

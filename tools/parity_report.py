@@ -36,7 +36,7 @@ def main():
     else:
         import torch
         from gym_quadruped_amd.quadruped_env import QuadrupedEnv
-        env = QuadrupedEnv('mini_cheetah', state_obs_names=('qpos',), num_envs=a.n, solver_iterations=a.iters, solver_tolerance=a.tol)
+        env = QuadrupedEnv('mini_cheetah', state_obs_names=('qpos',), num_envs=a.n, solver='pgs', solver_iterations=a.iters, solver_tolerance=a.tol)
         env._qpos.copy_(torch.as_tensor(qpos)); env._qvel.copy_(torch.as_tensor(qvel)); env._warm.copy_(torch.as_tensor(warm))
         env.enable_debug(a.n)
         env.step(torch.as_tensor(ctrl))

@@ -5,9 +5,9 @@ import numpy as np, torch
 ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
 from gym_quadruped_amd.quadruped_env import QuadrupedEnv
 
-def run(n, iters, tol, steps=300, auto=True, obs='all'):
+def run(n, iters, tol, steps=300, auto=True, obs='all', solver='pgs'):
     names = tuple(QuadrupedEnv.ALL_OBS) if obs == 'all' else QuadrupedEnv._DEFAULT_OBS
-    env = QuadrupedEnv('mini_cheetah', state_obs_names=names, num_envs=n, auto_reset=auto, solver_iterations=iters, solver_tolerance=tol, seed=1)
+    env = QuadrupedEnv('mini_cheetah', state_obs_names=names, num_envs=n, auto_reset=auto, solver=solver, solver_iterations=iters, solver_tolerance=tol, seed=1)
     env.reset()
     g = torch.Generator(device='cuda').manual_seed(0)
     pool = [torch.randn(n, 12, generator=g, device='cuda') * 50 for _ in range(16)]
@@ -24,19 +24,22 @@ def run(n, iters, tol, steps=300, auto=True, obs='all'):
         o, r, term, tr, info = env.step(pool[i % 16])
     e.record(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
     ms = s.elapsed_time(e) / steps
-    print(f'n={n:5d} iters={iters:3d} tol={tol:g} auto={auto} obs={obs}: {ms*1e3:7.1f} us/step (gpu) {wall/steps*1e6:7.1f} us/step (wall)  {n/ms/1e3:6.2f} M env-steps/s  mean niter {nit:.1f} nefc {nefc:.1f} term/step {float(term.float().mean()):.4f}')
+    print(f'{solver} n={n:5d} iters={iters:3d} tol={tol:g} auto={auto} obs={obs}: {ms*1e3:7.1f} us/step (gpu) {wall/steps*1e6:7.1f} us/step (wall)  {n/ms/1e3:6.2f} M env-steps/s  mean niter {nit:.1f} nefc {nefc:.1f} term/step {float(term.float().mean()):.4f}')
 
 if __name__ == '__main__' and len(sys.argv) == 1:
     for it, tol in [(0, 0), (10, 0), (50, 0), (100, 1e-8)]:
         run(4096, it, tol)
     run(4096, 100, 1e-8, auto=False)
+    run(4096, 100, 1e-8, solver='newton')
+    run(1024, 100, 1e-8, solver='newton')
+    run(16384, 100, 1e-8, solver='newton')
     run(4096, 100, 1e-8, obs='default')
     for n in (1024, 2048, 8192, 16384):
         run(n, 100, 1e-8)
 
 
-def stage_times(n=4096, iters=100, tol=1e-8):
-    env = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset=True, solver_iterations=iters, solver_tolerance=tol, seed=1)
+def stage_times(n=4096, iters=100, tol=1e-8, solver='newton'):
+    env = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset=True, solver=solver, solver_iterations=iters, solver_tolerance=tol, seed=1)
     env.reset()
     g = torch.Generator(device='cuda').manual_seed(0)
     for i in range(60): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)
@@ -56,4 +59,5 @@ def stage_times(n=4096, iters=100, tol=1e-8):
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'stages':
     for n in (int(x) for x in (sys.argv[2:] or ['4096'])):
-        stage_times(n)
+        for sv in ('pgs', 'newton'):
+            print(sv); stage_times(n, solver=sv)

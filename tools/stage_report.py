@@ -10,7 +10,7 @@ from oracle.oracle import Oracle
 from gym_quadruped_amd.quadruped_env import QuadrupedEnv
 
 n, iters = int(sys.argv[1]) if len(sys.argv) > 1 else 128, int(sys.argv[2]) if len(sys.argv) > 2 else 50
-env = QuadrupedEnv('mini_cheetah', state_obs_names=('qpos',), num_envs=n, solver_iterations=iters, solver_tolerance=0.0)
+env = QuadrupedEnv('mini_cheetah', state_obs_names=('qpos',), num_envs=n, solver='pgs', solver_iterations=iters, solver_tolerance=0.0)
 rng = np.random.default_rng(0)
 qpos, qvel = random_states(env.mjModel, n, rng)
 qvel = qvel.astype(np.float32)
