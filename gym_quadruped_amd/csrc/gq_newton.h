@@ -205,7 +205,7 @@ __device__ __forceinline__ void row_dd(int rtype, float y, float v, float R, flo
 /* Newton iterations.  In: row data in registers, qacc_smooth / warm / Mc / Mb in LDS, J rows in W.u.B.
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
 __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, const float* J, int rtype, float rR, float raref,
-                                     float rfloss, int nefc, int& niter) {
+                                     float rfloss, int nefc, int nsingle, int& niter) {
   const int lane = lane_id();
   const float rD = 1.0f / rR;
   const float scale = 1.0f / (m.meaninertia * 18.0f);
@@ -243,7 +243,7 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, const floa
     float ci, wact;
     f = row_law(rtype, y, rR, rD, rfloss, ci, wact);
     if (lane < GQ_NVD) dq[lane] = W.qacc[lane] - W.qacc_smooth[lane];
-    W.force[lane] = wact; /* Hessian weights of the rows */
+    W.force[lane] = f; /* row forces, read column-wise for J'f below */
     wave_barrier();
     float md = 0.0f;
     if (lane < GQ_NVD) { md = mul_m_row(W, dq, lane); Mdq[lane] = md; }
@@ -251,16 +251,21 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, const floa
     if (iter > 0 && scale * (oldcost - cost) < m.tolerance) break;
     if (iter >= m.iterations) break;
     oldcost = cost;
-    /* ---- gradient = M dq - J' f */
+    /* ---- gradient = M dq - J' f  (lane = dof walks its column of J in LDS) */
     float gd = 0.0f;
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) {
-      const float jf = wave_sum(f * J[k]);
-      gd = (lane == k) ? md - jf : gd;
+    if (lane < GQ_NVD) {
+      float s0 = 0.0f, s1 = 0.0f;
+      int r = 0;
+      for (; r + 2 <= nefc; r += 2) { s0 += W.u.B[r][lane] * W.force[r]; s1 += W.u.B[r + 1][lane] * W.force[r + 1]; }
+      if (r < nefc) s0 += W.u.B[r][lane] * W.force[r];
+      gd = md - (s0 + s1);
     }
     const float gnorm2 = wave_sum(lane < GQ_NVD ? gd * gd : 0.0f);
     if (scale * sqrtf(gnorm2) < m.tolerance) break;
     if (lane < GQ_NVD) grad[lane] = -gd; /* right-hand side of H search = -grad */
+    wave_barrier();
+    W.force[lane] = wact; /* Hessian weights of the rows replace the forces */
+    wave_barrier();
     /* ---- Hessian in M's tree-sparse layout: H = M + sum_r w_r J_r' J_r */
 #pragma unroll
     for (int pass = 0; pass < 3; pass++) {
@@ -280,7 +285,10 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, const floa
         }
         float s0 = 0.0f, s1 = 0.0f;
         if (valid) {
-          int r = 0;
+          /* friction-loss and limit rows are +-e_dof: they only touch the diagonal */
+          if (da == db)
+            for (int r = 0; r < nsingle; r++) s1 += W.force[r] * W.u.B[r][da] * W.u.B[r][da];
+          int r = nsingle;
           for (; r + 2 <= nefc; r += 2) {
             s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
             s1 += W.force[r + 1] * W.u.B[r + 1][da] * W.u.B[r + 1][db];
@@ -309,11 +317,11 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, const floa
     float h0 = 2.0f * q2 + wave_sum(d2);
     if (!(g0 < 0.0f)) break; /* not a descent direction: converged to working precision */
     alpha = -g0 / h0;
-    for (int ls = 0; ls < 16; ls++) {
+    for (int ls = 0; ls < 10; ls++) {
       row_dd(rtype, y + alpha * v, v, rR, rD, rfloss, d1, d2);
       const float ga = q1 + 2.0f * q2 * alpha + wave_sum(d1);
       const float ha = 2.0f * q2 + wave_sum(d2);
-      if (fabsf(ga) <= 1e-5f * fabsf(g0)) break;
+      if (fabsf(ga) <= 1e-3f * fabsf(g0)) break; /* MuJoCo's line search is approximate too (ls_tolerance 0.01) */
       if (ga < 0.0f) lo = alpha; else hi = alpha;
       float an = alpha - ga / ha;
       if (!(an > lo) || (hi > 0.0f && !(an < hi))) an = hi > 0.0f ? 0.5f * (lo + hi) : 2.0f * alpha;

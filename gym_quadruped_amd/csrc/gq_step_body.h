@@ -462,7 +462,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
 #pragma unroll
     for (int k = 0; k < GQ_NVD; k++) b_i += J[k] * W.qacc_smooth[k];
     GQ_TICK(8);
-    const float fN = newton_solve(W, m, J, rtype, rR, raref, rfloss, nefc, iter);
+    const float fN = newton_solve(W, m, J, rtype, rR, raref, rfloss, nefc, nfl + nlim, iter);
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
