@@ -204,9 +204,11 @@ __device__ __forceinline__ void row_dd(int rtype, float y, float v, float R, flo
 
 /* Newton iterations.  In: row data in registers, qacc_smooth / warm / Mc / Mb in LDS, J rows in W.u.B.
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
-__device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, const float* J, int rtype, float rR, float raref,
+__device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype, float rR, float raref,
                                      float rfloss, int nefc, int nsingle, int& niter) {
   const int lane = lane_id();
+  /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */
+  const float* J = W.u.B[lane];
   const float rD = 1.0f / rR;
   const float scale = 1.0f / (m.meaninertia * 18.0f);
   float* dq = W.qacc_int;       /* scratch 18-vectors: free until S10 */

@@ -457,12 +457,13 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     wave_barrier(); /* u.dyn is dead: J rows go to LDS for the Hessian assembly */
 #pragma unroll
     for (int k = 0; k < GQ_NVD; k++) W.u.B[lane][k] = active ? J[k] : 0.0f;
+    wave_barrier();
     solve_tree_one(W, W.F[0], W.smooth, W.qacc_smooth);
     b_i = -raref;
 #pragma unroll
     for (int k = 0; k < GQ_NVD; k++) b_i += J[k] * W.qacc_smooth[k];
     GQ_TICK(8);
-    const float fN = newton_solve(W, m, J, rtype, rR, raref, rfloss, nefc, nfl + nlim, iter);
+    const float fN = newton_solve(W, m, rtype, rR, raref, rfloss, nefc, nfl + nlim, iter);
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
@@ -857,7 +858,9 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
       const double x = m.terrain_limits[0] + (m.terrain_limits[1] - m.terrain_limits[0]) * (double)W.u.obs[RN_X];
       const double y = m.terrain_limits[2] + (m.terrain_limits[3] - m.terrain_limits[2]) * (double)W.u.obs[RN_Y];
       const float roll = (2.0f * W.u.obs[RN_ROLL] - 1.0f) * c.roll_sweep, pitch = (2.0f * W.u.obs[RN_PITCH] - 1.0f) * c.pitch_sweep;
-      const float yaw = (float)atan2(-y, -x); /* heading towards the origin (math_utils.py:37-51) */
+      /* heading towards the origin (math_utils.py:37-51); fp32 atan2f on purpose: the f64 routine's constant table
+       * was being hoisted to the kernel prologue and spilled by every wave of every step */
+      const float yaw = atan2f((float)(-y), (float)(-x));
       const float cr = cosf(0.5f * roll), sr = sinf(0.5f * roll), cp = cosf(0.5f * pitch), sp = sinf(0.5f * pitch);
       const float cy = cosf(0.5f * yaw), sy = sinf(0.5f * yaw);
       if (lane == 0) q = x;
