@@ -38,6 +38,17 @@ def algorithmic_bytes_per_env_step(obs_dim: int) -> int:
     return reads + writes
 
 
+def pmc_traffic():
+    """HBM bytes per step-kernel launch from the last committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/latest_traffic.json, gfx950 FETCH_SIZE x2 correction applied); counters cannot be read from inside
+    this process, so the figure comes from the separate profiling passes of the same command."""
+    p = ROOT / 'profiles' / 'latest_traffic.json'
+    try:
+        return json.loads(p.read_text())['traffic_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds_budget: float = 15.0):
     """Single-env CPU fp64 restatement of the reference step (oracle, MuJoCo's default Newton solver), 1 core."""
     from gym_quadruped_amd.cabi import ALL_OBS
@@ -146,7 +157,7 @@ def main():
                        'envs_per_gpu': n, 'total_envs': total_envs, 'parallelism': f'env-shards x{world} (no collectives)',
                        'state_finite': finite},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'gq::step_kernel',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(), 'kernel': 'gq::step_kernel',
                          'kernel_ms': kernel_ms, 'bytes_per_env_step': bytes_step,
                          'note': 'algorithmic bytes / HIP-event kernel time; the step is latency/VALU bound, not HBM bound'},
         }

@@ -161,7 +161,7 @@ class QuadrupedEnv:
         self._friction = torch.full((N,), -1.0, **f32)   # < 0: XML frictions until the first reset sets it
         self._cmd = torch.zeros(N, 4, **f32)
         self._ctrl = torch.zeros(N, nu, **f32)
-        self._zero_ctrl = torch.zeros(N, nu, **f32)
+        self._last_action = self._ctrl
         self._obs_dim = int(sum(OBS_DIMS[i] for i in self._obs_ids))
         self._obs_buf = torch.zeros(N, self._obs_dim, **f32)
         self._reward = torch.zeros(N, **f32)
@@ -237,17 +237,22 @@ class QuadrupedEnv:
         (views of one persistent buffer, overwritten by the next call), reward ``[N]``, terminated/truncated ``[N]``
         bool and info {'time' [N], 'step_num' [N], 'invalid_contacts' [N] bool}.
         """
-        a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
-        if a.dim() == 1:
-            a = a.unsqueeze(0).expand(self.num_envs, -1)
-        if a.shape != self._ctrl.shape:
-            raise ValueError(f'action must have shape {tuple(self._ctrl.shape)}, got {tuple(a.shape)}')
-        self._ctrl.copy_(a)
+        if (torch.is_tensor(action) and action.dtype == torch.float32 and action.device == self.device
+                and action.shape == self._ctrl.shape and action.is_contiguous()):
+            self._last_action = action      # zero-copy: the kernel reads the caller's tensor
+        else:
+            a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+            if a.dim() == 1:
+                a = a.unsqueeze(0).expand(self.num_envs, -1)
+            if a.shape != self._ctrl.shape:
+                raise ValueError(f'action must have shape {tuple(self._ctrl.shape)}, got {tuple(a.shape)}')
+            self._ctrl.copy_(a)
+            self._last_action = self._ctrl
         stream = torch.cuda.current_stream(self.device).cuda_stream
         ev = self._profile_events
         if ev is not None:
             ev[0].record()
-        _lib.check(self._L.gq_step(self._hbatch, self._ctrl.data_ptr(), None, self._st, self._out, self._auto_cfg,
+        _lib.check(self._L.gq_step(self._hbatch, self._last_action.data_ptr(), None, self._st, self._out, self._auto_cfg,
                                    self._episode.data_ptr(), self._lift_failed.data_ptr(), stream), 'gq_step')
         if ev is not None:
             ev[1].record()
@@ -379,7 +384,7 @@ class QuadrupedEnv:
 
     @property
     def torque_ctrl_setpoint(self):
-        return self._ctrl
+        return self._last_action
 
     @property
     def simulation_dt(self):
