@@ -5,13 +5,13 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-from .cabi import GqModelDesc, GqObsOut, GqResetCfg, GqState
+from .cabi import GqImuCfg, GqModelDesc, GqObsOut, GqResetCfg, GqState
 
 _LIB = None
 LIB_PATH = Path(__file__).parent / 'libgq.so'
 
 EXPORTS = ['gq_last_error', 'gq_version', 'gq_obs_dim', 'gq_model_create', 'gq_model_destroy', 'gq_batch_create',
-           'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get']
+           'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_batch_set_imu', 'gq_heightmap', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get']
 
 
 class GqError(RuntimeError):
@@ -33,10 +33,12 @@ def lib():
     L.gq_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.gq_batch_destroy.argtypes = [C.c_void_p]
     L.gq_batch_obs_dim.argtypes = [C.c_void_p]
+    L.gq_batch_set_imu.argtypes = [C.c_void_p, C.POINTER(GqImuCfg), C.c_void_p]
     L.gq_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, GqState, GqObsOut, C.POINTER(GqResetCfg), C.c_void_p,
                           C.c_void_p, C.c_void_p]
     L.gq_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GqResetCfg), GqState, GqObsOut,
                            C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gq_heightmap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     L.gq_debug_enable.argtypes = [C.c_void_p, C.c_int]
     L.gq_debug_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int]
     L.gq_obs_dim.argtypes = [C.c_int]

@@ -58,6 +58,11 @@ class GqResetCfg(C.Structure):
                 ('env_id_offset', C.c_int32)]
 
 
+class GqImuCfg(C.Structure):
+    _fields_ = [('site_pos', C.c_double * 3), ('site_quat', C.c_double * 4), ('accel_noise', C.c_float),
+                ('gyro_noise', C.c_float), ('accel_bias_rate', C.c_float), ('gyro_bias_rate', C.c_float), ('seed', C.c_uint64)]
+
+
 class GqObsOut(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('terminated', C.c_void_p), ('truncated', C.c_void_p),
                 ('invalid_contact', C.c_void_p), ('step_num', C.c_void_p)]
@@ -72,7 +77,10 @@ ALL_OBS = [
     'feet_pos', 'feet_pos:base', 'feet_vel', 'feet_vel_rel', 'feet_vel:base', 'feet_vel_rel:base',
     'contact_state', 'contact_forces', 'contact_forces:base',
 ]
-OBS_DIMS = [3, 3, 3, 3, 3, 3, 3, 4, 9, 3, 3, 3, 3, 3, 3, 19, 18, 12, 12, 12, 1, 1, 12, 12, 12, 12, 12, 12, 4, 12, 12]
+# sensor observables appended after ALL_OBS (enum GqObsId ids 31..36; reference sensors/imu.py:17-18)
+IMU_OBS = ['imu_acc', 'imu_acc_noise', 'imu_acc_bias', 'imu_gyro', 'imu_gyro_noise', 'imu_gyro_bias']
+OBS_NAMES = ALL_OBS + IMU_OBS
+OBS_DIMS = [3, 3, 3, 3, 3, 3, 3, 4, 9, 3, 3, 3, 3, 3, 3, 19, 18, 12, 12, 12, 1, 1, 12, 12, 12, 12, 12, 12, 4, 12, 12] + [3] * 6
 LEG_NAMES = ['FL', 'FR', 'RL', 'RR']
 
 SOLVER_PGS, SOLVER_NEWTON = 0, 1
@@ -123,7 +131,7 @@ class MarshalledModel:
 def obs_ids_from_names(names):
     ids = []
     for n in names:
-        if n not in ALL_OBS:
+        if n not in OBS_NAMES:
             raise ValueError(f'Invalid observation name: {n}, available obs: {ALL_OBS}')
-        ids.append(ALL_OBS.index(n))
+        ids.append(OBS_NAMES.index(n))
     return ids

@@ -18,6 +18,8 @@
 
 extern "C" void gq_launch_step(const gq::FusedArgs* a, int n_envs, int solver, hipStream_t stream);
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream);
+extern "C" void gq_launch_heightmap(const double* center, const float* yaw, int n_envs, int rows, int cols, float dist_x,
+                                    float dist_y, float* out, hipStream_t stream);
 
 static thread_local char g_err[512] = "";
 #define SET_ERR(...) std::snprintf(g_err, sizeof g_err, __VA_ARGS__)
@@ -40,6 +42,7 @@ struct GqBatch {
   GqDevBatch* dev;
   float* debug;       /* device, debug_envs * GQ_DBG_SIZE floats (lazily allocated) */
   float* friction_next; /* device [N]: friction drawn by reset, committed after the reset step */
+  float* imu_bias;      /* caller-owned device [N][6], set by gq_batch_set_imu */
   int debug_cap;
 };
 
@@ -83,7 +86,7 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   if (!m || !out || n_envs <= 0) { SET_ERR("gq_batch_create: bad argument"); return GQ_EINVAL; }
   GqBatch* b = new (std::nothrow) GqBatch();
   if (!b) return GQ_ENOMEM;
-  b->model = m; b->debug = nullptr; b->debug_cap = 0;
+  b->model = m; b->debug = nullptr; b->debug_cap = 0; b->imu_bias = nullptr;
   if (gq_build_dev_batch(n_envs, obs_ids, n_obs, legs_order, &b->host, g_err, sizeof g_err)) { delete b; return GQ_EINVAL; }
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipMalloc(&b->dev, sizeof(GqDevBatch)));
@@ -104,6 +107,15 @@ int gq_batch_destroy(GqBatch* b) {
 }
 
 int gq_batch_obs_dim(const GqBatch* b) { return b ? b->host.obs_dim : GQ_EINVAL; }
+
+int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state) {
+  if (!b || !cfg || !bias_state) { SET_ERR("gq_batch_set_imu: null argument"); return GQ_EINVAL; }
+  gq_fill_imu(&b->host, cfg);
+  b->imu_bias = bias_state;
+  HIP_TRY(hipSetDevice(b->model->device));
+  HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
+  return GQ_OK;
+}
 
 int gq_debug_enable(GqBatch* b, int n_debug_envs) {
   if (!b) return GQ_EINVAL;
@@ -134,6 +146,8 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const float* ctrl, const
   a->ctrl = ctrl; a->mask = mask; a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart;
   a->applied = st.qfrc_applied; a->time = st.time; a->friction = st.friction; a->cmd = st.cmd;
   a->friction_next = b->friction_next;
+  a->imu_bias = b->imu_bias;
+  a->episode_ro = nullptr;
   a->obs = out.obs; a->reward = out.reward; a->terminated = out.terminated; a->truncated = out.truncated;
   a->invalid_contact = out.invalid_contact; a->step_num = out.step_num;
   a->debug = b->host.debug_envs > 0 ? b->debug : nullptr; a->n_envs = b->host.n_envs;
@@ -158,6 +172,7 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
   fill_step_args(&a.s, b, ctrl, mask, st, out);
   a.auto_reset = auto_reset != nullptr; a.first_pass = 0;
   if (auto_reset) fill_reset_args(&a.r, b, nullptr, nullptr, nullptr, auto_reset, st, out, episode, lift_failed);
+  a.s.episode_ro = episode;
   gq_launch_step(&a, b->host.n_envs, b->model->host.solver, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
@@ -181,6 +196,14 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   a.s.debug = nullptr;
   a.auto_reset = 0; a.first_pass = 1;
   gq_launch_step(&a, b->host.n_envs, b->model->host.solver, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  return GQ_OK;
+}
+
+int gq_heightmap(GqBatch* b, const double* center, const float* yaw, int rows, int cols, float dist_x, float dist_y,
+                 float* out, void* hip_stream) {
+  if (!b || !center || !yaw || !out || rows <= 0 || cols <= 0) { SET_ERR("gq_heightmap: bad argument"); return GQ_EINVAL; }
+  gq_launch_heightmap(center, yaw, b->host.n_envs, rows, cols, dist_x, dist_y, out, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

@@ -9,15 +9,15 @@
 #include <cstdio>
 #include <cstring>
 
-namespace {
-
-void quat2mat(const double* q, double* m) {
+static void quat2mat(const double* q, double* m) {
   double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
   m[0] = w * w + x * x - y * y - z * z; m[4] = w * w - x * x + y * y - z * z; m[8] = w * w - x * x - y * y + z * z;
   m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y); m[3] = 2 * (x * y + w * z);
   m[5] = 2 * (y * z - w * x); m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x);
 }
+
+namespace {
 
 struct Mixed { int dim, rule; double margin, includemargin, solref[2], solimp[5]; };
 
@@ -184,7 +184,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
 }
 
 static const int kObsDims[GQ_OBS_COUNT] = {3, 3, 3, 3, 3, 3, 3, 4, 9, 3, 3, 3, 3, 3, 3, 19, 18, 12, 12, 12, 1, 1,
-                                           12, 12, 12, 12, 12, 12, 4, 12, 12};
+                                           12, 12, 12, 12, 12, 12, 4, 12, 12, 3, 3, 3, 3, 3, 3};
 
 int gq_obs_dim_host(int id) { return (id < 0 || id >= GQ_OBS_COUNT) ? -1 : kObsDims[id]; }
 
@@ -214,4 +214,15 @@ int gq_build_dev_batch(int n_envs, const int32_t* obs_ids, int n_obs, const int3
   }
   out->obs_dim = k;
   return 0;
+}
+
+void gq_fill_imu(GqDevBatch* b, const GqImuCfg* cfg) {
+  double R[9];
+  quat2mat(cfg->site_quat, R);
+  b->imu_enabled = 1;
+  for (int k = 0; k < 3; k++) b->imu_pos[k] = (float)cfg->site_pos[k];
+  for (int k = 0; k < 9; k++) b->imu_mat[k] = (float)R[k];
+  b->imu_acc_noise = cfg->accel_noise; b->imu_gyro_noise = cfg->gyro_noise;
+  b->imu_acc_bias_rate = cfg->accel_bias_rate; b->imu_gyro_bias_rate = cfg->gyro_bias_rate;
+  b->imu_seed_lo = (uint32_t)(cfg->seed & 0xffffffffu); b->imu_seed_hi = (uint32_t)(cfg->seed >> 32);
 }

@@ -11,3 +11,4 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
 int gq_build_dev_batch(int n_envs, const int32_t* obs_ids, int n_obs, const int32_t* legs_order, GqDevBatch* out,
                        char* err, size_t errlen);
 int gq_obs_dim_host(int id);
+void gq_fill_imu(GqDevBatch* b, const GqImuCfg* cfg);

@@ -31,7 +31,34 @@ __global__ void __launch_bounds__(GQ_WAVE) reset_kernel(ResetArgs a) {
   reset_wave(a, W);
 }
 
+/* HeightMap rays: one thread per (env, cell).  Scene = the floor plane z = 0 (flat). */
+__global__ void heightmap_kernel(const double* center, const float* yaw, int n_envs, int rows, int cols, float dist_x,
+                                 float dist_y, float* out) {
+  const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x), cells = rows * cols;
+  if (idx >= n_envs * cells) return;
+  const int env = idx / cells, cell = idx % cells, i = cell / cols, j = cell % cols;
+  const float c_rows = (rows % 2 == 0) ? 0.5f * rows : 0.5f * (rows - 1), c_cols = (cols % 2 == 0) ? 0.5f * cols : 0.5f * (cols - 1);
+  const float off_r = (rows % 2 == 0) ? -0.5f * dist_x : 0.0f, off_c = (cols % 2 == 0) ? -0.5f * dist_y : 0.0f;
+  const float ox = dist_x * (c_rows - (float)i) + off_r, oy = dist_y * (c_cols - (float)j) + off_c;
+  const float cy = cosf(yaw[env]), sy = sinf(yaw[env]);
+  /* offset in the world frame: R_W2H^T [ox, oy], R_W2H = [[c, s], [-s, c]] */
+  const double px = center[(size_t)env * 3 + 0] + (double)(cy * ox - sy * oy);
+  const double py = center[(size_t)env * 3 + 1] + (double)(sy * ox + cy * oy);
+  const double pz = center[(size_t)env * 3 + 2] + 0.6 - 0.07;
+  /* mj_ray along -z against the floor plane: distance = pz (ray starts above the floor), hit = origin - z * dist */
+  const double dist = pz > 0.0 ? pz : -1.0;   /* mj_ray returns -1 when nothing is hit */
+  float* o = out + (size_t)idx * 3;
+  o[0] = (float)px; o[1] = (float)py; o[2] = (float)(pz - dist);
+}
+
 }  // namespace gq
+
+extern "C" void gq_launch_heightmap(const double* center, const float* yaw, int n_envs, int rows, int cols, float dist_x,
+                                    float dist_y, float* out, hipStream_t stream) {
+  const int total = n_envs * rows * cols;
+  hipLaunchKernelGGL(gq::heightmap_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, center, yaw, n_envs, rows, cols,
+                     dist_x, dist_y, out);
+}
 
 extern "C" void gq_launch_step(const gq::FusedArgs* a, int n_envs, int solver, hipStream_t stream) {
   if (solver == 1) hipLaunchKernelGGL(gq::step_kernel<1>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);

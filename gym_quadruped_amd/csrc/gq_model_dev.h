@@ -15,6 +15,7 @@
 #define GQ_MAXCON 12    /* max simultaneous contacts fed to the solver */
 #define GQ_MAXEFC 63    /* constraint rows: one per lane, lane 63 carries the smooth-force solve */
 #define GQ_NOBS_ALL 227 /* scalars in QuadrupedEnv.ALL_OBS */
+#define GQ_NOBS_CANON 245 /* + 6 IMU observables x 3 */
 
 struct GqDevGeom {          /* a robot collision geom that is not a foot sphere */
   int32_t body;             /* 0..12 */
@@ -73,6 +74,11 @@ struct GqDevBatch {            /* per-batch constants */
   int32_t n_envs, obs_dim;
   int32_t obs_map[256];        /* output column -> canonical ALL_OBS scalar index */
   int32_t debug_envs;          /* number of leading envs whose internals are dumped */
+  /* IMU (0 = disabled) */
+  int32_t imu_enabled;
+  float imu_pos[3], imu_mat[9];
+  float imu_acc_noise, imu_gyro_noise, imu_acc_bias_rate, imu_gyro_bias_rate;
+  uint32_t imu_seed_lo, imu_seed_hi;
 };
 
 /* debug dump record (floats) per env, see gq_debug_get */

@@ -616,6 +616,23 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   }
 
   GQ_TICK(10);
+  /* IMU ground truth (mj_sensorAcc / mj_sensorVel of this forward pass: OLD pose and velocity, this step's qacc).
+   * accelerometer = site-frame acceleration of the site point minus gravity; gyro = site-frame angular velocity */
+  const bool imu_on = a.imu_bias != nullptr && a.batch->imu_enabled;
+  if (imu_on && lane == 0) {
+    const GqDevBatch& B = *a.batch;
+    Q4 qo = {W.qb[0], W.qb[1], W.qb[2], W.qb[3]};
+    float Ro[9];
+    q2mat(Ro, qnormalize(qo));
+    const V3 wb = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
+    const V3 ww = matvec(Ro, wb), aw = matvec(Ro, v3(W.qacc[3], W.qacc[4], W.qacc[5]));
+    const V3 r = matvec(Ro, ld3(B.imu_pos));
+    V3 ap = v3(W.qacc[0], W.qacc[1], W.qacc[2]) + cross(aw, r) + cross(ww, cross(ww, r));
+    ap.z -= m.gravity_z;
+    const V3 acc_s = matTvec(B.imu_mat, matTvec(Ro, ap)), gyr_s = matTvec(B.imu_mat, wb);
+    W.warm[0] = acc_s.x; W.warm[1] = acc_s.y; W.warm[2] = acc_s.z; W.warm[3] = gyr_s.x; W.warm[4] = gyr_s.y; W.warm[5] = gyr_s.z;
+  }
+
   /* semi-implicit Euler (mj_Euler): velocity with the damped system, then positions with the new velocity */
   float vnew = 0.0f;
   if (lane < GQ_NVD) {
@@ -754,6 +771,28 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     st3(ob + OB_CONTACT_F_B + 3 * lane, matTvec(Rn, cf));
   }
   wave_barrier();
+  /* IMU.step (sensors/imu.py:102-139): noise ~ N(0, sigma), bias += N(0, rate), measurement = truth + bias + noise.
+   * lanes 0-11 draw: acc noise xyz, acc bias step xyz, gyro noise xyz, gyro bias step xyz */
+  if (imu_on) {
+    const GqDevBatch& B = *a.batch;
+    float z = 0.0f;
+    if (lane < 12) {
+      const uint32_t stepc = (uint32_t)a.step_num[env], epi = a.episode_ro ? (uint32_t)a.episode_ro[env] : 0u;
+      z = philox_normal((uint32_t)lane, stepc, (uint32_t)env, 0x1a70u ^ (epi << 8), B.imu_seed_lo, B.imu_seed_hi);
+      const int grp = lane / 3;
+      z *= grp == 0 ? B.imu_acc_noise : (grp == 1 ? B.imu_acc_bias_rate : (grp == 2 ? B.imu_gyro_noise : B.imu_gyro_bias_rate));
+    }
+    if (lane < 12) W.warm[6 + lane] = z;
+    wave_barrier();
+    if (lane < 6) { /* lanes 0-2: accelerometer axes, lanes 3-5: gyro axes */
+      const int g = lane / 3, ax = lane % 3;
+      const float noise = W.warm[6 + 6 * g + ax], dbias = W.warm[6 + 6 * g + 3 + ax];
+      const float bias = a.imu_bias[(size_t)env * 6 + lane] + dbias;
+      a.imu_bias[(size_t)env * 6 + lane] = bias;
+      const int o = g == 0 ? OB_IMU_ACC : OB_IMU_GYRO;
+      ob[o + ax] = W.warm[lane] + bias + noise; ob[o + 3 + ax] = noise; ob[o + 6 + ax] = bias;
+    }
+  } else if (lane < 18) ob[OB_IMU_ACC + lane] = 0.0f;
   /* termination (quadruped_env.py:283-285): non-foot contact with the ground, or base outside the terrain */
   int terminated = 0;
   {
@@ -807,20 +846,6 @@ struct ResetArgs {
   uint8_t* clear_terminated; uint8_t* clear_truncated; uint8_t* clear_invalid; /* explicit reset(): flags zeroed; NULL inside a fused auto-reset */
   ResetCfgDev cfg;
 };
-
-__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
-/* Philox4x32-10 (Salmon et al. 2011); returns component `which` of the output block */
-__device__ inline uint32_t philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int which) {
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return which == 0 ? c0 : (which == 1 ? c1 : (which == 2 ? c2 : c3));
-}
 
 /* draw indices */
 enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH = 27, RN_VNORM = 28, RN_HEADING = 29,

@@ -35,6 +35,8 @@ struct StepArgs {
   const float* ctrl; const uint8_t* mask;
   double* qpos; float* qvel; float* qacc; float* warm; const float* applied; float* time; const float* friction;
   const float* cmd;
+  float* imu_bias;        /* [N][6] accelerometer / gyro bias random walks (in/out), NULL = no IMU */
+  const int32_t* episode_ro; /* [N] episode counters (RNG counter word), may be NULL */
   float* friction_next;   /* library scratch [N]: friction drawn at reset, committed after the reset's own step (:403-404) */
   float* obs; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* invalid_contact; int32_t* step_num;
   float* debug;
@@ -49,7 +51,9 @@ enum {
   OB_LIN_ACC_B = 43, OB_ANG_VEL_B = 46, OB_ANG_VEL_ERR_B = 49, OB_QPOS = 52, OB_QVEL = 71, OB_TAU = 89,
   OB_QPOS_JS = 101, OB_QVEL_JS = 113, OB_KE = 125, OB_WORK = 126, OB_FEET_POS = 127, OB_FEET_POS_B = 139,
   OB_FEET_VEL = 151, OB_FEET_VEL_REL = 163, OB_FEET_VEL_B = 175, OB_FEET_VEL_REL_B = 187, OB_CONTACT_STATE = 199,
-  OB_CONTACT_F = 203, OB_CONTACT_F_B = 215
+  OB_CONTACT_F = 203, OB_CONTACT_F_B = 215,
+  OB_IMU_ACC = 227, OB_IMU_ACC_NOISE = 230, OB_IMU_ACC_BIAS = 233, OB_IMU_GYRO = 236, OB_IMU_GYRO_NOISE = 239,
+  OB_IMU_GYRO_BIAS = 242
 };
 
 /* flat layout of one tree-sparse L'DL factor in LDS */
@@ -153,6 +157,27 @@ __device__ __forceinline__ void mul_inert(float* r, const float* i, const float*
   r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
   r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
   r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+/* Philox4x32-10 (Salmon et al. 2011); returns component `which` of the output block */
+__device__ inline uint32_t philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int which) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return which == 0 ? c0 : (which == 1 ? c1 : (which == 2 ? c2 : c3));
+}
+
+/* standard normal from one Philox block (Box-Muller on words 0,1): u1 in (0,1], u2 in [0,1) */
+__device__ __forceinline__ float philox_normal(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  const uint32_t x0 = philox4x32(c0, c1, c2, c3, k0, k1, 0), x1 = philox4x32(c0, c1, c2, c3, k0, k1, 1);
+  const float u1 = ((float)(x0 >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = (float)(x1 >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
 /* dof tree of the fixed topology: parent of dof d */

@@ -107,8 +107,6 @@ class QuadrupedEnv:
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise _lib.GqError('QuadrupedEnv runs on a ROCm GPU only (device must be cuda:N); there is no CPU path')
-        if sensors:
-            raise NotImplementedError('sensor plug-ins (IMU / HeightMap) are not available on the batched path yet')
 
         # scene + model (reference :150-183)
         self.scene_desc, self.terrain_limits = generate_terrain(scene, self.robot_cfg.hip_height, seed=10)
@@ -225,7 +223,20 @@ class QuadrupedEnv:
         if self.external_disturbances_kwargs is not None:
             self._sample_external_disturbances(self._mask_all.view(torch.bool))
         self.viewer = None
+        # sensors (reference :232-236): sensor_cls(mj_model=..., mj_data=..., **kwargs); mj_data is this env
         self.sensors = []
+        if sensors is not None:
+            for sensor_cls, kw in zip(sensors, sensors_kwargs or [{}] * len(sensors)):
+                self.sensors.append(sensor_cls(mj_model=self.mjModel, mj_data=self, **kw))
+        from .sensors.imu import IMU
+        for sn in self.sensors:
+            if isinstance(sn, IMU):
+                sn.cfg.seed = int(sn.cfg.seed) + int(env_id_offset)
+                _lib.check(L.gq_batch_set_imu(self._hbatch, C.byref(sn.cfg), sn.bias_state.data_ptr()), 'gq_batch_set_imu')
+        sensor_obs = [o for sn in self.sensors for o in sn.available_observations()]
+        for name in self.state_obs_names:
+            if name.startswith('imu') and name not in sensor_obs:
+                raise ValueError(f'Invalid observation name: {name}: no sensor provides it (pass sensors=(IMU,), sensors_kwargs=...)')
         self._profile_events = None  # optional (start, end) torch.cuda.Event pair recorded around the gq_step launch
 
     # ------------------------------------------------------------------ core API
@@ -256,6 +267,8 @@ class QuadrupedEnv:
                                    self._episode.data_ptr(), self._lift_failed.data_ptr(), stream), 'gq_step')
         if ev is not None:
             ev[1].record()
+        for sensor in self.sensors:  # reference :273-274 (kernel-side sensors: no-op)
+            sensor.step()
 
         if 'reset' in self.base_vel_command_type:  # reference :293-296
             if self.auto_reset:  # envs re-spawned inside the kernel restart their command interval (reference :1068-1070)

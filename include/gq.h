@@ -175,6 +175,8 @@ enum GqObsId {
   GQ_OBS_WORK,
   GQ_OBS_FEET_POS, GQ_OBS_FEET_POS_B, GQ_OBS_FEET_VEL, GQ_OBS_FEET_VEL_REL, GQ_OBS_FEET_VEL_B,
   GQ_OBS_FEET_VEL_REL_B, GQ_OBS_CONTACT_STATE, GQ_OBS_CONTACT_FORCES, GQ_OBS_CONTACT_FORCES_B,
+  /* sensor observables (sensors/imu.py:17-18, LIN_ACC_OBS + GYRO_OBS); valid after gq_batch_set_imu */
+  GQ_OBS_IMU_ACC, GQ_OBS_IMU_ACC_NOISE, GQ_OBS_IMU_ACC_BIAS, GQ_OBS_IMU_GYRO, GQ_OBS_IMU_GYRO_NOISE, GQ_OBS_IMU_GYRO_BIAS,
   GQ_OBS_COUNT
 };
 
@@ -194,6 +196,19 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
                     GqBatch** out);
 int gq_batch_destroy(GqBatch* b);
 int gq_batch_obs_dim(const GqBatch* b);
+
+/* IMU sensor plug-in (sensors/imu.py:20-139): accelerometer + gyro at a site of the base body, white noise and
+ * random-walk bias.  Replaces IMU.step()'s reads of mjData.sensordata (mj_sensorAcc / mj_sensorVel outputs) and its
+ * np.random.normal draws (counter-based Philox normals here; draw order acc noise, acc bias step, gyro noise, gyro
+ * bias step as in compute_linear_acceleration / compute_angular_velocity).  bias_state: device [N][6] in/out
+ * (accelerometer bias xyz, gyro bias xyz), caller-owned, persists across resets like the reference's IMU object. */
+typedef struct GqImuCfg {
+  double site_pos[3];    /* site in the base-body frame (<site name="imu" .../>) */
+  double site_quat[4];
+  float accel_noise, gyro_noise, accel_bias_rate, gyro_bias_rate;
+  uint64_t seed;
+} GqImuCfg;
+int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state);
 
 /* reset configuration: the knobs of QuadrupedEnv.reset / _sample_ref_vel / _set_ground_friction */
 typedef struct GqResetCfg {
@@ -233,6 +248,13 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
  * [N][18] f32 or both NULL. */
 int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new, const GqResetCfg* cfg,
              GqState st, GqObsOut out, int32_t* episode, uint8_t* lift_failed, void* hip_stream);
+
+/* HeightMap.create_sensor_matrix (sensors/heightmap.py:106-169) for every env: rows x cols downward rays
+ * (mujoco.mj_ray, heightmap.py:90-99, static geoms only) from the grid centred above `center` and rotated by `yaw`
+ * into the heading frame; ray origin z = center.z + 0.6 - 0.07.  center: device [N][3] f64, yaw: device [N] f32,
+ * out: device [N][rows][cols][3] f32 hit points ((-1,-1,-1)-style misses cannot occur over the infinite floor). */
+int gq_heightmap(GqBatch* b, const double* center, const float* yaw, int rows, int cols, float dist_x, float dist_y,
+                 float* out, void* hip_stream);
 
 /* debug / inspection: last forward pass internals of env `env` copied to host (doubles).
  * name in {"M","qfrc_bias","qfrc_smooth","qacc_smooth","qfrc_constraint","efc_J","efc_aref","efc_R","efc_b",

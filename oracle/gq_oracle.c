@@ -79,6 +79,8 @@ typedef struct GqOracle {
   double efc_R[NEFC], efc_D[NEFC], efc_vel[NEFC], efc_aref[NEFC], efc_b[NEFC], efc_force[NEFC];
   double efc_solref[NEFC][2], efc_solimp[NEFC][5];
   int solver_niter;
+  /* IMU site on the base body + last mj_sensorAcc / mj_sensorVel readings (noise-free) */
+  double imu_pos[3], imu_quat[4], imu_acc[3], imu_gyro[3];
   int warning; /* bad qpos/qvel/qacc seen (mj_checkPos/Vel/Acc) */
 } GqOracle;
 
@@ -187,6 +189,7 @@ int gqo_create(const GqModelDesc* desc, GqOracle** out) {
   OWN(actuator_forcelimited, nu); OWN(actuator_forcerange, 2 * nu);
   memcpy(o->qpos, o->d.qpos0, sizeof(double) * NQ);
   o->friction = -1.0;
+  o->imu_quat[0] = 1.0;
   *out = o;
   return GQ_OK;
 }
@@ -974,6 +977,27 @@ int gqo_forward(GqOracle* o, const double* ctrl, int stage) {
   gqo_fwd_actuation(o);
   gqo_fwd_acceleration(o);
   gqo_fwd_constraint(o);
+  { /* mj_sensorVel / mj_sensorAcc for a gyro + accelerometer pair on a base-body site: site-frame angular velocity,
+     * site-frame acceleration of the site point minus gravity (reads +9.81 along world z at rest) */
+    const double* R = o->xmat[1];
+    double Rs[9], RS[9], r[3], ww[3], aw[3], t1[3], t2[3], ap[3];
+    quat2mat(Rs, o->imu_quat);
+    mulmat3(RS, R, Rs);
+    mulmatvec3(r, R, o->imu_pos);
+    mulmatvec3(ww, R, o->qvel + 3);
+    mulmatvec3(aw, R, o->qacc + 3);
+    cross3(t1, aw, r); cross3(t2, ww, r); cross3(t2, ww, t2);
+    for (int k = 0; k < 3; k++) ap[k] = o->qacc[k] + t1[k] + t2[k] - o->d.gravity[k];
+    mulmatTvec3(o->imu_acc, RS, ap);
+    mulmatTvec3(o->imu_gyro, Rs, o->qvel + 3);
+  }
+  return GQ_OK;
+}
+
+int gqo_set_imu(GqOracle* o, const double* pos, const double* quat) {
+  memcpy(o->imu_pos, pos, sizeof o->imu_pos);
+  memcpy(o->imu_quat, quat, sizeof o->imu_quat);
+  quat_normalize(o->imu_quat);
   return GQ_OK;
 }
 
@@ -1028,6 +1052,7 @@ int gqo_get(const GqOracle* o, const char* name, double* out, int max_n) {
   GET("geom_xpos", o->geom_xpos, 3 * m->ngeom) GET("geom_xmat", o->geom_xmat, 9 * m->ngeom)
   GET("M", o->M, NV * NV) GET("qfrc_bias", o->qfrc_bias, NV) GET("qfrc_passive", o->qfrc_passive, NV)
   GET("qfrc_actuator", o->qfrc_actuator, NV) GET("qfrc_smooth", o->qfrc_smooth, NV) GET("qacc_smooth", o->qacc_smooth, NV)
+  GET("imu_acc", o->imu_acc, 3) GET("imu_gyro", o->imu_gyro, 3)
   GET("qfrc_constraint", o->qfrc_constraint, NV) GET("cvel", o->cvel, 6 * m->nbody)
   GET("efc_pos", o->efc_pos, o->nefc) GET("efc_margin", o->efc_margin, o->nefc) GET("efc_R", o->efc_R, o->nefc)
   GET("efc_D", o->efc_D, o->nefc) GET("efc_aref", o->efc_aref, o->nefc) GET("efc_vel", o->efc_vel, o->nefc)

@@ -41,6 +41,7 @@ def lib():
         L.gqo_jac_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.gqo_get_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gqo_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.gqo_set_imu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.gqo_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
@@ -71,6 +72,10 @@ class Oracle:
     def set_state(self, qpos=None, qvel=None, qacc_warmstart=None, qfrc_applied=None, time=0.0, friction=-1.0):
         arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (qpos, qvel, qacc_warmstart, qfrc_applied)]
         self.L.gqo_set_state(self.h, *[_p(a) for a in arrs], float(time), float(friction))
+
+    def set_imu(self, pos=(0, 0, 0), quat=(1, 0, 0, 0)):
+        p, q = np.asarray(pos, dtype=np.float64), np.asarray(quat, dtype=np.float64)
+        self.L.gqo_set_imu(self.h, _p(p), _p(q))
 
     def set_solver(self, solver, iterations=100, tolerance=1e-8):
         self.L.gqo_set_solver(self.h, int(solver), int(iterations), float(tolerance))

@@ -13,7 +13,7 @@ ROOT = Path(__file__).resolve().parents[1]
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-from gym_quadruped_amd.cabi import ALL_OBS, OBS_DIMS, GqModelDesc, MarshalledModel, obs_ids_from_names  # noqa: E402
+from gym_quadruped_amd.cabi import ALL_OBS, IMU_OBS, OBS_DIMS, OBS_NAMES, GqImuCfg, GqModelDesc, MarshalledModel, obs_ids_from_names  # noqa: E402
 from gym_quadruped_amd.mjcf import load_compiled  # noqa: E402
 from gym_quadruped_amd.robot_cfgs import get_robot_config  # noqa: E402
 
@@ -72,7 +72,8 @@ def _p(a):
 
 
 def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=None, cmd=None, obs_names=ALL_OBS,
-             legs_order=(0, 1, 2, 3), mask=None, debug_envs=0, auto_reset=None, episode=None, first_pass=0):
+             legs_order=(0, 1, 2, 3), mask=None, debug_envs=0, auto_reset=None, episode=None, first_pass=0, imu=None,
+             imu_bias=None, step_num=None):
     """Run the kernel body under the emulator. Arrays are updated in place like the device tensors would be."""
     L = emu_lib()
     n = qpos.shape[0]
@@ -85,9 +86,10 @@ def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=
         time=f32(time, (n,)), friction=np.full(n, -1, np.float32) if friction is None else f32(friction, (n,)),
         cmd=f32(cmd, (n, 4)), obs=np.zeros((n, od), np.float32), reward=np.zeros(n, np.float32),
         terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8), invalid=np.zeros(n, np.uint8),
-        step_num=np.zeros(n, np.int32), debug=np.zeros((max(debug_envs, 1), DBG_SIZE), np.float32),
+        step_num=np.zeros(n, np.int32) if step_num is None else np.ascontiguousarray(step_num, dtype=np.int32), debug=np.zeros((max(debug_envs, 1), DBG_SIZE), np.float32),
         episode=np.zeros(n, np.int32) if episode is None else np.ascontiguousarray(episode, dtype=np.int32),
-        lift_failed=np.zeros(n, np.uint8), friction_next=np.zeros(n, np.float32))
+        lift_failed=np.zeros(n, np.uint8), friction_next=np.zeros(n, np.float32),
+        imu_bias=np.zeros((n, 6), np.float32) if imu_bias is None else np.ascontiguousarray(imu_bias, dtype=np.float32))
     lo = np.asarray(legs_order, dtype=np.int32)
     err = C.create_string_buffer(512)
     m8 = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
@@ -95,7 +97,8 @@ def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=
                     _p(st['qacc']), _p(st['warm']), _p(st['applied']), _p(st['time']), _p(st['friction']), _p(st['cmd']),
                     _p(st['obs']), _p(st['reward']), _p(st['terminated']), _p(st['truncated']), _p(st['invalid']),
                     _p(st['step_num']), _p(st['debug']), debug_envs, None if auto_reset is None else C.byref(auto_reset),
-                    _p(st['episode']), _p(st['lift_failed']), _p(st['friction_next']), int(first_pass), err, 512)
+                    _p(st['episode']), _p(st['lift_failed']), _p(st['friction_next']), int(first_pass),
+                    None if imu is None else C.byref(imu), _p(st['imu_bias']), err, 512)
     if rc < 0:
         raise RuntimeError(err.value.decode())
     st['obs_names'] = list(obs_names)
@@ -110,7 +113,7 @@ def dbg(rec, name):
 def split_obs(row, obs_names):
     out, k = {}, 0
     for nme in obs_names:
-        d = OBS_DIMS[ALL_OBS.index(nme)]
+        d = OBS_DIMS[OBS_NAMES.index(nme)]
         out[nme] = row[k:k + d]
         k += d
     return out

@@ -25,3 +25,15 @@ def draws(seed, env, episode):
         for j in range(4):
             u[4 * blk + j] = np.float32(w[j] >> 8) * np.float32(1.0 / 16777216.0)
     return u
+
+
+def imu_normals(seed, env, step_num, episode=0):
+    """The 12 standard normals of one IMU update (csrc gq_step_body.h): block counter (draw, step_num, env,
+    0x1a70 ^ (episode << 8)), Box-Muller on words 0,1: acc noise xyz, acc bias step xyz, gyro noise xyz, gyro bias step xyz."""
+    z = np.zeros(12, dtype=np.float64)
+    for d in range(12):
+        w = philox4x32((d, step_num, env, 0x1a70 ^ ((episode << 8) & 0xffffffff)), (seed & 0xffffffff, seed >> 32))
+        u1 = (np.float32(w[0] >> 8) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+        u2 = np.float32(w[1] >> 8) * np.float32(1.0 / 16777216.0)
+        z[d] = np.sqrt(-2.0 * np.log(np.float64(u1))) * np.cos(2 * np.pi * np.float64(u2))
+    return z

@@ -25,20 +25,22 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
                         float* applied, float* time, float* friction, float* cmd, float* obs,
                         float* reward, uint8_t* terminated, uint8_t* truncated, uint8_t* invalid_contact,
                         int32_t* step_num, float* debug, int debug_envs, const GqResetCfg* auto_reset, int32_t* episode,
-                        uint8_t* lift_failed, float* friction_next, int first_pass, char* err, int errlen) {
+                        uint8_t* lift_failed, float* friction_next, int first_pass, const GqImuCfg* imu, float* imu_bias,
+                        char* err, int errlen) {
   static GqDevModel M;
   static GqDevBatch B;
   std::vector<float> vx, vy, vz;
   if (gq_build_dev_model(desc, &M, &vx, &vy, &vz, err, (size_t)errlen)) return -1;
   if (gq_build_dev_batch(n_envs, obs_ids, n_obs, legs_order, &B, err, (size_t)errlen)) return -1;
   B.debug_envs = debug_envs;
+  if (imu) gq_fill_imu(&B, imu);
   gq::FusedArgs f{};
   gq::StepArgs& a = f.s;
   a.model = &M; a.batch = &B; a.vx = vx.data(); a.vy = vy.data(); a.vz = vz.data();
   a.ctrl = ctrl; a.mask = mask; a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied;
   a.time = time; a.friction = friction; a.cmd = cmd; a.friction_next = friction_next; a.obs = obs; a.reward = reward;
   a.terminated = terminated; a.truncated = truncated; a.invalid_contact = invalid_contact; a.step_num = step_num;
-  a.debug = debug; a.n_envs = n_envs;
+  a.debug = debug; a.n_envs = n_envs; a.imu_bias = imu ? imu_bias : nullptr; a.episode_ro = episode;
   f.auto_reset = auto_reset != nullptr; f.first_pass = first_pass;
   if (auto_reset) {
     gq::ResetArgs& r = f.r;

@@ -196,3 +196,47 @@ def test_newton_step_matches_converged_oracle(robot):
         assert bool(tg[e]) == t and bool(ig[e]) == inv
         assert dbg[e]['niter'][0] <= 20
     assert nchecked > 0.8 * n and ncon > n
+
+
+def test_sensors_imu_and_heightmap_on_gpu():
+    """aliengo + IMU plug-in + HeightMap (examples/aliengo_with_imu.py, aliengo_with_heightmap.py re-expressed)."""
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    from gym_quadruped_amd.sensors import IMU, HeightMap
+    from oracle.oracle import Oracle
+    from philox_ref import imu_normals
+    n = 32
+    names = ('qpos', 'qvel', 'base_ori_euler_xyz') + IMU.ALL_OBS
+    kw = dict(accel_name='imu_acc', gyro_name='imu_gyro', imu_site_name='imu', accel_noise=0.01, gyro_noise=0.02,
+              accel_bias_rate=0.03, gyro_bias_rate=0.04, seed=5)
+    env = QuadrupedEnv('aliengo', state_obs_names=names, num_envs=n, sensors=(IMU,), sensors_kwargs=(kw,), solver='newton')
+    env.reset(random=True)
+    torch.cuda.synchronize()
+    o = Oracle(marshalled('aliengo', solver=1, iterations=100, tolerance=1e-12))
+    o.set_imu((0, 0, 0), (1, 0, 0, 0))
+    q0, v0, w0 = env.qpos.cpu().numpy().copy(), env.qvel.cpu().numpy().copy(), env._warm.cpu().numpy().copy()
+    fr, b0 = env._friction.cpu().numpy().copy(), env.sensors[0].bias_state.cpu().numpy().copy()
+    ep = env._episode.cpu().numpy().copy()
+    act = torch.randn(n, 12, device='cuda') * 20
+    obs, *_ = env.step(act)
+    torch.cuda.synchronize()
+    for e in range(n):
+        o.set_state(q0[e], v0[e].astype(np.float64), w0[e].astype(np.float64), np.zeros(18), 0.002, float(fr[e]))
+        o.step(act[e].cpu().numpy().astype(np.float64))
+        z = imu_normals(5, e, 0, int(ep[e]))
+        ab, gb = b0[e, :3] + z[3:6] * 0.03, b0[e, 3:] + z[9:12] * 0.04
+        assert np.abs(obs['imu_acc'][e].cpu().numpy() - (o.imu_acc + ab + z[0:3] * 0.01)).max() < 2e-3 * max(1, np.abs(o.imu_acc).max())
+        assert np.abs(obs['imu_gyro'][e].cpu().numpy() - (o.imu_gyro + gb + z[6:9] * 0.02)).max() < 1e-4
+        assert np.abs(env.sensors[0].get_observation('imu_gyro_bias')[e].cpu().numpy() - gb).max() < 1e-6
+    hm = HeightMap(num_rows=5, num_cols=4, dist_x=0.1, dist_y=0.2, mj_model=env.mjModel, mj_data=env)
+    data = hm.update_height_map(env.qpos[:, 0:3], yaw=obs['base_ori_euler_xyz'][:, 2])
+    torch.cuda.synchronize()
+    assert tuple(data.shape) == (n, 5, 4, 1, 3)
+    d = data.cpu().numpy()[:, :, :, 0, :]
+    c, yaw = env.qpos.cpu().numpy()[:, :3], obs['base_ori_euler_xyz'][:, 2].cpu().numpy()
+    assert np.all(d[..., 2] == 0.0)                                           # rays end on the floor
+    for e in range(0, n, 7):                                                  # grid layout of heightmap.py:106-146
+        R = np.array([[np.cos(yaw[e]), np.sin(yaw[e])], [-np.sin(yaw[e]), np.cos(yaw[e])]])
+        for i in range(5):
+            for j in range(4):
+                off = R.T @ np.array([0.1 * (2 - i), 0.2 * (2 - j) - 0.1])
+                assert np.abs(d[e, i, j, :2] - (c[e, :2] + off)).max() < 1e-4 + 1e-7 * np.abs(c[e, :2]).max()

@@ -98,3 +98,50 @@ def test_reset_kernel_stream_lift_and_bookkeeping():
     qn = np.tile(key, (2, 1)); qn[:, 2] = 0.05
     st2 = emu_reset(mm, 2, cfg, qpos_new=qn, qvel_new=np.ones((2, 18), np.float32))
     assert np.array_equal(st2['qpos'], qn) and np.all(st2['qvel'] == 1)
+
+
+def test_imu_truth_noise_and_bias_walk():
+    """IMU observables out of the step kernel: ground truth == oracle's mj_sensorAcc/Vel restatement, noise and bias
+    random walk == the documented Philox normal stream (tests/philox_ref.py), draw order of sensors/imu.py:110-139."""
+    import ctypes as C
+    from helpers import IMU_OBS, GqImuCfg
+    from philox_ref import imu_normals
+    mm = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-8)
+    o = Oracle(marshalled('aliengo', solver=1, iterations=100, tolerance=1e-12))
+    pos, quat = (0.05, -0.02, 0.03), np.array([0.9, 0.1, -0.3, 0.2])
+    quat = quat / np.linalg.norm(quat)
+    o.set_imu(pos, quat)
+    imu = GqImuCfg(site_pos=(C.c_double * 3)(*pos), site_quat=(C.c_double * 4)(*quat), accel_noise=0.01, gyro_noise=0.02,
+                   accel_bias_rate=0.03, gyro_bias_rate=0.04, seed=777)
+    rng = np.random.default_rng(5)
+    n = 6
+    qpos, qvel = random_states(mm.md, n, rng, z_range=(0.25, 0.5))
+    qvel = qvel.astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 20).astype(np.float32)
+    b0 = rng.normal(0, 0.1, (n, 6)).astype(np.float32)
+    names = ['qpos'] + list(IMU_OBS)
+    st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), obs_names=names, imu=imu, imu_bias=b0.copy(), step_num=np.arange(n) + 10,
+                  episode=np.arange(n))
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e], np.zeros(18), np.zeros(18), 0, -1)
+        o.step(ctrl[e].astype(np.float64))
+        got = split_obs(st['obs'][e], names)
+        z = imu_normals(777, e, 10 + e, e)
+        an, ab, gn, gb = z[0:3] * 0.01, b0[e, :3] + z[3:6] * 0.03, z[6:9] * 0.02, b0[e, 3:] + z[9:12] * 0.04
+        tol = 2e-5 * max(1.0, np.abs(o.imu_acc).max())
+        assert np.abs(got['imu_acc'] - (o.imu_acc + ab + an)).max() < tol
+        assert np.abs(got['imu_gyro'] - (o.imu_gyro + gb + gn)).max() < 1e-5
+        np.testing.assert_allclose(got['imu_acc_noise'], an, atol=1e-7); np.testing.assert_allclose(got['imu_gyro_noise'], gn, atol=1e-7)
+        np.testing.assert_allclose(got['imu_acc_bias'], ab, atol=1e-6); np.testing.assert_allclose(got['imu_gyro_bias'], gb, atol=1e-6)
+        np.testing.assert_allclose(st['imu_bias'][e], np.r_[ab, gb], atol=1e-6)
+    # free fall: the accelerometer reads zero (and +g once something holds the base still: a = 0 -> reading = -gravity)
+    mm2 = marshalled('aliengo', solver=1)
+    o2 = Oracle(mm2)
+    q = mm2.md.key_qpos[0].copy(); q[2] = 2.0
+    o2.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18))
+    o2.forward(np.zeros(12))
+    assert np.abs(o2.imu_acc).max() < 1e-9 and np.abs(o2.imu_gyro).max() == 0
+    hold = np.zeros(18); hold[2] = mm2.md.total_mass * 9.81          # external force cancelling the weight
+    o2.set_state(q, np.zeros(18), np.zeros(18), hold)
+    o2.forward(np.zeros(12))
+    assert np.abs(o2.imu_acc - [0, 0, 9.81]).max() < 0.2               # legs still sag, the base barely moves
