@@ -144,4 +144,4 @@ def test_imu_truth_noise_and_bias_walk():
     hold = np.zeros(18); hold[2] = mm2.md.total_mass * 9.81          # external force cancelling the weight
     o2.set_state(q, np.zeros(18), np.zeros(18), hold)
     o2.forward(np.zeros(12))
-    assert np.abs(o2.imu_acc - [0, 0, 9.81]).max() < 0.2               # legs still sag, the base barely moves
+    assert np.abs(o2.imu_acc - [0, 0, 9.81]).max() < 0.5               # legs still sag, the base barely moves
