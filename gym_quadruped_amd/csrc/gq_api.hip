@@ -215,7 +215,7 @@ static const struct { const char* name; int off, n; } kDbg[] = {
     {"efc_J", GQ_DBG_EFC_J, 64 * 18}, {"efc_aref", GQ_DBG_EFC_AREF, 64}, {"efc_R", GQ_DBG_EFC_R, 64},
     {"efc_b", GQ_DBG_EFC_B, 64}, {"efc_force", GQ_DBG_EFC_FORCE, 64}, {"efc_type", GQ_DBG_EFC_TYPE, 64},
     {"contact_dist", GQ_DBG_CON_DIST, GQ_MAXCON}, {"contact_geom", GQ_DBG_CON_GEOM, GQ_MAXCON},
-    {"foot_pos", GQ_DBG_FOOT_POS, 12}, {"qacc", GQ_DBG_QACC, 18}, {"timer", GQ_DBG_TIMER, 16}, {"record", 0, GQ_DBG_SIZE}};
+    {"foot_pos", GQ_DBG_FOOT_POS, 12}, {"qacc", GQ_DBG_QACC, 18}, {"timer", GQ_DBG_TIMER, 32}, {"record", 0, GQ_DBG_SIZE}};
 
 int gq_debug_get(GqBatch* b, int env, const char* name, double* out, int max_n) {
   if (!b || !name || !out || env < 0 || env >= b->host.debug_envs || !b->debug) { SET_ERR("gq_debug_get: bad argument / debug not enabled"); return GQ_EINVAL; }

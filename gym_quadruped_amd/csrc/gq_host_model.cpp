@@ -110,7 +110,8 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     M.dof_frictionloss[i] = (float)d->dof_frictionloss[i]; M.dof_invweight0[i] = (float)d->dof_invweight0[i];
     for (int k = 0; k < 2; k++) M.dof_solref[i][k] = (float)d->dof_solref[2 * i + k];
     for (int k = 0; k < 5; k++) M.dof_solimp[i][k] = (float)d->dof_solimp[5 * i + k];
-    if (d->dof_frictionloss[i] > 0) M.fl_dof[M.nfl++] = i;
+    M.fl_row_of_dof[i] = -1;
+    if (d->dof_frictionloss[i] > 0) { M.fl_row_of_dof[i] = M.nfl; M.fl_dof[M.nfl++] = i; }
   }
   for (int u = 0; u < d->nu; u++) {
     int j = d->actuator_trnid[u] - 1;

@@ -50,6 +50,7 @@ struct GqDevModel {
   float dof_damping[GQ_NVD], dof_armature[GQ_NVD], dof_frictionloss[GQ_NVD], dof_invweight0[GQ_NVD];
   float dof_solref[GQ_NVD][2], dof_solimp[GQ_NVD][5];
   int32_t fl_dof[GQ_NVD];        /* dofs that own a friction-loss row, compacted; nfl of them */
+  int32_t fl_row_of_dof[GQ_NVD]; /* inverse map: friction-loss row of dof d, -1 if it has none */
   /* motors, one per hinge dof slot (index = hinge 0..11), 0 gear if the joint is unactuated */
   int32_t act_of_jnt[GQ_NJ];     /* ctrl index driving hinge j, -1 none */
   float act_gear[GQ_NJ];
@@ -103,4 +104,4 @@ struct GqDevBatch {            /* per-batch constants */
 #define GQ_DBG_FOOT_POS (GQ_DBG_CON_GEOM + GQ_MAXCON)
 #define GQ_DBG_QACC (GQ_DBG_FOOT_POS + 12)
 #define GQ_DBG_TIMER (GQ_DBG_QACC + 18) /* 16 stage time stamps, shader cycles relative to kernel entry */
-#define GQ_DBG_SIZE (GQ_DBG_TIMER + 16)
+#define GQ_DBG_SIZE (GQ_DBG_TIMER + 32) /* 0-15 stage stamps, 16-23 Newton sub-stage cycle sums */

@@ -97,31 +97,36 @@ __device__ inline void factor_tree_one(WaveMem& W, const float (*Sc)[9], const f
     for (int q = 0; q < 21; q++) acc[lane][q] = bb[q];
   }
   wave_barrier();
-  if (lane == 0) {
-    float b[6][6];
+  { /* 6x6 base block, row-parallel: lane i < 6 owns row i (lower part); pivots k = 5..0, row k is broadcast with
+     * v_readlane and the rows above it are updated at once */
+    float row[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int j = 0; j <= i; j++) {
-        const int q = i * (i + 1) / 2 + j;
-        b[i][j] = Sb[i][j] + acc[0][q] + acc[1][q] + acc[2][q] + acc[3][q];
+    for (int j = 0; j < 6; j++) {
+      float v = 0.0f;
+      if (lane < 6 && j <= lane) {
+        const int q = lane * (lane + 1) / 2 + j;
+        v = Sb[lane][j] + acc[0][q] + acc[1][q] + acc[2][q] + acc[3][q];
       }
-#pragma unroll
-    for (int k = 5; k >= 0; k--) {
-      const float inv = fast_rcp(b[k][k]);
-#pragma unroll
-      for (int i = k - 1; i >= 0; i--) {
-        const float tmp = b[k][i] * inv;
-#pragma unroll
-        for (int j = 0; j <= i; j++) b[i][j] -= b[k][j] * tmp;
-        b[k][i] = tmp;
-      }
-      F[GQ_F_DINV(k)] = inv;
+      row[j] = v;
     }
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+    for (int k = 5; k >= 0; k--) {
+      float rk[6];
 #pragma unroll
-      for (int j = 0; j < i; j++) F[GQ_F_LB(i, j)] = b[i][j];
+      for (int j = 0; j <= k; j++) rk[j] = bcast(row[j], k);
+      const float inv = fast_rcp(rk[k]);
+      float rki = 0.0f;
+#pragma unroll
+      for (int j = 0; j < k; j++) rki = (lane == j) ? rk[j] : rki;
+      const float tmp = rki * inv;
+#pragma unroll
+      for (int j = 0; j < k; j++) row[j] -= (lane < k && j <= lane) ? rk[j] * tmp : 0.0f;
+      if (lane == k) {
+        F[GQ_F_DINV(k)] = inv;
+#pragma unroll
+        for (int j = 0; j < k; j++) F[GQ_F_LB(k, j)] = rk[j] * inv;
+      }
+    }
   }
   wave_barrier();
 }
@@ -205,7 +210,7 @@ __device__ __forceinline__ void row_dd(int rtype, float y, float v, float R, flo
 /* Newton iterations.  In: row data in registers, qacc_smooth / warm / Mc / Mb in LDS, J rows in W.u.B.
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
 __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype, float rR, float raref,
-                                     float rfloss, int nefc, int nsingle, int& niter) {
+                                     float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg) {
   const int lane = lane_id();
   /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */
   const float* J = W.u.B[lane];
@@ -237,22 +242,29 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
   }
   float f = 0.0f, oldcost = 0.0f;
   int iter = 0;
+  long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = tdbg ? cycles() : 0;
+#define NW_T(i) do { if (tdbg) { const long long tn = cycles(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+  NW_T(0);
+  /* residual y = J qacc - aref and Ma-terms are evaluated once, then advanced incrementally along the search
+   * direction (y += alpha J s, M dq += alpha M s), as mj_solNewton does */
+  float y = -raref, dqv = 0.0f, md = 0.0f;
+#pragma unroll
+  for (int k = 0; k < GQ_NVD; k++) y += J[k] * W.qacc[k];
+  if (lane < GQ_NVD) { dqv = W.qacc[lane] - W.qacc_smooth[lane]; dq[lane] = dqv; }
+  wave_barrier();
+  if (lane < GQ_NVD) md = mul_m_row(W, dq, lane);
   for (;; iter++) {
     /* ---- constraint state at the current iterate */
-    float y = -raref;
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) y += J[k] * W.qacc[k];
     float ci, wact;
     f = row_law(rtype, y, rR, rD, rfloss, ci, wact);
-    if (lane < GQ_NVD) dq[lane] = W.qacc[lane] - W.qacc_smooth[lane];
     W.force[lane] = f; /* row forces, read column-wise for J'f below */
+    if (lane < GQ_NVD) Mdq[lane] = md;
     wave_barrier();
-    float md = 0.0f;
-    if (lane < GQ_NVD) { md = mul_m_row(W, dq, lane); Mdq[lane] = md; }
-    const float cost = wave_sum(ci + (lane < GQ_NVD ? 0.5f * dq[lane] * md : 0.0f));
+    const float cost = wave_sum(ci + (lane < GQ_NVD ? 0.5f * dqv * md : 0.0f));
     if (iter > 0 && scale * (oldcost - cost) < m.tolerance) break;
     if (iter >= m.iterations) break;
     oldcost = cost;
+    NW_T(1);
     /* ---- gradient = M dq - J' f  (lane = dof walks its column of J in LDS) */
     float gd = 0.0f;
     if (lane < GQ_NVD) {
@@ -268,42 +280,51 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     wave_barrier();
     W.force[lane] = wact; /* Hessian weights of the rows replace the forces */
     wave_barrier();
-    /* ---- Hessian in M's tree-sparse layout: H = M + sum_r w_r J_r' J_r */
+    NW_T(2);
+    /* ---- Hessian in M's tree-sparse layout: H = M + sum_r w_r J_r' J_r.  117 structurally non-zero entries, two
+     * passes of one entry per lane.  Friction-loss rows are +-e_dof: their weight goes straight to the diagonal; limit
+     * rows (few) and contact rows are walked generically. */
 #pragma unroll
-    for (int pass = 0; pass < 3; pass++) {
+    for (int pass = 0; pass < 2; pass++) {
       const int e = pass * 64 + lane;
-      if (e < 144) {
-        int da, db, valid = 1;
-        float base;
-        if (e < 108) {
-          const int j = e / 9, col = e % 9;
-          da = 6 + j;
-          db = col < 6 ? col : 6 + 3 * (j / 3) + (col - 6);
-          valid = col < 6 || (col - 6) <= j % 3;
-          base = W.Mc[j][col];
-        } else {
-          da = (e - 108) / 6; db = (e - 108) % 6;
-          base = W.Mb[da][db];
+      if (e < 117) {
+        int da, db, slot;            /* dof pair (da >= db) and the slot in Hc (0..107) or Hb (108 + 6*i + j) */
+        if (e < 96) {                /* leg rows: hip 7, thigh 8, calf 9 entries -> 24 per leg */
+          const int leg = e / 24, q = e % 24;
+          const int dep = q < 7 ? 0 : (q < 15 ? 1 : 2), col = q - (dep == 0 ? 0 : (dep == 1 ? 7 : 15));
+          const int j = 3 * leg + dep;
+          da = 6 + j; db = col < 6 ? col : 6 + 3 * leg + (col - 6);
+          slot = j * 9 + col;
+        } else {                     /* base block, lower triangle */
+          const int q = e - 96;
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= q) i++;
+          da = i; db = q - i * (i + 1) / 2;
+          slot = 108 + 6 * da + db;
         }
-        float s0 = 0.0f, s1 = 0.0f;
-        if (valid) {
-          /* friction-loss and limit rows are +-e_dof: they only touch the diagonal */
-          if (da == db)
-            for (int r = 0; r < nsingle; r++) s1 += W.force[r] * W.u.B[r][da] * W.u.B[r][da];
-          int r = nsingle;
-          for (; r + 2 <= nefc; r += 2) {
-            s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
-            s1 += W.force[r + 1] * W.u.B[r + 1][da] * W.u.B[r + 1][db];
-          }
-          if (r < nefc) s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
+        float s0 = slot < 108 ? W.Mc[slot / 9][slot % 9] : W.Mb[da][db], s1 = 0.0f;
+        if (da == db) {
+          const int fr = m.fl_row_of_dof[da];
+          if (fr >= 0) s0 += W.force[fr];
+          for (int r = nfl; r < nsingle; r++) s1 += W.force[r] * W.u.B[r][da] * W.u.B[r][da];
         }
-        const float hv = base + s0 + s1;
-        if (e < 108) W.u2.n.Hc[e / 9][e % 9] = hv; else W.u2.n.Hb[da][db] = hv;
+        int r = nsingle;
+        for (; r + 2 <= nefc; r += 2) {
+          s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
+          s1 += W.force[r + 1] * W.u.B[r + 1][da] * W.u.B[r + 1][db];
+        }
+        if (r < nefc) s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
+        const float hv = s0 + s1;
+        if (slot < 108) W.u2.n.Hc[slot / 9][slot % 9] = hv;
+        else { W.u2.n.Hb[da][db] = hv; W.u2.n.Hb[db][da] = hv; }
       }
     }
     wave_barrier();
+    NW_T(3);
     factor_tree_one(W, W.u2.n.Hc, W.u2.n.Hb, W.F[0]);
+    NW_T(4);
     solve_tree_one(W, W.F[0], grad, search);
+    NW_T(5);
     /* ---- exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on phi' */
     float v = 0.0f;
 #pragma unroll
@@ -330,9 +351,14 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
       alpha = an;
     }
     wave_barrier();
-    if (lane < GQ_NVD) W.qacc[lane] += alpha * search[lane];
+    if (lane < GQ_NVD) { W.qacc[lane] += alpha * search[lane]; dqv += alpha * search[lane]; md += alpha * ms; }
+    y += alpha * v;
     wave_barrier();
+    NW_T(6);
   }
+  if (tdbg && lane == 0)
+    for (int k = 0; k < 7; k++) tdbg[16 + k] = (float)tacc[k];
+#undef NW_T
   niter = iter;
   wave_barrier();
   return f;

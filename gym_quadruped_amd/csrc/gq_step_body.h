@@ -463,7 +463,8 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
 #pragma unroll
     for (int k = 0; k < GQ_NVD; k++) b_i += J[k] * W.qacc_smooth[k];
     GQ_TICK(8);
-    const float fN = newton_solve(W, m, rtype, rR, raref, rfloss, nefc, nfl + nlim, iter);
+    const float fN = newton_solve(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
+                                  timing ? a.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr);
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {

@@ -55,9 +55,12 @@ def stage_times(n=4096, iters=100, tol=1e-8, solver='newton'):
         dt = T[:, k] - prev; prev = T[:, k]
         print(f'  {nm:10s} {dt.mean():9.0f} {np.percentile(dt,95):9.0f} {dt.max():9.0f}')
     print(f'  total      {T[:,13].mean():9.0f} {np.percentile(T[:,13],95):9.0f} {T[:,13].max():9.0f}')
+    if solver == 'newton':
+        for nm, k in zip(['warm', 'state+cost', 'gradient', 'hessian', 'factor', 'solve', 'linesearch'], range(16, 23)):
+            print(f'    newton {nm:11s} {T[:, k].mean():9.0f} {np.percentile(T[:, k], 95):9.0f} {T[:, k].max():9.0f}   per-iter {T[:, k].sum() / max(1, nit.sum()):7.0f}')
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'stages':
     for n in (int(x) for x in (sys.argv[2:] or ['4096'])):
-        for sv in ('pgs', 'newton'):
+        for sv in ('newton',):
             print(sv); stage_times(n, solver=sv)
