@@ -39,6 +39,7 @@ __device__ __forceinline__ int shfl_xor(int v, int m) { return __shfl_xor(v, m, 
 
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
+__device__ __forceinline__ int ffs64(uint64_t m) { return __ffsll((long long)m) - 1; } /* index of the lowest set bit */
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -55,13 +56,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   float r0 = readlane<15>(v), r1 = readlane<31>(v), r2 = readlane<47>(v), r3 = readlane<63>(v);
   return (r0 + r1) + (r2 + r3);
 }
+/* min / max: the same row_shr ladder; out-of-row lanes read their own value (bound_ctrl off, old = self) */
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_self(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_min(float v) {
-  for (int m = 32; m >= 1; m >>= 1) v = fminf(v, shfl_xor(v, m));
-  return v;
+  v = fminf(v, dpp_mov_self<0x111>(v)); v = fminf(v, dpp_mov_self<0x112>(v));
+  v = fminf(v, dpp_mov_self<0x114>(v)); v = fminf(v, dpp_mov_self<0x118>(v));
+  return fminf(fminf(readlane<15>(v), readlane<31>(v)), fminf(readlane<47>(v), readlane<63>(v)));
 }
 __device__ __forceinline__ float wave_max(float v) {
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
-  return v;
+  v = fmaxf(v, dpp_mov_self<0x111>(v)); v = fmaxf(v, dpp_mov_self<0x112>(v));
+  v = fmaxf(v, dpp_mov_self<0x114>(v)); v = fmaxf(v, dpp_mov_self<0x118>(v));
+  return fmaxf(fmaxf(readlane<15>(v), readlane<31>(v)), fmaxf(readlane<47>(v), readlane<63>(v)));
 }
 
 /* optimisation barrier: the value becomes opaque to the compiler (no code is emitted) */

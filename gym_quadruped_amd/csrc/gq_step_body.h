@@ -70,38 +70,61 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
     V3 c = ld3(W.xpos[b]) + matvec(W.xmat[b], ld3(m.foot_pos[lane]));
     st3(W.foot_world[lane], c);
   }
-  /* link geoms: wave-wide scan of the vertex cloud, OBB lower bound first */
+  /* link geoms.  Phase 1, lane = geom: plane normal in the geom frame and the OBB lower bound of the cloud.
+   * Phase 2, only for the geoms whose box can reach the floor (wave-uniform loop over the ballot mask): wave-wide scan
+   * of the vertex cloud for the deepest vertex. */
   const int nlg = m.nlg;
-  for (int g = 0; g < nlg; g++) {
-    const GqDevGeom& G = m.lg[g];
-    if (calf_only && !(G.body > 0 && (G.body - 1) % 3 == 2)) { if (lane == 0) W.u2.c.lg_dist[g] = 1e30f; continue; }
+  V3 ng = v3(0.0f, 0.0f, 0.0f);
+  float d0 = 0.0f;
+  bool needs = false;
+  if (lane < nlg) {
+    const GqDevGeom& G = m.lg[lane];
     const float* Rb = W.xmat[G.body];
     /* plane normal in the geom frame: n_g = Rg' Rb' n, n = (0,0,1) */
-    V3 nb = v3(Rb[6], Rb[7], Rb[8]);
-    V3 ng = matTvec(G.mat, nb);
-    float d0 = W.xpos[G.body][2] + dot(nb, ld3(G.pos));
-    float lower = d0 + dot(ng, ld3(G.aabb_c)) - (fabsf(ng.x) * G.aabb_h[0] + fabsf(ng.y) * G.aabb_h[1] + fabsf(ng.z) * G.aabb_h[2]) - G.radius;
+    const V3 nb = v3(Rb[6], Rb[7], Rb[8]);
+    ng = matTvec(G.mat, nb);
+    d0 = W.xpos[G.body][2] + dot(nb, ld3(G.pos));
+    const float lower = d0 + dot(ng, ld3(G.aabb_c)) - (fabsf(ng.x) * G.aabb_h[0] + fabsf(ng.y) * G.aabb_h[1] + fabsf(ng.z) * G.aabb_h[2]) - G.radius;
+    const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
+    needs = lower < G.margin && (!calf_only || calf);
+    if (!needs) W.u2.c.lg_dist[lane] = 1e30f;
+  }
+  uint64_t todo = ballot(needs);
+  while (todo) { /* wave-uniform */
+    const int g = ffs64(todo);
+    todo &= todo - 1;
+    const GqDevGeom& G = m.lg[g];
+    const float gx = bcast(ng.x, g), gy = bcast(ng.y, g), gz = bcast(ng.z, g), gd0 = bcast(d0, g);
     float best = 1e30f;
     int bi = 0;
-    if (lower < G.margin) { /* wave-uniform */
-      for (int v = lane; v < G.cloud_num; v += GQ_WAVE) {
-        int idx = G.cloud_adr + v;
-        float dv = ng.x * vx[idx] + ng.y * vy[idx] + ng.z * vz[idx];
-        if (dv < best) { best = dv; bi = idx; }
+    /* the cloud is fetched in chunks of 4 x 64 vertices with all 12 loads of a chunk in flight together (one memory
+     * latency per chunk instead of one per 64 vertices); out-of-range lanes re-read the last vertex */
+    const int last = G.cloud_adr + G.cloud_num - 1;
+    for (int v0 = 0; v0 < G.cloud_num; v0 += 4 * GQ_WAVE) { /* wave-uniform trip count */
+      int idx[4];
+      float px[4], py[4], pz[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = G.cloud_adr + v0 + u * GQ_WAVE + lane;
+        idx[u] = i < last ? i : last;
+        px[u] = vx[idx[u]]; py[u] = vy[idx[u]]; pz[u] = vz[idx[u]];
       }
-      float wmin = wave_min(best);
-      uint64_t who = ballot(best == wmin);
-      int src = 0;
-      while (!((who >> src) & 1)) src++;
-      bi = bcast(bi, src);
-      best = wmin + d0 - G.radius;
-      if (lane == 0) {
-        W.u2.c.lg_dist[g] = best;
-        V3 vl = v3(vx[bi], vy[bi], vz[bi]);
-        V3 vb = ld3(G.pos) + matvec(G.mat, vl);
-        st3(W.u2.c.lg_pt[g], ld3(W.xpos[G.body]) + matvec(Rb, vb));
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float dv = gx * px[u] + gy * py[u] + gz * pz[u];
+        if (dv < best) { best = dv; bi = idx[u]; }
       }
-    } else if (lane == 0) W.u2.c.lg_dist[g] = 1e30f;
+    }
+    const float wmin = wave_min(best);
+    const uint64_t who = ballot(best == wmin);
+    bi = bcast(bi, ffs64(who));
+    if (lane == 0) {
+      W.u2.c.lg_dist[g] = wmin + gd0 - G.radius;
+      const float* Rb = W.xmat[G.body];
+      const V3 vl = v3(vx[bi], vy[bi], vz[bi]);
+      const V3 vb = ld3(G.pos) + matvec(G.mat, vl);
+      st3(W.u2.c.lg_pt[g], ld3(W.xpos[G.body]) + matvec(Rb, vb));
+    }
   }
   wave_barrier();
 }

@@ -51,6 +51,7 @@ static inline float wave_sum(float v) { uint32_t u; memcpy(&u, &v, 4); const uin
 static inline float wave_min(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::min(r, t); } return r; }
 static inline float wave_max(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = -INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::max(r, t); } return r; }
 static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+static inline int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 static inline void opaque(int&) {}
 static inline void opaque_s(int&) {}
 static inline void sched_fence() {}
