@@ -8,7 +8,10 @@ from pathlib import Path
 from .cabi import GqImuCfg, GqModelDesc, GqObsOut, GqResetCfg, GqState
 
 _LIB = None
-LIB_PATH = Path(__file__).parent / 'libgq.so'
+import os
+
+# GQ_LIBGQ_PATH: developer override used for A/B timing of two kernel builds inside one GPU session
+LIB_PATH = Path(os.environ.get('GQ_LIBGQ_PATH', Path(__file__).parent / 'libgq.so'))
 
 EXPORTS = ['gq_last_error', 'gq_version', 'gq_obs_dim', 'gq_model_create', 'gq_model_destroy', 'gq_batch_create',
            'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_batch_set_imu', 'gq_heightmap', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get']

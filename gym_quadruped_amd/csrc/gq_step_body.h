@@ -27,28 +27,41 @@ __device__ inline Q4 stage_kinematics(WaveMem& W, const GqDevModel& m) {
     W.xpos[0][0] = 0.0f; W.xpos[0][1] = 0.0f; W.xpos[0][2] = W.basez;
     q2mat(W.xmat[0], qbase);
   }
+  /* phase 1, lane = link (12 lanes): local transform of the link in its parent's frame - all model reads and the
+   * sin/cos of the joint angle happen here, in parallel */
+  if (lane < GQ_NJ) {
+    const int b = 1 + lane, j = lane;
+    const Q4 bq = {m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2], m.body_quat[b][3]};
+    const V3 bp = ld3(m.body_pos[b]), jp = ld3(m.jnt_pos[j]), ax = ld3(m.jnt_axis[j]);
+    float R0[9], R1[9], sn, cs;
+    q2mat(R0, bq);
+    sincosf(0.5f * (W.qj[j] - m.qpos0[j]), &sn, &cs);
+    const Q4 qr = {cs, ax.x * sn, ax.y * sn, ax.z * sn};
+    const Q4 ql = qmul(bq, qr);
+    q2mat(R1, ql);
+    const V3 aloc = bp + matvec(R0, jp);            /* joint anchor in the parent frame */
+    const V3 ploc = aloc - matvec(R1, jp);          /* child origin: rotation about the anchor keeps it fixed */
+    float* o = W.u.dyn.fkloc[lane];
+    o[0] = ql.w; o[1] = ql.x; o[2] = ql.y; o[3] = ql.z;
+    st3(o + 4, ploc); st3(o + 7, aloc); st3(o + 10, matvec(R0, ax));
+  }
+  wave_barrier();
+  /* phase 2, lane = leg: compose the three local transforms down the chain */
   if (lane < 4) {
     float Rp[9];
     q2mat(Rp, qbase);
     V3 pp = v3(0.0f, 0.0f, W.basez);
     Q4 pq = qbase;
+#pragma unroll
     for (int i = 0; i < 3; i++) {
       const int b = 1 + 3 * lane + i, j = 3 * lane + i;
-      Q4 bq = {m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2], m.body_quat[b][3]};
-      V3 pos = pp + matvec(Rp, ld3(m.body_pos[b]));
-      Q4 q = qmul(pq, bq);
-      float R0[9];
-      q2mat(R0, q);
-      V3 jp = ld3(m.jnt_pos[j]), ax = ld3(m.jnt_axis[j]);
-      V3 anchor = pos + matvec(R0, jp);
-      st3(W.u.dyn.anchor[j], anchor);
-      st3(W.u.dyn.axis[j], matvec(R0, ax));
-      float ang = W.qj[j] - m.qpos0[j];
-      float s = sinf(0.5f * ang), c = cosf(0.5f * ang);
-      Q4 ql = {c, ax.x * s, ax.y * s, ax.z * s};
-      q = qnormalize(qmul(q, ql));
+      const float* o = W.u.dyn.fkloc[j];
+      const Q4 ql = {o[0], o[1], o[2], o[3]};
+      st3(W.u.dyn.anchor[j], pp + matvec(Rp, ld3(o + 7)));   /* anchor/axis do not overlay fkloc */
+      st3(W.u.dyn.axis[j], matvec(Rp, ld3(o + 10)));
+      const V3 pos = pp + matvec(Rp, ld3(o + 4));
+      const Q4 q = qnormalize(qmul(pq, ql));
       q2mat(Rp, q);
-      pos = anchor - matvec(Rp, jp);
       st3(W.xpos[b], pos);
 #pragma unroll
       for (int k = 0; k < 9; k++) W.xmat[b][k] = Rp[k];
@@ -743,8 +756,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   /* kinetic energy 1/2 v'Mv and work (M qacc).v with the OLD mass matrix, NEW velocity, qacc of this step */
   float ke_part = 0.0f, wk_part = 0.0f;
   if (lane < GQ_NVD) {
-    float mv = 0.0f, ma = 0.0f;
-    for (int k = 0; k < GQ_NVD; k++) { const float mk = m_entry(W, lane, k); mv += mk * W.qvel[k]; ma += mk * W.qacc[k]; }
+    const float mv = mul_m_row(W, W.qvel, lane), ma = mul_m_row(W, W.qacc, lane);
     ke_part = 0.5f * W.qvel[lane] * mv; wk_part = ma * W.qvel[lane];
   }
   float ke = wave_sum(ke_part), wk = wave_sum(wk_part);

@@ -71,7 +71,11 @@ struct WaveDyn {
   float anchor[GQ_NJ][3], axis[GQ_NJ][3];
   float cinert[GQ_NB][10];
   union { float crb[GQ_NB][10]; float acc[8][21]; };    /* acc: per-leg Schur updates of the base block (S4, crb is dead) */
-  float cvel[GQ_NB][6], cacc[GQ_NB][6], cfrc[GQ_NB][6];
+  union {
+    struct { float cvel[GQ_NB][6], cacc[GQ_NB][6]; };
+    float fkloc[GQ_NJ][13];   /* S1 only: per-link local transform (quat 4, offset 3, anchor 3, axis 3) */
+  };
+  float cfrc[GQ_NB][6];
 };
 struct WaveMem {
   float qj[12], qb[4], basez, qvel[18], ctrl[12], warm[18], applied[18], cmd[4];
