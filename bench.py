@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--obs', choices=['all', 'default'], default='all')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--auto-reset', choices=['next_step', 'same_step', 'off'], default='next_step')
     ap.add_argument('--no-auto-reset', action='store_true')
     ap.add_argument('--solver', choices=['newton', 'pgs'], default='newton')
     args = ap.parse_args()
@@ -108,7 +109,7 @@ def main():
     obs_names = tuple(QuadrupedEnv.ALL_OBS) if args.obs == 'all' else QuadrupedEnv._DEFAULT_OBS
     n = args.envs_per_gpu
     env = QuadrupedEnv('mini_cheetah', state_obs_names=obs_names, scene='flat', num_envs=n, device=device,
-                       auto_reset=not args.no_auto_reset, solver=args.solver, solver_iterations=100, solver_tolerance=1e-8,
+                       auto_reset=False if (args.no_auto_reset or args.auto_reset == 'off') else args.auto_reset, solver=args.solver, solver_iterations=100, solver_tolerance=1e-8,
                        seed=1000, env_id_offset=rank * n)  # shards: disjoint global env ids -> disjoint RNG counters
     env.reset(random=True)
     g = torch.Generator(device=device).manual_seed(rank)
@@ -153,7 +154,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'mini_cheetah flat, {n} envs/GPU, random-action rollout (50*N(0,1) torques), '
                                    f'{"ALL_OBS" if args.obs == "all" else "_DEFAULT_OBS"} ({env._obs_dim} scalars), '
-                                   f'auto-reset on termination, sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8',
+                                   f'auto-reset on termination ({env.auto_reset_mode}), sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8',
                        'envs_per_gpu': n, 'total_envs': total_envs, 'parallelism': f'env-shards x{world} (no collectives)',
                        'state_finite': finite},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

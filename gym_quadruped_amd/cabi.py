@@ -55,7 +55,7 @@ class GqResetCfg(C.Structure):
                 ('roll_sweep', C.c_float), ('pitch_sweep', C.c_float), ('hip_height', C.c_float),
                 ('lin_vel_range', C.c_float * 2), ('ang_vel_range', C.c_float * 2), ('friction_range', C.c_float * 2),
                 ('cmd_forward', C.c_int32), ('cmd_random', C.c_int32), ('cmd_rotate', C.c_int32), ('cmd_human', C.c_int32),
-                ('env_id_offset', C.c_int32)]
+                ('env_id_offset', C.c_int32), ('autoreset_next_step', C.c_int32)]
 
 
 class GqImuCfg(C.Structure):

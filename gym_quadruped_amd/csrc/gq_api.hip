@@ -42,6 +42,7 @@ struct GqBatch {
   GqDevBatch* dev;
   float* debug;       /* device, debug_envs * GQ_DBG_SIZE floats (lazily allocated) */
   float* friction_next; /* device [N]: friction drawn by reset, committed after the reset step */
+  uint8_t* pending;     /* device [N]: next-step auto-reset flags */
   float* imu_bias;      /* caller-owned device [N][6], set by gq_batch_set_imu */
   int debug_cap;
 };
@@ -93,6 +94,8 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&b->friction_next, sizeof(float) * (size_t)n_envs));
   HIP_TRY(hipMemset(b->friction_next, 0, sizeof(float) * (size_t)n_envs));
+  HIP_TRY(hipMalloc(&b->pending, (size_t)n_envs));
+  HIP_TRY(hipMemset(b->pending, 0, (size_t)n_envs));
   *out = b;
   return GQ_OK;
 }
@@ -100,7 +103,7 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
 int gq_batch_destroy(GqBatch* b) {
   if (!b) return GQ_OK;
   hipSetDevice(b->model->device);
-  hipFree(b->dev); hipFree(b->friction_next);
+  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending);
   if (b->debug) hipFree(b->debug);
   delete b;
   return GQ_OK;
@@ -145,7 +148,7 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const float* ctrl, const
   a->model = m->dev; a->batch = b->dev; a->vx = m->vx; a->vy = m->vy; a->vz = m->vz;
   a->ctrl = ctrl; a->mask = mask; a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart;
   a->applied = st.qfrc_applied; a->time = st.time; a->friction = st.friction; a->cmd = st.cmd;
-  a->friction_next = b->friction_next;
+  a->friction_next = b->friction_next; a->pending = b->pending;
   a->imu_bias = b->imu_bias;
   a->episode_ro = nullptr;
   a->obs = out.obs; a->reward = out.reward; a->terminated = out.terminated; a->truncated = out.truncated;
@@ -170,7 +173,7 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
   }
   gq::FusedArgs a{};
   fill_step_args(&a.s, b, ctrl, mask, st, out);
-  a.auto_reset = auto_reset != nullptr; a.first_pass = 0;
+  a.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; a.first_pass = 0;
   if (auto_reset) fill_reset_args(&a.r, b, nullptr, nullptr, nullptr, auto_reset, st, out, episode, lift_failed);
   a.s.episode_ro = episode;
   gq_launch_step(&a, b->host.n_envs, b->model->host.solver, (hipStream_t)hip_stream);

@@ -9,19 +9,24 @@
 
 namespace gq {
 
-/* step (+ in-kernel auto-reset): a terminated env is re-spawned by the same wavefront - reset_wave, then the reset's
- * own mj_step as a second pass through step_wave - so auto-reset costs no extra launches and only the few
- * terminated envs pay for the second pass. */
+/* step (+ in-kernel auto-reset).  Same-step mode: a terminated env is re-spawned by the same wavefront - reset_wave,
+ * then the reset's own mj_step as a second pass through step_wave; no extra launches, but the launch lasts as long as
+ * its two-pass waves.  Next-step mode: the env waits (pending flag) and spends its next launch on reset_wave + the
+ * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
 template <int SOLVER>
 __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(FusedArgs a) {
   if (a.s.mask && !a.s.mask[blockIdx.x]) return; /* wave-uniform */
   __shared__ WaveMem W;
   int pass = a.first_pass;
-  for (;;) {
+  bool respawn = a.auto_reset == 2 && a.s.pending[blockIdx.x]; /* wave-uniform */
+  for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
+    if (respawn) {
+      reset_wave(a.r, W);
+      pass = a.auto_reset;
+    }
     const int term = step_wave<SOLVER>(a.s, W, pass);
-    if (pass == 1 || !a.auto_reset || !term) break;
-    reset_wave(a.r, W);
-    pass = 1;
+    if (pass != 0 || a.auto_reset != 1 || !term) break;
+    respawn = true;
   }
 }
 

@@ -143,7 +143,8 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
 }
 
 /* One mj_step + observation epilogue for this wave's env.  pass 0: the user's step.  pass 1: the reset's own step
- * (zero control, friction committed afterwards, termination flags of pass 0 are kept).  Returns `terminated`. */
+ * (zero control, friction committed afterwards, termination flags of pass 0 are kept).  pass 2: the reset's own step of
+ * a next-step auto-reset (as pass 1, flags cleared).  Returns `terminated`. */
 template <int SOLVER> /* 0: PGS (mj_solPGS), 1: Newton (mj_solNewton, MuJoCo's default) */
 __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
@@ -407,26 +408,28 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
 
   GQ_TICK(6);
   /* ================================================================ S7: constraint rows, lane = row */
-  float J[GQ_NVD];
-#pragma unroll
-  for (int k = 0; k < GQ_NVD; k++) J[k] = 0.0f;
+  /* per-lane row descriptor first (what kind of row, which dof / contact direction), then ONE unrolled sweep over the
+   * 18 dofs produces the J entries for every row kind at once: J[k] = cdof[k] . [p x dir ; dir] on the contact's chain,
+   * +-1 at the dof of a friction-loss / limit row.  The Newton path streams the entries straight into LDS (its solver
+   * only reads J from there) - no 18-register row is kept live across the row set-up; PGS keeps them in registers. */
   int rtype = ROW_NONE;
   float rpos = 0.0f, rmargin = 0.0f, rfloss = 0.0f, rdiag = 0.0f, rmu = 0.0f, rdiag_first = 0.0f;
   const float* rsolref = m.dof_solref[0];
   const float* rsolimp = m.dof_solimp[0];
+  int jd = -1, jleg = -1, jdepth = -1;   /* single-entry rows: dof index; contact rows: leg / depth of the body (-1: base) */
+  float jsgn = 0.0f;
+  bool jcon = false;
+  V3 dir = v3(0.0f, 0.0f, 0.0f), w = v3(0.0f, 0.0f, 0.0f);
   if (lane < nfl) {
     const int d = m.fl_dof[lane];
     rtype = ROW_FRICTION; rfloss = m.dof_frictionloss[d]; rdiag = m.dof_invweight0[d];
     rsolref = m.dof_solref[d]; rsolimp = m.dof_solimp[d];
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) J[k] = (k == d) ? 1.0f : 0.0f;
+    jd = d; jsgn = 1.0f;
   } else if (lane < nfl + nlim) {
     const int r = lane - nfl, j = W.u2.c.lim_jnt[r], d = 6 + j;
     rtype = ROW_LIMIT; rpos = W.u2.c.lim_dist[r]; rmargin = m.jnt_margin[j]; rdiag = m.dof_invweight0[d];
     rsolref = m.jnt_solref[j]; rsolimp = m.jnt_solimp[j];
-    const float sgn = W.u2.c.lim_side[r];
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) J[k] = (k == d) ? sgn : 0.0f;
+    jd = d; jsgn = W.u2.c.lim_side[r];
   } else if (lane < nefc) {
     int c = 0;
     for (int q = 1; q < ncon; q++)
@@ -436,7 +439,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     rpos = W.con_dist[c]; rmargin = W.con_inc[c]; rsolref = W.con_solref[c]; rsolimp = W.con_solimp[c];
     const float tran = m.body_invweight0[body][0];
     /* contact frame of a horizontal floor (mju_makeFrame): n = z, t1 = y, t2 = -x */
-    V3 dir = v3(0.0f, 0.0f, 1.0f);
+    dir = v3(0.0f, 0.0f, 1.0f);
     if (dim == 1) { rtype = ROW_CONTACT1; rdiag = tran; }
     else {
       rtype = ROW_PYRAMID;
@@ -446,23 +449,21 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
       rdiag_first = rdiag;
       rmu = mu / sqrtf(m.impratio);
     }
-    V3 p = ld3(W.con_pos[c]) - O;
-    V3 w = cross(p, dir);
-    /* J[d] = cdof[d] . [p x dir ; dir] for the dofs on the chain of `body` */
+    w = cross(ld3(W.con_pos[c]) - O, dir);
+    jcon = true;
+    if (body > 0) { jleg = (body - 1) / 3; jdepth = (body - 1) % 3; }
+  }
+  float J[SOLVER == 1 ? 1 : GQ_NVD];
+  float vel = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const float* s = W.cdof[k];
-      J[k] = s[0] * w.x + s[1] * w.y + s[2] * w.z + s[3] * dir.x + s[4] * dir.y + s[5] * dir.z;
-    }
-    if (body > 0) {
-      const int leg = (body - 1) / 3, depth = (body - 1) % 3;
-#pragma unroll
-      for (int k = 6; k < GQ_NVD; k++) {
-        const float* s = W.cdof[k];
-        float v = s[0] * w.x + s[1] * w.y + s[2] * w.z + s[3] * dir.x + s[4] * dir.y + s[5] * dir.z;
-        J[k] = ((k - 6) / 3 == leg && (k - 6) % 3 <= depth) ? v : 0.0f;
-      }
-    }
+  for (int k = 0; k < GQ_NVD; k++) {
+    const float* sd = W.cdof[k]; /* wave-uniform LDS reads */
+    float v = sd[0] * w.x + sd[1] * w.y + sd[2] * w.z + sd[3] * dir.x + sd[4] * dir.y + sd[5] * dir.z;
+    const bool on_chain = k < 6 ? jcon : (jcon && (k - 6) / 3 == jleg && (k - 6) % 3 <= jdepth);
+    v = on_chain ? v : (k == jd ? jsgn : 0.0f);
+    vel += v * W.qvel[k];
+    if constexpr (SOLVER == 1) W.u.B[lane][k] = v; /* rows >= nefc are all-zero: rtype NONE sets no descriptor */
+    else J[k] = v;
   }
   float rR = 1.0f, raref = 0.0f;
   if (rtype != ROW_NONE) {
@@ -474,9 +475,6 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
       K = 1.0f / fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr);
       B = 2.0f / fmaxf(1e-15f, dmax * tc);
     } else { K = -rsolref[0] / fmaxf(1e-15f, dmax * dmax); B = -rsolref[1] / fmaxf(1e-15f, dmax); }
-    float vel = 0.0f;
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) vel += J[k] * W.qvel[k];
     raref = -B * vel - K * imp * (rpos - rmargin);
     if (rtype == ROW_PYRAMID) { /* Rpy = 2 mu^2 R(first edge); all edges of a condim-3 contact share diagApprox */
       float Rfirst = fmaxf(1e-15f, (1.0f - imp) * rdiag_first / imp);
@@ -490,14 +488,8 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   int iter = 0;
   if constexpr (SOLVER == 1) {
     /* ================================================================ S8/S9 (Newton): primal solve, no dual operator */
-    wave_barrier(); /* u.dyn is dead: J rows go to LDS for the Hessian assembly */
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) W.u.B[lane][k] = active ? J[k] : 0.0f;
-    wave_barrier();
+    wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
     solve_tree_one(W, W.F[0], W.smooth, W.qacc_smooth);
-    b_i = -raref;
-#pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) b_i += J[k] * W.qacc_smooth[k];
     GQ_TICK(8);
     const float fN = newton_solve(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
                                   timing ? a.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr);
@@ -646,6 +638,10 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     }
     if (lane == 0) { D[GQ_DBG_NEFC] = (float)nefc; D[GQ_DBG_NCON] = (float)ncon; D[GQ_DBG_NITER] = (float)iter; }
     for (int k = 0; k < GQ_NVD; k++) D[GQ_DBG_EFC_J + lane * 18 + k] = W.u.B[lane][k];
+    if constexpr (SOLVER == 1) { /* efc_b = J qacc_smooth - aref: only the record wants it, the primal solver never forms it */
+      b_i = -raref;
+      for (int k = 0; k < GQ_NVD; k++) b_i += W.u.B[lane][k] * W.qacc_smooth[k];
+    }
     D[GQ_DBG_EFC_AREF + lane] = raref; D[GQ_DBG_EFC_R + lane] = rR; D[GQ_DBG_EFC_B + lane] = b_i;
     D[GQ_DBG_EFC_FORCE + lane] = W.force[lane]; D[GQ_DBG_EFC_TYPE + lane] = (float)rtype;
     if (lane < GQ_MAXCON) { D[GQ_DBG_CON_DIST + lane] = lane < ncon ? W.con_dist[lane] : 0.0f; D[GQ_DBG_CON_GEOM + lane] = lane < ncon ? (float)W.con_geom[lane] : -1.0f; }
@@ -840,10 +836,13 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
         a.invalid_contact[env] = (uint8_t)W.invalid;
         a.terminated[env] = (uint8_t)terminated;
         a.truncated[env] = 0;
+      } else if (pass == 2) { /* reset() reports no termination (quadruped_env.py:406 returns the observation only) */
+        a.invalid_contact[env] = 0; a.terminated[env] = 0; a.truncated[env] = 0;
       }
+      if (a.pending) a.pending[env] = (uint8_t)(pass == 0 ? terminated : 0);
       a.reward[env] = 0.0f;
       a.step_num[env] += 1;
-      if (pass == 1 && a.friction && a.friction_next) const_cast<float*>(a.friction)[env] = a.friction_next[env];
+      if (pass != 0 && a.friction && a.friction_next) const_cast<float*>(a.friction)[env] = a.friction_next[env];
     }
   }
   GQ_TICK(12);
@@ -990,7 +989,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
 struct FusedArgs {
   StepArgs s;
   ResetArgs r;          /* used when auto_reset != 0 */
-  int32_t auto_reset;
+  int32_t auto_reset;   /* 0 off, 1 same-step (second pass in this launch), 2 next-step (pending flag, one pass per launch) */
   int32_t first_pass;   /* 0: user step; 1: the reset's own step (gq_reset) */
 };
 

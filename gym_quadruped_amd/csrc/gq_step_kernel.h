@@ -38,6 +38,7 @@ struct StepArgs {
   float* imu_bias;        /* [N][6] accelerometer / gyro bias random walks (in/out), NULL = no IMU */
   const int32_t* episode_ro; /* [N] episode counters (RNG counter word), may be NULL */
   float* friction_next;   /* library scratch [N]: friction drawn at reset, committed after the reset's own step (:403-404) */
+  uint8_t* pending;       /* library scratch [N]: env terminated and waits for its next-step auto-reset (may be NULL) */
   float* obs; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* invalid_contact; int32_t* step_num;
   float* debug;
   int32_t n_envs;

@@ -85,7 +85,7 @@ class QuadrupedEnv:
         *,
         num_envs: int = 1,
         device: str | torch.device = 'cuda:0',
-        auto_reset: bool = False,
+        auto_reset: bool | str = False,
         solver: str = 'newton',
         solver_iterations: int = 100,
         solver_tolerance: float = 1e-8,
@@ -103,7 +103,13 @@ class QuadrupedEnv:
         self.ground_friction_coeff_range = _process_range(ground_friction_coeff)
         self.legs_order = tuple(legs_order)
         self.num_envs = int(num_envs)
+        # False | True / 'same_step' (terminated envs are re-spawned inside the same step call; obs = first of the new
+        # episode) | 'next_step' (gymnasium's NEXT_STEP: the terminal obs is returned and the env spends its next step
+        # call on reset(), ignoring that action) - see gq_step in include/gq.h
+        if auto_reset not in (False, True, 'same_step', 'next_step'):
+            raise ValueError(f"auto_reset must be False, True, 'same_step' or 'next_step', got {auto_reset!r}")
         self.auto_reset = bool(auto_reset)
+        self.auto_reset_mode = None if not auto_reset else ('next_step' if auto_reset == 'next_step' else 'same_step')
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise _lib.GqError('QuadrupedEnv runs on a ROCm GPU only (device must be cuda:N); there is no CPU path')
@@ -217,6 +223,7 @@ class QuadrupedEnv:
             cmd_rotate=int('rotate' in t), cmd_human=int('human' in t), env_id_offset=int(env_id_offset))
         # auto-reset happens inside the step kernel (terminated envs take a second pass); None = off
         self._auto_cfg_struct = GqResetCfg.from_buffer_copy(self._reset_cfg)  # user reset() options never leak into it
+        self._auto_cfg_struct.autoreset_next_step = int(self.auto_reset_mode == 'next_step')
         self._auto_cfg = C.pointer(self._auto_cfg_struct) if self.auto_reset else None
 
         self.external_disturbances_kwargs = external_disturbances_kwargs
@@ -260,6 +267,9 @@ class QuadrupedEnv:
             self._ctrl.copy_(a)
             self._last_action = self._ctrl
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        respawned = None
+        if self.auto_reset_mode == 'next_step' and 'reset' in self.base_vel_command_type:
+            respawned = self._terminated_b.clone()  # envs that terminated last step are reset by this one
         ev = self._profile_events
         if ev is not None:
             ev[0].record()
@@ -272,7 +282,7 @@ class QuadrupedEnv:
 
         if 'reset' in self.base_vel_command_type:  # reference :293-296
             if self.auto_reset:  # envs re-spawned inside the kernel restart their command interval (reference :1068-1070)
-                self._steps_after_vel.masked_fill_(self._terminated_b, 0)
+                self._steps_after_vel.masked_fill_(self._terminated_b if respawned is None else respawned, 0)
             self._steps_after_vel += 1
             due = self._steps_after_vel >= self._steps_before_vel
             self._sample_ref_vel(due)

@@ -223,6 +223,7 @@ typedef struct GqResetCfg {
   float friction_range[2];  /* ground_friction_coeff (min,max) (:143) */
   int32_t cmd_forward, cmd_random, cmd_rotate, cmd_human; /* substrings of base_vel_command_type (:1049-1066) */
   int32_t env_id_offset;    /* global id of env 0 of this batch (multi-GPU shards draw from disjoint counters) */
+  int32_t autoreset_next_step; /* only read by gq_step(auto_reset=...): 0 = same-step auto-reset, 1 = next-step (see gq_step) */
 } GqResetCfg;
 
 /* QuadrupedEnv.step body (quadruped_env.py:270-290): ctrl <- action; mj_step; _get_obs; reward; termination.
@@ -231,6 +232,11 @@ typedef struct GqResetCfg {
  * auto_reset != NULL: an env whose step terminates is re-spawned INSIDE the same launch (the batched stand-in for the
  * user's `if terminated: env.reset()` loop): reset state write + lift loop + the reset's own mj_step, exactly as
  * gq_reset does; its `terminated` flag stays set and its observation row is the first one of the new episode.
+ * auto_reset->autoreset_next_step != 0 selects gymnasium's NEXT_STEP convention instead: the terminating step returns
+ * the terminal observation, and the env spends its NEXT gq_step call on the reset (control ignored; state write + lift
+ * loop + the reset's own mj_step; flags 0, observation = first of the new episode).  Every launch then runs exactly
+ * one mj_step per env, so no wavefront does two passes.  The pending-reset flags live in the batch and are cleared by
+ * gq_reset for the envs it resets.
  * episode / lift_failed as in gq_reset (may be NULL when auto_reset is NULL). */
 int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out,
             const GqResetCfg* auto_reset, int32_t* episode, uint8_t* lift_failed, void* hip_stream);

@@ -73,7 +73,7 @@ def _p(a):
 
 def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=None, cmd=None, obs_names=ALL_OBS,
              legs_order=(0, 1, 2, 3), mask=None, debug_envs=0, auto_reset=None, episode=None, first_pass=0, imu=None,
-             imu_bias=None, step_num=None):
+             imu_bias=None, step_num=None, pending=None):
     """Run the kernel body under the emulator. Arrays are updated in place like the device tensors would be."""
     L = emu_lib()
     n = qpos.shape[0]
@@ -89,6 +89,7 @@ def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=
         step_num=np.zeros(n, np.int32) if step_num is None else np.ascontiguousarray(step_num, dtype=np.int32), debug=np.zeros((max(debug_envs, 1), DBG_SIZE), np.float32),
         episode=np.zeros(n, np.int32) if episode is None else np.ascontiguousarray(episode, dtype=np.int32),
         lift_failed=np.zeros(n, np.uint8), friction_next=np.zeros(n, np.float32),
+        pending=np.zeros(n, np.uint8) if pending is None else np.ascontiguousarray(pending, dtype=np.uint8),
         imu_bias=np.zeros((n, 6), np.float32) if imu_bias is None else np.ascontiguousarray(imu_bias, dtype=np.float32))
     lo = np.asarray(legs_order, dtype=np.int32)
     err = C.create_string_buffer(512)
@@ -98,7 +99,7 @@ def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=
                     _p(st['obs']), _p(st['reward']), _p(st['terminated']), _p(st['truncated']), _p(st['invalid']),
                     _p(st['step_num']), _p(st['debug']), debug_envs, None if auto_reset is None else C.byref(auto_reset),
                     _p(st['episode']), _p(st['lift_failed']), _p(st['friction_next']), int(first_pass),
-                    None if imu is None else C.byref(imu), _p(st['imu_bias']), err, 512)
+                    None if imu is None else C.byref(imu), _p(st['imu_bias']), _p(st['pending']), err, 512)
     if rc < 0:
         raise RuntimeError(err.value.decode())
     st['obs_names'] = list(obs_names)

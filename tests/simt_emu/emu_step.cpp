@@ -26,7 +26,7 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
                         float* reward, uint8_t* terminated, uint8_t* truncated, uint8_t* invalid_contact,
                         int32_t* step_num, float* debug, int debug_envs, const GqResetCfg* auto_reset, int32_t* episode,
                         uint8_t* lift_failed, float* friction_next, int first_pass, const GqImuCfg* imu, float* imu_bias,
-                        char* err, int errlen) {
+                        uint8_t* pending, char* err, int errlen) {
   static GqDevModel M;
   static GqDevBatch B;
   std::vector<float> vx, vy, vz;
@@ -38,10 +38,10 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
   gq::StepArgs& a = f.s;
   a.model = &M; a.batch = &B; a.vx = vx.data(); a.vy = vy.data(); a.vz = vz.data();
   a.ctrl = ctrl; a.mask = mask; a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied;
-  a.time = time; a.friction = friction; a.cmd = cmd; a.friction_next = friction_next; a.obs = obs; a.reward = reward;
+  a.time = time; a.friction = friction; a.cmd = cmd; a.friction_next = friction_next; a.pending = pending; a.obs = obs; a.reward = reward;
   a.terminated = terminated; a.truncated = truncated; a.invalid_contact = invalid_contact; a.step_num = step_num;
   a.debug = debug; a.n_envs = n_envs; a.imu_bias = imu ? imu_bias : nullptr; a.episode_ro = episode;
-  f.auto_reset = auto_reset != nullptr; f.first_pass = first_pass;
+  f.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; f.first_pass = first_pass;
   if (auto_reset) {
     gq::ResetArgs& r = f.r;
     r.model = &M; r.vx = vx.data(); r.vy = vy.data(); r.vz = vz.data();
@@ -54,11 +54,15 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
     emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
       __shared__ gq::WaveMem W;
       int pass = f.first_pass;
+      bool respawn = f.auto_reset == 2 && f.s.pending[e];
       for (;;) {
+        if (respawn) {
+          gq::reset_wave(f.r, W);
+          pass = f.auto_reset;
+        }
         const int term = M.solver == 1 ? gq::step_wave<1>(f.s, W, pass) : gq::step_wave<0>(f.s, W, pass);
-        if (pass == 1 || !f.auto_reset || !term) break;
-        gq::reset_wave(f.r, W);
-        pass = 1;
+        if (pass != 0 || f.auto_reset != 1 || !term) break;
+        respawn = true;
       }
     });
   }

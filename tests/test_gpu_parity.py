@@ -155,6 +155,37 @@ def test_full_size_invariants():
     assert nterm > 0, 'random +-50 Nm actions must terminate some envs'
 
 
+def test_next_step_auto_reset_equals_manual_reset_loop():
+    """gymnasium NEXT_STEP auto-reset: the terminating step returns the terminal observation with terminated=True; the
+    env's next step call ignores the action and performs reset() (state write, lift loop, the reset's own mj_step) -
+    exactly what the reference user loop `if terminated: env.reset()` does, so an explicit masked reset of a twin env
+    (same seed, same episode counters) lands on the same state."""
+    n = 512
+    kw = dict(obs=('qpos', 'qvel'), iters=50, tol=1e-8, solver='newton')
+    auto = _make_env(n, auto_reset='next_step', **kw)
+    twin = _make_env(n, auto_reset=False, **kw)
+    auto.reset(random=True); twin.reset(random=True)
+    assert torch.equal(auto.qpos, twin.qpos)
+    g = torch.Generator(device='cuda:0').manual_seed(3)
+    pending = torch.zeros(n, dtype=torch.bool, device='cuda:0')
+    nreset = 0
+    for _ in range(150):
+        act = torch.randn(n, 12, generator=g, device='cuda:0') * 50
+        o1, _, t1, _, _ = auto.step(act)
+        # twin: every env steps; the envs that terminated LAST step are then reset (reset() rewrites their whole state and
+        # clears their flags, so the dropped step leaves no trace) - the reference user's `if terminated: env.reset()`
+        o2, _, t2, _, _ = twin.step(act)
+        if bool(pending.any()):
+            o2 = twin.reset(random=True, env_ids=pending)
+            nreset += int(pending.sum())
+        assert torch.equal(t1, twin._terminated_b)
+        assert torch.equal(auto.qpos, twin.qpos) and torch.equal(auto.qvel, twin.qvel)
+        assert torch.equal(o1['qpos'], o2['qpos']) and torch.equal(o1['qvel'], o2['qvel'])
+        assert not bool((t1 & pending).any())   # a reset step never reports termination
+        pending = t1.clone()
+    assert nreset > 0
+
+
 @pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo', 'hyqreal2', 'b2'])
 def test_newton_step_matches_converged_oracle(robot):
     """solver='newton' (MuJoCo's default) on every pyramidal-cone robot of the registry: one step from random

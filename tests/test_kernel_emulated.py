@@ -145,3 +145,33 @@ def test_imu_truth_noise_and_bias_walk():
     o2.set_state(q, np.zeros(18), np.zeros(18), hold)
     o2.forward(np.zeros(12))
     assert np.abs(o2.imu_acc - [0, 0, 9.81]).max() < 0.5               # legs still sag, the base barely moves
+
+
+def test_auto_reset_same_step_and_next_step_agree():
+    """A terminated env (base out of bounds) is re-spawned either inside the same launch (second pass) or by its next
+    launch (gymnasium NEXT_STEP): both run reset_wave + the reset's own mj_step on the same RNG counters, so the state
+    after 'step' (same-step) equals the state after 'step, step' (next-step); the untouched env just steps."""
+    mm = marshalled('mini_cheetah', iterations=20, terrain_limits=(5, -5, 5, -5))
+    q = np.tile(mm.md.key_qpos[0], (2, 1)); q[:, 2] = 0.6
+    q[0, 0] = 5.5    # env 0 is outside the terrain -> terminates
+    v = np.zeros((2, 18), np.float32)
+    ctrl = np.ones((2, 12), np.float32)
+    epi = np.array([3, 4], np.int32)
+    cfg_same = default_reset_cfg(seed=77, fric=(0.3, 0.9))
+    cfg_next = default_reset_cfg(seed=77, fric=(0.3, 0.9)); cfg_next.autoreset_next_step = 1
+    a = emu_step(mm, ctrl, q.copy(), v.copy(), auto_reset=cfg_same, episode=epi.copy())
+    assert a['terminated'].tolist() == [1, 0] and a['episode'].tolist() == [4, 4] and a['pending'].tolist() == [0, 0]
+    assert a['step_num'].tolist() == [0, 1] and abs(a['qpos'][0, 0]) <= 5.0
+    b1 = emu_step(mm, ctrl, q.copy(), v.copy(), auto_reset=cfg_next, episode=epi.copy())
+    assert b1['terminated'].tolist() == [1, 0] and b1['pending'].tolist() == [1, 0] and b1['episode'].tolist() == [3, 4]
+    assert abs(b1['qpos'][0, 0] - 5.5) < 1e-4 and b1['step_num'].tolist() == [1, 1]      # terminal state / observation kept
+    np.testing.assert_array_equal(b1['qpos'][1], a['qpos'][1])
+    q1_prev = b1['qpos'][1].copy()   # emu_step updates the arrays in place
+    b2 = emu_step(mm, ctrl, b1['qpos'], b1['qvel'], warm=b1['warm'], time=b1['time'], friction=b1['friction'], cmd=b1['cmd'],
+                  auto_reset=cfg_next, episode=b1['episode'], pending=b1['pending'], step_num=b1['step_num'])
+    assert b2['terminated'].tolist() == [0, 0] and b2['pending'].tolist() == [0, 0] and b2['episode'].tolist() == [4, 4]
+    assert b2['step_num'].tolist() == [0, 2]
+    for k in ('qpos', 'qvel', 'warm', 'time', 'friction', 'cmd'):
+        np.testing.assert_array_equal(b2[k][0], a[k][0], err_msg=k)   # same draws, same reset step: bit-identical
+    np.testing.assert_array_equal(b2['obs'][0], a['obs'][0])
+    assert not np.array_equal(b2['qpos'][1], q1_prev)          # env 1 kept stepping with the user's control
