@@ -41,7 +41,7 @@ class GqModelDesc(C.Structure):
         ('floor_condim', C.c_int32), ('floor_priority', C.c_int32),
         ('feet_geomid', C.c_int32 * GQ_NLEG), ('terrain_limits', C.c_double * 4), ('meaninertia', C.c_double),
         ('key_qpos', C.c_double * 19),
-        ('solver', C.c_int32), ('iterations', C.c_int32), ('tolerance', C.c_double),
+        ('solver', C.c_int32), ('iterations', C.c_int32), ('tolerance', C.c_double), ('noise_floor', C.c_double),
     ]
 
 
@@ -90,7 +90,8 @@ class MarshalledModel:
     """Owns the numpy buffers a GqModelDesc points into (keep alive for as long as the struct is in use)."""
 
     def __init__(self, md: ModelDesc, *, qpos0=None, feet_geom_names=None, terrain_limits=(1e4, -1e4, 1e4, -1e4),
-                 timestep=None, solver=SOLVER_PGS, iterations=100, tolerance=1e-8, floor=None):
+                 timestep=None, solver=SOLVER_PGS, iterations=100, tolerance=1e-8, floor=None,
+                 noise_floor=0.0):
         self.md = md
         self._keep = []
         d = GqModelDesc()
@@ -125,6 +126,7 @@ class MarshalledModel:
         kq = md.key_qpos[0] if len(md.key_qpos) else q0
         d.key_qpos = (C.c_double * 19)(*[float(v) for v in kq])
         d.solver, d.iterations, d.tolerance = int(solver), int(iterations), float(tolerance)
+        d.noise_floor = float(noise_floor)
         self.desc = d
 
 

@@ -72,7 +72,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
   if (d->solver != 0 && d->solver != 1) FAIL("solver must be 0 (PGS) or 1 (Newton)");
   if (d->gravity[0] != 0 || d->gravity[1] != 0) FAIL("gravity must be along z");
   M.timestep = (float)d->timestep; M.gravity_z = (float)d->gravity[2]; M.impratio = (float)d->impratio;
-  M.meaninertia = (float)d->meaninertia; M.tolerance = (float)d->tolerance; M.iterations = d->iterations; M.cone = d->cone; M.solver = d->solver;
+  M.meaninertia = (float)d->meaninertia; M.tolerance = (float)d->tolerance; M.noise_floor = (float)d->noise_floor; M.iterations = d->iterations; M.cone = d->cone; M.solver = d->solver;
   for (int b = 0; b < GQ_NB; b++) {
     int s = b + 1;
     for (int k = 0; k < 3; k++) { M.body_pos[b][k] = (float)d->body_pos[3 * s + k]; M.body_ipos[b][k] = (float)d->body_ipos[3 * s + k]; }

@@ -34,7 +34,7 @@ struct GqDevGeom {          /* a robot collision geom that is not a foot sphere 
 };
 
 struct GqDevModel {
-  float timestep, gravity_z, impratio, meaninertia, tolerance;
+  float timestep, gravity_z, impratio, meaninertia, tolerance, noise_floor;
   int32_t iterations, cone, nlg, nfl, solver;
   /* bodies */
   float body_pos[GQ_NB][3], body_quat[GQ_NB][4], body_ipos[GQ_NB][3], body_mass[GQ_NB];

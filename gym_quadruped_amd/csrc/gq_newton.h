@@ -266,16 +266,20 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     oldcost = cost;
     NW_T(1);
     /* ---- gradient = M dq - J' f  (lane = dof walks its column of J in LDS) */
-    float gd = 0.0f;
+    float gd = 0.0f, gterm = 0.0f;
     if (lane < GQ_NVD) {
       float s0 = 0.0f, s1 = 0.0f;
       int r = 0;
       for (; r + 2 <= nefc; r += 2) { s0 += W.u.B[r][lane] * W.force[r]; s1 += W.u.B[r + 1][lane] * W.force[r + 1]; }
       if (r < nefc) s0 += W.u.B[r][lane] * W.force[r];
       gd = md - (s0 + s1);
+      gterm = md * md + (s0 + s1) * (s0 + s1);
     }
     const float gnorm2 = wave_sum(lane < GQ_NVD ? gd * gd : 0.0f);
     if (scale * sqrtf(gnorm2) < m.tolerance) break;
+    /* fp32 floor (GqModelDesc.noise_floor): the gradient is a difference of two vectors; once it is down at their
+     * round-off a further Newton step only chases noise */
+    if (iter > 0 && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(gterm)) break;
     if (lane < GQ_NVD) grad[lane] = -gd; /* right-hand side of H search = -grad */
     wave_barrier();
     W.force[lane] = wact; /* Hessian weights of the rows replace the forces */

@@ -588,9 +588,8 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   }
   W.force[lane] = active ? f : 0.0f;
   wave_barrier();
-
-  GQ_TICK(9);
   }
+  GQ_TICK(9);
   /* ================================================================ S10: accelerations and integration */
   if constexpr (SOLVER == 1) {
     /* qacc and qfrc_constraint (= M (qacc - qacc_smooth)) come out of the Newton solve; only the Euler system

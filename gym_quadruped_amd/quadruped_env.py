@@ -89,6 +89,7 @@ class QuadrupedEnv:
         solver: str = 'newton',
         solver_iterations: int = 100,
         solver_tolerance: float = 1e-8,
+        solver_noise_floor: float = 1e-5,
         seed: int | None = None,
         mjcf_path: str | None = None,
         env_id_offset: int = 0,
@@ -124,7 +125,7 @@ class QuadrupedEnv:
         self.mjModel.qpos0 = qpos0
         self._mm = MarshalledModel(self.mjModel, qpos0=qpos0, feet_geom_names=self.robot_cfg.feet_geom_names,
                                    terrain_limits=self.terrain_limits, timestep=sim_dt, solver={'pgs': 0, 'newton': 1}[solver],
-                                   iterations=solver_iterations, tolerance=solver_tolerance,
+                                   iterations=solver_iterations, tolerance=solver_tolerance, noise_floor=solver_noise_floor,
                                    floor=self.scene_desc.get('floor'))
         self._sim_dt = float(sim_dt)
 

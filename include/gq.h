@@ -137,6 +137,11 @@ typedef struct GqModelDesc {
   int32_t solver;                /* 0 PGS (mj_solPGS, named by the north-star), 1 Newton (mj_solNewton, MuJoCo's default) */
   int32_t iterations;
   double tolerance;
+  /* fp32 stopping rule of the Newton solver (no MuJoCo counterpart; 0 = off): after at least one Newton step the
+   * iteration also stops when |grad| <= noise_floor * sqrt(|M dq|^2 + |J'f|^2), i.e. when the gradient - a
+   * difference of those two vectors - is down at the round-off of its own terms and `tolerance` (meant for fp64
+   * magnitudes) can no longer be met by anything but a wasted extra iteration. */
+  double noise_floor;
 } GqModelDesc;
 
 typedef struct GqModel GqModel;

@@ -39,7 +39,7 @@ if __name__ == '__main__' and len(sys.argv) == 1:
 
 
 def stage_times(n=4096, iters=100, tol=1e-8, solver='newton'):
-    env = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset=True, solver=solver, solver_iterations=iters, solver_tolerance=tol, seed=1)
+    env = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', solver=solver, solver_iterations=iters, solver_tolerance=tol, seed=1)
     env.reset()
     g = torch.Generator(device='cuda').manual_seed(0)
     for i in range(60): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)
@@ -47,7 +47,7 @@ def stage_times(n=4096, iters=100, tol=1e-8, solver='newton'):
     env.step(torch.randn(n, 12, generator=g, device='cuda') * 50); torch.cuda.synchronize()
     d = env.debug_internals(n, ['timer', 'niter', 'nefc'])
     T = np.stack([x['timer'] for x in d]); nit = np.array([x['niter'][0] for x in d]); ne = np.array([x['nefc'][0] for x in d])
-    names = ['S0+S1 kin', 'S2 inert', 'S3 M', 'S4 factor', 'S5 rne', 'S6a scan', 'S6b list', 'S7 rows', 'S8 dual', 'S9 pgs', 'S10 acc', 'dump+euler', 'S11 obs', 'gather']
+    names = ['S0+S1 kin', 'S2 inert', 'S3 M', 'S4 factor', 'S5 rne', 'S6a scan', 'S6b list', 'S7 rows', 'S8 dual/qs', 'S9 solver', 'S10 acc', 'dump+euler', 'S11 obs', 'gather']
     order = [1, 2, 3, 4, 5, 14, 6, 7, 8, 9, 10, 11, 12, 13]
     prev = np.zeros(n)
     print(f'stage times in shader cycles (mean / p95 / max over {n} envs); niter mean {nit.mean():.1f} p95 {np.percentile(nit,95):.0f} max {nit.max():.0f}; nefc mean {ne.mean():.1f} max {ne.max():.0f}')
