@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -16,11 +17,12 @@
 #include "gq_step_kernel.h"
 #include "gq_step_body.h"
 
-extern "C" void gq_launch_step(const gq::FusedArgs* a, int n_envs, int solver, hipStream_t stream);
+extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, hipStream_t stream);
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream);
 extern "C" void gq_launch_heightmap(const double* center, const float* yaw, int n_envs, int rows, int cols, float dist_x,
                                     float dist_y, float* out, hipStream_t stream);
 
+#define GQ_ARG_SLOTS 8
 static thread_local char g_err[512] = "";
 #define SET_ERR(...) std::snprintf(g_err, sizeof g_err, __VA_ARGS__)
 #define HIP_TRY(expr)                                                                   \
@@ -43,6 +45,14 @@ struct GqBatch {
   float* debug;       /* device, debug_envs * GQ_DBG_SIZE floats (lazily allocated) */
   float* friction_next; /* device [N]: friction drawn by reset, committed after the reset step */
   uint8_t* pending;     /* device [N]: next-step auto-reset flags */
+  int stop_stage;       /* profiling aid: GQ_STOP_STAGE at batch creation */
+  /* argument block of step_kernel: device copy, host shadow of what the device holds, pinned staging ring for the
+   * (rare) stream-ordered re-upload */
+  gq::FusedArgs* dev_args;
+  gq::FusedArgs shadow;
+  gq::FusedArgs* staging;   /* pinned host, GQ_ARG_SLOTS entries */
+  int staging_next;
+  bool shadow_valid;
   float* imu_bias;      /* caller-owned device [N][6], set by gq_batch_set_imu */
   int debug_cap;
 };
@@ -96,6 +106,11 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   HIP_TRY(hipMemset(b->friction_next, 0, sizeof(float) * (size_t)n_envs));
   HIP_TRY(hipMalloc(&b->pending, (size_t)n_envs));
   HIP_TRY(hipMemset(b->pending, 0, (size_t)n_envs));
+  { const char* s = getenv("GQ_STOP_STAGE"); b->stop_stage = s ? atoi(s) : 0; }
+  HIP_TRY(hipMalloc(&b->dev_args, sizeof(gq::FusedArgs)));
+  HIP_TRY(hipHostMalloc(&b->staging, sizeof(gq::FusedArgs) * GQ_ARG_SLOTS, hipHostMallocDefault));
+  b->staging_next = 0; b->shadow_valid = false;
+  std::memset(&b->shadow, 0, sizeof b->shadow);
   *out = b;
   return GQ_OK;
 }
@@ -103,7 +118,7 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
 int gq_batch_destroy(GqBatch* b) {
   if (!b) return GQ_OK;
   hipSetDevice(b->model->device);
-  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending);
+  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->dev_args); hipHostFree(b->staging);
   if (b->debug) hipFree(b->debug);
   delete b;
   return GQ_OK;
@@ -143,17 +158,38 @@ static void fill_reset_cfg(gq::ResetCfgDev* d, const GqResetCfg* cfg) {
   d->cmd_forward = cfg->cmd_forward; d->cmd_random = cfg->cmd_random; d->cmd_rotate = cfg->cmd_rotate; d->cmd_human = cfg->cmd_human;
   d->env_id_offset = cfg->env_id_offset;
 }
-static void fill_step_args(gq::StepArgs* a, GqBatch* b, const float* ctrl, const uint8_t* mask, const GqState& st, const GqObsOut& out) {
+static void fill_reset_args(gq::ResetArgs* a, GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new,
+                            const GqResetCfg* cfg, const GqState& st, const GqObsOut& out, int32_t* episode, uint8_t* lift_failed);
+static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const GqObsOut& out, const int32_t* episode) {
   GqModel* m = b->model;
   a->model = m->dev; a->batch = b->dev; a->vx = m->vx; a->vy = m->vy; a->vz = m->vz;
-  a->ctrl = ctrl; a->mask = mask; a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart;
+  a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart;
   a->applied = st.qfrc_applied; a->time = st.time; a->friction = st.friction; a->cmd = st.cmd;
   a->friction_next = b->friction_next; a->pending = b->pending;
   a->imu_bias = b->imu_bias;
-  a->episode_ro = nullptr;
+  a->episode_ro = episode;
   a->obs = out.obs; a->reward = out.reward; a->terminated = out.terminated; a->truncated = out.truncated;
   a->invalid_contact = out.invalid_contact; a->step_num = out.step_num;
-  a->debug = b->host.debug_envs > 0 ? b->debug : nullptr; a->n_envs = b->host.n_envs;
+  a->n_envs = b->host.n_envs;
+}
+/* Make the device argument block describe (st, out, episode, lift_failed[, auto-reset cfg]).  Steady state: a memcmp.
+ * On a change the new block goes through a pinned staging slot with a stream-ordered copy, so launches already queued
+ * on `stream` still see the old block.  reset_cfg NULL keeps whatever auto-reset block the device holds. */
+static int ensure_args(GqBatch* b, const GqState& st, const GqObsOut& out, int32_t* episode, uint8_t* lift_failed,
+                       const GqResetCfg* reset_cfg, hipStream_t stream) {
+  gq::FusedArgs want = b->shadow; /* struct copy keeps padding bytes identical for the memcmp */
+  fill_step_args(&want.s, b, st, out, episode);
+  if (reset_cfg) fill_reset_args(&want.r, b, nullptr, nullptr, nullptr, reset_cfg, st, out, episode, lift_failed);
+  if (b->shadow_valid && std::memcmp(&want, &b->shadow, sizeof want) == 0) return GQ_OK;
+  if (b->staging_next == GQ_ARG_SLOTS) { /* every slot may still be in flight: drain before reusing the ring */
+    HIP_TRY(hipStreamSynchronize(stream));
+    b->staging_next = 0;
+  }
+  gq::FusedArgs* slot = b->staging + b->staging_next++;
+  std::memcpy(slot, &want, sizeof want);
+  HIP_TRY(hipMemcpyAsync(b->dev_args, slot, sizeof want, hipMemcpyHostToDevice, stream));
+  b->shadow = want; b->shadow_valid = true;
+  return GQ_OK;
 }
 static void fill_reset_args(gq::ResetArgs* a, GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new,
                             const GqResetCfg* cfg, const GqState& st, const GqObsOut& out, int32_t* episode, uint8_t* lift_failed) {
@@ -171,12 +207,13 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
       !out.terminated || !out.truncated || !out.invalid_contact || !out.step_num) {
     SET_ERR("gq_step: null tensor"); return GQ_EINVAL;
   }
-  gq::FusedArgs a{};
-  fill_step_args(&a.s, b, ctrl, mask, st, out);
-  a.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; a.first_pass = 0;
-  if (auto_reset) fill_reset_args(&a.r, b, nullptr, nullptr, nullptr, auto_reset, st, out, episode, lift_failed);
-  a.s.episode_ro = episode;
-  gq_launch_step(&a, b->host.n_envs, b->model->host.solver, (hipStream_t)hip_stream);
+  if (auto_reset && (!episode || !st.cmd)) { SET_ERR("gq_step: auto-reset needs the episode counters and the command tensor"); return GQ_EINVAL; }
+  const int rc = ensure_args(b, st, out, episode, lift_failed, auto_reset, (hipStream_t)hip_stream);
+  if (rc != GQ_OK) return rc;
+  gq::StepCall c{};
+  c.ctrl = ctrl; c.mask = mask; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
+  c.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; c.first_pass = 0; c.stop_stage = b->stop_stage;
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }
@@ -194,12 +231,19 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   gq_launch_reset(&r, b->host.n_envs, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */
-  gq::FusedArgs a{};
-  fill_step_args(&a.s, b, nullptr, mask, st, out);
-  a.s.debug = nullptr;
-  a.auto_reset = 0; a.first_pass = 1;
-  gq_launch_step(&a, b->host.n_envs, b->model->host.solver, (hipStream_t)hip_stream);
+  const int rc = ensure_args(b, st, out, episode, lift_failed, nullptr, (hipStream_t)hip_stream);
+  if (rc != GQ_OK) return rc;
+  gq::StepCall c{};
+  c.mask = mask; c.first_pass = 1;
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
+  return GQ_OK;
+}
+
+int gq_batch_set_pending(GqBatch* b, const uint8_t* flags, void* hip_stream) {
+  if (!b) { SET_ERR("gq_batch_set_pending: null batch"); return GQ_EINVAL; }
+  if (flags) HIP_TRY(hipMemcpyAsync(b->pending, flags, (size_t)b->host.n_envs, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+  else HIP_TRY(hipMemsetAsync(b->pending, 0, (size_t)b->host.n_envs, (hipStream_t)hip_stream));
   return GQ_OK;
 }
 

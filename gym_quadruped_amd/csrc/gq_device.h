@@ -83,6 +83,12 @@ __device__ __forceinline__ long long cycles() { return (long long)__builtin_read
 /* instruction-scheduling fence: nothing moves across it */
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
+/* issue priority of this wave among the waves of its SIMD (s_setprio 0..3).  The launch lasts as long as its slowest
+ * wave, so a wave that finds out it has a lot of work left (many constraint rows, a Newton solve that needs more
+ * iterations) raises its priority and stops sharing issue slots evenly with neighbours that will finish early anyway. */
+template <int P>
+__device__ __forceinline__ void wave_priority() { __builtin_amdgcn_s_setprio(P); }
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }

@@ -14,18 +14,18 @@ namespace gq {
  * its two-pass waves.  Next-step mode: the env waits (pending flag) and spends its next launch on reset_wave + the
  * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
 template <int SOLVER>
-__global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(FusedArgs a) {
-  if (a.s.mask && !a.s.mask[blockIdx.x]) return; /* wave-uniform */
+__global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
+  if (c.mask && !c.mask[blockIdx.x]) return; /* wave-uniform */
   __shared__ WaveMem W;
-  int pass = a.first_pass;
-  bool respawn = a.auto_reset == 2 && a.s.pending[blockIdx.x]; /* wave-uniform */
+  int pass = c.first_pass;
+  bool respawn = c.auto_reset == 2 && A->s.pending[blockIdx.x]; /* wave-uniform */
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
-      reset_wave(a.r, W);
-      pass = a.auto_reset;
+      reset_wave(A->r, W);
+      pass = c.auto_reset;
     }
-    const int term = step_wave<SOLVER>(a.s, W, pass);
-    if (pass != 0 || a.auto_reset != 1 || !term) break;
+    const int term = step_wave<SOLVER>(A->s, c, W, pass);
+    if (pass != 0 || c.auto_reset != 1 || !term) break;
     respawn = true;
   }
 }
@@ -65,9 +65,9 @@ extern "C" void gq_launch_heightmap(const double* center, const float* yaw, int 
                      dist_x, dist_y, out);
 }
 
-extern "C" void gq_launch_step(const gq::FusedArgs* a, int n_envs, int solver, hipStream_t stream) {
-  if (solver == 1) hipLaunchKernelGGL(gq::step_kernel<1>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
-  else hipLaunchKernelGGL(gq::step_kernel<0>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
+extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, hipStream_t stream) {
+  if (solver == 1) hipLaunchKernelGGL(gq::step_kernel<1>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
+  else hipLaunchKernelGGL(gq::step_kernel<0>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
 }
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream) {
   hipLaunchKernelGGL(gq::reset_kernel, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);

@@ -264,6 +264,7 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     if (iter > 0 && scale * (oldcost - cost) < m.tolerance) break;
     if (iter >= m.iterations) break;
     oldcost = cost;
+    if (iter == 1) wave_priority<2>(); else if (iter == 3) wave_priority<3>(); /* wave-uniform */
     NW_T(1);
     /* ---- gradient = M dq - J' f  (lane = dof walks its column of J in LDS) */
     float gd = 0.0f, gterm = 0.0f;
@@ -364,6 +365,7 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     for (int k = 0; k < 7; k++) tdbg[16 + k] = (float)tacc[k];
 #undef NW_T
   niter = iter;
+  wave_priority<0>();
   wave_barrier();
   return f;
 }

@@ -35,7 +35,7 @@ __device__ inline Q4 stage_kinematics(WaveMem& W, const GqDevModel& m) {
     const V3 bp = ld3(m.body_pos[b]), jp = ld3(m.jnt_pos[j]), ax = ld3(m.jnt_axis[j]);
     float R0[9], R1[9], sn, cs;
     q2mat(R0, bq);
-    sincosf(0.5f * (W.qj[j] - m.qpos0[j]), &sn, &cs);
+    sincos_small(0.5f * (W.qj[j] - m.qpos0[j]), sn, cs);
     const Q4 qr = {cs, ax.x * sn, ax.y * sn, ax.z * sn};
     const Q4 ql = qmul(bq, qr);
     q2mat(R1, ql);
@@ -146,7 +146,7 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
  * (zero control, friction committed afterwards, termination flags of pass 0 are kept).  pass 2: the reset's own step of
  * a next-step auto-reset (as pass 1, flags cleared).  Returns `terminated`. */
 template <int SOLVER> /* 0: PGS (mj_solPGS), 1: Newton (mj_solNewton, MuJoCo's default) */
-__device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
+__device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
   int lane_o = lane_id(), env_o = (int)blockIdx.x;
@@ -154,9 +154,10 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   const int lane = lane_o, env = env_o;
   const GqDevModel& m = *a.model;
   const float h = m.timestep;
-  const bool timing = a.debug && pass == 0 && env < a.batch->debug_envs;
+  const bool timing = call.debug && pass == 0 && env < a.batch->debug_envs;
   const long long t_start = timing ? cycles() : 0;
-#define GQ_TICK(i) do { if (timing && lane == 0) a.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); } while (0)
+#define GQ_TICK(i) do { if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); \
+                        if (call.stop_stage == (i) && pass == 0) return 0; } while (0)
 
   /* ================================================================ S0: load the env's state rows */
   if (lane < 19) {
@@ -171,7 +172,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     W.warm[lane] = a.warm[(size_t)env * 18 + lane];
     W.applied[lane] = a.applied ? a.applied[(size_t)env * 18 + lane] : 0.0f;
   }
-  if (lane < 12) W.ctrl[lane] = (a.ctrl && pass == 0) ? a.ctrl[(size_t)env * 12 + lane] : 0.0f;
+  if (lane < 12) W.ctrl[lane] = (call.ctrl && pass == 0) ? call.ctrl[(size_t)env * 12 + lane] : 0.0f;
   if (lane < 4) W.cmd[lane] = a.cmd ? a.cmd[(size_t)env * 4 + lane] : 0.0f;
   const float mu_env = a.friction ? a.friction[env] : -1.0f;
   wave_barrier();
@@ -401,7 +402,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   wave_barrier();
   const int nefc = W.nefc, ncon = W.ncon, nlim = W.nlim, nfl = m.nfl;
   if (timing) { /* body poses go to the debug record now: xmat's LDS is reused by the Newton solver */
-    float* D = a.debug + (size_t)env * GQ_DBG_SIZE;
+    float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
     if (lane < 39) D[GQ_DBG_XPOS + lane] = W.xpos[lane / 3][lane % 3];
     for (int k = lane; k < 117; k += GQ_WAVE) D[GQ_DBG_XMAT + k] = W.xmat[k / 9][k % 9];
   }
@@ -492,7 +493,7 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     solve_tree_one(W, W.F[0], W.smooth, W.qacc_smooth);
     GQ_TICK(8);
     const float fN = newton_solve(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
-                                  timing ? a.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr);
+                                  timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr);
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
@@ -627,8 +628,8 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   wave_barrier();
 
   }
-  if (a.debug && pass == 0 && env < a.batch->debug_envs) {
-    float* D = a.debug + (size_t)env * GQ_DBG_SIZE;
+  if (call.debug && pass == 0 && env < a.batch->debug_envs) {
+    float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
     for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = m_entry(W, k / 18, k % 18);
     if (lane < 18) {
       D[GQ_DBG_BIAS + lane] = W.bias[lane]; D[GQ_DBG_SMOOTH + lane] = W.smooth[lane];
@@ -694,7 +695,9 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
     /* mju_quatIntegrate starts from the raw (un-normalised) qpos quaternion; it was normalised above, the
      * difference is removed by the normalisation that follows */
     if (n > 1e-15f) {
-      float ang = h * n, s = sinf(0.5f * ang) / n, c = cosf(0.5f * ang);
+      float ang = h * n, s, c;
+      sincos_small(0.5f * ang, s, c);
+      s /= n;
       Q4 qr = {c, w.x * s, w.y * s, w.z * s};
       qn = qmul(qbase, qr);
     }
@@ -719,10 +722,13 @@ __device__ inline int step_wave(const StepArgs& a, WaveMem& W, const int pass) {
   q2mat(Rn, qn);
   /* scipy as_euler('xyz') of the new orientation */
   float sy = fminf(fmaxf(-Rn[6], -1.0f), 1.0f);
-  float e0, e1 = asinf(sy), e2;
-  if (fabsf(sy) < 0.9999999f) { e0 = atan2f(Rn[7], Rn[8]); e2 = atan2f(Rn[3], Rn[0]); }
-  else { e0 = 0.0f; e2 = atan2f(-Rn[1], Rn[4]); }
-  const float cyaw = cosf(e2), syaw = sinf(e2);
+  float e0, e1 = asinf(sy), e2, cyaw, syaw;
+  if (fabsf(sy) < 0.9999999f) { e0 = atan2f(Rn[7], Rn[8]); e2 = atan2f(Rn[3], Rn[0]); syaw = Rn[3]; cyaw = Rn[0]; }
+  else { e0 = 0.0f; e2 = atan2f(-Rn[1], Rn[4]); syaw = -Rn[1]; cyaw = Rn[4]; }
+  { /* cos / sin of the yaw angle straight from the atan2 arguments */
+    const float hyp2 = syaw * syaw + cyaw * cyaw, inv = hyp2 > 0.0f ? fast_rsqrt(hyp2) : 0.0f;
+    syaw *= inv; cyaw = hyp2 > 0.0f ? cyaw * inv : 1.0f;
+  }
   V3 cmdl = v3(W.cmd[0], W.cmd[1], W.cmd[2]);
   V3 tl = v3(cyaw * cmdl.x - syaw * cmdl.y, syaw * cmdl.x + cyaw * cmdl.y, cmdl.z);
   V3 ta = v3(0.0f, 0.0f, W.cmd[3]);
@@ -985,11 +991,9 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
 }
 
 
-struct FusedArgs {
+struct FusedArgs {      /* device-resident argument block of step_kernel */
   StepArgs s;
-  ResetArgs r;          /* used when auto_reset != 0 */
-  int32_t auto_reset;   /* 0 off, 1 same-step (second pass in this launch), 2 next-step (pending flag, one pass per launch) */
-  int32_t first_pass;   /* 0: user step; 1: the reset's own step (gq_reset) */
+  ResetArgs r;          /* used when StepCall.auto_reset != 0 */
 };
 
 }  // namespace gq

@@ -28,11 +28,14 @@
 
 namespace gq {
 
+/* StepArgs lives in DEVICE memory (one block per batch, re-uploaded only when a pointer changes): the kernel reads the
+ * pointers where it uses them (scalar loads).  Passed by value, the ~60 pointers of a fused step + reset were preloaded
+ * into SGPRs at kernel entry and immediately spilled lane-by-lane into VGPRs (v_writelane / v_readlane: ~10 % of the
+ * kernel's VALU issue slots).  What changes from call to call travels by value in StepCall. */
 struct StepArgs {
   const GqDevModel* model;
   const GqDevBatch* batch;
   const float* vx; const float* vy; const float* vz; /* cloud vertices SoA */
-  const float* ctrl; const uint8_t* mask;
   double* qpos; float* qvel; float* qacc; float* warm; const float* applied; float* time; const float* friction;
   const float* cmd;
   float* imu_bias;        /* [N][6] accelerometer / gyro bias random walks (in/out), NULL = no IMU */
@@ -40,9 +43,15 @@ struct StepArgs {
   float* friction_next;   /* library scratch [N]: friction drawn at reset, committed after the reset's own step (:403-404) */
   uint8_t* pending;       /* library scratch [N]: env terminated and waits for its next-step auto-reset (may be NULL) */
   float* obs; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* invalid_contact; int32_t* step_num;
-  float* debug;
   int32_t n_envs;
-  int32_t forward_only; /* 1: stop after the position stage bookkeeping (unused by step) */
+};
+struct StepCall {
+  const float* ctrl;    /* [N][nu] or NULL (zero control) */
+  const uint8_t* mask;  /* [N] or NULL */
+  float* debug;         /* debug record block or NULL */
+  int32_t auto_reset;   /* 0 off, 1 same-step (second pass in this launch), 2 next-step (pending flag, one pass per launch) */
+  int32_t first_pass;   /* 0: user step; 1: the reset's own step (gq_reset) */
+  int32_t stop_stage;   /* profiling aid (env GQ_STOP_STAGE, tools/stage_insts.sh): return after stage marker i; 0 = run everything */
 };
 
 /* canonical ALL_OBS scalar offsets (order of QuadrupedEnv.ALL_OBS, quadruped_env.py:35-66,81) */
@@ -131,10 +140,25 @@ __device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
           a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
   return r;
 }
+/* sin and cos of a moderate angle (joint half-angles, integration increments, yaw: |x| well below 1e3 rad): two-term
+ * Cody-Waite reduction to [-pi/4, pi/4] and the classic single-precision minimax kernels, ~30 VALU for both values
+ * and 1-2 ulp - the libm routines carry a large-argument reduction that is never needed here */
+__device__ __forceinline__ void sincos_small(float x, float& s, float& c) {
+  const float kf = rintf(x * 0.636619772367581343f);
+  float r = fmaf(-kf, 1.5707962512969970703125f, x);   /* pi/2 split: high 24 bits + remainder */
+  r = fmaf(-kf, 7.54978995489188e-08f, r);
+  const float z = r * r;
+  const float sp = r + r * z * (-0.166666666416265235595f + z * (0.0083333293858894631756f + z * (-0.000198393348360966317347f + z * 0.0000027183114939898219064f)));
+  const float cp = 1.0f + z * (-0.499999997251031003120f + z * (0.0416666233237390631894f + z * (-0.00138867637746099294692f + z * 0.0000243904487962774090654f)));
+  const int q = (int)kf & 3;
+  const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
 __device__ __forceinline__ Q4 qnormalize(Q4 q) {
   float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
   if (n2 < 1e-30f) { Q4 i = {1, 0, 0, 0}; return i; }
-  float s = 1.0f / sqrtf(n2);
+  float s = fast_rsqrt(n2);
   Q4 r = {q.w * s, q.x * s, q.y * s, q.z * s};
   return r;
 }
@@ -199,6 +223,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   if (x <= 0.0f) return dmin;
   float y;
   if (power == 1.0f) y = x;
+  else if (power == 2.0f) y = x <= mid ? x * x / mid : 1.0f - (1.0f - x) * (1.0f - x) / (1.0f - mid); /* MuJoCo's default */
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.0f);
   else y = 1.0f - powf(1.0f - x, power) / powf(1.0f - mid, power - 1.0f);
   return dmin + y * (dmax - dmin);

@@ -437,7 +437,7 @@ class QuadrupedEnv:
 
     def state_dict(self):
         """Checkpoint: everything needed to resume a rollout bit-for-bit."""
-        keys = ['_qpos', '_qvel', '_qacc', '_warm', '_applied', '_time', '_friction', '_cmd', '_step_num', '_episode',
+        keys = ['_qpos', '_qvel', '_qacc', '_warm', '_applied', '_time', '_friction', '_cmd', '_step_num', '_episode', '_terminated',
                 '_steps_after_vel', '_steps_before_vel', '_steps_after_dist', '_steps_before_dist', '_ext_dist']
         d = {k: getattr(self, k).clone() for k in keys}
         d['rng'] = self._gen.get_state()
@@ -451,6 +451,9 @@ class QuadrupedEnv:
                 self._ext_dist = v.to(self.device).clone()
             else:
                 getattr(self, k).copy_(v)
+        if '_terminated' in d:  # next-step auto-reset: the envs that terminated last step are still waiting for their reset
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._L.gq_batch_set_pending(self._hbatch, self._terminated.data_ptr(), stream), 'gq_batch_set_pending')
 
     def debug_internals(self, n_envs: int, names):
         """Copy solver / dynamics internals of the LAST step for the first ``n_envs`` envs (must be enabled before

@@ -260,6 +260,11 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
 int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new, const GqResetCfg* cfg,
              GqState st, GqObsOut out, int32_t* episode, uint8_t* lift_failed, void* hip_stream);
 
+/* Checkpoint resume of a next-step auto-reset rollout: overwrite the batch's pending-reset flags with `flags` (device
+ * [N] u8; they always equal the `terminated` row of the last gq_step) or clear them (flags NULL).  No reference
+ * counterpart - the reference has no auto-reset. */
+int gq_batch_set_pending(GqBatch* b, const uint8_t* flags, void* hip_stream);
+
 /* HeightMap.create_sensor_matrix (sensors/heightmap.py:106-169) for every env: rows x cols downward rays
  * (mujoco.mj_ray, heightmap.py:90-99, static geoms only) from the grid centred above `center` and rotated by `yaw`
  * into the heading frame; ray origin z = center.z + 0.6 - 0.07.  center: device [N][3] f64, yaw: device [N] f32,

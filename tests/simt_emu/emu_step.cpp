@@ -37,11 +37,13 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
   gq::FusedArgs f{};
   gq::StepArgs& a = f.s;
   a.model = &M; a.batch = &B; a.vx = vx.data(); a.vy = vy.data(); a.vz = vz.data();
-  a.ctrl = ctrl; a.mask = mask; a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied;
+  a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied;
   a.time = time; a.friction = friction; a.cmd = cmd; a.friction_next = friction_next; a.pending = pending; a.obs = obs; a.reward = reward;
   a.terminated = terminated; a.truncated = truncated; a.invalid_contact = invalid_contact; a.step_num = step_num;
-  a.debug = debug; a.n_envs = n_envs; a.imu_bias = imu ? imu_bias : nullptr; a.episode_ro = episode;
-  f.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; f.first_pass = first_pass;
+  a.n_envs = n_envs; a.imu_bias = imu ? imu_bias : nullptr; a.episode_ro = episode;
+  gq::StepCall call{};
+  call.ctrl = ctrl; call.mask = mask; call.debug = debug;
+  call.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; call.first_pass = first_pass;
   if (auto_reset) {
     gq::ResetArgs& r = f.r;
     r.model = &M; r.vx = vx.data(); r.vy = vy.data(); r.vz = vz.data();
@@ -53,15 +55,15 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
     if (mask && !mask[e]) continue;
     emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
       __shared__ gq::WaveMem W;
-      int pass = f.first_pass;
-      bool respawn = f.auto_reset == 2 && f.s.pending[e];
+      int pass = call.first_pass;
+      bool respawn = call.auto_reset == 2 && f.s.pending[e];
       for (;;) {
         if (respawn) {
           gq::reset_wave(f.r, W);
-          pass = f.auto_reset;
+          pass = call.auto_reset;
         }
-        const int term = M.solver == 1 ? gq::step_wave<1>(f.s, W, pass) : gq::step_wave<0>(f.s, W, pass);
-        if (pass != 0 || f.auto_reset != 1 || !term) break;
+        const int term = M.solver == 1 ? gq::step_wave<1>(f.s, call, W, pass) : gq::step_wave<0>(f.s, call, W, pass);
+        if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
       }
     });

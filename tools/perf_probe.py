@@ -55,6 +55,16 @@ def stage_times(n=4096, iters=100, tol=1e-8, solver='newton'):
         dt = T[:, k] - prev; prev = T[:, k]
         print(f'  {nm:10s} {dt.mean():9.0f} {np.percentile(dt,95):9.0f} {dt.max():9.0f}')
     print(f'  total      {T[:,13].mean():9.0f} {np.percentile(T[:,13],95):9.0f} {T[:,13].max():9.0f}')
+    top = np.argsort(-T[:, 13])[:10]
+    print('  slowest waves (env: total | per-stage ... | niter nefc):')
+    for e in top:
+        prev = 0.0; parts = []
+        for k in order:
+            parts.append(T[e, k] - prev); prev = T[e, k]
+        print(f'   env {e:5d}: {T[e,13]:8.0f} | ' + ' '.join(f'{x:6.0f}' for x in parts) + f' | niter {nit[e]:.0f} nefc {ne[e]:.0f}')
+    h, edges = np.histogram(T[:, 13], bins=12)
+    print('  histogram of totals:', ' '.join(f'{int(lo/1000)}k:{c}' for lo, c in zip(edges[:-1], h)))
+    hn = np.bincount(nit.astype(int)); print('  niter histogram:', hn.tolist())
     if solver == 'newton':
         for nm, k in zip(['warm', 'state+cost', 'gradient', 'hessian', 'factor', 'solve', 'linesearch'], range(16, 23)):
             print(f'    newton {nm:11s} {T[:, k].mean():9.0f} {np.percentile(T[:, k], 95):9.0f} {T[:, k].max():9.0f}   per-iter {T[:, k].sum() / max(1, nit.sum()):7.0f}')
