@@ -75,6 +75,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 /* optimisation barrier: the value becomes opaque to the compiler (no code is emitted) */
 __device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
+template <class T> __device__ __forceinline__ const T* opaque_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; } /* per-lane pointer */
 __device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); } /* wave-uniform value */
 
 /* shader clock (s_memtime) for the stage timers of the debug record */
@@ -82,12 +83,6 @@ __device__ __forceinline__ long long cycles() { return (long long)__builtin_read
 
 /* instruction-scheduling fence: nothing moves across it */
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-
-/* issue priority of this wave among the waves of its SIMD (s_setprio 0..3).  The launch lasts as long as its slowest
- * wave, so a wave that finds out it has a lot of work left (many constraint rows, a Newton solve that needs more
- * iterations) raises its priority and stops sharing issue slots evenly with neighbours that will finish early anyway. */
-template <int P>
-__device__ __forceinline__ void wave_priority() { __builtin_amdgcn_s_setprio(P); }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }

@@ -195,6 +195,12 @@ __device__ __forceinline__ float row_law(int rtype, float y, float R, float D, f
   return f;
 }
 
+/* which piece of its piecewise-quadratic cost a row is on at residual y */
+__device__ __forceinline__ int row_piece(int rtype, float y, float R, float floss) {
+  if (rtype == ROW_FRICTION) return y <= -R * floss ? 0 : (y >= R * floss ? 2 : 1);
+  return (rtype != ROW_NONE && y < 0.0f) ? 1 : 0;
+}
+
 /* derivative pieces of one row along the search direction (first and second derivative of s_i(y + alpha*v)) */
 __device__ __forceinline__ void row_dd(int rtype, float y, float v, float R, float D, float floss, float& d1, float& d2) {
   d1 = 0.0f; d2 = 0.0f;
@@ -209,11 +215,14 @@ __device__ __forceinline__ void row_dd(int rtype, float y, float v, float R, flo
 
 /* Newton iterations.  In: row data in registers, qacc_smooth / warm / Mc / Mb in LDS, J rows in W.u.B.
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
+template <bool DBG>
 __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype, float rR, float raref,
                                      float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg) {
   const int lane = lane_id();
   /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */
-  const float* J = W.u.B[lane];
+  /* (each use goes through opaque_ptr: otherwise the compiler merges the re-reads, keeps the 18 values live across the
+   * whole solve and spills them to scratch - the opposite of the intent) */
+#define J (opaque_ptr(W.u.B[lane]))
   const float rD = 1.0f / rR;
   const float scale = 1.0f / (m.meaninertia * 18.0f);
   float* dq = W.qacc_int;       /* scratch 18-vectors: free until S10 */
@@ -242,8 +251,32 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
   }
   float f = 0.0f, oldcost = 0.0f;
   int iter = 0;
-  long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = tdbg ? cycles() : 0;
-#define NW_T(i) do { if (tdbg) { const long long tn = cycles(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+  const int fl_row = lane < GQ_NVD ? m.fl_row_of_dof[lane] : -1;
+  /* the two Hessian entries this lane assembles every iteration (pass 0: entry lane, pass 1: entry 64 + lane), packed
+   * da | db << 8 | slot << 16; -1: none.  Leg rows: hip 7, thigh 8, calf 9 entries -> 24 per leg (slots of Hc);
+   * entries 96..116: lower triangle of the base block (slot 108 + 6 da + db). */
+  int hent[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int e = pass * 64 + lane;
+    int da = 0, db = 0, slot = 0;
+    if (e < 96) {
+      const int leg = e / 24, q = e % 24;
+      const int dep = q < 7 ? 0 : (q < 15 ? 1 : 2), col = q - (dep == 0 ? 0 : (dep == 1 ? 7 : 15));
+      const int j = 3 * leg + dep;
+      da = 6 + j; db = col < 6 ? col : 6 + 3 * leg + (col - 6);
+      slot = j * 9 + col;
+    } else {
+      const int q = e - 96;
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= q) i++;
+      da = i; db = q - i * (i + 1) / 2;
+      slot = 108 + 6 * da + db;
+    }
+    hent[pass] = e < 117 ? (da | (db << 8) | (slot << 16)) : -1;
+  }
+  long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = (DBG && tdbg) ? cycles() : 0;
+#define NW_T(i) do { if constexpr (DBG) if (tdbg) { const long long tn = cycles(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
   NW_T(0);
   /* residual y = J qacc - aref and Ma-terms are evaluated once, then advanced incrementally along the search
    * direction (y += alpha J s, M dq += alpha M s), as mj_solNewton does */
@@ -264,13 +297,13 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     if (iter > 0 && scale * (oldcost - cost) < m.tolerance) break;
     if (iter >= m.iterations) break;
     oldcost = cost;
-    if (iter == 1) wave_priority<2>(); else if (iter == 3) wave_priority<3>(); /* wave-uniform */
     NW_T(1);
     /* ---- gradient = M dq - J' f  (lane = dof walks its column of J in LDS) */
     float gd = 0.0f, gterm = 0.0f;
     if (lane < GQ_NVD) {
-      float s0 = 0.0f, s1 = 0.0f;
-      int r = 0;
+      /* friction-loss rows are e_dof: their force lands on one dof, only limit / contact rows are walked */
+      float s0 = fl_row >= 0 ? W.force[fl_row] : 0.0f, s1 = 0.0f;
+      int r = nfl;
       for (; r + 2 <= nefc; r += 2) { s0 += W.u.B[r][lane] * W.force[r]; s1 += W.u.B[r + 1][lane] * W.force[r + 1]; }
       if (r < nefc) s0 += W.u.B[r][lane] * W.force[r];
       gd = md - (s0 + s1);
@@ -291,22 +324,8 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
      * rows (few) and contact rows are walked generically. */
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-      const int e = pass * 64 + lane;
-      if (e < 117) {
-        int da, db, slot;            /* dof pair (da >= db) and the slot in Hc (0..107) or Hb (108 + 6*i + j) */
-        if (e < 96) {                /* leg rows: hip 7, thigh 8, calf 9 entries -> 24 per leg */
-          const int leg = e / 24, q = e % 24;
-          const int dep = q < 7 ? 0 : (q < 15 ? 1 : 2), col = q - (dep == 0 ? 0 : (dep == 1 ? 7 : 15));
-          const int j = 3 * leg + dep;
-          da = 6 + j; db = col < 6 ? col : 6 + 3 * leg + (col - 6);
-          slot = j * 9 + col;
-        } else {                     /* base block, lower triangle */
-          const int q = e - 96;
-          int i = 0;
-          while ((i + 1) * (i + 2) / 2 <= q) i++;
-          da = i; db = q - i * (i + 1) / 2;
-          slot = 108 + 6 * da + db;
-        }
+      if (hent[pass] >= 0) {
+        const int da = hent[pass] & 0xff, db = (hent[pass] >> 8) & 0xff, slot = hent[pass] >> 16;
         float s0 = slot < 108 ? W.Mc[slot / 9][slot % 9] : W.Mb[da][db], s1 = 0.0f;
         if (da == db) {
           const int fr = m.fl_row_of_dof[da];
@@ -339,6 +358,7 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     const float q1 = wave_sum(lane < GQ_NVD ? search[lane] * md : 0.0f);
     const float q2 = wave_sum(lane < GQ_NVD ? 0.5f * search[lane] * ms : 0.0f);
     float alpha = 0.0f, lo = 0.0f, hi = -1.0f; /* hi < 0: no upper bracket yet */
+    bool first_try = false;
     float d1, d2;
     row_dd(rtype, y, v, rR, rD, rfloss, d1, d2);
     const float g0 = q1 + wave_sum(d1);
@@ -349,7 +369,7 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
       row_dd(rtype, y + alpha * v, v, rR, rD, rfloss, d1, d2);
       const float ga = q1 + 2.0f * q2 * alpha + wave_sum(d1);
       const float ha = 2.0f * q2 + wave_sum(d2);
-      if (fabsf(ga) <= 1e-3f * fabsf(g0)) break; /* MuJoCo's line search is approximate too (ls_tolerance 0.01) */
+      if (fabsf(ga) <= 1e-3f * fabsf(g0)) { first_try = ls == 0; break; } /* MuJoCo's line search is approximate too (ls_tolerance 0.01) */
       if (ga < 0.0f) lo = alpha; else hi = alpha;
       float an = alpha - ga / ha;
       if (!(an > lo) || (hi > 0.0f && !(an < hi))) an = hi > 0.0f ? 0.5f * (lo + hi) : 2.0f * alpha;
@@ -357,15 +377,27 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     }
     wave_barrier();
     if (lane < GQ_NVD) { W.qacc[lane] += alpha * search[lane]; dqv += alpha * search[lane]; md += alpha * ms; }
-    y += alpha * v;
+    const float ynew = y + alpha * v;
+    /* the cost is piecewise quadratic.  A full Newton step (accepted at the first trial) that leaves every row on the
+     * piece it was linearised on has reached the minimiser of a model that IS the cost there: converged, and the
+     * usual extra iteration that only re-evaluates cost and gradient to find that out is skipped */
+    const bool moved = row_piece(rtype, y, rR, rfloss) != row_piece(rtype, ynew, rR, rfloss);
+    y = ynew;
     wave_barrier();
     NW_T(6);
+    if (first_try && ballot(moved) == 0) {
+      float ci, wact;
+      f = row_law(rtype, y, rR, rD, rfloss, ci, wact);
+      if (lane < GQ_NVD) Mdq[lane] = md;
+      iter++;
+      break;
+    }
   }
-  if (tdbg && lane == 0)
+  if constexpr (DBG) if (tdbg && lane == 0)
     for (int k = 0; k < 7; k++) tdbg[16 + k] = (float)tacc[k];
 #undef NW_T
+#undef J
   niter = iter;
-  wave_priority<0>();
   wave_barrier();
   return f;
 }

@@ -145,7 +145,10 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
 /* One mj_step + observation epilogue for this wave's env.  pass 0: the user's step.  pass 1: the reset's own step
  * (zero control, friction committed afterwards, termination flags of pass 0 are kept).  pass 2: the reset's own step of
  * a next-step auto-reset (as pass 1, flags cleared).  Returns `terminated`. */
-template <int SOLVER> /* 0: PGS (mj_solPGS), 1: Newton (mj_solNewton, MuJoCo's default) */
+/* SOLVER 0: PGS (mj_solPGS), 1: Newton (mj_solNewton, MuJoCo's default).  DBG: the variant with the debug record, the
+ * stage timers and the GQ_STOP_STAGE cut compiled in - the production variant carries none of it (no timer
+ * accumulators or row data kept live for the record: they cost registers inside the solver loop). */
+template <int SOLVER, bool DBG>
 __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
@@ -154,10 +157,11 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   const int lane = lane_o, env = env_o;
   const GqDevModel& m = *a.model;
   const float h = m.timestep;
-  const bool timing = call.debug && pass == 0 && env < a.batch->debug_envs;
+  const bool timing = DBG && call.debug && pass == 0 && env < a.batch->debug_envs;
   const long long t_start = timing ? cycles() : 0;
-#define GQ_TICK(i) do { if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); \
-                        if (call.stop_stage == (i) && pass == 0) return 0; } while (0)
+#define GQ_TICK(i) do { if constexpr (DBG) { \
+    if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); \
+    if (call.stop_stage == (i) && pass == 0) return 0; } } while (0)
 
   /* ================================================================ S0: load the env's state rows */
   if (lane < 19) {
@@ -492,7 +496,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
     solve_tree_one(W, W.F[0], W.smooth, W.qacc_smooth);
     GQ_TICK(8);
-    const float fN = newton_solve(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
+    const float fN = newton_solve<DBG>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
                                   timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr);
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
@@ -628,7 +632,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   wave_barrier();
 
   }
-  if (call.debug && pass == 0 && env < a.batch->debug_envs) {
+  if constexpr (DBG) if (call.debug && pass == 0 && env < a.batch->debug_envs) {
     float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
     for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = m_entry(W, k / 18, k % 18);
     if (lane < 18) {

@@ -54,8 +54,8 @@ static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 static inline void opaque(int&) {}
 static inline void opaque_s(int&) {}
+template <class T> static inline const T* opaque_ptr(const T* p) { return p; }
 static inline void sched_fence() {}
-template <int P> static inline void wave_priority() {}
 static inline long long cycles() { return 0; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
