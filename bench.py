@@ -2,8 +2,9 @@
 
 Workload (BASELINE.json configs[1]): mini_cheetah on the flat scene, 4096 envs per GPU, random-action rollout
 (50 * N(0,1) torques, what the reference's ``action_space.sample() * 50`` produces), ALL_OBS observations (227
-scalars), masked auto-reset on termination, sim_dt = 0.002, PGS with MuJoCo's default iteration cap / tolerance
-(100 / 1e-8).  One "step" = one ``env.step(action)`` over the whole batch, exactly what the reference's ``step``
+scalars), auto-reset on termination (gymnasium NEXT_STEP convention by default: a terminated env spends its next step
+slot on reset() and its mj_step; --auto-reset same_step re-spawns inside the terminating launch), sim_dt = 0.002,
+MuJoCo's default Newton solver with its default iteration cap / tolerance (100 / 1e-8); --solver pgs selects PGS.  One "step" = one ``env.step(action)`` over the whole batch, exactly what the reference's ``step``
 does for one env: mj_step + observation/termination assembly.
 
     python bench.py --gpus N --steps K --warmup W

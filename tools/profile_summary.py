@@ -42,8 +42,36 @@ def pmc(dirs, out_md, n_envs, bytes_per_env):
                     f'= {(2*rd+wr)/alg:.2f}x algorithmic.\n')
             print(json.dumps({'traffic_bytes_per_launch': 2 * rd + wr, 'fetch': rd, 'write': wr}))
 
+def sq(dirs, out_md, n_envs):
+    """Instruction-mix / occupancy counters of gq::step_kernel (SQ_* groups), normalised per wave (= per env-step)."""
+    tot = {}
+    for d in dirs:
+        for fn in glob.glob(f'{d}/**/*counter_collection.csv', recursive=True):
+            acc = {}
+            for row in csv.DictReader(open(fn)):
+                if 'step_kernel' not in row.get('Kernel_Name', ''): continue
+                acc.setdefault(row['Counter_Name'], []).append(float(row['Counter_Value']))
+            for k, v in acc.items():
+                if k.startswith('SQ_'):
+                    tot[k] = (sum(v) / len(v), len(v))
+    with open(out_md, 'w') as f:
+        f.write('# SQ counters of gq::step_kernel (rocprofv3 --pmc, four counters per pass, no trace domains besides --kernel-trace)\n\n')
+        f.write(f'{n_envs} waves per launch (one env per wavefront).  *_CYCLES / ACTIVE / WAIT counters are in quad-cycles (x4 = shader cycles).\n\n')
+        f.write('| counter | mean per launch | per wave | launches |\n|---|---|---|---|\n')
+        for k in sorted(tot):
+            m, n = tot[k]
+            f.write(f'| {k} | {m:.0f} | {m / n_envs:.1f} | {n} |\n')
+        g = lambda k: tot.get(k, (0, 0))[0]
+        if g('SQ_WAVE_CYCLES'):
+            f.write(f'\nper wave: {g("SQ_INSTS_VALU")/n_envs:.0f} VALU, {g("SQ_INSTS_SALU")/n_envs:.0f} SALU, {g("SQ_INSTS_LDS")/n_envs:.0f} LDS, '
+                    f'{(g("SQ_INSTS_VMEM_RD")+g("SQ_INSTS_VMEM_WR"))/n_envs:.0f} VMEM instructions over {4*g("SQ_WAVE_CYCLES")/n_envs:.0f} cycles of wave lifetime; '
+                    f'VALU busy {g("SQ_ACTIVE_INST_VALU")/g("SQ_WAVE_CYCLES")*100:.0f} % of a wave\'s lifetime (x4 resident waves per SIMD), '
+                    f'waiting on any instruction {g("SQ_WAIT_INST_ANY")/g("SQ_WAVE_CYCLES")*100:.0f} %, on LDS {g("SQ_WAIT_INST_LDS")/g("SQ_WAVE_CYCLES")*100:.0f} %.\n')
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'sq':
+        sq(sys.argv[2].split(','), sys.argv[3], int(sys.argv[4]))
+    elif sys.argv[1] == 'stats':
         kernel_stats(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
     else:
         pmc(sys.argv[2].split(','), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]))
