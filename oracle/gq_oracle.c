@@ -44,6 +44,7 @@
 #define NEFC 512
 #define MINVAL 1e-15
 #define MINIMP 0.0001
+#define MINMU 1e-5
 #define MAXIMP 0.9999
 
 enum { EFC_FRICTION_DOF = 0, EFC_LIMIT_JOINT = 1, EFC_CONTACT_FRICTIONLESS = 2, EFC_CONTACT_PYRAMIDAL = 3,
@@ -434,6 +435,7 @@ static void contact_param(const GqOracle* o, int g, Contact* c) {
     memcpy(c->solimp, floor_wins ? m->floor_solimp : m->geom_solimp + 5 * g, sizeof c->solimp);
   }
   c->friction[0] = c->friction[1] = fri[0]; c->friction[2] = fri[1]; c->friction[3] = c->friction[4] = fri[2];
+  for (int k = 0; k < 5; k++) c->friction[k] = fmax(MINMU, c->friction[k]); /* mjMINMU */
   double margin = m->floor_margin > m->geom_margin[g] ? m->floor_margin : m->geom_margin[g];
   double gap = m->floor_gap > m->geom_gap[g] ? m->floor_gap : m->geom_gap[g];
   c->includemargin = margin - gap;
@@ -540,6 +542,13 @@ static void gqo_make_constraint(GqOracle* o) {
     if (con->dim == 1) {
       int r = add_row(o, EFC_CONTACT_FRICTIONLESS, c, con->dist, con->includemargin, 0, con->solref, con->solimp, tran);
       memcpy(o->efc_J[r], Jc[0], sizeof Jc[0]);
+    } else if (m->cone == 1) { /* elliptic: one row per contact-space dimension [n, t1, t2, torsion, roll1, roll2]; only
+                                 * the normal row carries the penetration (pos, margin), friction rows have pos = 0 */
+      for (int k = 0; k < con->dim; k++) {
+        int r = add_row(o, EFC_CONTACT_ELLIPTIC, c, k == 0 ? con->dist : 0, k == 0 ? con->includemargin : 0, 0, con->solref,
+                        con->solimp, k < 3 ? tran : rot);
+        memcpy(o->efc_J[r], Jc[k], sizeof Jc[k]);
+      }
     } else { /* pyramidal: 2*(dim-1) edges  Jn +- mu_k * Jt_k */
       for (int k = 1; k < con->dim; k++)
         for (int s = 0; s < 2; s++) {
@@ -572,7 +581,12 @@ static void gqo_make_constraint(GqOracle* o) {
   /* friction-adjusted R of pyramid edges: Rpy = 2 mu^2 R(first edge) for every edge of the contact */
   for (int c = 0; c < o->ncon; c++) {
     Contact* con = &o->contact[c];
-    if (con->dim > 1) {
+    if (con->dim > 1 && m->cone == 1) { /* elliptic: R_j = R_n mu^2 / friction_j^2, so that in the scaled space
+                                          * (f_n/mu, f_j/friction_j) the regulariser is isotropic and the cone circular */
+      int a = con->efc_address;
+      for (int j = 1; j < con->dim; j++)
+        o->efc_R[a + j] = fmax(MINVAL, o->efc_R[a] * con->mu * con->mu / (con->friction[j - 1] * con->friction[j - 1]));
+    } else if (con->dim > 1) {
       int a = con->efc_address;
       double Rpy = 2 * con->mu * con->mu * o->efc_R[a];
       for (int e = 0; e < 2 * (con->dim - 1); e++) o->efc_R[a + e] = fmax(MINVAL, Rpy);
@@ -681,11 +695,63 @@ static void gqo_fwd_acceleration(GqOracle* o) {
 
 /* ------------------------------------------------------------------ constraint force law (mj_constraintUpdate):
  * force and cost of every row given jar = J*qacc - aref.  Returns the constraint cost. */
+/* Elliptic contact at residual z = jar[a..a+dim) (mj_constraintUpdate, mjCNSTR_CONTACT_ELLIPTIC).  With
+ * N = mu z_0, U_j = friction_j z_j, T = |U|:  top zone (N >= mu T): cost 0;  bottom zone (mu N + T <= 0): plain
+ * quadratic sum_j D_j z_j^2 / 2;  middle zone: Dm (N - mu T)^2 / 2 with Dm = D_0 / (mu^2 (1 + mu^2)) - the dual of
+ * projecting onto the (scaled, circular) friction cone.  Returns the zone (0 top, 1 bottom, 2 middle); grad = ds/dz;
+ * hess (dim x dim, row-major, may be NULL) = d2s/dz2. */
+static int elliptic_eval(const GqOracle* o, const Contact* con, const double* z, double* cost, double* grad, double* hess) {
+  const int dim = con->dim, a = con->efc_address;
+  const double mu = con->mu, *fri = con->friction;
+  double U[6], T = 0;
+  const double N = mu * z[0];
+  for (int j = 1; j < dim; j++) { U[j] = fri[j - 1] * z[j]; T += U[j] * U[j]; }
+  T = sqrt(T);
+  *cost = 0;
+  for (int j = 0; j < dim; j++) grad[j] = 0;
+  if (hess) memset(hess, 0, sizeof(double) * 36);
+  if (N >= mu * T || (T <= 0 && N >= 0)) return 0;
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    for (int j = 0; j < dim; j++) {
+      const double D = o->efc_D[a + j];
+      *cost += 0.5 * D * z[j] * z[j]; grad[j] = D * z[j];
+      if (hess) hess[6 * j + j] = D;
+    }
+    return 1;
+  }
+  const double Dm = o->efc_D[a] / (mu * mu * (1 + mu * mu)), q = N - mu * T;
+  *cost = 0.5 * Dm * q * q;
+  double g[6];
+  g[0] = mu;
+  for (int j = 1; j < dim; j++) g[j] = -mu * fri[j - 1] * U[j] / T;
+  for (int j = 0; j < dim; j++) grad[j] = Dm * q * g[j];
+  if (hess) {
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) hess[6 * i + j] = Dm * g[i] * g[j];
+    /* q * d2q/dz2, d2q = -mu d2T:  d2T_ij = f_i f_j (delta_ij - u_i u_j) / T */
+    for (int i = 1; i < dim; i++)
+      for (int j = 1; j < dim; j++) {
+        const double ui = U[i] / T, uj = U[j] / T;
+        hess[6 * i + j] += Dm * q * (-mu) * fri[i - 1] * fri[j - 1] * ((i == j ? 1.0 : 0.0) - ui * uj) / T;
+      }
+  }
+  return 2;
+}
+
 static double constraint_update(GqOracle* o, const double* jar, double* force, int* active) {
   double cost = 0;
   for (int i = 0; i < o->nefc; i++) {
     double R = o->efc_R[i], D = o->efc_D[i], x = jar[i];
     int act = 1;
+    if (o->efc_type[i] == EFC_CONTACT_ELLIPTIC) { /* whole contact at once; active[] holds the zone on every row */
+      const Contact* con = &o->contact[o->efc_id[i]];
+      double c, g[6];
+      const int zone = elliptic_eval(o, con, jar + i, &c, g, NULL);
+      cost += c;
+      for (int j = 0; j < con->dim; j++) { force[i + j] = -g[j]; if (active) active[i + j] = zone; }
+      i += con->dim - 1;
+      continue;
+    }
     if (o->efc_type[i] == EFC_FRICTION_DOF) {
       double f = o->efc_frictionloss[i];
       if (x <= -R * f) { force[i] = f; cost += -0.5 * R * f * f - f * x; act = 0; }
@@ -724,6 +790,32 @@ static double primal_cost(GqOracle* o, const double* qacc, double* force) {
   return cost + constraint_update(o, jar, force ? force : tmp, NULL);
 }
 
+/* phi'(alpha), phi''(alpha) of the total cost along the search direction (jar + alpha*jv per row) */
+static void line_derivs(const GqOracle* o, const double* jar, const double* jv, double alpha, double q1, double q2,
+                        double* d1, double* d2) {
+  double s1 = q1 + 2 * q2 * alpha, s2 = 2 * q2;
+  for (int r = 0; r < o->nefc; r++) {
+    const double x = jar[r] + alpha * jv[r], v = jv[r], D = o->efc_D[r], R = o->efc_R[r];
+    if (o->efc_type[r] == EFC_CONTACT_ELLIPTIC) {
+      const Contact* con = &o->contact[o->efc_id[r]];
+      double z[6], c, g[6], hs[36];
+      for (int j = 0; j < con->dim; j++) z[j] = jar[r + j] + alpha * jv[r + j];
+      elliptic_eval(o, con, z, &c, g, hs);
+      for (int a = 0; a < con->dim; a++) {
+        s1 += g[a] * jv[r + a];
+        for (int b = 0; b < con->dim; b++) s2 += jv[r + a] * hs[6 * a + b] * jv[r + b];
+      }
+      r += con->dim - 1;
+    } else if (o->efc_type[r] == EFC_FRICTION_DOF) {
+      const double f = o->efc_frictionloss[r];
+      if (x <= -R * f) s1 += -f * v;
+      else if (x >= R * f) s1 += f * v;
+      else { s1 += D * x * v; s2 += D * v * v; }
+    } else if (x < 0) { s1 += D * x * v; s2 += D * v * v; }
+  }
+  *d1 = s1; *d2 = s2;
+}
+
 static void gqo_sol_newton(GqOracle* o, int maxiter, double tol) {
   const int nefc = o->nefc;
   double qacc[NV], jar[NEFC], grad[NV], search[NV], jv[NEFC], Mv[NV], H[NV][NV];
@@ -753,13 +845,34 @@ static void gqo_sol_newton(GqOracle* o, int maxiter, double tol) {
     /* Hessian = M + J' diag(D active) J ; dense Cholesky */
     for (int i = 0; i < NV; i++)
       for (int j = 0; j < NV; j++) H[i][j] = o->M[i][j];
-    for (int r = 0; r < nefc; r++)
+    int has_cone = 0;
+    for (int r = 0; r < nefc; r++) {
+      if (o->efc_type[r] == EFC_CONTACT_ELLIPTIC) { /* dense dim x dim block: H += Jc' (d2s/dz2) Jc */
+        const Contact* con = &o->contact[o->efc_id[r]];
+        double c, g[6], hs[36];
+        const int zone = elliptic_eval(o, con, jar + r, &c, g, hs);
+        has_cone = 1;
+        if (zone != 0)
+          for (int a = 0; a < con->dim; a++)
+            for (int b = 0; b < con->dim; b++) {
+              const double w = hs[6 * a + b];
+              if (w != 0)
+                for (int i = 0; i < NV; i++) {
+                  const double t = o->efc_J[r + a][i] * w;
+                  if (t != 0)
+                    for (int j = 0; j < NV; j++) H[i][j] += t * o->efc_J[r + b][j];
+                }
+            }
+        r += con->dim - 1;
+        continue;
+      }
       if (active[r])
         for (int i = 0; i < NV; i++) {
           double a = o->efc_J[r][i] * o->efc_D[r];
           if (a != 0)
             for (int j = 0; j < NV; j++) H[i][j] += a * o->efc_J[r][j];
         }
+    }
     for (int j = 0; j < NV; j++) {
       for (int k = 0; k < j; k++)
         for (int i = j; i < NV; i++) H[i][j] -= H[i][k] * H[j][k];
@@ -793,6 +906,30 @@ static void gqo_sol_newton(GqOracle* o, int maxiter, double tol) {
       for (int k = 0; k < NV; k++) s += o->M[i][k] * (qacc[k] - o->qacc_smooth[k]);
       q1 += search[i] * s;
       q2 += 0.5 * search[i] * Mv[i];
+    }
+    if (has_cone) { /* elliptic contacts: phi is convex and C1 but not piecewise quadratic -> safeguarded Newton on phi' */
+      double lo = 0, hi = -1, alpha = 0, g0 = 0;
+      int ok = 0;
+      for (int it = 0; it < 200; it++) {
+        double d1, d2;
+        line_derivs(o, jar, jv, alpha, q1, q2, &d1, &d2);
+        if (it == 0) {
+          g0 = d1;
+          if (!(g0 < 0)) break; /* not a descent direction: converged */
+          ok = 1;
+          alpha = d2 > 0 ? -d1 / d2 : 1.0;
+          continue;
+        }
+        if (fabs(d1) <= 1e-13 * fabs(g0)) break;
+        if (d1 < 0) lo = alpha; else hi = alpha;
+        double an = d2 > 0 ? alpha - d1 / d2 : -1;
+        if (!(an > lo) || (hi > 0 && !(an < hi))) an = hi > 0 ? 0.5 * (lo + hi) : 2 * alpha;
+        if (hi > 0 && hi - lo <= 1e-15 * hi) { alpha = an; break; }
+        alpha = an;
+      }
+      if (!ok || alpha <= 0) break;
+      for (int i = 0; i < NV; i++) qacc[i] += alpha * search[i];
+      continue;
     }
     /* derivative phi'(a) = d1 + 2*d2*a, accumulate row pieces valid at a = 0+, then sweep breakpoints */
     static Breakpt bp[2 * NEFC];
@@ -919,7 +1056,7 @@ static void gqo_fwd_constraint(GqOracle* o) {
     o->solver_niter = 0;
     return;
   }
-  if (o->d.solver == 1) gqo_sol_newton(o, o->d.iterations, o->d.tolerance);
+  if (o->d.solver == 1 || o->d.cone == 1) gqo_sol_newton(o, o->d.iterations, o->d.tolerance); /* no elliptic PGS (needs the per-contact QCQP) */
   else gqo_sol_pgs(o, o->d.iterations, o->d.tolerance);
   memset(o->qfrc_constraint, 0, sizeof o->qfrc_constraint);
   for (int i = 0; i < o->nefc; i++)
@@ -1020,6 +1157,9 @@ int gqo_set_state(GqOracle* o, const double* qpos, const double* qvel, const dou
   return GQ_OK;
 }
 
+/* value of the primal objective mj_solNewton minimises, at an arbitrary qacc (after gqo_forward built the rows) */
+double gqo_primal_cost(GqOracle* o, const double* qacc) { return primal_cost(o, qacc, NULL); }
+
 int gqo_set_solver(GqOracle* o, int solver, int iterations, double tolerance) {
   o->d.solver = solver; o->d.iterations = iterations; o->d.tolerance = tolerance;
   return GQ_OK;
@@ -1031,6 +1171,7 @@ static void gqo_contact_force(const GqOracle* o, int c, double* out6) {
   memset(out6, 0, sizeof(double) * 6);
   const double* f = o->efc_force + con->efc_address;
   if (con->dim == 1) { out6[0] = f[0]; return; }
+  if (o->d.cone == 1) { for (int k = 0; k < con->dim; k++) out6[k] = f[k]; return; } /* elliptic: rows are the contact-space force */
   for (int e = 0; e < 2 * (con->dim - 1); e++) out6[0] += f[e];
   for (int k = 0; k < con->dim - 1; k++) out6[k + 1] = (f[2 * k] - f[2 * k + 1]) * con->friction[k];
 }
@@ -1071,6 +1212,10 @@ int gqo_get(const GqOracle* o, const char* name, double* out, int max_n) {
   if (!strcmp(name, "contact_dist")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].dist; return n; }
   if (!strcmp(name, "contact_tiegap")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].tiegap; return n; }
   if (!strcmp(name, "contact_geom")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].geom; return n; }
+  if (!strcmp(name, "contact_dim")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].dim; return n; }
+  if (!strcmp(name, "contact_mu")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].mu; return n; }
+  if (!strcmp(name, "contact_efc_address")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].efc_address; return n; }
+  if (!strcmp(name, "contact_friction")) { int n = 5 * o->ncon < max_n ? 5 * o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i / 5].friction[i % 5]; return n; }
   if (!strcmp(name, "contact_body")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].body; return n; }
   if (!strcmp(name, "contact_pos")) { int n = 3 * o->ncon < max_n ? 3 * o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i / 3].pos[i % 3]; return n; }
   if (!strcmp(name, "contact_frame")) { int n = 9 * o->ncon < max_n ? 9 * o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i / 9].frame[i % 9]; return n; }

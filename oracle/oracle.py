@@ -42,6 +42,8 @@ def lib():
         L.gqo_get_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gqo_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.gqo_set_imu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gqo_primal_cost.argtypes = [C.c_void_p, C.c_void_p]
+        L.gqo_primal_cost.restype = C.c_double
         L.gqo_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
@@ -79,6 +81,10 @@ class Oracle:
 
     def set_solver(self, solver, iterations=100, tolerance=1e-8):
         self.L.gqo_set_solver(self.h, int(solver), int(iterations), float(tolerance))
+
+    def primal_cost(self, qacc):
+        a = np.ascontiguousarray(qacc, dtype=np.float64)
+        return float(self.L.gqo_primal_cost(self.h, _p(a)))
 
     def forward(self, ctrl=None, stage=0):
         c = None if ctrl is None else np.ascontiguousarray(ctrl, dtype=np.float64)

@@ -6,7 +6,8 @@ from helpers import marshalled, random_states
 from gym_quadruped_amd.mjcf import mass_matrix_dense
 from oracle.oracle import Oracle
 
-ROBOTS = ['mini_cheetah', 'aliengo', 'hyqreal2', 'b2']
+ROBOTS = ['mini_cheetah', 'aliengo', 'hyqreal2', 'b2', 'go1', 'go2', 'hyqreal1', 'spot']
+ELLIPTIC = ['go1', 'go2', 'hyqreal1', 'spot']   # cone="elliptic" impratio=100; go1 / go2 / spot feet are condim 6
 
 
 def _state(md, rng, z=1.0):
@@ -77,7 +78,7 @@ def test_momentum_in_flight():
     np.testing.assert_allclose(p1 - p0, [0, 0, -md.total_mass * 9.81 * nstep * 0.002], atol=2e-2)
 
 
-@pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo'])
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo', 'go2', 'hyqreal1'])
 def test_static_stance_carries_the_weight(robot):
     mm = marshalled(robot, solver=1, iterations=100, tolerance=1e-10)
     md, o = mm.md, Oracle(mm)
@@ -135,3 +136,61 @@ def test_contact_forces_oppose_penetration_and_respect_friction_cone():
             mu = 0.7 if o.contact_geom[c] in [mm.md.geom_names.index(k) for k in ('FL', 'FR', 'RL', 'RR')] else 0.7
             assert abs(cf[c, 1]) <= mu * cf[c, 0] + 1e-7 and abs(cf[c, 2]) <= mu * cf[c, 0] + 1e-7
     assert n > 20
+
+
+@pytest.mark.parametrize('robot', ELLIPTIC)
+def test_elliptic_cone_solution_is_optimal_and_inside_the_cone(robot):
+    """Elliptic friction cones (mj_constraintUpdate, mjCNSTR_CONTACT_ELLIPTIC): the Newton iterate must (i) zero the
+    gradient M (qacc - qacc_smooth) - J' f, (ii) be a minimiser of the primal objective (no random perturbation lowers
+    it), (iii) give contact forces inside the elliptic cone f_n >= 0, sum_j (f_j / friction_j)^2 <= f_n^2 - the
+    cost's middle zone is exactly the dual of the projection onto that cone - and (iv) regularise the friction
+    dimensions with R_j = R_n mu^2 / friction_j^2, mu = friction_0 / sqrt(impratio)."""
+    mm = marshalled(robot, solver=1, iterations=200, tolerance=1e-14)
+    md, o = mm.md, Oracle(mm)
+    assert md.cone == 1
+    rng = np.random.default_rng(7)
+    qpos, qvel = random_states(md, 24, rng, z_range=(0.6 * mm.desc.key_qpos[2], 1.05 * mm.desc.key_qpos[2]))
+    ncon = nmiddle = 0
+    for e in range(24):
+        o.set_state(qpos[e], qvel[e] * 0.5, np.zeros(18), np.zeros(18), friction=0.6 if e % 2 else -1.0)
+        o.forward(rng.normal(0, 10, 12))
+        if o.ncon == 0:
+            continue
+        J, f, R = o.efc_J, o.efc_force, o.efc_R
+        grad = o.M @ (o.qacc - o.qacc_smooth) - J.T @ f
+        assert np.abs(grad).max() < 1e-6 * max(1.0, np.abs(J.T @ f).max())
+        c0 = o.primal_cost(o.qacc)
+        for _ in range(20):
+            d = rng.normal(size=18) * 10.0 ** rng.uniform(-4, -1)
+            assert o.primal_cost(o.qacc + d) >= c0 - 1e-9 * max(1.0, abs(c0))
+        dims, adr, fri, mu = o.get('contact_dim').astype(int), o.get('contact_efc_address').astype(int), o.get('contact_friction').reshape(-1, 5), o.get('contact_mu')
+        cf = o.contact_force
+        for c in range(o.ncon):
+            ncon += 1
+            a, dim = adr[c], dims[c]
+            if dim == 1:
+                continue
+            assert abs(mu[c] - fri[c, 0] / np.sqrt(md.impratio)) < 1e-15
+            np.testing.assert_allclose(R[a + 1:a + dim], R[a] * mu[c] ** 2 / fri[c, :dim - 1] ** 2, rtol=1e-12)
+            fn, ft = f[a], f[a + 1:a + dim]
+            np.testing.assert_allclose(cf[c, :dim], f[a:a + dim])           # mj_contactForce is the identity for elliptic rows
+            assert fn >= -1e-12
+            assert np.sqrt(np.sum((ft / fri[c, :dim - 1]) ** 2)) <= fn * (1 + 1e-9) + 1e-12
+            nmiddle += fn > 1e-9 and np.sqrt(np.sum((ft / fri[c, :dim - 1]) ** 2)) > fn * (1 - 1e-6)   # on the cone surface: sliding
+    assert ncon >= 10 and nmiddle >= 1
+
+
+def test_elliptic_stance_weight_and_cone_at_rest():
+    """hyqreal1 (elliptic, condim 3) dropped on its feet and left to settle: the floor carries the weight and every
+    contact force stays inside its cone (the unactuated legs splay, so the tangential forces are large)."""
+    mm_e = marshalled('hyqreal1', solver=1, iterations=200, tolerance=1e-12)
+    oe = Oracle(mm_e)
+    oe.set_state(mm_e.md.key_qpos[0].copy(), np.zeros(18), np.zeros(18), np.zeros(18))
+    for _ in range(3000):
+        oe.step(np.zeros(12))
+    fz = oe.contact_force[:, 0].sum()
+    assert abs(fz - mm_e.md.total_mass * 9.81) < 0.05 * mm_e.md.total_mass * 9.81
+    fri = oe.get('contact_friction').reshape(-1, 5)
+    cf = oe.contact_force
+    for c in range(oe.ncon):
+        assert np.hypot(cf[c, 1] / fri[c, 0], cf[c, 2] / fri[c, 1]) <= cf[c, 0] * (1 + 1e-9) + 1e-9
