@@ -37,6 +37,13 @@ __device__ __forceinline__ float readlane(float v) {
 __device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, GQ_WAVE); }
 __device__ __forceinline__ int shfl_xor(int v, int m) { return __shfl_xor(v, m, GQ_WAVE); }
 
+/* a value the program knows to be wave-uniform but the compiler does not (e.g. read from LDS): v_readfirstlane */
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+/* read lane `src` (per-lane index) - ds_bpermute_b32 */
+__device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, GQ_WAVE); }
+__device__ __forceinline__ int shfl_idx(int v, int src) { return __shfl(v, src, GQ_WAVE); }
+
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
 __device__ __forceinline__ int ffs64(uint64_t m) { return __ffsll((long long)m) - 1; } /* index of the lowest set bit */

@@ -68,7 +68,8 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     if (d->body_jntnum[b] != 1 || d->jnt_type[d->body_jntadr[b]] != 3 || d->body_jntadr[b] != b - 1)
       FAIL("body %d must carry exactly one hinge joint (joint %d)", b, b - 1);
   }
-  if (d->cone != 0) FAIL("elliptic friction cones are not supported by the HIP path yet (pyramidal only)");
+  if (d->cone != 0 && d->cone != 1) FAIL("cone must be 0 (pyramidal) or 1 (elliptic)");
+  if (d->cone == 1 && d->solver != 1) FAIL("elliptic friction cones need the Newton solver (solver = 1): the PGS path has no per-contact cone projection");
   if (d->solver != 0 && d->solver != 1) FAIL("solver must be 0 (PGS) or 1 (Newton)");
   if (d->gravity[0] != 0 || d->gravity[1] != 0) FAIL("gravity must be along z");
   M.timestep = (float)d->timestep; M.gravity_z = (float)d->gravity[2]; M.impratio = (float)d->impratio;
@@ -139,7 +140,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     for (int i = 0; i < 3; i++) M.foot_pos[k][i] = (float)(d->geom_pos[3 * g + i] + R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2]);
     M.foot_radius[k] = (float)d->cloud_radius[cl];
     Mixed mx = mix_with_floor(d, g);
-    if (mx.dim != 1 && mx.dim != 3) FAIL("foot contact dimension %d not supported (1 or 3)", mx.dim);
+    if (mx.dim != 1 && mx.dim != 3 && !(d->cone == 1 && mx.dim == 6)) FAIL("foot contact dimension %d not supported (1, 3; 6 with elliptic cones)", mx.dim);
     M.foot_dim[k] = mx.dim; M.foot_fric_rule[k] = mx.rule; M.foot_margin[k] = (float)mx.margin; M.foot_includemargin[k] = (float)mx.includemargin;
     for (int i = 0; i < 3; i++) M.foot_friction[k][i] = (float)d->geom_friction[3 * g + i];
     for (int i = 0; i < 2; i++) M.foot_solref[k][i] = (float)mx.solref[i];
@@ -175,7 +176,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       }
     for (int i = 0; i < 3; i++) { G.aabb_c[i] = (float)(0.5 * (lo[i] + hi[i])); G.aabb_h[i] = (float)(0.5 * (hi[i] - lo[i]) * 1.0001 + 1e-7); }
     Mixed mx = mix_with_floor(d, g);
-    if (mx.dim != 1 && mx.dim != 3) FAIL("contact dimension %d of geom %d not supported (1 or 3)", mx.dim, g);
+    if (mx.dim != 1 && mx.dim != 3 && !(d->cone == 1 && mx.dim == 6)) FAIL("contact dimension %d of geom %d not supported (1, 3; 6 with elliptic cones)", mx.dim, g);
     G.dim = mx.dim; G.fric_rule = mx.rule; G.margin = (float)mx.margin; G.includemargin = (float)mx.includemargin;
     for (int i = 0; i < 3; i++) G.friction[i] = (float)d->geom_friction[3 * g + i];
     for (int i = 0; i < 2; i++) G.solref[i] = (float)mx.solref[i];

@@ -11,7 +11,7 @@
 #define GQ_NB 13        /* moving bodies: 0 = base, 1 + 3*leg + link */
 #define GQ_NVD 18       /* dofs: 0..5 base, 6 + 3*leg + link */
 #define GQ_NJ 12        /* hinge joints */
-#define GQ_MAXLG 28     /* max link (non-foot) collision geoms */
+#define GQ_MAXLG 38     /* max link (non-foot) collision geoms */
 #define GQ_MAXCON 12    /* max simultaneous contacts fed to the solver */
 #define GQ_MAXEFC 63    /* constraint rows: one per lane, lane 63 carries the smooth-force solve */
 #define GQ_NOBS_ALL 227 /* scalars in QuadrupedEnv.ALL_OBS */

@@ -213,11 +213,70 @@ __device__ __forceinline__ void row_dd(int rtype, float y, float v, float R, flo
   }
 }
 
+/* Per-lane description of a row of an elliptic contact (CONE): code = e | dim << 4 (0: not such a row), r0 = lane of
+ * the contact's normal row, fri = friction coefficient of this row (e >= 1), mu = friction_0 / sqrt(impratio),
+ * D0 = 1 / R of the normal row.  Cost of the contact at residual z (mj_constraintUpdate): with N = mu z_0,
+ * U_j = fri_j z_j, T = |U|:  top zone N >= mu T: 0;  bottom zone mu N + T <= 0: sum_j D_j z_j^2 / 2;  middle zone:
+ * Dm (N - mu T)^2 / 2, Dm = D0 / (mu^2 (1 + mu^2)) - the dual of projecting onto the (scaled, circular) cone. */
+struct EllRow { int code, r0; float fri, mu, D0; };
+
+/* sum of `val` over the friction rows (e = 1 .. dim-1) of the lane's contact, available on every lane of the contact */
+__device__ __forceinline__ float ell_seg_sum(const EllRow& E, float val) {
+  const int dim = E.code >> 4;
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 1; j < 6; j++) {
+    const float t = shfl_idx(val, E.r0 + j); /* wave-uniform call; lanes outside a contact read themselves */
+    s += j < dim ? t : 0.0f;
+  }
+  return s;
+}
+__device__ __forceinline__ int ell_zone(float N, float T, float mu) { /* 0 top, 1 bottom, 2 middle */
+  if (N >= mu * T || (T <= 0.0f && N >= 0.0f)) return 0;
+  if (mu * N + T <= 0.0f || (T <= 0.0f && N < 0.0f)) return 1;
+  return 2;
+}
+
+/* first and second derivative along the search direction of the lane's share of an elliptic contact's cost at step
+ * alpha (lane-local: TT, UV, VV, y0, N1 are the contact sums at alpha = 0).  Bottom zone: every row its own quadratic;
+ * middle zone: the normal row carries s = Dm q^2 / 2, q = N - mu T:  s' = Dm q q',  s'' = Dm (q'^2 + q q'') */
+__device__ __forceinline__ void ell_dd(const EllRow& E, float alpha, float y, float v, float rD, float TT, float y0, float UV,
+                                       float VV, float N1, float& d1, float& d2) {
+  const float Na = E.mu * y0 + alpha * N1, TTa = fmaxf(0.0f, TT + 2.0f * alpha * UV + alpha * alpha * VV), Ta = sqrtf(TTa);
+  const int zone = ell_zone(Na, Ta, E.mu);
+  d1 = 0.0f; d2 = 0.0f;
+  if (zone == 1) { d1 = rD * (y + alpha * v) * v; d2 = rD * v * v; }
+  else if (zone == 2 && (E.code & 15) == 0) {
+    const float Dm = E.D0 / (E.mu * E.mu * (1.0f + E.mu * E.mu)), q = Na - E.mu * Ta;
+    const float Tp = (UV + alpha * VV) / Ta, qp = N1 - E.mu * Tp, Tpp = fmaxf(0.0f, VV - Tp * Tp) / Ta;
+    d1 = Dm * q * qp; d2 = Dm * (qp * qp - q * E.mu * Tpp);
+  }
+}
+
+/* state of the lane's elliptic row at residual y (wave-uniform call): force, cost share (the normal row carries the
+ * middle-zone cost of the contact), row weight for the Hessian (bottom zone only), zone, u_e = U_e / T, T^2 and z_0 */
+__device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, float& ci, float& wact, int& zone, float& uhat,
+                                           float& TT, float& y0) {
+  const int e = E.code & 15;
+  const float u = e >= 1 ? E.fri * y : 0.0f;
+  TT = ell_seg_sum(E, u * u);
+  y0 = shfl_idx(y, E.r0);
+  const float N = E.mu * y0, T = sqrtf(TT);
+  zone = ell_zone(N, T, E.mu);
+  ci = 0.0f; wact = 0.0f; uhat = 0.0f;
+  if (E.code == 0 || zone == 0) return 0.0f;
+  if (zone == 1) { ci = 0.5f * rD * y * y; wact = rD; return -rD * y; }
+  const float Dm = E.D0 / (E.mu * E.mu * (1.0f + E.mu * E.mu)), q = N - E.mu * T;
+  if (e == 0) { ci = 0.5f * Dm * q * q; return -Dm * q * E.mu; }
+  uhat = u / T;                       /* the middle zone's curvature is carried entirely by the virtual rows */
+  return Dm * q * E.mu * E.fri * uhat;
+}
+
 /* Newton iterations.  In: row data in registers, qacc_smooth / warm / Mc / Mb in LDS, J rows in W.u.B.
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
-template <bool DBG>
+template <bool DBG, bool CONE>
 __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype, float rR, float raref,
-                                     float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg) {
+                                     float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg, const EllRow E) {
   const int lane = lane_id();
   /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */
   /* (each use goes through opaque_ptr: otherwise the compiler merges the re-reads, keeps the 18 values live across the
@@ -239,6 +298,11 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     float cw, cs, tmp;
     row_law(rtype, yw, rR, rD, rfloss, cw, tmp);
     row_law(rtype, ys, rR, rD, rfloss, cs, tmp);
+    if constexpr (CONE) {
+      float c2, t1, t2, t3, t4; int z;
+      ell_state(E, yw, rD, c2, t1, z, t2, t3, t4); if (E.code) cw = c2;
+      ell_state(E, ys, rD, c2, t1, z, t2, t3, t4); if (E.code) cs = c2;
+    }
     if (lane < GQ_NVD) dq[lane] = W.warm[lane] - W.qacc_smooth[lane];
     wave_barrier();
     float g = 0.0f;
@@ -249,8 +313,8 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     if (lane < GQ_NVD) W.qacc[lane] = cost_w < cost_s ? W.warm[lane] : W.qacc_smooth[lane];
     wave_barrier();
   }
-  float f = 0.0f, oldcost = 0.0f;
-  int iter = 0;
+  float f = 0.0f;
+  int iter = 0, exit_code = 0; /* why the loop ended (debug record, timer slot 23) */
   const int fl_row = lane < GQ_NVD ? m.fl_row_of_dof[lane] : -1;
   /* the two Hessian entries this lane assembles every iteration (pass 0: entry lane, pass 1: entry 64 + lane), packed
    * da | db << 8 | slot << 16; -1: none.  Leg rows: hip 7, thigh 8, calf 9 entries -> 24 per leg (slots of Hc);
@@ -290,13 +354,20 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     /* ---- constraint state at the current iterate */
     float ci, wact;
     f = row_law(rtype, y, rR, rD, rfloss, ci, wact);
+    int zone = 0;
+    float uhat = 0.0f, TT = 0.0f, y0 = 0.0f;
+    if constexpr (CONE) {
+      float c2, w2;
+      const float f2 = ell_state(E, y, rD, c2, w2, zone, uhat, TT, y0);
+      if (E.code) { f = f2; ci = c2; wact = w2; }
+    }
     W.force[lane] = f; /* row forces, read column-wise for J'f below */
     if (lane < GQ_NVD) Mdq[lane] = md;
     wave_barrier();
-    const float cost = wave_sum(ci + (lane < GQ_NVD ? 0.5f * dqv * md : 0.0f));
-    if (iter > 0 && scale * (oldcost - cost) < m.tolerance) break;
-    if (iter >= m.iterations) break;
-    oldcost = cost;
+    /* (MuJoCo's improvement test compares successive costs; in fp32 their round-off - 1e-7 of a cost dominated by stiff
+     * contact rows - is far above `tolerance`, so the test is applied to the decrease predicted by the line search,
+     * after the step, below) */
+    if (iter >= m.iterations) { exit_code = 2; break; }
     NW_T(1);
     /* ---- gradient = M dq - J' f  (lane = dof walks its column of J in LDS) */
     float gd = 0.0f, gterm = 0.0f;
@@ -310,14 +381,66 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
       gterm = md * md + (s0 + s1) * (s0 + s1);
     }
     const float gnorm2 = wave_sum(lane < GQ_NVD ? gd * gd : 0.0f);
-    if (scale * sqrtf(gnorm2) < m.tolerance) break;
+    if (scale * sqrtf(gnorm2) < m.tolerance) { exit_code = 3; break; }
     /* fp32 floor (GqModelDesc.noise_floor): the gradient is a difference of two vectors; once it is down at their
      * round-off a further Newton step only chases noise */
-    if (iter > 0 && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(gterm)) break;
+    if (iter > 0 && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(gterm)) { exit_code = 4; break; }
     if (lane < GQ_NVD) grad[lane] = -gd; /* right-hand side of H search = -grad */
     wave_barrier();
     W.force[lane] = wact; /* Hessian weights of the rows replace the forces */
     wave_barrier();
+    int nrowh = nefc; /* rows the Hessian assembly walks */
+    if constexpr (CONE) {
+      /* a contact in the middle zone has the dense block  Dm g g' + Dm kappa F^(1/2) (I - u u') F^(1/2)  (F = diag of the
+       * squared friction coefficients, u = U / T, kappa = -mu q / T > 0).  It is added as virtual rows above nefc (S6
+       * reserved the space), every one with a POSITIVE weight so that H stays positive semi-definite in fp32 whatever the
+       * round-off:  a = sum_i g_i J_i (weight Dm)  and, for an orthonormal basis p_k of the complement of u,
+       * b_k = sum_j fri_j p_kj J_j (weight Dm kappa).  dim 3: p = (-u_2, u_1);  dim 6: columns 2..5 of the Householder
+       * reflection that maps e_1 to -+u.  (Formed as diag - w w' the projector loses definiteness by ~1e-7 Dm kappa, which
+       * is comparable to the inertia of a light leg.) */
+      const int ncon = W.ncon;
+      for (int c = 0; c < ncon; c++) { /* wave-uniform */
+        const int r0 = uniform(W.con_row[c]), dim = uniform(W.con_dim[c]);
+        if (dim == 1) continue;
+        if (bcast(zone, r0) != 2) continue;
+        const float mu_c = bcast(E.mu, r0), Tc = sqrtf(bcast(TT, r0)), qc = mu_c * bcast(y0, r0) - mu_c * Tc;
+        const float Dm = bcast(E.D0, r0) / (mu_c * mu_c * (1.0f + mu_c * mu_c)), wk = Dm * (-mu_c * qc) / Tc;
+        float uh[6], fr[6], Jr[6]; /* [0] unused for uh / fr */
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          uh[i] = (i >= 1 && i < dim) ? bcast(uhat, r0 + i) : 0.0f;
+          fr[i] = (i >= 1 && i < dim) ? bcast(E.fri, r0 + i) : 0.0f;
+          Jr[i] = (i < dim && lane < GQ_NVD) ? W.u.B[r0 + i][lane] : 0.0f;
+        }
+        float av = mu_c * Jr[0];
+#pragma unroll
+        for (int i = 1; i < 6; i++) av -= mu_c * fr[i] * uh[i] * Jr[i];
+        if (lane < GQ_NVD) W.u.B[nrowh][lane] = av;
+        if (lane == 0) W.force[nrowh] = Dm;
+        nrowh++;
+        if (dim == 3) {
+          if (lane < GQ_NVD) W.u.B[nrowh][lane] = -uh[2] * fr[1] * Jr[1] + uh[1] * fr[2] * Jr[2];
+          if (lane == 0) W.force[nrowh] = wk;
+          nrowh++;
+        } else {
+          const float sg = uh[1] < 0.0f ? -1.0f : 1.0f;
+          float hv[6];
+#pragma unroll
+          for (int i = 1; i < 6; i++) hv[i] = uh[i] + (i == 1 ? sg : 0.0f);
+          const float inv = 1.0f / (1.0f + fabsf(uh[1])); /* 2 / (h'h), h'h = 2 (1 + |u_1|) */
+#pragma unroll
+          for (int k = 2; k < 6; k++) {
+            float bv = 0.0f;
+#pragma unroll
+            for (int i = 1; i < 6; i++) bv += ((i == k ? 1.0f : 0.0f) - hv[i] * hv[k] * inv) * fr[i] * Jr[i];
+            if (lane < GQ_NVD) W.u.B[nrowh][lane] = bv;
+            if (lane == 0) W.force[nrowh] = wk;
+            nrowh++;
+          }
+        }
+      }
+      wave_barrier();
+    }
     NW_T(2);
     /* ---- Hessian in M's tree-sparse layout: H = M + sum_r w_r J_r' J_r.  117 structurally non-zero entries, two
      * passes of one entry per lane.  Friction-loss rows are +-e_dof: their weight goes straight to the diagonal; limit
@@ -333,11 +456,11 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
           for (int r = nfl; r < nsingle; r++) s1 += W.force[r] * W.u.B[r][da] * W.u.B[r][da];
         }
         int r = nsingle;
-        for (; r + 2 <= nefc; r += 2) {
+        for (; r + 2 <= nrowh; r += 2) {
           s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
           s1 += W.force[r + 1] * W.u.B[r + 1][da] * W.u.B[r + 1][db];
         }
-        if (r < nefc) s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
+        if (r < nrowh) s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
         const float hv = s0 + s1;
         if (slot < 108) W.u2.n.Hc[slot / 9][slot % 9] = hv;
         else { W.u2.n.Hb[da][db] = hv; W.u2.n.Hb[db][da] = hv; }
@@ -361,12 +484,22 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     bool first_try = false;
     float d1, d2;
     row_dd(rtype, y, v, rR, rD, rfloss, d1, d2);
+    /* elliptic contacts: along the line T(alpha)^2 = TT + 2 alpha UV + alpha^2 VV and N(alpha) = N + alpha N1, so three
+     * contact sums taken once make every trial step a lane-local evaluation */
+    float UV = 0.0f, VV = 0.0f, N1 = 0.0f;
+    if constexpr (CONE) {
+      const bool fr = (E.code & 15) >= 1;
+      const float u = fr ? E.fri * y : 0.0f, V = fr ? E.fri * v : 0.0f;
+      UV = ell_seg_sum(E, u * V); VV = ell_seg_sum(E, V * V); N1 = E.mu * shfl_idx(v, E.r0);
+      if (E.code) ell_dd(E, 0.0f, y, v, rD, TT, y0, UV, VV, N1, d1, d2);
+    }
     const float g0 = q1 + wave_sum(d1);
     float h0 = 2.0f * q2 + wave_sum(d2);
-    if (!(g0 < 0.0f)) break; /* not a descent direction: converged to working precision */
+    if (!(g0 < 0.0f)) { exit_code = 5; break; } /* not a descent direction: converged to working precision */
     alpha = -g0 / h0;
     for (int ls = 0; ls < 10; ls++) {
       row_dd(rtype, y + alpha * v, v, rR, rD, rfloss, d1, d2);
+      if constexpr (CONE) if (E.code) ell_dd(E, alpha, y, v, rD, TT, y0, UV, VV, N1, d1, d2);
       const float ga = q1 + 2.0f * q2 * alpha + wave_sum(d1);
       const float ha = 2.0f * q2 + wave_sum(d2);
       if (fabsf(ga) <= 1e-3f * fabsf(g0)) { first_try = ls == 0; break; } /* MuJoCo's line search is approximate too (ls_tolerance 0.01) */
@@ -381,20 +514,33 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     /* the cost is piecewise quadratic.  A full Newton step (accepted at the first trial) that leaves every row on the
      * piece it was linearised on has reached the minimiser of a model that IS the cost there: converged, and the
      * usual extra iteration that only re-evaluates cost and gradient to find that out is skipped */
-    const bool moved = row_piece(rtype, y, rR, rfloss) != row_piece(rtype, ynew, rR, rfloss);
+    bool moved = row_piece(rtype, y, rR, rfloss) != row_piece(rtype, ynew, rR, rfloss);
+    if constexpr (CONE) if (E.code) { /* the middle zone is not quadratic: a contact there (before or after) always counts as moved */
+      const float TTn = fmaxf(0.0f, TT + 2.0f * alpha * UV + alpha * alpha * VV);
+      const int zn = ell_zone(E.mu * y0 + alpha * N1, sqrtf(TTn), E.mu);
+      moved = zn != zone || zone == 2;
+    }
     y = ynew;
     wave_barrier();
     NW_T(6);
-    if (first_try && ballot(moved) == 0) {
+    /* improvement of this step from the line-search model (exact for a quadratic phi): phi(0) - phi(alpha) = -g0 alpha / 2 */
+    const bool small_step = scale * (-0.5f * g0 * alpha) < m.tolerance;
+    if ((first_try && ballot(moved) == 0) || small_step) {
       float ci, wact;
       f = row_law(rtype, y, rR, rD, rfloss, ci, wact);
+      if constexpr (CONE) {
+        int z2; float t1, t2, t3;
+        const float f2 = ell_state(E, y, rD, ci, wact, z2, t1, t2, t3);
+        if (E.code) f = f2;
+      }
       if (lane < GQ_NVD) Mdq[lane] = md;
       iter++;
+      exit_code = small_step ? 1 : 6;
       break;
     }
   }
   if constexpr (DBG) if (tdbg && lane == 0)
-    for (int k = 0; k < 7; k++) tdbg[16 + k] = (float)tacc[k];
+  { for (int k = 0; k < 7; k++) tdbg[16 + k] = (float)tacc[k]; tdbg[23] = (float)exit_code; }
 #undef NW_T
 #undef J
   niter = iter;

@@ -147,8 +147,9 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
  * a next-step auto-reset (as pass 1, flags cleared).  Returns `terminated`. */
 /* SOLVER 0: PGS (mj_solPGS), 1: Newton (mj_solNewton, MuJoCo's default).  DBG: the variant with the debug record, the
  * stage timers and the GQ_STOP_STAGE cut compiled in - the production variant carries none of it (no timer
- * accumulators or row data kept live for the record: they cost registers inside the solver loop). */
-template <int SOLVER, bool DBG>
+ * accumulators or row data kept live for the record: they cost registers inside the solver loop).
+ * CONE: elliptic friction cones (Newton only): contacts take dim rows [n, t1, t2, torsion, roll1, roll2]. */
+template <int SOLVER, bool DBG, bool CONE>
 __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
@@ -344,7 +345,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
         /* friction mixing; _set_ground_friction overrides floor and feet with [mu, 0.005, 0] (quadruped_env.py:1292) */
         const float fg = mu_env >= 0.0f ? mu_env : m.foot_friction[k][0];
         const int rule = m.foot_fric_rule[k];
-        mu = rule == 0 ? fmaxf(ff, fg) : (rule == 1 ? ff : fg);
+        mu = fmaxf(1e-5f, rule == 0 ? fmaxf(ff, fg) : (rule == 1 ? ff : fg)); /* mjMINMU */
         solref = m.foot_solref[k]; solimp = m.foot_solimp[k];
       } else {
         const int g = code - 4;
@@ -354,7 +355,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
         body = G.body; dim = G.dim; inc = G.includemargin; calf = G.body > 0 && (G.body - 1) % 3 == 2;
         px = W.u2.c.lg_pt[g][0]; py = W.u2.c.lg_pt[g][1]; pz = W.u2.c.lg_pt[g][2] - (G.radius + 0.5f * dist);
         const float fg = G.friction[0];
-        mu = G.fric_rule == 0 ? fmaxf(ff, fg) : (G.fric_rule == 1 ? ff : fg);
+        mu = fmaxf(1e-5f, G.fric_rule == 0 ? fmaxf(ff, fg) : (G.fric_rule == 1 ? ff : fg));
         solref = G.solref; solimp = G.solimp;
       }
     }
@@ -383,12 +384,17 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     /* row budget: friction rows, limit rows, then whole contacts in order while they fit (a prefix of the list) */
     const int idx = popc64(touch_mask & lt);
     const bool kept = touching && idx < GQ_MAXCON;
-    const int need = dim == 1 ? 1 : 2 * (dim - 1);
-    const uint64_t m1 = ballot(kept && need == 1), m4 = ballot(kept && need == 4);
-    const int row0 = m.nfl + nl + popc64(m1 & lt) + 4 * popc64(m4 & lt);
-    const bool fits = kept && row0 + need <= GQ_MAXEFC;
+    /* pyramidal: 2 (dim - 1) edge rows; elliptic: dim rows + (dim - 1) rows of LDS above nefc reserved per cone contact
+     * for the virtual rows of its Hessian block (gq_newton.h) */
+    const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
+    const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4),
+                   m6 = ballot(kept && need == 6);
+    const int row0 = m.nfl + nl + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
+    const int reserve = CONE ? 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) + (need > 1 ? need - 1 : 0) : 0;
+    const bool fits = kept && row0 + need + reserve <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
     const uint64_t fit_mask = ballot(fits);
-    const uint64_t f1 = ballot(fits && need == 1), f4 = ballot(fits && need == 4);
+    const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4),
+                   f6 = ballot(fits && need == 6);
     if (fits) {
       W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
       W.con_dist[idx] = dist; W.con_inc[idx] = inc; W.con_mu[idx] = mu;
@@ -398,7 +404,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = solimp[q];
     }
     if (lane == 0) {
-      W.ncon = popc64(fit_mask); W.nlim = nl; W.nefc = m.nfl + nl + popc64(f1) + 4 * popc64(f4); W.invalid = invalid;
+      W.ncon = popc64(fit_mask); W.nlim = nl; W.nefc = m.nfl + nl + popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6); W.invalid = invalid;
 #pragma unroll
       for (int k = 0; k < 4; k++) W.foot_touch[k] = ft[k];
     }
@@ -421,6 +427,10 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   float rpos = 0.0f, rmargin = 0.0f, rfloss = 0.0f, rdiag = 0.0f, rmu = 0.0f, rdiag_first = 0.0f;
   const float* rsolref = m.dof_solref[0];
   const float* rsolimp = m.dof_solimp[0];
+  /* elliptic rows (CONE): position in the contact and its dim, first row of the contact, friction coefficient of this
+   * row (e >= 1), the contact's mu = friction_0 / sqrt(impratio) */
+  int ecode = 0, er0 = lane;
+  float efri = 0.0f, emu = 0.0f, eR0 = 1.0f, econ_dist = 0.0f, econ_inc = 0.0f;
   int jd = -1, jleg = -1, jdepth = -1;   /* single-entry rows: dof index; contact rows: leg / depth of the body (-1: base) */
   float jsgn = 0.0f;
   bool jcon = false;
@@ -445,8 +455,32 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     const float tran = m.body_invweight0[body][0];
     /* contact frame of a horizontal floor (mju_makeFrame): n = z, t1 = y, t2 = -x */
     dir = v3(0.0f, 0.0f, 1.0f);
+    bool rotational = false;
     if (dim == 1) { rtype = ROW_CONTACT1; rdiag = tran; }
-    else {
+    else if constexpr (CONE) {
+      rtype = ROW_ELLIPTIC; ecode = e | (dim << 4); er0 = W.con_row[c];
+      econ_dist = rpos; econ_inc = rmargin;
+      emu = mu / sqrtf(m.impratio);
+      /* torsional / rolling coefficients: same mixing rule as the sliding one (S6), _set_ground_friction overrides
+       * floor and feet with [mu, 0.005, 0.0]; clamped at mjMINMU */
+      const int code = W.con_geom[c];
+      const int rule = code < 4 ? m.foot_fric_rule[code] : m.lg[code - 4].fric_rule;
+      float fr[3] = {mu, 0.0f, 0.0f};
+#pragma unroll
+      for (int q = 1; q < 3; q++) {
+        const float ovr = q == 1 ? 0.005f : 0.0f;
+        const float ff = mu_env >= 0.0f ? ovr : m.floor_friction[q];
+        const float fg = code < 4 ? (mu_env >= 0.0f ? ovr : m.foot_friction[code][q]) : m.lg[code - 4].friction[q];
+        fr[q] = fmaxf(1e-5f, rule == 0 ? fmaxf(ff, fg) : (rule == 1 ? ff : fg));
+      }
+      efri = e == 0 ? 0.0f : (e < 3 ? fr[0] : (e == 3 ? fr[1] : fr[2]));
+      rotational = e >= 3;
+      const int ax = e % 3; /* 0: n = z, 1: t1 = y, 2: t2 = -x */
+      dir = ax == 0 ? v3(0.0f, 0.0f, 1.0f) : (ax == 1 ? v3(0.0f, 1.0f, 0.0f) : v3(-1.0f, 0.0f, 0.0f));
+      rdiag = rotational ? m.body_invweight0[body][1] : tran;
+      rdiag_first = tran;                                   /* R of the contact's normal row */
+      if (e > 0) { rpos = 0.0f; rmargin = 0.0f; }           /* friction rows carry no penetration */
+    } else {
       rtype = ROW_PYRAMID;
       const float sgn = (e & 1) ? -mu : mu;
       if ((e >> 1) == 0) dir.y = sgn; else dir.x = -sgn;
@@ -455,6 +489,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       rmu = mu / sqrtf(m.impratio);
     }
     w = cross(ld3(W.con_pos[c]) - O, dir);
+    if (rotational) { w = dir; dir = v3(0.0f, 0.0f, 0.0f); } /* torsion / rolling rows act on the angular Jacobian */
     jcon = true;
     if (body > 0) { jleg = (body - 1) / 3; jdepth = (body - 1) % 3; }
   }
@@ -485,6 +520,13 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       float Rfirst = fmaxf(1e-15f, (1.0f - imp) * rdiag_first / imp);
       rR = fmaxf(1e-15f, 2.0f * rmu * rmu * Rfirst);
     }
+    if constexpr (CONE) if (rtype == ROW_ELLIPTIC) {
+      /* R_n from the normal row's impedance (penetration of the contact), friction rows R_j = R_n mu^2 / friction_j^2 */
+      const float impn = impedance(rsolimp, econ_dist, econ_inc);
+      eR0 = fmaxf(1e-15f, (1.0f - impn) * rdiag_first / impn);
+      if ((ecode & 15) > 0) rR = fmaxf(1e-15f, eR0 * emu * emu / (efri * efri));
+      else rR = eR0;
+    }
   }
 
   GQ_TICK(7);
@@ -496,8 +538,9 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
     solve_tree_one(W, W.F[0], W.smooth, W.qacc_smooth);
     GQ_TICK(8);
-    const float fN = newton_solve<DBG>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
-                                  timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr);
+    const EllRow ell = {ecode, er0, efri, emu, 1.0f / eR0};
+    const float fN = newton_solve<DBG, CONE>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
+                                  timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell);
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
@@ -792,6 +835,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       cs = 1.0f;
       const int r0 = W.con_row[c];
       if (W.con_dim[c] == 1) cf.z += W.force[r0];
+      else if constexpr (CONE) cf = cf + v3(-W.force[r0 + 2], W.force[r0 + 1], W.force[r0]); /* frame' * f: n = z, t1 = y, t2 = -x */
       else {
         float f0 = W.force[r0], f1 = W.force[r0 + 1], f2 = W.force[r0 + 2], f3 = W.force[r0 + 3], mu = W.con_mu[c];
         /* mju_decodePyramid, then frame' * f with n = z, t1 = y, t2 = -x */

@@ -72,7 +72,7 @@ enum {
 #define GQ_F_DINV(k) (132 + (k))
 #define GQ_FACTOR_SIZE 150
 
-enum { ROW_NONE = 0, ROW_FRICTION = 1, ROW_LIMIT = 2, ROW_CONTACT1 = 3, ROW_PYRAMID = 4 };
+enum { ROW_NONE = 0, ROW_FRICTION = 1, ROW_LIMIT = 2, ROW_CONTACT1 = 3, ROW_PYRAMID = 4, ROW_ELLIPTIC = 5 };
 
 /* ------------------------------------------------------------------ per-wave LDS working set (8.5 KB: 16+ waves per CU)
  * `u` overlays three regions with disjoint lifetimes: the spatial-dynamics scratch (S1-S5), the half-batch of

@@ -46,6 +46,9 @@ static inline int bcast(int v, int src) { const uint32_t* s = exchange((uint32_t
 template <int SRC> static inline float readlane(float v) { return bcast(v, SRC); }
 static inline float shfl_xor(float v, int m) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r; memcpy(&r, &s[lane_id() ^ m], 4); return r; }
 static inline int shfl_xor(int v, int m) { const uint32_t* s = exchange((uint32_t)v); return (int)s[lane_id() ^ m]; }
+static inline float shfl_idx(float v, int src) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r; memcpy(&r, &s[src & 63], 4); return r; }
+static inline int shfl_idx(int v, int src) { const uint32_t* s = exchange((uint32_t)v); return (int)s[src & 63]; }
+static inline int uniform(int v) { return v; }
 static inline uint64_t ballot(bool p) { const uint32_t* s = exchange(p ? 1u : 0u); uint64_t m = 0; for (int i = 0; i < 64; i++) m |= (uint64_t)(s[i] & 1) << i; return m; }
 static inline float wave_sum(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = 0; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r += t; } return r; }
 static inline float wave_min(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::min(r, t); } return r; }

