@@ -186,6 +186,28 @@ def test_next_step_auto_reset_equals_manual_reset_loop():
     assert nreset > 0
 
 
+def test_go2_rollout_elliptic_condim6_invariants():
+    """BASELINE config 4 (go2, flat, elliptic cones, feet condim 6) at one shard: 4096 envs, 150 random-action steps with
+    next-step auto-reset: state stays finite, quaternions unit, feet above the soft-contact depth, envs get re-spawned."""
+    n = 4096
+    env = _make_env(n, obs=('qpos', 'qvel', 'feet_pos', 'contact_forces'), iters=100, tol=1e-8, solver='newton', robot='go2',
+                    auto_reset='next_step')
+    env.reset(random=True)
+    g = torch.Generator(device='cuda:0').manual_seed(1)
+    nterm = 0
+    for _ in range(150):
+        obs, rew, term, trunc, info = env.step(torch.randn(n, 12, generator=g, device='cuda:0') * 20)
+        nterm += int(term.sum())
+    torch.cuda.synchronize()
+    q = env.qpos
+    assert torch.isfinite(q).all() and torch.isfinite(env.qvel).all() and torch.isfinite(obs['contact_forces']).all()
+    assert (q[:, 3:7].norm(dim=1) - 1).abs().max() < 1e-5
+    assert obs['feet_pos'].reshape(n, 4, 3)[:, :, 2].min() > -0.15
+    fz = obs['contact_forces'].reshape(n, 4, 3)[:, :, 2]
+    assert fz.min() > -1e-3 and fz.max() < 5e4    # unilateral, bounded
+    assert nterm > 0
+
+
 @pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo', 'hyqreal2', 'b2', 'go1', 'go2', 'hyqreal1', 'spot'])
 def test_newton_step_matches_converged_oracle(robot):
     """solver='newton' (MuJoCo's default) on every robot of the registry - pyramidal cones (mini_cheetah, aliengo,
