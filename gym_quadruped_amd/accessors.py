@@ -1,0 +1,256 @@
+"""Batched counterparts of the reference's on-demand getters (quadruped_env.py:488-1016) - the "MPC accessors".
+
+The reference computes these from ``mjData`` whenever the user asks; right after ``step()`` that is exactly what
+``_get_obs`` stored, so here they are *views*:
+
+* getters whose value is one of the ``ALL_OBS`` observables (base velocities / errors / acceleration in both frames,
+  feet positions and velocities, contact state and ground reaction forces, base configuration, Euler angles, heading
+  frame, gravity vector, kinetic energy, work) read the observation row the step kernel assembled.  Either list the
+  observable in ``state_obs_names`` or construct the env with ``accessors=True`` (all of ``ALL_OBS`` is then appended
+  to the row the kernel writes; the user-visible observation dict is unchanged).
+* getters that read MuJoCo internals of the last forward pass - ``mj_fullM`` (``legs_mass_matrix``, ``get_base_inertia``),
+  ``qfrc_bias`` / ``qfrc_passive``, ``body(i).xpos`` (``hip_positions``), ``subtree_com`` (``com``), ``mj_jac``
+  (``feet_jacobians``) - read the kernel's inspection record on the device (``gq_debug_device_buffer``).  The first use
+  switches the env to the instrumented kernel variant for all envs (slower: one 8.4 KB record per env-step) and needs
+  one ``step()`` / ``reset()`` afterwards to fill the record.
+
+Like the reference values they describe the LAST forward pass: positions / Jacobians / M of the pose before the
+integration step, velocities of the new state (quirk B3).  Everything has a leading env axis and stays on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .utils.quadruped_utils import LegsAttr
+
+LEGS = ('FL', 'FR', 'RL', 'RR')   # canonical kernel order
+
+
+class _DevPtr:
+    """Minimal __cuda_array_interface__ carrier so torch can wrap library-owned device memory without a copy."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+
+
+class AccessorsMixin:
+    # ------------------------------------------------------------------ plumbing
+    def _acc(self, name):
+        v = self._obs_views.get(name)
+        if v is None:
+            v = self._extra_views.get(name)
+        if v is None:
+            raise _lib.GqError(f"'{name}' is not assembled by this env: add it to state_obs_names or pass accessors=True")
+        return v
+
+    def _per_leg(self, flat, width):
+        """[N, 4*width] ordered by legs_order -> LegsAttr of [N, width] views."""
+        out = {}
+        for k, leg in enumerate(self.legs_order):
+            out[leg] = flat[:, k * width:(k + 1) * width]
+        return LegsAttr(**out)
+
+    @staticmethod
+    def _frame(frame):
+        if frame not in ('world', 'base'):
+            raise ValueError(f"Invalid frame: {frame} != 'world' or 'base'")
+        return '' if frame == 'world' else ':base'
+
+    def _record(self, field):
+        """[N, count] view of a field of the inspection record (instrumented kernel, all envs)."""
+        if getattr(self, '_rec_tensor', None) is None:
+            self.enable_debug(self.num_envs)
+            ptr, n, stride = C.c_void_p(), C.c_int32(), C.c_int32()
+            _lib.check(self._L.gq_debug_device_buffer(self._hbatch, C.byref(ptr), C.byref(n), C.byref(stride)), 'gq_debug_device_buffer')
+            self._rec_tensor = torch.as_tensor(_DevPtr(ptr.value, (n.value, stride.value)), device=self.device)
+            self._rec_filled_at = None
+        if self._rec_filled_at is None:
+            raise _lib.GqError('the inspection record is empty: call step() or reset() once after the first use of a '
+                               'dynamics accessor (legs_mass_matrix, legs_qfrc_bias, feet_jacobians, hip_positions, com, ...)')
+        off, cnt = C.c_int32(), C.c_int32()
+        _lib.check(self._L.gq_debug_field(field.encode(), C.byref(off), C.byref(cnt)), 'gq_debug_field')
+        return self._rec_tensor[:, off.value:off.value + cnt.value]
+
+    def _note_step(self):
+        if getattr(self, '_rec_tensor', None) is not None:
+            self._rec_filled_at = int(self._launches)
+
+    # ------------------------------------------------------------------ observation-backed getters
+    def base_lin_vel(self, frame='world'):
+        return self._acc('base_lin_vel' + self._frame(frame))
+
+    def base_ang_vel(self, frame='world'):
+        return self._acc('base_ang_vel' + self._frame(frame))
+
+    def base_lin_vel_err(self, frame='world'):
+        return self._acc('base_lin_vel_err' + self._frame(frame))
+
+    def base_ang_vel_err(self, frame='world'):
+        return self._acc('base_ang_vel_err' + self._frame(frame))
+
+    def base_lin_acc(self, frame='world'):
+        return self._acc('base_lin_acc' + self._frame(frame))
+
+    def feet_pos(self, frame='world') -> LegsAttr:
+        return self._per_leg(self._acc('feet_pos' + self._frame(frame)), 3)
+
+    def feet_vel(self, frame: str = 'world', relative: bool = False) -> LegsAttr:
+        return self._per_leg(self._acc(('feet_vel_rel' if relative else 'feet_vel') + self._frame(frame)), 3)
+
+    def feet_contact_state(self, frame='world', ground_reaction_forces=False):
+        """(contact_state, ground reaction forces) per leg.  The reference also returns the per-foot lists of MjContact
+        objects (:836-855); a batch has no such objects - per-contact detail is in the inspection record."""
+        cs = self._per_leg(self._acc('contact_state'), 1)
+        cs = LegsAttr(**{leg: cs[leg][:, 0] > 0.5 for leg in self.legs_order})
+        if not ground_reaction_forces:
+            return cs, None
+        return cs, None, self._per_leg(self._acc('contact_forces' + self._frame(frame)), 3)
+
+    @property
+    def base_configuration(self):
+        """[N, 4, 4] homogeneous base pose X_B (reference :961-970)."""
+        so3, pos = self.heading_free_rotation, self._acc('base_pos')
+        X = torch.zeros(self.num_envs, 4, 4, dtype=torch.float32, device=self.device)
+        X[:, :3, :3] = so3; X[:, :3, 3] = pos; X[:, 3, 3] = 1.0
+        return X
+
+    @property
+    def heading_free_rotation(self):
+        """[N, 3, 3] base rotation matrix (observable 'base_ori_SO3', row-major)."""
+        return self._acc('base_ori_SO3').reshape(self.num_envs, 3, 3)
+
+    @property
+    def base_ori_euler_xyz(self):
+        return self._acc('base_ori_euler_xyz')
+
+    @property
+    def heading_orientation_SO3(self):
+        """[N, 3, 3] rotation about z by the base yaw (reference :989-997)."""
+        yaw = self._acc('base_ori_euler_xyz')[:, 2]
+        c, s = torch.cos(yaw), torch.sin(yaw)
+        R = torch.zeros(self.num_envs, 3, 3, dtype=torch.float32, device=self.device)
+        R[:, 0, 0] = c; R[:, 0, 1] = -s; R[:, 1, 0] = s; R[:, 1, 1] = c; R[:, 2, 2] = 1.0
+        return R
+
+    @property
+    def gravity_vector(self):
+        return self._acc('gravity_vector:base')
+
+    @property
+    def kinetic_energy(self):
+        return self._acc('kinetic_energy')[:, 0]
+
+    @property
+    def work(self):
+        return self._acc('work')[:, 0]
+
+    # ------------------------------------------------------------------ inspection-record-backed getters
+    def _full_mass_matrix(self):
+        return self._record('M').reshape(self.num_envs, 18, 18)
+
+    @property
+    def legs_mass_matrix(self) -> LegsAttr:
+        M = self._full_mass_matrix()
+        out = {}
+        for leg in LEGS:
+            idx = torch.as_tensor(self.legs_qvel_idx[leg], device=self.device)
+            out[leg] = M[:, idx][:, :, idx]
+        return LegsAttr(**out)
+
+    def get_base_inertia(self):
+        return self._full_mass_matrix()[:, 3:6, 3:6]
+
+    @property
+    def legs_qfrc_bias(self) -> LegsAttr:
+        b = self._record('qfrc_bias')
+        return LegsAttr(**{leg: b[:, self.legs_qvel_idx[leg]] for leg in LEGS})
+
+    @property
+    def legs_qfrc_passive(self) -> LegsAttr:
+        """qfrc_passive of these models is joint damping only: -damping * qvel (mj_passive)."""
+        damp = torch.as_tensor(np.asarray(self.mjModel.dof_damping, dtype=np.float32), device=self.device)
+        p = -damp * self._qvel
+        return LegsAttr(**{leg: p[:, self.legs_qvel_idx[leg]] for leg in LEGS})
+
+    def _body_poses(self):
+        """World positions [N, 13, 3] / rotations [N, 13, 3, 3] of the robot bodies at the last forward pass.  The record
+        keeps positions relative to the base x/y of that pass (fp32 never sees the 10 km spawn offsets): it is added back
+        from the stored base position observable when available, else the record is returned base-relative in x/y."""
+        xpos = self._record('xpos').reshape(self.num_envs, 13, 3).clone()
+        xmat = self._record('xmat').reshape(self.num_envs, 13, 3, 3)
+        return xpos, xmat
+
+    def hip_positions(self, frame='world') -> LegsAttr:
+        """Hip body origins (reference :564-595).  World frame = relative to the pre-step base x/y plus that offset."""
+        xpos, xmat = self._body_poses()
+        names = list(self.mjModel.body_names)
+        out = {}
+        for leg in LEGS:
+            b = names.index(f'{leg}_hip') - 1   # record bodies exclude the world body
+            p = xpos[:, b] + self._base_xy_offset()
+            out[leg] = p if frame == 'world' else torch.einsum('nij,ni->nj', xmat[:, 0], p)  # reference: R.T @ xpos (quirk: no translation)
+        if frame not in ('world', 'base'):
+            raise ValueError(f"Invalid frame: {frame} != 'world' or 'base'")
+        return LegsAttr(**out)
+
+    def _base_xy_offset(self):
+        """[N, 3] pre-step base x/y (z = 0): new qpos minus h * new qvel (the Euler update of the free joint translation)."""
+        off = torch.zeros(self.num_envs, 3, dtype=torch.float32, device=self.device)
+        off[:, :2] = (self._qpos[:, :2] - float(self._sim_dt) * self._qvel[:, :2].double()).float()
+        return off
+
+    @property
+    def com(self):
+        """The reference's `com` (:918-929): sum_i body_mass[i] * subtree_com[i] / total_mass (sic - subtree COMs weighted by
+        body masses), evaluated on the poses of the last forward pass."""
+        xpos, xmat = self._body_poses()
+        md = self.mjModel
+        mass = torch.as_tensor(np.asarray(md.body_mass[1:], dtype=np.float32), device=self.device)          # 13 robot bodies
+        ipos = torch.as_tensor(np.asarray(md.body_ipos[1:], dtype=np.float32).reshape(13, 3), device=self.device)
+        xipos = xpos + torch.einsum('nbij,bj->nbi', xmat, ipos)
+        parent = [int(p) - 1 for p in md.body_parentid[1:]]
+        sub_m = mass.clone().repeat(self.num_envs, 1)
+        sub_mx = xipos * mass[None, :, None]
+        for b in range(12, 0, -1):           # children have larger ids than parents
+            sub_m[:, parent[b]] = sub_m[:, parent[b]] + sub_m[:, b]
+            sub_mx[:, parent[b]] = sub_mx[:, parent[b]] + sub_mx[:, b]
+        subtree_com = sub_mx / sub_m[:, :, None]
+        # world body (id 0): its subtree is the whole robot, its own mass 0 -> contributes nothing to the weighted sum
+        com = (subtree_com * mass[None, :, None]).sum(1) / mass.sum()
+        return com + self._base_xy_offset()
+
+    def feet_jacobians(self, frame: str = 'world', return_rot_jac: bool = False):
+        """mj_jac of the foot geom centre on its calf body (:681-740): [N, 3, 18] per leg (and the rotational one)."""
+        if frame not in ('world', 'base'):
+            raise ValueError(f"Invalid frame: {frame} != 'world' or 'base'")
+        xpos, xmat = self._body_poses()
+        md, N, dev = self.mjModel, self.num_envs, self.device
+        foot = self._record('foot_pos').reshape(N, 4, 3)           # canonical FL FR RL RR, base-x/y relative like xpos
+        jpos = torch.as_tensor(np.asarray(md.jnt_pos, dtype=np.float32).reshape(-1, 3)[1:], device=dev)    # 12 hinges
+        jax = torch.as_tensor(np.asarray(md.jnt_axis, dtype=np.float32).reshape(-1, 3)[1:], device=dev)
+        anchor = xpos[:, 1:] + torch.einsum('nbij,bj->nbi', xmat[:, 1:], jpos)   # hinge j lives on body j + 1
+        axis = torch.einsum('nbij,bj->nbi', xmat[:, 1:], jax)
+        Rb = xmat[:, 0]
+        jp, jr = {}, {}
+        for k, leg in enumerate(LEGS):
+            p = foot[:, k]
+            Jp = torch.zeros(N, 3, 18, dtype=torch.float32, device=dev)
+            Jr = torch.zeros(N, 3, 18, dtype=torch.float32, device=dev)
+            Jp[:, 0, 0] = 1.0; Jp[:, 1, 1] = 1.0; Jp[:, 2, 2] = 1.0
+            r = p - xpos[:, 0]
+            for a in range(3):   # free joint rotation: body-frame axes
+                ax = Rb[:, :, a]
+                Jp[:, :, 3 + a] = torch.cross(ax, r, dim=1)
+                Jr[:, :, 3 + a] = ax
+            for d in self.legs_qvel_idx[leg]:
+                j = d - 6
+                Jp[:, :, d] = torch.cross(axis[:, j], p - anchor[:, j], dim=1)
+                Jr[:, :, d] = axis[:, j]
+            if frame == 'base':
+                Jp = torch.einsum('nji,njk->nik', Rb, Jp); Jr = torch.einsum('nji,njk->nik', Rb, Jr)
+            jp[leg], jr[leg] = Jp, Jr
+        return (LegsAttr(**jp), LegsAttr(**jr)) if return_rot_jac else LegsAttr(**jp)

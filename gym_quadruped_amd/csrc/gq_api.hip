@@ -234,7 +234,7 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   const int rc = ensure_args(b, st, out, episode, lift_failed, nullptr, (hipStream_t)hip_stream);
   if (rc != GQ_OK) return rc;
   gq::StepCall c{};
-  c.mask = mask; c.first_pass = 1;
+  c.mask = mask; c.first_pass = 1; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
   gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
@@ -263,6 +263,20 @@ static const struct { const char* name; int off, n; } kDbg[] = {
     {"efc_b", GQ_DBG_EFC_B, 64}, {"efc_force", GQ_DBG_EFC_FORCE, 64}, {"efc_type", GQ_DBG_EFC_TYPE, 64},
     {"contact_dist", GQ_DBG_CON_DIST, GQ_MAXCON}, {"contact_geom", GQ_DBG_CON_GEOM, GQ_MAXCON},
     {"foot_pos", GQ_DBG_FOOT_POS, 12}, {"qacc", GQ_DBG_QACC, 18}, {"timer", GQ_DBG_TIMER, 32}, {"record", 0, GQ_DBG_SIZE}};
+
+int gq_debug_field(const char* name, int32_t* offset, int32_t* count) {
+  if (!name || !offset || !count) { SET_ERR("gq_debug_field: null argument"); return GQ_EINVAL; }
+  for (const auto& f : kDbg)
+    if (!std::strcmp(f.name, name)) { *offset = f.off; *count = f.n; return GQ_OK; }
+  SET_ERR("gq_debug_field: unknown field %s", name);
+  return GQ_EINVAL;
+}
+
+int gq_debug_device_buffer(GqBatch* b, float** dev, int32_t* n_envs, int32_t* stride) {
+  if (!b || !dev || !n_envs || !stride) { SET_ERR("gq_debug_device_buffer: null argument"); return GQ_EINVAL; }
+  *dev = b->host.debug_envs > 0 ? b->debug : nullptr; *n_envs = b->host.debug_envs; *stride = GQ_DBG_SIZE;
+  return GQ_OK;
+}
 
 int gq_debug_get(GqBatch* b, int env, const char* name, double* out, int max_n) {
   if (!b || !name || !out || env < 0 || env >= b->host.debug_envs || !b->debug) { SET_ERR("gq_debug_get: bad argument / debug not enabled"); return GQ_EINVAL; }

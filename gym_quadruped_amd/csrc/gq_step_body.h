@@ -158,7 +158,10 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   const int lane = lane_o, env = env_o;
   const GqDevModel& m = *a.model;
   const float h = m.timestep;
-  const bool timing = DBG && call.debug && pass == 0 && env < a.batch->debug_envs;
+  /* the record describes the forward pass whose results the caller sees: the user's step, the reset's own step of
+   * gq_reset, or the reset step of a next-step auto-reset - not the second pass of a same-step auto-reset */
+  const bool rec_pass = pass == call.first_pass || pass == 2;
+  const bool timing = DBG && call.debug && rec_pass && env < a.batch->debug_envs;
   const long long t_start = timing ? cycles() : 0;
 #define GQ_TICK(i) do { if constexpr (DBG) { \
     if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); \
@@ -675,7 +678,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   wave_barrier();
 
   }
-  if constexpr (DBG) if (call.debug && pass == 0 && env < a.batch->debug_envs) {
+  if constexpr (DBG) if (call.debug && rec_pass && env < a.batch->debug_envs) {
     float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
     for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = m_entry(W, k / 18, k % 18);
     if (lane < 18) {

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .accessors import AccessorsMixin
 from .cabi import ALL_OBS as _ALL_OBS
 from .cabi import LEG_NAMES, OBS_DIMS, GqObsOut, GqResetCfg, GqState, MarshalledModel, obs_ids_from_names
 from .mjcf import ModelDesc, compile_mjcf, load_compiled
@@ -60,7 +61,7 @@ class _Info(dict):
         return k in ('time', 'step_num', 'invalid_contacts')
 
 
-class QuadrupedEnv:
+class QuadrupedEnv(AccessorsMixin):
     """Batched quadruped environment (see module docstring).  Single-env semantics follow the reference class of the
     same name; ``num_envs`` / ``device`` / ``auto_reset`` / solver knobs are the only additions."""
 
@@ -93,6 +94,7 @@ class QuadrupedEnv:
         seed: int | None = None,
         mjcf_path: str | None = None,
         env_id_offset: int = 0,
+        accessors: bool = False,
     ):
         self._save_hyperparameters(constructor_params=locals().copy())
         log.info(f'Initializing {robot} environment with scene {scene}.')
@@ -153,6 +155,11 @@ class QuadrupedEnv:
         self.state_obs_names = tuple(state_obs_names)
         self.observation_space = configure_observation_space(mj_model=self.mjModel, obs_names=self.state_obs_names)
         self._obs_ids = obs_ids_from_names(self.state_obs_names)
+        # accessors=True: the kernel also writes every ALL_OBS observable the user did not ask for, behind the user's
+        # columns, so that the reference's getters (base_lin_vel(frame), feet_pos(frame), ...) are views (accessors.py)
+        self._extra_names = tuple(n for n in _ALL_OBS if n not in self.state_obs_names) if accessors else ()
+        self._all_ids = list(self._obs_ids) + obs_ids_from_names(self._extra_names)
+        self._launches = 0
 
         # device state: one tensor per field, env-major rows
         N, dev = self.num_envs, self.device
@@ -167,7 +174,7 @@ class QuadrupedEnv:
         self._cmd = torch.zeros(N, 4, **f32)
         self._ctrl = torch.zeros(N, nu, **f32)
         self._last_action = self._ctrl
-        self._obs_dim = int(sum(OBS_DIMS[i] for i in self._obs_ids))
+        self._obs_dim = int(sum(OBS_DIMS[i] for i in self._all_ids))   # row width the kernel writes
         self._obs_buf = torch.zeros(N, self._obs_dim, **f32)
         self._reward = torch.zeros(N, **f32)
         self._terminated = torch.zeros(N, dtype=torch.uint8, device=dev)
@@ -185,9 +192,9 @@ class QuadrupedEnv:
         self._steps_before_dist = torch.full((N,), 1 << 30, dtype=torch.int32, device=dev)
         self._ext_dist = torch.zeros(N, 6, **f32)
         self._has_cmd = False
-        self._obs_views, k = {}, 0
-        for name, i in zip(self.state_obs_names, self._obs_ids):
-            self._obs_views[name] = self._obs_buf[:, k:k + OBS_DIMS[i]]
+        self._obs_views, self._extra_views, k = {}, {}, 0
+        for name, i in zip(self.state_obs_names + self._extra_names, self._all_ids):
+            (self._obs_views if name in self.state_obs_names else self._extra_views)[name] = self._obs_buf[:, k:k + OBS_DIMS[i]]
             k += OBS_DIMS[i]
         self._key_qpos = torch.as_tensor(self.mjModel.key_qpos[0] if len(self.mjModel.key_qpos) else qpos0, dtype=torch.float64, device=dev)
         self._gen = torch.Generator(device=dev)
@@ -199,7 +206,7 @@ class QuadrupedEnv:
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._hmodel = C.c_void_p()
         _lib.check(L.gq_model_create(C.byref(self._mm.desc), int(dev_index), C.byref(self._hmodel)), 'gq_model_create')
-        ids = np.asarray(self._obs_ids, dtype=np.int32)
+        ids = np.asarray(self._all_ids, dtype=np.int32)
         lo = np.asarray([LEG_NAMES.index(l) for l in self.legs_order], dtype=np.int32)
         self._hbatch = C.c_void_p()
         _lib.check(L.gq_batch_create(self._hmodel, N, ids.ctypes.data, len(ids), lo.ctypes.data, C.byref(self._hbatch)), 'gq_batch_create')
@@ -278,6 +285,8 @@ class QuadrupedEnv:
                                    self._episode.data_ptr(), self._lift_failed.data_ptr(), stream), 'gq_step')
         if ev is not None:
             ev[1].record()
+        self._launches += 1
+        self._note_step()
         for sensor in self.sensors:  # reference :273-274 (kernel-side sensors: no-op)
             sensor.step()
 
@@ -334,6 +343,8 @@ class QuadrupedEnv:
         _lib.check(self._L.gq_reset(self._hbatch, mask.data_ptr(), None if qpos is None else qpos.data_ptr(),
                                     None if qvel is None else qvel.data_ptr(), C.byref(cfg), self._st, self._out,
                                     self._episode.data_ptr(), self._lift_failed.data_ptr(), stream), 'gq_reset')
+        self._launches += 1
+        self._note_step()
         if 'reset' in self.base_vel_command_type:
             mb = mask.view(torch.bool)
             nxt = torch.randint(1000, 3000, (self.num_envs,), generator=self._gen, device=self.device, dtype=torch.int32)

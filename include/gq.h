@@ -276,6 +276,12 @@ int gq_heightmap(GqBatch* b, const double* center, const float* yaw, int rows, i
  * name in {"M","qfrc_bias","qfrc_smooth","qacc_smooth","qfrc_constraint","efc_J","efc_aref","efc_R","efc_b",
  * "efc_force","efc_type","contact_dist","contact_geom","xpos","xmat","geom_xpos"}; returns count written. */
 int gq_debug_enable(GqBatch* b, int enable);
+/* The same records where they live: device pointer to the [n_envs][stride] float block the instrumented kernel fills
+ * (NULL while disabled), and offset / length of a named field inside one record.  This is what backs the reference's
+ * on-demand getters that read mjData after a step - mj_fullM (legs_mass_matrix :881, get_base_inertia :543),
+ * qfrc_bias (:895), body(i).xpos (hip_positions :564), mj_jac (feet_jacobians :681) - without a host round trip. */
+int gq_debug_device_buffer(GqBatch* b, float** dev, int32_t* n_envs, int32_t* stride);
+int gq_debug_field(const char* name, int32_t* offset, int32_t* count);
 int gq_debug_get(GqBatch* b, int env, const char* name, double* out, int max_n);
 
 #ifdef __cplusplus

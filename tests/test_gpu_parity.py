@@ -299,3 +299,65 @@ def test_sensors_imu_and_heightmap_on_gpu():
             for j in range(4):
                 off = R.T @ np.array([0.1 * (2 - i), 0.2 * (2 - j) - 0.1])
                 assert np.abs(d[e, i, j, :2] - (c[e, :2] + off)).max() < 1e-4 + 1e-7 * np.abs(c[e, :2]).max()
+
+
+def test_mpc_accessors_match_oracle():
+    """The reference's on-demand getters (quadruped_env.py:488-1016) as batched views: observation-backed ones
+    (accessors=True) and the ones that read MuJoCo internals of the last forward pass (mj_fullM, qfrc_bias, mj_jac,
+    body xpos, subtree_com) from the kernel's inspection record on the device - against the fp64 oracle."""
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    from oracle.oracle import Oracle
+    n = 24
+    env = QuadrupedEnv('aliengo', state_obs_names=('qpos', 'qvel'), num_envs=n, solver='newton', accessors=True, seed=3)
+    env.reset(random=True)
+    with pytest.raises(Exception):
+        QuadrupedEnv('aliengo', state_obs_names=('qpos',), num_envs=2).base_lin_vel('base')   # not assembled, no accessors
+    _ = None
+    try:
+        env.legs_mass_matrix          # first use: switches the instrumented kernel on, record still empty
+    except Exception as e:
+        _ = e
+    assert _ is not None
+    g = torch.Generator(device='cuda:0').manual_seed(0)
+    for _ in range(30):
+        act = torch.randn(n, 12, generator=g, device='cuda:0') * 15
+        q0, v0, w0 = env.qpos.cpu().numpy().copy(), env.qvel.cpu().numpy().copy(), env._warm.cpu().numpy().copy()
+        fr = env._friction.cpu().numpy().copy()
+        obs, *_rest = env.step(act)
+    torch.cuda.synchronize()
+    md = env.mjModel
+    o = Oracle(marshalled('aliengo', solver=1, iterations=100, tolerance=1e-12))
+    M_legs, bias, Jp = env.legs_mass_matrix, env.legs_qfrc_bias, env.feet_jacobians('world')
+    Jb, Jrb = env.feet_jacobians('base', return_rot_jac=True)
+    hips, com, Ib = env.hip_positions('world'), env.com, env.get_base_inertia()
+    fp_w, fv_b = env.feet_pos('world'), env.feet_vel('base', relative=True)
+    cs, _, grf = env.feet_contact_state('world', ground_reaction_forces=True)
+    X = env.base_configuration
+    a = act.cpu().numpy()
+    for e in range(n):
+        o.set_state(q0[e], v0[e], w0[e], np.zeros(18), 0.0, float(fr[e])); o.step(a[e].astype(np.float64))
+        M = o.M
+        ref, _t, _i = o.get_obs(ALL_OBS, env._cmd[e].cpu().numpy())
+        for k, leg in enumerate(('FL', 'FR', 'RL', 'RR')):
+            idx = env.legs_qvel_idx[leg]
+            np.testing.assert_allclose(M_legs[leg][e].cpu().numpy(), M[np.ix_(idx, idx)], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(bias[leg][e].cpu().numpy(), o.qfrc_bias[idx], rtol=1e-3, atol=2e-3)
+            g_id = md.geom_names.index(env.robot_cfg.feet_geom_names[leg])
+            jp, jr = o.jac(o.geom_xpos[g_id], int(md.geom_bodyid[g_id]))
+            np.testing.assert_allclose(Jp[leg][e].cpu().numpy(), jp, atol=2e-5)
+            Rb = o.xmat[1]
+            np.testing.assert_allclose(Jb[leg][e].cpu().numpy(), Rb.T @ jp, atol=2e-5)
+            np.testing.assert_allclose(Jrb[leg][e].cpu().numpy(), Rb.T @ jr, atol=2e-5)
+            hip_b = md.body_names.index(f'{leg}_hip')
+            np.testing.assert_allclose(hips[leg][e].cpu().numpy(), o.xpos[hip_b], atol=5e-6 * max(1.0, np.abs(o.xpos[hip_b]).max()))
+            sl = slice(3 * k, 3 * k + 3)
+            np.testing.assert_allclose(fp_w[leg][e].cpu().numpy(), ref['feet_pos'][sl], atol=5e-6 * max(1.0, np.abs(ref['feet_pos']).max()))
+            np.testing.assert_allclose(fv_b[leg][e].cpu().numpy(), ref['feet_vel_rel:base'][sl], atol=2e-3 * max(1.0, np.abs(ref['feet_vel_rel:base']).max()))
+            np.testing.assert_allclose(grf[leg][e].cpu().numpy(), ref['contact_forces'][sl], atol=2e-3 * max(1.0, np.abs(ref['contact_forces']).max()))
+            assert bool(cs[leg][e]) == bool(ref['contact_state'][k])
+        np.testing.assert_allclose(Ib[e].cpu().numpy(), M[3:6, 3:6], rtol=1e-4, atol=1e-6)
+        sc = o.get('subtree_com').reshape(-1, 3)
+        com_ref = (np.asarray(md.body_mass)[:, None] * sc).sum(0) / np.asarray(md.body_mass).sum()
+        np.testing.assert_allclose(com[e].cpu().numpy(), com_ref, atol=5e-6 * max(1.0, np.abs(com_ref).max()))
+        np.testing.assert_allclose(X[e, :3, :3].cpu().numpy().ravel(), ref['base_ori_SO3'], atol=1e-5)
+        np.testing.assert_allclose(env.base_lin_vel('base')[e].cpu().numpy(), ref['base_lin_vel:base'], atol=1e-4)

@@ -134,3 +134,16 @@ def test_dev_model_lowering_rejects_unsupported_models():
     q = np.tile(mm.md.key_qpos[0], (1, 1))
     with pytest.raises(RuntimeError, match='elliptic'):
         emu_step(mm, np.zeros((1, 12)), q, np.zeros((1, 18)))
+
+
+def test_reference_getter_surface_is_present():
+    """Every public getter of the reference class (quadruped_env.py:488-1016) exists on the batched class (callable on a
+    GPU box only); render / ghost / key-callback are viewer code and out of scope."""
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    for name in ('target_base_vel', 'base_lin_vel', 'base_lin_vel_err', 'base_ang_vel_err', 'base_ang_vel', 'base_lin_acc',
+                 'get_base_inertia', 'hip_positions', 'feet_pos', 'feet_vel', 'feet_jacobians', 'feet_contact_state', 'close',
+                 'legs_mass_matrix', 'legs_qfrc_bias', 'legs_qfrc_passive', 'com', 'kinetic_energy', 'work',
+                 'base_configuration', 'joint_space_state', 'base_pos', 'base_ori_euler_xyz', 'heading_orientation_SO3',
+                 'torque_ctrl_setpoint', 'gravity_vector', 'simulation_dt', 'simulation_time', 'robot_model',
+                 'get_hyperparameters', 'step', 'reset'):
+        assert hasattr(QuadrupedEnv, name), name
