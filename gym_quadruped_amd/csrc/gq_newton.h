@@ -373,10 +373,21 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     float gd = 0.0f, gterm = 0.0f;
     if (lane < GQ_NVD) {
       /* friction-loss rows are e_dof: their force lands on one dof, only limit / contact rows are walked */
-      float s0 = fl_row >= 0 ? W.force[fl_row] : 0.0f, s1 = 0.0f;
-      int r = nfl;
-      for (; r + 2 <= nefc; r += 2) { s0 += W.u.B[r][lane] * W.force[r]; s1 += W.u.B[r + 1][lane] * W.force[r + 1]; }
-      if (r < nefc) s0 += W.u.B[r][lane] * W.force[r];
+      /* rows in chunks of four, all eight LDS reads of a chunk in flight together (one LDS latency per chunk instead of
+       * one per row); rows past nefc hold zero forces (lanes >= nefc write 0) and row indices stay below 64 */
+      float s0 = fl_row >= 0 ? W.force[fl_row] : 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+      if constexpr (!CONE) { /* pyramidal models: mostly 0-8 contact rows, the two-row walk is cheaper there */
+        int r = nfl;
+        for (; r + 2 <= nefc; r += 2) { s0 += W.u.B[r][lane] * W.force[r]; s1 += W.u.B[r + 1][lane] * W.force[r + 1]; }
+        if (r < nefc) s0 += W.u.B[r][lane] * W.force[r];
+      } else
+      for (int r = nfl; r < nefc; r += 4) {
+        const int r1 = r + 1 < 64 ? r + 1 : 63, r2 = r + 2 < 64 ? r + 2 : 63, r3 = r + 3 < 64 ? r + 3 : 63;
+        const float b0 = W.u.B[r][lane], b1 = W.u.B[r1][lane], b2 = W.u.B[r2][lane], b3 = W.u.B[r3][lane];
+        const float f0 = W.force[r], f1 = r + 1 < nefc ? W.force[r1] : 0.0f, f2 = r + 2 < nefc ? W.force[r2] : 0.0f, f3 = r + 3 < nefc ? W.force[r3] : 0.0f;
+        s0 += b0 * f0; s1 += b1 * f1; s2 += b2 * f2; s3 += b3 * f3;
+      }
+      s0 += s2; s1 += s3;
       gd = md - (s0 + s1);
       gterm = md * md + (s0 + s1) * (s0 + s1);
     }
@@ -455,13 +466,24 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
           if (fr >= 0) s0 += W.force[fr];
           for (int r = nfl; r < nsingle; r++) s1 += W.force[r] * W.u.B[r][da] * W.u.B[r][da];
         }
-        int r = nsingle;
-        for (; r + 2 <= nrowh; r += 2) {
-          s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
-          s1 += W.force[r + 1] * W.u.B[r + 1][da] * W.u.B[r + 1][db];
+        float s2 = 0.0f, s3 = 0.0f;
+        if constexpr (!CONE) {
+          int r = nsingle;
+          for (; r + 2 <= nrowh; r += 2) {
+            s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
+            s1 += W.force[r + 1] * W.u.B[r + 1][da] * W.u.B[r + 1][db];
+          }
+          if (r < nrowh) s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
+        } else
+        for (int r = nsingle; r < nrowh; r += 4) { /* chunks of four rows: twelve LDS reads in flight per chunk */
+          const int r1 = r + 1 < 64 ? r + 1 : 63, r2 = r + 2 < 64 ? r + 2 : 63, r3 = r + 3 < 64 ? r + 3 : 63;
+          const float w0 = W.force[r], w1 = r + 1 < nrowh ? W.force[r1] : 0.0f, w2 = r + 2 < nrowh ? W.force[r2] : 0.0f,
+                      w3 = r + 3 < nrowh ? W.force[r3] : 0.0f;
+          const float a0 = W.u.B[r][da], a1 = W.u.B[r1][da], a2 = W.u.B[r2][da], a3 = W.u.B[r3][da];
+          const float c0 = W.u.B[r][db], c1 = W.u.B[r1][db], c2 = W.u.B[r2][db], c3 = W.u.B[r3][db];
+          s0 += w0 * a0 * c0; s1 += w1 * a1 * c1; s2 += w2 * a2 * c2; s3 += w3 * a3 * c3;
         }
-        if (r < nrowh) s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
-        const float hv = s0 + s1;
+        const float hv = (s0 + s1) + (s2 + s3);
         if (slot < 108) W.u2.n.Hc[slot / 9][slot % 9] = hv;
         else { W.u2.n.Hb[da][db] = hv; W.u2.n.Hb[db][da] = hv; }
       }
