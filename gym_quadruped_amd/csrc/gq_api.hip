@@ -264,6 +264,12 @@ static const struct { const char* name; int off, n; } kDbg[] = {
     {"contact_dist", GQ_DBG_CON_DIST, GQ_MAXCON}, {"contact_geom", GQ_DBG_CON_GEOM, GQ_MAXCON},
     {"foot_pos", GQ_DBG_FOOT_POS, 12}, {"qacc", GQ_DBG_QACC, 18}, {"timer", GQ_DBG_TIMER, 32}, {"record", 0, GQ_DBG_SIZE}};
 
+int gq_debug_stop_stage(GqBatch* b, int stage) {
+  if (!b) { SET_ERR("gq_debug_stop_stage: null batch"); return GQ_EINVAL; }
+  b->stop_stage = stage;
+  return GQ_OK;
+}
+
 int gq_debug_field(const char* name, int32_t* offset, int32_t* count) {
   if (!name || !offset || !count) { SET_ERR("gq_debug_field: null argument"); return GQ_EINVAL; }
   for (const auto& f : kDbg)

@@ -13,7 +13,7 @@ namespace gq {
  * then the reset's own mj_step as a second pass through step_wave; no extra launches, but the launch lasts as long as
  * its two-pass waves.  Next-step mode: the env waits (pending flag) and spends its next launch on reset_wave + the
  * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
-template <int SOLVER, bool DBG, bool CONE>
+template <int SOLVER, int MODE, bool CONE>
 __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
   if (c.mask && !c.mask[blockIdx.x]) return; /* wave-uniform */
   __shared__ WaveMem W;
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __res
       reset_wave(A->r, W);
       pass = c.auto_reset;
     }
-    const int term = step_wave<SOLVER, DBG, CONE>(A->s, c, W, pass);
+    const int term = step_wave<SOLVER, MODE, CONE>(A->s, c, W, pass);
     if (pass != 0 || c.auto_reset != 1 || !term) break;
     respawn = true;
   }
@@ -66,11 +66,15 @@ extern "C" void gq_launch_heightmap(const double* center, const float* yaw, int 
 }
 
 extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, hipStream_t stream) {
-  const bool dbg = c->debug != nullptr || c->stop_stage != 0; /* debug record / stage timers / stage cut: instrumented variant */
-#define GQ_LAUNCH(S, D, C) hipLaunchKernelGGL((gq::step_kernel<S, D, C>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c)
-  if (solver == 1 && cone) { if (dbg) GQ_LAUNCH(1, true, true); else GQ_LAUNCH(1, false, true); }
-  else if (solver == 1) { if (dbg) GQ_LAUNCH(1, true, false); else GQ_LAUNCH(1, false, false); }
-  else { if (dbg) GQ_LAUNCH(0, true, false); else GQ_LAUNCH(0, false, false); }
+  /* 0: production; 1: debug record + stage timers; 2: stage cut (GQ_STOP_STAGE / gq_debug_stop_stage) - the early returns
+   * of the cut cost the production kernel ~8 % when merely compiled in, hence a variant of their own */
+  const int mode = c->debug != nullptr ? 1 : (c->stop_stage != 0 ? 2 : 0);
+#define GQ_LAUNCH(S, M, C) hipLaunchKernelGGL((gq::step_kernel<S, M, C>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c)
+#define GQ_LAUNCH_MODE(S, C) do { if (mode == 1) GQ_LAUNCH(S, 1, C); else if (mode == 2) GQ_LAUNCH(S, 2, C); else GQ_LAUNCH(S, 0, C); } while (0)
+  if (solver == 1 && cone) GQ_LAUNCH_MODE(1, true);
+  else if (solver == 1) GQ_LAUNCH_MODE(1, false);
+  else GQ_LAUNCH_MODE(0, false);
+#undef GQ_LAUNCH_MODE
 #undef GQ_LAUNCH
 }
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream) {

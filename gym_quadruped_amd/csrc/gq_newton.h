@@ -337,7 +337,9 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
       da = i; db = q - i * (i + 1) / 2;
       slot = 108 + 6 * da + db;
     }
-    hent[pass] = e < 117 ? (da | (db << 8) | (slot << 16)) : -1;
+    /* bits 24-30: 1 + friction-loss row of a diagonal entry's dof (0: none) - read from the model once, not per iteration */
+    const int frp1 = (e < 117 && da == db) ? m.fl_row_of_dof[da] + 1 : 0;
+    hent[pass] = e < 117 ? (da | (db << 8) | (slot << 16) | (frp1 << 24)) : -1;
   }
   long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = (DBG && tdbg) ? cycles() : 0;
 #define NW_T(i) do { if constexpr (DBG) if (tdbg) { const long long tn = cycles(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
@@ -459,10 +461,10 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       if (hent[pass] >= 0) {
-        const int da = hent[pass] & 0xff, db = (hent[pass] >> 8) & 0xff, slot = hent[pass] >> 16;
+        const int da = hent[pass] & 0xff, db = (hent[pass] >> 8) & 0xff, slot = (hent[pass] >> 16) & 0xff;
         float s0 = slot < 108 ? W.Mc[slot / 9][slot % 9] : W.Mb[da][db], s1 = 0.0f;
         if (da == db) {
-          const int fr = m.fl_row_of_dof[da];
+          const int fr = (hent[pass] >> 24) - 1;
           if (fr >= 0) s0 += W.force[fr];
           for (int r = nfl; r < nsingle; r++) s1 += W.force[r] * W.u.B[r][da] * W.u.B[r][da];
         }

@@ -145,17 +145,19 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
 /* One mj_step + observation epilogue for this wave's env.  pass 0: the user's step.  pass 1: the reset's own step
  * (zero control, friction committed afterwards, termination flags of pass 0 are kept).  pass 2: the reset's own step of
  * a next-step auto-reset (as pass 1, flags cleared).  Returns `terminated`. */
-/* SOLVER 0: PGS (mj_solPGS), 1: Newton (mj_solNewton, MuJoCo's default).  DBG: the variant with the debug record, the
+/* SOLVER 0: PGS (mj_solPGS), 1: Newton (mj_solNewton, MuJoCo's default).  MODE 0: production; 2: production + the
+ * GQ_STOP_STAGE cut; 1 (DBG): the variant with the debug record, the
  * stage timers and the GQ_STOP_STAGE cut compiled in - the production variant carries none of it (no timer
  * accumulators or row data kept live for the record: they cost registers inside the solver loop).
  * CONE: elliptic friction cones (Newton only): contacts take dim rows [n, t1, t2, torsion, roll1, roll2]. */
-template <int SOLVER, bool DBG, bool CONE>
+template <int SOLVER, int MODE, bool CONE>
 __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
   int lane_o = lane_id(), env_o = (int)blockIdx.x;
   opaque(lane_o); opaque_s(env_o);
   const int lane = lane_o, env = env_o;
+  constexpr bool DBG = MODE == 1;
   const GqDevModel& m = *a.model;
   const float h = m.timestep;
   /* the record describes the forward pass whose results the caller sees: the user's step, the reset's own step of
@@ -164,8 +166,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   const bool timing = DBG && call.debug && rec_pass && env < a.batch->debug_envs;
   const long long t_start = timing ? cycles() : 0;
 #define GQ_TICK(i) do { if constexpr (DBG) { \
-    if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); \
-    if (call.stop_stage == (i) && pass == 0) return 0; } } while (0)
+    if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); } \
+    if constexpr (MODE == 2) { if (call.stop_stage == (i) && pass != 1) return 0; } } while (0)
 
   /* ================================================================ S0: load the env's state rows */
   if (lane < 19) {
@@ -182,7 +184,6 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   }
   if (lane < 12) W.ctrl[lane] = (call.ctrl && pass == 0) ? call.ctrl[(size_t)env * 12 + lane] : 0.0f;
   if (lane < 4) W.cmd[lane] = a.cmd ? a.cmd[(size_t)env * 4 + lane] : 0.0f;
-  const float mu_env = a.friction ? a.friction[env] : -1.0f;
   wave_barrier();
 
   stage_kinematics(W, m);
@@ -338,6 +339,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     const float* solimp = m.foot_solimp[0];
     if (lane < nitem) {
       code = m.con_order[lane];
+      const float mu_env = a.friction ? a.friction[env] : -1.0f; /* wave-uniform scalar load, issued here so that it is not live from S0 */
       const float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0];
       if (code < 4) {
         const int k = code;
@@ -413,7 +415,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     }
   }
   wave_barrier();
-  const int nefc = W.nefc, ncon = W.ncon, nlim = W.nlim, nfl = m.nfl;
+  const int nefc = uniform(W.nefc), ncon = uniform(W.ncon), nlim = uniform(W.nlim), nfl = m.nfl; /* SGPRs */
   if (timing) { /* body poses go to the debug record now: xmat's LDS is reused by the Newton solver */
     float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
     if (lane < 39) D[GQ_DBG_XPOS + lane] = W.xpos[lane / 3][lane % 3];
@@ -467,6 +469,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       /* torsional / rolling coefficients: same mixing rule as the sliding one (S6), _set_ground_friction overrides
        * floor and feet with [mu, 0.005, 0.0]; clamped at mjMINMU */
       const int code = W.con_geom[c];
+      const float mu_env = a.friction ? a.friction[env] : -1.0f;
       const int rule = code < 4 ? m.foot_fric_rule[code] : m.lg[code - 4].fric_rule;
       float fr[3] = {mu, 0.0f, 0.0f};
 #pragma unroll
@@ -491,7 +494,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       rdiag_first = rdiag;
       rmu = mu / sqrtf(m.impratio);
     }
-    w = cross(ld3(W.con_pos[c]) - O, dir);
+    w = cross(ld3(W.con_pos[c]) - v3(0.0f, 0.0f, W.basez), dir); /* O re-read: not kept live across the stages */
     if (rotational) { w = dir; dir = v3(0.0f, 0.0f, 0.0f); } /* torsion / rolling rows act on the angular Jacobian */
     jcon = true;
     if (body > 0) { jleg = (body - 1) / 3; jdepth = (body - 1) % 3; }
@@ -824,7 +827,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     for (int d = 6 + 3 * leg; d < 9 + 3 * leg; d++)
 #pragma unroll
       for (int k = 0; k < 6; k++) sv[k] += W.cdof[d][k] * W.qvel[d];
-    V3 fv = ld3(sv + 3) + cross(ld3(sv), pw - O);
+    V3 fv = ld3(sv + 3) + cross(ld3(sv), pw - v3(0.0f, 0.0f, W.basez));
     /* world position of the foot: old base x/y + relative.  feet_pos:base uses the NEW base pose (quirk B3) */
     V3 pworld = v3((float)(bx_d + (double)pw.x), (float)(by_d + (double)pw.y), pw.z);
     V3 prel_new = v3(pw.x - h * W.qvel[0], pw.y - h * W.qvel[1], pw.z - znew);

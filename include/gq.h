@@ -281,6 +281,9 @@ int gq_debug_enable(GqBatch* b, int enable);
  * on-demand getters that read mjData after a step - mj_fullM (legs_mass_matrix :881, get_base_inertia :543),
  * qfrc_bias (:895), body(i).xpos (hip_positions :564), mj_jac (feet_jacobians :681) - without a host round trip. */
 int gq_debug_device_buffer(GqBatch* b, float** dev, int32_t* n_envs, int32_t* stride);
+/* profiling aid (tools/stage_cuts.py): the following gq_step launches return after stage marker `stage` (0 = run
+ * everything; the environment variable GQ_STOP_STAGE sets the initial value).  Markers <= 10 have no side effects. */
+int gq_debug_stop_stage(GqBatch* b, int stage);
 int gq_debug_field(const char* name, int32_t* offset, int32_t* count);
 int gq_debug_get(GqBatch* b, int env, const char* name, double* out, int max_n);
 
