@@ -80,6 +80,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(readlane<15>(v), readlane<31>(v)), fmaxf(readlane<47>(v), readlane<63>(v)));
 }
 
+/* sum over the four lanes of the lane's quad, result in all four (two quad_perm DPP butterflies: [1,0,3,2], [2,3,0,1]) */
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_mov_self<0xB1>(v);
+  v += dpp_mov_self<0x4E>(v);
+  return v;
+}
+
 /* optimisation barrier: the value becomes opaque to the compiler (no code is emitted) */
 __device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
 template <class T> __device__ __forceinline__ const T* opaque_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; } /* per-lane pointer */

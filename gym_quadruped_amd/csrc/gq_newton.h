@@ -131,6 +131,125 @@ __device__ inline void factor_tree_one(WaveMem& W, const float (*Sc)[9], const f
   wave_barrier();
 }
 
+/* out <- S^-1 g for a tree-sparse symmetric positive definite S (Mc/Mb layout) + h_d * damping on the diagonal: Gaussian
+ * elimination and back-substitution fused, entirely in the registers of lanes 0-3.  Lane L eliminates calf, thigh and hip
+ * of leg L from the augmented system (S | g); the four Schur contributions to the 6x6 base block and its right-hand side
+ * are summed across the quad with DPP (no LDS, no barrier); every one of the four lanes then solves the same 6x6 system
+ * redundantly, so the base solution is already where the back-substitution of each leg needs it.  The factor is never
+ * stored: each system is solved for exactly one right-hand side (Newton search direction, qacc_smooth, the Euler
+ * system), which is what made storing L and D in LDS, re-reading them and three barriers per solve pure latency.
+ * g and out: LDS [18], may alias. */
+template <bool DAMP>
+__device__ inline void solve_tree_fused(const float (*Sc)[9], const float (*Sb)[6], const float* damping, float hd,
+                                        const float* g, float* out) {
+  const int lane = lane_id();
+  { /* every lane runs the same instruction stream (lanes >= 4 mirror leg 0 and are discarded at the end): no branch, and the
+     * cross-lane sums are called from wave-uniform control flow */
+    const int hh = 3 * (lane < 4 ? lane : 0), t = hh + 1, c = hh + 2; /* joint indices of the leg (dof = 6 + joint) */
+    float rc[9], rt[8], rh[7], bb[21], gb[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { rc[j] = Sc[c][j]; rt[j] = Sc[t][j]; rh[j] = Sc[hh][j]; }
+    rc[6] = Sc[c][6]; rc[7] = Sc[c][7]; rc[8] = Sc[c][8];
+    rt[6] = Sc[t][6]; rt[7] = Sc[t][7];
+    rh[6] = Sc[hh][6];
+    if constexpr (DAMP) { rc[8] += hd * damping[6 + c]; rt[7] += hd * damping[6 + t]; rh[6] += hd * damping[6 + hh]; }
+    float gc = g[6 + c], gt = g[6 + t], gh = g[6 + hh];
+    /* base block and right-hand side: lane 0 carries S_bb and g_b, the others start from zero (summed below) */
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      gb[i] = lane == 0 ? g[i] : 0.0f;
+#pragma unroll
+      for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] = lane == 0 ? Sb[i][j] + ((DAMP && i == j) ? hd * damping[i] : 0.0f) : 0.0f;
+    }
+    /* eliminate the calf: rows thigh, hip, base */
+    const float ic = fast_rcp(rc[8]);
+    {
+      float f = rc[7] * ic;
+#pragma unroll
+      for (int j = 0; j <= 7; j++) rt[j] -= rc[j] * f;
+      gt -= gc * f;
+      f = rc[6] * ic;
+#pragma unroll
+      for (int j = 0; j <= 6; j++) rh[j] -= rc[j] * f;
+      gh -= gc * f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        f = rc[i] * ic;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rc[j] * f;
+        gb[i] -= gc * f;
+      }
+    }
+    const float it = fast_rcp(rt[7]);
+    {
+      float f = rt[6] * it;
+#pragma unroll
+      for (int j = 0; j <= 6; j++) rh[j] -= rt[j] * f;
+      gh -= gt * f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        f = rt[i] * it;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rt[j] * f;
+        gb[i] -= gt * f;
+      }
+    }
+    const float ih = fast_rcp(rh[6]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const float f = rh[i] * ih;
+#pragma unroll
+      for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rh[j] * f;
+      gb[i] -= gh * f;
+    }
+    /* Schur complement of the base: sum of the four legs */
+#pragma unroll
+    for (int q = 0; q < 21; q++) bb[q] = quad_sum(bb[q]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) gb[i] = quad_sum(gb[i]);
+    /* 6x6 base system, redundantly on each of the four lanes: elimination from the last row up (same order as the tree) */
+    float xb[6];
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+      const float inv = fast_rcp(bb[k * (k + 1) / 2 + k]);
+#pragma unroll
+      for (int i = 0; i < k; i++) {
+        const float f = bb[k * (k + 1) / 2 + i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= bb[k * (k + 1) / 2 + j] * f;
+        gb[i] -= gb[k] * f;
+      }
+      gb[k] *= inv; /* gb[k] now holds (g_k - sum_{j<k} S_kj x_j ... ) / S_kk once the x_j below are known */
+      bb[k * (k + 1) / 2 + k] = inv;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      float s = gb[k];
+#pragma unroll
+      for (int j = 0; j < k; j++) s -= bb[k * (k + 1) / 2 + j] * bb[k * (k + 1) / 2 + k] * xb[j];
+      xb[k] = s;
+    }
+    /* back-substitution up the leg: hip, thigh, calf */
+    float xh = gh, xt = gt, xc = gc;
+#pragma unroll
+    for (int j = 0; j < 6; j++) xh -= rh[j] * xb[j];
+    xh *= ih;
+#pragma unroll
+    for (int j = 0; j < 6; j++) xt -= rt[j] * xb[j];
+    xt = (xt - rt[6] * xh) * it;
+#pragma unroll
+    for (int j = 0; j < 6; j++) xc -= rc[j] * xb[j];
+    xc = (xc - rc[6] * xh - rc[7] * xt) * ic;
+    wave_barrier(); /* g may alias out: every lane has read its right-hand side */
+    if (lane < 4) { out[6 + hh] = xh; out[6 + t] = xt; out[6 + c] = xc; }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) out[j] = xb[j];
+    }
+  }
+  wave_barrier();
+}
+
 /* single right-hand side solve, leg-parallel: out <- (L'DL)^-1 g ; g, out: LDS [18] (may alias) */
 __device__ inline void solve_tree_one(WaveMem& W, const float* F, const float* g, float* out) {
   const int lane = lane_id();
@@ -492,9 +611,8 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
     }
     wave_barrier();
     NW_T(3);
-    factor_tree_one(W, W.u2.n.Hc, W.u2.n.Hb, W.F[0]);
+    solve_tree_fused<false>(W.u2.n.Hc, W.u2.n.Hb, nullptr, 0.0f, grad, search);
     NW_T(4);
-    solve_tree_one(W, W.F[0], grad, search);
     NW_T(5);
     /* ---- exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on phi' */
     float v = 0.0f;

