@@ -169,6 +169,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); } \
     if constexpr (MODE == 2) { if (call.stop_stage == (i) && pass != 1) return 0; } } while (0)
 
+  GQ_TICK(15); /* marker 15: nothing done yet - the launch floor */
   /* ================================================================ S0: load the env's state rows */
   if (lane < 19) {
     double q = a.qpos[(size_t)env * 19 + lane];
@@ -720,10 +721,16 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     W.warm[0] = acc_s.x; W.warm[1] = acc_s.y; W.warm[2] = acc_s.z; W.warm[3] = gyr_s.x; W.warm[4] = gyr_s.y; W.warm[5] = gyr_s.z;
   }
 
+  /* mj_checkAcc: a non-finite or absurd acceleration (|qacc| >= 1e10, MuJoCo's mjMAXVAL) means the simulation diverged.
+   * MuJoCo resets the data and warns; here the env is frozen for this step (zero acceleration) and flagged terminated +
+   * truncated, so that an auto-resetting batch re-spawns it and a NaN never reaches the next step */
+  const bool diverged = ballot(lane < GQ_NVD && !(fabsf(W.qacc[lane]) < 1e10f && fabsf(W.qacc_int[lane]) < 1e10f)) != 0;
   /* semi-implicit Euler (mj_Euler): velocity with the damped system, then positions with the new velocity */
   float vnew = 0.0f;
   if (lane < GQ_NVD) {
+    if (diverged) { W.qacc[lane] = 0.0f; W.qacc_int[lane] = 0.0f; }
     vnew = W.qvel[lane] + h * W.qacc_int[lane];
+    if (!(fabsf(vnew) < 1e10f)) vnew = 0.0f;
     a.qvel[(size_t)env * 18 + lane] = vnew;
     a.qacc[(size_t)env * 18 + lane] = W.qacc[lane];
     a.warm[(size_t)env * 18 + lane] = W.qacc[lane];
@@ -890,12 +897,12 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   {
     const bool oob = bxn_d > m.terrain_limits[0] || bxn_d < m.terrain_limits[1] || byn_d > m.terrain_limits[2] ||
                      byn_d < m.terrain_limits[3];
-    terminated = W.invalid || oob;
+    terminated = W.invalid || oob || diverged;
     if (lane == 0) {
       if (pass == 0) { /* the flags of the user's step survive an in-kernel auto-reset */
         a.invalid_contact[env] = (uint8_t)W.invalid;
         a.terminated[env] = (uint8_t)terminated;
-        a.truncated[env] = 0;
+        a.truncated[env] = (uint8_t)diverged;
       } else if (pass == 2) { /* reset() reports no termination (quadruped_env.py:406 returns the observation only) */
         a.invalid_contact[env] = 0; a.terminated[env] = 0; a.truncated[env] = 0;
       }

@@ -215,3 +215,15 @@ def test_elliptic_cone_step_matches_converged_oracle(robot):
         for k in ('contact_forces:base', 'contact_forces', 'feet_vel', 'contact_state'):
             assert np.abs(got[k] - ref[k]).max() < 2e-3 * max(1.0, np.abs(ref[k]).max()), (e, k)
     assert nchecked >= n // 2 and ncon >= nchecked
+
+
+def test_divergence_guard_freezes_and_flags_the_env():
+    """mj_checkAcc analogue: a state whose acceleration is not finite must not propagate NaN - the env keeps a finite state,
+    and is flagged terminated + truncated (so that an auto-resetting batch re-spawns it); healthy envs are untouched."""
+    mm = marshalled('mini_cheetah', solver=1, iterations=20)
+    q = np.tile(mm.md.key_qpos[0], (2, 1)); q[:, 2] = 0.6
+    v = np.zeros((2, 18), np.float32); v[0, 8] = np.float32(3e19)      # absurd joint velocity -> Coriolis terms overflow
+    st = emu_step(mm, np.zeros((2, 12)), q, v)
+    assert st['terminated'].tolist() == [1, 0] and st['truncated'].tolist() == [1, 0]
+    assert np.isfinite(st['qpos']).all() and np.isfinite(st['qacc']).all()
+    assert np.isfinite(st['qvel'][1]).all() and np.isfinite(st['obs'][1]).all()
