@@ -187,6 +187,25 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   if (lane < 4) W.cmd[lane] = a.cmd ? a.cmd[(size_t)env * 4 + lane] : 0.0f;
   wave_barrier();
 
+  /* actuation (mj_fwdActuation: torque motors) and passive damping depend on ctrl / qvel and model constants only: done
+   * here, so that the (two-level dependent) model loads overlap with the kinematics instead of sitting on S5's path */
+  if (lane < GQ_NVD) {
+    float act = 0.0f;
+    if (lane >= 6) {
+      const int j = lane - 6, u = m.act_of_jnt[j];
+      if (u >= 0) {
+        float c = W.ctrl[u];
+        if (m.act_ctrllimited[j]) c = fminf(fmaxf(c, m.act_ctrlrange[j][0]), m.act_ctrlrange[j][1]);
+        if (m.act_forcelimited[j]) c = fminf(fmaxf(c, m.act_forcerange[j][0]), m.act_forcerange[j][1]);
+        act = m.act_gear[j] * c;
+      }
+      if (m.jnt_actfrclimited[j]) act = fminf(fmaxf(act, m.jnt_actfrcrange[j][0]), m.jnt_actfrcrange[j][1]);
+    }
+    W.act[lane] = act;
+    const float damp = m.dof_damping[lane];
+    if constexpr (SOLVER == 1) W.F[0][lane] = h * damp; /* the Newton path stores no factor: F keeps h*damping for the Euler system (S10) */
+    W.smooth[lane] = -damp * W.qvel[lane] + act + W.applied[lane];
+  }
   stage_kinematics(W, m);
 
   GQ_TICK(1);
@@ -308,20 +327,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     const float* f = W.u.dyn.cfrc[dof_body(lane)];
     float bias = s[0] * f[0] + s[1] * f[1] + s[2] * f[2] + s[3] * f[3] + s[4] * f[4] + s[5] * f[5];
     W.bias[lane] = bias;
-    /* actuation (mj_fwdActuation): torque motors */
-    float act = 0.0f;
-    if (lane >= 6) {
-      const int j = lane - 6, u = m.act_of_jnt[j];
-      if (u >= 0) {
-        float c = W.ctrl[u];
-        if (m.act_ctrllimited[j]) c = fminf(fmaxf(c, m.act_ctrlrange[j][0]), m.act_ctrlrange[j][1]);
-        if (m.act_forcelimited[j]) c = fminf(fmaxf(c, m.act_forcerange[j][0]), m.act_forcerange[j][1]);
-        act = m.act_gear[j] * c;
-      }
-      if (m.jnt_actfrclimited[j]) act = fminf(fmaxf(act, m.jnt_actfrcrange[j][0]), m.jnt_actfrcrange[j][1]);
-    }
-    W.act[lane] = act;
-    W.smooth[lane] = -m.dof_damping[lane] * W.qvel[lane] - bias + act + W.applied[lane];
+    W.smooth[lane] -= bias; /* passive + actuation + applied were put there right after S0 */
   }
 
   GQ_TICK(5);
@@ -652,7 +658,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
      * (M + h D) qacc_int = qfrc_smooth + qfrc_constraint is left */
     if (lane < GQ_NVD) W.act[lane] = W.smooth[lane] + W.qfrc_c[lane];
     wave_barrier();
-    solve_tree_fused<true>(W.Mc, W.Mb, m.dof_damping, h, W.act, W.qacc_int);
+    solve_tree_fused<true>(W.Mc, W.Mb, W.F[0], 1.0f, W.act, W.qacc_int); /* h*damping staged in LDS at S5: no model load on this path */
   } else {
   if (lane < GQ_NVD) { /* qfrc_constraint = J' f: four independent partial sums keep the LDS reads pipelined */
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
