@@ -112,7 +112,17 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     for (int k = 0; k < 2; k++) M.dof_solref[i][k] = (float)d->dof_solref[2 * i + k];
     for (int k = 0; k < 5; k++) M.dof_solimp[i][k] = (float)d->dof_solimp[5 * i + k];
     M.fl_row_of_dof[i] = -1;
-    if (d->dof_frictionloss[i] > 0) { M.fl_row_of_dof[i] = M.nfl; M.fl_dof[M.nfl++] = i; }
+    if (d->dof_frictionloss[i] > 0) {
+      /* mj_makeImpedance for a row with pos = margin = 0: imp = dmin (x = 0), R = (1 - imp) diagApprox / imp, B from solref */
+      const double* si = d->dof_solimp + 5 * i; const double* sr = d->dof_solref + 2 * i;
+      const double dmin = std::fmin(std::fmax(si[0], 0.0001), 0.9999), dmax = std::fmin(std::fmax(si[1], 0.0001), 0.9999);
+      const double width = std::fmax(1e-15, si[2]);
+      const double imp = (dmin == dmax || width <= 1e-15) ? 0.5 * (dmin + dmax) : dmin;
+      const double R = std::fmax(1e-15, (1.0 - imp) * d->dof_invweight0[i] / imp);
+      const double B = sr[0] > 0 ? 2.0 / std::fmax(1e-15, dmax * std::fmax(sr[0], 2.0 * d->timestep)) : -sr[1] / std::fmax(1e-15, dmax);
+      M.fl_row[M.nfl].dof = i; M.fl_row[M.nfl].R = (float)R; M.fl_row[M.nfl].B = (float)B; M.fl_row[M.nfl].floss = (float)d->dof_frictionloss[i];
+      M.fl_row_of_dof[i] = M.nfl; M.fl_dof[M.nfl++] = i;
+    }
   }
   for (int u = 0; u < d->nu; u++) {
     int j = d->actuator_trnid[u] - 1;

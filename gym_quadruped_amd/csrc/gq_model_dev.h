@@ -51,6 +51,10 @@ struct GqDevModel {
   float dof_solref[GQ_NVD][2], dof_solimp[GQ_NVD][5];
   int32_t fl_dof[GQ_NVD];        /* dofs that own a friction-loss row, compacted; nfl of them */
   int32_t fl_row_of_dof[GQ_NVD]; /* inverse map: friction-loss row of dof d, -1 if it has none */
+  /* friction-loss rows are state independent up to their velocity term (pos = margin = 0): R and the damping gain B of
+   * aref = -B vel are folded on the host (mj_makeImpedance at x = 0) - one 16-byte load per row instead of a three-level
+   * chain fl_dof -> dof -> solref / solimp */
+  struct { int32_t dof; float R, B, floss; } fl_row[GQ_NVD];
   /* motors, one per hinge dof slot (index = hinge 0..11), 0 gear if the joint is unactuated */
   int32_t act_of_jnt[GQ_NJ];     /* ctrl index driving hinge j, -1 none */
   float act_gear[GQ_NJ];

@@ -438,8 +438,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
    * only reads J from there) - no 18-register row is kept live across the row set-up; PGS keeps them in registers. */
   int rtype = ROW_NONE;
   float rpos = 0.0f, rmargin = 0.0f, rfloss = 0.0f, rdiag = 0.0f, rmu = 0.0f, rdiag_first = 0.0f;
-  const float* rsolref = m.dof_solref[0];
-  const float* rsolimp = m.dof_solimp[0];
+  float rsolref[2] = {0.02f, 1.0f}, rsolimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.0f}; /* copied per row kind: typed loads, no flat pointer */
+  float flR = 0.0f, flB = 0.0f; /* friction-loss rows: host-folded R and damping gain */
   /* elliptic rows (CONE): position in the contact and its dim, first row of the contact, friction coefficient of this
    * row (e >= 1), the contact's mu = friction_0 / sqrt(impratio) */
   int ecode = 0, er0 = lane;
@@ -449,14 +449,14 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   bool jcon = false;
   V3 dir = v3(0.0f, 0.0f, 0.0f), w = v3(0.0f, 0.0f, 0.0f);
   if (lane < nfl) {
-    const int d = m.fl_dof[lane];
-    rtype = ROW_FRICTION; rfloss = m.dof_frictionloss[d]; rdiag = m.dof_invweight0[d];
-    rsolref = m.dof_solref[d]; rsolimp = m.dof_solimp[d];
-    jd = d; jsgn = 1.0f;
+    rtype = ROW_FRICTION; rfloss = m.fl_row[lane].floss; flR = m.fl_row[lane].R; flB = m.fl_row[lane].B;
+    jd = m.fl_row[lane].dof; jsgn = 1.0f;
   } else if (lane < nfl + nlim) {
     const int r = lane - nfl, j = W.u2.c.lim_jnt[r], d = 6 + j;
     rtype = ROW_LIMIT; rpos = W.u2.c.lim_dist[r]; rmargin = m.jnt_margin[j]; rdiag = m.dof_invweight0[d];
-    rsolref = m.jnt_solref[j]; rsolimp = m.jnt_solimp[j];
+    rsolref[0] = m.jnt_solref[j][0]; rsolref[1] = m.jnt_solref[j][1];
+#pragma unroll
+    for (int q = 0; q < 5; q++) rsolimp[q] = m.jnt_solimp[j][q];
     jd = d; jsgn = W.u2.c.lim_side[r];
   } else if (lane < nefc) {
     int c = 0;
@@ -464,7 +464,10 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       if (lane >= W.con_row[q]) c = q;
     const int e = lane - W.con_row[c], dim = W.con_dim[c], body = W.con_body[c];
     const float mu = W.con_mu[c];
-    rpos = W.con_dist[c]; rmargin = W.con_inc[c]; rsolref = W.con_solref[c]; rsolimp = W.con_solimp[c];
+    rpos = W.con_dist[c]; rmargin = W.con_inc[c];
+    rsolref[0] = W.con_solref[c][0]; rsolref[1] = W.con_solref[c][1];
+#pragma unroll
+    for (int q = 0; q < 5; q++) rsolimp[q] = W.con_solimp[c][q];
     const float tran = m.body_invweight0[body][0];
     /* contact frame of a horizontal floor (mju_makeFrame): n = z, t1 = y, t2 = -x */
     dir = v3(0.0f, 0.0f, 1.0f);
@@ -520,7 +523,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     else J[k] = v;
   }
   float rR = 1.0f, raref = 0.0f;
-  if (rtype != ROW_NONE) {
+  if (rtype == ROW_FRICTION) { rR = flR; raref = -flB * vel; }
+  else if (rtype != ROW_NONE) {
     float imp = impedance(rsolimp, rpos, rmargin);
     rR = fmaxf(1e-15f, (1.0f - imp) * rdiag / imp);
     float dmax = fminf(fmaxf(rsolimp[1], 0.0001f), 0.9999f), K, B;
@@ -658,7 +662,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
      * (M + h D) qacc_int = qfrc_smooth + qfrc_constraint is left */
     if (lane < GQ_NVD) W.act[lane] = W.smooth[lane] + W.qfrc_c[lane];
     wave_barrier();
-    solve_tree_fused<true>(W.Mc, W.Mb, W.F[0], 1.0f, W.act, W.qacc_int); /* h*damping staged in LDS at S5: no model load on this path */
+    solve_tree_fused<true>(W.Mc, W.Mb, W.F[0], 1.0f, W.act, W.qacc_int); /* h*damping staged in LDS right after S0: no model load on this path */
   } else {
   if (lane < GQ_NVD) { /* qfrc_constraint = J' f: four independent partial sums keep the LDS reads pipelined */
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
