@@ -6,17 +6,19 @@
  * (gym_quadruped/quadruped_env.py:270-290): mjData.ctrl = action; mujoco.mj_step; _get_obs; reward;
  * termination checks.  The stages follow MuJoCo's mj_step (restated on the CPU in oracle/gq_oracle.c):
  *
- *   S1 kinematics          lanes 0-3 walk the 4 leg chains              (mj_kinematics)
+ *   S0 load                state rows -> LDS; actuation and passive damping (mj_fwdActuation, mj_passive)
+ *   S1 kinematics          lane = link local transforms, then lanes 0-3 compose the 4 leg chains (mj_kinematics)
  *   S2 spatial inertias    lane = body; composite = plain sums          (mj_comPos, mj_crb)
- *   S3 mass matrix         lane = dof                                   (mj_crb)
- *   S4 L'DL factorisation  lanes 0-3 = legs, then the 6x6 base block    (mj_factorM), M and M + h*D
- *   S5 bias forces         RNE, lanes 0-3 chains / lane = body          (mj_comVel, mj_rne, mj_passive)
+ *   S3 mass matrix         lane = dof, tree-sparse storage              (mj_crb)
+ *   S4 L'DL factorisation  PGS path only: lanes 0-3 = legs, 6x6 base block (mj_factorM), M and M + h*D
+ *   S5 bias forces         RNE, lanes 0-3 chains / lane = body          (mj_comVel, mj_rne)
  *   S6 collision           feet spheres + link vertex clouds vs floor   (mj_collision)
  *   S7 constraint rows     lane = row: J row, impedance, R, aref        (mj_makeConstraint, mj_makeImpedance)
- *   S8 dual operator       lane i solves M x = J_i' and owns row i of A = J M^-1 J' + R   (mj_projectConstraint)
- *   S9 PGS                 sequential rows, residual vector kept in lanes (mj_solPGS)
+ *   S8/S9 Newton (default) primal solve, fused register-resident elimination (gq_newton.h)   (mj_solNewton)
+ *   S8/S9 PGS              lane i solves M x = J_i' and owns row i of A = J M^-1 J' + R; sequential rows, residual kept
+ *                          in lanes                                     (mj_projectConstraint, mj_solPGS)
  *   S10 integration        semi-implicit Euler with implicit damping    (mj_Euler)
- *   S11 observations       ALL_OBS scalars assembled in LDS, gathered to the requested layout (_get_obs, _check_*)
+ *   S11 observations       ALL_OBS (+IMU) scalars assembled in LDS, gathered to the requested layout (_get_obs, _check_*)
  *
  * Spatial quantities are expressed in world-aligned axes about O = base-body origin (MuJoCo uses the subtree
  * centre of mass; M, bias forces and Jacobians are independent of that choice) and base x/y are removed from
@@ -74,7 +76,7 @@ enum {
 
 enum { ROW_NONE = 0, ROW_FRICTION = 1, ROW_LIMIT = 2, ROW_CONTACT1 = 3, ROW_PYRAMID = 4, ROW_ELLIPTIC = 5 };
 
-/* ------------------------------------------------------------------ per-wave LDS working set (8.5 KB: 16+ waves per CU)
+/* ------------------------------------------------------------------ per-wave LDS working set (10 196 B: 16 waves per CU fit the 160 KB)
  * `u` overlays three regions with disjoint lifetimes: the spatial-dynamics scratch (S1-S5), the half-batch of
  * B = M^-1 J' rows while the dual operator is built (S8), and the observation row (S11). */
 struct WaveDyn {
