@@ -119,6 +119,11 @@ class QuadrupedEnv(AccessorsMixin):
 
         # scene + model (reference :150-183)
         self.scene_desc, self.terrain_limits = generate_terrain(scene, self.robot_cfg.hip_height, seed=10)
+        if self.scene_desc.get('boxes'):
+            raise NotImplementedError(
+                f"scene '{scene}' is generated ({len(self.scene_desc['boxes'])} world boxes, spawn limits {self.terrain_limits}; "
+                f"gym_quadruped_amd.terrain.generate_terrain) but the step kernel has no box narrow phase yet (SURVEY.md §8f rank 2): "
+                f"only 'flat' can be simulated")
         self.mjModel: ModelDesc = (compile_mjcf(mjcf_path) if mjcf_path
                                    else load_compiled(Path(self.robot_cfg.mjcf_filename).stem))
         qpos0 = self.mjModel.qpos0.copy()

@@ -147,3 +147,31 @@ def test_reference_getter_surface_is_present():
                  'torque_ctrl_setpoint', 'gravity_vector', 'simulation_dt', 'simulation_time', 'robot_model',
                  'get_hyperparameters', 'step', 'reset'):
         assert hasattr(QuadrupedEnv, name), name
+
+
+def test_procedural_box_scenes_match_the_reference_generator():
+    """random_boxes / random_pyramids: same numpy draws in the same order as the reference's add_world_of_boxes /
+    add_world_of_pyramid -> the same boxes and spawn limits (golden: the reference's own generate_terrain, seed 10)."""
+    import json
+    from pathlib import Path
+    from gym_quadruped_amd.terrain import generate_terrain
+    gold = json.loads((Path(__file__).parent / 'golden' / 'terrain_boxes.json').read_text())
+    state = np.random.get_state()[1][:5].copy()
+    for key, ref in gold.items():
+        name, hip = key.split('@')
+        scene, lim = generate_terrain(name, float(hip), seed=10)
+        assert len(scene['boxes']) == len(ref['boxes']), key
+        np.testing.assert_allclose(lim, ref['terrain_limits'], rtol=0, atol=1e-12)
+        for b, r in zip(scene['boxes'], ref['boxes']):
+            np.testing.assert_allclose(b['pos'], r['pos'], atol=1e-12)
+            np.testing.assert_allclose(b['size'], r['size'], atol=1e-12)
+            np.testing.assert_allclose(b['quat'], r['quat'], atol=1e-12)
+    assert np.array_equal(np.random.get_state()[1][:5], state), 'the global numpy generator must be restored (local_seed)'
+    for name, nbox in (('ramp', 1), ('slippery', 2), ('stairs', 50)):
+        scene, lim = generate_terrain(name, 0.3)
+        assert len(scene['boxes']) == nbox and lim == (10000.0, -10000.0, 10000.0, -10000.0)
+    assert generate_terrain('slippery', 0.3)[0]['boxes'][0]['priority'] == 2
+    with pytest.raises(NotImplementedError):
+        generate_terrain('perlin', 0.3)
+    with pytest.raises(ValueError):
+        generate_terrain('moon', 0.3)
