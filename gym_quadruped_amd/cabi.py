@@ -42,6 +42,8 @@ class GqModelDesc(C.Structure):
         ('feet_geomid', C.c_int32 * GQ_NLEG), ('terrain_limits', C.c_double * 4), ('meaninertia', C.c_double),
         ('key_qpos', C.c_double * 19),
         ('solver', C.c_int32), ('iterations', C.c_int32), ('tolerance', C.c_double), ('noise_floor', C.c_double),
+        ('nbox', C.c_int32), ('box_pos', _D), ('box_mat', _D), ('box_size', _D), ('box_friction', _D), ('box_margin', _D),
+        ('box_gap', _D), ('box_solmix', _D), ('box_solref', _D), ('box_solimp', _D), ('box_condim', _I), ('box_priority', _I),
     ]
 
 
@@ -91,7 +93,7 @@ class MarshalledModel:
 
     def __init__(self, md: ModelDesc, *, qpos0=None, feet_geom_names=None, terrain_limits=(1e4, -1e4, 1e4, -1e4),
                  timestep=None, solver=SOLVER_PGS, iterations=100, tolerance=1e-8, floor=None,
-                 noise_floor=0.0):
+                 noise_floor=0.0, boxes=None):
         self.md = md
         self._keep = []
         d = GqModelDesc()
@@ -103,9 +105,19 @@ class MarshalledModel:
         d.gravity = (C.c_double * 3)(*md.gravity)
         d.cone, d.impratio, d.integrator = int(md.cone), float(md.impratio), int(md.integrator)
         q0 = np.array(md.qpos0 if qpos0 is None else qpos0, dtype=np.float64)
+        boxes = list(boxes or [])
+        from scipy.spatial.transform import Rotation as _Rot
+        box_arrays = dict(
+            box_pos=[b['pos'] for b in boxes], box_size=[b['size'] for b in boxes],
+            box_mat=[_Rot.from_quat(np.asarray(b['quat'], float), scalar_first=True).as_matrix().ravel() for b in boxes],
+            box_friction=[b['friction'] for b in boxes], box_margin=[b['margin'] for b in boxes], box_gap=[b['gap'] for b in boxes],
+            box_solmix=[b['solmix'] for b in boxes], box_solref=[b['solref'] for b in boxes], box_solimp=[b['solimp'] for b in boxes],
+            box_condim=[b['condim'] for b in boxes], box_priority=[b['priority'] for b in boxes])
+        d.nbox = len(boxes)
+        self.boxes = boxes
         for name, ctype in GqModelDesc._fields_:
             if ctype in (_I, _D):
-                src = q0 if name == 'qpos0' else getattr(md, name)
+                src = q0 if name == 'qpos0' else (box_arrays[name] if name in box_arrays else getattr(md, name))
                 arr = np.ascontiguousarray(src, dtype=np.int32 if ctype is _I else np.float64)
                 if arr.size == 0:
                     arr = np.zeros(1, dtype=arr.dtype)

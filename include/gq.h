@@ -142,6 +142,21 @@ typedef struct GqModelDesc {
    * difference of those two vectors - is down at the round-off of its own terms and `tolerance` (meant for fp64
    * magnitudes) can no longer be met by anything but a wasted extra iteration. */
   double noise_floor;
+  /* static world boxes of the scene (terrain.py add_box :121-142: random_boxes, random_pyramids, ramp, slippery, stairs):
+   * world geoms 1..nbox after the floor, each with MuJoCo's per-geom contact parameters.  box_mat is the row-major
+   * rotation (columns = box axes in the world), box_size the half extents. */
+  int32_t nbox;
+  const double* box_pos;        /* [nbox][3] */
+  const double* box_mat;        /* [nbox][9] */
+  const double* box_size;       /* [nbox][3] */
+  const double* box_friction;   /* [nbox][3] */
+  const double* box_margin;     /* [nbox] */
+  const double* box_gap;
+  const double* box_solmix;
+  const double* box_solref;     /* [nbox][2] */
+  const double* box_solimp;     /* [nbox][5] */
+  const int32_t* box_condim;
+  const int32_t* box_priority;
 } GqModelDesc;
 
 typedef struct GqModel GqModel;

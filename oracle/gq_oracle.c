@@ -402,42 +402,48 @@ static int is_foot(const GqModelDesc* m, int g) {
   return 0;
 }
 
-/* mj_contactParam: mix floor (geom 1) and robot geom (geom 2) */
-static void contact_param(const GqOracle* o, int g, Contact* c) {
+/* mj_contactParam: mix the world geom (geom 1: the floor for w < 0, world box w otherwise) and robot geom g (geom 2) */
+static void contact_param(const GqOracle* o, int w, int g, Contact* c) {
   const GqModelDesc* m = &o->d;
   double f1[3], f2[3];
-  memcpy(f1, m->floor_friction, sizeof f1);
+  memcpy(f1, w < 0 ? m->floor_friction : m->box_friction + 3 * w, sizeof f1);
   memcpy(f2, m->geom_friction + 3 * g, sizeof f2);
-  if (o->friction >= 0) { /* _set_ground_friction (quadruped_env.py:1292-1296): floor + feet = [mu, 0.005, 0.0] */
-    f1[0] = o->friction; f1[1] = 0.005; f1[2] = 0.0;
+  if (o->friction >= 0) { /* _set_ground_friction (quadruped_env.py:1277-1298): geoms named ground/floor/hfield/terrain and the
+                           * feet get [mu, 0.005, 0.0]; the unnamed world boxes keep their own friction (quirk B8) */
+    if (w < 0) { f1[0] = o->friction; f1[1] = 0.005; f1[2] = 0.0; }
     if (is_foot(m, g)) { f2[0] = o->friction; f2[1] = 0.005; f2[2] = 0.0; }
   }
-  int p1 = m->floor_priority, p2 = m->geom_priority[g];
+  const int w_condim = w < 0 ? m->floor_condim : m->box_condim[w], w_priority = w < 0 ? m->floor_priority : m->box_priority[w];
+  const double w_solmix = w < 0 ? m->floor_solmix : m->box_solmix[w], w_margin = w < 0 ? m->floor_margin : m->box_margin[w];
+  const double w_gap = w < 0 ? m->floor_gap : m->box_gap[w];
+  const double* w_solref = w < 0 ? m->floor_solref : m->box_solref + 2 * w;
+  const double* w_solimp = w < 0 ? m->floor_solimp : m->box_solimp + 5 * w;
+  int p1 = w_priority, p2 = m->geom_priority[g];
   double fri[3];
   if (p1 == p2) {
-    c->dim = m->floor_condim > m->geom_condim[g] ? m->floor_condim : m->geom_condim[g];
+    c->dim = w_condim > m->geom_condim[g] ? w_condim : m->geom_condim[g];
     for (int k = 0; k < 3; k++) fri[k] = f1[k] > f2[k] ? f1[k] : f2[k];
-    double s1 = m->floor_solmix, s2 = m->geom_solmix[g], mix;
+    double s1 = w_solmix, s2 = m->geom_solmix[g], mix;
     if (s1 >= MINVAL && s2 >= MINVAL) mix = s1 / (s1 + s2);
     else if (s1 < MINVAL && s2 < MINVAL) mix = 0.5;
     else mix = s1 < MINVAL ? 0.0 : 1.0;
-    const double* r1 = m->floor_solref; const double* r2 = m->geom_solref + 2 * g;
+    const double* r1 = w_solref; const double* r2 = m->geom_solref + 2 * g;
     if (r1[0] > 0 && r2[0] > 0)
       for (int k = 0; k < 2; k++) c->solref[k] = mix * r1[k] + (1 - mix) * r2[k];
     else
       for (int k = 0; k < 2; k++) c->solref[k] = r1[k] < r2[k] ? r1[k] : r2[k];
-    for (int k = 0; k < 5; k++) c->solimp[k] = mix * m->floor_solimp[k] + (1 - mix) * m->geom_solimp[5 * g + k];
+    for (int k = 0; k < 5; k++) c->solimp[k] = mix * w_solimp[k] + (1 - mix) * m->geom_solimp[5 * g + k];
   } else {
     int floor_wins = p1 > p2;
-    c->dim = floor_wins ? m->floor_condim : m->geom_condim[g];
+    c->dim = floor_wins ? w_condim : m->geom_condim[g];
     memcpy(fri, floor_wins ? f1 : f2, sizeof fri);
-    memcpy(c->solref, floor_wins ? m->floor_solref : m->geom_solref + 2 * g, sizeof c->solref);
-    memcpy(c->solimp, floor_wins ? m->floor_solimp : m->geom_solimp + 5 * g, sizeof c->solimp);
+    memcpy(c->solref, floor_wins ? w_solref : m->geom_solref + 2 * g, sizeof c->solref);
+    memcpy(c->solimp, floor_wins ? w_solimp : m->geom_solimp + 5 * g, sizeof c->solimp);
   }
   c->friction[0] = c->friction[1] = fri[0]; c->friction[2] = fri[1]; c->friction[3] = c->friction[4] = fri[2];
   for (int k = 0; k < 5; k++) c->friction[k] = fmax(MINMU, c->friction[k]); /* mjMINMU */
-  double margin = m->floor_margin > m->geom_margin[g] ? m->floor_margin : m->geom_margin[g];
-  double gap = m->floor_gap > m->geom_gap[g] ? m->floor_gap : m->geom_gap[g];
+  double margin = w_margin > m->geom_margin[g] ? w_margin : m->geom_margin[g];
+  double gap = w_gap > m->geom_gap[g] ? w_gap : m->geom_gap[g];
   c->includemargin = margin - gap;
   c->mu = 0;
 }
@@ -471,7 +477,54 @@ static void gqo_collision(GqOracle* o) {
     for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - normal[k] * (r + 0.5 * best);
     memcpy(c->frame, normal, sizeof normal);
     make_frame(c->frame);
-    contact_param(o, g, c);
+    contact_param(o, -1, g, c);
+  }
+  /* world boxes (geoms 1..nbox of the world body).  Sphere geoms: exact sphere-box distance (mjc_SphereBox: clamp the
+   * centre into the box; inside, leave through the nearest face).  Every other robot geom: the same test for each vertex
+   * of its cloud inflated by the cloud radius, deepest one kept - one contact per (box, geom) pair.  NOT MuJoCo's
+   * mesh-box routine (libccd penetration on the convex hulls): an approximation that is exact for vertex-face touching. */
+  for (int g = 0; g < m->ngeom && o->ncon < NCON; g++) {
+    int cl = m->geom_cloudid[g];
+    if (cl < 0 || m->geom_bodyid[g] == 0) continue;
+    const double r = m->cloud_radius[cl];
+    for (int w = 0; w < m->nbox && o->ncon < NCON; w++) {
+      const double* bp = m->box_pos + 3 * w; const double* bm = m->box_mat + 9 * w; const double* bs = m->box_size + 3 * w;
+      const double margin = m->box_margin[w] > m->geom_margin[g] ? m->box_margin[w] : m->geom_margin[g];
+      double dc[3] = {o->geom_xpos[g][0] - bp[0], o->geom_xpos[g][1] - bp[1], o->geom_xpos[g][2] - bp[2]};
+      const double brad = sqrt(bs[0] * bs[0] + bs[1] * bs[1] + bs[2] * bs[2]);
+      if (sqrt(dot3(dc, dc)) > brad + m->geom_rbound[g] + margin) continue; /* bounding spheres */
+      double best = 1e300, second = 1e300, bn[3] = {0, 0, 1}, bv[3] = {0, 0, 0};
+      for (int v = 0; v < m->cloud_vertnum[cl]; v++) {
+        double wv[3], lc[3], q[3], nl[3], dist;
+        mulmatvec3(wv, o->geom_xmat[g], m->vert_pos + 3 * (m->cloud_vertadr[cl] + v));
+        for (int k = 0; k < 3; k++) wv[k] += o->geom_xpos[g][k] - bp[k];
+        mulmatTvec3(lc, bm, wv);                       /* vertex in the box frame */
+        int inside = 1;
+        for (int k = 0; k < 3; k++) { q[k] = fmin(fmax(lc[k], -bs[k]), bs[k]); if (q[k] != lc[k]) inside = 0; }
+        if (inside) { /* leave through the nearest face */
+          int ax = 0; double dmin = 1e300;
+          for (int k = 0; k < 3; k++) { double dk = bs[k] - fabs(lc[k]); if (dk < dmin) { dmin = dk; ax = k; } }
+          nl[0] = nl[1] = nl[2] = 0; nl[ax] = lc[ax] >= 0 ? 1 : -1;
+          dist = -dmin - r;
+        } else {
+          double dd[3] = {lc[0] - q[0], lc[1] - q[1], lc[2] - q[2]}, len = sqrt(dot3(dd, dd));
+          for (int k = 0; k < 3; k++) nl[k] = dd[k] / len;
+          dist = len - r;
+        }
+        if (dist < best) {
+          second = best; best = dist;
+          mulmatvec3(bn, bm, nl);
+          for (int k = 0; k < 3; k++) bv[k] = wv[k] + bp[k];
+        } else if (dist < second) second = dist;
+      }
+      if (best >= margin) continue;
+      Contact* c = &o->contact[o->ncon++];
+      c->geom = g; c->body = m->geom_bodyid[g]; c->dist = best; c->tiegap = second - best;
+      for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - bn[k] * (r + 0.5 * best); /* midway between the surfaces */
+      memcpy(c->frame, bn, sizeof bn);
+      make_frame(c->frame);
+      contact_param(o, w, g, c);
+    }
   }
 }
 

@@ -194,3 +194,78 @@ def test_elliptic_stance_weight_and_cone_at_rest():
     cf = oe.contact_force
     for c in range(oe.ncon):
         assert np.hypot(cf[c, 1] / fri[c, 0], cf[c, 2] / fri[c, 1]) <= cf[c, 0] * (1 + 1e-9) + 1e-9
+
+
+def _slab(z_top, half=(6.0, 6.0, 1.0), pos_xy=(0.0, 0.0), euler=(0.0, 0.0, 0.0)):
+    from gym_quadruped_amd.terrain import _box
+    return _box([pos_xy[0], pos_xy[1], z_top - half[2]], euler, [2 * h for h in half])
+
+
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo', 'go2'])
+def test_world_box_top_face_is_a_raised_floor(robot):
+    """World boxes (terrain.py add_box): a wide slab whose top face is at height H under the robot must give exactly the
+    dynamics of the floor plane H lower - same distances, frames (normal +z), mixing with default geom parameters."""
+    H = 1.37   # thick slab: random test states sink up to 0.1 m into the ground, the top face must stay the nearest one
+    mmF = marshalled(robot, solver=1, iterations=100, tolerance=1e-12)
+    mmB = marshalled(robot, solver=1, iterations=100, tolerance=1e-12, boxes=[_slab(H)])
+    oF, oB = Oracle(mmF), Oracle(mmB)
+    rng = np.random.default_rng(9)
+    hip = float(mmF.desc.key_qpos[2])
+    qpos, qvel = random_states(mmF.md, 10, rng, z_range=(0.7 * hip, 1.1 * hip))
+    ncon = 0
+    for e in range(10):
+        ctrl = rng.normal(0, 10, 12)
+        oF.set_state(qpos[e], qvel[e], np.zeros(18), np.zeros(18)); oF.step(ctrl)
+        qb = qpos[e].copy(); qb[2] += H
+        oB.set_state(qb, qvel[e], np.zeros(18), np.zeros(18)); oB.step(ctrl)
+        assert oB.ncon == oF.ncon
+        ncon += oF.ncon
+        np.testing.assert_allclose(oB.qacc, oF.qacc, rtol=1e-7, atol=1e-7 * max(1, np.abs(oF.qacc).max()))
+        np.testing.assert_allclose(oB.get('contact_dist'), oF.get('contact_dist'), atol=1e-12)
+        np.testing.assert_allclose(oB.contact_frame, oF.contact_frame, atol=1e-12)
+    assert ncon > 10
+
+
+def test_world_box_side_face_and_ramp_normals():
+    """Sphere-box narrow phase: a foot next to a box is pushed out through the nearest face (horizontal normal for a side
+    face), a foot on a tilted ramp gets the ramp's normal; forces respect the friction pyramid in the contact frame."""
+    from gym_quadruped_amd.terrain import generate_terrain
+    scene, _ = generate_terrain('ramp', 0.3)
+    mm = marshalled('aliengo', solver=1, iterations=200, tolerance=1e-12, boxes=scene['boxes'])
+    o = Oracle(mm)
+    b = scene['boxes'][0]
+    from scipy.spatial.transform import Rotation
+    Rb = Rotation.from_quat(np.asarray(b['quat'], float) / np.linalg.norm(b['quat']), scalar_first=True).as_matrix()
+    n_top = Rb[:, 2]
+    q = mm.md.key_qpos[0].copy()
+    # put the robot on the ramp surface: 1 m up-slope of the ramp centre, base raised along the ramp normal
+    p_on = np.asarray(b['pos']) + Rb @ np.array([1.0, 0.0, b['size'][2]])
+    q[0:3] = p_on + np.array([0, 0, float(mm.desc.key_qpos[2]) * 1.5])
+    o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12), stage=1)
+    # lower the robot until its deepest foot sinks 2 mm into the ramp (the ramp slab is only 5 cm thick)
+    top = np.asarray(b['pos']) + Rb @ np.array([0.0, 0.0, b['size'][2]])
+    feet = [mm.md.geom_names.index(k) for k in ('FL', 'FR', 'RL', 'RR')]
+    rad = float(mm.md.cloud_radius[mm.md.geom_cloudid[feet[0]]])
+    dmin = min(float(n_top @ (o.geom_xpos[g] - top)) - rad for g in feet)
+    q[2] -= (dmin + 0.002) / n_top[2]
+    o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12))
+    assert o.ncon >= 2
+    fr = o.contact_frame
+    cf = o.contact_force
+    for c in range(o.ncon):
+        np.testing.assert_allclose(fr[c] @ fr[c].T, np.eye(3), atol=1e-12)
+        assert fr[c][0] @ n_top > 0.999                      # ramp normal, not the world z axis
+        assert abs(fr[c][0][2] - 1.0) > 1e-3
+        assert cf[c, 0] >= -1e-9 and abs(cf[c, 1]) <= cf[c, 0] + 1e-6 and abs(cf[c, 2]) <= cf[c, 0] + 1e-6
+    # a foot beside a tall box: nearest face is a side face -> horizontal normal
+    tall = _slab(1.0, half=(0.2, 0.2, 0.5), pos_xy=(0.0, 0.0))
+    mm2 = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-10, boxes=[tall])
+    o2 = Oracle(mm2)
+    q = mm2.md.key_qpos[0].copy(); q[2] = 0.6
+    o2.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o2.forward(np.zeros(12), stage=1)
+    foot = o2.geom_xpos[mm2.md.geom_names.index('FL')]
+    q[0] += -foot[0] + 0.2 + 0.02                               # FL foot centre 2 cm outside the +x face
+    q[1] += -foot[1]
+    o2.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o2.forward(np.zeros(12))
+    normals = o2.contact_frame[:, 0]
+    assert any(abs(nv[0] - 1.0) < 1e-9 and abs(nv[2]) < 1e-9 for nv in normals), normals
