@@ -17,7 +17,7 @@
 #include "gq_step_kernel.h"
 #include "gq_step_body.h"
 
-extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, hipStream_t stream);
+extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, hipStream_t stream);
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream);
 extern "C" void gq_launch_heightmap(const double* center, const float* yaw, int n_envs, int rows, int cols, float dist_x,
                                     float dist_y, float* out, hipStream_t stream);
@@ -213,7 +213,7 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
   gq::StepCall c{};
   c.ctrl = ctrl; c.mask = mask; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
   c.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; c.first_pass = 0; c.stop_stage = b->stop_stage;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, b->model->host.nbox > 0, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }
@@ -235,7 +235,7 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   if (rc != GQ_OK) return rc;
   gq::StepCall c{};
   c.mask = mask; c.first_pass = 1; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, b->model->host.nbox > 0, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

@@ -23,29 +23,39 @@ struct Mixed { int dim, rule; double margin, includemargin, solref[2], solimp[5]
 
 /* mj_contactParam between the floor plane and robot geom g (friction itself is mixed at run time because
  * _set_ground_friction rewrites it per env) */
+struct WorldGeom { int condim, priority; double solmix, margin, gap; const double* solref; const double* solimp; };
+Mixed mix_with(const GqModelDesc* d, const WorldGeom& w, int g);
 Mixed mix_with_floor(const GqModelDesc* d, int g) {
+  WorldGeom w{d->floor_condim, d->floor_priority, d->floor_solmix, d->floor_margin, d->floor_gap, d->floor_solref, d->floor_solimp};
+  return mix_with(d, w, g);
+}
+Mixed mix_with_box(const GqModelDesc* d, int b, int g) {
+  WorldGeom w{d->box_condim[b], d->box_priority[b], d->box_solmix[b], d->box_margin[b], d->box_gap[b], d->box_solref + 2 * b, d->box_solimp + 5 * b};
+  return mix_with(d, w, g);
+}
+Mixed mix_with(const GqModelDesc* d, const WorldGeom& w, int g) {
   Mixed r;
-  int p1 = d->floor_priority, p2 = d->geom_priority[g];
+  int p1 = w.priority, p2 = d->geom_priority[g];
   if (p1 == p2) {
     r.rule = 0;
-    r.dim = d->floor_condim > d->geom_condim[g] ? d->floor_condim : d->geom_condim[g];
-    double s1 = d->floor_solmix, s2 = d->geom_solmix[g], mix;
+    r.dim = w.condim > d->geom_condim[g] ? w.condim : d->geom_condim[g];
+    double s1 = w.solmix, s2 = d->geom_solmix[g], mix;
     if (s1 >= 1e-15 && s2 >= 1e-15) mix = s1 / (s1 + s2);
     else if (s1 < 1e-15 && s2 < 1e-15) mix = 0.5;
     else mix = s1 < 1e-15 ? 0.0 : 1.0;
-    const double* r1 = d->floor_solref; const double* r2 = d->geom_solref + 2 * g;
+    const double* r1 = w.solref; const double* r2 = d->geom_solref + 2 * g;
     for (int k = 0; k < 2; k++)
       r.solref[k] = (r1[0] > 0 && r2[0] > 0) ? mix * r1[k] + (1 - mix) * r2[k] : (r1[k] < r2[k] ? r1[k] : r2[k]);
-    for (int k = 0; k < 5; k++) r.solimp[k] = mix * d->floor_solimp[k] + (1 - mix) * d->geom_solimp[5 * g + k];
+    for (int k = 0; k < 5; k++) r.solimp[k] = mix * w.solimp[k] + (1 - mix) * d->geom_solimp[5 * g + k];
   } else {
     bool floor_wins = p1 > p2;
     r.rule = floor_wins ? 1 : 2;
-    r.dim = floor_wins ? d->floor_condim : d->geom_condim[g];
-    std::memcpy(r.solref, floor_wins ? d->floor_solref : d->geom_solref + 2 * g, sizeof r.solref);
-    std::memcpy(r.solimp, floor_wins ? d->floor_solimp : d->geom_solimp + 5 * g, sizeof r.solimp);
+    r.dim = floor_wins ? w.condim : d->geom_condim[g];
+    std::memcpy(r.solref, floor_wins ? w.solref : d->geom_solref + 2 * g, sizeof r.solref);
+    std::memcpy(r.solimp, floor_wins ? w.solimp : d->geom_solimp + 5 * g, sizeof r.solimp);
   }
-  r.margin = d->floor_margin > d->geom_margin[g] ? d->floor_margin : d->geom_margin[g];
-  double gap = d->floor_gap > d->geom_gap[g] ? d->floor_gap : d->geom_gap[g];
+  r.margin = w.margin > d->geom_margin[g] ? w.margin : d->geom_margin[g];
+  double gap = w.gap > d->geom_gap[g] ? w.gap : d->geom_gap[g];
   r.includemargin = r.margin - gap;
   return r;
 }
@@ -191,6 +201,66 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     for (int i = 0; i < 3; i++) G.friction[i] = (float)d->geom_friction[3 * g + i];
     for (int i = 0; i < 2; i++) G.solref[i] = (float)mx.solref[i];
     for (int i = 0; i < 5; i++) G.solimp[i] = (float)mx.solimp[i];
+  }
+  /* static world boxes: geometry per box, contact parameters per class of identical boxes x collision item */
+  if (d->nbox < 0 || d->nbox > GQ_MAXBOX) FAIL("scene has %d world boxes, at most %d are supported", d->nbox, GQ_MAXBOX);
+  if (d->nbox > 0 && d->solver != 1) FAIL("scenes with world boxes need the Newton solver (solver = 1): the PGS path handles the floor plane only");
+  M.nbox = d->nbox; M.nboxcls = 0;
+  int item_geom[4 + GQ_MAXLG];
+  {
+    int k = 0, lg = 0;
+    for (int g = 0; g < d->ngeom; g++) {
+      if (g < 1024 && is_foot[g]) continue;
+      if (d->geom_cloudid[g] < 0 || d->geom_bodyid[g] == 0) continue;
+      item_geom[4 + lg++] = g;
+    }
+    for (k = 0; k < 4; k++) item_geom[k] = d->feet_geomid[k];
+  }
+  int cls_rep[GQ_MAXBOXCLS];
+  for (int b = 0; b < d->nbox; b++) {
+    GqDevBox& B = M.box[b];
+    for (int i = 0; i < 3; i++) { B.pos[i] = (float)d->box_pos[3 * b + i]; B.size[i] = (float)d->box_size[3 * b + i]; }
+    for (int i = 0; i < 9; i++) B.mat[i] = (float)d->box_mat[9 * b + i];
+    B.rad = (float)std::sqrt(d->box_size[3 * b] * d->box_size[3 * b] + d->box_size[3 * b + 1] * d->box_size[3 * b + 1] + d->box_size[3 * b + 2] * d->box_size[3 * b + 2]);
+    int cls = -1;
+    for (int c = 0; c < M.nboxcls && cls < 0; c++) {
+      const int r = cls_rep[c];
+      bool same = d->box_condim[b] == d->box_condim[r] && d->box_priority[b] == d->box_priority[r] && d->box_solmix[b] == d->box_solmix[r] &&
+                  d->box_margin[b] == d->box_margin[r] && d->box_gap[b] == d->box_gap[r];
+      for (int i = 0; i < 3 && same; i++) same = d->box_friction[3 * b + i] == d->box_friction[3 * r + i];
+      for (int i = 0; i < 2 && same; i++) same = d->box_solref[2 * b + i] == d->box_solref[2 * r + i];
+      for (int i = 0; i < 5 && same; i++) same = d->box_solimp[5 * b + i] == d->box_solimp[5 * r + i];
+      if (same) cls = c;
+    }
+    if (cls < 0) {
+      if (M.nboxcls >= GQ_MAXBOXCLS) FAIL("more than %d distinct contact-parameter sets among the world boxes", GQ_MAXBOXCLS);
+      cls = M.nboxcls++; cls_rep[cls] = b;
+      for (int i = 0; i < 3; i++) M.boxcls_friction[cls][i] = (float)d->box_friction[3 * b + i];
+      for (int it = 0; it < 4 + M.nlg; it++) {
+        Mixed mx = mix_with_box(d, b, item_geom[it]);
+        if (mx.dim != 1 && mx.dim != 3 && !(d->cone == 1 && mx.dim == 6)) FAIL("box contact dimension %d not supported", mx.dim);
+        GqDevMix& X = M.boxmix[cls][it];
+        X.dim = mx.dim; X.rule = mx.rule; X.margin = (float)mx.margin; X.includemargin = (float)mx.includemargin;
+        for (int i = 0; i < 2; i++) X.solref[i] = (float)mx.solref[i];
+        for (int i = 0; i < 5; i++) X.solimp[i] = (float)mx.solimp[i];
+      }
+    }
+    B.cls = cls;
+  }
+  { /* broad-phase radius: longest leg chain (hip + thigh + calf offsets + foot) or base geom extent, plus the largest geom */
+    double reach = 0, grb = 0;
+    for (int l = 0; l < 4; l++) {
+      double s = 0;
+      for (int i = 0; i < 3; i++) { const double* p = d->body_pos + 3 * (2 + 3 * l + i); s += std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]); }
+      if (s > reach) reach = s;
+    }
+    for (int g = 0; g < d->ngeom; g++)
+      if (d->geom_bodyid[g] != 0 && d->geom_cloudid[g] >= 0) {
+        const double* p = d->geom_pos + 3 * g;
+        double e = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + d->geom_rbound[g];
+        if (e > grb) grb = e;
+      }
+    M.robot_radius = (float)(reach + grb);
   }
   return 0;
 }

@@ -13,6 +13,8 @@
 #define GQ_NJ 12        /* hinge joints */
 #define GQ_MAXLG 38     /* max link (non-foot) collision geoms */
 #define GQ_MAXCON 12    /* max simultaneous contacts fed to the solver */
+#define GQ_MAXBOX 128    /* static world boxes of the scene (random_boxes: 100, stairs: 50) */
+#define GQ_MAXBOXCLS 4   /* distinct contact-parameter sets among them (slippery: 2) */
 #define GQ_MAXEFC 63    /* constraint rows: one per lane, lane 63 carries the smooth-force solve */
 #define GQ_NOBS_ALL 227 /* scalars in QuadrupedEnv.ALL_OBS */
 #define GQ_NOBS_CANON 245 /* + 6 IMU observables x 3 */
@@ -32,6 +34,11 @@ struct GqDevGeom {          /* a robot collision geom that is not a foot sphere 
   float includemargin;      /* margin - gap */
   float solref[2], solimp[5];
 };
+
+/* contact parameters of one (world geom class, robot geom) pair, mixed on the host (mj_contactParam); friction itself is
+ * mixed at run time because _set_ground_friction rewrites the feet per env */
+struct GqDevMix { int32_t dim, rule; float margin, includemargin, solref[2], solimp[5]; };
+struct GqDevBox { float pos[3], mat[9], size[3], rad; int32_t cls; }; /* mat: columns = box axes in the world; rad: bounding sphere */
 
 struct GqDevModel {
   float timestep, gravity_z, impratio, meaninertia, tolerance, noise_floor;
@@ -70,6 +77,12 @@ struct GqDevModel {
   /* link geoms */
   GqDevGeom lg[GQ_MAXLG];
   int32_t con_order[4 + GQ_MAXLG]; /* collision items by increasing geom id: k<4 foot k, else 4 + link geom */
+  /* static world boxes (scene geoms after the floor): collision items are evaluated against every box near the robot */
+  int32_t nbox, nboxcls;
+  float robot_radius;            /* bound on the distance from the base origin to any point of the robot (broad phase) */
+  float boxcls_friction[GQ_MAXBOXCLS][3];
+  GqDevMix boxmix[GQ_MAXBOXCLS][4 + GQ_MAXLG]; /* [class][collision item: k < 4 foot k, else 4 + link geom] */
+  GqDevBox box[GQ_MAXBOX];
   /* env */
   double terrain_limits[4];
   float key_qpos[19];            /* keyframe 0 */

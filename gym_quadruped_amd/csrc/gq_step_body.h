@@ -6,6 +6,7 @@
 #pragma once
 #include "gq_step_kernel.h"
 #include "gq_newton.h"
+#include "gq_boxes.h"
 
 namespace gq {
 
@@ -149,8 +150,9 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GqDevModel& m, con
  * GQ_STOP_STAGE cut; 1 (DBG): the variant with the debug record, the
  * stage timers and the GQ_STOP_STAGE cut compiled in - the production variant carries none of it (no timer
  * accumulators or row data kept live for the record: they cost registers inside the solver loop).
- * CONE: elliptic friction cones (Newton only): contacts take dim rows [n, t1, t2, torsion, roll1, roll2]. */
-template <int SOLVER, int MODE, bool CONE>
+ * CONE: elliptic friction cones (Newton only): contacts take dim rows [n, t1, t2, torsion, roll1, roll2].
+ * BOXES: the scene has static world boxes (gq_boxes.h; Newton only): contacts carry their own normal. */
+template <int SOLVER, int MODE, bool CONE, bool BOXES>
 __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
@@ -423,6 +425,11 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     }
   }
   wave_barrier();
+  if constexpr (BOXES) {
+    const double bx0 = a.qpos[(size_t)env * 19 + 0], by0 = a.qpos[(size_t)env * 19 + 1]; /* base x/y of this forward pass, f64 */
+    const float mu_b = a.friction ? a.friction[env] : -1.0f;
+    stage_box_contacts<CONE>(W, m, a.vx, a.vy, a.vz, bx0, by0, mu_b);
+  }
   const int nefc = uniform(W.nefc), ncon = uniform(W.ncon), nlim = uniform(W.nlim), nfl = m.nfl; /* SGPRs */
   if (timing) { /* body poses go to the debug record now: xmat's LDS is reused by the Newton solver */
     float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
@@ -469,8 +476,10 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
 #pragma unroll
     for (int q = 0; q < 5; q++) rsolimp[q] = W.con_solimp[c][q];
     const float tran = m.body_invweight0[body][0];
-    /* contact frame of a horizontal floor (mju_makeFrame): n = z, t1 = y, t2 = -x */
-    dir = v3(0.0f, 0.0f, 1.0f);
+    /* contact frame (mju_makeFrame): horizontal floor n = z, t1 = y, t2 = -x; box contacts bring their own normal */
+    V3 cn = v3(0.0f, 0.0f, 1.0f), ct1 = v3(0.0f, 1.0f, 0.0f), ct2 = v3(-1.0f, 0.0f, 0.0f);
+    if constexpr (BOXES) { cn = ld3(GQ_BX_CONNRM(W) + 3 * c); make_frame(cn, ct1, ct2); }
+    dir = cn;
     bool rotational = false;
     if (dim == 1) { rtype = ROW_CONTACT1; rdiag = tran; }
     else if constexpr (CONE) {
@@ -486,21 +495,22 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
 #pragma unroll
       for (int q = 1; q < 3; q++) {
         const float ovr = q == 1 ? 0.005f : 0.0f;
-        const float ff = mu_env >= 0.0f ? ovr : m.floor_friction[q];
+        float ff = mu_env >= 0.0f ? ovr : m.floor_friction[q];
+        if constexpr (BOXES) { const int wc = GQ_BX_WCLS(W)[c]; if (wc >= 0) ff = m.boxcls_friction[wc][q]; }
         const float fg = code < 4 ? (mu_env >= 0.0f ? ovr : m.foot_friction[code][q]) : m.lg[code - 4].friction[q];
         fr[q] = fmaxf(1e-5f, rule == 0 ? fmaxf(ff, fg) : (rule == 1 ? ff : fg));
       }
       efri = e == 0 ? 0.0f : (e < 3 ? fr[0] : (e == 3 ? fr[1] : fr[2]));
       rotational = e >= 3;
-      const int ax = e % 3; /* 0: n = z, 1: t1 = y, 2: t2 = -x */
-      dir = ax == 0 ? v3(0.0f, 0.0f, 1.0f) : (ax == 1 ? v3(0.0f, 1.0f, 0.0f) : v3(-1.0f, 0.0f, 0.0f));
+      const int ax = e % 3; /* 0: n, 1: t1, 2: t2 */
+      dir = ax == 0 ? cn : (ax == 1 ? ct1 : ct2);
       rdiag = rotational ? m.body_invweight0[body][1] : tran;
       rdiag_first = tran;                                   /* R of the contact's normal row */
       if (e > 0) { rpos = 0.0f; rmargin = 0.0f; }           /* friction rows carry no penetration */
     } else {
       rtype = ROW_PYRAMID;
       const float sgn = (e & 1) ? -mu : mu;
-      if ((e >> 1) == 0) dir.y = sgn; else dir.x = -sgn;
+      dir = cn + sgn * ((e >> 1) == 0 ? ct1 : ct2);
       rdiag = tran + mu * mu * tran;
       rdiag_first = rdiag;
       rmu = mu / sqrtf(m.impratio);
@@ -858,14 +868,19 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       if (W.con_body[c] != body) continue;
       cs = 1.0f;
       const int r0 = W.con_row[c];
-      if (W.con_dim[c] == 1) cf.z += W.force[r0];
-      else if constexpr (CONE) cf = cf + v3(-W.force[r0 + 2], W.force[r0 + 1], W.force[r0]); /* frame' * f: n = z, t1 = y, t2 = -x */
-      else {
-        float f0 = W.force[r0], f1 = W.force[r0 + 1], f2 = W.force[r0 + 2], f3 = W.force[r0 + 3], mu = W.con_mu[c];
-        /* mju_decodePyramid, then frame' * f with n = z, t1 = y, t2 = -x */
-        float fn = f0 + f1 + f2 + f3, ft1 = mu * (f0 - f1), ft2 = mu * (f2 - f3);
-        cf = cf + v3(-ft2, ft1, fn);
+      float fn, ft1 = 0.0f, ft2 = 0.0f; /* contact-frame force: mj_contactForce */
+      if (W.con_dim[c] == 1) fn = W.force[r0];
+      else if constexpr (CONE) { fn = W.force[r0]; ft1 = W.force[r0 + 1]; ft2 = W.force[r0 + 2]; }
+      else { /* mju_decodePyramid */
+        const float f0 = W.force[r0], f1 = W.force[r0 + 1], f2 = W.force[r0 + 2], f3 = W.force[r0 + 3], mu = W.con_mu[c];
+        fn = f0 + f1 + f2 + f3; ft1 = mu * (f0 - f1); ft2 = mu * (f2 - f3);
       }
+      if constexpr (BOXES) { /* frame' * f with the contact's own frame */
+        const V3 cn = ld3(GQ_BX_CONNRM(W) + 3 * c);
+        V3 ct1, ct2;
+        make_frame(cn, ct1, ct2);
+        cf = cf + fn * cn + ft1 * ct1 + ft2 * ct2;
+      } else cf = cf + v3(-ft2, ft1, fn); /* n = z, t1 = y, t2 = -x */
     }
     if (W.foot_touch[lane]) cs = 1.0f; /* contact detected but dropped by the row budget */
     /* slot of this foot in legs_order-dependent observables is resolved by obs_map; canonical order = FL FR RL RR */

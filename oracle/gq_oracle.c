@@ -483,11 +483,11 @@ static void gqo_collision(GqOracle* o) {
    * centre into the box; inside, leave through the nearest face).  Every other robot geom: the same test for each vertex
    * of its cloud inflated by the cloud radius, deepest one kept - one contact per (box, geom) pair.  NOT MuJoCo's
    * mesh-box routine (libccd penetration on the convex hulls): an approximation that is exact for vertex-face touching. */
-  for (int g = 0; g < m->ngeom && o->ncon < NCON; g++) {
-    int cl = m->geom_cloudid[g];
-    if (cl < 0 || m->geom_bodyid[g] == 0) continue;
-    const double r = m->cloud_radius[cl];
-    for (int w = 0; w < m->nbox && o->ncon < NCON; w++) {
+  for (int w = 0; w < m->nbox && o->ncon < NCON; w++) { /* (box, geom id) order, as the kernel appends them */
+    for (int g = 0; g < m->ngeom && o->ncon < NCON; g++) {
+      int cl = m->geom_cloudid[g];
+      if (cl < 0 || m->geom_bodyid[g] == 0) continue;
+      const double r = m->cloud_radius[cl];
       const double* bp = m->box_pos + 3 * w; const double* bm = m->box_mat + 9 * w; const double* bs = m->box_size + 3 * w;
       const double margin = m->box_margin[w] > m->geom_margin[g] ? m->box_margin[w] : m->geom_margin[g];
       double dc[3] = {o->geom_xpos[g][0] - bp[0], o->geom_xpos[g][1] - bp[1], o->geom_xpos[g][2] - bp[2]};

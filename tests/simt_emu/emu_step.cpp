@@ -62,8 +62,10 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
           gq::reset_wave(f.r, W);
           pass = call.auto_reset;
         }
-        const int term = M.solver == 1 ? (M.cone ? gq::step_wave<1, 1, true>(f.s, call, W, pass) : gq::step_wave<1, 1, false>(f.s, call, W, pass))
-                                       : gq::step_wave<0, 1, false>(f.s, call, W, pass);
+        int term;
+        if (M.solver != 1) term = gq::step_wave<0, 1, false, false>(f.s, call, W, pass);
+        else if (M.nbox > 0) term = M.cone ? gq::step_wave<1, 1, true, true>(f.s, call, W, pass) : gq::step_wave<1, 1, false, true>(f.s, call, W, pass);
+        else term = M.cone ? gq::step_wave<1, 1, true, false>(f.s, call, W, pass) : gq::step_wave<1, 1, false, false>(f.s, call, W, pass);
         if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
       }
