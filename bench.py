@@ -87,6 +87,7 @@ def main():
     ap.add_argument('--auto-reset', choices=['next_step', 'same_step', 'off'], default='next_step')
     ap.add_argument('--no-auto-reset', action='store_true')
     ap.add_argument('--solver', choices=['newton', 'pgs'], default='newton')
+    ap.add_argument('--scene', default='flat', help="headline metric: flat; box scenes (random_boxes, stairs, ...) for the secondary configs")
     ap.add_argument('--robot', default='mini_cheetah', help='headline metric: mini_cheetah; other registry robots for the secondary configs')
     args = ap.parse_args()
 
@@ -111,7 +112,7 @@ def main():
 
     obs_names = tuple(QuadrupedEnv.ALL_OBS) if args.obs == 'all' else QuadrupedEnv._DEFAULT_OBS
     n = args.envs_per_gpu
-    env = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene='flat', num_envs=n, device=device,
+    env = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device,
                        auto_reset=False if (args.no_auto_reset or args.auto_reset == 'off') else args.auto_reset, solver=args.solver, solver_iterations=100, solver_tolerance=1e-8,
                        seed=1000, env_id_offset=rank * n)  # shards: disjoint global env ids -> disjoint RNG counters
     env.reset(random=True)
@@ -158,7 +159,7 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': f'{args.robot} flat, {n} envs/GPU, random-action rollout (50*N(0,1) torques), '
+            'config': {'workload': f'{args.robot} {args.scene}, {n} envs/GPU, random-action rollout (50*N(0,1) torques), '
                                    f'{"ALL_OBS" if args.obs == "all" else "_DEFAULT_OBS"} ({env._obs_dim} scalars), '
                                    f'auto-reset on termination ({env.auto_reset_mode}), sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8',
                        'envs_per_gpu': n, 'total_envs': total_envs, 'parallelism': f'env-shards x{world} (no collectives)',

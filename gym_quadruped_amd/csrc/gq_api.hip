@@ -18,9 +18,9 @@
 #include "gq_step_body.h"
 
 extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, hipStream_t stream);
-extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream);
-extern "C" void gq_launch_heightmap(const double* center, const float* yaw, int n_envs, int rows, int cols, float dist_x,
-                                    float dist_y, float* out, hipStream_t stream);
+extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, int boxes, hipStream_t stream);
+extern "C" void gq_launch_heightmap(const GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
+                                    float dist_x, float dist_y, float* out, hipStream_t stream);
 
 #define GQ_ARG_SLOTS 8
 static thread_local char g_err[512] = "";
@@ -228,7 +228,7 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   gq::ResetArgs r{};
   fill_reset_args(&r, b, mask, qpos_new, qvel_new, cfg, st, out, episode, lift_failed);
   r.clear_terminated = out.terminated; r.clear_truncated = out.truncated; r.clear_invalid = out.invalid_contact;
-  gq_launch_reset(&r, b->host.n_envs, (hipStream_t)hip_stream);
+  gq_launch_reset(&r, b->host.n_envs, b->model->host.nbox > 0, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */
   const int rc = ensure_args(b, st, out, episode, lift_failed, nullptr, (hipStream_t)hip_stream);
@@ -250,7 +250,7 @@ int gq_batch_set_pending(GqBatch* b, const uint8_t* flags, void* hip_stream) {
 int gq_heightmap(GqBatch* b, const double* center, const float* yaw, int rows, int cols, float dist_x, float dist_y,
                  float* out, void* hip_stream) {
   if (!b || !center || !yaw || !out || rows <= 0 || cols <= 0) { SET_ERR("gq_heightmap: bad argument"); return GQ_EINVAL; }
-  gq_launch_heightmap(center, yaw, b->host.n_envs, rows, cols, dist_x, dist_y, out, (hipStream_t)hip_stream);
+  gq_launch_heightmap(b->model->dev, center, yaw, b->host.n_envs, rows, cols, dist_x, dist_y, out, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

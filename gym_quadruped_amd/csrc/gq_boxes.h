@@ -51,7 +51,7 @@ __device__ __forceinline__ void make_frame(V3 n, V3& t1, V3& t2) {
 }
 
 /* bit mask (two words) of the boxes whose bounding sphere meets the robot's; base = (0, 0, basez) in kernel coordinates */
-__device__ inline void box_candidates(const WaveMem& W, const GqDevModel& m, double bx, double by, uint64_t cand[2]) {
+__device__ inline void box_candidates(const WaveMem& W, const GqDevModel& m, double bx, double by, float zoff, uint64_t cand[2]) {
   const int lane = lane_id();
 #pragma unroll
   for (int half = 0; half < 2; half++) {
@@ -59,7 +59,7 @@ __device__ inline void box_candidates(const WaveMem& W, const GqDevModel& m, dou
     bool near = false;
     if (b < m.nbox) {
       const GqDevBox& B = m.box[b];
-      const float dx = (float)((double)B.pos[0] - bx), dy = (float)((double)B.pos[1] - by), dz = B.pos[2] - W.basez;
+      const float dx = (float)((double)B.pos[0] - bx), dy = (float)((double)B.pos[1] - by), dz = B.pos[2] - (W.basez + zoff);
       const float reach = B.rad + m.robot_radius + 0.05f;
       near = dx * dx + dy * dy + dz * dz < reach * reach;
     }
@@ -167,7 +167,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GqDevModel& m, const
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); reserve += d > 1 ? d - 1 : 0; }
   uint64_t cand[2];
-  box_candidates(W, m, bx, by, cand);
+  box_candidates(W, m, bx, by, 0.0f, cand);
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
     uint64_t todo = cand[half];

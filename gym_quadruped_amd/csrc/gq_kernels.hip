@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __res
   bool respawn = c.auto_reset == 2 && A->s.pending[blockIdx.x]; /* wave-uniform */
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
-      reset_wave(A->r, W);
+      reset_wave<BOXES>(A->r, W);
       pass = c.auto_reset;
     }
     const int term = step_wave<SOLVER, MODE, CONE, BOXES>(A->s, c, W, pass);
@@ -30,15 +30,17 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __res
   }
 }
 
+template <bool BOXES>
 __global__ void __launch_bounds__(GQ_WAVE) reset_kernel(ResetArgs a) {
   if (a.mask && !a.mask[blockIdx.x]) return;
   __shared__ WaveMem W;
-  reset_wave(a, W);
+  reset_wave<BOXES>(a, W);
 }
 
-/* HeightMap rays: one thread per (env, cell).  Scene = the floor plane z = 0 (flat). */
-__global__ void heightmap_kernel(const double* center, const float* yaw, int n_envs, int rows, int cols, float dist_x,
-                                 float dist_y, float* out) {
+/* HeightMap rays: one thread per (env, cell).  Scene = the floor plane z = 0 plus the static world boxes (mj_ray against
+ * static geoms, heightmap.py:90-99): the nearest hit of the vertical ray with any box (slab test in the box frame). */
+__global__ void heightmap_kernel(const GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
+                                 float dist_x, float dist_y, float* out) {
   const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x), cells = rows * cols;
   if (idx >= n_envs * cells) return;
   const int env = idx / cells, cell = idx % cells, i = cell / cols, j = cell % cols;
@@ -51,17 +53,37 @@ __global__ void heightmap_kernel(const double* center, const float* yaw, int n_e
   const double py = center[(size_t)env * 3 + 1] + (double)(sy * ox + cy * oy);
   const double pz = center[(size_t)env * 3 + 2] + 0.6 - 0.07;
   /* mj_ray along -z against the floor plane: distance = pz (ray starts above the floor), hit = origin - z * dist */
-  const double dist = pz > 0.0 ? pz : -1.0;   /* mj_ray returns -1 when nothing is hit */
+  double dist = pz > 0.0 ? pz : -1.0;   /* mj_ray returns -1 when nothing is hit */
+  const int nbox = model->nbox;
+  for (int b = 0; b < nbox; b++) {
+    const GqDevBox& B = model->box[b];
+    const double ox = px - (double)B.pos[0], oy = py - (double)B.pos[1], oz = pz - (double)B.pos[2];
+    if (ox * ox + oy * oy > (double)(B.rad * B.rad)) continue; /* the vertical ray misses the bounding sphere */
+    /* origin and direction (0, 0, -1) in the box frame */
+    double tin = 0.0, tout = 1e30;
+    bool hit = true;
+    for (int k = 0; k < 3 && hit; k++) {
+      const double ol = (double)B.mat[k] * ox + (double)B.mat[3 + k] * oy + (double)B.mat[6 + k] * oz, dl = -(double)B.mat[6 + k];
+      const double s = (double)B.size[k];
+      if (fabs(dl) < 1e-12) { hit = fabs(ol) <= s; continue; }
+      double t0 = (-s - ol) / dl, t1 = (s - ol) / dl;
+      if (t0 > t1) { const double tt = t0; t0 = t1; t1 = tt; }
+      if (t0 > tin) tin = t0;
+      if (t1 < tout) tout = t1;
+      hit = tin <= tout;
+    }
+    if (hit && tout >= 0.0 && (dist < 0.0 || tin < dist)) dist = tin;
+  }
   float* o = out + (size_t)idx * 3;
   o[0] = (float)px; o[1] = (float)py; o[2] = (float)(pz - dist);
 }
 
 }  // namespace gq
 
-extern "C" void gq_launch_heightmap(const double* center, const float* yaw, int n_envs, int rows, int cols, float dist_x,
-                                    float dist_y, float* out, hipStream_t stream) {
+extern "C" void gq_launch_heightmap(const GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
+                                    float dist_x, float dist_y, float* out, hipStream_t stream) {
   const int total = n_envs * rows * cols;
-  hipLaunchKernelGGL(gq::heightmap_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, center, yaw, n_envs, rows, cols,
+  hipLaunchKernelGGL(gq::heightmap_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, model, center, yaw, n_envs, rows, cols,
                      dist_x, dist_y, out);
 }
 
@@ -82,6 +104,7 @@ extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall
 #undef GQ_LAUNCH_MODE
 #undef GQ_LAUNCH
 }
-extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, hipStream_t stream) {
-  hipLaunchKernelGGL(gq::reset_kernel, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
+extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, int boxes, hipStream_t stream) {
+  if (boxes) hipLaunchKernelGGL(gq::reset_kernel<true>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
+  else hipLaunchKernelGGL(gq::reset_kernel<false>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
 }

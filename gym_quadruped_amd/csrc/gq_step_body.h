@@ -978,6 +978,7 @@ struct ResetArgs {
 enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH = 27, RN_VNORM = 28, RN_HEADING = 29,
        RN_YAWDOT = 30, RN_FRICTION = 31 };
 
+template <bool BOXES>
 __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   int lane_o = lane_id(), env_o = (int)blockIdx.x;
   opaque(lane_o); opaque_s(env_o); /* see step_wave: no address arithmetic may be hoisted to the kernel prologue */
@@ -997,6 +998,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   const float u_vnorm = W.u.obs[RN_VNORM], u_heading = W.u.obs[RN_HEADING], u_yawdot = W.u.obs[RN_YAWDOT], u_fric = W.u.obs[RN_FRICTION];
   const bool explicit_state = a.qpos_new != nullptr;
   double q = 0.0;
+  double spawn_x = (double)m.key_qpos[0], spawn_y = (double)m.key_qpos[1]; /* wave-uniform: base x/y of the lift loop (BOXES) */
   float qv = 0.0f;
   if (explicit_state) {
     if (lane < 19) q = a.qpos_new[(size_t)env * 19 + lane];
@@ -1015,6 +1017,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
       const float yaw = atan2f((float)(-y), (float)(-x));
       const float cr = cosf(0.5f * roll), sr = sinf(0.5f * roll), cp = cosf(0.5f * pitch), sp = sinf(0.5f * pitch);
       const float cy = cosf(0.5f * yaw), sy = sinf(0.5f * yaw);
+      spawn_x = x; spawn_y = y;
       if (lane == 0) q = x;
       if (lane == 1) q = y;
       if (lane == 2) q = (double)c.hip_height;
@@ -1039,13 +1042,42 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
     float dist = 1e30f, margin = 0.0f;
     if (lane < 4) { dist = W.foot_world[lane][2] - m.foot_radius[lane]; margin = m.foot_margin[lane]; }
     else if (lane - 4 < m.nlg) { dist = W.u2.c.lg_dist[lane - 4]; margin = m.lg[lane - 4].margin; }
-    for (int it = 0; it < 100; it++) {
-      const bool touching = dist + dz < margin;
-      if (ballot(touching) == 0) break;
-      float pen = wave_max(touching ? fabsf(dist + dz) : 0.0f);
-      dz += 1.1f * pen;
+    if constexpr (!BOXES) {
+      for (int it = 0; it < 100; it++) {
+        const bool touching = dist + dz < margin;
+        if (ballot(touching) == 0) break;
+        float pen = wave_max(touching ? fabsf(dist + dz) : 0.0f);
+        dz += 1.1f * pen;
+      }
+      failed = ballot(dist + dz < margin) != 0;
+    } else {
+      /* with world boxes a lift changes the box distances unevenly: every iteration re-evaluates the calf-body items against
+       * the floor (shifted) and against the boxes near the lifted robot, like the reference's mj_step1 per iteration */
+      for (int it = 0; it <= 100; it++) {
+        float pen = (dist + dz < margin) ? fabsf(dist + dz) : 0.0f;
+        uint64_t cand[2];
+        box_candidates(W, m, spawn_x, spawn_y, dz, cand); /* around the lifted base */
+        for (int half = 0; half < 2; half++) {
+          uint64_t todo = cand[half];
+          while (todo) { /* wave-uniform */
+            const int b = half * GQ_WAVE + ffs64(todo);
+            todo &= todo - 1;
+            float bd; V3 bn, bp;
+            box_item_scan(W, m, a.vx, a.vy, a.vz, b, spawn_x, spawn_y, dz, true, bd, bn, bp);
+            if (lane < 4 + m.nlg) {
+              const int code = m.con_order[lane];
+              const bool calf = code < 4 || (m.lg[code - 4].body > 0 && (m.lg[code - 4].body - 1) % 3 == 2);
+              if (calf && bd < m.boxmix[m.box[b].cls][code].margin) pen = fmaxf(pen, fabsf(bd));
+            }
+            wave_barrier();
+          }
+        }
+        pen = wave_max(pen);
+        failed = pen > 0.0f;
+        if (!failed || it == 100) break;
+        dz += 1.1f * pen;
+      }
     }
-    failed = ballot(dist + dz < margin) != 0;
   }
   if (lane < 19) a.qpos[(size_t)env * 19 + lane] = lane == 2 ? q + (double)dz : q;
   if (lane < 18) {

@@ -119,11 +119,6 @@ class QuadrupedEnv(AccessorsMixin):
 
         # scene + model (reference :150-183)
         self.scene_desc, self.terrain_limits = generate_terrain(scene, self.robot_cfg.hip_height, seed=10)
-        if self.scene_desc.get('boxes'):
-            raise NotImplementedError(
-                f"scene '{scene}' is generated ({len(self.scene_desc['boxes'])} world boxes, spawn limits {self.terrain_limits}; "
-                f"gym_quadruped_amd.terrain.generate_terrain) but the step kernel has no box narrow phase yet (SURVEY.md §8f rank 2): "
-                f"only 'flat' can be simulated")
         self.mjModel: ModelDesc = (compile_mjcf(mjcf_path) if mjcf_path
                                    else load_compiled(Path(self.robot_cfg.mjcf_filename).stem))
         qpos0 = self.mjModel.qpos0.copy()
@@ -133,7 +128,7 @@ class QuadrupedEnv(AccessorsMixin):
         self._mm = MarshalledModel(self.mjModel, qpos0=qpos0, feet_geom_names=self.robot_cfg.feet_geom_names,
                                    terrain_limits=self.terrain_limits, timestep=sim_dt, solver={'pgs': 0, 'newton': 1}[solver],
                                    iterations=solver_iterations, tolerance=solver_tolerance, noise_floor=solver_noise_floor,
-                                   floor=self.scene_desc.get('floor'))
+                                   floor=self.scene_desc.get('floor'), boxes=self.scene_desc.get('boxes'))
         self._sim_dt = float(sim_dt)
 
         # leg index maps (reference :189-212)

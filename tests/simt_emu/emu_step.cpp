@@ -59,7 +59,7 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
       bool respawn = call.auto_reset == 2 && f.s.pending[e];
       for (;;) {
         if (respawn) {
-          gq::reset_wave(f.r, W);
+          if (M.nbox > 0) gq::reset_wave<true>(f.r, W); else gq::reset_wave<false>(f.r, W);
           pass = call.auto_reset;
         }
         int term;
@@ -90,7 +90,7 @@ extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mas
     if (mask && !mask[e]) continue;
     emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
       __shared__ gq::WaveMem W;
-      gq::reset_wave(a, W);
+      if (M.nbox > 0) gq::reset_wave<true>(a, W); else gq::reset_wave<false>(a, W);
     });
   }
   return 0;

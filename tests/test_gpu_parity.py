@@ -397,3 +397,81 @@ def test_step_is_hip_graph_capturable():
         gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(eager.qpos, graphed.qpos) and torch.equal(eager.qvel, graphed.qvel)
+
+
+@pytest.mark.parametrize('robot,scene', [('aliengo', 'random_boxes'), ('hyqreal1', 'random_boxes'), ('mini_cheetah', 'stairs'),
+                                         ('go2', 'random_pyramids'), ('aliengo', 'ramp'), ('b2', 'slippery')])
+def test_box_scenes_rollout_and_step_parity(robot, scene):
+    """Scenes with static world boxes (terrain.py: random_boxes / random_pyramids procedural, ramp / slippery / stairs static;
+    BASELINE config 5 is hyqreal1 on random_boxes): reset inside the scene's limits, a random rollout with next-step
+    auto-reset stays finite, and one step from the rollout state matches the fp64 oracle (same box narrow phase)."""
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    from oracle.oracle import Oracle
+    n = 256
+    env = QuadrupedEnv(robot, scene=scene, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, solver='newton',
+                       auto_reset='next_step', seed=11)
+    assert len(env.scene_desc['boxes']) > 0
+    env.reset(random=True)
+    lim = env.terrain_limits
+    q = env.qpos
+    assert bool(((q[:, 0] <= lim[0]) & (q[:, 0] >= lim[1]) & (q[:, 1] <= lim[2]) & (q[:, 1] >= lim[3])).all())
+    g = torch.Generator(device='cuda:0').manual_seed(2)
+    for _ in range(120):
+        obs, rew, term, trunc, info = env.step(torch.randn(n, 12, generator=g, device='cuda:0') * 15)
+    torch.cuda.synchronize()
+    assert torch.isfinite(env.qpos).all() and torch.isfinite(env.qvel).all() and torch.isfinite(env._obs_buf).all()
+    # one more step, checked against the oracle
+    q0, v0, w0, fr = env.qpos.cpu().numpy().copy(), env.qvel.cpu().numpy().copy(), env._warm.cpu().numpy().copy(), env._friction.cpu().numpy().copy()
+    pend = env._terminated_b.cpu().numpy().copy()
+    act = torch.randn(n, 12, generator=g, device='cuda:0') * 15
+    env.enable_debug(n)
+    obs, rew, term, trunc, info = env.step(act)
+    torch.cuda.synchronize()
+    dbg = env.debug_internals(n, ['qacc', 'nefc'])
+    o = Oracle(marshalled(robot, solver=1, iterations=100, tolerance=1e-12, boxes=env.scene_desc['boxes'], terrain_limits=lim))
+    a = act.cpu().numpy()
+    qv = env.qvel.cpu().numpy()
+    nchecked = nbox = 0
+    for e in range(n):
+        if pend[e]:
+            continue   # this env spent the step on its reset
+        o.set_state(q0[e], v0[e], w0[e], np.zeros(18), 0.0, float(fr[e])); o.step(a[e].astype(np.float64))
+        if (o.ncon and o.get('contact_tiegap').min() < 3e-6) or int(dbg[e]['nefc'][0]) != o.nefc:
+            continue
+        nchecked += 1
+        nbox += int((np.abs(o.contact_frame[:, 0, 2] - 1.0) > 1e-9).sum() + (np.abs(o.contact_pos[:, 2]) > 5e-3).sum()) if o.ncon else 0
+        assert np.abs(dbg[e]['qacc'] - o.qacc).max() < 3e-4 * max(1.0, np.abs(o.qacc).max()), e
+        assert np.abs(qv[e] - o.qvel).max() < 1e-3
+    assert nchecked > 0.5 * n and nbox > 0, (nchecked, nbox)
+
+
+def test_heightmap_rays_hit_world_boxes():
+    """HeightMap on a box scene: every ray's hit height equals the highest box top (or the floor) under it (numpy ray-box)."""
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    from gym_quadruped_amd.sensors import HeightMap
+    from scipy.spatial.transform import Rotation
+    n = 64
+    env = QuadrupedEnv('aliengo', scene='random_boxes', state_obs_names=('qpos',), num_envs=n, solver='newton', seed=5)
+    env.reset(random=True)
+    hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)
+    data = hm.update_height_map(env.qpos[:, 0:3], yaw=0.3).reshape(n, -1, 3).cpu().numpy()
+    boxes = env.scene_desc['boxes']
+    R = [Rotation.from_quat(np.asarray(b['quat']), scalar_first=True).as_matrix() for b in boxes]
+    nhit = 0
+    for e in range(0, n, 7):
+        for p in data[e]:
+            top = 0.0
+            for b, Rb in zip(boxes, R):
+                o_l = Rb.T @ (np.array([p[0], p[1], 10.0]) - np.asarray(b['pos'])); d_l = Rb.T @ np.array([0.0, 0.0, -1.0])
+                tin, tout, ok = -1e30, 1e30, True
+                for k in range(3):
+                    if abs(d_l[k]) < 1e-12:
+                        ok &= abs(o_l[k]) <= b['size'][k]
+                        continue
+                    t0, t1 = (-b['size'][k] - o_l[k]) / d_l[k], (b['size'][k] - o_l[k]) / d_l[k]
+                    tin, tout = max(tin, min(t0, t1)), min(tout, max(t0, t1))
+                if ok and tin <= tout and tout >= 0:
+                    top = max(top, 10.0 - tin)
+            assert abs(p[2] - top) < 1e-4, (e, p, top)
+            nhit += top > 1e-6
+    assert nhit > 0
