@@ -13,8 +13,8 @@ marshaller (``cabi.MarshalledModel``): the floor plane plus a list of static wor
   (``model_data/static_scenes.json``, extracted by ``tools/gen_golden_terrain.py``).
 * ``perlin`` needs a height-field narrow phase and ``noise.pnoise2``: not built - raises.
 
-Scene generation is host-side set-up code; whether the batched GPU path can SIMULATE a scene with boxes is decided
-by the model marshaller / ``gq_model_create`` (world boxes need the box narrow phase).
+Scene generation is host-side set-up code; the boxes travel in ``GqModelDesc`` (``box_*`` tables) and are simulated by the
+BOXES variants of the step kernel (``csrc/gq_boxes.h``; Newton solver only - ``gq_model_create`` rejects them with PGS).
 """
 from __future__ import annotations
 
