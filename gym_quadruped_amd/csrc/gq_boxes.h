@@ -59,19 +59,35 @@ __device__ inline void box_candidates(const WaveMem& W, const GqDevModel& m, dou
     bool near = false;
     if (b < m.nbox) {
       const GqDevBox& B = m.box[b];
-      const float dx = (float)((double)B.pos[0] - bx), dy = (float)((double)B.pos[1] - by), dz = B.pos[2] - (W.basez + zoff);
-      const float reach = B.rad + m.robot_radius + 0.05f;
-      near = dx * dx + dy * dy + dz * dz < reach * reach;
+      /* robot bounding sphere against the box itself (not its bounding sphere: the boxes are flat slabs) */
+      const V3 cb = v3((float)(bx - (double)B.pos[0]), (float)(by - (double)B.pos[1]), W.basez + zoff - B.pos[2]);
+      V3 nn;
+      near = sphere_box(matTvec(B.mat, cb), ld3(B.size), m.robot_radius, nn) < 0.05f;
     }
     cand[half] = ballot(near);
   }
 }
 
 /* Collision items against box b (wave-uniform): after the call lane `it` (position in con_order) holds the signed distance,
- * world normal and contact point (midway between the surfaces) of its item.  calf_only: only geoms of the calf bodies
- * (reset lift loop).  zoff: extra height of the robot (lift loop). */
-__device__ inline void box_item_scan(WaveMem& W, const GqDevModel& m, const float* vx, const float* vy, const float* vz, int b,
-                                     double bx, double by, float zoff, bool calf_only, float& dist, V3& nrm, V3& pt) {
+ * world normal and contact point (midway between the surfaces) of its item; false (and no barrier) when nothing is near.
+ * (cg, rg): item_sphere of the lane's link geom.  zoff: extra height of the robot (lift loop). */
+/* bounding sphere of link geom `lane`'s cloud in kernel coordinates (box independent: taken once per step / reset);
+ * radius < 0: the lane has no geom, or not a calf geom when calf_only */
+__device__ inline void item_sphere(const WaveMem& W, const GqDevModel& m, bool calf_only, V3& c, float& r) {
+  const int lane = lane_id();
+  c = v3(0.0f, 0.0f, 0.0f); r = -1.0f;
+  if (lane < m.nlg) {
+    const GqDevGeom& G = m.lg[lane];
+    const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
+    if (!calf_only || calf) {
+      c = ld3(W.xpos[G.body]) + matvec(W.xmat[G.body], ld3(G.pos) + matvec(G.mat, ld3(G.aabb_c)));
+      r = sqrtf(G.aabb_h[0] * G.aabb_h[0] + G.aabb_h[1] * G.aabb_h[1] + G.aabb_h[2] * G.aabb_h[2]) + G.radius;
+    }
+  }
+}
+
+__device__ inline bool box_item_scan(WaveMem& W, const GqDevModel& m, const float* vx, const float* vy, const float* vz, int b,
+                                     double bx, double by, float zoff, V3 cg, float rg, float& dist, V3& nrm, V3& pt) {
   const int lane = lane_id();
   const GqDevBox& B = m.box[b];
   const V3 bp = v3((float)((double)B.pos[0] - bx), (float)((double)B.pos[1] - by), B.pos[2] - zoff); /* box relative to the base x/y */
@@ -80,17 +96,20 @@ __device__ inline void box_item_scan(WaveMem& W, const GqDevModel& m, const floa
   /* phase A, lane = link geom: bounding spheres */
   bool needs = false;
   if (lane < nlg) {
-    const GqDevGeom& G = m.lg[lane];
-    const float* Rb = W.xmat[G.body];
-    const V3 cg = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos) + matvec(G.mat, ld3(G.aabb_c)));
-    const float rg = sqrtf(G.aabb_h[0] * G.aabb_h[0] + G.aabb_h[1] * G.aabb_h[1] + G.aabb_h[2] * G.aabb_h[2]) + G.radius;
-    const V3 d = cg - bp;
-    const float reach = rg + B.rad + m.boxmix[B.cls][4 + lane].margin;
-    const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
-    needs = dot(d, d) < reach * reach && (!calf_only || calf);
+    V3 nn; /* bounding sphere of the cloud against the box itself */
+    needs = rg >= 0.0f && sphere_box(matTvec(B.mat, cg - bp), bs, rg, nn) < m.boxmix[B.cls][4 + lane].margin;
     if (!needs) W.u2.c.lg_dist[lane] = 1e30f;
   }
   uint64_t todo = ballot(needs);
+  { /* nothing near this box (no link geom, no foot): skip the scan, the barrier and the item pass */
+    bool foot_near = false;
+    if (lane < 4) {
+      V3 nn;
+      foot_near = sphere_box(matTvec(B.mat, ld3(W.foot_world[lane]) - bp), bs, m.foot_radius[lane], nn) < m.boxmix[B.cls][lane].margin;
+    }
+    dist = 1e30f; nrm = v3(0.0f, 0.0f, 1.0f); pt = v3(0.0f, 0.0f, 0.0f);
+    if ((todo | ballot(foot_near)) == 0) return false;
+  }
   while (todo) { /* wave-uniform */
     const int g = ffs64(todo);
     todo &= todo - 1;
@@ -147,6 +166,7 @@ __device__ inline void box_item_scan(WaveMem& W, const GqDevModel& m, const floa
       dist = W.u2.c.lg_dist[code - 4]; nrm = ld3(GQ_BX_LGNRM(W) + 3 * (code - 4)); pt = ld3(W.u2.c.lg_pt[code - 4]);
     }
   }
+  return true;
 }
 
 /* S6 (BOXES): append the contacts with the world boxes to the list the floor pass left in W (ncon, nefc, invalid,
@@ -168,6 +188,8 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GqDevModel& m, const
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); reserve += d > 1 ? d - 1 : 0; }
   uint64_t cand[2];
   box_candidates(W, m, bx, by, 0.0f, cand);
+  V3 cg; float rg;
+  item_sphere(W, m, false, cg, rg);
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
     uint64_t todo = cand[half];
@@ -175,7 +197,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GqDevModel& m, const
       const int b = half * GQ_WAVE + ffs64(todo);
       todo &= todo - 1;
       float dist; V3 nrm, pt;
-      box_item_scan(W, m, vx, vy, vz, b, bx, by, 0.0f, false, dist, nrm, pt);
+      if (!box_item_scan(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, dist, nrm, pt)) continue;
       const int cls = m.box[b].cls;
       bool touching = false, calf = false;
       int code = 0, body = 0, dim = 3;

@@ -978,6 +978,7 @@ struct ResetArgs {
 enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH = 27, RN_VNORM = 28, RN_HEADING = 29,
        RN_YAWDOT = 30, RN_FRICTION = 31 };
 
+#define GQ_LIFT_RULE_ITERS 4
 template <bool BOXES>
 __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   int lane_o = lane_id(), env_o = (int)blockIdx.x;
@@ -1053,8 +1054,15 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
     } else {
       /* with world boxes a lift changes the box distances unevenly: every iteration re-evaluates the calf-body items against
        * the floor (shifted) and against the boxes near the lifted robot, like the reference's mj_step1 per iteration */
+      /* The reference's rule (z += 1.1 max|dist| until nothing touches) converges geometrically when a foot leaves a box
+       * through a steep side face (gain 1.1 |dist| n_z per iteration) and then raises RuntimeError after 100 iterations.
+       * Here the rule is followed for GQ_LIFT_RULE_ITERS iterations; after that the lift is whatever clears the top of
+       * every box still touched (boxes are convex: the pose above them is free) - a handful of scans instead of 100. */
+      V3 calf_c; float calf_r;
+      item_sphere(W, m, true, calf_c, calf_r);
       for (int it = 0; it <= 100; it++) {
         float pen = (dist + dz < margin) ? fabsf(dist + dz) : 0.0f;
+        float clear = 0.0f; /* lift that takes the touching item above the box altogether */
         uint64_t cand[2];
         box_candidates(W, m, spawn_x, spawn_y, dz, cand); /* around the lifted base */
         for (int half = 0; half < 2; half++) {
@@ -1063,11 +1071,17 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
             const int b = half * GQ_WAVE + ffs64(todo);
             todo &= todo - 1;
             float bd; V3 bn, bp;
-            box_item_scan(W, m, a.vx, a.vy, a.vz, b, spawn_x, spawn_y, dz, true, bd, bn, bp);
+            if (!box_item_scan(W, m, a.vx, a.vy, a.vz, b, spawn_x, spawn_y, dz, calf_c, calf_r, bd, bn, bp)) continue;
             if (lane < 4 + m.nlg) {
               const int code = m.con_order[lane];
               const bool calf = code < 4 || (m.lg[code - 4].body > 0 && (m.lg[code - 4].body - 1) % 3 == 2);
-              if (calf && bd < m.boxmix[m.box[b].cls][code].margin) pen = fmaxf(pen, fabsf(bd));
+              if (calf && bd < m.boxmix[m.box[b].cls][code].margin) {
+                pen = fmaxf(pen, fabsf(bd));
+                const GqDevBox& B = m.box[b];
+                const float ztop = B.pos[2] + fabsf(B.mat[6]) * B.size[0] + fabsf(B.mat[7]) * B.size[1] + fabsf(B.mat[8]) * B.size[2];
+                /* contact point is midway between the surfaces: the item's lowest point is at most |bd| + its radius below */
+                clear = fmaxf(clear, ztop - (bp.z + dz) + fabsf(bd) + 0.02f);
+              }
             }
             wave_barrier();
           }
@@ -1075,7 +1089,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
         pen = wave_max(pen);
         failed = pen > 0.0f;
         if (!failed || it == 100) break;
-        dz += 1.1f * pen;
+        dz += it < GQ_LIFT_RULE_ITERS ? 1.1f * pen : fmaxf(1.1f * pen, wave_max(clear));
       }
     }
   }

@@ -17,7 +17,8 @@ from gym_quadruped_amd import _lib
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 robot = sys.argv[2] if len(sys.argv) > 2 else 'mini_cheetah'
-env = QuadrupedEnv(robot, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', seed=1000)
+scene = sys.argv[3] if len(sys.argv) > 3 else 'flat'
+env = QuadrupedEnv(robot, scene=scene, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', seed=1000)
 env.reset(random=True)
 g = torch.Generator(device='cuda').manual_seed(0)
 pool = [torch.randn(n, 12, generator=g, device='cuda') * 50 for _ in range(16)]
