@@ -475,3 +475,30 @@ def test_heightmap_rays_hit_world_boxes():
             assert abs(p[2] - top) < 1e-4, (e, p, top)
             nhit += top > 1e-6
     assert nhit > 0
+
+
+def test_baseline_config5_hyqreal1_boxes_imu_heightmap():
+    """BASELINE.json configs[4]: hyqreal1 on random_boxes with the IMU plug-in and a 5x5 HeightMap, the full observation
+    pipeline (ALL_OBS + 6 IMU observables): reset, a short auto-resetting rollout, everything finite and shaped."""
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    from gym_quadruped_amd.sensors import IMU, HeightMap
+    n = 512
+    names = tuple(QuadrupedEnv.ALL_OBS) + IMU.ALL_OBS
+    kw = dict(accel_name='Body_Acc', gyro_name='Body_Gyro', imu_site_name='imu', accel_noise=0.01, gyro_noise=0.01,
+              accel_bias_rate=0.01, gyro_bias_rate=0.01, seed=1)
+    env = QuadrupedEnv('hyqreal1', scene='random_boxes', state_obs_names=names, num_envs=n, sensors=(IMU,), sensors_kwargs=(kw,),
+                       solver='newton', auto_reset='next_step', seed=2)
+    obs = env.reset(random=True)
+    hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)
+    g = torch.Generator(device='cuda:0').manual_seed(0)
+    nterm = 0
+    for _ in range(60):
+        obs, rew, term, trunc, info = env.step(torch.randn(n, 12, generator=g, device='cuda:0') * 60)
+        nterm += int(term.sum())
+        heights = hm.update_height_map(env.qpos[:, 0:3], yaw=obs['base_ori_euler_xyz'][:, 2])
+    torch.cuda.synchronize()
+    assert tuple(heights.shape) == (n, 5, 5, 1, 3) and torch.isfinite(heights).all()
+    assert float(heights[..., 2].max()) > 0.02 and float(heights[..., 2].min()) >= 0.0    # some rays land on boxes, none below the floor
+    for k in names:
+        assert torch.isfinite(obs[k]).all(), k
+    assert tuple(obs['imu_acc'].shape) == (n, 3) and float(obs['imu_acc'].abs().max()) > 1.0
