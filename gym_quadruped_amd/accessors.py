@@ -254,3 +254,54 @@ class AccessorsMixin:
                 Jp = torch.einsum('nji,njk->nik', Rb, Jp); Jr = torch.einsum('nji,njk->nik', Rb, Jr)
             jp[leg], jr[leg] = Jp, Jr
         return (LegsAttr(**jp), LegsAttr(**jr)) if return_rot_jac else LegsAttr(**jp)
+
+    def feet_jacobians_dot(self, frame: str = 'world', return_rot_jac: bool = False):
+        """mj_jacDot of the foot points (:742-797): time derivative of ``feet_jacobians`` along the current velocity, the point
+        moving with its calf body; poses of the last forward pass, velocities of the current state (like every getter
+        here).  For a hinge with world axis a on a body of angular velocity w, anchored at c:  d/dt [a x (p - c)] =
+        (w x a) x (p - c) + a x (v_p - v_c);  the free joint's rotational columns use the base axes the same way."""
+        if frame not in ('world', 'base'):
+            raise ValueError(f"Invalid frame: {frame} != 'world' or 'base'")
+        xpos, xmat = self._body_poses()
+        md, N, dev = self.mjModel, self.num_envs, self.device
+        qv = self._qvel
+        foot = self._record('foot_pos').reshape(N, 4, 3)
+        jpos = torch.as_tensor(np.asarray(md.jnt_pos, dtype=np.float32).reshape(-1, 3)[1:], device=dev)
+        jax = torch.as_tensor(np.asarray(md.jnt_axis, dtype=np.float32).reshape(-1, 3)[1:], device=dev)
+        anchor = xpos[:, 1:] + torch.einsum('nbij,bj->nbi', xmat[:, 1:], jpos)
+        axis = torch.einsum('nbij,bj->nbi', xmat[:, 1:], jax)
+        Rb, xb = xmat[:, 0], xpos[:, 0]
+        w_base = torch.einsum('nij,nj->ni', Rb, qv[:, 3:6])
+        v_base = qv[:, 0:3]
+        cross = lambda a, b: torch.cross(a, b, dim=1)
+        jp, jr = {}, {}
+        for k, leg in enumerate(LEGS):
+            p = foot[:, k]
+            dofs = self.legs_qvel_idx[leg]                       # hip, thigh, calf dofs of this leg
+            # angular velocity of each chain body and velocity of a point r carried by chain body i (i = 0 hip .. 2 calf)
+            w = [w_base]
+            for d in dofs:
+                w.append(w[-1] + axis[:, d - 6] * qv[:, d:d + 1])
+
+            def vel(r, upto):   # velocity of world point r attached to the body after `upto` hinges of the leg
+                v = v_base + cross(w_base, r - xb)
+                for d in dofs[:upto]:
+                    v = v + cross(axis[:, d - 6], r - anchor[:, d - 6]) * qv[:, d:d + 1]
+                return v
+            vp = vel(p, 3)
+            Jp = torch.zeros(N, 3, 18, dtype=torch.float32, device=dev)
+            Jr = torch.zeros(N, 3, 18, dtype=torch.float32, device=dev)
+            for a in range(3):
+                e = Rb[:, :, a]
+                ed = cross(w_base, e)
+                Jp[:, :, 3 + a] = cross(ed, p - xb) + cross(e, vp - v_base)
+                Jr[:, :, 3 + a] = ed
+            for i, d in enumerate(dofs):
+                a_d, c_d = axis[:, d - 6], anchor[:, d - 6]
+                ad = cross(w[i], a_d)                            # the axis turns with the body the hinge hangs from
+                Jp[:, :, d] = cross(ad, p - c_d) + cross(a_d, vp - vel(c_d, i))
+                Jr[:, :, d] = ad
+            if frame == 'base':
+                Jp = torch.einsum('nji,njk->nik', Rb, Jp); Jr = torch.einsum('nji,njk->nik', Rb, Jr)
+            jp[leg], jr[leg] = Jp, Jr
+        return (LegsAttr(**jp), LegsAttr(**jr)) if return_rot_jac else LegsAttr(**jp)

@@ -367,6 +367,27 @@ def test_mpc_accessors_match_oracle():
         np.testing.assert_allclose(com[e].cpu().numpy(), com_ref, atol=5e-6 * max(1.0, np.abs(com_ref).max()))
         np.testing.assert_allclose(X[e, :3, :3].cpu().numpy().ravel(), ref['base_ori_SO3'], atol=1e-5)
         np.testing.assert_allclose(env.base_lin_vel('base')[e].cpu().numpy(), ref['base_lin_vel:base'], atol=1e-4)
+    # feet_jacobians_dot (mj_jacDot) against a finite difference of the oracle's mj_jac along the velocity: the record holds the
+    # poses of the last forward pass (q0) and the getters use the CURRENT velocity (env.qvel), like the reference's would
+    Jd = env.feet_jacobians_dot('world')
+    vnow = env.qvel.cpu().numpy().astype(np.float64)
+    eps = 1e-6
+    for e in range(0, n, 5):
+        def jac_at(q):
+            o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12), stage=1)
+            return {leg: o.jac(o.geom_xpos[md.geom_names.index(env.robot_cfg.feet_geom_names[leg])],
+                               int(md.geom_bodyid[md.geom_names.index(env.robot_cfg.feet_geom_names[leg])]))[0] for leg in ('FL', 'FR', 'RL', 'RR')}
+        q1 = q0[e].copy()
+        q1[0:3] += eps * vnow[e, 0:3]; q1[7:] += eps * vnow[e, 6:]
+        wq = vnow[e, 3:6] * eps   # body-frame angular increment: q <- q * exp(w dt)
+        ang = np.linalg.norm(wq)
+        dq = np.r_[np.cos(ang / 2), np.sin(ang / 2) * wq / max(ang, 1e-30)]
+        a0 = q0[e, 3:7]
+        q1[3:7] = [a0[0] * dq[0] - a0[1:] @ dq[1:], *(a0[0] * dq[1:] + dq[0] * a0[1:] + np.cross(a0[1:], dq[1:]))]
+        Ja, Jb = jac_at(q0[e]), jac_at(q1)
+        for leg in ('FL', 'FR', 'RL', 'RR'):
+            fd = (Jb[leg] - Ja[leg]) / eps
+            np.testing.assert_allclose(Jd[leg][e].cpu().numpy(), fd, atol=2e-3 * max(1.0, np.abs(fd).max()))
 
 
 def test_step_is_hip_graph_capturable():

@@ -141,7 +141,7 @@ def test_reference_getter_surface_is_present():
     GPU box only); render / ghost / key-callback are viewer code and out of scope."""
     from gym_quadruped_amd.quadruped_env import QuadrupedEnv
     for name in ('target_base_vel', 'base_lin_vel', 'base_lin_vel_err', 'base_ang_vel_err', 'base_ang_vel', 'base_lin_acc',
-                 'get_base_inertia', 'hip_positions', 'feet_pos', 'feet_vel', 'feet_jacobians', 'feet_contact_state', 'close',
+                 'get_base_inertia', 'hip_positions', 'feet_pos', 'feet_vel', 'feet_jacobians', 'feet_jacobians_dot', 'feet_contact_state', 'close',
                  'legs_mass_matrix', 'legs_qfrc_bias', 'legs_qfrc_passive', 'com', 'kinetic_energy', 'work',
                  'base_configuration', 'joint_space_state', 'base_pos', 'base_ori_euler_xyz', 'heading_orientation_SO3',
                  'torque_ctrl_setpoint', 'gravity_vector', 'simulation_dt', 'simulation_time', 'robot_model',
