@@ -4,14 +4,14 @@ States come from CPU oracle rollouts under the bench's action distribution (50*N
 previous step's qacc like in the benchmark.  For each floor value the kernel body (host SIMT emulator) takes one step
 from every state; reported: mean / max Newton iterations and the qacc error against the CONVERGED fp64 Newton oracle.
 
-    python tools/newton_floor_sweep.py [n_states]
+    python tests/reports/newton_floor_sweep.py [n_states]
 """
 import sys
 from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 from helpers import dbg, emu_step, marshalled  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402

@@ -7,7 +7,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 from helpers import ALL_OBS, dbg, emu_step, marshalled, random_states  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402

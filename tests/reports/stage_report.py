@@ -2,7 +2,7 @@
 import sys
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 import torch
 from helpers import marshalled, random_states
