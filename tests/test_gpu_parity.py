@@ -523,3 +523,39 @@ def test_baseline_config5_hyqreal1_boxes_imu_heightmap():
     for k in names:
         assert torch.isfinite(obs[k]).all(), k
     assert tuple(obs['imu_acc'].shape) == (n, 3) and float(obs['imu_acc'].abs().max()) > 1.0
+
+
+def test_api_edge_cases_single_env_action_forms_and_errors():
+    """Drop-in edge cases: one env (the reference's shape), [nu] and numpy actions, masked reset leaving other envs alone,
+    and the reference's error behaviour (unknown observable / robot / scene names raise ValueError; 'hyqreal' alone is not a
+    registry key; PGS with elliptic cones or box scenes is refused with a reason)."""
+    from gym_quadruped_amd import _lib
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    env = QuadrupedEnv('mini_cheetah', num_envs=1)
+    obs = env.reset()
+    assert tuple(obs['qpos'].shape) == (1, 19)
+    a = env.action_space.sample() * 10                      # numpy [nu]
+    o1, r, term, trunc, info = env.step(a)
+    assert tuple(o1['qvel'].shape) == (1, 18) and r.shape == (1,) and term.dtype == torch.bool
+    o2, *_ = env.step(torch.as_tensor(a, dtype=torch.float64))   # wrong dtype / device: converted, same semantics
+    with pytest.raises(ValueError):
+        env.step(np.zeros((1, 7)))
+    env4 = QuadrupedEnv('mini_cheetah', num_envs=4, seed=1)
+    env4.reset(random=True)
+    before = env4.qpos.clone()
+    env4.reset(random=True, env_ids=[1, 3])
+    after = env4.qpos
+    assert torch.equal(after[0], before[0]) and torch.equal(after[2], before[2])
+    assert not torch.equal(after[1], before[1]) and not torch.equal(after[3], before[3])
+    with pytest.raises(ValueError):
+        QuadrupedEnv('mini_cheetah', state_obs_names=('qpos', 'not_an_observable'), num_envs=1)
+    with pytest.raises(ValueError):
+        QuadrupedEnv('hyqreal', num_envs=1)
+    with pytest.raises(ValueError):
+        QuadrupedEnv('mini_cheetah', scene='moon', num_envs=1)
+    with pytest.raises(NotImplementedError):
+        QuadrupedEnv('mini_cheetah', scene='perlin', num_envs=1)
+    with pytest.raises(_lib.GqError, match='Newton'):
+        QuadrupedEnv('go2', solver='pgs', num_envs=1)
+    with pytest.raises(_lib.GqError, match='Newton'):
+        QuadrupedEnv('aliengo', scene='stairs', solver='pgs', num_envs=1)
