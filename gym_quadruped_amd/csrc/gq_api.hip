@@ -57,6 +57,14 @@ struct GqBatch {
   int debug_cap;
 };
 
+/* the launches must be issued with the batch's device current (the caller's stream belongs to it); restore the caller's
+ * device afterwards so that a framework sharing the thread is not surprised */
+struct DeviceGuard {
+  int prev = -1, dev;
+  explicit DeviceGuard(int d) : dev(d) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+
 extern "C" {
 
 const char* gq_last_error(void) { return g_err; }
@@ -207,6 +215,7 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
       !out.terminated || !out.truncated || !out.invalid_contact || !out.step_num) {
     SET_ERR("gq_step: null tensor"); return GQ_EINVAL;
   }
+  DeviceGuard guard(b->model->device);
   if (auto_reset && (!episode || !st.cmd)) { SET_ERR("gq_step: auto-reset needs the episode counters and the command tensor"); return GQ_EINVAL; }
   const int rc = ensure_args(b, st, out, episode, lift_failed, auto_reset, (hipStream_t)hip_stream);
   if (rc != GQ_OK) return rc;
@@ -225,6 +234,7 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
     SET_ERR("gq_reset: null tensor"); return GQ_EINVAL;
   }
   if ((qpos_new == nullptr) != (qvel_new == nullptr)) { SET_ERR("gq_reset: qpos_new and qvel_new must be given together"); return GQ_EINVAL; }
+  DeviceGuard guard(b->model->device);
   gq::ResetArgs r{};
   fill_reset_args(&r, b, mask, qpos_new, qvel_new, cfg, st, out, episode, lift_failed);
   r.clear_terminated = out.terminated; r.clear_truncated = out.truncated; r.clear_invalid = out.invalid_contact;
@@ -250,6 +260,7 @@ int gq_batch_set_pending(GqBatch* b, const uint8_t* flags, void* hip_stream) {
 int gq_heightmap(GqBatch* b, const double* center, const float* yaw, int rows, int cols, float dist_x, float dist_y,
                  float* out, void* hip_stream) {
   if (!b || !center || !yaw || !out || rows <= 0 || cols <= 0) { SET_ERR("gq_heightmap: bad argument"); return GQ_EINVAL; }
+  DeviceGuard guard(b->model->device);
   gq_launch_heightmap(b->model->dev, center, yaw, b->host.n_envs, rows, cols, dist_x, dist_y, out, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
