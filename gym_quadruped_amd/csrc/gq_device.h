@@ -89,6 +89,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 /* optimisation barrier: the value becomes opaque to the compiler (no code is emitted) */
 __device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ int opaque_lane(int l) { asm volatile("" : "+v"(l)); return l; }
 template <class T> __device__ __forceinline__ const T* opaque_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; } /* per-lane pointer */
 __device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); } /* wave-uniform value */
 

@@ -400,7 +400,7 @@ __device__ inline float newton_solve(WaveMem& W, const GqDevModel& m, int rtype,
   /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */
   /* (each use goes through opaque_ptr: otherwise the compiler merges the re-reads, keeps the 18 values live across the
    * whole solve and spills them to scratch - the opposite of the intent) */
-#define J (opaque_ptr(W.u.B[lane]))
+#define J (W.u.B[opaque_lane(lane)]) /* an opaque INDEX: an opaque pointer would lose its LDS address space and turn into flat loads */
   const float rD = 1.0f / rR;
   const float scale = 1.0f / (m.meaninertia * 18.0f);
   float* dq = W.qacc_int;       /* scratch 18-vectors: free until S10 */

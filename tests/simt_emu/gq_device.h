@@ -59,6 +59,7 @@ static inline int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 static inline void opaque(int&) {}
 static inline void opaque_s(int&) {}
 template <class T> static inline const T* opaque_ptr(const T* p) { return p; }
+static inline int opaque_lane(int l) { return l; }
 static inline void sched_fence() {}
 static inline long long cycles() { return 0; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
