@@ -8,6 +8,12 @@
 
 #define GQ_WAVE 64
 
+/* Pointers that the kernels load FROM MEMORY (the device-resident argument block) have no address space the compiler
+ * could infer: every access through them becomes a FLAT instruction (64-bit VGPR addresses, both wait counters).  They
+ * all point to global memory, so they are cast into address space 1 where they are used: global_load / global_store
+ * with a scalar base again. */
+#define GQ_GLOBAL __attribute__((address_space(1)))
+
 namespace gq {
 
 /* The lane index is deliberately opaque to the optimiser (empty asm volatile): per-lane address arithmetic then stays
@@ -89,6 +95,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 /* optimisation barrier: the value becomes opaque to the compiler (no code is emitted) */
 __device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
+template <class T> __device__ __forceinline__ GQ_GLOBAL T* gptr(T* p) { return (GQ_GLOBAL T*)p; }
 __device__ __forceinline__ int opaque_lane(int l) { asm volatile("" : "+v"(l)); return l; }
 template <class T> __device__ __forceinline__ const T* opaque_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; } /* per-lane pointer */
 __device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); } /* wave-uniform value */

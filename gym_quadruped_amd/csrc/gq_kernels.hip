@@ -15,10 +15,10 @@ namespace gq {
  * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
 template <int SOLVER, int MODE, bool CONE, bool BOXES>
 __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
-  if (c.mask && !c.mask[blockIdx.x]) return; /* wave-uniform */
+  if (c.mask && !gptr(c.mask)[blockIdx.x]) return; /* wave-uniform */
   __shared__ WaveMem W;
   int pass = c.first_pass;
-  bool respawn = c.auto_reset == 2 && A->s.pending[blockIdx.x]; /* wave-uniform */
+  bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[blockIdx.x]; /* wave-uniform */
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
       reset_wave<BOXES>(A->r, W);
@@ -32,14 +32,14 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __res
 
 template <bool BOXES>
 __global__ void __launch_bounds__(GQ_WAVE) reset_kernel(ResetArgs a) {
-  if (a.mask && !a.mask[blockIdx.x]) return;
+  if (a.mask && !gptr(a.mask)[blockIdx.x]) return;
   __shared__ WaveMem W;
   reset_wave<BOXES>(a, W);
 }
 
 /* HeightMap rays: one thread per (env, cell).  Scene = the floor plane z = 0 plus the static world boxes (mj_ray against
  * static geoms, heightmap.py:90-99): the nearest hit of the vertical ray with any box (slab test in the box frame). */
-__global__ void heightmap_kernel(const GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
+__global__ void heightmap_kernel(const GQ_GLOBAL GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
                                  float dist_x, float dist_y, float* out) {
   const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x), cells = rows * cols;
   if (idx >= n_envs * cells) return;
@@ -56,7 +56,7 @@ __global__ void heightmap_kernel(const GqDevModel* model, const double* center, 
   double dist = pz > 0.0 ? pz : -1.0;   /* mj_ray returns -1 when nothing is hit */
   const int nbox = model->nbox;
   for (int b = 0; b < nbox; b++) {
-    const GqDevBox& B = model->box[b];
+    const GQ_GLOBAL GqDevBox& B = model->box[b];
     const double ox = px - (double)B.pos[0], oy = py - (double)B.pos[1], oz = pz - (double)B.pos[2];
     if (ox * ox + oy * oy > (double)(B.rad * B.rad)) continue; /* the vertical ray misses the bounding sphere */
     /* origin and direction (0, 0, -1) in the box frame */
@@ -80,7 +80,7 @@ __global__ void heightmap_kernel(const GqDevModel* model, const double* center, 
 
 }  // namespace gq
 
-extern "C" void gq_launch_heightmap(const GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
+extern "C" void gq_launch_heightmap(const GQ_GLOBAL GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
                                     float dist_x, float dist_y, float* out, hipStream_t stream) {
   const int total = n_envs * rows * cols;
   hipLaunchKernelGGL(gq::heightmap_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, model, center, yaw, n_envs, rows, cols,

@@ -123,17 +123,17 @@ struct WaveMem {
 /* ------------------------------------------------------------------ small math */
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
-__device__ __forceinline__ V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+template <class P> __device__ __forceinline__ V3 ld3(P p) { return v3(p[0], p[1], p[2]); } /* any address space */
 __device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ V3 matvec(const float* m, V3 v) {
+template <class P> __device__ __forceinline__ V3 matvec(P m, V3 v) {
   return v3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
 }
-__device__ __forceinline__ V3 matTvec(const float* m, V3 v) {
+template <class P> __device__ __forceinline__ V3 matTvec(P m, V3 v) {
   return v3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z);
 }
 struct Q4 { float w, x, y, z; };
@@ -235,7 +235,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
  * (mj_factorI), both at once: lanes 0-3 eliminate the three dofs of their leg for factor 0 in registers, lanes 4-7 do
  * the same for factor 1, each emitting its Schur contribution to the 6x6 base block; lanes 0 and 4 then factor the
  * two base blocks.  Reciprocals use v_rcp_f32 (1 ulp). */
-__device__ inline void factor_tree_both(WaveMem& W, const float* damping, const float h) {
+__device__ inline void factor_tree_both(WaveMem& W, const GQ_GLOBAL float* damping, const float h) {
   const int lane = lane_id();
   const int which = (lane >> 2) & 1, leg = lane & 3;
   const float hscale = which ? h : 0.0f;
