@@ -88,8 +88,8 @@ __device__ __forceinline__ float wave_max(float v) {
 
 /* sum over the four lanes of the lane's quad, result in all four (two quad_perm DPP butterflies: [1,0,3,2], [2,3,0,1]) */
 __device__ __forceinline__ float quad_sum(float v) {
-  v += dpp_mov_self<0xB1>(v);
-  v += dpp_mov_self<0x4E>(v);
+  v += dpp_mov<0xB1>(v); /* every source lane of a quad_perm is inside the quad: the plain form folds into v_add_f32_dpp */
+  v += dpp_mov<0x4E>(v);
   return v;
 }
 

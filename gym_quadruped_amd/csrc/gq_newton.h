@@ -400,7 +400,8 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_GLOBAL GqDevModel& m, 
   /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */
   /* (each use goes through opaque_ptr: otherwise the compiler merges the re-reads, keeps the 18 values live across the
    * whole solve and spills them to scratch - the opposite of the intent) */
-#define J (W.u.B[opaque_lane(lane)]) /* an opaque INDEX: an opaque pointer would lose its LDS address space and turn into flat loads */
+#define JROW() (W.u.B[opaque_lane(lane)]) /* an opaque INDEX (an opaque pointer would lose its LDS address space and turn into flat
+                                           * loads); taken ONCE per use site: each expansion re-derives lane * 72 with a slow v_mul_lo_u32 */
   const float rD = 1.0f / rR;
   const float scale = 1.0f / (m.meaninertia * 18.0f);
   float* dq = W.qacc_int;       /* scratch 18-vectors: free until S10 */
@@ -412,8 +413,11 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_GLOBAL GqDevModel& m, 
   float cost_w, cost_s;
   {
     float yw = -raref, ys = -raref;
+    {
+      const float* J = JROW();
 #pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) { yw += J[k] * W.warm[k]; ys += J[k] * W.qacc_smooth[k]; }
+      for (int k = 0; k < GQ_NVD; k++) { yw += J[k] * W.warm[k]; ys += J[k] * W.qacc_smooth[k]; }
+    }
     float cw, cs, tmp;
     row_law(rtype, yw, rR, rD, rfloss, cw, tmp);
     row_law(rtype, ys, rR, rD, rfloss, cs, tmp);
@@ -466,8 +470,11 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_GLOBAL GqDevModel& m, 
   /* residual y = J qacc - aref and Ma-terms are evaluated once, then advanced incrementally along the search
    * direction (y += alpha J s, M dq += alpha M s), as mj_solNewton does */
   float y = -raref, dqv = 0.0f, md = 0.0f;
+  {
+    const float* J = JROW();
 #pragma unroll
-  for (int k = 0; k < GQ_NVD; k++) y += J[k] * W.qacc[k];
+    for (int k = 0; k < GQ_NVD; k++) y += J[k] * W.qacc[k];
+  }
   if (lane < GQ_NVD) { dqv = W.qacc[lane] - W.qacc_smooth[lane]; dq[lane] = dqv; }
   wave_barrier();
   if (lane < GQ_NVD) md = mul_m_row(W, dq, lane);
@@ -616,8 +623,11 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_GLOBAL GqDevModel& m, 
     NW_T(5);
     /* ---- exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on phi' */
     float v = 0.0f;
+    {
+      const float* J = JROW();
 #pragma unroll
-    for (int k = 0; k < GQ_NVD; k++) v += J[k] * search[k];
+      for (int k = 0; k < GQ_NVD; k++) v += J[k] * search[k];
+    }
     float ms = 0.0f;
     if (lane < GQ_NVD) { ms = mul_m_row(W, search, lane); Ms[lane] = ms; }
     const float q1 = wave_sum(lane < GQ_NVD ? search[lane] * md : 0.0f);
@@ -684,7 +694,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_GLOBAL GqDevModel& m, 
   if constexpr (DBG) if (tdbg && lane == 0)
   { for (int k = 0; k < 7; k++) tdbg[16 + k] = (float)tacc[k]; tdbg[23] = (float)exit_code; }
 #undef NW_T
-#undef J
+#undef JROW
   niter = iter;
   wave_barrier();
   return f;
