@@ -51,14 +51,14 @@ __device__ __forceinline__ void make_frame(V3 n, V3& t1, V3& t2) {
 }
 
 /* bit mask (two words) of the boxes whose bounding sphere meets the robot's; base = (0, 0, basez) in kernel coordinates */
-__device__ inline void box_candidates(const WaveMem& W, const GQ_GLOBAL GqDevModel& m, double bx, double by, float zoff, uint64_t cand[2]) {
+__device__ inline void box_candidates(const WaveMem& W, const GQ_MODEL GqDevModel& m, double bx, double by, float zoff, uint64_t cand[2]) {
   const int lane = lane_id();
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     const int b = half * GQ_WAVE + lane;
     bool near = false;
     if (b < m.nbox) {
-      const GQ_GLOBAL GqDevBox& B = m.box[b];
+      const GQ_MODEL GqDevBox& B = m.box[b];
       /* robot bounding sphere against the box itself (not its bounding sphere: the boxes are flat slabs) */
       const V3 cb = v3((float)(bx - (double)B.pos[0]), (float)(by - (double)B.pos[1]), W.basez + zoff - B.pos[2]);
       V3 nn;
@@ -73,11 +73,11 @@ __device__ inline void box_candidates(const WaveMem& W, const GQ_GLOBAL GqDevMod
  * (cg, rg): item_sphere of the lane's link geom.  zoff: extra height of the robot (lift loop). */
 /* bounding sphere of link geom `lane`'s cloud in kernel coordinates (box independent: taken once per step / reset);
  * radius < 0: the lane has no geom, or not a calf geom when calf_only */
-__device__ inline void item_sphere(const WaveMem& W, const GQ_GLOBAL GqDevModel& m, bool calf_only, V3& c, float& r) {
+__device__ inline void item_sphere(const WaveMem& W, const GQ_MODEL GqDevModel& m, bool calf_only, V3& c, float& r) {
   const int lane = lane_id();
   c = v3(0.0f, 0.0f, 0.0f); r = -1.0f;
   if (lane < m.nlg) {
-    const GQ_GLOBAL GqDevGeom& G = m.lg[lane];
+    const GQ_MODEL GqDevGeom& G = m.lg[lane];
     const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
     if (!calf_only || calf) {
       c = ld3(W.xpos[G.body]) + matvec(W.xmat[G.body], ld3(G.pos) + matvec(G.mat, ld3(G.aabb_c)));
@@ -86,10 +86,10 @@ __device__ inline void item_sphere(const WaveMem& W, const GQ_GLOBAL GqDevModel&
   }
 }
 
-__device__ inline bool box_item_scan(WaveMem& W, const GQ_GLOBAL GqDevModel& m, const GQ_GLOBAL float* vx, const GQ_GLOBAL float* vy, const GQ_GLOBAL float* vz, int b,
+__device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, int b,
                                      double bx, double by, float zoff, V3 cg, float rg, float& dist, V3& nrm, V3& pt) {
   const int lane = lane_id();
-  const GQ_GLOBAL GqDevBox& B = m.box[b];
+  const GQ_MODEL GqDevBox& B = m.box[b];
   const V3 bp = v3((float)((double)B.pos[0] - bx), (float)((double)B.pos[1] - by), B.pos[2] - zoff); /* box relative to the base x/y */
   const V3 bs = ld3(B.size);
   const int nlg = m.nlg;
@@ -113,7 +113,7 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_GLOBAL GqDevModel& m, 
   while (todo) { /* wave-uniform */
     const int g = ffs64(todo);
     todo &= todo - 1;
-    const GQ_GLOBAL GqDevGeom& G = m.lg[g];
+    const GQ_MODEL GqDevGeom& G = m.lg[g];
     const float* Rb = W.xmat[G.body];
     /* vertex -> box frame: p = A v + t, A = Bmat' Rb Rg, t = Bmat' (xpos + Rb gpos - bpos) */
     float RbRg[9], A[9];
@@ -172,7 +172,7 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_GLOBAL GqDevModel& m, 
 /* S6 (BOXES): append the contacts with the world boxes to the list the floor pass left in W (ncon, nefc, invalid,
  * foot_touch are updated; rows / row budget as in the floor pass).  Ends with a barrier. */
 template <bool CONE>
-__device__ inline void stage_box_contacts(WaveMem& W, const GQ_GLOBAL GqDevModel& m, const GQ_GLOBAL float* vx, const GQ_GLOBAL float* vy, const GQ_GLOBAL float* vz,
+__device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
                                           double bx, double by, float mu_env) {
   const int lane = lane_id();
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -204,13 +204,13 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_GLOBAL GqDevModel
       float mu = 0.0f;
       if (lane < 4 + m.nlg) {
         code = m.con_order[lane];
-        const GQ_GLOBAL GqDevMix& X = m.boxmix[cls][code];
+        const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
         touching = dist < X.margin;
         dim = X.dim;
         const float ff = m.boxcls_friction[cls][0]; /* _set_ground_friction leaves unnamed world boxes alone (quirk B8) */
         float fg;
         if (code < 4) { body = 3 + 3 * m.foot_leg[code]; calf = true; fg = mu_env >= 0.0f ? mu_env : m.foot_friction[code][0]; }
-        else { const GQ_GLOBAL GqDevGeom& G = m.lg[code - 4]; body = G.body; calf = G.body > 0 && (G.body - 1) % 3 == 2; fg = G.friction[0]; }
+        else { const GQ_MODEL GqDevGeom& G = m.lg[code - 4]; body = G.body; calf = G.body > 0 && (G.body - 1) % 3 == 2; fg = G.friction[0]; }
         mu = fmaxf(1e-5f, X.rule == 0 ? fmaxf(ff, fg) : (X.rule == 1 ? ff : fg));
       }
       const uint64_t touch_mask = ballot(touching);
@@ -227,7 +227,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_GLOBAL GqDevModel
       const bool fits = kept && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
       const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4), f6 = ballot(fits && need == 6);
       if (fits) {
-        const GQ_GLOBAL GqDevMix& X = m.boxmix[cls][code];
+        const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
         W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
         W.con_dist[idx] = dist; W.con_inc[idx] = X.includemargin; W.con_mu[idx] = mu;
         st3(W.con_pos[idx], pt);

@@ -13,6 +13,10 @@
  * all point to global memory, so they are cast into address space 1 where they are used: global_load / global_store
  * with a scalar base again. */
 #define GQ_GLOBAL __attribute__((address_space(1)))
+/* The model (GqDevModel and the collision clouds) is never written while a kernel runs: it is read through the constant
+ * address space, so that its loads are invariant - scalar loads where the address is uniform, free to be hoisted above
+ * stores and to be merged where the same word is read twice. */
+#define GQ_MODEL __attribute__((address_space(4)))
 
 namespace gq {
 
@@ -96,6 +100,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 /* optimisation barrier: the value becomes opaque to the compiler (no code is emitted) */
 __device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
 template <class T> __device__ __forceinline__ GQ_GLOBAL T* gptr(T* p) { return (GQ_GLOBAL T*)p; }
+template <class T> __device__ __forceinline__ const GQ_MODEL T* mptr(const T* p) { return (const GQ_MODEL T*)p; }
 __device__ __forceinline__ int opaque_lane(int l) { asm volatile("" : "+v"(l)); return l; }
 template <class T> __device__ __forceinline__ const T* opaque_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; } /* per-lane pointer */
 __device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); } /* wave-uniform value */

@@ -394,7 +394,7 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
 /* Newton iterations.  In: row data in registers, qacc_smooth / warm / Mc / Mb in LDS, J rows in W.u.B.
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
 template <bool DBG, bool CONE>
-__device__ inline float newton_solve(WaveMem& W, const GQ_GLOBAL GqDevModel& m, int rtype, float rR, float raref,
+__device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, int rtype, float rR, float raref,
                                      float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg, const EllRow E) {
   const int lane = lane_id();
   /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */

@@ -20,7 +20,7 @@ __device__ __forceinline__ float m_entry(const WaveMem& W, int i, int j) {
 }
 
 /* S1 (mj_kinematics): lanes 0-3 walk the leg chains; returns the normalised base quaternion (all lanes) */
-__device__ inline Q4 stage_kinematics(WaveMem& W, const GQ_GLOBAL GqDevModel& m) {
+__device__ inline Q4 stage_kinematics(WaveMem& W, const GQ_MODEL GqDevModel& m) {
   const int lane = lane_id();
   Q4 qbase = {W.qb[0], W.qb[1], W.qb[2], W.qb[3]};
   qbase = qnormalize(qbase);
@@ -76,7 +76,7 @@ __device__ inline Q4 stage_kinematics(WaveMem& W, const GQ_GLOBAL GqDevModel& m)
 
 /* S6 (mj_collision, floor plane z = 0): foot sphere centres and, per link geom, the deepest cloud vertex.
  * calf_only restricts the scan to geoms of the calf bodies (reset lift loop, quadruped_env.py:376-388). */
-__device__ inline void stage_collision_scan(WaveMem& W, const GQ_GLOBAL GqDevModel& m, const GQ_GLOBAL float* vx, const GQ_GLOBAL float* vy, const GQ_GLOBAL float* vz,
+__device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
                                             bool calf_only) {
   const int lane = lane_id();
   if (lane < 4) { /* feet: exact plane-sphere */
@@ -92,7 +92,7 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_GLOBAL GqDevMod
   float d0 = 0.0f;
   bool needs = false;
   if (lane < nlg) {
-    const GQ_GLOBAL GqDevGeom& G = m.lg[lane];
+    const GQ_MODEL GqDevGeom& G = m.lg[lane];
     const float* Rb = W.xmat[G.body];
     /* plane normal in the geom frame: n_g = Rg' Rb' n, n = (0,0,1) */
     const V3 nb = v3(Rb[6], Rb[7], Rb[8]);
@@ -107,7 +107,7 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_GLOBAL GqDevMod
   while (todo) { /* wave-uniform */
     const int g = ffs64(todo);
     todo &= todo - 1;
-    const GQ_GLOBAL GqDevGeom& G = m.lg[g];
+    const GQ_MODEL GqDevGeom& G = m.lg[g];
     const float gx = bcast(ng.x, g), gy = bcast(ng.y, g), gz = bcast(ng.z, g), gd0 = bcast(d0, g);
     float best = 1e30f;
     int bi = 0;
@@ -160,12 +160,12 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   opaque(lane_o); opaque_s(env_o);
   const int lane = lane_o, env = env_o;
   constexpr bool DBG = MODE == 1;
-  const GQ_GLOBAL GqDevModel& m = *gptr(a.model);
+  const GQ_MODEL GqDevModel& m = *mptr(a.model);
   const float h = m.timestep;
   /* the record describes the forward pass whose results the caller sees: the user's step, the reset's own step of
    * gq_reset, or the reset step of a next-step auto-reset - not the second pass of a same-step auto-reset */
   const bool rec_pass = pass == call.first_pass || pass == 2;
-  const bool timing = DBG && call.debug && rec_pass && env < gptr(a.batch)->debug_envs;
+  const bool timing = DBG && call.debug && rec_pass && env < mptr(a.batch)->debug_envs;
   const long long t_start = timing ? cycles() : 0;
 #define GQ_TICK(i) do { if constexpr (DBG) { \
     if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); } \
@@ -175,7 +175,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   /* ================================================================ S0: load the env's state rows */
   if (lane < 19) {
     double q = gptr(a.qpos)[(size_t)env * 19 + lane];
-    if (lane < 2) { }
+    if (lane < 2) W.bxy[lane] = q;
     else if (lane == 2) W.basez = (float)q;
     else if (lane < 7) W.qb[lane - 3] = (float)q;
     else W.qj[lane - 7] = (float)q;
@@ -187,6 +187,14 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   }
   if (lane < 12) W.ctrl[lane] = (call.ctrl && pass == 0) ? gptr(call.ctrl)[(size_t)env * 12 + lane] : 0.0f;
   if (lane < 4) W.cmd[lane] = a.cmd ? gptr(a.cmd)[(size_t)env * 4 + lane] : 0.0f;
+  /* per-env scalars that later stages need are fetched with the state rows (one memory round trip for all of them)
+   * and wait in LDS; the clock and the step counter advance here: nothing reads them in between */
+  if (lane == 0) {
+    W.mu_env = a.friction ? gptr(a.friction)[env] : -1.0f;
+    const int32_t sn = gptr(a.step_num)[env];
+    W.step_old = sn; gptr(a.step_num)[env] = sn + 1;
+    gptr(a.time)[env] = gptr(a.time)[env] + h;
+  }
   wave_barrier();
 
   /* actuation (mj_fwdActuation: torque motors) and passive damping depend on ctrl / qvel and model constants only: done
@@ -218,7 +226,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     const float* R = W.xmat[b];
     V3 d = ld3(W.xpos[b]) + matvec(R, ld3(m.body_ipos[b])) - O;
     /* I_w = R Ib R' */
-    const GQ_GLOBAL float* Ib = m.body_I[b];
+    const GQ_MODEL float* Ib = m.body_I[b];
     float A[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]}, T[9], Iw[9];
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -335,7 +343,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   GQ_TICK(5);
   /* ================================================================ S6: collision with the floor (z = 0) */
   const int nlg = m.nlg;
-  stage_collision_scan(W, m, gptr(a.vx), gptr(a.vy), gptr(a.vz), false);
+  stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), false);
   GQ_TICK(14);
   /* contact list in MuJoCo's order (increasing geom id; con_order interleaves feet and link geoms), capped.
    * Lane `it` evaluates collision item `it`; ranks and row offsets come from ballots (no serial section). */
@@ -345,11 +353,11 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     bool touching = false, calf = false;
     int code = 0, body = 0, dim = 3;
     float dist = 0.0f, inc = 0.0f, mu = 0.0f, px = 0.0f, py = 0.0f, pz = 0.0f;
-    const GQ_GLOBAL float* solref = m.foot_solref[0];
-    const GQ_GLOBAL float* solimp = m.foot_solimp[0];
+    const GQ_MODEL float* solref = m.foot_solref[0];
+    const GQ_MODEL float* solimp = m.foot_solimp[0];
     if (lane < nitem) {
       code = m.con_order[lane];
-      const float mu_env = a.friction ? gptr(a.friction)[env] : -1.0f; /* wave-uniform scalar load, issued here so that it is not live from S0 */
+      const float mu_env = W.mu_env;
       const float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0];
       if (code < 4) {
         const int k = code;
@@ -364,7 +372,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
         solref = m.foot_solref[k]; solimp = m.foot_solimp[k];
       } else {
         const int g = code - 4;
-        const GQ_GLOBAL GqDevGeom& G = m.lg[g];
+        const GQ_MODEL GqDevGeom& G = m.lg[g];
         dist = W.u2.c.lg_dist[g];
         touching = dist < G.margin;
         body = G.body; dim = G.dim; inc = G.includemargin; calf = G.body > 0 && (G.body - 1) % 3 == 2;
@@ -426,9 +434,9 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   }
   wave_barrier();
   if constexpr (BOXES) {
-    const double bx0 = gptr(a.qpos)[(size_t)env * 19 + 0], by0 = gptr(a.qpos)[(size_t)env * 19 + 1]; /* base x/y of this forward pass, f64 */
-    const float mu_b = a.friction ? gptr(a.friction)[env] : -1.0f;
-    stage_box_contacts<CONE>(W, m, gptr(a.vx), gptr(a.vy), gptr(a.vz), bx0, by0, mu_b);
+    const double bx0 = W.bxy[0], by0 = W.bxy[1]; /* base x/y of this forward pass, f64 */
+    const float mu_b = W.mu_env;
+    stage_box_contacts<CONE>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), bx0, by0, mu_b);
   }
   const int nefc = uniform(W.nefc), ncon = uniform(W.ncon), nlim = uniform(W.nlim), nfl = m.nfl; /* SGPRs */
   if (timing) { /* body poses go to the debug record now: xmat's LDS is reused by the Newton solver */
@@ -489,7 +497,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       /* torsional / rolling coefficients: same mixing rule as the sliding one (S6), _set_ground_friction overrides
        * floor and feet with [mu, 0.005, 0.0]; clamped at mjMINMU */
       const int code = W.con_geom[c];
-      const float mu_env = a.friction ? gptr(a.friction)[env] : -1.0f;
+      const float mu_env = W.mu_env;
       const int rule = code < 4 ? m.foot_fric_rule[code] : m.lg[code - 4].fric_rule;
       float fr[3] = {mu, 0.0f, 0.0f};
 #pragma unroll
@@ -703,7 +711,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   wave_barrier();
 
   }
-  if constexpr (DBG) if (call.debug && rec_pass && env < gptr(a.batch)->debug_envs) {
+  if constexpr (DBG) if (call.debug && rec_pass && env < mptr(a.batch)->debug_envs) {
     float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
     for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = m_entry(W, k / 18, k % 18);
     if (lane < 18) {
@@ -724,11 +732,16 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   }
 
   GQ_TICK(10);
+  /* the output layout (column -> canonical scalar) of this lane's columns: fetched now, used by the gather at the end */
+  const int od = mptr(a.batch)->obs_dim;
+  int omap[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const int k = lane + GQ_WAVE * i; omap[i] = k < od ? mptr(a.batch)->obs_map[k] : 0; }
   /* IMU ground truth (mj_sensorAcc / mj_sensorVel of this forward pass: OLD pose and velocity, this step's qacc).
    * accelerometer = site-frame acceleration of the site point minus gravity; gyro = site-frame angular velocity */
-  const bool imu_on = a.imu_bias != nullptr && gptr(a.batch)->imu_enabled;
+  const bool imu_on = a.imu_bias != nullptr && mptr(a.batch)->imu_enabled;
   if (imu_on && lane == 0) {
-    const GQ_GLOBAL GqDevBatch& B = *gptr(a.batch);
+    const GQ_MODEL GqDevBatch& B = *mptr(a.batch);
     Q4 qo = {W.qb[0], W.qb[1], W.qb[2], W.qb[3]};
     float Ro[9];
     q2mat(Ro, qnormalize(qo));
@@ -755,9 +768,9 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     gptr(a.qacc)[(size_t)env * 18 + lane] = W.qacc[lane];
     gptr(a.warm)[(size_t)env * 18 + lane] = W.qacc[lane];
   }
-  /* base x,y stay in f64 (uniform: every lane reads the same two words) and never enter fp32 arithmetic; they are
-   * read here, not at the top, so they do not occupy registers across the solver */
-  const double bx_d = gptr(a.qpos)[(size_t)env * 19 + 0], by_d = gptr(a.qpos)[(size_t)env * 19 + 1];
+  /* base x,y stay in f64 (uniform: every lane reads the same two words) and never enter fp32 arithmetic; they wait
+   * in LDS since S0, so they do not occupy registers across the solver */
+  const double bx_d = W.bxy[0], by_d = W.bxy[1];
   wave_barrier();
   if (lane < GQ_NVD) W.qvel[lane] = vnew; /* new qvel; old one is not needed any more */
   wave_barrier();
@@ -794,8 +807,6 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     qjn = W.qj[lane - 7] + h * W.qvel[lane - 1];
     gptr(a.qpos)[(size_t)env * 19 + lane] = (double)qjn;
   }
-  float tnew = 0.0f;
-  if (lane == 0) { tnew = gptr(a.time)[env] + h; gptr(a.time)[env] = tnew; }
 
   GQ_TICK(11);
   /* ================================================================ S11: observations (new qpos/qvel, old kinematics) */
@@ -898,10 +909,10 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   /* IMU.step (sensors/imu.py:102-139): noise ~ N(0, sigma), bias += N(0, rate), measurement = truth + bias + noise.
    * lanes 0-11 draw: acc noise xyz, acc bias step xyz, gyro noise xyz, gyro bias step xyz */
   if (imu_on) {
-    const GQ_GLOBAL GqDevBatch& B = *gptr(a.batch);
+    const GQ_MODEL GqDevBatch& B = *mptr(a.batch);
     float z = 0.0f;
     if (lane < 12) {
-      const uint32_t stepc = (uint32_t)gptr(a.step_num)[env], epi = a.episode_ro ? (uint32_t)gptr(a.episode_ro)[env] : 0u;
+      const uint32_t stepc = (uint32_t)W.step_old, epi = a.episode_ro ? (uint32_t)gptr(a.episode_ro)[env] : 0u;
       z = philox_normal((uint32_t)lane, stepc, (uint32_t)env, 0x1a70u ^ (epi << 8), B.imu_seed_lo, B.imu_seed_hi);
       const int grp = lane / 3;
       z *= grp == 0 ? B.imu_acc_noise : (grp == 1 ? B.imu_acc_bias_rate : (grp == 2 ? B.imu_gyro_noise : B.imu_gyro_bias_rate));
@@ -933,15 +944,14 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       }
       if (a.pending) gptr(a.pending)[env] = (uint8_t)(pass == 0 ? terminated : 0);
       gptr(a.reward)[env] = 0.0f;
-      gptr(a.step_num)[env] += 1;
       if (pass != 0 && a.friction && a.friction_next) gptr(const_cast<float*>(a.friction))[env] = gptr(a.friction_next)[env];
     }
   }
   GQ_TICK(12);
   /* gather to the requested observation layout: coalesced row write */
   {
-    const int od = gptr(a.batch)->obs_dim;
-    for (int k = lane; k < od; k += GQ_WAVE) gptr(a.obs)[(size_t)env * od + k] = ob[gptr(a.batch)->obs_map[k]];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int k = lane + GQ_WAVE * i; if (k < od) gptr(a.obs)[(size_t)env * od + k] = ob[omap[i]]; }
   }
   wave_barrier(); /* the obs row overlays u: finish reading it before a second pass reuses the region */
   GQ_TICK(13);
@@ -984,7 +994,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   int lane_o = lane_id(), env_o = (int)blockIdx.x;
   opaque(lane_o); opaque_s(env_o); /* see step_wave: no address arithmetic may be hoisted to the kernel prologue */
   const int lane = lane_o, env = env_o;
-  const GQ_GLOBAL GqDevModel& m = *gptr(a.model);
+  const GQ_MODEL GqDevModel& m = *mptr(a.model);
   const ResetCfgDev& c = a.cfg;
   const int episode = a.episode ? gptr(a.episode)[env] : 0;
   /* one uniform in [0,1) per lane < 32 */
@@ -1038,7 +1048,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   if (!explicit_state) {
     stage_kinematics(W, m);
     wave_barrier();
-    stage_collision_scan(W, m, gptr(a.vx), gptr(a.vy), gptr(a.vz), true);
+    stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), true);
     /* distances and margins of everything attached to a calf body (feet_contact_state is body-level) */
     float dist = 1e30f, margin = 0.0f;
     if (lane < 4) { dist = W.foot_world[lane][2] - m.foot_radius[lane]; margin = m.foot_margin[lane]; }
@@ -1071,13 +1081,13 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
             const int b = half * GQ_WAVE + ffs64(todo);
             todo &= todo - 1;
             float bd; V3 bn, bp;
-            if (!box_item_scan(W, m, gptr(a.vx), gptr(a.vy), gptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, bd, bn, bp)) continue;
+            if (!box_item_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, bd, bn, bp)) continue;
             if (lane < 4 + m.nlg) {
               const int code = m.con_order[lane];
               const bool calf = code < 4 || (m.lg[code - 4].body > 0 && (m.lg[code - 4].body - 1) % 3 == 2);
               if (calf && bd < m.boxmix[m.box[b].cls][code].margin) {
                 pen = fmaxf(pen, fabsf(bd));
-                const GQ_GLOBAL GqDevBox& B = m.box[b];
+                const GQ_MODEL GqDevBox& B = m.box[b];
                 const float ztop = B.pos[2] + fabsf(B.mat[6]) * B.size[0] + fabsf(B.mat[7]) * B.size[1] + fabsf(B.mat[8]) * B.size[2];
                 /* contact point is midway between the surfaces: the item's lowest point is at most |bd| + its radius below */
                 clear = fmaxf(clear, ztop - (bp.z + dz) + fabsf(bd) + 0.02f);

@@ -90,6 +90,8 @@ struct WaveDyn {
   float cfrc[GQ_NB][6];
 };
 struct WaveMem {
+  double bxy[2];               /* base x, y of this forward pass (f64, never enters fp32 arithmetic) */
+  float mu_env; int32_t step_old; /* the env's friction override (-1: none) and its step counter before this step */
   float qj[12], qb[4], basez, qvel[18], ctrl[12], warm[18], applied[18], cmd[4];
   float xpos[GQ_NB][3];
   union { float xmat[GQ_NB][9]; float acc2[5][21]; };   /* acc2: Newton factor/solve exchange (xmat is dead after S6) */
@@ -235,7 +237,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
  * (mj_factorI), both at once: lanes 0-3 eliminate the three dofs of their leg for factor 0 in registers, lanes 4-7 do
  * the same for factor 1, each emitting its Schur contribution to the 6x6 base block; lanes 0 and 4 then factor the
  * two base blocks.  Reciprocals use v_rcp_f32 (1 ulp). */
-__device__ inline void factor_tree_both(WaveMem& W, const GQ_GLOBAL float* damping, const float h) {
+__device__ inline void factor_tree_both(WaveMem& W, const GQ_MODEL float* damping, const float h) {
   const int lane = lane_id();
   const int which = (lane >> 2) & 1, leg = lane & 3;
   const float hscale = which ? h : 0.0f;

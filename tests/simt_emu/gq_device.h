@@ -16,6 +16,7 @@
 
 #define GQ_WAVE 64
 #define GQ_GLOBAL
+#define GQ_MODEL
 #define __global__
 #define __device__
 #define __host__
@@ -62,6 +63,7 @@ static inline void opaque_s(int&) {}
 template <class T> static inline const T* opaque_ptr(const T* p) { return p; }
 static inline int opaque_lane(int l) { return l; }
 template <class T> static inline T* gptr(T* p) { return p; }
+template <class T> static inline const T* mptr(const T* p) { return p; }
 static inline void sched_fence() {}
 static inline long long cycles() { return 0; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
