@@ -45,6 +45,7 @@ struct GqBatch {
   float* debug;       /* device, debug_envs * GQ_DBG_SIZE floats (lazily allocated) */
   float* friction_next; /* device [N]: friction drawn by reset, committed after the reset step */
   uint8_t* pending;     /* device [N]: next-step auto-reset flags */
+  uint8_t* load_hint;   /* device [N]: per-env solver load of the previous step (scheduling hint of the step kernel) */
   int stop_stage;       /* profiling aid: GQ_STOP_STAGE at batch creation */
   /* argument block of step_kernel: device copy, host shadow of what the device holds, pinned staging ring for the
    * (rare) stream-ordered re-upload */
@@ -114,6 +115,8 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   HIP_TRY(hipMemset(b->friction_next, 0, sizeof(float) * (size_t)n_envs));
   HIP_TRY(hipMalloc(&b->pending, (size_t)n_envs));
   HIP_TRY(hipMemset(b->pending, 0, (size_t)n_envs));
+  HIP_TRY(hipMalloc(&b->load_hint, (size_t)n_envs));
+  HIP_TRY(hipMemset(b->load_hint, 0, (size_t)n_envs));
   { const char* s = getenv("GQ_STOP_STAGE"); b->stop_stage = s ? atoi(s) : 0; }
   HIP_TRY(hipMalloc(&b->dev_args, sizeof(gq::FusedArgs)));
   HIP_TRY(hipHostMalloc(&b->staging, sizeof(gq::FusedArgs) * GQ_ARG_SLOTS, hipHostMallocDefault));
@@ -126,7 +129,7 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
 int gq_batch_destroy(GqBatch* b) {
   if (!b) return GQ_OK;
   hipSetDevice(b->model->device);
-  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->dev_args); hipHostFree(b->staging);
+  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->load_hint); hipFree(b->dev_args); hipHostFree(b->staging);
   if (b->debug) hipFree(b->debug);
   delete b;
   return GQ_OK;
@@ -173,7 +176,7 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const
   a->model = m->dev; a->batch = b->dev; a->vx = m->vx; a->vy = m->vy; a->vz = m->vz;
   a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart;
   a->applied = st.qfrc_applied; a->time = st.time; a->friction = st.friction; a->cmd = st.cmd;
-  a->friction_next = b->friction_next; a->pending = b->pending;
+  a->friction_next = b->friction_next; a->pending = b->pending; a->load_hint = b->load_hint;
   a->imu_bias = b->imu_bias;
   a->episode_ro = episode;
   a->obs = out.obs; a->reward = out.reward; a->terminated = out.terminated; a->truncated = out.truncated;

@@ -101,6 +101,14 @@ __device__ __forceinline__ float quad_sum(float v) {
 __device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
 template <class T> __device__ __forceinline__ GQ_GLOBAL T* gptr(T* p) { return (GQ_GLOBAL T*)p; }
 template <class T> __device__ __forceinline__ const GQ_MODEL T* mptr(const T* p) { return (const GQ_MODEL T*)p; }
+/* issue priority of this wave among the waves of its SIMD (0 lowest .. 3); p is wave-uniform */
+__device__ __forceinline__ void wave_priority(int p) {
+  p = __builtin_amdgcn_readfirstlane(p);
+  if (p <= 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
 __device__ __forceinline__ int opaque_lane(int l) { asm volatile("" : "+v"(l)); return l; }
 template <class T> __device__ __forceinline__ const T* opaque_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; } /* per-lane pointer */
 __device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); } /* wave-uniform value */

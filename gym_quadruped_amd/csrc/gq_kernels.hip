@@ -21,6 +21,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __res
   bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[blockIdx.x]; /* wave-uniform */
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
+      wave_priority(3); /* reset + step in one launch: this wave is the longest of its SIMD */
       reset_wave<BOXES>(A->r, W);
       pass = c.auto_reset;
     }

@@ -395,7 +395,7 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
 template <bool DBG, bool CONE>
 __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, int rtype, float rR, float raref,
-                                     float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg, const EllRow E) {
+                                     float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg, const EllRow E, int prio) {
   const int lane = lane_id();
   /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */
   /* (each use goes through opaque_ptr: otherwise the compiler merges the re-reads, keeps the 18 values live across the
@@ -479,6 +479,8 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
   wave_barrier();
   if (lane < GQ_NVD) md = mul_m_row(W, dq, lane);
   for (;; iter++) {
+    /* a wave that needs many iterations decides when the launch ends: it moves ahead of the waves it shares the SIMD with */
+    if (iter + 1 > prio && iter > 0) { prio = iter + 1; wave_priority(prio); }
     /* ---- constraint state at the current iterate */
     float ci, wact;
     f = row_law(rtype, y, rR, rD, rfloss, ci, wact);

@@ -171,6 +171,12 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); } \
     if constexpr (MODE == 2) { if (call.stop_stage == (i) && pass != 1) return 0; } } while (0)
 
+  if constexpr (DBG) if (timing && lane == 0) { /* where and when this wave runs: slots 24-27 of the time stamps */
+    float* T = call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER;
+    T[24] = (float)(wall_clock64() & 0xFFFFF);                                  /* 100 MHz clock common to the device */
+    T[26] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFF);        /* HW_ID: wave, simd, pipe, cu, sh, se */
+    T[27] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF);          /* XCC_ID */
+  }
   GQ_TICK(15); /* marker 15: nothing done yet - the launch floor */
   /* ================================================================ S0: load the env's state rows */
   if (lane < 19) {
@@ -189,6 +195,9 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   if (lane < 4) W.cmd[lane] = a.cmd ? gptr(a.cmd)[(size_t)env * 4 + lane] : 0.0f;
   /* per-env scalars that later stages need are fetched with the state rows (one memory round trip for all of them)
    * and wait in LDS; the clock and the step counter advance here: nothing reads them in between */
+  /* scheduling hint: an env whose previous step needed several Newton iterations will most likely need them again; its
+   * wave gets issue priority from the start (the launch lasts as long as its slowest wave) */
+  const int prio_hint = pass != 0 ? 3 : ((SOLVER == 1 && a.load_hint) ? (int)gptr(a.load_hint)[env] : 0);
   if (lane == 0) {
     W.mu_env = a.friction ? gptr(a.friction)[env] : -1.0f;
     const int32_t sn = gptr(a.step_num)[env];
@@ -216,6 +225,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     if constexpr (SOLVER == 1) W.F[0][lane] = h * damp; /* the Newton path stores no factor: F keeps h*damping for the Euler system (S10) */
     W.smooth[lane] = -damp * W.qvel[lane] + act + W.applied[lane];
   }
+  if constexpr (SOLVER == 1) wave_priority(prio_hint);
+  if constexpr (DBG) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 28] = (float)prio_hint;
   stage_kinematics(W, m);
 
   GQ_TICK(1);
@@ -576,7 +587,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     GQ_TICK(8);
     const EllRow ell = {ecode, er0, efri, emu, 1.0f / eR0};
     const float fN = newton_solve<DBG, CONE>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
-                                  timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell);
+                                  timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint);
+    if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)(iter < 2 ? 0 : (iter > 2 ? 3 : 2));
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
@@ -955,6 +967,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   }
   wave_barrier(); /* the obs row overlays u: finish reading it before a second pass reuses the region */
   GQ_TICK(13);
+  if constexpr (DBG) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 25] = (float)(wall_clock64() & 0xFFFFF);
 #undef GQ_TICK
   return terminated;
 }

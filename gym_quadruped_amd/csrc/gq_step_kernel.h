@@ -44,6 +44,7 @@ struct StepArgs {
   const int32_t* episode_ro; /* [N] episode counters (RNG counter word), may be NULL */
   float* friction_next;   /* library scratch [N]: friction drawn at reset, committed after the reset's own step (:403-404) */
   uint8_t* pending;       /* library scratch [N]: env terminated and waits for its next-step auto-reset (may be NULL) */
+  uint8_t* load_hint;     /* library scratch [N]: Newton iterations of the env's previous step, capped (may be NULL) */
   float* obs; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* invalid_contact; int32_t* step_num;
   int32_t n_envs;
 };

@@ -66,6 +66,9 @@ template <class T> static inline T* gptr(T* p) { return p; }
 template <class T> static inline const T* mptr(const T* p) { return p; }
 static inline void sched_fence() {}
 static inline long long cycles() { return 0; }
+static inline long long wall_clock64() { return 0; }
+static inline void wave_priority(int) {}
+#define __builtin_amdgcn_s_getreg(x) 0
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 static inline float med3(float x, float lo, float hi) { return std::min(std::max(x, lo), hi); }

@@ -1,0 +1,44 @@
+"""Where and when each wave of one step launch runs (debug kernel: it records a device-wide 100 MHz clock at wave start
+and end, the per-stage cycle stamps and the hardware slot).  Shows the dispatch ramp, the end-time distribution, how
+waves sharing a SIMD affect each other and which waves form the tail.   Usage: wave_timeline.py [n] [robot]"""
+import sys
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
+from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+robot = sys.argv[2] if len(sys.argv) > 2 else 'mini_cheetah'
+env = QuadrupedEnv(robot, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', seed=1)
+env.reset()
+g = torch.Generator(device='cuda').manual_seed(0)
+for i in range(60): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)
+env.enable_debug(n)
+pend = env._terminated.clone().cpu().numpy().astype(bool) if hasattr(env, '_terminated') else np.zeros(n, bool)
+env.step(torch.randn(n, 12, generator=g, device='cuda') * 50); torch.cuda.synchronize()
+d = env.debug_internals(n, ['timer', 'niter', 'nefc'])
+T = np.stack([x['timer'] for x in d]); nit = np.array([x['niter'][0] for x in d]).astype(int)
+t0 = T[:, 24]; t1 = T[:, 25]
+base = t0.min()
+t0 = (t0 - base) % (1 << 20) / 100.0; t1 = (t1 - base) % (1 << 20) / 100.0      # us
+hint = T[:, 28].astype(int)
+hw = T[:, 26].astype(int); xcc = T[:, 27].astype(int)
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+slot = ((xcc * 8 + se) * 2 + sh) * 16 * 4 + cu * 4 + simd
+print(f'{robot}, {n} waves: start min {t0.min():.1f} p50 {np.median(t0):.1f} p99 {np.percentile(t0, 99):.1f} max {t0.max():.1f} us;  end p50 {np.median(t1):.1f} p90 {np.percentile(t1, 90):.1f} p99 {np.percentile(t1, 99):.1f} max {t1.max():.1f} us')
+print(f'pending (reset first) waves: {int(pend.sum())};  distinct SIMD slots used: {len(np.unique(slot))}, waves per slot max {np.bincount(np.unique(slot, return_inverse=True)[1]).max()}')
+dur = t1 - t0
+for k in range(0, nit.max() + 1):
+    sel = (nit == k) & ~pend
+    if sel.sum(): print(f'  niter {k}: {sel.sum():5d} waves, lifetime mean {dur[sel].mean():6.1f} max {dur[sel].max():6.1f} us, end max {t1[sel].max():6.1f}')
+if pend.sum(): print(f'  pending:  {pend.sum():5d} waves, lifetime mean {dur[pend].mean():6.1f} max {dur[pend].max():6.1f} us, end max {t1[pend].max():6.1f}, niter mean {nit[pend].mean():.1f} max {nit[pend].max()}')
+for hv in range(4):
+    sel = hint == hv
+    if sel.sum(): print(f'  hint {hv}: {sel.sum():5d} waves, niter histogram {np.bincount(nit[sel], minlength=7).tolist()}, lifetime mean {dur[sel].mean():6.1f}')
+busy = np.array([((t0 <= t) & (t1 > t)).sum() for t in np.arange(0, t1.max(), 2.0)])
+print('resident waves every 2 us:', busy.tolist())
+last = np.argsort(-t1)[:12]
+print('last waves to finish (end us | start | niter nefc pending | co-resident waves on the SIMD: their niter):')
+for e in last:
+    co = np.where(slot == slot[e])[0]
+    print(f'  env {e:5d}: {t1[e]:6.1f} | {t0[e]:5.1f} | {nit[e]} {int(d[e]["nefc"][0]):2d} {int(pend[e])} hint {hint[e]} | ' + ' '.join(f'{nit[c]}{"r" if pend[c] else ""}h{hint[c]}@{t1[c]:.0f}' for c in co if c != e))
