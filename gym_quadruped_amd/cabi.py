@@ -44,6 +44,11 @@ class GqModelDesc(C.Structure):
         ('solver', C.c_int32), ('iterations', C.c_int32), ('tolerance', C.c_double), ('noise_floor', C.c_double),
         ('nbox', C.c_int32), ('box_pos', _D), ('box_mat', _D), ('box_size', _D), ('box_friction', _D), ('box_margin', _D),
         ('box_gap', _D), ('box_solmix', _D), ('box_solref', _D), ('box_solimp', _D), ('box_condim', _I), ('box_priority', _I),
+        ('hfield_nrow', C.c_int32), ('hfield_ncol', C.c_int32), ('hfield_data', C.POINTER(C.c_float)),
+        ('hfield_size', C.c_double * 4), ('hfield_pos', C.c_double * 3),
+        ('hfield_friction', C.c_double * 3), ('hfield_margin', C.c_double), ('hfield_gap', C.c_double),
+        ('hfield_solmix', C.c_double), ('hfield_solref', C.c_double * 2), ('hfield_solimp', C.c_double * 5),
+        ('hfield_condim', C.c_int32), ('hfield_priority', C.c_int32),
     ]
 
 
@@ -93,7 +98,7 @@ class MarshalledModel:
 
     def __init__(self, md: ModelDesc, *, qpos0=None, feet_geom_names=None, terrain_limits=(1e4, -1e4, 1e4, -1e4),
                  timestep=None, solver=SOLVER_PGS, iterations=100, tolerance=1e-8, floor=None,
-                 noise_floor=0.0, boxes=None):
+                 noise_floor=0.0, boxes=None, hfield=None):
         self.md = md
         self._keep = []
         d = GqModelDesc()
@@ -139,6 +144,25 @@ class MarshalledModel:
         d.key_qpos = (C.c_double * 19)(*[float(v) for v in kq])
         d.solver, d.iterations, d.tolerance = int(solver), int(iterations), float(tolerance)
         d.noise_floor = float(noise_floor)
+        # height field: dict(data=[nrow][ncol] in [0, 1], size=(rx, ry, elevation, base), pos=(x, y, z), + geom defaults)
+        self.hfield = hfield
+        if hfield is not None:
+            data = np.ascontiguousarray(hfield['data'], dtype=np.float32)
+            if data.ndim != 2:
+                raise ValueError('hfield data must be a 2-D array [nrow][ncol]')
+            self._keep.append(data)
+            d.hfield_nrow, d.hfield_ncol = int(data.shape[0]), int(data.shape[1])
+            d.hfield_data = data.ctypes.data_as(C.POINTER(C.c_float))
+            d.hfield_size = (C.c_double * 4)(*[float(v) for v in hfield['size']])
+            d.hfield_pos = (C.c_double * 3)(*[float(v) for v in hfield.get('pos', (0.0, 0.0, 0.0))])
+            hg = dict(friction=(1.0, 0.005, 0.0001), margin=0.0, gap=0.0, solmix=1.0, solref=(0.02, 1.0),
+                      solimp=(0.9, 0.95, 0.001, 0.5, 2.0), condim=3, priority=0)
+            hg.update({k: v for k, v in hfield.items() if k in hg})
+            d.hfield_friction = (C.c_double * 3)(*hg['friction'])
+            d.hfield_margin, d.hfield_gap, d.hfield_solmix = hg['margin'], hg['gap'], hg['solmix']
+            d.hfield_solref = (C.c_double * 2)(*hg['solref'])
+            d.hfield_solimp = (C.c_double * 5)(*hg['solimp'])
+            d.hfield_condim, d.hfield_priority = hg['condim'], hg['priority']
         self.desc = d
 
 

@@ -36,6 +36,7 @@ struct GqModel {
   GqDevModel host;
   GqDevModel* dev;
   float *vx, *vy, *vz;
+  float* hf;            /* device elevations of the scene's height field (NULL: none) */
   int nvert;
 };
 struct GqBatch {
@@ -83,6 +84,14 @@ int gq_model_create(const GqModelDesc* desc, int device, GqModel** out) {
   if (gq_build_dev_model(desc, &m->host, &vx, &vy, &vz, g_err, sizeof g_err)) { delete m; return GQ_EINVAL; }
   m->device = device; m->nvert = (int)vx.size();
   HIP_TRY(hipSetDevice(device));
+  m->hf = nullptr;
+  if (m->host.hf_nrow > 0) {
+    std::vector<float> hf;
+    gq_hfield_heights(desc, &hf);
+    HIP_TRY(hipMalloc(&m->hf, hf.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(m->hf, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
+    m->host.hf_data = m->hf;
+  }
   HIP_TRY(hipMalloc(&m->dev, sizeof(GqDevModel)));
   HIP_TRY(hipMemcpy(m->dev, &m->host, sizeof(GqDevModel), hipMemcpyHostToDevice));
   size_t vb = vx.size() * sizeof(float);
@@ -97,7 +106,7 @@ int gq_model_create(const GqModelDesc* desc, int device, GqModel** out) {
 int gq_model_destroy(GqModel* m) {
   if (!m) return GQ_OK;
   hipSetDevice(m->device);
-  hipFree(m->dev); hipFree(m->vx); hipFree(m->vy); hipFree(m->vz);
+  hipFree(m->dev); hipFree(m->vx); hipFree(m->vy); hipFree(m->vz); hipFree(m->hf);
   delete m;
   return GQ_OK;
 }
@@ -225,7 +234,7 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
   gq::StepCall c{};
   c.ctrl = ctrl; c.mask = mask; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
   c.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; c.first_pass = 0; c.stop_stage = b->stop_stage;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, b->model->host.nbox > 0, (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }
@@ -241,14 +250,14 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   gq::ResetArgs r{};
   fill_reset_args(&r, b, mask, qpos_new, qvel_new, cfg, st, out, episode, lift_failed);
   r.clear_terminated = out.terminated; r.clear_truncated = out.truncated; r.clear_invalid = out.invalid_contact;
-  gq_launch_reset(&r, b->host.n_envs, b->model->host.nbox > 0, (hipStream_t)hip_stream);
+  gq_launch_reset(&r, b->host.n_envs, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */
   const int rc = ensure_args(b, st, out, episode, lift_failed, nullptr, (hipStream_t)hip_stream);
   if (rc != GQ_OK) return rc;
   gq::StepCall c{};
   c.mask = mask; c.first_pass = 1; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, b->model->host.nbox > 0, (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

@@ -169,23 +169,247 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
   return true;
 }
 
+
+/* ------------------------------------------------------------------ height field (terrain.py add_perlin_heightfield :26-113)
+ * One static hfield geom: nrow x ncol elevations over [-sx, sx] x [-sy, sy] around hf_pos, identity orientation.  Every
+ * grid cell is two triangles, split like MuJoCo's prism strip (vertices (c,r), (c,r+1), (c+1,r), (c+1,r+1): the diagonal
+ * runs from (c,r+1) to (c+1,r)).  MuJoCo collides a convex geom with the prisms under its bounding box, one contact per
+ * prism; here every collision item keeps ONE contact with the height field: a foot sphere its closest triangle (exact
+ * point-triangle distance, centre above the surface), a link geom its deepest cloud vertex measured against the plane
+ * of the triangle under that vertex - the same simplification as for the world boxes, restated in the oracle. */
+struct HfTri { V3 a, b, c, n; }; /* corners and unit normal (n.z > 0) */
+/* All height-field geometry is expressed relative to a reference grid corner (cb, rb) next to the robot's base, so that
+ * the fp32 coordinates stay small (a foot sphere of 2-3 cm resolved against coordinates of 15 m would lose its normal to
+ * round-off).  Cell (cb + kc, rb + kr) has its (c, r) corner at (kc dx, kr dy). */
+struct HfRef { int cb, rb; };
+
+/* triangle `upper` (0: contains the cell's (c,r) corner, 1: contains (c+1,r+1)) of cell (ref + (kc, kr)); false outside the grid */
+__device__ __forceinline__ bool hf_cell_triangle(const GQ_MODEL GqDevModel& m, const GQ_MODEL float* H, HfRef ref, int kc, int kr, int upper, HfTri& t) {
+  const int nc = m.hf_ncol, c = ref.cb + kc, r = ref.rb + kr;
+  if (c < 0 || r < 0 || c > nc - 2 || r > m.hf_nrow - 2) return false;
+  const float x0 = m.hf_dx * (float)kc, y0 = m.hf_dy * (float)kr, x1 = x0 + m.hf_dx, y1 = y0 + m.hf_dy;
+  const float h10 = H[r * nc + c + 1], h01 = H[(r + 1) * nc + c], hq = upper ? H[(r + 1) * nc + c + 1] : H[r * nc + c];
+  t.b = v3(x1, y0, h10); t.c = v3(x0, y1, h01);
+  float gx, gy;
+  if (!upper) { t.a = v3(x0, y0, hq); gx = (h10 - hq) * m.hf_inv_dx; gy = (h01 - hq) * m.hf_inv_dy; }
+  else { t.a = v3(x1, y1, hq); gx = (hq - h01) * m.hf_inv_dx; gy = (hq - h10) * m.hf_inv_dy; }
+  const float inv = fast_rsqrt(gx * gx + gy * gy + 1.0f);
+  t.n = v3(-gx * inv, -gy * inv, inv);
+  return true;
+}
+/* the triangle under the point (x, y) given relative to the reference corner; false outside the grid */
+__device__ __forceinline__ bool hf_triangle_under(const GQ_MODEL GqDevModel& m, const GQ_MODEL float* H, HfRef ref, float x, float y, HfTri& t) {
+  const float fx = x * m.hf_inv_dx, fy = y * m.hf_inv_dy;
+  const int kc = (int)floorf(fx), kr = (int)floorf(fy);
+  return hf_cell_triangle(m, H, ref, kc, kr, (fx - (float)kc) + (fy - (float)kr) > 1.0f ? 1 : 0, t);
+}
+/* closest point of triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5) */
+__device__ inline V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c, bool& interior) {
+  interior = false;
+  const V3 ab = b - a, ac = c - a, ap = p - a;
+  const float d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) return a;
+  const V3 bp = p - b;
+  const float d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) return b;
+  const float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) return a + (d1 / (d1 - d3)) * ab;
+  const V3 cp = p - c;
+  const float d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) return c;
+  const float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) return a + (d2 / (d2 - d6)) * ac;
+  const float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) return b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b);
+  const float den = 1.0f / (va + vb + vc);
+  interior = true; /* the projection of p falls inside the triangle */
+  return a + (vb * den) * ab + (vc * den) * ac;
+}
+/* sphere (centre p relative to the reference corner, radius r) against the height field: signed distance, normal,
+ * false if nothing within `reach` of the surface.  Triangles of the cells under the sphere's footprint (+ reach) are visited. */
+__device__ inline bool sphere_hfield(const GQ_MODEL GqDevModel& m, const GQ_MODEL float* H, HfRef ref, V3 p, float r, float reach, float& dist, V3& n) {
+  const float R = r + reach;
+  const int c0 = (int)floorf((p.x - R) * m.hf_inv_dx), c1 = (int)floorf((p.x + R) * m.hf_inv_dx);
+  const int r0 = (int)floorf((p.y - R) * m.hf_inv_dy), r1 = (int)floorf((p.y + R) * m.hf_inv_dy);
+  dist = 1e30f; n = v3(0.0f, 0.0f, 1.0f);
+  for (int rr = r0; rr <= r1; rr++)
+    for (int cc = c0; cc <= c1; cc++)
+      for (int up = 0; up < 2; up++) {
+        HfTri t;
+        if (!hf_cell_triangle(m, H, ref, cc, rr, up, t)) continue;
+        const float side = dot(p - t.a, t.n);
+        bool inside;
+        const V3 q = closest_on_triangle(p, t.a, t.b, t.c, inside);
+        float dd; V3 nn;
+        if (inside) { dd = side - r; nn = t.n; } /* over (or under) the face: distance along its normal, whatever the sign */
+        else {
+          if (side < 0.0f) continue;             /* below the plane and outside the column: a neighbour's business */
+          const V3 d = p - q;
+          const float l2 = dot(d, d);
+          if (!(l2 > 1e-12f)) continue;
+          const float inv = fast_rsqrt(l2);
+          dd = l2 * inv - r; nn = inv * d;
+        }
+        if (dd < dist) { dist = dd; n = nn; }
+      }
+  return dist < reach;
+}
+
+/* Collision items against the height field; same contract as box_item_scan (lane `it` of con_order gets its item's
+ * distance / normal / point, false and no barrier when nothing is near). */
+__device__ inline bool hfield_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
+                                        double bx, double by, float zoff, V3 cg, float rg, float& dist, V3& nrm, V3& pt) {
+  const int lane = lane_id();
+  const GQ_MODEL float* H = mptr(m.hf_data);
+  /* reference corner: the grid node at or below the base x/y (f64), its position relative to the base in kernel coordinates */
+  const double gx = (bx - (double)m.hf_pos[0] + (double)m.hf_sx) * (double)m.hf_inv_dx, gy = (by - (double)m.hf_pos[1] + (double)m.hf_sy) * (double)m.hf_inv_dy;
+  const HfRef ref = {(int)floor(gx), (int)floor(gy)};
+  const V3 hp = v3((float)((double)m.hf_pos[0] - (double)m.hf_sx + (double)ref.cb * (double)m.hf_dx - bx),
+                   (float)((double)m.hf_pos[1] - (double)m.hf_sy + (double)ref.rb * (double)m.hf_dy - by), m.hf_pos[2] - zoff);
+  const int nlg = m.nlg, cls = m.hf_cls;
+  /* phase A, lane = link geom / foot: bounding sphere above the surface?  (surface within rho of a point rises at most maxslope * rho) */
+  bool needs = false, foot_near = false;
+  if (lane < nlg && rg >= 0.0f) {
+    const V3 cl = cg - hp;
+    HfTri t;
+    if (hf_triangle_under(m, H, ref, cl.x, cl.y, t)) {
+      const float hc = t.a.z - (t.n.x * (cl.x - t.a.x) + t.n.y * (cl.y - t.a.y)) / t.n.z;
+      needs = cl.z - rg - (hc + m.hf_maxslope * rg) < m.boxmix[cls][4 + lane].margin;
+    }
+  }
+  if (lane < nlg && !needs) W.u2.c.lg_dist[lane] = 1e30f;
+  if (lane < 4) {
+    const V3 cl = ld3(W.foot_world[lane]) - hp;
+    HfTri t;
+    if (hf_triangle_under(m, H, ref, cl.x, cl.y, t)) {
+      const float hc = t.a.z - (t.n.x * (cl.x - t.a.x) + t.n.y * (cl.y - t.a.y)) / t.n.z, rf = m.foot_radius[lane];
+      foot_near = cl.z - rf - (hc + m.hf_maxslope * rf) < m.boxmix[cls][lane].margin;
+    }
+  }
+  uint64_t todo = ballot(needs);
+  const uint64_t feet = ballot(foot_near);
+  dist = 1e30f; nrm = v3(0.0f, 0.0f, 1.0f); pt = v3(0.0f, 0.0f, 0.0f);
+  if ((todo | feet) == 0) return false;
+  while (todo) { /* wave-uniform */
+    const int g = ffs64(todo);
+    todo &= todo - 1;
+    const GQ_MODEL GqDevGeom& G = m.lg[g];
+    const float* Rb = W.xmat[G.body];
+    float A[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) A[3 * i + j] = Rb[3 * i] * G.mat[j] + Rb[3 * i + 1] * G.mat[3 + j] + Rb[3 * i + 2] * G.mat[6 + j];
+    const V3 t0 = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos)) - hp;
+    float best = 1e30f;
+    V3 bn = v3(0.0f, 0.0f, 1.0f), bc = v3(0.0f, 0.0f, 0.0f);
+    for (int v0 = 0; v0 < G.cloud_num; v0 += GQ_WAVE) { /* wave-uniform trip count */
+      const int i = G.cloud_adr + v0 + lane;
+      const bool in = v0 + lane < G.cloud_num;
+      const int ii = in ? i : G.cloud_adr;
+      const V3 c = t0 + matvec(A, v3(vx[ii], vy[ii], vz[ii]));
+      HfTri t;
+      if (in && hf_triangle_under(m, H, ref, c.x, c.y, t)) {
+        const float dv = dot(c - t.a, t.n) - G.radius;
+        if (dv < best) { best = dv; bn = t.n; bc = c; }
+      }
+    }
+    const float wmin = wave_min(best);
+    const int who = ffs64(ballot(best == wmin));
+    const V3 n_w = v3(bcast(bn.x, who), bcast(bn.y, who), bcast(bn.z, who));
+    const V3 c_w = v3(bcast(bc.x, who), bcast(bc.y, who), bcast(bc.z, who));
+    if (lane == 0) {
+      W.u2.c.lg_dist[g] = wmin;
+      st3(W.u2.c.lg_pt[g], hp + c_w - (G.radius + 0.5f * wmin) * n_w);
+      st3(GQ_BX_LGNRM(W) + 3 * g, n_w);
+    }
+  }
+  wave_barrier();
+  /* phase C, lane = collision item */
+  if (lane < 4 + nlg) {
+    const int code = m.con_order[lane];
+    if (code < 4) {
+      if ((feet >> code) & 1) {
+        V3 n; float d;
+        if (sphere_hfield(m, H, ref, ld3(W.foot_world[code]) - hp, m.foot_radius[code], fmaxf(m.boxmix[cls][code].margin, 0.0f) + 1e-4f, d, n)) {
+          dist = d; nrm = n; pt = ld3(W.foot_world[code]) - (m.foot_radius[code] + 0.5f * d) * n;
+        }
+      }
+    } else { dist = W.u2.c.lg_dist[code - 4]; nrm = ld3(GQ_BX_LGNRM(W) + 3 * (code - 4)); pt = ld3(W.u2.c.lg_pt[code - 4]); }
+  }
+  return true;
+}
+
+/* running totals of the contact list while world geoms are appended to it */
+struct WorldAppend { int ncon, rows, invalid, reserve, ft[4]; };
+
+/* append the contacts of the collision items (lane = position in con_order: dist / nrm / pt) with one world geom of
+ * contact-parameter class cls; rows / row budget as in the floor pass.  No barrier inside. */
+template <bool CONE>
+__device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, int cls, float mu_env, float dist, V3 nrm, V3 pt, WorldAppend& S) {
+  const int lane = lane_id();
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int& ncon = S.ncon; int& rows = S.rows; int& invalid = S.invalid; int& reserve = S.reserve; int* ft = S.ft;
+  bool touching = false, calf = false;
+  int code = 0, body = 0, dim = 3;
+  float mu = 0.0f;
+  if (lane < 4 + m.nlg) {
+    code = m.con_order[lane];
+    const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
+    touching = dist < X.margin;
+    dim = X.dim;
+    const float ff = m.boxcls_friction[cls][0]; /* _set_ground_friction leaves unnamed world boxes alone (quirk B8) */
+    float fg;
+    if (code < 4) { body = 3 + 3 * m.foot_leg[code]; calf = true; fg = mu_env >= 0.0f ? mu_env : m.foot_friction[code][0]; }
+    else { const GQ_MODEL GqDevGeom& G = m.lg[code - 4]; body = G.body; calf = G.body > 0 && (G.body - 1) % 3 == 2; fg = G.friction[0]; }
+    mu = fmaxf(1e-5f, X.rule == 0 ? fmaxf(ff, fg) : (X.rule == 1 ? ff : fg));
+  }
+  const uint64_t touch_mask = ballot(touching);
+  if (touch_mask == 0) return;
+  invalid |= ballot(touching && !calf) != 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) ft[k] |= ballot(touching && body == 3 + 3 * m.foot_leg[k]) != 0;
+  const int idx = ncon + popc64(touch_mask & lt);
+  const bool kept = touching && idx < GQ_MAXCON;
+  const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
+  const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4), m6 = ballot(kept && need == 6);
+  const int row0 = rows + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
+  const int res = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) + (need > 1 ? need - 1 : 0) : 0;
+  const bool fits = kept && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
+  const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4), f6 = ballot(fits && need == 6);
+  if (fits) {
+    const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
+    W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
+    W.con_dist[idx] = dist; W.con_inc[idx] = X.includemargin; W.con_mu[idx] = mu;
+    st3(W.con_pos[idx], pt);
+    W.con_solref[idx][0] = X.solref[0]; W.con_solref[idx][1] = X.solref[1];
+#pragma unroll
+    for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = X.solimp[q];
+    st3(GQ_BX_CONNRM(W) + 3 * idx, nrm);
+    GQ_BX_WCLS(W)[idx] = cls;
+  }
+  ncon += popc64(f1 | f3 | f4 | f6);
+  rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
+  if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
+}
+
 /* S6 (BOXES): append the contacts with the world boxes to the list the floor pass left in W (ncon, nefc, invalid,
  * foot_touch are updated; rows / row budget as in the floor pass).  Ends with a barrier. */
 template <bool CONE>
 __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
                                           double bx, double by, float mu_env) {
   const int lane = lane_id();
-  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  int ncon = uniform(W.ncon), rows = uniform(W.nefc), invalid = uniform(W.invalid), reserve = 0;
-  int ft[4];
+  WorldAppend S;
+  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) ft[k] = uniform(W.foot_touch[k]);
+  for (int k = 0; k < 4; k++) S.ft[k] = uniform(W.foot_touch[k]);
+  const int ncon = S.ncon;
   if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
     st3(GQ_BX_CONNRM(W) + 3 * lane, v3(0.0f, 0.0f, 1.0f));
     GQ_BX_WCLS(W)[lane] = -1;
   }
   if constexpr (CONE)
-    for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); reserve += d > 1 ? d - 1 : 0; }
+    for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
   uint64_t cand[2];
   box_candidates(W, m, bx, by, 0.0f, cand);
   V3 cg; float rg;
@@ -198,55 +422,21 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
       todo &= todo - 1;
       float dist; V3 nrm, pt;
       if (!box_item_scan(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, dist, nrm, pt)) continue;
-      const int cls = m.box[b].cls;
-      bool touching = false, calf = false;
-      int code = 0, body = 0, dim = 3;
-      float mu = 0.0f;
-      if (lane < 4 + m.nlg) {
-        code = m.con_order[lane];
-        const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
-        touching = dist < X.margin;
-        dim = X.dim;
-        const float ff = m.boxcls_friction[cls][0]; /* _set_ground_friction leaves unnamed world boxes alone (quirk B8) */
-        float fg;
-        if (code < 4) { body = 3 + 3 * m.foot_leg[code]; calf = true; fg = mu_env >= 0.0f ? mu_env : m.foot_friction[code][0]; }
-        else { const GQ_MODEL GqDevGeom& G = m.lg[code - 4]; body = G.body; calf = G.body > 0 && (G.body - 1) % 3 == 2; fg = G.friction[0]; }
-        mu = fmaxf(1e-5f, X.rule == 0 ? fmaxf(ff, fg) : (X.rule == 1 ? ff : fg));
-      }
-      const uint64_t touch_mask = ballot(touching);
-      if (touch_mask == 0) { wave_barrier(); continue; }
-      invalid |= ballot(touching && !calf) != 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) ft[k] |= ballot(touching && body == 3 + 3 * m.foot_leg[k]) != 0;
-      const int idx = ncon + popc64(touch_mask & lt);
-      const bool kept = touching && idx < GQ_MAXCON;
-      const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
-      const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4), m6 = ballot(kept && need == 6);
-      const int row0 = rows + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
-      const int res = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) + (need > 1 ? need - 1 : 0) : 0;
-      const bool fits = kept && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
-      const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4), f6 = ballot(fits && need == 6);
-      if (fits) {
-        const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
-        W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
-        W.con_dist[idx] = dist; W.con_inc[idx] = X.includemargin; W.con_mu[idx] = mu;
-        st3(W.con_pos[idx], pt);
-        W.con_solref[idx][0] = X.solref[0]; W.con_solref[idx][1] = X.solref[1];
-#pragma unroll
-        for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = X.solimp[q];
-        st3(GQ_BX_CONNRM(W) + 3 * idx, nrm);
-        GQ_BX_WCLS(W)[idx] = cls;
-      }
-      ncon += popc64(f1 | f3 | f4 | f6);
-      rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
-      if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
+      append_world_contacts<CONE>(W, m, m.box[b].cls, mu_env, dist, nrm, pt, S);
+      wave_barrier();
+    }
+  }
+  if (m.hf_nrow > 0) { /* the scene's height field: one more world geom */
+    float dist; V3 nrm, pt;
+    if (hfield_item_scan(W, m, vx, vy, vz, bx, by, 0.0f, cg, rg, dist, nrm, pt)) {
+      append_world_contacts<CONE>(W, m, m.hf_cls, mu_env, dist, nrm, pt, S);
       wave_barrier();
     }
   }
   if (lane == 0) {
-    W.ncon = ncon; W.nefc = rows; W.invalid = invalid;
+    W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid;
 #pragma unroll
-    for (int k = 0; k < 4; k++) W.foot_touch[k] = ft[k];
+    for (int k = 0; k < 4; k++) W.foot_touch[k] = S.ft[k];
   }
   wave_barrier();
 }

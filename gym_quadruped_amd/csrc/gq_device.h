@@ -101,6 +101,8 @@ __device__ __forceinline__ float quad_sum(float v) {
 __device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
 template <class T> __device__ __forceinline__ GQ_GLOBAL T* gptr(T* p) { return (GQ_GLOBAL T*)p; }
 template <class T> __device__ __forceinline__ const GQ_MODEL T* mptr(const T* p) { return (const GQ_MODEL T*)p; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 /* issue priority of this wave among the waves of its SIMD (0 lowest .. 3); p is wave-uniform */
 __device__ __forceinline__ void wave_priority(int p) {
   p = __builtin_amdgcn_readfirstlane(p);

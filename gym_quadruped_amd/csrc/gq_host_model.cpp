@@ -247,6 +247,45 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     }
     B.cls = cls;
   }
+  /* height field: scalars here, the elevations themselves through gq_hfield_heights (the caller owns their memory) */
+  M.hf_nrow = 0; M.hf_ncol = 0; M.hf_cls = 0; M.hf_data = nullptr;
+  if (d->hfield_nrow != 0 || d->hfield_ncol != 0) {
+    if (d->hfield_nrow < 2 || d->hfield_ncol < 2 || d->hfield_nrow > 4096 || d->hfield_ncol > 4096) FAIL("height field of %d x %d samples not supported", d->hfield_nrow, d->hfield_ncol);
+    if (!d->hfield_data) FAIL("hfield_data is NULL");
+    if (d->solver != 1) FAIL("scenes with a height field need the Newton solver (solver = 1): the PGS path handles the floor plane only");
+    if (!(d->hfield_size[0] > 0 && d->hfield_size[1] > 0 && d->hfield_size[2] > 0)) FAIL("hfield_size must be positive");
+    if (M.nboxcls >= GQ_MAXBOXCLS) FAIL("no contact-parameter class left for the height field (%d distinct box classes)", M.nboxcls);
+    M.hf_nrow = d->hfield_nrow; M.hf_ncol = d->hfield_ncol;
+    for (int i = 0; i < 3; i++) M.hf_pos[i] = (float)d->hfield_pos[i];
+    M.hf_sx = (float)d->hfield_size[0]; M.hf_sy = (float)d->hfield_size[1];
+    const double dx = 2 * d->hfield_size[0] / (d->hfield_ncol - 1), dy = 2 * d->hfield_size[1] / (d->hfield_nrow - 1);
+    M.hf_dx = (float)dx; M.hf_dy = (float)dy; M.hf_inv_dx = (float)(1 / dx); M.hf_inv_dy = (float)(1 / dy);
+    double slope = 0, zmax = 0;
+    const int nr = d->hfield_nrow, nc = d->hfield_ncol;
+    const double sz = d->hfield_size[2], dd = std::sqrt(dx * dx + dy * dy);
+    for (int r = 0; r < nr; r++)
+      for (int c = 0; c < nc; c++) {
+        const double h = sz * d->hfield_data[r * nc + c];
+        if (h > zmax) zmax = h;
+        if (c + 1 < nc) slope = std::fmax(slope, std::fabs(sz * d->hfield_data[r * nc + c + 1] - h) / dx);
+        if (r + 1 < nr) slope = std::fmax(slope, std::fabs(sz * d->hfield_data[(r + 1) * nc + c] - h) / dy);
+        if (r + 1 < nr && c > 0) slope = std::fmax(slope, std::fabs(sz * d->hfield_data[(r + 1) * nc + c - 1] - h) / dd);
+      }
+    /* the steepest line on a triangle is its gradient: bounded by the two edge slopes that span it */
+    M.hf_maxslope = (float)(std::sqrt(2.0) * slope); M.hf_zmax = (float)zmax;
+    const int cls = M.nboxcls++;
+    M.hf_cls = cls;
+    for (int i = 0; i < 3; i++) M.boxcls_friction[cls][i] = (float)d->hfield_friction[i];
+    WorldGeom w{d->hfield_condim, d->hfield_priority, d->hfield_solmix, d->hfield_margin, d->hfield_gap, d->hfield_solref, d->hfield_solimp};
+    for (int it = 0; it < 4 + M.nlg; it++) {
+      Mixed mx = mix_with(d, w, item_geom[it]);
+      if (mx.dim != 1 && mx.dim != 3 && !(d->cone == 1 && mx.dim == 6)) FAIL("height-field contact dimension %d not supported", mx.dim);
+      GqDevMix& X = M.boxmix[cls][it];
+      X.dim = mx.dim; X.rule = mx.rule; X.margin = (float)mx.margin; X.includemargin = (float)mx.includemargin;
+      for (int i = 0; i < 2; i++) X.solref[i] = (float)mx.solref[i];
+      for (int i = 0; i < 5; i++) X.solimp[i] = (float)mx.solimp[i];
+    }
+  }
   { /* broad-phase radius: longest leg chain (hip + thigh + calf offsets + foot) or base geom extent, plus the largest geom */
     double reach = 0, grb = 0;
     for (int l = 0; l < 4; l++) {
@@ -263,6 +302,13 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     M.robot_radius = (float)(reach + grb);
   }
   return 0;
+}
+
+void gq_hfield_heights(const GqModelDesc* d, std::vector<float>* out) {
+  out->clear();
+  const size_t n = (size_t)(d->hfield_nrow > 0 ? d->hfield_nrow : 0) * (size_t)(d->hfield_ncol > 0 ? d->hfield_ncol : 0);
+  out->resize(n);
+  for (size_t i = 0; i < n; i++) (*out)[i] = (float)(d->hfield_size[2] * (double)d->hfield_data[i]);
 }
 
 static const int kObsDims[GQ_OBS_COUNT] = {3, 3, 3, 3, 3, 3, 3, 4, 9, 3, 3, 3, 3, 3, 3, 19, 18, 12, 12, 12, 1, 1,

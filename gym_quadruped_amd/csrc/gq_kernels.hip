@@ -75,6 +75,20 @@ __global__ void heightmap_kernel(const GQ_GLOBAL GqDevModel* model, const double
     }
     if (hit && tout >= 0.0 && (dist < 0.0 || tin < dist)) dist = tin;
   }
+  if (model->hf_nrow > 0) { /* height field: the vertical ray meets the triangle under (px, py) */
+    const GQ_GLOBAL GqDevModel& M = *model;
+    const float x = (float)(px - (double)M.hf_pos[0]), y = (float)(py - (double)M.hf_pos[1]);
+    const float fx = (x + M.hf_sx) * M.hf_inv_dx, fy = (y + M.hf_sy) * M.hf_inv_dy;
+    if (fx >= 0.0f && fy >= 0.0f && fx <= (float)(M.hf_ncol - 1) && fy <= (float)(M.hf_nrow - 1)) {
+      const int nc = M.hf_ncol, c = min((int)fx, nc - 2), r = min((int)fy, M.hf_nrow - 2);
+      const float u = fx - (float)c, v = fy - (float)r;
+      const float* H = M.hf_data;
+      const float h00 = H[r * nc + c], h10 = H[r * nc + c + 1], h01 = H[(r + 1) * nc + c], h11 = H[(r + 1) * nc + c + 1];
+      const float h = u + v <= 1.0f ? h00 + u * (h10 - h00) + v * (h01 - h00) : h11 + (1.0f - u) * (h01 - h11) + (1.0f - v) * (h10 - h11);
+      const double top = (double)M.hf_pos[2] + (double)h, t = pz - top;
+      if (t >= 0.0 && (dist < 0.0 || t < dist)) dist = t;
+    }
+  }
   float* o = out + (size_t)idx * 3;
   o[0] = (float)px; o[1] = (float)py; o[2] = (float)(pz - dist);
 }

@@ -83,6 +83,11 @@ struct GqDevModel {
   float boxcls_friction[GQ_MAXBOXCLS][3];
   GqDevMix boxmix[GQ_MAXBOXCLS][4 + GQ_MAXLG]; /* [class][collision item: k < 4 foot k, else 4 + link geom] */
   GqDevBox box[GQ_MAXBOX];
+  /* height field of the scene (0 rows: none): elevations in metres relative to hf_pos[2], row r <-> y, column c <-> x */
+  int32_t hf_nrow, hf_ncol, hf_cls; /* hf_cls: its contact-parameter class in boxmix / boxcls_friction */
+  float hf_pos[3], hf_sx, hf_sy, hf_dx, hf_dy, hf_inv_dx, hf_inv_dy;
+  float hf_maxslope, hf_zmax;       /* largest |dh| / distance along any cell edge or diagonal; highest elevation */
+  const float* hf_data;             /* [nrow][ncol], device memory owned by the GqModel */
   /* env */
   double terrain_limits[4];
   float key_qpos[19];            /* keyframe 0 */

@@ -1109,6 +1109,20 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
             wave_barrier();
           }
         }
+        if (m.hf_nrow > 0) { /* the height field: a lift by dz changes a distance by dz * n_z */
+          float hd; V3 hn, hpt;
+          if (hfield_item_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), spawn_x, spawn_y, dz, calf_c, calf_r, hd, hn, hpt)) {
+            if (lane < 4 + m.nlg) {
+              const int code = m.con_order[lane];
+              const bool calf = code < 4 || (m.lg[code - 4].body > 0 && (m.lg[code - 4].body - 1) % 3 == 2);
+              if (calf && hd < m.boxmix[m.hf_cls][code].margin) {
+                pen = fmaxf(pen, fabsf(hd));
+                clear = fmaxf(clear, fabsf(hd) / fmaxf(hn.z, 0.2f) + 0.005f);
+              }
+            }
+            wave_barrier();
+          }
+        }
         pen = wave_max(pen);
         failed = pen > 0.0f;
         if (!failed || it == 100) break;

@@ -128,7 +128,8 @@ class QuadrupedEnv(AccessorsMixin):
         self._mm = MarshalledModel(self.mjModel, qpos0=qpos0, feet_geom_names=self.robot_cfg.feet_geom_names,
                                    terrain_limits=self.terrain_limits, timestep=sim_dt, solver={'pgs': 0, 'newton': 1}[solver],
                                    iterations=solver_iterations, tolerance=solver_tolerance, noise_floor=solver_noise_floor,
-                                   floor=self.scene_desc.get('floor'), boxes=self.scene_desc.get('boxes'))
+                                   floor=self.scene_desc.get('floor'), boxes=self.scene_desc.get('boxes'),
+                                   hfield=self.scene_desc.get('hfield'))
         self._sim_dt = float(sim_dt)
 
         # leg index maps (reference :189-212)

@@ -11,10 +11,17 @@ marshaller (``cabi.MarshalledModel``): the floor plane plus a list of static wor
   (pinned by ``tests/golden/terrain_boxes.json``, produced by running the reference's own function).
 * ``ramp`` / ``slippery`` / ``stairs``: the box geoms of the reference's static scene files, shipped as data
   (``model_data/static_scenes.json``, extracted by ``tools/gen_golden_terrain.py``).
-* ``perlin`` needs a height-field narrow phase and ``noise.pnoise2``: not built - raises.
+* ``perlin`` (terrain.py:26-118, parameters :345-356): a 128 x 128 height field of ``noise.pnoise2`` samples over the flat
+  floor.  ``noise`` (Casey Duncan's package, C extension ``_perlin``) is third-party and absent here; ``pnoise2`` below
+  restates its published algorithm (Ken Perlin's improved noise with the classic permutation table, fp32 arithmetic, octave
+  sum normalised by the amplitude sum) and is pinned by the image the reference ships
+  (``robot_model/mini_cheetah/height_field.png``, reproduced bit for bit with add_perlin_heightfield's default arguments:
+  ``tests/golden/perlin_default.npz``).  The reference writes the image to a PNG and MuJoCo's compiler loads it: rows
+  flipped, elevation shifted / scaled to [0, 1] (from MuJoCo's documentation, unverified here - no MuJoCo).
 
-Scene generation is host-side set-up code; the boxes travel in ``GqModelDesc`` (``box_*`` tables) and are simulated by the
-BOXES variants of the step kernel (``csrc/gq_boxes.h``; Newton solver only - ``gq_model_create`` rejects them with PGS).
+Scene generation is host-side set-up code; the boxes and the height field travel in ``GqModelDesc`` (``box_*`` tables,
+``hfield_*``) and are simulated by the BOXES variants of the step kernel (``csrc/gq_boxes.h``; Newton solver only -
+``gq_model_create`` rejects them with PGS).
 """
 from __future__ import annotations
 
@@ -31,6 +38,88 @@ _BOX_DEFAULT = dict(friction=(1.0, 0.005, 0.0001), margin=0.0, gap=0.0, solmix=1
                     solimp=(0.9, 0.95, 0.001, 0.5, 2.0), condim=3, priority=0)
 _STATIC = ('ramp', 'slippery', 'stairs')
 _FLAT_LIMITS = (10000.0, -10000.0, 10000.0, -10000.0)
+
+
+_PERM = np.array([
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6,
+    148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136,
+    171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55,
+    46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188,
+    159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59,
+    227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9,
+    129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12,
+    191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45,
+    127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180] * 2, dtype=np.int64)
+_GRAD_XY = np.array([[1, 1], [-1, 1], [1, -1], [-1, -1], [1, 0], [-1, 0], [1, 0], [-1, 0], [0, 1], [0, -1], [0, 1], [0, -1],
+                     [1, 0], [-1, 0], [0, -1], [0, 1]], dtype=np.float32)   # x, y of the 16 gradient directions
+
+
+def _noise2(x, y, repeatx, repeaty, base=0):
+    """One octave of 2-D improved Perlin noise on float32 arrays (the `noise` package's noise2)."""
+    f32 = np.float32
+    i = np.floor(np.fmod(x, f32(repeatx))).astype(np.int64)
+    j = np.floor(np.fmod(y, f32(repeaty))).astype(np.int64)
+    ii = np.fmod((i + 1).astype(f32), f32(repeatx)).astype(np.int64)
+    jj = np.fmod((j + 1).astype(f32), f32(repeaty)).astype(np.int64)
+    i, j, ii, jj = (i & 255) + base, (j & 255) + base, (ii & 255) + base, (jj & 255) + base
+    x = x - np.floor(x)
+    y = y - np.floor(y)
+    fx = x * x * x * (x * (x * f32(6) - f32(15)) + f32(10))
+    fy = y * y * y * (y * (y * f32(6) - f32(15)) + f32(10))
+    a, b = _PERM[i], _PERM[ii]
+    aa, ab, ba, bb = _PERM[a + j], _PERM[a + jj], _PERM[b + j], _PERM[b + jj]
+
+    def grad(h, xx, yy):
+        g = _GRAD_XY[h & 15]
+        return xx * g[..., 0] + yy * g[..., 1]
+
+    def lerp(t, p, q):
+        return p + t * (q - p)
+
+    return lerp(fy, lerp(fx, grad(_PERM[aa], x, y), grad(_PERM[ba], x - 1, y)),
+                lerp(fx, grad(_PERM[ab], x, y - 1), grad(_PERM[bb], x - 1, y - 1)))
+
+
+def pnoise2(x, y, octaves=1, persistence=0.5, lacunarity=2.0, repeatx=1024.0, repeaty=1024.0, base=0):
+    """``noise.pnoise2`` on arrays: octaves of :func:`_noise2`, frequency x lacunarity and amplitude x persistence per
+    octave, the sum divided by the sum of the amplitudes; float32 throughout, like the C extension."""
+    f32 = np.float32
+    x, y = np.asarray(x, dtype=f32), np.asarray(y, dtype=f32)
+    if octaves == 1:
+        return _noise2(x, y, repeatx, repeaty, base)
+    freq, amp, total_amp, total = f32(1), f32(1), f32(0), np.zeros(np.broadcast(x, y).shape, dtype=f32)
+    for _ in range(int(octaves)):
+        total = total + _noise2(x * freq, y * freq, f32(repeatx) * freq, f32(repeaty) * freq, base) * amp
+        total_amp = f32(total_amp + amp)
+        freq = f32(freq * f32(lacunarity))
+        amp = f32(amp * f32(persistence))
+    return total / total_amp
+
+
+def perlin_image(image_width=128, img_height=128, smooth=100.0, perlin_octaves=6, perlin_persistence=0.5, perlin_lacunarity=2.0):
+    """The uint8 image add_perlin_heightfield writes (terrain.py:75-86): ``image[y, x] = int((pnoise2(x / smooth,
+    y / smooth, ...) + 1) / 2 * 255)``; the reference loops ``range(image_width)`` for both axes."""
+    xs, ys = np.meshgrid(np.arange(image_width, dtype=np.float64), np.arange(image_width, dtype=np.float64))
+    nv = pnoise2(xs / smooth, ys / smooth, perlin_octaves, perlin_persistence, perlin_lacunarity).astype(np.float64)
+    img = np.zeros((img_height, image_width), dtype=np.uint8)
+    img[:image_width, :] = ((nv + 1.0) / 2.0 * 255.0).astype(np.int64).astype(np.uint8)[:img_height]
+    return img
+
+
+def _perlin_heightfield(size, max_height, min_height, position=(0.0, 0.0, 0.0), **image_kwargs):
+    """Height-field description + terrain limits of add_perlin_heightfield (terrain.py:26-118): hfield ``size`` =
+    (size_x / 2, size_y / 2, max_height, min_height); MuJoCo's compiler flips the image rows (row 0 of the data is the
+    image's last row, at y = -size_y / 2) and maps the elevation to [0, 1]."""
+    img = perlin_image(**image_kwargs).astype(np.float64)[::-1]
+    lo, hi = img.min(), img.max()
+    data = (img - lo) / (hi - lo) if hi > lo else np.zeros_like(img)
+    hfield = dict(_BOX_DEFAULT)
+    hfield.update(data=data.astype(np.float32), size=(size[0] / 2.0, size[1] / 2.0, float(max_height), float(min_height)),
+                  pos=tuple(float(v) for v in position))
+    cx, cy = position[0], position[1]
+    mx, my = size[0] / 2.0, size[1] / 2.0
+    radius = 0.8 * np.sqrt((mx - cx) * (mx - cx)) if mx >= my else 0.8 * np.sqrt((my - cy) * (my - cy))
+    return hfield, (cx + radius, cx - radius, cy + radius, cy - radius)
 
 
 @contextlib.contextmanager
@@ -114,7 +203,8 @@ def _world_of_pyramid(init_pos, yaw, width, max_height, length, stair_nums):
 
 def generate_terrain(terrain_name: str = 'flat', hip_height: float = 0.3, seed: int = 10):
     """Returns ``(scene_desc, terrain_limits)``: ``scene_desc = {'name', 'floor': {...}, 'boxes': [{pos, size (half
-    extents), quat (wxyz), friction, priority, condim, solref, solimp, solmix, margin, gap}, ...]}``."""
+    extents), quat (wxyz), friction, priority, condim, solref, solimp, solmix, margin, gap}, ...], 'hfield': {data [nrow][ncol]
+    in [0, 1], size (rx, ry, elevation, base), pos, + contact parameters} (perlin only)}``."""
     scene = {'name': terrain_name, 'floor': dict(_FLOOR_DEFAULT), 'boxes': []}
     if terrain_name == 'flat':
         return scene, _FLAT_LIMITS
@@ -139,7 +229,10 @@ def generate_terrain(terrain_name: str = 'flat', hip_height: float = 0.3, seed: 
             scene['boxes'], limits = _world_of_pyramid(init_pos=[3, 0, 0.02], yaw=0.0, width=10 * h, max_height=5 * h, length=10 * h,
                                                        stair_nums=stair_nums)
             return scene, limits
-    if terrain_name == 'perlin':
-        raise NotImplementedError("scene 'perlin' needs a height-field narrow phase and noise.pnoise2 (SURVEY.md §8f rank 2): not built")
+    if terrain_name == 'perlin':            # :345-356
+        h = float(hip_height)
+        scene['hfield'], limits = _perlin_heightfield(size=(h * 100, h * 100), max_height=2 * h, min_height=0.005, image_width=128,
+                                                      img_height=128, smooth=50, perlin_octaves=5, perlin_lacunarity=4.0)
+        return scene, tuple(float(v) for v in limits)
     raise ValueError(f'Invalid scene name: {terrain_name}, available are: flat, random_boxes, random_pyramids, '
                      f'perlin, stairs, ramp, slippery')

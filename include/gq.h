@@ -157,6 +157,16 @@ typedef struct GqModelDesc {
   const double* box_solimp;     /* [nbox][5] */
   const int32_t* box_condim;
   const int32_t* box_priority;
+  /* height field of the scene (terrain.py add_perlin_heightfield :26-113; MuJoCo hfield geom, identity orientation):
+   * hfield_data holds the elevation normalised to [0, 1] as MuJoCo's compiler leaves it, [nrow][ncol] with row r at
+   * y = -size[1] + r * 2 size[1] / (nrow - 1) and column c likewise along x; world elevation = pos[2] + data * size[2].
+   * hfield_nrow = 0: no height field.  Contact parameters as for any geom.  Needs the Newton solver. */
+  int32_t hfield_nrow, hfield_ncol;
+  const float* hfield_data;
+  double hfield_size[4];        /* radius_x, radius_y, elevation_z, base_z */
+  double hfield_pos[3];
+  double hfield_friction[3], hfield_margin, hfield_gap, hfield_solmix, hfield_solref[2], hfield_solimp[5];
+  int32_t hfield_condim, hfield_priority;
 } GqModelDesc;
 
 typedef struct GqModel GqModel;

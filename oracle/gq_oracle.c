@@ -406,18 +406,21 @@ static int is_foot(const GqModelDesc* m, int g) {
 static void contact_param(const GqOracle* o, int w, int g, Contact* c) {
   const GqModelDesc* m = &o->d;
   double f1[3], f2[3];
-  memcpy(f1, w < 0 ? m->floor_friction : m->box_friction + 3 * w, sizeof f1);
+  const int hf = w >= m->nbox; /* the height field comes after the boxes */
+  memcpy(f1, w < 0 ? m->floor_friction : (hf ? m->hfield_friction : m->box_friction + 3 * w), sizeof f1);
   memcpy(f2, m->geom_friction + 3 * g, sizeof f2);
   if (o->friction >= 0) { /* _set_ground_friction (quadruped_env.py:1277-1298): geoms named ground/floor/hfield/terrain and the
                            * feet get [mu, 0.005, 0.0]; the unnamed world boxes keep their own friction (quirk B8) */
     if (w < 0) { f1[0] = o->friction; f1[1] = 0.005; f1[2] = 0.0; }
     if (is_foot(m, g)) { f2[0] = o->friction; f2[1] = 0.005; f2[2] = 0.0; }
   }
-  const int w_condim = w < 0 ? m->floor_condim : m->box_condim[w], w_priority = w < 0 ? m->floor_priority : m->box_priority[w];
-  const double w_solmix = w < 0 ? m->floor_solmix : m->box_solmix[w], w_margin = w < 0 ? m->floor_margin : m->box_margin[w];
-  const double w_gap = w < 0 ? m->floor_gap : m->box_gap[w];
-  const double* w_solref = w < 0 ? m->floor_solref : m->box_solref + 2 * w;
-  const double* w_solimp = w < 0 ? m->floor_solimp : m->box_solimp + 5 * w;
+  const int w_condim = w < 0 ? m->floor_condim : (hf ? m->hfield_condim : m->box_condim[w]);
+  const int w_priority = w < 0 ? m->floor_priority : (hf ? m->hfield_priority : m->box_priority[w]);
+  const double w_solmix = w < 0 ? m->floor_solmix : (hf ? m->hfield_solmix : m->box_solmix[w]);
+  const double w_margin = w < 0 ? m->floor_margin : (hf ? m->hfield_margin : m->box_margin[w]);
+  const double w_gap = w < 0 ? m->floor_gap : (hf ? m->hfield_gap : m->box_gap[w]);
+  const double* w_solref = w < 0 ? m->floor_solref : (hf ? m->hfield_solref : m->box_solref + 2 * w);
+  const double* w_solimp = w < 0 ? m->floor_solimp : (hf ? m->hfield_solimp : m->box_solimp + 5 * w);
   int p1 = w_priority, p2 = m->geom_priority[g];
   double fri[3];
   if (p1 == p2) {
@@ -446,6 +449,85 @@ static void contact_param(const GqOracle* o, int w, int g, Contact* c) {
   double gap = w_gap > m->geom_gap[g] ? w_gap : m->geom_gap[g];
   c->includemargin = margin - gap;
   c->mu = 0;
+}
+
+
+/* ------------------------------------------------------------------ height field (MuJoCo hfield geom, identity orientation)
+ * Grid cell (c, r) is split like MuJoCo's prism strip: vertices (c,r), (c,r+1), (c+1,r), (c+1,r+1), i.e. the diagonal
+ * runs from (c,r+1) to (c+1,r).  MuJoCo (mjc_ConvexHField) emits one contact per prism under the geom's bounding box;
+ * this restatement keeps ONE contact per robot geom: a sphere its closest triangle (exact point-triangle distance), any
+ * other geom its deepest cloud vertex measured against the plane of the triangle under that vertex. */
+typedef struct { double a[3], b[3], c[3], n[3]; } HfTri;
+static double hf_h(const GqModelDesc* m, int r, int c) { return m->hfield_size[2] * (double)m->hfield_data[r * m->hfield_ncol + c]; }
+static void hf_cell_triangle(const GqModelDesc* m, int c, int r, int upper, HfTri* t) {
+  const double dx = 2 * m->hfield_size[0] / (m->hfield_ncol - 1), dy = 2 * m->hfield_size[1] / (m->hfield_nrow - 1);
+  const double x0 = -m->hfield_size[0] + dx * c, y0 = -m->hfield_size[1] + dy * r, x1 = x0 + dx, y1 = y0 + dy;
+  const double h10 = hf_h(m, r, c + 1), h01 = hf_h(m, r + 1, c), hq = upper ? hf_h(m, r + 1, c + 1) : hf_h(m, r, c);
+  double gx, gy;
+  t->b[0] = x1; t->b[1] = y0; t->b[2] = h10; t->c[0] = x0; t->c[1] = y1; t->c[2] = h01;
+  if (!upper) { t->a[0] = x0; t->a[1] = y0; t->a[2] = hq; gx = (h10 - hq) / dx; gy = (h01 - hq) / dy; }
+  else { t->a[0] = x1; t->a[1] = y1; t->a[2] = hq; gx = (hq - h01) / dx; gy = (hq - h10) / dy; }
+  const double inv = 1 / sqrt(gx * gx + gy * gy + 1);
+  t->n[0] = -gx * inv; t->n[1] = -gy * inv; t->n[2] = inv;
+}
+static int hf_triangle_under(const GqModelDesc* m, double x, double y, HfTri* t) {
+  const double dx = 2 * m->hfield_size[0] / (m->hfield_ncol - 1), dy = 2 * m->hfield_size[1] / (m->hfield_nrow - 1);
+  const double fx = (x + m->hfield_size[0]) / dx, fy = (y + m->hfield_size[1]) / dy;
+  if (!(fx >= 0 && fy >= 0 && fx <= m->hfield_ncol - 1 && fy <= m->hfield_nrow - 1)) return 0;
+  int c = (int)fx, r = (int)fy;
+  if (c > m->hfield_ncol - 2) c = m->hfield_ncol - 2;
+  if (r > m->hfield_nrow - 2) r = m->hfield_nrow - 2;
+  hf_cell_triangle(m, c, r, (fx - c) + (fy - r) > 1.0, t);
+  return 1;
+}
+/* closest point of triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5) */
+static int closest_on_triangle(const double* p, const double* a, const double* b, const double* c, double* q) { /* 1: the projection of p falls inside */
+  double ab[3], ac[3], ap[3], bp[3], cp[3];
+  for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; ap[k] = p[k] - a[k]; bp[k] = p[k] - b[k]; cp[k] = p[k] - c[k]; }
+  const double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { memcpy(q, a, 24); return 0; }
+  const double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { memcpy(q, b, 24); return 0; }
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); for (int k = 0; k < 3; k++) q[k] = a[k] + v * ab[k]; return 0; }
+  const double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { memcpy(q, c, 24); return 0; }
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); for (int k = 0; k < 3; k++) q[k] = a[k] + w * ac[k]; return 0; }
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); for (int k = 0; k < 3; k++) q[k] = b[k] + w * (c[k] - b[k]); return 0; }
+  const double den = 1 / (va + vb + vc);
+  for (int k = 0; k < 3; k++) q[k] = a[k] + vb * den * ab[k] + vc * den * ac[k];
+  return 1;
+}
+/* sphere (centre p in hfield-local coordinates) against the field: signed distance and normal; 0 if farther than reach */
+static int sphere_hfield(const GqModelDesc* m, const double* p, double r, double reach, double* dist, double* n) {
+  const double dx = 2 * m->hfield_size[0] / (m->hfield_ncol - 1), dy = 2 * m->hfield_size[1] / (m->hfield_nrow - 1), R = r + reach;
+  int c0 = (int)floor((p[0] - R + m->hfield_size[0]) / dx), c1 = (int)floor((p[0] + R + m->hfield_size[0]) / dx);
+  int r0 = (int)floor((p[1] - R + m->hfield_size[1]) / dy), r1 = (int)floor((p[1] + R + m->hfield_size[1]) / dy);
+  if (c0 < 0) c0 = 0;
+  if (r0 < 0) r0 = 0;
+  if (c1 > m->hfield_ncol - 2) c1 = m->hfield_ncol - 2;
+  if (r1 > m->hfield_nrow - 2) r1 = m->hfield_nrow - 2;
+  *dist = 1e300; n[0] = n[1] = 0; n[2] = 1;
+  for (int rr = r0; rr <= r1; rr++)
+    for (int cc = c0; cc <= c1; cc++)
+      for (int up = 0; up < 2; up++) {
+        HfTri t;
+        hf_cell_triangle(m, cc, rr, up, &t);
+        double pa[3] = {p[0] - t.a[0], p[1] - t.a[1], p[2] - t.a[2]}, q[3], d[3], dd, nn[3];
+        const double side = dot3(pa, t.n);
+        if (closest_on_triangle(p, t.a, t.b, t.c, q)) { dd = side - r; memcpy(nn, t.n, sizeof nn); } /* over / under the face */
+        else {
+          if (side < 0) continue; /* below the plane and outside the column: a neighbour's business */
+          for (int k = 0; k < 3; k++) d[k] = p[k] - q[k];
+          const double l2 = dot3(d, d);
+          if (!(l2 > 1e-12)) continue;
+          const double l = sqrt(l2); dd = l - r; for (int k = 0; k < 3; k++) nn[k] = d[k] / l;
+        }
+        if (dd < *dist) { *dist = dd; memcpy(n, nn, sizeof nn); }
+      }
+  return *dist < reach;
 }
 
 static void gqo_collision(GqOracle* o) {
@@ -526,6 +608,39 @@ static void gqo_collision(GqOracle* o) {
       contact_param(o, w, g, c);
     }
   }
+  /* the height field: world geom after the boxes */
+  if (m->hfield_nrow > 0)
+    for (int g = 0; g < m->ngeom && o->ncon < NCON; g++) {
+      int cl = m->geom_cloudid[g];
+      if (cl < 0 || m->geom_bodyid[g] == 0) continue;
+      const double r = m->cloud_radius[cl];
+      const double margin = m->hfield_margin > m->geom_margin[g] ? m->hfield_margin : m->geom_margin[g];
+      double best = 1e300, second = 1e300, bn[3] = {0, 0, 1}, bv[3] = {0, 0, 0};
+      if (is_foot(m, g)) { /* foot sphere (the kernel's other collision items are vertex clouds, spheres included) */
+        double wv[3], lc[3], d, n[3];
+        mulmatvec3(wv, o->geom_xmat[g], m->vert_pos + 3 * m->cloud_vertadr[cl]);
+        for (int k = 0; k < 3; k++) { wv[k] += o->geom_xpos[g][k]; lc[k] = wv[k] - m->hfield_pos[k]; }
+        if (!sphere_hfield(m, lc, r, fmax(margin, 0) + 1e-4, &d, n)) continue;
+        best = d; memcpy(bn, n, sizeof bn); memcpy(bv, wv, sizeof bv);
+      } else
+        for (int v = 0; v < m->cloud_vertnum[cl]; v++) {
+          double wv[3], lc[3];
+          mulmatvec3(wv, o->geom_xmat[g], m->vert_pos + 3 * (m->cloud_vertadr[cl] + v));
+          for (int k = 0; k < 3; k++) { wv[k] += o->geom_xpos[g][k]; lc[k] = wv[k] - m->hfield_pos[k]; }
+          HfTri t;
+          if (!hf_triangle_under(m, lc[0], lc[1], &t)) continue;
+          const double pa[3] = {lc[0] - t.a[0], lc[1] - t.a[1], lc[2] - t.a[2]}, dist = dot3(pa, t.n) - r;
+          if (dist < best) { second = best; best = dist; memcpy(bn, t.n, sizeof bn); memcpy(bv, wv, sizeof bv); }
+          else if (dist < second) second = dist;
+        }
+      if (best >= margin) continue;
+      Contact* c = &o->contact[o->ncon++];
+      c->geom = g; c->body = m->geom_bodyid[g]; c->dist = best; c->tiegap = second - best;
+      for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - bn[k] * (r + 0.5 * best);
+      memcpy(c->frame, bn, sizeof bn);
+      make_frame(c->frame);
+      contact_param(o, m->nbox, g, c);
+    }
 }
 
 /* ------------------------------------------------------------------ constraint construction */

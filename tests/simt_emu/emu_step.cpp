@@ -31,6 +31,9 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
   static GqDevBatch B;
   std::vector<float> vx, vy, vz;
   if (gq_build_dev_model(desc, &M, &vx, &vy, &vz, err, (size_t)errlen)) return -1;
+  static std::vector<float> hf_heights;
+  gq_hfield_heights(desc, &hf_heights);
+  M.hf_data = hf_heights.empty() ? nullptr : hf_heights.data();
   if (gq_build_dev_batch(n_envs, obs_ids, n_obs, legs_order, &B, err, (size_t)errlen)) return -1;
   B.debug_envs = debug_envs;
   if (imu) gq_fill_imu(&B, imu);
@@ -59,12 +62,12 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
       bool respawn = call.auto_reset == 2 && f.s.pending[e];
       for (;;) {
         if (respawn) {
-          if (M.nbox > 0) gq::reset_wave<true>(f.r, W); else gq::reset_wave<false>(f.r, W);
+          if ((M.nbox > 0 || M.hf_nrow > 0)) gq::reset_wave<true>(f.r, W); else gq::reset_wave<false>(f.r, W);
           pass = call.auto_reset;
         }
         int term;
         if (M.solver != 1) term = gq::step_wave<0, 1, false, false>(f.s, call, W, pass);
-        else if (M.nbox > 0) term = M.cone ? gq::step_wave<1, 1, true, true>(f.s, call, W, pass) : gq::step_wave<1, 1, false, true>(f.s, call, W, pass);
+        else if ((M.nbox > 0 || M.hf_nrow > 0)) term = M.cone ? gq::step_wave<1, 1, true, true>(f.s, call, W, pass) : gq::step_wave<1, 1, false, true>(f.s, call, W, pass);
         else term = M.cone ? gq::step_wave<1, 1, true, false>(f.s, call, W, pass) : gq::step_wave<1, 1, false, false>(f.s, call, W, pass);
         if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
@@ -81,6 +84,9 @@ extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mas
   static GqDevModel M;
   std::vector<float> vx, vy, vz;
   if (gq_build_dev_model(desc, &M, &vx, &vy, &vz, err, (size_t)errlen)) return -1;
+  static std::vector<float> hf_heights;
+  gq_hfield_heights(desc, &hf_heights);
+  M.hf_data = hf_heights.empty() ? nullptr : hf_heights.data();
   gq::ResetArgs a{};
   a.model = &M; a.vx = vx.data(); a.vy = vy.data(); a.vz = vz.data(); a.mask = mask; a.qpos_new = qpos_new; a.qvel_new = qvel_new;
   a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied; a.time = time; a.cmd = cmd;
@@ -90,7 +96,7 @@ extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mas
     if (mask && !mask[e]) continue;
     emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
       __shared__ gq::WaveMem W;
-      if (M.nbox > 0) gq::reset_wave<true>(a, W); else gq::reset_wave<false>(a, W);
+      if ((M.nbox > 0 || M.hf_nrow > 0)) gq::reset_wave<true>(a, W); else gq::reset_wave<false>(a, W);
     });
   }
   return 0;

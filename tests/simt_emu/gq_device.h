@@ -68,6 +68,8 @@ static inline void sched_fence() {}
 static inline long long cycles() { return 0; }
 static inline long long wall_clock64() { return 0; }
 static inline void wave_priority(int) {}
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
 #define __builtin_amdgcn_s_getreg(x) 0
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }

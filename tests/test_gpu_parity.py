@@ -113,7 +113,7 @@ def test_rollout_tracks_oracle():
 @pytest.mark.parametrize('robot_name', ['b2', 'go1', 'go2', 'hyqreal1', 'hyqreal2', 'mini_cheetah', 'aliengo'])
 def test_reset_contract_and_shapes(robot_name):
     """The reference's own test (tests/env_test.py:13-53) re-expressed for the batch, same robot list, scene 'flat'
-    (its second scene, 'perlin', is not built yet and raises NotImplementedError): three resets, shapes, 10 steps."""
+    (its second scene, 'perlin': test_perlin_scene_contract_and_parity): three resets, shapes, 10 steps."""
     from gym_quadruped_amd.quadruped_env import QuadrupedEnv
     n = 64
     env = QuadrupedEnv(robot=robot_name, scene='flat', ref_base_lin_vel=(0.5, 1.0), ground_friction_coeff=(0.2, 1.5),
@@ -553,9 +553,85 @@ def test_api_edge_cases_single_env_action_forms_and_errors():
         QuadrupedEnv('hyqreal', num_envs=1)
     with pytest.raises(ValueError):
         QuadrupedEnv('mini_cheetah', scene='moon', num_envs=1)
-    with pytest.raises(NotImplementedError):
-        QuadrupedEnv('mini_cheetah', scene='perlin', num_envs=1)
+    with pytest.raises(_lib.GqError, match='Newton'):
+        QuadrupedEnv('aliengo', scene='perlin', solver='pgs', num_envs=1)
     with pytest.raises(_lib.GqError, match='Newton'):
         QuadrupedEnv('go2', solver='pgs', num_envs=1)
     with pytest.raises(_lib.GqError, match='Newton'):
         QuadrupedEnv('aliengo', scene='stairs', solver='pgs', num_envs=1)
+
+
+def _hfield_height(hf, x, y):
+    """Elevation of the height field's triangulated surface at world (x, y) (numpy, the triangulation of gq_boxes.h)."""
+    data = np.asarray(hf['data'], np.float64); sx, sy, sz, _ = hf['size']; px, py, pz = hf.get('pos', (0.0, 0.0, 0.0))
+    nr, nc = data.shape
+    fx, fy = (x - px + sx) / (2 * sx) * (nc - 1), (y - py + sy) / (2 * sy) * (nr - 1)
+    c, r = min(int(fx), nc - 2), min(int(fy), nr - 2)
+    u, v = fx - c, fy - r
+    h00, h10, h01, h11 = sz * data[r, c], sz * data[r, c + 1], sz * data[r + 1, c], sz * data[r + 1, c + 1]
+    return pz + (h00 + u * (h10 - h00) + v * (h01 - h00) if u + v <= 1 else h11 + (1 - u) * (h01 - h11) + (1 - v) * (h10 - h11))
+
+
+@pytest.mark.parametrize('robot', ['aliengo', 'hyqreal1', 'mini_cheetah'])
+def test_perlin_scene_contract_and_parity(robot):
+    """BASELINE.json configs[2] (aliengo on 'perlin', the second scene of the reference's own test tests/env_test.py:13-53):
+    reset lifts every robot clear of the hills, a random rollout with next-step auto-reset stays finite and on the terrain,
+    one step from the rollout state matches the fp64 oracle (same height-field narrow phase), HeightMap rays land on the
+    triangulated surface."""
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    from gym_quadruped_amd.sensors import HeightMap
+    from oracle.oracle import Oracle
+    n = 256
+    env = QuadrupedEnv(robot, scene='perlin', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, solver='newton',
+                       auto_reset='next_step', seed=11)
+    hf = env.scene_desc['hfield']
+    state = env.reset(random=True)
+    torch.cuda.synchronize()
+    assert not bool(env.lift_failed.any())
+    for name in QuadrupedEnv.ALL_OBS:
+        assert tuple(state[name].shape) == (n,) + tuple(env.observation_space[name].shape)
+    lim = env.terrain_limits
+    q = env.qpos.cpu().numpy()
+    assert np.all((q[:, 0] <= lim[0]) & (q[:, 0] >= lim[1]) & (q[:, 1] <= lim[2]) & (q[:, 1] >= lim[3]))
+    ground = np.array([_hfield_height(hf, q[e, 0], q[e, 1]) for e in range(n)])
+    assert np.all(q[:, 2] > ground) and ground.max() > 0.3 * hf['size'][2]       # bases above the local surface, hills present
+    g = torch.Generator(device='cuda:0').manual_seed(2)
+    nterm = 0
+    for _ in range(150):
+        obs, rew, term, trunc, info = env.step(torch.randn(n, 12, generator=g, device='cuda:0') * 15)
+        nterm += int(term.sum())
+    torch.cuda.synchronize()
+    assert torch.isfinite(env.qpos).all() and torch.isfinite(env.qvel).all() and torch.isfinite(env._obs_buf).all()
+    q = env.qpos.cpu().numpy()
+    ground = np.array([_hfield_height(hf, q[e, 0], q[e, 1]) for e in range(n)])
+    assert np.all(q[:, 2] > ground - 0.05), 'a robot fell through the terrain'
+    assert float(obs['contact_state'].float().mean()) > 0.03                     # feet on the hills (most robots are mid-fall after a respawn)
+    # one more step, checked against the oracle
+    q0, v0, w0, fr = env.qpos.cpu().numpy().copy(), env.qvel.cpu().numpy().copy(), env._warm.cpu().numpy().copy(), env._friction.cpu().numpy().copy()
+    pend = env._terminated_b.cpu().numpy().copy()
+    act = torch.randn(n, 12, generator=g, device='cuda:0') * 15
+    env.enable_debug(n)
+    obs, rew, term, trunc, info = env.step(act)
+    torch.cuda.synchronize()
+    dbg = env.debug_internals(n, ['qacc', 'nefc'])
+    o = Oracle(marshalled(robot, solver=1, iterations=100, tolerance=1e-12, hfield=hf, terrain_limits=lim))
+    a = act.cpu().numpy()
+    qv = env.qvel.cpu().numpy()
+    nchecked = nhf = 0
+    for e in range(n):
+        if pend[e]:
+            continue
+        o.set_state(q0[e], v0[e], w0[e], np.zeros(18), 0.0, float(fr[e])); o.step(a[e].astype(np.float64))
+        if (o.ncon and o.get('contact_tiegap').min() < 3e-6) or int(dbg[e]['nefc'][0]) != o.nefc:
+            continue
+        nchecked += 1
+        nhf += int((np.abs(o.contact_frame[:, 0, 2] - 1.0) > 1e-9).sum()) if o.ncon else 0
+        assert np.abs(dbg[e]['qacc'] - o.qacc).max() < 3e-4 * max(1.0, np.abs(o.qacc).max()), e
+        assert np.abs(qv[e] - o.qvel).max() < 1e-3
+    assert nchecked > 0.5 * n and nhf > n // 4, (nchecked, nhf)
+    # HeightMap: vertical rays against the same surface
+    hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)
+    data = hm.update_height_map(env.qpos[:, 0:3], yaw=0.3).reshape(n, -1, 3).cpu().numpy()
+    for e in range(0, n, 9):
+        for p in data[e]:
+            assert abs(p[2] - max(0.0, _hfield_height(hf, p[0], p[1]))) < 2e-4, (e, p)

@@ -102,8 +102,22 @@ def test_env_fails_loudly_without_gpu_or_library():
             QuadrupedEnv('mini_cheetah', num_envs=2)   # no silent CPU fallback
     with pytest.raises(ValueError):
         QuadrupedEnv('hyqreal', device='cpu')
-    with pytest.raises((NotImplementedError, _lib.GqError)):
+    with pytest.raises(_lib.GqError):
         QuadrupedEnv('mini_cheetah', scene='perlin', device='cpu')
+
+
+def test_pnoise2_restatement_reproduces_the_reference_image():
+    """noise.pnoise2 (third party, absent here) restated in terrain.py: the image the reference ships - an output of its
+    add_perlin_heightfield with default arguments (tools/gen_golden_perlin.py) - is reproduced bit for bit."""
+    from gym_quadruped_amd.terrain import perlin_image, pnoise2
+    g = np.load(Path(__file__).parent / 'golden' / 'perlin_default.npz')
+    img = perlin_image(128, 128, smooth=float(g['smooth']), perlin_octaves=int(g['octaves']), perlin_persistence=float(g['persistence']),
+                       perlin_lacunarity=float(g['lacunarity']))
+    assert img.dtype == np.uint8 and np.array_equal(img, g['image'])
+    # lattice points are zeros of every octave; one octave is bounded by sqrt(2) / 2 in 2-D
+    assert np.all(pnoise2(np.arange(5.0), np.arange(5.0), octaves=3) == 0.0)
+    xs = np.linspace(0.0, 7.3, 400)
+    assert np.abs(pnoise2(xs, xs[::-1] * 1.37)).max() <= 0.7072
 
 
 def test_legsattr_spaces_and_joint_maps():
@@ -171,7 +185,12 @@ def test_procedural_box_scenes_match_the_reference_generator():
         scene, lim = generate_terrain(name, 0.3)
         assert len(scene['boxes']) == nbox and lim == (10000.0, -10000.0, 10000.0, -10000.0)
     assert generate_terrain('slippery', 0.3)[0]['boxes'][0]['priority'] == 2
-    with pytest.raises(NotImplementedError):
-        generate_terrain('perlin', 0.3)
+    # perlin (terrain.py:345-356): 128 x 128 field, half extents 50 x hip, elevation 2 x hip, base 0.005; limits = 0.8 x half extent
+    scene, lim = generate_terrain('perlin', 0.35)
+    hf = scene['hfield']
+    assert hf['data'].shape == (128, 128) and float(hf['data'].min()) == 0.0 and float(hf['data'].max()) == 1.0
+    np.testing.assert_allclose(hf['size'], (17.5, 17.5, 0.7, 0.005))
+    np.testing.assert_allclose(lim, (14.0, -14.0, 14.0, -14.0))
+    assert not scene['boxes']
     with pytest.raises(ValueError):
         generate_terrain('moon', 0.3)

@@ -329,3 +329,97 @@ def test_reset_lifts_clear_of_world_boxes():
             assert not calf_touch, 'a calf body still touches the floor or a box'
         lifted += st['qpos'][e, 2] > hip + 1e-4
     assert lifted >= 3 and nfailed <= 2   # some spawn poses did sit in a box
+
+
+@pytest.mark.parametrize('robot', ['aliengo', 'hyqreal1'])   # pyramidal / elliptic cones
+def test_perlin_height_field_step_matches_oracle(robot):
+    """BOXES kernel variant on the reference's perlin scene (128 x 128 height field, terrain.py:345-356): contact rows,
+    frames and the Newton solution against the fp64 oracle for robots dropped onto the hills."""
+    from gym_quadruped_amd.robot_cfgs import get_robot_config
+    from gym_quadruped_amd.terrain import generate_terrain
+    hip = get_robot_config(robot).hip_height
+    scene, lim = generate_terrain('perlin', hip)
+    kw = dict(solver=1, iterations=100, hfield=scene['hfield'], terrain_limits=lim)
+    mm = marshalled(robot, tolerance=1e-8, noise_floor=1e-5, **kw)
+    mmN = marshalled(robot, tolerance=1e-13, **kw)
+    rng = np.random.default_rng(21)
+    n = 16
+    qpos, qvel = random_states(mm.md, n, rng, z_range=(0.75 * hip, 1.05 * hip))
+    qpos[:, 0:2] = rng.uniform(-0.7 * lim[0], 0.7 * lim[0], (n, 2))
+    # terrain elevation under the base: put the robots at their drawn height above the local surface
+    hf = scene['hfield']; data = np.asarray(hf['data'], float); sx, sy, sz, _ = hf['size']
+    ci = np.clip(((qpos[:, 0] + sx) / (2 * sx) * (data.shape[1] - 1)).round().astype(int), 0, data.shape[1] - 1)
+    ri = np.clip(((qpos[:, 1] + sy) / (2 * sy) * (data.shape[0] - 1)).round().astype(int), 0, data.shape[0] - 1)
+    qpos[:, 2] += sz * data[ri, ci]
+    qvel = qvel.astype(np.float32)
+    warm = rng.normal(0, 3, (n, 18)).astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 20).astype(np.float32)
+    st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), warm=warm.copy(), debug_envs=n)
+    o = Oracle(mmN)
+    nhf_con = nchecked = 0
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e].astype(np.float64), warm[e].astype(np.float64), np.zeros(18)); o.step(ctrl[e].astype(np.float64))
+        rec = st['debug'][e]
+        nefc = int(dbg(rec, 'nefc')[0])
+        if (o.ncon and o.get('contact_tiegap').min() < 3e-6) or nefc != o.nefc:
+            continue
+        nchecked += 1
+        nhf_con += int((np.abs(o.contact_frame[:, 0, 2] - 1.0) > 1e-9).sum()) if o.ncon else 0
+        J = dbg(rec, 'efc_J').reshape(64, 18)[:nefc]
+        np.testing.assert_allclose(J, o.efc_J, atol=3e-5 * max(1.0, np.abs(o.efc_J).max()))
+        np.testing.assert_allclose(dbg(rec, 'efc_R')[:nefc], o.efc_R, rtol=3e-4)
+        np.testing.assert_allclose(dbg(rec, 'efc_aref')[:nefc], o.efc_aref, atol=3e-4 * max(1.0, np.abs(o.efc_aref).max()))
+        assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 2e-4 * max(1.0, np.abs(o.qacc).max()), e
+        assert np.abs(st['qvel'][e] - o.qvel).max() < 5e-4
+        ref, t, inv = o.get_obs(ALL_OBS, np.zeros(4))
+        got = split_obs(st['obs'][e], ALL_OBS)
+        for k in ('contact_forces', 'contact_forces:base', 'contact_state', 'feet_vel'):
+            assert np.abs(got[k] - ref[k]).max() < 1e-2 * max(1.0, np.abs(ref[k]).max(), 0.1 * 9.81 * mm.md.total_mass), (e, k)
+        assert bool(st['terminated'][e]) == t
+    assert nchecked >= n // 2 and nhf_con >= 8, (nchecked, nhf_con)
+
+
+def test_flat_height_field_equals_raised_floor_in_the_kernel():
+    H = 1.37
+    flat = dict(data=np.zeros((17, 17), np.float32), size=(8.0, 8.0, 1.0, 0.01), pos=(0.0, 0.0, H))
+    mmF = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-8)
+    mmH = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-8, hfield=flat)
+    rng = np.random.default_rng(3)
+    n = 8
+    qpos, qvel = random_states(mmF.md, n, rng, z_range=(0.3, 0.45))
+    qvel = qvel.astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 10).astype(np.float32)
+    a = emu_step(mmF, ctrl, qpos.copy(), qvel.copy(), debug_envs=n)
+    qb = qpos.copy(); qb[:, 2] += H
+    b = emu_step(mmH, ctrl, qb, qvel.copy(), debug_envs=n)
+    seen = 0
+    for e in range(n):
+        na, nb = int(dbg(a['debug'][e], 'nefc')[0]), int(dbg(b['debug'][e], 'nefc')[0])
+        assert na == nb
+        seen += na > 12
+        np.testing.assert_allclose(dbg(b['debug'][e], 'qacc'), dbg(a['debug'][e], 'qacc'), rtol=2e-4, atol=2e-4 * max(1.0, np.abs(dbg(a['debug'][e], 'qacc')).max()))
+        np.testing.assert_allclose(b['qvel'][e], a['qvel'][e], atol=1e-4)
+    assert seen >= 4
+
+
+def test_reset_lifts_clear_of_the_height_field():
+    """Reset on the perlin scene: the keyframe pose spawns inside the hills (elevation up to 2 x hip height); the lift loop
+    (:376-388), re-evaluating floor and height field per iteration, must end with no calf-body geom touching anything."""
+    from gym_quadruped_amd.robot_cfgs import get_robot_config
+    from gym_quadruped_amd.terrain import generate_terrain
+    hip = get_robot_config('aliengo').hip_height
+    scene, lim = generate_terrain('perlin', hip)
+    mm = marshalled('aliengo', solver=1, terrain_limits=lim, hfield=scene['hfield'])
+    cfg = default_reset_cfg(seed=77, hip_height=hip)
+    n = 12
+    st = emu_reset(mm, n, cfg, episode=np.arange(n))
+    o = Oracle(mm)
+    lifted = 0
+    for e in range(n):
+        assert lim[1] <= st['qpos'][e, 0] <= lim[0] and lim[3] <= st['qpos'][e, 1] <= lim[2]
+        assert not st['lift_failed'][e]
+        o.set_state(st['qpos'][e], st['qvel'][e].astype(np.float64), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12), stage=1)
+        bodies = o.get('contact_body') if o.ncon else []
+        assert not [c for c, bd in enumerate(bodies) if (int(bd) - 2) % 3 == 2], 'a calf body still touches the terrain'
+        lifted += st['qpos'][e, 2] > hip + 1e-3
+    assert lifted >= n // 2

@@ -269,3 +269,77 @@ def test_world_box_side_face_and_ramp_normals():
     o2.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o2.forward(np.zeros(12))
     normals = o2.contact_frame[:, 0]
     assert any(abs(nv[0] - 1.0) < 1e-9 and abs(nv[2]) < 1e-9 for nv in normals), normals
+
+
+def _plane_hfield(H=0.0, slope=0.0, half=6.0, n=33, elevation=1.0):
+    """Height field whose samples lie on the plane z = H + slope * (x + half) (data in [0, 1] x elevation)."""
+    x = np.linspace(-half, half, n)
+    data = np.tile(slope * (x + half) / elevation, (n, 1)).astype(np.float32)
+    assert data.max() <= 1.0
+    return dict(data=data, size=(half, half, elevation, 0.01), pos=(0.0, 0.0, H))
+
+
+@pytest.mark.parametrize('robot', ['aliengo', 'hyqreal1'])
+def test_flat_height_field_is_a_raised_floor(robot):
+    """A height field with constant elevation H under the robot must give exactly the dynamics of the floor plane H lower
+    (sphere-triangle and vertex-plane distances degenerate to the plane's, normal +z, default geom parameters)."""
+    H = 1.37
+    mmF = marshalled(robot, solver=1, iterations=100, tolerance=1e-12)
+    mmH = marshalled(robot, solver=1, iterations=100, tolerance=1e-12, hfield=_plane_hfield(H))
+    oF, oH = Oracle(mmF), Oracle(mmH)
+    rng = np.random.default_rng(19)
+    hip = float(mmF.desc.key_qpos[2])
+    qpos, qvel = random_states(mmF.md, 10, rng, z_range=(0.7 * hip, 1.1 * hip))
+    ncon = 0
+    for e in range(10):
+        ctrl = rng.normal(0, 10, 12)
+        oF.set_state(qpos[e], qvel[e], np.zeros(18), np.zeros(18)); oF.step(ctrl)
+        qb = qpos[e].copy(); qb[2] += H
+        oH.set_state(qb, qvel[e], np.zeros(18), np.zeros(18)); oH.step(ctrl)
+        assert oH.ncon == oF.ncon
+        ncon += oF.ncon
+        np.testing.assert_allclose(oH.qacc, oF.qacc, rtol=1e-6, atol=1e-6 * max(1, np.abs(oF.qacc).max()))
+        np.testing.assert_allclose(oH.get('contact_dist'), oF.get('contact_dist'), atol=1e-9)
+        np.testing.assert_allclose(oH.contact_frame, oF.contact_frame, atol=1e-9)
+    assert ncon > 10
+
+
+def test_sloped_height_field_normals_and_cone():
+    """Feet on a height field that is one tilted plane: every contact carries the plane's normal and the sphere's distance
+    to it; the forces stay inside the friction pyramid of that frame; a ridge (two planes meeting) is met at its edge."""
+    s = 0.25
+    mm = marshalled('aliengo', solver=1, iterations=200, tolerance=1e-12, hfield=_plane_hfield(0.5, s, elevation=4.0))
+    o = Oracle(mm)
+    n_pl = np.array([-s, 0.0, 1.0]) / np.sqrt(1 + s * s)
+    q = mm.md.key_qpos[0].copy()
+    q[0:2] = (0.37, -0.21)
+    q[2] = 3.0
+    o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12), stage=1)
+    feet = [mm.md.geom_names.index(k) for k in ('FL', 'FR', 'RL', 'RR')]
+    rad = float(mm.md.cloud_radius[mm.md.geom_cloudid[feet[0]]])
+    p0 = np.array([-6.0, 0.0, 0.5])                                    # a point of the plane
+    dmin = min(float(n_pl @ (o.geom_xpos[g] - p0)) - rad for g in feet)
+    q[2] -= (dmin + 0.002) / n_pl[2]
+    o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12))
+    assert o.ncon >= 2
+    fr, cf, dist = o.contact_frame, o.contact_force, o.get('contact_dist')
+    geoms = o.get('contact_geom').astype(int)
+    for c in range(o.ncon):
+        np.testing.assert_allclose(fr[c][0], n_pl, atol=1e-9)
+        if geoms[c] in feet:
+            np.testing.assert_allclose(dist[c], n_pl @ (o.geom_xpos[geoms[c]] - p0) - rad, atol=1e-9)
+        assert cf[c, 0] >= -1e-9 and abs(cf[c, 1]) <= cf[c, 0] + 1e-6 and abs(cf[c, 2]) <= cf[c, 0] + 1e-6
+    # ridge: z = 1 - |x| sampled on the grid (apex on a grid line): a sphere above the apex touches the edge, normal +z
+    x = np.linspace(-2.0, 2.0, 41)
+    ridge = dict(data=np.tile(1.0 - np.abs(x) / 2.0, (41, 1)).astype(np.float32), size=(2.0, 2.0, 2.0, 0.01), pos=(0.0, 0.0, 0.0))
+    mm2 = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-10, hfield=ridge)
+    o2 = Oracle(mm2)
+    q = mm2.md.key_qpos[0].copy(); q[2] = 3.0
+    o2.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o2.forward(np.zeros(12), stage=1)
+    foot = o2.geom_xpos[mm2.md.geom_names.index('FL')]
+    q[0] -= foot[0]                                                    # FL foot centre exactly above the ridge line x = 0
+    q[2] -= foot[2] - (2.0 + rad - 0.001)                              # 1 mm into the apex (height 2 at x = 0)
+    o2.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o2.forward(np.zeros(12))
+    c = list(o2.get('contact_geom').astype(int)).index(mm2.md.geom_names.index('FL'))
+    np.testing.assert_allclose(o2.contact_frame[c][0], [0, 0, 1], atol=1e-9)
+    np.testing.assert_allclose(o2.get('contact_dist')[c], -0.001, atol=1e-9)
