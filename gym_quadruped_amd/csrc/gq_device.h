@@ -123,6 +123,11 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+/* a^p / b^q for a, b in (0, 1]: exp2(p log2 a - q log2 b) on the transcendental unit (v_log_f32 / v_exp_f32, ~1 ulp each;
+ * the library powf is 600 instructions of special-case handling that these arguments never reach) */
+__device__ __forceinline__ float fast_pow_ratio(float a, float p, float b, float q) {
+  return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(a) - q * __builtin_amdgcn_logf(b));
+}
 __device__ __forceinline__ float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 }  // namespace gq

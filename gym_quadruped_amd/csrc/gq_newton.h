@@ -391,7 +391,7 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
   return Dm * q * E.mu * E.fri * uhat;
 }
 
-/* Newton iterations.  In: row data in registers, qacc_smooth / warm / Mc / Mb in LDS, J rows in W.u.B.
+/* Newton iterations.  In: row data in registers, smooth (= qfrc_smooth) / warm / Mc / Mb in LDS, J rows in W.u.B.
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
 template <bool DBG, bool CONE>
 __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, int rtype, float rR, float raref,
@@ -409,31 +409,15 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
   float* grad = W.act;
   float* search = W.u2.n.nw[0];
   float* Ms = W.u2.n.nw[1];
-  /* ---- warm start: qacc_warmstart unless qacc_smooth is cheaper (mj_fwdConstraint) */
-  float cost_w, cost_s;
+  /* ---- starting point.  mj_fwdConstraint starts from qacc_warmstart unless the unconstrained acceleration qacc_smooth =
+   * M^-1 qfrc_smooth has the lower cost.  The minimiser does not depend on the starting point (strictly convex cost), and
+   * qacc_smooth is needed for nothing else in this formulation (the Gauss term enters through M qacc - qfrc_smooth), so
+   * its tree solve - a fifth of an average step's arithmetic - is only spent where the warm start carries no information:
+   * an env whose warm start is all zero (fresh from a reset).  The debug variant always fills qacc_smooth for the record. */
   {
-    float yw = -raref, ys = -raref;
-    {
-      const float* J = JROW();
-#pragma unroll
-      for (int k = 0; k < GQ_NVD; k++) { yw += J[k] * W.warm[k]; ys += J[k] * W.qacc_smooth[k]; }
-    }
-    float cw, cs, tmp;
-    row_law(rtype, yw, rR, rD, rfloss, cw, tmp);
-    row_law(rtype, ys, rR, rD, rfloss, cs, tmp);
-    if constexpr (CONE) {
-      float c2, t1, t2, t3, t4; int z;
-      ell_state(E, yw, rD, c2, t1, z, t2, t3, t4); if (E.code) cw = c2;
-      ell_state(E, ys, rD, c2, t1, z, t2, t3, t4); if (E.code) cs = c2;
-    }
-    if (lane < GQ_NVD) dq[lane] = W.warm[lane] - W.qacc_smooth[lane];
-    wave_barrier();
-    float g = 0.0f;
-    if (lane < GQ_NVD) g = 0.5f * dq[lane] * mul_m_row(W, dq, lane);
-    cost_w = wave_sum(cw + g);
-    cost_s = wave_sum(cs);
-    wave_barrier();
-    if (lane < GQ_NVD) W.qacc[lane] = cost_w < cost_s ? W.warm[lane] : W.qacc_smooth[lane];
+    const bool cold = ballot(lane < GQ_NVD && W.warm[lane] != 0.0f) == 0; /* wave-uniform */
+    if (DBG || cold) solve_tree_fused<false>(W.Mc, W.Mb, nullptr, 0.0f, W.smooth, W.qacc_smooth);
+    if (lane < GQ_NVD) W.qacc[lane] = cold ? W.qacc_smooth[lane] : W.warm[lane];
     wave_barrier();
   }
   float f = 0.0f;
@@ -469,18 +453,17 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
   NW_T(0);
   /* residual y = J qacc - aref and Ma-terms are evaluated once, then advanced incrementally along the search
    * direction (y += alpha J s, M dq += alpha M s), as mj_solNewton does */
-  float y = -raref, dqv = 0.0f, md = 0.0f;
+  float y = -raref, md = 0.0f;
   {
     const float* J = JROW();
 #pragma unroll
     for (int k = 0; k < GQ_NVD; k++) y += J[k] * W.qacc[k];
   }
-  if (lane < GQ_NVD) { dqv = W.qacc[lane] - W.qacc_smooth[lane]; dq[lane] = dqv; }
-  wave_barrier();
-  if (lane < GQ_NVD) md = mul_m_row(W, dq, lane);
+  /* md = M (qacc - qacc_smooth) = M qacc - qfrc_smooth */
+  if (lane < GQ_NVD) md = mul_m_row(W, W.qacc, lane) - W.smooth[lane];
   for (;; iter++) {
     /* a wave that needs many iterations decides when the launch ends: it moves ahead of the waves it shares the SIMD with */
-    if (iter + 1 > prio && iter > 0) { prio = iter + 1; wave_priority(prio); }
+    if (iter > prio && iter > 1) { prio = iter; wave_priority(prio); }
     /* ---- constraint state at the current iterate */
     float ci, wact;
     f = row_law(rtype, y, rR, rD, rfloss, ci, wact);
@@ -663,7 +646,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       alpha = an;
     }
     wave_barrier();
-    if (lane < GQ_NVD) { W.qacc[lane] += alpha * search[lane]; dqv += alpha * search[lane]; md += alpha * ms; }
+    if (lane < GQ_NVD) { W.qacc[lane] += alpha * search[lane]; md += alpha * ms; }
     const float ynew = y + alpha * v;
     /* the cost is piecewise quadratic.  A full Newton step (accepted at the first trial) that leaves every row on the
      * piece it was linearised on has reached the minimiser of a model that IS the cost there: converged, and the

@@ -583,12 +583,11 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   if constexpr (SOLVER == 1) {
     /* ================================================================ S8/S9 (Newton): primal solve, no dual operator */
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
-    solve_tree_fused<false>(W.Mc, W.Mb, nullptr, 0.0f, W.smooth, W.qacc_smooth);
     GQ_TICK(8);
     const EllRow ell = {ecode, er0, efri, emu, 1.0f / eR0};
     const float fN = newton_solve<DBG, CONE>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
                                   timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint);
-    if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)(iter < 2 ? 0 : (iter > 2 ? 3 : 2));
+    if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)(iter < 3 ? 0 : (iter > 3 ? 3 : 2));
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {

@@ -229,8 +229,8 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   float y;
   if (power == 1.0f) y = x;
   else if (power == 2.0f) y = x <= mid ? x * x / mid : 1.0f - (1.0f - x) * (1.0f - x) / (1.0f - mid); /* MuJoCo's default */
-  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.0f);
-  else y = 1.0f - powf(1.0f - x, power) / powf(1.0f - mid, power - 1.0f);
+  else if (x <= mid) y = fast_pow_ratio(x, power, mid, power - 1.0f);
+  else y = 1.0f - fast_pow_ratio(1.0f - x, power, 1.0f - mid, power - 1.0f);
   return dmin + y * (dmax - dmin);
 }
 

@@ -423,3 +423,38 @@ def test_reset_lifts_clear_of_the_height_field():
         assert not [c for c, bd in enumerate(bodies) if (int(bd) - 2) % 3 == 2], 'a calf body still touches the terrain'
         lifted += st['qpos'][e, 2] > hip + 1e-3
     assert lifted >= n // 2
+
+
+def test_general_impedance_power_matches_oracle():
+    """solimp power other than MuJoCo's default 2 (and than 1): the kernel's exp2/log2 form of x^p / mid^(p-1) against the
+    oracle's pow()."""
+    import copy
+    mm0 = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-8)
+    md = copy.copy(mm0.md)
+    md.geom_solimp = np.array(md.geom_solimp, dtype=np.float64).reshape(-1, 5).copy()
+    md.geom_solimp[:, 4] = 3.5; md.geom_solimp[:, 3] = 0.3
+    floor = dict(solimp=(0.9, 0.95, 0.001, 0.3, 3.5))
+    from gym_quadruped_amd.cabi import MarshalledModel
+    kw = dict(qpos0=np.array(mm0.md.qpos0), feet_geom_names=None, solver=1, iterations=100, floor=floor)
+    from gym_quadruped_amd.robot_cfgs import get_robot_config
+    kw['feet_geom_names'] = get_robot_config('aliengo').feet_geom_names
+    mm = MarshalledModel(md, tolerance=1e-8, **kw)
+    mmN = MarshalledModel(md, tolerance=1e-13, **kw)
+    rng = np.random.default_rng(5)
+    n = 8
+    qpos, qvel = random_states(md, n, rng, z_range=(0.3, 0.42))
+    qvel = qvel.astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 10).astype(np.float32)
+    st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), debug_envs=n)
+    o = Oracle(mmN)
+    rows = 0
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e].astype(np.float64), np.zeros(18), np.zeros(18)); o.step(ctrl[e].astype(np.float64))
+        rec = st['debug'][e]
+        nefc = int(dbg(rec, 'nefc')[0])
+        assert nefc == o.nefc
+        rows += nefc - 12
+        np.testing.assert_allclose(dbg(rec, 'efc_R')[:nefc], o.efc_R, rtol=3e-4)
+        np.testing.assert_allclose(dbg(rec, 'efc_aref')[:nefc], o.efc_aref, atol=3e-4 * max(1.0, np.abs(o.efc_aref).max()))
+        assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 2e-4 * max(1.0, np.abs(o.qacc).max()), e
+    assert rows > 40
