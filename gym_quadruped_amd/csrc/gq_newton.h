@@ -408,7 +408,6 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
   float* Mdq = W.qfrc_c;
   float* grad = W.act;
   float* search = W.u2.n.nw[0];
-  float* Ms = W.u2.n.nw[1];
   /* ---- starting point.  mj_fwdConstraint starts from qacc_warmstart unless the unconstrained acceleration qacc_smooth =
    * M^-1 qfrc_smooth has the lower cost.  The minimiser does not depend on the starting point (strictly convex cost), and
    * qacc_smooth is needed for nothing else in this formulation (the Gauss term enters through M qacc - qfrc_smooth), so
@@ -614,23 +613,30 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       for (int k = 0; k < GQ_NVD; k++) v += J[k] * search[k];
     }
     float ms = 0.0f;
-    if (lane < GQ_NVD) { ms = mul_m_row(W, search, lane); Ms[lane] = ms; }
-    const float q1 = wave_sum(lane < GQ_NVD ? search[lane] * md : 0.0f);
-    const float q2 = wave_sum(lane < GQ_NVD ? 0.5f * search[lane] * ms : 0.0f);
+    if (lane < GQ_NVD) ms = mul_m_row(W, search, lane);
     float alpha = 0.0f, lo = 0.0f, hi = -1.0f; /* hi < 0: no upper bracket yet */
     bool first_try = false;
+    float g0 = 0.0f, UV = 0.0f, VV = 0.0f, N1 = 0.0f;
+    /* the cost is piecewise quadratic in every row's residual, the pieces being intervals: if the full Newton step leaves
+     * every row on the piece the Hessian was assembled for, phi is one parabola on [0, 1] and its minimiser is the Newton
+     * step itself - no derivative sums, no trial steps (the usual last iteration of a solve) */
+    bool full_step = false;
+    if constexpr (!CONE) full_step = ballot(row_piece(rtype, y, rR, rfloss) != row_piece(rtype, y + v, rR, rfloss)) == 0;
+    if (full_step) { alpha = 1.0f; first_try = true; }
+    else {
+    const float q1 = wave_sum(lane < GQ_NVD ? search[lane] * md : 0.0f);
+    const float q2 = wave_sum(lane < GQ_NVD ? 0.5f * search[lane] * ms : 0.0f);
     float d1, d2;
     row_dd(rtype, y, v, rR, rD, rfloss, d1, d2);
     /* elliptic contacts: along the line T(alpha)^2 = TT + 2 alpha UV + alpha^2 VV and N(alpha) = N + alpha N1, so three
      * contact sums taken once make every trial step a lane-local evaluation */
-    float UV = 0.0f, VV = 0.0f, N1 = 0.0f;
     if constexpr (CONE) {
       const bool fr = (E.code & 15) >= 1;
       const float u = fr ? E.fri * y : 0.0f, V = fr ? E.fri * v : 0.0f;
       UV = ell_seg_sum(E, u * V); VV = ell_seg_sum(E, V * V); N1 = E.mu * shfl_idx(v, E.r0);
       if (E.code) ell_dd(E, 0.0f, y, v, rD, TT, y0, UV, VV, N1, d1, d2);
     }
-    const float g0 = q1 + wave_sum(d1);
+    g0 = q1 + wave_sum(d1);
     float h0 = 2.0f * q2 + wave_sum(d2);
     if (!(g0 < 0.0f)) { exit_code = 5; break; } /* not a descent direction: converged to working precision */
     alpha = -g0 / h0;
@@ -644,6 +650,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       float an = alpha - ga / ha;
       if (!(an > lo) || (hi > 0.0f && !(an < hi))) an = hi > 0.0f ? 0.5f * (lo + hi) : 2.0f * alpha;
       alpha = an;
+    }
     }
     wave_barrier();
     if (lane < GQ_NVD) { W.qacc[lane] += alpha * search[lane]; md += alpha * ms; }
