@@ -587,7 +587,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     const EllRow ell = {ecode, er0, efri, emu, 1.0f / eR0};
     const float fN = newton_solve<DBG, CONE>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
                                   timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint);
-    if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)(iter < 3 ? 0 : (iter > 3 ? 3 : 2));
+    if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)(iter < 2 ? 0 : (iter > 2 ? 3 : 2));
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
