@@ -826,8 +826,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   /* scipy as_euler('xyz') of the new orientation */
   float sy = fminf(fmaxf(-Rn[6], -1.0f), 1.0f);
   float e0, e1 = asinf(sy), e2, cyaw, syaw;
-  if (fabsf(sy) < 0.9999999f) { e0 = atan2f(Rn[7], Rn[8]); e2 = atan2f(Rn[3], Rn[0]); syaw = Rn[3]; cyaw = Rn[0]; }
-  else { e0 = 0.0f; e2 = atan2f(-Rn[1], Rn[4]); syaw = -Rn[1]; cyaw = Rn[4]; }
+  if (fabsf(sy) < 0.9999999f) { e0 = atan2_fast(Rn[7], Rn[8]); e2 = atan2_fast(Rn[3], Rn[0]); syaw = Rn[3]; cyaw = Rn[0]; }
+  else { e0 = 0.0f; e2 = atan2_fast(-Rn[1], Rn[4]); syaw = -Rn[1]; cyaw = Rn[4]; }
   { /* cos / sin of the yaw angle straight from the atan2 arguments */
     const float hyp2 = syaw * syaw + cyaw * cyaw, inv = hyp2 > 0.0f ? fast_rsqrt(hyp2) : 0.0f;
     syaw *= inv; cyaw = hyp2 > 0.0f ? cyaw * inv : 1.0f;

@@ -145,6 +145,22 @@ __device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
           a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
   return r;
 }
+/* atan2 for finite arguments: odd minimax polynomial of degree 15 on [0, 1] (|error| < 1.2e-7 rad) after the usual
+ * octant reduction; the library routine's handling of infinities, NaNs and denormals is not needed for rotation-matrix
+ * entries, and it is three times the instructions */
+__device__ __forceinline__ float atan2_fast(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y), mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float a = mx > 0.0f ? mn * fast_rcp(mx) : 0.0f, s = a * a;
+  float p = -0.0040543945506215096f;
+  p = fmaf(p, s, 0.021862290799617767f); p = fmaf(p, s, -0.055911291390657425f); p = fmaf(p, s, 0.09642115235328674f);
+  p = fmaf(p, s, -0.13908594846725464f); p = fmaf(p, s, 0.1994655728340149f); p = fmaf(p, s, -0.33329859375953674f);
+  p = fmaf(p, s, 0.9999993443489075f);
+  float r = p * a;
+  if (ay > ax) r = 1.57079632679489662f - r;
+  if (x < 0.0f) r = 3.14159265358979324f - r;
+  return y < 0.0f ? -r : r;
+}
+
 /* sin and cos of a moderate angle (joint half-angles, integration increments, yaw: |x| well below 1e3 rad): two-term
  * Cody-Waite reduction to [-pi/4, pi/4] and the classic single-precision minimax kernels, ~30 VALU for both values
  * and 1-2 ulp - the libm routines carry a large-argument reduction that is never needed here */
