@@ -39,3 +39,6 @@ for robot in sys.argv[1:] or ['mini_cheetah']:
     nit, nefc, ex = field('niter')[:, 0], field('nefc')[:, 0], field('timer')[:, 23]
     print(f'{robot}: niter histogram {np.bincount(np.minimum(nit.astype(int), 30)).tolist()} max {nit.max():.0f}; nefc mean {nefc.mean():.1f} max {nefc.max():.0f}')
     print(f'   exit codes {np.bincount(ex.astype(int), minlength=7).tolist()}')
+    for k in range(1, int(nit.max()) + 1):
+        sel = nit.astype(int) == k
+        if sel.sum(): print(f'   niter {k}: {int(sel.sum()):5d} envs, exit codes {np.bincount(ex[sel].astype(int), minlength=7).tolist()}')
