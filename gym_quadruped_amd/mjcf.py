@@ -177,7 +177,7 @@ class ModelDesc:
     gravity: np.ndarray
     cone: int  # 0 pyramidal, 1 elliptic
     impratio: float
-    integrator: int  # 0 Euler, 3 implicitfast (treated as Euler+implicit damping; documented deviation)
+    integrator: int  # 0 Euler, 3 implicitfast (run as Euler + implicit damping: the same update for torque motors + joint damping)
     # sizes
     nq: int
     nv: int
