@@ -393,6 +393,10 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
 
 /* Newton iterations.  In: row data in registers, smooth (= qfrc_smooth) / warm / Mc / Mb in LDS, J rows in W.u.B.
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
+/* relative tolerance of the line search on phi' (MuJoCo: opt.ls_tolerance = 0.01) */
+#ifndef GQ_LS_TOL
+#define GQ_LS_TOL 1e-2f
+#endif
 template <bool DBG, bool CONE>
 __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, int rtype, float rR, float raref,
                                      float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg, const EllRow E, int prio) {
@@ -643,7 +647,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       if constexpr (CONE) if (E.code) ell_dd(E, alpha, y, v, rD, TT, y0, UV, VV, N1, d1, d2);
       const float ga = q1 + 2.0f * q2 * alpha + wave_sum(d1);
       const float ha = 2.0f * q2 + wave_sum(d2);
-      if (fabsf(ga) <= 1e-3f * fabsf(g0)) { first_try = ls == 0; break; } /* MuJoCo's line search is approximate too (ls_tolerance 0.01) */
+      if (fabsf(ga) <= GQ_LS_TOL * fabsf(g0)) { first_try = ls == 0; break; } /* an approximate line search, like MuJoCo's */
       if (ga < 0.0f) lo = alpha; else hi = alpha;
       float an = alpha - ga / ha;
       if (!(an > lo) || (hi > 0.0f && !(an < hi))) an = hi > 0.0f ? 0.5f * (lo + hi) : 2.0f * alpha;
