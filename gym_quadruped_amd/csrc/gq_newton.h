@@ -393,6 +393,9 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
 
 /* Newton iterations.  In: row data in registers, smooth (= qfrc_smooth) / warm / Mc / Mb in LDS, J rows in W.u.B.
  * Out: W.qacc (solution), W.qfrc_c (= M (qacc - qacc_smooth) = J' f), returns the row's force; niter by reference. */
+#ifndef GQ_HCHUNK
+#define GQ_HCHUNK 4
+#endif
 /* relative tolerance of the line search on phi' (MuJoCo: opt.ls_tolerance = 0.01) */
 #ifndef GQ_LS_TOL
 #define GQ_LS_TOL 1e-2f
@@ -589,13 +592,15 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
           }
           if (r < nrowh) s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
         } else
-        for (int r = nsingle; r < nrowh; r += 4) { /* chunks of four rows: twelve LDS reads in flight per chunk */
-          const int r1 = r + 1 < 64 ? r + 1 : 63, r2 = r + 2 < 64 ? r + 2 : 63, r3 = r + 3 < 64 ? r + 3 : 63;
-          const float w0 = W.force[r], w1 = r + 1 < nrowh ? W.force[r1] : 0.0f, w2 = r + 2 < nrowh ? W.force[r2] : 0.0f,
-                      w3 = r + 3 < nrowh ? W.force[r3] : 0.0f;
-          const float a0 = W.u.B[r][da], a1 = W.u.B[r1][da], a2 = W.u.B[r2][da], a3 = W.u.B[r3][da];
-          const float c0 = W.u.B[r][db], c1 = W.u.B[r1][db], c2 = W.u.B[r2][db], c3 = W.u.B[r3][db];
-          s0 += w0 * a0 * c0; s1 += w1 * a1 * c1; s2 += w2 * a2 * c2; s3 += w3 * a3 * c3;
+        for (int r = nsingle; r < nrowh; r += GQ_HCHUNK) { /* chunks of rows: three LDS reads per row in flight together */
+          float w[GQ_HCHUNK], av[GQ_HCHUNK], cv[GQ_HCHUNK];
+#pragma unroll
+          for (int u = 0; u < GQ_HCHUNK; u++) {
+            const int ru = r + u < 64 ? r + u : 63;
+            w[u] = r + u < nrowh ? W.force[ru] : 0.0f; av[u] = W.u.B[ru][da]; cv[u] = W.u.B[ru][db];
+          }
+#pragma unroll
+          for (int u = 0; u < GQ_HCHUNK; u += 4) { s0 += w[u] * av[u] * cv[u]; s1 += w[u + 1] * av[u + 1] * cv[u + 1]; s2 += w[u + 2] * av[u + 2] * cv[u + 2]; s3 += w[u + 3] * av[u + 3] * cv[u + 3]; }
         }
         const float hv = (s0 + s1) + (s2 + s3);
         if (slot < 108) W.u2.n.Hc[slot / 9][slot % 9] = hv;
