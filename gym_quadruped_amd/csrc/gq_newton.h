@@ -631,8 +631,9 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     if constexpr (!CONE) full_step = ballot(row_piece(rtype, y, rR, rfloss) != row_piece(rtype, y + v, rR, rfloss)) == 0;
     if (full_step) { alpha = 1.0f; first_try = true; }
     else {
-    const float q1 = wave_sum(lane < GQ_NVD ? search[lane] * md : 0.0f);
-    const float q2 = wave_sum(lane < GQ_NVD ? 0.5f * search[lane] * ms : 0.0f);
+    /* phi'(alpha) = sum over lanes of (s.Mdq + alpha s.Ms) [dof lanes] + d1(alpha) [row lanes]: the quadratic part rides
+     * in the same reduction as the rows' derivatives */
+    const float p1 = lane < GQ_NVD ? search[lane] * md : 0.0f, p2 = lane < GQ_NVD ? search[lane] * ms : 0.0f;
     float d1, d2;
     row_dd(rtype, y, v, rR, rD, rfloss, d1, d2);
     /* elliptic contacts: along the line T(alpha)^2 = TT + 2 alpha UV + alpha^2 VV and N(alpha) = N + alpha N1, so three
@@ -643,15 +644,15 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       UV = ell_seg_sum(E, u * V); VV = ell_seg_sum(E, V * V); N1 = E.mu * shfl_idx(v, E.r0);
       if (E.code) ell_dd(E, 0.0f, y, v, rD, TT, y0, UV, VV, N1, d1, d2);
     }
-    g0 = q1 + wave_sum(d1);
-    float h0 = 2.0f * q2 + wave_sum(d2);
+    g0 = wave_sum(p1 + d1);
+    float h0 = wave_sum(p2 + d2);
     if (!(g0 < 0.0f)) { exit_code = 5; break; } /* not a descent direction: converged to working precision */
     alpha = -g0 / h0;
     for (int ls = 0; ls < 10; ls++) {
       row_dd(rtype, y + alpha * v, v, rR, rD, rfloss, d1, d2);
       if constexpr (CONE) if (E.code) ell_dd(E, alpha, y, v, rD, TT, y0, UV, VV, N1, d1, d2);
-      const float ga = q1 + 2.0f * q2 * alpha + wave_sum(d1);
-      const float ha = 2.0f * q2 + wave_sum(d2);
+      const float ga = wave_sum(p1 + alpha * p2 + d1);
+      const float ha = wave_sum(p2 + d2);
       if (fabsf(ga) <= GQ_LS_TOL * fabsf(g0)) { first_try = ls == 0; break; } /* an approximate line search, like MuJoCo's */
       if (ga < 0.0f) lo = alpha; else hi = alpha;
       float an = alpha - ga / ha;
