@@ -194,3 +194,21 @@ def test_procedural_box_scenes_match_the_reference_generator():
     assert not scene['boxes']
     with pytest.raises(ValueError):
         generate_terrain('moon', 0.3)
+
+
+def test_dataset_hparams_encoding_follows_the_reference_conventions():
+    """utils/data.py: env_hparams are stored the way the reference's save_dict_to_h5 does (h5py.py:22-48): lists / tuples
+    as JSON, class references as 'TYPE:module.Class', None dropped by the HDF5 writer, nested dicts as groups."""
+    import json
+    from gym_quadruped_amd.sensors import IMU
+    from gym_quadruped_amd.utils.data import _hparams_to_jsonable
+    hp = dict(robot='aliengo', scene='flat', sim_dt=0.002, ref_base_lin_vel=(0.5, 1.0), legs_order=('FL', 'FR', 'RL', 'RR'),
+              sensors=(IMU,), sensors_kwargs=({'accel_noise': 0.01},), external_disturbances_kwargs=None,
+              state_obs_names=('qpos', 'qvel'), nested={'a': np.arange(3), 'b': np.float32(1.5)})
+    enc = _hparams_to_jsonable(hp)
+    assert enc['sensors'] == ['TYPE:gym_quadruped_amd.sensors.imu.IMU'] or enc['sensors'][0].startswith('TYPE:gym_quadruped_amd.sensors')
+    assert enc['ref_base_lin_vel'] == [0.5, 1.0] and enc['external_disturbances_kwargs'] is None
+    assert enc['nested'] == {'a': [0, 1, 2], 'b': 1.5} and enc['sensors_kwargs'] == [{'accel_noise': 0.01}]
+    json.dumps(enc)   # everything is JSON-serialisable
+    with pytest.raises(TypeError):
+        _hparams_to_jsonable({'bad': object()})
