@@ -341,6 +341,11 @@ int gq_build_dev_batch(int n_envs, const int32_t* obs_ids, int n_obs, const int3
     }
   }
   out->obs_dim = k;
+  out->obs_need = 0;
+  for (int i = 0; i < k; i++) {
+    const int c = out->obs_map[i];
+    out->obs_need |= c < 52 ? GQ_NEED_BASE : ((c >= 125 && c < 127) ? GQ_NEED_ENERGY : ((c >= 127 && c < 199) ? GQ_NEED_FEET : ((c >= 199 && c < 227) ? GQ_NEED_CONTACT : 0)));
+  }
   return 0;
 }
 

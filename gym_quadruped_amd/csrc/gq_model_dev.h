@@ -93,10 +93,15 @@ struct GqDevModel {
   float key_qpos[19];            /* keyframe 0 */
 };
 
+#define GQ_NEED_BASE 1    /* base pose / velocity / frame observables (canonical scalars 0..51) */
+#define GQ_NEED_ENERGY 2  /* kinetic_energy, work */
+#define GQ_NEED_FEET 4    /* feet_pos*, feet_vel* */
+#define GQ_NEED_CONTACT 8 /* contact_state, contact_forces* */
 struct GqDevBatch {            /* per-batch constants */
   int32_t n_envs, obs_dim;
   int32_t obs_map[256];        /* output column -> canonical ALL_OBS scalar index */
   int32_t debug_envs;          /* number of leading envs whose internals are dumped */
+  int32_t obs_need;            /* groups of canonical observables that obs_map refers to: GQ_NEED_* (the others are not computed) */
   /* IMU (0 = disabled) */
   int32_t imu_enabled;
   float imu_pos[3], imu_mat[9];

@@ -744,7 +744,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
 
   GQ_TICK(10);
   /* the output layout (column -> canonical scalar) of this lane's columns: fetched now, used by the gather at the end */
-  const int od = mptr(a.batch)->obs_dim;
+  const int od = mptr(a.batch)->obs_dim, obs_need = mptr(a.batch)->obs_need;
   int omap[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) { const int k = lane + GQ_WAVE * i; omap[i] = k < od ? mptr(a.batch)->obs_map[k] : 0; }
@@ -823,6 +823,14 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   /* ================================================================ S11: observations (new qpos/qvel, old kinematics) */
   float Rn[9];
   q2mat(Rn, qn);
+  V3 vlin = v3(W.qvel[0], W.qvel[1], W.qvel[2]), wloc = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
+  float* ob = W.u.obs;
+  /* observables nobody asked for are not computed (obs_need: groups of canonical scalars the output layout refers to) */
+  if (lane == 0) {
+    ob[OB_QPOS] = (float)bxn_d; ob[OB_QPOS + 1] = (float)byn_d; ob[OB_QPOS + 2] = znew;
+    ob[OB_QPOS + 3] = qn.w; ob[OB_QPOS + 4] = qn.x; ob[OB_QPOS + 5] = qn.y; ob[OB_QPOS + 6] = qn.z;
+  }
+  if (obs_need & GQ_NEED_BASE) {
   /* scipy as_euler('xyz') of the new orientation */
   float sy = fminf(fmaxf(-Rn[6], -1.0f), 1.0f);
   float e0, e1 = asinf(sy), e2, cyaw, syaw;
@@ -835,18 +843,14 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   V3 cmdl = v3(W.cmd[0], W.cmd[1], W.cmd[2]);
   V3 tl = v3(cyaw * cmdl.x - syaw * cmdl.y, syaw * cmdl.x + cyaw * cmdl.y, cmdl.z);
   V3 ta = v3(0.0f, 0.0f, W.cmd[3]);
-  V3 vlin = v3(W.qvel[0], W.qvel[1], W.qvel[2]), wloc = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
   V3 acc3 = v3(W.qacc[0], W.qacc[1], W.qacc[2]);
-  float* ob = W.u.obs;
   if (lane == 0) {
     ob[OB_BASE_POS] = (float)bxn_d; ob[OB_BASE_POS + 1] = (float)byn_d; ob[OB_BASE_POS + 2] = znew;
-    ob[OB_QPOS] = (float)bxn_d; ob[OB_QPOS + 1] = (float)byn_d; ob[OB_QPOS + 2] = znew;
     st3(ob + OB_LIN_VEL, vlin); st3(ob + OB_LIN_VEL_ERR, tl - vlin); st3(ob + OB_LIN_ACC, acc3);
     V3 ww = matvec(Rn, wloc);
     st3(ob + OB_ANG_VEL, ww); st3(ob + OB_ANG_VEL_ERR, ta - ww);
     ob[OB_EULER] = e0; ob[OB_EULER + 1] = e1; ob[OB_EULER + 2] = e2;
     ob[OB_QUAT] = qn.w; ob[OB_QUAT + 1] = qn.x; ob[OB_QUAT + 2] = qn.y; ob[OB_QUAT + 3] = qn.z;
-    ob[OB_QPOS + 3] = qn.w; ob[OB_QPOS + 4] = qn.x; ob[OB_QPOS + 5] = qn.y; ob[OB_QPOS + 6] = qn.z;
 #pragma unroll
     for (int k = 0; k < 9; k++) ob[OB_SO3 + k] = Rn[k];
     st3(ob + OB_GRAV_B, matTvec(Rn, v3(0.0f, 0.0f, -1.0f)));
@@ -854,19 +858,22 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     st3(ob + OB_LIN_VEL_B, vb); st3(ob + OB_LIN_VEL_ERR_B, matTvec(Rn, tl) - vb); st3(ob + OB_LIN_ACC_B, matTvec(Rn, acc3));
     st3(ob + OB_ANG_VEL_B, wloc); st3(ob + OB_ANG_VEL_ERR_B, matTvec(Rn, ta) - wloc);
   }
+  }
   if (lane < GQ_NVD) ob[OB_QVEL + lane] = W.qvel[lane];
   if (lane < 12) { ob[OB_TAU + lane] = W.ctrl[lane]; ob[OB_QVEL_JS + lane] = W.qvel[6 + lane]; }
   if (lane >= 7 && lane < 19) { ob[OB_QPOS + lane] = qjn; ob[OB_QPOS_JS + lane - 7] = qjn; }
   /* kinetic energy 1/2 v'Mv and work (M qacc).v with the OLD mass matrix, NEW velocity, qacc of this step */
-  float ke_part = 0.0f, wk_part = 0.0f;
-  if (lane < GQ_NVD) {
-    const float mv = mul_m_row(W, W.qvel, lane), ma = mul_m_row(W, W.qacc, lane);
-    ke_part = 0.5f * W.qvel[lane] * mv; wk_part = ma * W.qvel[lane];
+  if (obs_need & GQ_NEED_ENERGY) {
+    float ke_part = 0.0f, wk_part = 0.0f;
+    if (lane < GQ_NVD) {
+      const float mv = mul_m_row(W, W.qvel, lane), ma = mul_m_row(W, W.qacc, lane);
+      ke_part = 0.5f * W.qvel[lane] * mv; wk_part = ma * W.qvel[lane];
+    }
+    float ke = wave_sum(ke_part), wk = wave_sum(wk_part);
+    if (lane == 0) { ob[OB_KE] = ke; ob[OB_WORK] = wk; }
   }
-  float ke = wave_sum(ke_part), wk = wave_sum(wk_part);
-  if (lane == 0) { ob[OB_KE] = ke; ob[OB_WORK] = wk; }
   /* feet: lane k < 4 = foot k in FL FR RL RR order */
-  if (lane < 4) {
+  if ((obs_need & (GQ_NEED_FEET | GQ_NEED_CONTACT)) && lane < 4) {
     const int leg = m.foot_leg[lane], body = 3 + 3 * leg;
     V3 pw = ld3(W.foot_world[lane]); /* relative to the OLD base x/y */
     /* spatial velocity of the calf with old cdof and new qvel (J_old * qvel_new) */
@@ -886,7 +893,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
      * and calf link geom alike) sets the state and adds its force */
     V3 cf = v3(0.0f, 0.0f, 0.0f);
     float cs = 0.0f;
-    for (int c = 0; c < ncon; c++) {
+    for (int c = 0; c < ((obs_need & GQ_NEED_CONTACT) ? ncon : 0); c++) {
       if (W.con_body[c] != body) continue;
       cs = 1.0f;
       const int r0 = W.con_row[c];
