@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-from .cabi import GqImuCfg, GqModelDesc, GqObsOut, GqResetCfg, GqState
+from .cabi import GqImuCfg, GqModelDesc, GqObsOut, GqResampleCfg, GqResetCfg, GqState
 
 _LIB = None
 import os
@@ -14,7 +14,7 @@ import os
 LIB_PATH = Path(os.environ.get('GQ_LIBGQ_PATH', Path(__file__).parent / 'libgq.so'))
 
 EXPORTS = ['gq_last_error', 'gq_version', 'gq_obs_dim', 'gq_model_create', 'gq_model_destroy', 'gq_batch_create',
-           'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_batch_set_imu', 'gq_batch_set_pending', 'gq_heightmap', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get', 'gq_debug_device_buffer', 'gq_debug_field', 'gq_debug_stop_stage']
+           'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_batch_set_imu', 'gq_batch_set_pending', 'gq_batch_set_resampling', 'gq_heightmap', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get', 'gq_debug_device_buffer', 'gq_debug_field', 'gq_debug_stop_stage']
 
 
 class GqError(RuntimeError):
@@ -37,6 +37,7 @@ def lib():
     L.gq_batch_destroy.argtypes = [C.c_void_p]
     L.gq_batch_obs_dim.argtypes = [C.c_void_p]
     L.gq_batch_set_imu.argtypes = [C.c_void_p, C.POINTER(GqImuCfg), C.c_void_p]
+    L.gq_batch_set_resampling.argtypes = [C.c_void_p, C.POINTER(GqResampleCfg), C.POINTER(GqResetCfg), C.c_void_p, C.c_void_p]
     L.gq_batch_set_pending.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.gq_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, GqState, GqObsOut, C.POINTER(GqResetCfg), C.c_void_p,
                           C.c_void_p, C.c_void_p]

@@ -104,8 +104,10 @@ class AccessorsMixin:
     def feet_contact_state(self, frame='world', ground_reaction_forces=False):
         """(contact_state, ground reaction forces) per leg.  The reference also returns the per-foot lists of MjContact
         objects (:836-855); a batch has no such objects - per-contact detail is in the inspection record."""
-        cs = self._per_leg(self._acc('contact_state'), 1)
-        cs = LegsAttr(**{leg: cs[leg][:, 0] > 0.5 for leg in self.legs_order})
+        # 'contact_state' is ALWAYS in FL, FR, RL, RR order, whatever legs_order says (the reference builds it with
+        # to_list() without `order=`, quadruped_env.py:1194-1195, quirk B5); the forces below follow legs_order
+        cs_row = self._acc('contact_state')
+        cs = LegsAttr(**{leg: cs_row[:, k] > 0.5 for k, leg in enumerate(LEGS)})
         if not ground_reaction_forces:
             return cs, None
         return cs, None, self._per_leg(self._acc('contact_forces' + self._frame(frame)), 3)

@@ -72,7 +72,12 @@ class GqImuCfg(C.Structure):
 
 class GqObsOut(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('terminated', C.c_void_p), ('truncated', C.c_void_p),
-                ('invalid_contact', C.c_void_p), ('step_num', C.c_void_p)]
+                ('invalid_contact', C.c_void_p), ('step_num', C.c_void_p), ('step_num_prev', C.c_void_p)]
+
+
+class GqResampleCfg(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('cmd_reset', C.c_int32), ('dist_reset', C.c_int32), ('dist_kind', C.c_int32 * 6),
+                ('dist_range', (C.c_float * 2) * 6), ('env_id_offset', C.c_int32)]
 
 
 # index into QuadrupedEnv.ALL_OBS (reference quadruped_env.py:35-66,81) == enum GqObsId

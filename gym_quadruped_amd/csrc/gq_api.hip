@@ -56,6 +56,8 @@ struct GqBatch {
   int staging_next;
   bool shadow_valid;
   float* imu_bias;      /* caller-owned device [N][6], set by gq_batch_set_imu */
+  int32_t* h9;          /* caller-owned device [N][6] resampling counters, set by gq_batch_set_resampling */
+  float* ext_dist;      /* caller-owned device [N][6] */
   int debug_cap;
 };
 
@@ -72,40 +74,50 @@ extern "C" {
 const char* gq_last_error(void) { return g_err; }
 int gq_version(void) { return 100; }
 int gq_obs_dim(int obs_id) { return gq_obs_dim_host(obs_id); }
+int gq_model_destroy(GqModel* m);
+int gq_batch_destroy(GqBatch* b);
+
+/* HIP call inside a constructor: on failure the partially built handle is destroyed (frees whatever was allocated) */
+#define HIP_TRY_OR_DESTROY(expr, destroy_call)                                          \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) { SET_ERR("%s: %s", #expr, hipGetErrorString(e_)); destroy_call; return GQ_EDEVICE; } \
+  } while (0)
 
 int gq_model_create(const GqModelDesc* desc, int device, GqModel** out) {
   if (!desc || !out) { SET_ERR("gq_model_create: null argument"); return GQ_EINVAL; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { SET_ERR("no HIP device visible"); return GQ_ENODEVICE; }
   if (device < 0 || device >= ndev) { SET_ERR("device %d out of range (have %d)", device, ndev); return GQ_EINVAL; }
-  GqModel* m = new (std::nothrow) GqModel();
+  GqModel* m = new (std::nothrow) GqModel();   /* value-initialised: every pointer starts NULL */
   if (!m) return GQ_ENOMEM;
   std::vector<float> vx, vy, vz;
   if (gq_build_dev_model(desc, &m->host, &vx, &vy, &vz, g_err, sizeof g_err)) { delete m; return GQ_EINVAL; }
   m->device = device; m->nvert = (int)vx.size();
-  HIP_TRY(hipSetDevice(device));
-  m->hf = nullptr;
+  DeviceGuard guard(device);
   if (m->host.hf_nrow > 0) {
     std::vector<float> hf;
     gq_hfield_heights(desc, &hf);
-    HIP_TRY(hipMalloc(&m->hf, hf.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(m->hf, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY_OR_DESTROY(hipMalloc(&m->hf, hf.size() * sizeof(float)), gq_model_destroy(m));
+    HIP_TRY_OR_DESTROY(hipMemcpy(m->hf, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice), gq_model_destroy(m));
     m->host.hf_data = m->hf;
   }
-  HIP_TRY(hipMalloc(&m->dev, sizeof(GqDevModel)));
-  HIP_TRY(hipMemcpy(m->dev, &m->host, sizeof(GqDevModel), hipMemcpyHostToDevice));
+  HIP_TRY_OR_DESTROY(hipMalloc(&m->dev, sizeof(GqDevModel)), gq_model_destroy(m));
+  HIP_TRY_OR_DESTROY(hipMemcpy(m->dev, &m->host, sizeof(GqDevModel), hipMemcpyHostToDevice), gq_model_destroy(m));
   size_t vb = vx.size() * sizeof(float);
-  HIP_TRY(hipMalloc(&m->vx, vb)); HIP_TRY(hipMalloc(&m->vy, vb)); HIP_TRY(hipMalloc(&m->vz, vb));
-  HIP_TRY(hipMemcpy(m->vx, vx.data(), vb, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(m->vy, vy.data(), vb, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(m->vz, vz.data(), vb, hipMemcpyHostToDevice));
+  HIP_TRY_OR_DESTROY(hipMalloc(&m->vx, vb), gq_model_destroy(m));
+  HIP_TRY_OR_DESTROY(hipMalloc(&m->vy, vb), gq_model_destroy(m));
+  HIP_TRY_OR_DESTROY(hipMalloc(&m->vz, vb), gq_model_destroy(m));
+  HIP_TRY_OR_DESTROY(hipMemcpy(m->vx, vx.data(), vb, hipMemcpyHostToDevice), gq_model_destroy(m));
+  HIP_TRY_OR_DESTROY(hipMemcpy(m->vy, vy.data(), vb, hipMemcpyHostToDevice), gq_model_destroy(m));
+  HIP_TRY_OR_DESTROY(hipMemcpy(m->vz, vz.data(), vb, hipMemcpyHostToDevice), gq_model_destroy(m));
   *out = m;
   return GQ_OK;
 }
 
 int gq_model_destroy(GqModel* m) {
   if (!m) return GQ_OK;
-  hipSetDevice(m->device);
+  DeviceGuard guard(m->device);
   hipFree(m->dev); hipFree(m->vx); hipFree(m->vy); hipFree(m->vz); hipFree(m->hf);
   delete m;
   return GQ_OK;
@@ -113,22 +125,22 @@ int gq_model_destroy(GqModel* m) {
 
 int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, const int32_t* legs_order, GqBatch** out) {
   if (!m || !out || n_envs <= 0) { SET_ERR("gq_batch_create: bad argument"); return GQ_EINVAL; }
-  GqBatch* b = new (std::nothrow) GqBatch();
+  GqBatch* b = new (std::nothrow) GqBatch();   /* value-initialised: every pointer starts NULL */
   if (!b) return GQ_ENOMEM;
-  b->model = m; b->debug = nullptr; b->debug_cap = 0; b->imu_bias = nullptr;
+  b->model = m;
   if (gq_build_dev_batch(n_envs, obs_ids, n_obs, legs_order, &b->host, g_err, sizeof g_err)) { delete b; return GQ_EINVAL; }
-  HIP_TRY(hipSetDevice(m->device));
-  HIP_TRY(hipMalloc(&b->dev, sizeof(GqDevBatch)));
-  HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&b->friction_next, sizeof(float) * (size_t)n_envs));
-  HIP_TRY(hipMemset(b->friction_next, 0, sizeof(float) * (size_t)n_envs));
-  HIP_TRY(hipMalloc(&b->pending, (size_t)n_envs));
-  HIP_TRY(hipMemset(b->pending, 0, (size_t)n_envs));
-  HIP_TRY(hipMalloc(&b->load_hint, (size_t)n_envs));
-  HIP_TRY(hipMemset(b->load_hint, 0, (size_t)n_envs));
+  DeviceGuard guard(m->device);
+  HIP_TRY_OR_DESTROY(hipMalloc(&b->dev, sizeof(GqDevBatch)), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipMalloc(&b->friction_next, sizeof(float) * (size_t)n_envs), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipMemset(b->friction_next, 0, sizeof(float) * (size_t)n_envs), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipMalloc(&b->pending, (size_t)n_envs), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipMemset(b->pending, 0, (size_t)n_envs), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipMalloc(&b->load_hint, (size_t)n_envs), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipMemset(b->load_hint, 0, (size_t)n_envs), gq_batch_destroy(b));
   { const char* s = getenv("GQ_STOP_STAGE"); b->stop_stage = s ? atoi(s) : 0; }
-  HIP_TRY(hipMalloc(&b->dev_args, sizeof(gq::FusedArgs)));
-  HIP_TRY(hipHostMalloc(&b->staging, sizeof(gq::FusedArgs) * GQ_ARG_SLOTS, hipHostMallocDefault));
+  HIP_TRY_OR_DESTROY(hipMalloc(&b->dev_args, sizeof(gq::FusedArgs)), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipHostMalloc(&b->staging, sizeof(gq::FusedArgs) * GQ_ARG_SLOTS, hipHostMallocDefault), gq_batch_destroy(b));
   b->staging_next = 0; b->shadow_valid = false;
   std::memset(&b->shadow, 0, sizeof b->shadow);
   *out = b;
@@ -137,8 +149,9 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
 
 int gq_batch_destroy(GqBatch* b) {
   if (!b) return GQ_OK;
-  hipSetDevice(b->model->device);
-  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->load_hint); hipFree(b->dev_args); hipHostFree(b->staging);
+  DeviceGuard guard(b->model->device);
+  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->load_hint); hipFree(b->dev_args);
+  if (b->staging) hipHostFree(b->staging);
   if (b->debug) hipFree(b->debug);
   delete b;
   return GQ_OK;
@@ -150,7 +163,29 @@ int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state) {
   if (!b || !cfg || !bias_state) { SET_ERR("gq_batch_set_imu: null argument"); return GQ_EINVAL; }
   gq_fill_imu(&b->host, cfg);
   b->imu_bias = bias_state;
-  HIP_TRY(hipSetDevice(b->model->device));
+  DeviceGuard guard(b->model->device);
+  HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
+  return GQ_OK;
+}
+
+int gq_batch_set_resampling(GqBatch* b, const GqResampleCfg* cfg, const GqResetCfg* cmd_cfg, int32_t* counters, float* ext_dist) {
+  if (!b) { SET_ERR("gq_batch_set_resampling: null batch"); return GQ_EINVAL; }
+  GqDevBatch& h = b->host;
+  if (!cfg) { h.rs_cmd_reset = 0; h.rs_dist_reset = 0; b->h9 = nullptr; b->ext_dist = nullptr; }
+  else {
+    if (!counters || ((cfg->cmd_reset != 0) && !cmd_cfg) || ((cfg->dist_reset != 0) && !ext_dist)) {
+      SET_ERR("gq_batch_set_resampling: counters (and the command knobs / wrench tensor of the enabled parts) are required"); return GQ_EINVAL;
+    }
+    h.rs_cmd_reset = cfg->cmd_reset != 0; h.rs_dist_reset = cfg->dist_reset != 0; h.rs_env_id_offset = cfg->env_id_offset;
+    for (int k = 0; k < 6; k++) { h.rs_dist_kind[k] = cfg->dist_kind[k]; h.rs_dist_range[k][0] = cfg->dist_range[k][0]; h.rs_dist_range[k][1] = cfg->dist_range[k][1]; }
+    if (cmd_cfg) {
+      for (int k = 0; k < 2; k++) { h.rs_lin_vel_range[k] = cmd_cfg->lin_vel_range[k]; h.rs_ang_vel_range[k] = cmd_cfg->ang_vel_range[k]; }
+      h.rs_cmd_forward = cmd_cfg->cmd_forward; h.rs_cmd_random = cmd_cfg->cmd_random; h.rs_cmd_rotate = cmd_cfg->cmd_rotate;
+    }
+    h.rs_seed_lo = (uint32_t)(cfg->seed & 0xffffffffu); h.rs_seed_hi = (uint32_t)(cfg->seed >> 32);
+    b->h9 = counters; b->ext_dist = ext_dist;
+  }
+  DeviceGuard guard(b->model->device);
   HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
   return GQ_OK;
 }
@@ -158,7 +193,7 @@ int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state) {
 int gq_debug_enable(GqBatch* b, int n_debug_envs) {
   if (!b) return GQ_EINVAL;
   if (n_debug_envs > b->host.n_envs) n_debug_envs = b->host.n_envs;
-  HIP_TRY(hipSetDevice(b->model->device));
+  DeviceGuard guard(b->model->device);
   if (n_debug_envs > b->debug_cap) {
     if (b->debug) hipFree(b->debug);
     HIP_TRY(hipMalloc(&b->debug, (size_t)n_debug_envs * GQ_DBG_SIZE * sizeof(float)));
@@ -187,9 +222,10 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const
   a->applied = st.qfrc_applied; a->time = st.time; a->friction = st.friction; a->cmd = st.cmd;
   a->friction_next = b->friction_next; a->pending = b->pending; a->load_hint = b->load_hint;
   a->imu_bias = b->imu_bias;
+  a->h9 = b->h9; a->ext_dist = b->ext_dist;
   a->episode_ro = episode;
   a->obs = out.obs; a->reward = out.reward; a->terminated = out.terminated; a->truncated = out.truncated;
-  a->invalid_contact = out.invalid_contact; a->step_num = out.step_num;
+  a->invalid_contact = out.invalid_contact; a->step_num = out.step_num; a->step_prev = out.step_num_prev;
   a->n_envs = b->host.n_envs;
 }
 /* Make the device argument block describe (st, out, episode, lift_failed[, auto-reset cfg]).  Steady state: a memcmp.
@@ -218,12 +254,14 @@ static void fill_reset_args(gq::ResetArgs* a, GqBatch* b, const uint8_t* mask, c
   a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart; a->applied = st.qfrc_applied;
   a->time = st.time; a->cmd = st.cmd; a->friction_next = st.friction ? b->friction_next : nullptr;
   a->step_num = out.step_num; a->episode = episode; a->lift_failed = lift_failed;
+  a->h9 = b->h9;
   fill_reset_cfg(&a->cfg, cfg);
+  a->cfg.cmd_reset = b->host.rs_cmd_reset;
 }
 
 int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
             int32_t* episode, uint8_t* lift_failed, void* hip_stream) {
-  if (!b || !ctrl || !st.qpos || !st.qvel || !st.qacc || !st.qacc_warmstart || !st.time || !out.obs || !out.reward ||
+  if (!b || !st.qpos || !st.qvel || !st.qacc || !st.qacc_warmstart || !st.time || !out.obs || !out.reward ||
       !out.terminated || !out.truncated || !out.invalid_contact || !out.step_num) {
     SET_ERR("gq_step: null tensor"); return GQ_EINVAL;
   }
@@ -264,6 +302,7 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
 
 int gq_batch_set_pending(GqBatch* b, const uint8_t* flags, void* hip_stream) {
   if (!b) { SET_ERR("gq_batch_set_pending: null batch"); return GQ_EINVAL; }
+  DeviceGuard guard(b->model->device);
   if (flags) HIP_TRY(hipMemcpyAsync(b->pending, flags, (size_t)b->host.n_envs, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
   else HIP_TRY(hipMemsetAsync(b->pending, 0, (size_t)b->host.n_envs, (hipStream_t)hip_stream));
   return GQ_OK;
@@ -313,7 +352,7 @@ int gq_debug_get(GqBatch* b, int env, const char* name, double* out, int max_n) 
     if (!std::strcmp(f.name, name)) {
       int n = f.n < max_n ? f.n : max_n;
       std::vector<float> tmp((size_t)n);
-      HIP_TRY(hipSetDevice(b->model->device));
+      DeviceGuard guard(b->model->device);
       HIP_TRY(hipDeviceSynchronize());
       HIP_TRY(hipMemcpy(tmp.data(), b->debug + (size_t)env * GQ_DBG_SIZE + f.off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
       for (int i = 0; i < n; i++) out[i] = tmp[(size_t)i];

@@ -107,6 +107,13 @@ struct GqDevBatch {            /* per-batch constants */
   float imu_pos[3], imu_mat[9];
   float imu_acc_noise, imu_gyro_noise, imu_acc_bias_rate, imu_gyro_bias_rate;
   uint32_t imu_seed_lo, imu_seed_hi;
+  /* in-episode resampling of the velocity command / disturbance wrench (gq_batch_set_resampling; 0 = off) */
+  int32_t rs_cmd_reset, rs_dist_reset, rs_env_id_offset;
+  int32_t rs_dist_kind[6];
+  float rs_dist_range[6][2];
+  float rs_lin_vel_range[2], rs_ang_vel_range[2];
+  int32_t rs_cmd_forward, rs_cmd_random, rs_cmd_rotate;
+  uint32_t rs_seed_lo, rs_seed_hi;
 };
 
 /* debug dump record (floats) per env, see gq_debug_get */

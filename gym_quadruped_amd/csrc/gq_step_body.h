@@ -143,6 +143,55 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
   wave_barrier();
 }
 
+/* _sample_ref_vel (quadruped_env.py:1046-1072) and _sample_external_disturbances (:1074-1139) for the wave's env when their
+ * step countdowns run out (:292-305).  Counter-based draws: Philox block (b, n, global env id, 0xc0de | 0xd157), n = number
+ * of redraws so far; uniform = (word >> 8) 2^-24; np.random.randint(1000, 3000) = 1000 + floor(2000 u). */
+__device__ inline void resample_wave(const StepArgs& a, const int env) {
+  const int lane = lane_id();
+  const GQ_MODEL GqDevBatch& B = *mptr(a.batch);
+  GQ_GLOBAL int32_t* hc = gptr(a.h9) + (size_t)env * 6;
+  const uint32_t gid = (uint32_t)(env + B.rs_env_id_offset);
+  if (B.rs_cmd_reset) {
+    const int after = hc[0] + 1, before = hc[1]; /* wave-uniform */
+    if (after >= before) {
+      const int n = hc[2];
+      float u = 0.0f;
+      if (lane < 4) u = (float)(philox4x32(0u, (uint32_t)n, gid, 0xc0deu, B.rs_seed_lo, B.rs_seed_hi, lane) >> 8) * (1.0f / 16777216.0f);
+      const float u_norm = bcast(u, 0), u_head = bcast(u, 1), u_yaw = bcast(u, 2), u_int = bcast(u, 3);
+      if (lane == 0) {
+        float norm = 0.0f, heading = 0.0f, yaw_dot = 0.0f;
+        if (B.rs_cmd_forward) norm = B.rs_lin_vel_range[0] + (B.rs_lin_vel_range[1] - B.rs_lin_vel_range[0]) * u_norm;
+        else if (B.rs_cmd_random) {
+          norm = B.rs_lin_vel_range[0] + (B.rs_lin_vel_range[1] - B.rs_lin_vel_range[0]) * u_norm;
+          heading = (2.0f * u_head - 1.0f) * 3.14159265358979f;
+        }
+        if (B.rs_cmd_rotate) yaw_dot = B.rs_ang_vel_range[0] + (B.rs_ang_vel_range[1] - B.rs_ang_vel_range[0]) * u_yaw;
+        GQ_GLOBAL float* cmd = gptr(const_cast<float*>(a.cmd)) + (size_t)env * 4;
+        cmd[0] = norm * cosf(heading); cmd[1] = norm * sinf(heading); cmd[2] = 0.0f; cmd[3] = yaw_dot;
+        hc[0] = 0; hc[1] = 1000 + (int)(2000.0f * u_int); hc[2] = n + 1;
+      }
+    } else if (lane == 0) hc[0] = after;
+  }
+  if (B.rs_dist_reset && a.ext_dist) {
+    const int after = hc[3] + 1, before = hc[4];
+    GQ_GLOBAL float* ed = gptr(a.ext_dist) + (size_t)env * 6;
+    float val = lane < 6 ? ed[lane] : 0.0f;
+    if (after >= before) {
+      const int n = hc[5];
+      float u = 0.0f;
+      if (lane < 8) u = (float)(philox4x32((uint32_t)(lane >> 2), (uint32_t)n, gid, 0xd157u, B.rs_seed_lo, B.rs_seed_hi, lane & 3) >> 8) * (1.0f / 16777216.0f);
+      if (lane < 6) {
+        const int kind = B.rs_dist_kind[lane];
+        val = kind == 0 ? 0.0f : (kind == 1 ? B.rs_dist_range[lane][0] : B.rs_dist_range[lane][0] + (B.rs_dist_range[lane][1] - B.rs_dist_range[lane][0]) * u);
+        ed[lane] = val;
+      }
+      const float u_int = bcast(u, 6);
+      if (lane == 0) { hc[3] = 0; hc[4] = 1000 + (int)(2000.0f * u_int); hc[5] = n + 1; }
+    } else if (lane == 0) hc[3] = after;
+    if (lane < 6 && a.applied) gptr(const_cast<float*>(a.applied))[(size_t)env * 18 + lane] = val; /* :305 */
+  }
+}
+
 /* One mj_step + observation epilogue for this wave's env.  pass 0: the user's step.  pass 1: the reset's own step
  * (zero control, friction committed afterwards, termination flags of pass 0 are kept).  pass 2: the reset's own step of
  * a next-step auto-reset (as pass 1, flags cleared).  Returns `terminated`. */
@@ -202,6 +251,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     W.mu_env = a.friction ? gptr(a.friction)[env] : -1.0f;
     const int32_t sn = gptr(a.step_num)[env];
     W.step_old = sn; gptr(a.step_num)[env] = sn + 1;
+    if (a.step_prev) gptr(a.step_prev)[env] = sn;
     gptr(a.time)[env] = gptr(a.time)[env] + h;
   }
   wave_barrier();
@@ -972,6 +1022,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     for (int i = 0; i < 4; i++) { const int k = lane + GQ_WAVE * i; if (k < od) gptr(a.obs)[(size_t)env * od + k] = ob[omap[i]]; }
   }
   wave_barrier(); /* the obs row overlays u: finish reading it before a second pass reuses the region */
+  /* in-episode resampling (quadruped_env.py:292-305): the user's step only; a redraw acts from the next step on */
+  if (pass == 0 && a.h9) resample_wave(a, env);
   GQ_TICK(13);
   if constexpr (DBG) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 25] = (float)(wall_clock64() & 0xFFFFF);
 #undef GQ_TICK
@@ -991,6 +1043,7 @@ struct ResetCfgDev {
   float q_pos_amp, q_vel_amp, roll_sweep, pitch_sweep, hip_height;
   float lin_vel_range[2], ang_vel_range[2], friction_range[2];
   int32_t cmd_forward, cmd_random, cmd_rotate, cmd_human, env_id_offset;
+  int32_t cmd_reset;      /* 'reset' in base_vel_command_type: reset restarts the redraw interval (gq_batch_set_resampling) */
 };
 struct ResetArgs {
   const GqDevModel* model;
@@ -998,6 +1051,7 @@ struct ResetArgs {
   const uint8_t* mask; const double* qpos_new; const float* qvel_new;
   double* qpos; float* qvel; float* qacc; float* warm; float* applied; float* time; float* cmd; float* friction_next;
   int32_t* step_num; int32_t* episode;
+  int32_t* h9;            /* resampling counters (see StepArgs), may be NULL */
   uint8_t* lift_failed;
   uint8_t* clear_terminated; uint8_t* clear_truncated; uint8_t* clear_invalid; /* explicit reset(): flags zeroed; NULL inside a fused auto-reset */
   ResetCfgDev cfg;
@@ -1005,7 +1059,7 @@ struct ResetArgs {
 
 /* draw indices */
 enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH = 27, RN_VNORM = 28, RN_HEADING = 29,
-       RN_YAWDOT = 30, RN_FRICTION = 31 };
+       RN_YAWDOT = 30, RN_FRICTION = 31, RN_VEL_INTERVAL = 32 };
 
 #define GQ_LIFT_RULE_ITERS 4
 template <bool BOXES>
@@ -1016,9 +1070,9 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   const GQ_MODEL GqDevModel& m = *mptr(a.model);
   const ResetCfgDev& c = a.cfg;
   const int episode = a.episode ? gptr(a.episode)[env] : 0;
-  /* one uniform in [0,1) per lane < 32 */
+  /* one uniform in [0,1) per lane < 36 (draw table: RN_*) */
   float u = 0.0f;
-  if (lane < 32) {
+  if (lane < 36) {
     uint32_t x = philox4x32((uint32_t)(lane >> 2), (uint32_t)episode, (uint32_t)(env + c.env_id_offset), 0x5eedu, c.seed_lo, c.seed_hi, lane & 3);
     u = (float)(x >> 8) * (1.0f / 16777216.0f);
   }
@@ -1026,6 +1080,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   wave_barrier();
   /* draws needed after the kinematics pass (which reuses the union) */
   const float u_vnorm = W.u.obs[RN_VNORM], u_heading = W.u.obs[RN_HEADING], u_yawdot = W.u.obs[RN_YAWDOT], u_fric = W.u.obs[RN_FRICTION];
+  const float u_interval = W.u.obs[RN_VEL_INTERVAL];
   const bool explicit_state = a.qpos_new != nullptr;
   double q = 0.0;
   double spawn_x = (double)m.key_qpos[0], spawn_y = (double)m.key_qpos[1]; /* wave-uniform: base x/y of the lift loop (BOXES) */
@@ -1160,6 +1215,8 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
       if (c.cmd_rotate) yaw_dot = c.ang_vel_range[0] + (c.ang_vel_range[1] - c.ang_vel_range[0]) * u_yawdot;
       gptr(a.cmd)[(size_t)env * 4 + 0] = norm * cosf(heading); gptr(a.cmd)[(size_t)env * 4 + 1] = norm * sinf(heading);
       gptr(a.cmd)[(size_t)env * 4 + 2] = 0.0f; gptr(a.cmd)[(size_t)env * 4 + 3] = yaw_dot;
+      /* 'reset' command types restart their redraw interval (:1068-1070) */
+      if (a.h9 && c.cmd_reset) { gptr(a.h9)[(size_t)env * 6 + 0] = 0; gptr(a.h9)[(size_t)env * 6 + 1] = 1000 + (int)(2000.0f * u_interval); }
     }
     if (a.friction_next)
       gptr(a.friction_next)[env] = c.friction_range[0] + (c.friction_range[1] - c.friction_range[0]) * u_fric;

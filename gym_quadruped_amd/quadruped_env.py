@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from .accessors import AccessorsMixin
 from .cabi import ALL_OBS as _ALL_OBS
-from .cabi import LEG_NAMES, OBS_DIMS, GqObsOut, GqResetCfg, GqState, MarshalledModel, obs_ids_from_names
+from .cabi import LEG_NAMES, OBS_DIMS, GqObsOut, GqResampleCfg, GqResetCfg, GqState, MarshalledModel, obs_ids_from_names
 from .mjcf import ModelDesc, compile_mjcf, load_compiled
 from .robot_cfgs import RobotConfig, get_robot_config
 from .terrain import generate_terrain
@@ -39,26 +39,12 @@ GEN_COORDS_OBS = _ALL_OBS[15:22]
 FEET_OBS = _ALL_OBS[22:31]
 
 
-class _Info(dict):
+def _make_info(env):
     """``info`` dict of ``step``: 'time', 'step_num' (value before this step's increment, as the reference reports
-    it, quadruped_env.py:288-290) and 'invalid_contacts' (bool mask instead of a dict of MjContact objects)."""
-
-    def __init__(self, env):
-        super().__init__()
-        self._env = env
-        dict.__setitem__(self, 'time', env._time)
-        dict.__setitem__(self, 'invalid_contacts', env._invalid_b)
-
-    def __getitem__(self, k):
-        if k == 'step_num':
-            return self._env._step_num - 1
-        return dict.__getitem__(self, k)
-
-    def keys(self):
-        return ['time', 'step_num', 'invalid_contacts']
-
-    def __contains__(self, k):
-        return k in ('time', 'step_num', 'invalid_contacts')
+    it, quadruped_env.py:288-290) and 'invalid_contacts' (bool mask instead of a dict of MjContact objects).  A plain
+    dict of persistent tensors: 'step_num' is refreshed in place by every step / reset, so ``get``, ``items``, ``**info``
+    and copies all see it."""
+    return {'time': env._time, 'step_num': env._step_num_prev, 'invalid_contacts': env._invalid_b}
 
 
 class QuadrupedEnv(AccessorsMixin):
@@ -185,12 +171,14 @@ class QuadrupedEnv(AccessorsMixin):
         self._truncated_b = self._truncated.view(torch.bool)
         self._invalid_b = self._invalid.view(torch.bool)
         self._step_num = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._step_num_prev = torch.zeros(N, dtype=torch.int32, device=dev)   # info['step_num'], written by the kernel
         self._lift_failed = torch.zeros(N, dtype=torch.uint8, device=dev)
         self._mask_all = torch.ones(N, dtype=torch.uint8, device=dev)
-        self._steps_after_vel = torch.zeros(N, dtype=torch.int32, device=dev)
-        self._steps_before_vel = torch.full((N,), 1 << 30, dtype=torch.int32, device=dev)
-        self._steps_after_dist = torch.zeros(N, dtype=torch.int32, device=dev)
-        self._steps_before_dist = torch.full((N,), 1 << 30, dtype=torch.int32, device=dev)
+        # in-episode resampling state (reference :292-305), advanced by the step kernel's epilogue:
+        # columns {after_vel, before_vel, n_vel, after_dist, before_dist, n_dist} (gq_batch_set_resampling)
+        self._h9 = torch.zeros(N, 6, dtype=torch.int32, device=dev)
+        self._h9[:, 1] = 1 << 30
+        self._h9[:, 4] = 1 << 30
         self._ext_dist = torch.zeros(N, 6, **f32)
         self._has_cmd = False
         self._obs_views, self._extra_views, k = {}, {}, 0
@@ -215,8 +203,9 @@ class QuadrupedEnv(AccessorsMixin):
         self._st = GqState(self._qpos.data_ptr(), self._qvel.data_ptr(), self._qacc.data_ptr(), self._warm.data_ptr(),
                            self._applied.data_ptr(), self._time.data_ptr(), self._friction.data_ptr(), self._cmd.data_ptr())
         self._out = GqObsOut(self._obs_buf.data_ptr(), self._reward.data_ptr(), self._terminated.data_ptr(),
-                             self._truncated.data_ptr(), self._invalid.data_ptr(), self._step_num.data_ptr())
-        self._info = _Info(self)
+                             self._truncated.data_ptr(), self._invalid.data_ptr(), self._step_num.data_ptr(),
+                             self._step_num_prev.data_ptr())
+        self._info = _make_info(self)
         self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
         t = self.base_vel_command_type
         if not any(k in t for k in ('forward', 'random', 'human')):
@@ -237,7 +226,19 @@ class QuadrupedEnv(AccessorsMixin):
 
         self.external_disturbances_kwargs = external_disturbances_kwargs
         if self.external_disturbances_kwargs is not None:
-            self._sample_external_disturbances(self._mask_all.view(torch.bool))
+            self._sample_external_disturbances(self._mask_all.view(torch.bool))   # reference :240-242 (constructor draw)
+        dist_reset = external_disturbances_kwargs is not None and external_disturbances_kwargs.get('type') == 'reset'
+        if 'reset' in t or dist_reset:
+            rs = GqResampleCfg(seed=self._seed, cmd_reset=int('reset' in t), dist_reset=int(dist_reset), env_id_offset=int(env_id_offset))
+            for k, key in enumerate(('x', 'y', 'z', 'roll', 'pitch', 'yaw')):
+                r = (external_disturbances_kwargs or {}).get(key)
+                kind = 0 if (r is None or len(r) == 0) else min(len(r), 2)
+                rs.dist_kind[k] = kind
+                rs.dist_range[k][0] = float(r[0]) if kind >= 1 else 0.0
+                rs.dist_range[k][1] = float(r[1]) if kind == 2 else 0.0
+            self._resample_cfg = rs
+            _lib.check(L.gq_batch_set_resampling(self._hbatch, C.byref(rs), C.byref(self._reset_cfg), self._h9.data_ptr(),
+                                                 self._ext_dist.data_ptr()), 'gq_batch_set_resampling')
         self.viewer = None
         # sensors (reference :232-236): sensor_cls(mj_model=..., mj_data=..., **kwargs); mj_data is this env
         self.sensors = []
@@ -276,9 +277,6 @@ class QuadrupedEnv(AccessorsMixin):
             self._ctrl.copy_(a)
             self._last_action = self._ctrl
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        respawned = None
-        if self.auto_reset_mode == 'next_step' and 'reset' in self.base_vel_command_type:
-            respawned = self._terminated_b.clone()  # envs that terminated last step are reset by this one
         ev = self._profile_events
         if ev is not None:
             ev[0].record()
@@ -291,17 +289,7 @@ class QuadrupedEnv(AccessorsMixin):
         for sensor in self.sensors:  # reference :273-274 (kernel-side sensors: no-op)
             sensor.step()
 
-        if 'reset' in self.base_vel_command_type:  # reference :293-296
-            if self.auto_reset:  # envs re-spawned inside the kernel restart their command interval (reference :1068-1070)
-                self._steps_after_vel.masked_fill_(self._terminated_b if respawned is None else respawned, 0)
-            self._steps_after_vel += 1
-            due = self._steps_after_vel >= self._steps_before_vel
-            self._sample_ref_vel(due)
-        if self.external_disturbances_kwargs is not None and self.external_disturbances_kwargs['type'] == 'reset':
-            self._steps_after_dist += 1
-            due = self._steps_after_dist >= self._steps_before_dist
-            self._sample_external_disturbances(due)
-            self._applied[:, :6] = self._ext_dist  # acts from the NEXT step on (reference :305, quirk B9)
+        # command / disturbance resampling (reference :292-305) ran in the kernel's epilogue (gq_batch_set_resampling)
         return self._obs_views, self._reward, self._terminated_b, self._truncated_b, self._info
 
     def reset(self, qpos=None, qvel=None, seed: int | None = None, random: bool = True,
@@ -314,6 +302,11 @@ class QuadrupedEnv(AccessorsMixin):
             self._reset_cfg.seed = self._seed
             self._auto_cfg_struct.seed = self._seed
             self._episode.zero_()
+            if getattr(self, '_resample_cfg', None) is not None:
+                self._resample_cfg.seed = self._seed
+                self._h9[:, 2] = 0; self._h9[:, 5] = 0
+                _lib.check(self._L.gq_batch_set_resampling(self._hbatch, C.byref(self._resample_cfg), C.byref(self._reset_cfg),
+                                                           self._h9.data_ptr(), self._ext_dist.data_ptr()), 'gq_batch_set_resampling')
         N = self.num_envs
         if env_ids is None:
             mask = self._mask_all
@@ -346,11 +339,9 @@ class QuadrupedEnv(AccessorsMixin):
                                     self._episode.data_ptr(), self._lift_failed.data_ptr(), stream), 'gq_reset')
         self._launches += 1
         self._note_step()
-        if 'reset' in self.base_vel_command_type:
-            mb = mask.view(torch.bool)
-            nxt = torch.randint(1000, 3000, (self.num_envs,), generator=self._gen, device=self.device, dtype=torch.int32)
-            self._steps_before_vel = torch.where(mb, nxt, self._steps_before_vel)
-            self._steps_after_vel = torch.where(mb, torch.zeros_like(nxt), self._steps_after_vel)
+        if mask is self._mask_all:  # the reference zeroes mjData.ctrl in reset (:334): torque_ctrl_setpoint reads zero afterwards
+            self._ctrl.zero_()
+            self._last_action = self._ctrl
 
     # ------------------------------------------------------------------ command / disturbance sampling
     def _sample_ref_vel(self, mask):
@@ -378,8 +369,8 @@ class QuadrupedEnv(AccessorsMixin):
         self._cmd.copy_(torch.where(mask.unsqueeze(1), new, self._cmd))
         if 'reset' in t:
             nxt = torch.randint(1000, 3000, (N,), generator=g, device=dev, dtype=torch.int32)
-            self._steps_before_vel = torch.where(mask, nxt, self._steps_before_vel)
-            self._steps_after_vel = torch.where(mask, torch.zeros_like(nxt), self._steps_after_vel)
+            self._h9[:, 1] = torch.where(mask, nxt, self._h9[:, 1])
+            self._h9[:, 0] = torch.where(mask, torch.zeros_like(nxt), self._h9[:, 0])
         self._has_cmd = True
 
     def _sample_external_disturbances(self, mask):
@@ -396,10 +387,10 @@ class QuadrupedEnv(AccessorsMixin):
             else:
                 cols.append(float(r[0]) + (float(r[1]) - float(r[0])) * torch.rand(N, generator=g, device=dev))
         new = torch.stack(cols, 1)
-        self._ext_dist = torch.where(mask.unsqueeze(1), new, self._ext_dist)
+        self._ext_dist.copy_(torch.where(mask.unsqueeze(1), new, self._ext_dist))   # in place: the kernel holds the pointer
         nxt = torch.randint(1000, 3000, (N,), generator=g, device=dev, dtype=torch.int32)
-        self._steps_before_dist = torch.where(mask, nxt, self._steps_before_dist)
-        self._steps_after_dist = torch.where(mask, torch.zeros_like(nxt), self._steps_after_dist)
+        self._h9[:, 4] = torch.where(mask, nxt, self._h9[:, 4])
+        self._h9[:, 3] = torch.where(mask, torch.zeros_like(nxt), self._h9[:, 3])
 
     # ------------------------------------------------------------------ accessors (reference names)
     @property
@@ -450,17 +441,22 @@ class QuadrupedEnv(AccessorsMixin):
     def state_dict(self):
         """Checkpoint: everything needed to resume a rollout bit-for-bit."""
         keys = ['_qpos', '_qvel', '_qacc', '_warm', '_applied', '_time', '_friction', '_cmd', '_step_num', '_episode', '_terminated',
-                '_steps_after_vel', '_steps_before_vel', '_steps_after_dist', '_steps_before_dist', '_ext_dist']
+                '_h9', '_ext_dist', '_step_num_prev']
+        keys.append('_lift_failed')
         d = {k: getattr(self, k).clone() for k in keys}
         d['rng'] = self._gen.get_state()
+        # sensor state the kernel reads and writes every step: the IMU bias random walks
+        d['sensor_bias'] = [sn.bias_state.clone() if hasattr(sn, 'bias_state') else None for sn in self.sensors]
         return d
 
     def load_state_dict(self, d):
         for k, v in d.items():
             if k == 'rng':
                 self._gen.set_state(v)
-            elif k == '_ext_dist':
-                self._ext_dist = v.to(self.device).clone()
+            elif k == 'sensor_bias':
+                for sn, b in zip(self.sensors, v):
+                    if b is not None:
+                        sn.bias_state.copy_(b)  # in place: the kernel holds this tensor's pointer
             else:
                 getattr(self, k).copy_(v)
         if '_terminated' in d:  # next-step auto-reset: the envs that terminated last step are still waiting for their reset

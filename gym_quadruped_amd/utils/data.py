@@ -38,6 +38,8 @@ def _hparams_to_jsonable(d):
             out[k] = v
         elif isinstance(v, (np.integer, np.floating)):
             out[k] = v.item()
+        elif isinstance(v, torch.device):
+            out[k] = str(v)
         else:
             raise TypeError(f"Cannot save type {type(v)} for key '{k}'")
     return out
@@ -59,6 +61,7 @@ class RolloutRecorder:
         self.env = env
         self.horizon = int(horizon)
         self.t = 0
+        _hparams_to_jsonable(env.get_hyperparameters())  # fail now, not at export time after the rollout was recorded
         n, dev = env.num_envs, env.device
         self.shapes = {k: tuple(sp.shape) for k, sp in env.observation_space.spaces.items()}
         self.shapes['action'] = tuple(env.action_space.shape)

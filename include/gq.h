@@ -192,6 +192,7 @@ typedef struct GqObsOut {
   uint8_t* truncated;      /* [N]   always 0 (:286)                                                 */
   uint8_t* invalid_contact;/* [N]   info['invalid_contacts'] non-empty (:1228-1248)                 */
   int32_t* step_num;       /* [N]   in/out                                                          */
+  int32_t* step_num_prev;  /* [N]   out, may be NULL: the counter BEFORE this step's increment = info['step_num'] (:288-290) */
 } GqObsOut;
 
 /* observable ids = index into QuadrupedEnv.ALL_OBS (quadruped_env.py:35-66,81) */
@@ -256,8 +257,28 @@ typedef struct GqResetCfg {
   int32_t autoreset_next_step; /* only read by gq_step(auto_reset=...): 0 = same-step auto-reset, 1 = next-step (see gq_step) */
 } GqResetCfg;
 
+/* In-episode resampling of the velocity command and of the external disturbance wrench (QuadrupedEnv.step
+ * quadruped_env.py:292-305, _sample_ref_vel :1046-1072, _sample_external_disturbances :1074-1139), folded into the
+ * epilogue of gq_step for every env: `after += 1; if (after >= before) redraw` with `before ~ U{1000..2999}`.
+ * counters: device [N][6] int32, caller-owned, in/out: {after_vel, before_vel, n_vel, after_dist, before_dist, n_dist}
+ * (n_* = number of redraws so far: the RNG counter word).  ext_dist: device [N][6] f32 in/out, the current wrench
+ * (x y z roll pitch yaw); when dist_reset != 0 every user step ends with qfrc_applied[:6] = ext_dist, which therefore acts
+ * from the NEXT step on (:305).  The command redraw uses the knobs of the GqResetCfg passed here (ranges, cmd_* flags);
+ * gq_reset / the in-kernel auto-reset restart the command interval of the envs they reset (:1068-1070).
+ * Draws: Philox4x32-10, key = seed, counter = (draw / 4, n_*, global env id, 0xc0de) - see tests/philox_ref.py.
+ * dist_kind[k]: 0 absent (0.0), 1 constant dist_range[k][0], 2 uniform in dist_range[k].  cfg NULL switches it off. */
+typedef struct GqResampleCfg {
+  uint64_t seed;
+  int32_t cmd_reset;        /* 'reset' in base_vel_command_type (:293) */
+  int32_t dist_reset;       /* external_disturbances_kwargs['type'] == 'reset' (:299) */
+  int32_t dist_kind[6];
+  float dist_range[6][2];
+  int32_t env_id_offset;
+} GqResampleCfg;
+int gq_batch_set_resampling(GqBatch* b, const GqResampleCfg* cfg, const GqResetCfg* cmd_cfg, int32_t* counters, float* ext_dist);
+
 /* QuadrupedEnv.step body (quadruped_env.py:270-290): ctrl <- action; mj_step; _get_obs; reward; termination.
- * ctrl: device [N][nu] f32.  mask: device [N] u8 or NULL - envs with mask==0 are left untouched
+ * ctrl: device [N][nu] f32, or NULL for zero control.  mask: device [N] u8 or NULL - envs with mask==0 are left untouched
  * (used by reset(), which ends with one mj_step for the envs being reset, quadruped_env.py:397).
  * auto_reset != NULL: an env whose step terminates is re-spawned INSIDE the same launch (the batched stand-in for the
  * user's `if terminated: env.reset()` loop): reset state write + lift loop + the reset's own mj_step, exactly as

@@ -148,3 +148,54 @@ def default_reset_cfg(seed=0, random=1, hip_height=0.225, lin=(0.5, 0.5), ang=(0
                       ang_vel_range=(C.c_float * 2)(*ang), friction_range=(C.c_float * 2)(*fric),
                       cmd_forward=int('forward' in cmd), cmd_random=int('forward' not in cmd and 'random' in cmd),
                       cmd_rotate=int('rotate' in cmd), cmd_human=int('human' in cmd))
+
+
+GQ_MAXCON, GQ_MAXEFC = 12, 63   # csrc/gq_model_dev.h
+
+
+def oracle_fits_row_budget(o, cone):
+    """Does the oracle's (uncapped) constraint set fit the kernel's per-wave row budget?  The kernel keeps whole contacts in
+    MuJoCo's order while contacts <= 12, rows <= 63 and - elliptic cones - rows + the (dim - 1) virtual Hessian rows reserved
+    per cone contact <= 64 (csrc/gq_step_body.h S6, gq_boxes.h); a prefix rule, so everything fits iff the totals do."""
+    if o.ncon == 0:
+        return True
+    dims = o.get('contact_dim').astype(int)
+    reserve = int(sum(d - 1 for d in dims if d > 1)) if cone else 0
+    return o.ncon <= GQ_MAXCON and o.nefc <= GQ_MAXEFC and o.nefc + reserve <= (64 if cone else GQ_MAXEFC)
+
+
+class ParityTally:
+    """Why an env was (not) compared value-by-value.  `mismatch` - kernel and oracle disagree on the number of constraint
+    rows although the oracle's set fits the kernel's budget and no deepest-vertex tie explains it - is a FAILURE, never a
+    skip: that is what a contact-detection bug looks like."""
+
+    def __init__(self, cone, tie_threshold):
+        self.cone, self.tie_threshold = bool(cone), tie_threshold
+        self.n = self.checked = self.tie = self.budget = 0
+        self.mismatch = []
+
+    def classify(self, e, o, nefc_kernel):
+        self.n += 1
+        if o.ncon and o.get('contact_tiegap').min() < self.tie_threshold:
+            self.tie += 1          # two hull vertices of (numerically) equal depth: fp32 / fp64 may pick either
+            return 'tie'
+        if not oracle_fits_row_budget(o, self.cone):
+            self.budget += 1       # robot lying on the ground with more contacts than one wave's 63 rows
+            assert nefc_kernel <= GQ_MAXEFC and nefc_kernel < o.nefc, (e, nefc_kernel, o.nefc)
+            return 'budget'
+        if int(nefc_kernel) != o.nefc:
+            self.mismatch.append((e, int(nefc_kernel), o.nefc))
+            return 'mismatch'
+        self.checked += 1
+        return 'ok'
+
+    def report(self, what):
+        msg = (f'{what}: {self.n} envs, {self.checked} compared, {self.tie} deepest-vertex ties, {self.budget} over the row '
+               f'budget, {len(self.mismatch)} MISMATCHED {self.mismatch[:8]}')
+        print(msg)
+        return msg
+
+    def finish(self, what, min_checked, max_tie, max_budget):
+        msg = self.report(what)
+        assert not self.mismatch, msg
+        assert self.checked >= min_checked * self.n and self.tie <= max_tie * self.n and self.budget <= max_budget * self.n, msg

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box session (via gpurun): everything writes under gpurun_out/<tag>/.   Usage: tools/gpu_session.sh <tag> [parts...]
+# parts: probe tests perf bench profiles
+set -u
+TAG=${1:-r02x}; shift
+PARTS=${*:-"probe tests perf bench"}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+for p in $PARTS; do
+  case $p in
+    probe) timeout 300 python tools/mujoco_probe.py > $OUT/mujoco_probe.txt 2>&1; cp gpurun_out/mujoco_probe.log $OUT/ 2>/dev/null;;
+    tests) timeout 2400 python -m pytest tests -m gpu -q -x --timeout=900 -s 2>&1 | tail -150 > $OUT/pytest_gpu.txt;;
+    testsall) timeout 3000 python -m pytest tests -m gpu -q --timeout=900 -s 2>&1 | tail -250 > $OUT/pytest_gpu.txt;;
+    perf) timeout 600 python tools/perf_probe.py stages 256 > $OUT/stages256.txt 2>&1
+          timeout 600 python tools/perf_probe.py stages 4096 > $OUT/stages4096.txt 2>&1
+          timeout 600 python tools/stage_cuts.py 4096 > $OUT/stage_cuts4096.txt 2>&1
+          timeout 600 python tools/stage_cuts.py 256 > $OUT/stage_cuts256.txt 2>&1
+          timeout 600 python tools/wave_timeline.py 4096 > $OUT/wave_timeline.txt 2>&1;;
+    bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err;;
+    nscan) timeout 900 python tools/nscan.py > $OUT/nscan.txt 2>&1;;
+    profiles) timeout 2400 bash tools/run_profiles.sh $TAG > $OUT/run_profiles.txt 2>&1;;
+  esac
+done
+tail -5 $OUT/pytest_gpu.txt 2>/dev/null; cat $OUT/bench.json 2>/dev/null | head -c 600

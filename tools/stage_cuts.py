@@ -24,12 +24,12 @@ g = torch.Generator(device='cuda').manual_seed(0)
 pool = [torch.randn(n, 12, generator=g, device='cuda') * 50 for _ in range(16)]
 for i in range(300):
     env.step(pool[i % 16])
-names = {1: 'S0+S1 load+kinematics', 2: 'S2 inertias', 3: 'S3 mass matrix', 4: 'S4 factor x2', 5: 'S5 rne+actuation', 14: 'S6a collision scan',
+names = {15: 'launch floor (nothing done)', 1: 'S0+S1 load+kinematics', 2: 'S2 inertias', 3: 'S3 mass matrix', 4: 'S4 factor x2', 5: 'S5 rne+actuation', 14: 'S6a collision scan',
          6: 'S6b contact list', 7: 'S7 rows', 8: 'S8 qacc_smooth', 9: 'S9 solver', 10: 'S10 accelerations', 0: 'euler + S11 obs + gather (full)'}
 stop = lambda k: _lib.check(env._L.gq_debug_stop_stage(env._hbatch, k), 'gq_debug_stop_stage')
 prev = 0.0
 print(f'{robot}, {n} envs: launch time of the kernel cut after each stage (us, mean of 300 launches interleaved with complete steps)')
-for k in [1, 2, 3, 4, 5, 14, 6, 7, 8, 9, 10, 0]:
+for k in [15, 1, 2, 3, 4, 5, 14, 6, 7, 8, 9, 10, 0]:
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(300)]
     torch.cuda.synchronize()
     for i in range(300):
