@@ -46,6 +46,7 @@ struct GqBatch {
   float* debug;       /* device, debug_envs * GQ_DBG_SIZE floats (lazily allocated) */
   float* friction_next; /* device [N]: friction drawn by reset, committed after the reset step */
   uint8_t* pending;     /* device [N]: next-step auto-reset flags */
+  uint8_t* lift_pending;/* device [N]: reset kernel -> the reset's own step: lift loop still due */
   uint8_t* load_hint;   /* device [N]: per-env solver load of the previous step (scheduling hint of the step kernel) */
   int stop_stage;       /* profiling aid: GQ_STOP_STAGE at batch creation */
   /* argument block of step_kernel: device copy, host shadow of what the device holds, pinned staging ring for the
@@ -136,6 +137,8 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   HIP_TRY_OR_DESTROY(hipMemset(b->friction_next, 0, sizeof(float) * (size_t)n_envs), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipMalloc(&b->pending, (size_t)n_envs), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipMemset(b->pending, 0, (size_t)n_envs), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipMalloc(&b->lift_pending, (size_t)n_envs), gq_batch_destroy(b));
+  HIP_TRY_OR_DESTROY(hipMemset(b->lift_pending, 0, (size_t)n_envs), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipMalloc(&b->load_hint, (size_t)n_envs), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipMemset(b->load_hint, 0, (size_t)n_envs), gq_batch_destroy(b));
   { const char* s = getenv("GQ_STOP_STAGE"); b->stop_stage = s ? atoi(s) : 0; }
@@ -150,7 +153,7 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
 int gq_batch_destroy(GqBatch* b) {
   if (!b) return GQ_OK;
   DeviceGuard guard(b->model->device);
-  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->load_hint); hipFree(b->dev_args);
+  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->lift_pending); hipFree(b->load_hint); hipFree(b->dev_args);
   if (b->staging) hipHostFree(b->staging);
   if (b->debug) hipFree(b->debug);
   delete b;
@@ -215,7 +218,7 @@ static void fill_reset_cfg(gq::ResetCfgDev* d, const GqResetCfg* cfg) {
 }
 static void fill_reset_args(gq::ResetArgs* a, GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new,
                             const GqResetCfg* cfg, const GqState& st, const GqObsOut& out, int32_t* episode, uint8_t* lift_failed);
-static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const GqObsOut& out, const int32_t* episode) {
+static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const GqObsOut& out, const int32_t* episode, uint8_t* lift_failed) {
   GqModel* m = b->model;
   a->model = m->dev; a->batch = b->dev; a->vx = m->vx; a->vy = m->vy; a->vz = m->vz;
   a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart;
@@ -223,6 +226,7 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const
   a->friction_next = b->friction_next; a->pending = b->pending; a->load_hint = b->load_hint;
   a->imu_bias = b->imu_bias;
   a->h9 = b->h9; a->ext_dist = b->ext_dist;
+  a->lift_failed = lift_failed; a->lift_pending = b->lift_pending;
   a->episode_ro = episode;
   a->obs = out.obs; a->reward = out.reward; a->terminated = out.terminated; a->truncated = out.truncated;
   a->invalid_contact = out.invalid_contact; a->step_num = out.step_num; a->step_prev = out.step_num_prev;
@@ -234,7 +238,7 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const
 static int ensure_args(GqBatch* b, const GqState& st, const GqObsOut& out, int32_t* episode, uint8_t* lift_failed,
                        const GqResetCfg* reset_cfg, hipStream_t stream) {
   gq::FusedArgs want = b->shadow; /* struct copy keeps padding bytes identical for the memcmp */
-  fill_step_args(&want.s, b, st, out, episode);
+  fill_step_args(&want.s, b, st, out, episode, lift_failed);
   if (reset_cfg) fill_reset_args(&want.r, b, nullptr, nullptr, nullptr, reset_cfg, st, out, episode, lift_failed);
   if (b->shadow_valid && std::memcmp(&want, &b->shadow, sizeof want) == 0) return GQ_OK;
   if (b->staging_next == GQ_ARG_SLOTS) { /* every slot may still be in flight: drain before reusing the ring */
@@ -255,6 +259,7 @@ static void fill_reset_args(gq::ResetArgs* a, GqBatch* b, const uint8_t* mask, c
   a->time = st.time; a->cmd = st.cmd; a->friction_next = st.friction ? b->friction_next : nullptr;
   a->step_num = out.step_num; a->episode = episode; a->lift_failed = lift_failed;
   a->h9 = b->h9;
+  a->lift_pending = nullptr;   /* fused auto-reset: the wave hands the flag to its own step; gq_reset sets the scratch pointer */
   fill_reset_cfg(&a->cfg, cfg);
   a->cfg.cmd_reset = b->host.rs_cmd_reset;
 }
@@ -288,6 +293,7 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   gq::ResetArgs r{};
   fill_reset_args(&r, b, mask, qpos_new, qvel_new, cfg, st, out, episode, lift_failed);
   r.clear_terminated = out.terminated; r.clear_truncated = out.truncated; r.clear_invalid = out.invalid_contact;
+  r.lift_pending = b->lift_pending;
   gq_launch_reset(&r, b->host.n_envs, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */

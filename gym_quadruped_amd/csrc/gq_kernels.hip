@@ -19,13 +19,15 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __res
   __shared__ WaveMem W;
   int pass = c.first_pass;
   bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[blockIdx.x]; /* wave-uniform */
+  /* the reset's own step after an explicit gq_reset: the reset kernel left word whether the lift loop is still due */
+  int lift = (!BOXES && c.first_pass && A->s.lift_pending) ? (int)gptr(A->s.lift_pending)[blockIdx.x] : 0;
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
       wave_priority(3); /* reset + step in one launch: this wave is the longest of its SIMD */
-      reset_wave<BOXES>(A->r, W);
+      lift = reset_wave<BOXES>(A->r, W);
       pass = c.auto_reset;
     }
-    const int term = step_wave<SOLVER, MODE, CONE, BOXES>(A->s, c, W, pass);
+    const int term = step_wave<SOLVER, MODE, CONE, BOXES>(A->s, c, W, pass, lift);
     if (pass != 0 || c.auto_reset != 1 || !term) break;
     respawn = true;
   }

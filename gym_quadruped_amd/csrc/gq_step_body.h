@@ -167,7 +167,9 @@ __device__ inline void resample_wave(const StepArgs& a, const int env) {
         }
         if (B.rs_cmd_rotate) yaw_dot = B.rs_ang_vel_range[0] + (B.rs_ang_vel_range[1] - B.rs_ang_vel_range[0]) * u_yaw;
         GQ_GLOBAL float* cmd = gptr(const_cast<float*>(a.cmd)) + (size_t)env * 4;
-        cmd[0] = norm * cosf(heading); cmd[1] = norm * sinf(heading); cmd[2] = 0.0f; cmd[3] = yaw_dot;
+        float sh, ch;
+        sincos_small(heading, sh, ch);
+        cmd[0] = norm * ch; cmd[1] = norm * sh; cmd[2] = 0.0f; cmd[3] = yaw_dot;
         hc[0] = 0; hc[1] = 1000 + (int)(2000.0f * u_int); hc[2] = n + 1;
       }
     } else if (lane == 0) hc[0] = after;
@@ -202,7 +204,7 @@ __device__ inline void resample_wave(const StepArgs& a, const int env) {
  * CONE: elliptic friction cones (Newton only): contacts take dim rows [n, t1, t2, torsion, roll1, roll2].
  * BOXES: the scene has static world boxes (gq_boxes.h; Newton only): contacts carry their own normal. */
 template <int SOLVER, int MODE, bool CONE, bool BOXES>
-__device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass) {
+__device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
   int lane_o = lane_id(), env_o = (int)blockIdx.x;
@@ -405,6 +407,32 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   /* ================================================================ S6: collision with the floor (z = 0) */
   const int nlg = m.nlg;
   stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), false);
+  /* reset on a scene without world boxes / height field: the lift loop of QuadrupedEnv.reset (quadruped_env.py:376-388:
+   * z += 1.1 max|dist| until no foot-body contact, <= 100 iterations) runs HERE, on the distances this step's own
+   * kinematics and collision scan just produced, instead of on a kinematics + scan pass of its own inside reset_wave: on
+   * the flat floor a lift by dz moves every distance by dz and leaves everything that S2-S5 computed (all of it relative
+   * to the base origin) untouched, so the reset's mj_step simply continues from the lifted pose */
+  if constexpr (!BOXES) if (lift) { /* wave-uniform */
+    float dist = 1e30f, margin = 0.0f;
+    if (lane < 4) { dist = W.foot_world[lane][2] - m.foot_radius[lane]; margin = m.foot_margin[lane]; }
+    else if (lane - 4 < nlg) {
+      const GQ_MODEL GqDevGeom& G = m.lg[lane - 4];
+      if (G.body > 0 && (G.body - 1) % 3 == 2) { dist = W.u2.c.lg_dist[lane - 4]; margin = G.margin; }
+    }
+    float dz = 0.0f;
+    for (int it = 0; it < 100; it++) {
+      const bool touching = dist + dz < margin;
+      if (ballot(touching) == 0) break;
+      dz += 1.1f * wave_max(touching ? fabsf(dist + dz) : 0.0f);
+    }
+    const int failed = ballot(dist + dz < margin) != 0;
+    wave_barrier();
+    if (lane == 0) { W.basez += dz; if (a.lift_failed) gptr(a.lift_failed)[env] = (uint8_t)failed; }
+    if (lane < GQ_NB) W.xpos[lane][2] += dz;
+    if (lane < 4) W.foot_world[lane][2] += dz;
+    if (lane < nlg && W.u2.c.lg_dist[lane] < 1e29f) { W.u2.c.lg_dist[lane] += dz; W.u2.c.lg_pt[lane][2] += dz; }
+    wave_barrier();
+  }
   GQ_TICK(14);
   /* contact list in MuJoCo's order (increasing geom id; con_order interleaves feet and link geoms), capped.
    * Lane `it` evaluates collision item `it`; ranks and row offsets come from ballots (no serial section). */
@@ -1052,6 +1080,8 @@ struct ResetArgs {
   double* qpos; float* qvel; float* qacc; float* warm; float* applied; float* time; float* cmd; float* friction_next;
   int32_t* step_num; int32_t* episode;
   int32_t* h9;            /* resampling counters (see StepArgs), may be NULL */
+  uint8_t* lift_pending;  /* library scratch [N]: 1 = the env's next first-pass step performs the lift (explicit gq_reset: the
+                           * reset kernel and the reset's mj_step are two launches); NULL inside a fused auto-reset */
   uint8_t* lift_failed;
   uint8_t* clear_terminated; uint8_t* clear_truncated; uint8_t* clear_invalid; /* explicit reset(): flags zeroed; NULL inside a fused auto-reset */
   ResetCfgDev cfg;
@@ -1063,7 +1093,7 @@ enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH =
 
 #define GQ_LIFT_RULE_ITERS 4
 template <bool BOXES>
-__device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
+__device__ inline int reset_wave(const ResetArgs& a, WaveMem& W) {
   int lane_o = lane_id(), env_o = (int)blockIdx.x;
   opaque(lane_o); opaque_s(env_o); /* see step_wave: no address arithmetic may be hoisted to the kernel prologue */
   const int lane = lane_o, env = env_o;
@@ -1099,9 +1129,9 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
       const float roll = (2.0f * W.u.obs[RN_ROLL] - 1.0f) * c.roll_sweep, pitch = (2.0f * W.u.obs[RN_PITCH] - 1.0f) * c.pitch_sweep;
       /* heading towards the origin (math_utils.py:37-51); fp32 atan2f on purpose: the f64 routine's constant table
        * was being hoisted to the kernel prologue and spilled by every wave of every step */
-      const float yaw = atan2f((float)(-y), (float)(-x));
-      const float cr = cosf(0.5f * roll), sr = sinf(0.5f * roll), cp = cosf(0.5f * pitch), sp = sinf(0.5f * pitch);
-      const float cy = cosf(0.5f * yaw), sy = sinf(0.5f * yaw);
+      const float yaw = atan2_fast((float)(-y), (float)(-x));
+      float cr, sr, cp, sp, cy, sy;
+      sincos_small(0.5f * roll, sr, cr); sincos_small(0.5f * pitch, sp, cp); sincos_small(0.5f * yaw, sy, cy);
       spawn_x = x; spawn_y = y;
       if (lane == 0) q = x;
       if (lane == 1) q = y;
@@ -1119,7 +1149,10 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
   wave_barrier();
   float dz = 0.0f;
   int failed = 0;
-  if (!explicit_state) {
+  /* scenes without world boxes / height field: the lift loop runs inside the reset's own mj_step (step_wave, S6) on that
+   * step's kinematics and collision scan - this function only writes the spawn state and says that a lift is due */
+  const int lift_due = (!BOXES && !explicit_state) ? 1 : 0;
+  if (BOXES && !explicit_state) {
     stage_kinematics(W, m);
     wave_barrier();
     stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), true);
@@ -1202,7 +1235,8 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
     gptr(a.time)[env] = 0.0f;
     gptr(a.step_num)[env] = -1; /* the reset's own mj_step brings it to 0 (:332, :397) */
     if (a.episode) gptr(a.episode)[env] = episode + 1;
-    if (a.lift_failed) gptr(a.lift_failed)[env] = (uint8_t)failed;
+    if (a.lift_failed && !lift_due) gptr(a.lift_failed)[env] = (uint8_t)failed;
+    if (a.lift_pending) gptr(a.lift_pending)[env] = (uint8_t)lift_due;
     if (a.clear_terminated) { gptr(a.clear_terminated)[env] = 0; gptr(a.clear_truncated)[env] = 0; gptr(a.clear_invalid)[env] = 0; }
     /* _sample_ref_vel (:1046-1072) */
     if (a.cmd) {
@@ -1213,7 +1247,9 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
         heading = (2.0f * u_heading - 1.0f) * 3.14159265358979f;
       }
       if (c.cmd_rotate) yaw_dot = c.ang_vel_range[0] + (c.ang_vel_range[1] - c.ang_vel_range[0]) * u_yawdot;
-      gptr(a.cmd)[(size_t)env * 4 + 0] = norm * cosf(heading); gptr(a.cmd)[(size_t)env * 4 + 1] = norm * sinf(heading);
+      float sh, ch;
+      sincos_small(heading, sh, ch);
+      gptr(a.cmd)[(size_t)env * 4 + 0] = norm * ch; gptr(a.cmd)[(size_t)env * 4 + 1] = norm * sh;
       gptr(a.cmd)[(size_t)env * 4 + 2] = 0.0f; gptr(a.cmd)[(size_t)env * 4 + 3] = yaw_dot;
       /* 'reset' command types restart their redraw interval (:1068-1070) */
       if (a.h9 && c.cmd_reset) { gptr(a.h9)[(size_t)env * 6 + 0] = 0; gptr(a.h9)[(size_t)env * 6 + 1] = 1000 + (int)(2000.0f * u_interval); }
@@ -1221,6 +1257,7 @@ __device__ inline void reset_wave(const ResetArgs& a, WaveMem& W) {
     if (a.friction_next)
       gptr(a.friction_next)[env] = c.friction_range[0] + (c.friction_range[1] - c.friction_range[0]) * u_fric;
   }
+  return lift_due;
 }
 
 

@@ -46,6 +46,8 @@ struct StepArgs {
   uint8_t* pending;       /* library scratch [N]: env terminated and waits for its next-step auto-reset (may be NULL) */
   uint8_t* load_hint;     /* library scratch [N]: Newton iterations of the env's previous step, capped (may be NULL) */
   float* obs; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* invalid_contact; int32_t* step_num;
+  uint8_t* lift_failed;   /* [N] out: the reset RuntimeError condition (:387-388), written by the step that performs a lift; may be NULL */
+  const uint8_t* lift_pending; /* library scratch [N] written by reset_kernel (see ResetArgs), read by first-pass steps; may be NULL */
   int32_t* step_prev;     /* [N] step counter before this step's increment (info['step_num']), may be NULL */
   int32_t* h9;            /* [N][6] resampling counters {after_vel, before_vel, n_vel, after_dist, before_dist, n_dist}, may be NULL */
   float* ext_dist;        /* [N][6] current disturbance wrench, may be NULL */

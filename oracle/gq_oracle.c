@@ -991,6 +991,13 @@ static void gqo_sol_newton(GqOracle* o, int maxiter, double tol) {
   /* warm start: whichever of qacc_warmstart / qacc_smooth has the lower cost */
   double cw = primal_cost(o, o->qacc_warmstart, NULL), cs = primal_cost(o, o->qacc_smooth, NULL);
   memcpy(qacc, cw < cs ? o->qacc_warmstart : o->qacc_smooth, sizeof qacc);
+  { /* experiment knob (tools/newton_start_experiment.py): GQO_NEWTON_START = 1 qacc_smooth, 2 zero, 3 warm start */
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("GQO_NEWTON_START"); mode = e ? atoi(e) : 0; }
+    if (mode == 1) memcpy(qacc, o->qacc_smooth, sizeof qacc);
+    else if (mode == 2) memset(qacc, 0, sizeof qacc);
+    else if (mode == 3) memcpy(qacc, o->qacc_warmstart, sizeof qacc);
+  }
   double scale = 1.0 / (o->d.meaninertia * NV);
   int iter = 0;
   for (; iter < maxiter; iter++) {
@@ -1133,6 +1140,15 @@ static void gqo_sol_newton(GqOracle* o, int maxiter, double tol) {
     qsort(bp, nbp, sizeof(Breakpt), cmp_bp);
     double alpha = 0;
     int found = 0;
+    { /* experiment knob GQO_LS_MODE = 1: take the full Newton step whenever it lowers the cost (semi-smooth Newton) */
+      static int lsmode = -1;
+      if (lsmode < 0) { const char* e = getenv("GQO_LS_MODE"); lsmode = e ? atoi(e) : 0; }
+      if (lsmode == 1) {
+        double trial[NV];
+        for (int i = 0; i < NV; i++) trial[i] = qacc[i] + search[i];
+        if (primal_cost(o, trial, NULL) < primal_cost(o, qacc, NULL)) { memcpy(qacc, trial, sizeof qacc); continue; }
+      }
+    }
     if (d1 >= 0) { alpha = 0; found = 1; }
     for (int k = 0; k <= nbp && !found; k++) {
       double hi = k < nbp ? bp[k].a : 1e300;

@@ -74,7 +74,7 @@ def _p(a):
 
 def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=None, cmd=None, obs_names=ALL_OBS,
              legs_order=(0, 1, 2, 3), mask=None, debug_envs=0, auto_reset=None, episode=None, first_pass=0, imu=None,
-             imu_bias=None, step_num=None, pending=None):
+             imu_bias=None, step_num=None, pending=None, lift_pending=None, friction_next=None, lift_failed=None):
     """Run the kernel body under the emulator. Arrays are updated in place like the device tensors would be."""
     L = emu_lib()
     n = qpos.shape[0]
@@ -89,7 +89,9 @@ def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=
         terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8), invalid=np.zeros(n, np.uint8),
         step_num=np.zeros(n, np.int32) if step_num is None else np.ascontiguousarray(step_num, dtype=np.int32), debug=np.zeros((max(debug_envs, 1), DBG_SIZE), np.float32),
         episode=np.zeros(n, np.int32) if episode is None else np.ascontiguousarray(episode, dtype=np.int32),
-        lift_failed=np.zeros(n, np.uint8), friction_next=np.zeros(n, np.float32),
+        lift_failed=np.zeros(n, np.uint8) if lift_failed is None else lift_failed,
+        friction_next=np.zeros(n, np.float32) if friction_next is None else np.ascontiguousarray(friction_next, dtype=np.float32),
+        lift_pending=np.zeros(n, np.uint8) if lift_pending is None else np.ascontiguousarray(lift_pending, dtype=np.uint8),
         pending=np.zeros(n, np.uint8) if pending is None else np.ascontiguousarray(pending, dtype=np.uint8),
         imu_bias=np.zeros((n, 6), np.float32) if imu_bias is None else np.ascontiguousarray(imu_bias, dtype=np.float32))
     lo = np.asarray(legs_order, dtype=np.int32)
@@ -100,7 +102,7 @@ def emu_step(mm, ctrl, qpos, qvel, warm=None, applied=None, time=None, friction=
                     _p(st['obs']), _p(st['reward']), _p(st['terminated']), _p(st['truncated']), _p(st['invalid']),
                     _p(st['step_num']), _p(st['debug']), debug_envs, None if auto_reset is None else C.byref(auto_reset),
                     _p(st['episode']), _p(st['lift_failed']), _p(st['friction_next']), int(first_pass),
-                    None if imu is None else C.byref(imu), _p(st['imu_bias']), _p(st['pending']), err, 512)
+                    None if imu is None else C.byref(imu), _p(st['imu_bias']), _p(st['pending']), _p(st['lift_pending']), err, 512)
     if rc < 0:
         raise RuntimeError(err.value.decode())
     st['obs_names'] = list(obs_names)
@@ -128,14 +130,14 @@ def emu_reset(mm, n, cfg, qpos_new=None, qvel_new=None, mask=None, episode=None)
               warm=np.ones((n, 18), np.float32), applied=np.ones((n, 18), np.float32), time=np.ones(n, np.float32),
               cmd=np.zeros((n, 4), np.float32), friction_next=np.zeros(n, np.float32), step_num=np.full(n, 7, np.int32),
               episode=np.zeros(n, np.int32) if episode is None else np.ascontiguousarray(episode, dtype=np.int32),
-              lift_failed=np.zeros(n, np.uint8))
+              lift_failed=np.zeros(n, np.uint8), lift_pending=np.zeros(n, np.uint8))
     err = C.create_string_buffer(512)
     m8 = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
     qn = None if qpos_new is None else np.ascontiguousarray(qpos_new, dtype=np.float64)
     vn = None if qvel_new is None else np.ascontiguousarray(qvel_new, dtype=np.float32)
     rc = L.emu_reset(C.byref(mm.desc), n, _p(m8), _p(qn), _p(vn), C.byref(cfg), _p(st['qpos']), _p(st['qvel']), _p(st['qacc']),
                      _p(st['warm']), _p(st['applied']), _p(st['time']), _p(st['cmd']), _p(st['friction_next']),
-                     _p(st['step_num']), _p(st['episode']), _p(st['lift_failed']), err, 512)
+                     _p(st['step_num']), _p(st['episode']), _p(st['lift_failed']), _p(st['lift_pending']), err, 512)
     if rc < 0:
         raise RuntimeError(err.value.decode())
     return st
@@ -199,3 +201,19 @@ class ParityTally:
         msg = self.report(what)
         assert not self.mismatch, msg
         assert self.checked >= min_checked * self.n and self.tie <= max_tie * self.n and self.budget <= max_budget * self.n, msg
+
+
+def oracle_reset_lift(o, q0, v0, hip_height):
+    """The reference's lift loop (quadruped_env.py:376-388) on the oracle: mj_step1, then z += 1.1 max|dist| over the contacts
+    of the calf bodies until none is left (<= 100 iterations).  Returns (lifted z, iterations)."""
+    z, it = float(hip_height), 0
+    while True:
+        o.set_state(np.r_[q0[:2], z, q0[3:]], v0, np.zeros(18), np.zeros(18), 0.0, -1.0)
+        o.forward(np.zeros(12), stage=1)
+        bodies = o.get('contact_body').astype(int) if o.ncon else np.zeros(0, int)
+        dist = o.get('contact_dist') if o.ncon else np.zeros(0)
+        calf = np.array([(b - 2) % 3 == 2 for b in bodies], bool)
+        if not calf.any() or it >= 100:
+            return z, it
+        z += 1.1 * np.abs(dist[calf]).max()
+        it += 1

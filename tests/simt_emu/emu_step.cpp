@@ -26,7 +26,7 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
                         float* reward, uint8_t* terminated, uint8_t* truncated, uint8_t* invalid_contact,
                         int32_t* step_num, float* debug, int debug_envs, const GqResetCfg* auto_reset, int32_t* episode,
                         uint8_t* lift_failed, float* friction_next, int first_pass, const GqImuCfg* imu, float* imu_bias,
-                        uint8_t* pending, char* err, int errlen) {
+                        uint8_t* pending, uint8_t* lift_pending, char* err, int errlen) {
   static GqDevModel M;
   static GqDevBatch B;
   std::vector<float> vx, vy, vz;
@@ -44,6 +44,7 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
   a.time = time; a.friction = friction; a.cmd = cmd; a.friction_next = friction_next; a.pending = pending; a.obs = obs; a.reward = reward;
   a.terminated = terminated; a.truncated = truncated; a.invalid_contact = invalid_contact; a.step_num = step_num;
   a.n_envs = n_envs; a.imu_bias = imu ? imu_bias : nullptr; a.episode_ro = episode;
+  a.lift_failed = lift_failed; a.lift_pending = lift_pending;
   gq::StepCall call{};
   call.ctrl = ctrl; call.mask = mask; call.debug = debug;
   call.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; call.first_pass = first_pass;
@@ -60,15 +61,17 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
       __shared__ gq::WaveMem W;
       int pass = call.first_pass;
       bool respawn = call.auto_reset == 2 && f.s.pending[e];
+      const bool boxes = M.nbox > 0 || M.hf_nrow > 0;
+      int lift = (!boxes && call.first_pass && lift_pending) ? (int)lift_pending[e] : 0;
       for (;;) {
         if (respawn) {
-          if ((M.nbox > 0 || M.hf_nrow > 0)) gq::reset_wave<true>(f.r, W); else gq::reset_wave<false>(f.r, W);
+          lift = boxes ? gq::reset_wave<true>(f.r, W) : gq::reset_wave<false>(f.r, W);
           pass = call.auto_reset;
         }
         int term;
-        if (M.solver != 1) term = gq::step_wave<0, 1, false, false>(f.s, call, W, pass);
-        else if ((M.nbox > 0 || M.hf_nrow > 0)) term = M.cone ? gq::step_wave<1, 1, true, true>(f.s, call, W, pass) : gq::step_wave<1, 1, false, true>(f.s, call, W, pass);
-        else term = M.cone ? gq::step_wave<1, 1, true, false>(f.s, call, W, pass) : gq::step_wave<1, 1, false, false>(f.s, call, W, pass);
+        if (M.solver != 1) term = gq::step_wave<0, 1, false, false>(f.s, call, W, pass, lift);
+        else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true>(f.s, call, W, pass, lift) : gq::step_wave<1, 1, false, true>(f.s, call, W, pass, lift);
+        else term = M.cone ? gq::step_wave<1, 1, true, false>(f.s, call, W, pass, lift) : gq::step_wave<1, 1, false, false>(f.s, call, W, pass, lift);
         if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
       }
@@ -80,7 +83,7 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
 extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mask, const double* qpos_new, const float* qvel_new,
                          const GqResetCfg* cfg, double* qpos, float* qvel, float* qacc, float* warm, float* applied,
                          float* time, float* cmd, float* friction_next, int32_t* step_num, int32_t* episode,
-                         uint8_t* lift_failed, char* err, int errlen) {
+                         uint8_t* lift_failed, uint8_t* lift_pending, char* err, int errlen) {
   static GqDevModel M;
   std::vector<float> vx, vy, vz;
   if (gq_build_dev_model(desc, &M, &vx, &vy, &vz, err, (size_t)errlen)) return -1;
@@ -91,6 +94,7 @@ extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mas
   a.model = &M; a.vx = vx.data(); a.vy = vy.data(); a.vz = vz.data(); a.mask = mask; a.qpos_new = qpos_new; a.qvel_new = qvel_new;
   a.qpos = qpos; a.qvel = qvel; a.qacc = qacc; a.warm = warm; a.applied = applied; a.time = time; a.cmd = cmd;
   a.friction_next = friction_next; a.step_num = step_num; a.episode = episode; a.lift_failed = lift_failed;
+  a.lift_pending = lift_pending;
   emu_fill_cfg(&a.cfg, cfg);
   for (int e = 0; e < n_envs; e++) {
     if (mask && !mask[e]) continue;

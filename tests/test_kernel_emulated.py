@@ -3,7 +3,7 @@ the CPU oracle: same parity contract as tests/test_gpu_parity.py, runnable witho
 import numpy as np
 import pytest
 
-from helpers import ALL_OBS, dbg, default_reset_cfg, emu_reset, emu_step, marshalled, random_states, split_obs
+from helpers import ALL_OBS, dbg, default_reset_cfg, emu_reset, emu_step, marshalled, oracle_reset_lift, random_states, split_obs
 from oracle.oracle import Oracle
 from philox_ref import draws
 
@@ -87,13 +87,28 @@ def test_reset_kernel_stream_lift_and_bookkeeping():
         norm, head = 0.5 + 0.5 * u[28], (2 * u[29] - 1) * np.pi
         np.testing.assert_allclose(st['cmd'][e], [norm * np.cos(head), norm * np.sin(head), 0, -0.3 + 0.6 * u[30]], atol=1e-5)
         assert abs(st['friction_next'][e] - (0.2 + 1.3 * u[31])) < 1e-6
-        assert st['episode'][e] == e + 1 and st['step_num'][e] == -1 and st['time'][e] == 0 and not st['lift_failed'][e]
+        assert st['episode'][e] == e + 1 and st['step_num'][e] == -1 and st['time'][e] == 0
         assert not st['qacc'][e].any() and not st['warm'][e].any() and not st['applied'][e].any()
-        # lift loop: no foot-body contact at the final height, and the base was raised above hip_height
-        o.set_state(st['qpos'][e], st['qvel'][e].astype(np.float64), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12), stage=1)
-        calf = [b for b in o.get('contact_body')] if o.ncon else []
-        assert all((int(b) - 2) % 3 != 2 for b in calf), 'a calf body still touches the floor'
-        assert st['qpos'][e, 2] >= 0.225 - 1e-6
+        # flat scene: the reset kernel writes the spawn pose at hip height and leaves word that the lift loop is due; it
+        # runs inside the reset's own mj_step (below)
+        assert st['lift_pending'][e] == 1 and abs(st['qpos'][e, 2] - 0.225) < 1e-7
+    spawn_q, spawn_v = st['qpos'].copy(), st['qvel'].copy()
+    st1 = emu_step(mm, np.zeros((n, 12)), st['qpos'], st['qvel'], warm=st['warm'], applied=st['applied'], time=st['time'],
+                   cmd=st['cmd'], step_num=st['step_num'], episode=st['episode'], first_pass=1, lift_pending=st['lift_pending'],
+                   friction_next=st['friction_next'], obs_names=['qpos', 'feet_pos'])
+    nlift = 0
+    for e in range(n):
+        # lift loop on the oracle (the reference's rule), then the reset's mj_step from the lifted pose
+        z, it = oracle_reset_lift(o, spawn_q[e], spawn_v[e].astype(np.float64), 0.225)
+        nlift += it > 0
+        q0 = spawn_q[e].copy(); q0[2] = z
+        o.set_state(q0, spawn_v[e].astype(np.float64), np.zeros(18), np.zeros(18), 0.0, -1.0); o.step(np.zeros(12))
+        assert not st1['lift_failed'][e] and st1['step_num'][e] == 0
+        assert np.abs(st1['qpos'][e] - o.qpos).max() < 1e-6 and np.abs(st1['qvel'][e] - o.qvel).max() < 5e-5, (e, it)
+        ref, _, _ = o.get_obs(['feet_pos'])
+        assert np.abs(split_obs(st1['obs'][e], ['qpos', 'feet_pos'])['feet_pos'] - ref['feet_pos']).max() < 2e-5   # old kinematics AT THE LIFTED POSE
+        assert abs(st1['friction'][e] - st['friction_next'][e]) < 1e-9      # committed after the reset's step (:403-404)
+    assert nlift > 0
     # explicit state: copied verbatim, no lift
     qn = np.tile(key, (2, 1)); qn[:, 2] = 0.05
     st2 = emu_reset(mm, 2, cfg, qpos_new=qn, qvel_new=np.ones((2, 18), np.float32))
