@@ -43,12 +43,26 @@ def algorithmic_bytes_per_env_step(obs_dim: int) -> int:
 def pmc_traffic():
     """HBM bytes per step-kernel launch from the last committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (profiles/latest_traffic.json, gfx950 FETCH_SIZE x2 correction applied); counters cannot be read from inside
-    this process, so the figure comes from the separate profiling passes of the same command."""
+    this process, so the figure comes from the separate profiling passes of the same command.  Returns (bytes, provenance):
+    the provenance names the kernel source the counters were taken on (sha256/16 of the csrc/ sources) and says whether the
+    library being benchmarked was built from the same sources - a stale figure is labelled, not silently replayed."""
     p = ROOT / 'profiles' / 'latest_traffic.json'
     try:
-        return json.loads(p.read_text())['traffic_bytes_per_launch']
+        d = json.loads(p.read_text())
+        now = kernel_source_hash()
+        return d['traffic_bytes_per_launch'], {'profile': d.get('profile', 'profiles/latest_traffic.json'), 'kernel_src_sha16': d.get('kernel_src_sha16'),
+                                               'current_kernel_src_sha16': now, 'stale': d.get('kernel_src_sha16') != now}
     except Exception:
-        return None
+        return None, None
+
+
+def kernel_source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / 'gym_quadruped_amd' / 'csrc').glob('*')):
+        if f.suffix in ('.h', '.hip', '.cpp') or f.name == 'Makefile':
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(seconds_budget: float = 15.0):
@@ -70,10 +84,70 @@ def cpu_baseline(seconds_budget: float = 15.0):
         o.rollout(ctrl, ALL_OBS)
         t_used += time.perf_counter() - t0
         done += chunk
-    return {'value': done / t_used, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{done} steps of 1 mini_cheetah env on flat, 50*N(0,1) torques, ALL_OBS assembled each step, '
-                      f'reset to the start state on termination; C fp64 restatement of mj_step with the Newton solver '
-                      f'(MuJoCo itself is not installable here), {os.cpu_count()} host cores present, 1 used'}
+    out = {'value': done / t_used, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+           'sample': f'{done} steps of 1 mini_cheetah env on flat, 50*N(0,1) torques, ALL_OBS assembled each step, '
+                     f'reset to the start state on termination; C fp64 restatement of mj_step with the Newton solver '
+                     f'(MuJoCo itself is not installable here), {os.cpu_count()} host cores present, 1 used'}
+    try:
+        out['all_cores'] = cpu_baseline_all_cores()
+    except Exception as e:  # noqa: BLE001 - a reported extra, never fatal
+        out['all_cores'] = {'error': f'{type(e).__name__}: {e}'}
+    return out
+
+
+def _cpu_worker(args):
+    """One host process = one oracle env stepping for `budget` seconds (N envs over all host cores)."""
+    seed, budget = args
+    from gym_quadruped_amd.cabi import ALL_OBS
+    from oracle.oracle import Oracle
+    from tests.helpers import marshalled
+    mm = marshalled('mini_cheetah', solver=1, iterations=100, tolerance=1e-8)
+    o = Oracle(mm)
+    q = mm.md.key_qpos[0].copy()
+    q[2] = 0.3
+    o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18), 0.0, -1.0)
+    rng = np.random.default_rng(seed)
+    chunk, done = 5000, 0
+    ctrl = rng.normal(0, 1, (chunk, 12)).astype(np.float32).astype(np.float64) * 50
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        o.rollout(ctrl, ALL_OBS)
+        done += chunk
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(seconds_budget: float = 6.0):
+    """The same CPU restatement with one independent env per host core (no shared state: embarrassingly parallel), all
+    cores busy for `seconds_budget`; value = total env-steps / the slowest worker's time."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    with mp.get_context('fork').Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(k, seconds_budget) for k in range(cores)])
+    total, tmax = sum(r[0] for r in res), max(r[1] for r in res)
+    return {'value': total / tmax, 'unit': 'env-steps/s', 'cores': cores,
+            'sample': f'{cores} processes x 1 env each, {total} env-steps in {tmax:.1f} s (slowest worker), same workload as the 1-core figure'}
+
+
+def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
+    """Short runs of the same workload with (i) the reference's default observation set (73 scalars, SURVEY.md 8d
+    "secondary") and (ii) the PGS solver the north-star names; same timing discipline, reported next to the headline."""
+    out = {}
+    for key, obs_names, solver in (('default_obs', QuadrupedEnv._DEFAULT_OBS, args.solver), ('pgs', tuple(QuadrupedEnv.ALL_OBS), 'pgs')):
+        env = QuadrupedEnv('mini_cheetah', state_obs_names=obs_names, scene='flat', num_envs=n, device=device, auto_reset='next_step',
+                           solver=solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000)
+        env.reset(random=True)
+        for i in range(warmup):
+            env.step(pool[i % 64])
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            env.step(pool[i % 64])
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out[key] = {'value': n * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps,
+                    'obs_dim': env._obs_dim, 'solver': solver, 'bytes_per_env_step': algorithmic_bytes_per_env_step(env._obs_dim)}
+        env.close()
+    return out
 
 
 def main():
@@ -84,6 +158,7 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--obs', choices=['all', 'default'], default='all')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the short secondary measurements (_DEFAULT_OBS, PGS)')
     ap.add_argument('--auto-reset', choices=['next_step', 'same_step', 'off'], default='next_step')
     ap.add_argument('--no-auto-reset', action='store_true')
     ap.add_argument('--solver', choices=['newton', 'pgs'], default='newton')
@@ -91,13 +166,18 @@ def main():
     ap.add_argument('--robot', default='mini_cheetah', help='headline metric: mini_cheetah; other registry robots for the secondary configs')
     args = ap.parse_args()
 
+    from gym_quadruped_amd.sharding import aggregate_throughput, shard_plan
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    shard = shard_plan(rank, world, args.envs_per_gpu)   # contiguous, independent shards; no data-path collective
     if args.gpus != world and world > 1:
         raise SystemExit(f'--gpus {args.gpus} != WORLD_SIZE {world}')
     if args.gpus > 1 and world == 1:
         raise SystemExit('launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+    # the CPU baseline runs first: its all-cores leg forks worker processes, which must happen before this process
+    # creates a HIP context
+    cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -114,7 +194,7 @@ def main():
     n = args.envs_per_gpu
     env = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device,
                        auto_reset=False if (args.no_auto_reset or args.auto_reset == 'off') else args.auto_reset, solver=args.solver, solver_iterations=100, solver_tolerance=1e-8,
-                       seed=1000, env_id_offset=rank * n)  # shards: disjoint global env ids -> disjoint RNG counters
+                       seed=1000, env_id_offset=shard.env_offset)  # shards: disjoint global env ids -> disjoint RNG counters
     env.reset(random=True)
     g = torch.Generator(device=device).manual_seed(rank)
     pool = [torch.randn(n, 12, generator=g, device=device) * 50 for _ in range(64)]
@@ -125,6 +205,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    # device clocks: a GPU that has been idle while the host built the model sits in a low power state and needs a few
+    # milliseconds of load to ramp up; a short busy loop of unrelated work (no env is touched, not a step) makes a
+    # --steps 20 run measure the same clocks as a --steps 2000 one
+    spin = torch.empty(1 << 22, device=device)
+    for _ in range(300):
+        spin.normal_()
+    del spin
     for i in range(args.warmup):
         env.step(pool[i % 64])
     # timed region: exactly K steps bracketed by barrier + synchronize
@@ -149,9 +236,12 @@ def main():
     kernel_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in ev if p is not None]))
     finite = bool(torch.isfinite(env.qpos).all() and torch.isfinite(env.qvel).all())
 
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary and args.robot == 'mini_cheetah' and args.scene == 'flat':
+        secondary = secondary_lines(QuadrupedEnv, n, device, pool, args)
     if rank == 0:
-        total_envs = n * world
-        value = total_envs * args.steps / dt
+        total_envs = shard.global_envs
+        value = aggregate_throughput([dt] * world, args.steps, n)   # dt is already the max over ranks
         bytes_step = algorithmic_bytes_per_env_step(env._obs_dim)
         achieved = n * bytes_step / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -165,12 +255,14 @@ def main():
                        'envs_per_gpu': n, 'total_envs': total_envs, 'parallelism': f'env-shards x{world} (no collectives)',
                        'state_finite': finite},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(), 'kernel': 'gq::step_kernel',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic()[0], 'traffic_source': pmc_traffic()[1], 'kernel': 'gq::step_kernel',
                          'kernel_ms': kernel_ms, 'bytes_per_env_step': bytes_step,
                          'note': 'algorithmic bytes / HIP-event kernel time; the step is latency/VALU bound, not HBM bound'},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+        if secondary:
+            out['secondary'] = secondary
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

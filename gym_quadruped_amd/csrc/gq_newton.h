@@ -454,6 +454,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     hent[pass] = e < 117 ? (da | (db << 8) | (slot << 16) | (frp1 << 24)) : -1;
   }
   long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = (DBG && tdbg) ? cycles() : 0;
+  if constexpr (DBG) if (tdbg && lane == 0) { tdbg[29] = 0.0f; tdbg[30] = 0.0f; } /* line-search trials, full-step shortcuts */
 #define NW_T(i) do { if constexpr (DBG) if (tdbg) { const long long tn = cycles(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
   NW_T(0);
   /* residual y = J qacc - aref and Ma-terms are evaluated once, then advanced incrementally along the search
@@ -611,7 +612,6 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     NW_T(3);
     solve_tree_fused<false>(W.u2.n.Hc, W.u2.n.Hb, nullptr, 0.0f, grad, search);
     NW_T(4);
-    NW_T(5);
     /* ---- exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on phi' */
     float v = 0.0f;
     {
@@ -629,6 +629,8 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
      * step itself - no derivative sums, no trial steps (the usual last iteration of a solve) */
     bool full_step = false;
     if constexpr (!CONE) full_step = ballot(row_piece(rtype, y, rR, rfloss) != row_piece(rtype, y + v, rR, rfloss)) == 0;
+    NW_T(5);
+    if constexpr (DBG) if (tdbg && lane == 0 && full_step) tdbg[30] += 1.0f;
     if (full_step) { alpha = 1.0f; first_try = true; }
     else {
     /* phi'(alpha) = sum over lanes of (s.Mdq + alpha s.Ms) [dof lanes] + d1(alpha) [row lanes]: the quadratic part rides
@@ -649,6 +651,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     if (!(g0 < 0.0f)) { exit_code = 5; break; } /* not a descent direction: converged to working precision */
     alpha = -g0 / h0;
     for (int ls = 0; ls < 10; ls++) {
+      if constexpr (DBG) if (tdbg && lane == 0) tdbg[29] += 1.0f;
       row_dd(rtype, y + alpha * v, v, rR, rD, rfloss, d1, d2);
       if constexpr (CONE) if (E.code) ell_dd(E, alpha, y, v, rD, TT, y0, UV, VV, N1, d1, d2);
       const float ga = wave_sum(p1 + alpha * p2 + d1);

@@ -13,7 +13,8 @@ for p in $PARTS; do
     probe) timeout 300 python tools/mujoco_probe.py > $OUT/mujoco_probe.txt 2>&1; cp gpurun_out/mujoco_probe.log $OUT/ 2>/dev/null;;
     tests) timeout 2400 python -m pytest tests -m gpu -q -x --timeout=900 -s 2>&1 | tail -150 > $OUT/pytest_gpu.txt;;
     testsall) timeout 3000 python -m pytest tests -m gpu -q --timeout=900 -s 2>&1 | tail -250 > $OUT/pytest_gpu.txt;;
-    perf) timeout 600 python tools/perf_probe.py stages 256 > $OUT/stages256.txt 2>&1
+    perf) timeout 600 python tools/perf_probe.py stages 64 > $OUT/stages64.txt 2>&1
+          timeout 600 python tools/perf_probe.py stages 256 > $OUT/stages256.txt 2>&1
           timeout 600 python tools/perf_probe.py stages 4096 > $OUT/stages4096.txt 2>&1
           timeout 600 python tools/stage_cuts.py 4096 > $OUT/stage_cuts4096.txt 2>&1
           timeout 600 python tools/stage_cuts.py 256 > $OUT/stage_cuts256.txt 2>&1

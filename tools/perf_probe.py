@@ -66,8 +66,13 @@ def stage_times(n=4096, iters=100, tol=1e-8, solver='newton', robot='mini_cheeta
     print('  histogram of totals:', ' '.join(f'{int(lo/1000)}k:{c}' for lo, c in zip(edges[:-1], h)))
     hn = np.bincount(nit.astype(int)); print('  niter histogram:', hn.tolist())
     if solver == 'newton':
-        for nm, k in zip(['warm', 'state+cost', 'gradient', 'hessian', 'factor', 'solve', 'linesearch'], range(16, 23)):
-            print(f'    newton {nm:11s} {T[:, k].mean():9.0f} {np.percentile(T[:, k], 95):9.0f} {T[:, k].max():9.0f}   per-iter {T[:, k].sum() / max(1, nit.sum()):7.0f}')
+        for nm, k in zip(['setup', 'state+cost', 'gradient', 'hessian', 'solve', 'ls prep', 'ls trials+upd'], range(16, 23)):
+            print(f'    newton {nm:13s} {T[:, k].mean():9.0f} {np.percentile(T[:, k], 95):9.0f} {T[:, k].max():9.0f}   per-iter {T[:, k].sum() / max(1, nit.sum()):7.0f}')
+        print(f'    line-search trials per iteration {T[:, 29].sum() / max(1, nit.sum()):.2f}; full-step shortcuts per iteration {T[:, 30].sum() / max(1, nit.sum()):.2f}')
+        for k in range(2, int(nit.max()) + 1):
+            sel = nit == k
+            if sel.sum():
+                print(f'    niter {k}: {sel.sum():4d} waves, solver stage {(T[sel, 9] - T[sel, 8]).mean():8.0f} cycles, per part ' + ' '.join(f'{T[sel, j].mean():7.0f}' for j in range(16, 23)) + f' | ls trials {T[sel, 29].mean():.1f} full {T[sel, 30].mean():.1f}')
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'stages':

@@ -40,7 +40,13 @@ def pmc(dirs, out_md, n_envs, bytes_per_env):
             f.write(f'\nper launch ({n_envs} envs): fetched {rd/1e6:.2f} MB (x2 corrected {2*rd/1e6:.2f} MB), written {wr/1e6:.2f} MB; '
                     f'algorithmic {alg/1e6:.2f} MB ({bytes_per_env} B/env-step). traffic (corrected) = {(2*rd+wr)/1e6:.2f} MB '
                     f'= {(2*rd+wr)/alg:.2f}x algorithmic.\n')
-            print(json.dumps({'traffic_bytes_per_launch': 2 * rd + wr, 'fetch': rd, 'write': wr}))
+            sha = None
+            for d in dirs:   # run_profiles.sh leaves the hash of the kernel sources it profiled next to the pass directories
+                h = Path(d).parent / 'kernel_src_sha16.txt'
+                if h.exists():
+                    sha = h.read_text().strip() or None
+            print(json.dumps({'traffic_bytes_per_launch': 2 * rd + wr, 'fetch': rd, 'write': wr, 'kernel_src_sha16': sha,
+                              'profile': str(out_md)}))
 
 def sq(dirs, out_md, n_envs):
     """Instruction-mix / occupancy counters of gq::step_kernel (SQ_* groups), normalised per wave (= per env-step)."""

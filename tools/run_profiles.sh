@@ -6,6 +6,7 @@ TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+(cd $ROOT && python -c "import bench; print(bench.kernel_source_hash())") > $OUT/kernel_src_sha16.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/bench_stats.json 2> $OUT/stats.log
