@@ -164,6 +164,8 @@ def main():
     ap.add_argument('--solver', choices=['newton', 'pgs'], default='newton')
     ap.add_argument('--scene', default='flat', help="headline metric: flat; box scenes (random_boxes, stairs, ...) for the secondary configs")
     ap.add_argument('--robot', default='mini_cheetah', help='headline metric: mini_cheetah; other registry robots for the secondary configs')
+    ap.add_argument('--imu', action='store_true', help='BASELINE config 5: IMU plug-in (6 observables; robots that expose accelerometer + gyro sensors)')
+    ap.add_argument('--heightmap', action='store_true', help='BASELINE config 5: a 5x5 HeightMap @ 0.1 m updated every step')
     args = ap.parse_args()
 
     from gym_quadruped_amd.sharding import aggregate_throughput, shard_plan
@@ -192,7 +194,14 @@ def main():
 
     obs_names = tuple(QuadrupedEnv.ALL_OBS) if args.obs == 'all' else QuadrupedEnv._DEFAULT_OBS
     n = args.envs_per_gpu
-    env = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device,
+    sensors, sensors_kwargs = None, None
+    if args.imu:   # examples/aliengo_with_imu.py:23-31 (noise 0.01, bias rate 0.01); sensor names per robot
+        from gym_quadruped_amd.sensors import IMU
+        names = {'hyqreal1': ('Body_Acc', 'Body_Gyro')}.get(args.robot, ('imu_acc', 'imu_gyro'))
+        sensors, sensors_kwargs = (IMU,), (dict(accel_name=names[0], gyro_name=names[1], imu_site_name='imu', accel_noise=0.01, gyro_noise=0.01,
+                                               accel_bias_rate=0.01, gyro_bias_rate=0.01, seed=1),)
+        obs_names = obs_names + IMU.ALL_OBS
+    env = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device, sensors=sensors, sensors_kwargs=sensors_kwargs,
                        auto_reset=False if (args.no_auto_reset or args.auto_reset == 'off') else args.auto_reset, solver=args.solver, solver_iterations=100, solver_tolerance=1e-8,
                        seed=1000, env_id_offset=shard.env_offset)  # shards: disjoint global env ids -> disjoint RNG counters
     env.reset(random=True)
@@ -212,6 +221,11 @@ def main():
     for _ in range(300):
         spin.normal_()
     del spin
+    hm = None
+    if args.heightmap:   # examples/aliengo_with_heightmap.py:25
+        from gym_quadruped_amd.sensors import HeightMap
+        hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)
+        yaw0 = torch.zeros(n, device=device)
     for i in range(args.warmup):
         env.step(pool[i % 64])
     # timed region: exactly K steps bracketed by barrier + synchronize
@@ -225,7 +239,9 @@ def main():
     nterm = 0
     for i in range(args.steps):
         env._profile_events = ev[i]  # HIP events around the step-kernel launch on the launch stream
-        env.step(pool[i % 64])
+        o_i = env.step(pool[i % 64])[0]
+        if hm is not None:
+            hm.update_height_map(env.qpos[:, 0:3], yaw=o_i['base_ori_euler_xyz'][:, 2] if 'base_ori_euler_xyz' in o_i else yaw0)
     env._profile_events = None
     barrier()
     dt = time.perf_counter() - t0
@@ -251,7 +267,8 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'{args.robot} {args.scene}, {n} envs/GPU, random-action rollout (50*N(0,1) torques), '
                                    f'{"ALL_OBS" if args.obs == "all" else "_DEFAULT_OBS"} ({env._obs_dim} scalars), '
-                                   f'auto-reset on termination ({env.auto_reset_mode}), sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8',
+                                   f'auto-reset on termination ({env.auto_reset_mode}), sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8'
+                                   + (', IMU plug-in' if args.imu else '') + (', 5x5 HeightMap every step' if args.heightmap else ''),
                        'envs_per_gpu': n, 'total_envs': total_envs, 'parallelism': f'env-shards x{world} (no collectives)',
                        'state_finite': finite},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

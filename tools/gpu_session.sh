@@ -20,6 +20,12 @@ for p in $PARTS; do
           timeout 600 python tools/stage_cuts.py 256 > $OUT/stage_cuts256.txt 2>&1
           timeout 600 python tools/wave_timeline.py 4096 > $OUT/wave_timeline.txt 2>&1;;
     bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err;;
+    configs) # BASELINE configs 3, 4 (one shard), 5 + PGS / default obs: driver-grade bench lines
+          timeout 600 python bench.py --robot aliengo --scene perlin --no-cpu-baseline > $OUT/bench_cfg3_aliengo_perlin.json 2> $OUT/bench_cfg3.err
+          timeout 600 python bench.py --robot go2 --no-cpu-baseline > $OUT/bench_cfg4_go2_flat.json 2> $OUT/bench_cfg4.err
+          timeout 600 python bench.py --robot hyqreal1 --scene random_boxes --imu --heightmap --no-cpu-baseline > $OUT/bench_cfg5_hyqreal1_boxes_imu_hm.json 2> $OUT/bench_cfg5.err
+          timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_like_20steps.json 2> $OUT/bench_20.err;;
+    parity) timeout 1500 python tests/reports/newton_parity_report.py 512 > $OUT/newton_parity_report.txt 2>&1;;
     nscan) timeout 900 python tools/nscan.py > $OUT/nscan.txt 2>&1;;
     profiles) timeout 2400 bash tools/run_profiles.sh $TAG > $OUT/run_profiles.txt 2>&1;;
   esac
