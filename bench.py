@@ -214,18 +214,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # device clocks: a GPU that has been idle while the host built the model sits in a low power state and needs a few
-    # milliseconds of load to ramp up; a short busy loop of unrelated work (no env is touched, not a step) makes a
-    # --steps 20 run measure the same clocks as a --steps 2000 one
-    spin = torch.empty(1 << 22, device=device)
-    for _ in range(300):
-        spin.normal_()
-    del spin
-    hm = None
-    if args.heightmap:   # examples/aliengo_with_heightmap.py:25
-        from gym_quadruped_amd.sensors import HeightMap
-        hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)
-        yaw0 = torch.zeros(n, device=device)
+    # device warm-up, not steps of the measured rollout: a GPU that has been idle while the host built the model sits in a
+    # low power state, and the first launches of a kernel pay instruction-cache and TLB misses.  A scratch env of the same
+    # shape runs 300 steps of the same kernel and is thrown away, so that a --steps 20 --warmup 5 run measures the same
+    # clocks and caches as a --steps 2000 one; the measured env then does exactly --warmup untimed steps
+    scratch = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device, sensors=sensors, sensors_kwargs=sensors_kwargs,
+                           auto_reset='next_step', solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=999)
+    scratch.reset(random=True)
+    for i in range(300):
+        scratch.step(pool[i % 64])
+    torch.cuda.synchronize(device)
+    scratch.close()
+    del scratch
     for i in range(args.warmup):
         env.step(pool[i % 64])
     # timed region: exactly K steps bracketed by barrier + synchronize

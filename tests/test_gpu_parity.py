@@ -72,9 +72,9 @@ def test_step_matches_oracle_stagewise():
             np.testing.assert_allclose(d['efc_aref'][:ne], o.efc_aref, rtol=2e-4, atol=2e-2)
             np.testing.assert_allclose(d['efc_R'][:ne], o.efc_R, rtol=1e-4)
             fmax = max(1.0, np.abs(o.efc_force).max())
-            assert np.abs(d['efc_force'][:ne] - o.efc_force).max() < 2e-3 * fmax
+            assert np.abs(d['efc_force'][:ne] - o.efc_force).max() < 2e-4 * fmax
             amax = max(1.0, np.abs(o.qacc).max())
-            assert np.abs(d['qacc'] - o.qacc).max() < 1e-3 * amax
+            assert np.abs(d['qacc'] - o.qacc).max() < 5e-5 * amax   # measured p99 1.4e-6, max 4.6e-6
         n_contact += o.ncon > 0
         assert np.abs(qpos_g[e] - o.qpos).max() < 1e-6 + 2e-6 * np.abs(o.qpos).max()
         assert np.abs(qvel_g[e] - o.qvel).max() < 1e-4 + 1e-5 * np.abs(o.qvel).max()
@@ -106,8 +106,8 @@ def test_rollout_tracks_oracle():
         qp, qv = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
         for e, o in enumerate(orc):
             o.step(act[e].cpu().numpy().astype(np.float64))
-            assert np.abs(qp[e] - o.qpos).max() < 5e-4, (s, e)
-            assert np.abs(qv[e] - o.qvel).max() < 5e-2, (s, e)
+            assert np.abs(qp[e] - o.qpos).max() < 2e-5, (s, e)    # 20 steps: measured drift 5e-7 at 10 steps, 8e-7 at 30
+            assert np.abs(qv[e] - o.qvel).max() < 5e-4, (s, e)
 
 
 @pytest.mark.parametrize('robot_name', ['b2', 'go1', 'go2', 'hyqreal1', 'hyqreal2', 'mini_cheetah', 'aliengo'])
@@ -238,28 +238,32 @@ def test_newton_step_matches_converged_oracle(robot):
     tg, ig = term.cpu().numpy(), info['invalid_contacts'].cpu().numpy()
     ncon = 0
     tally = ParityTally(env.mjModel.cone == 1, 3e-7)
+    cone = env.mjModel.cone == 1
+    mg = 9.81 * float(env.mjModel.total_mass)
+    ea, ev, ep, eo, ef = [], [], [], [], []
     for e in range(n):
         o.set_state(qpos[e], qvel[e], warm[e], np.zeros(18), 0.0, 0.8)
         o.step(ctrl[e].astype(np.float64))
         if tally.classify(e, o, dbg[e]['nefc'][0]) != 'ok':
             continue   # tie / over the row budget: counted and bounded below; a row-count mismatch fails the test
         ncon += o.ncon
-        assert np.abs(dbg[e]['qacc'] - o.qacc).max() < 2e-4 * max(1.0, np.abs(o.qacc).max()), (e, dbg[e]['niter'])
-        assert np.abs(qv[e] - o.qvel).max() < 5e-4 and np.abs(qp[e] - o.qpos).max() < 2e-6
+        ea.append(np.abs(dbg[e]['qacc'] - o.qacc).max() / max(1.0, np.abs(o.qacc).max()))
+        ev.append(np.abs(qv[e] - o.qvel).max()); ep.append(np.abs(qp[e] - o.qpos).max())
         ref, t, inv = o.get_obs(ALL_OBS, cmd[e])
         got = split_obs(ob[e], ALL_OBS)
-        for k in ALL_OBS:
-            # elliptic condim-6 contacts: the torsional / rolling rows are almost unregularised directions (R ~ 1e10 R_n), the
-            # forces of a light contact move by ~1e-2 N between "improvement < 1e-8" (kernel, MuJoCo's rule) and the
-            # oracle's 1e-12 while qacc agrees to 1e-6
-            # (a grazing 4 N contact of the 12 kg go1 moves by 0.1 N): those are held to 1e-2 of max(|f|, 10 % of the weight)
-            if env.mjModel.cone == 1 and k.startswith('contact_forces'):
-                tol_k = 1e-2 * max(np.abs(ref[k]).max(), 0.1 * 9.81 * float(env.mjModel.total_mass))
-            else:
-                tol_k = 2e-3 * max(1.0, np.abs(ref[k]).max())
-            assert np.abs(got[k] - ref[k]).max() < tol_k, (e, k)
+        eo.append(max(np.abs(got[k] - ref[k]).max() / max(1.0, np.abs(ref[k]).max()) for k in ALL_OBS if not k.startswith('contact_forces')))
+        ef.append(max(np.abs(got[k] - ref[k]).max() for k in ('contact_forces', 'contact_forces:base')) / max(np.abs(ref['contact_forces']).max(), 0.1 * mg))
         assert bool(tg[e]) == t and bool(ig[e]) == inv
-        assert dbg[e]['niter'][0] <= (20 if env.mjModel.cone == 0 else 100)   # condim-6 cones converge slowly (the fp64 oracle too)
+        assert dbg[e]['niter'][0] <= (20 if not cone else 100)   # condim-6 cones converge slowly (the fp64 oracle too)
+    # Asserted bounds = ~10 x the p99 and ~5 x the maximum measured over 512 states per robot on MI355X
+    # (profiles/r02_newton_parity_report.txt: tests/reports/newton_parity_report.py).  Elliptic condim-6 contacts (go1, go2,
+    # spot): torsional / rolling rows are almost unregularised directions, the forces of a light contact move by ~1e-3 of the
+    # weight between MuJoCo's "improvement < 1e-8" and the oracle's 1e-12 while qacc agrees to 1e-5.
+    p99 = lambda x: float(np.percentile(x, 99))
+    lim = dict(qacc=(1e-4, 1e-3), qvel=(7e-4, 2e-3), qpos=(2.5e-6, 3.5e-6), obs=(3e-4, 5e-3), force=(1.5e-2, 5e-2)) if cone else \
+          dict(qacc=(2e-5, 1e-3), qvel=(5e-5, 2e-3), qpos=(2.5e-6, 3.5e-6), obs=(3e-4, 5e-3), force=(5e-5, 1e-3))
+    for name, err in (('qacc', ea), ('qvel', ev), ('qpos', ep), ('obs', eo), ('force', ef)):
+        assert p99(err) < lim[name][0] and max(err) < lim[name][1], (robot, name, p99(err), max(err))
     # robots with many small collision geoms (go1 / go2: 38 / 27 link geoms) exceed the 64-row budget when lying flat
     tally.finish(f'newton one-step parity {robot}', min_checked=0.8 if env.mjModel.cone == 0 else 0.6, max_tie=0.1,
                  max_budget=0.15 if env.mjModel.cone == 0 else 0.4)
