@@ -49,6 +49,7 @@ class GqModelDesc(C.Structure):
         ('hfield_friction', C.c_double * 3), ('hfield_margin', C.c_double), ('hfield_gap', C.c_double),
         ('hfield_solmix', C.c_double), ('hfield_solref', C.c_double * 2), ('hfield_solimp', C.c_double * 5),
         ('hfield_condim', C.c_int32), ('hfield_priority', C.c_int32),
+        ('nselfpair', C.c_int32), ('selfpair_geom1', _I), ('selfpair_geom2', _I), ('geom_capsule', _D),
     ]
 
 
@@ -103,7 +104,7 @@ class MarshalledModel:
 
     def __init__(self, md: ModelDesc, *, qpos0=None, feet_geom_names=None, terrain_limits=(1e4, -1e4, 1e4, -1e4),
                  timestep=None, solver=SOLVER_PGS, iterations=100, tolerance=1e-8, floor=None,
-                 noise_floor=0.0, boxes=None, hfield=None):
+                 noise_floor=0.0, boxes=None, hfield=None, self_collision=None):
         self.md = md
         self._keep = []
         d = GqModelDesc()
@@ -125,6 +126,13 @@ class MarshalledModel:
             box_condim=[b['condim'] for b in boxes], box_priority=[b['priority'] for b in boxes])
         d.nbox = len(boxes)
         self.boxes = boxes
+        from .selfcol import geom_capsules, self_pairs
+        if self_collision is None:   # MuJoCo's behaviour (robot geoms collide with each other) wherever the solver supports it
+            self_collision = int(solver) == SOLVER_NEWTON
+        pairs = self_pairs(md) if self_collision else np.zeros((0, 2), np.int32)
+        box_arrays.update(selfpair_geom1=pairs[:, 0], selfpair_geom2=pairs[:, 1], geom_capsule=geom_capsules(md))
+        d.nselfpair = int(len(pairs))
+        self.self_pairs = pairs
         for name, ctype in GqModelDesc._fields_:
             if ctype in (_I, _D):
                 src = q0 if name == 'qpos0' else (box_arrays[name] if name in box_arrays else getattr(md, name))

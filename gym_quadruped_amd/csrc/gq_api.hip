@@ -277,7 +277,7 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
   gq::StepCall c{};
   c.ctrl = ctrl; c.mask = mask; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
   c.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; c.first_pass = 0; c.stop_stage = b->stop_stage;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0 || b->model->host.nbp > 0), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }
@@ -294,14 +294,14 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   fill_reset_args(&r, b, mask, qpos_new, qvel_new, cfg, st, out, episode, lift_failed);
   r.clear_terminated = out.terminated; r.clear_truncated = out.truncated; r.clear_invalid = out.invalid_contact;
   r.lift_pending = b->lift_pending;
-  gq_launch_reset(&r, b->host.n_envs, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (hipStream_t)hip_stream);
+  gq_launch_reset(&r, b->host.n_envs, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0 || b->model->host.nbp > 0), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */
   const int rc = ensure_args(b, st, out, episode, lift_failed, nullptr, (hipStream_t)hip_stream);
   if (rc != GQ_OK) return rc;
   gq::StepCall c{};
   c.mask = mask; c.first_pass = 1; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0 || b->model->host.nbp > 0), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

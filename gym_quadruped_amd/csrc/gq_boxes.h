@@ -341,7 +341,7 @@ __device__ inline bool hfield_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m
 }
 
 /* running totals of the contact list while world geoms are appended to it */
-struct WorldAppend { int ncon, rows, invalid, reserve, ft[4]; };
+struct WorldAppend { int ncon, rows, invalid, reserve, ft[4], nself; };
 
 /* append the contacts of the collision items (lane = position in con_order: dist / nrm / pt) with one world geom of
  * contact-parameter class cls; rows / row budget as in the floor pass.  No barrier inside. */
@@ -393,6 +393,127 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
   if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
 }
 
+/* closest points of the segments p1 + s d1 and p2 + t d2, s, t in [0, 1] (Ericson, Real-Time Collision Detection 5.1.9;
+ * restated identically in oracle/gq_oracle.c::closest_seg_seg); degenerate segments (spheres) included */
+__device__ __forceinline__ void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
+  const V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+  const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), EPS = 1e-12f;
+  float s, t;
+  if (a <= EPS && e <= EPS) { s = 0.0f; t = 0.0f; }
+  else if (a <= EPS) { s = 0.0f; t = med3(f / e, 0.0f, 1.0f); }
+  else {
+    const float c = dot(d1, r);
+    if (e <= EPS) { t = 0.0f; s = med3(-c / a, 0.0f, 1.0f); }
+    else {
+      const float b = dot(d1, d2), den = a * e - b * b;
+      s = den > 1e-6f * a * e ? med3((b * f - c * e) / den, 0.0f, 1.0f) : 0.0f; /* (nearly) parallel: any s will do; 0 */
+      t = (b * s + f) / e;
+      if (t < 0.0f) { t = 0.0f; s = med3(-c / a, 0.0f, 1.0f); }
+      else if (t > 1.0f) { t = 1.0f; s = med3((b - c) / a, 0.0f, 1.0f); }
+    }
+  }
+  c1 = p1 + s * d1; c2 = p2 + t * d2;
+}
+
+/* contact frame word of a robot-robot contact: con_body = body2 | (body1 + 1) << 8, con_geom = item2 | (item1 + 1) << 8
+ * (the high byte is 0 for contacts with a world geom); world class -2 */
+#define GQ_CON_BODY2(x) ((x) & 0xff)
+#define GQ_CON_BODY1(x) (((x) >> 8) - 1)   /* -1: world */
+#define GQ_WCLS_SELF (-2)
+
+/* S6, robot self-collision (mj_collision between two bodies of the robot; gym_quadruped_amd/selfcol.py has the pair
+ * filter and the capsule proxies).  Broad phase: lane = body pair, bounding spheres of the bodies' proxies (two ballots
+ * for <= 66 pairs).  Narrow phase per near body pair (wave-uniform loop): lane = geom pair, closest points of the two
+ * capsule axes; one contact per pair, normal from geom1 to geom2, point midway between the surfaces.  Contacts are
+ * appended after the world contacts in (body pair, geom1, geom2) order - MuJoCo's order - under the same row budget, capped at
+ * GQ_SELF_ROWS rows so that the dense Newton Hessian of such an env fits above them. */
+template <bool CONE>
+__device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S) {
+  const int lane = lane_id();
+  const int nbp = m.nbp;
+  if (nbp == 0) return;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint64_t near[2];
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const int p = half * GQ_WAVE + lane;
+    bool nr = false;
+    if (p < nbp) {
+      const GQ_MODEL GqDevBodyPair& P = m.bp[p];
+      const V3 c1 = ld3(W.xpos[P.b1]) + matvec(W.xmat[P.b1], ld3(m.body_sph[P.b1]));
+      const V3 c2 = ld3(W.xpos[P.b2]) + matvec(W.xmat[P.b2], ld3(m.body_sph[P.b2]));
+      const V3 d = c2 - c1;
+      const float rr = m.body_sph[P.b1][3] + m.body_sph[P.b2][3] + m.self_margin;
+      nr = dot(d, d) < rr * rr;
+    }
+    near[half] = ballot(nr);
+  }
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    uint64_t todo = near[half];
+    while (todo) { /* wave-uniform */
+      const int p = half * GQ_WAVE + ffs64(todo);
+      todo &= todo - 1;
+      const GQ_MODEL GqDevBodyPair& P = m.bp[p];
+      const int b1 = P.b1, b2 = P.b2;
+      bool touching = false;
+      float dist = 0.0f, mu = 0.0f;
+      V3 nrm = v3(0.0f, 0.0f, 1.0f), pt = v3(0.0f, 0.0f, 0.0f);
+      int it1 = 0, it2 = 0, dim = 3;
+      const GQ_MODEL GqDevSelfPair* sp = &m.sp[P.first];
+      if (lane < P.count) {
+        sp = &m.sp[P.first + lane];
+        it1 = sp->it1; it2 = sp->it2; dim = sp->mix.dim;
+        const GQ_MODEL float* k1 = m.item_caps[it1];
+        const GQ_MODEL float* k2 = m.item_caps[it2];
+        const V3 o1 = ld3(W.xpos[b1]), o2 = ld3(W.xpos[b2]);
+        const V3 a0 = o1 + matvec(W.xmat[b1], ld3(k1)), a1 = o1 + matvec(W.xmat[b1], ld3(k1 + 3));
+        const V3 e0 = o2 + matvec(W.xmat[b2], ld3(k2)), e1 = o2 + matvec(W.xmat[b2], ld3(k2 + 3));
+        V3 c1, c2;
+        closest_seg_seg(a0, a1, e0, e1, c1, c2);
+        const V3 d = c2 - c1;
+        const float l2 = dot(d, d), len = sqrtf(l2);
+        dist = len - k1[6] - k2[6];
+        touching = dist < sp->mix.margin && len >= 1e-9f;
+        if (touching) {
+          nrm = (1.0f / len) * d;
+          pt = c1 + (k1[6] + 0.5f * dist) * nrm;
+          /* sliding friction: _set_ground_friction rewrites the feet (quadruped_env.py:1277-1298) */
+          const float f1 = it1 < 4 ? (mu_env >= 0.0f ? mu_env : m.foot_friction[it1][0]) : m.lg[it1 - 4].friction[0];
+          const float f2 = it2 < 4 ? (mu_env >= 0.0f ? mu_env : m.foot_friction[it2][0]) : m.lg[it2 - 4].friction[0];
+          mu = fmaxf(1e-5f, sp->mix.rule == 0 ? fmaxf(f1, f2) : (sp->mix.rule == 1 ? f1 : f2));
+        }
+      }
+      const uint64_t touch_mask = ballot(touching);
+      if (touch_mask == 0) continue;
+      int& ncon = S.ncon; int& rows = S.rows; int& reserve = S.reserve;
+      const int idx = ncon + popc64(touch_mask & lt);
+      const bool kept = touching && idx < GQ_MAXCON;
+      const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
+      const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4), m6 = ballot(kept && need == 6);
+      const int row0 = rows + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
+      const int res = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) + (need > 1 ? need - 1 : 0) : 0;
+      const bool fits = kept && row0 + need + res <= GQ_SELF_ROWS;
+      const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4), f6 = ballot(fits && need == 6);
+      if (fits) {
+        W.con_geom[idx] = it2 | ((it1 + 1) << 8) | (sp->mix.rule << 16); W.con_body[idx] = b2 | ((b1 + 1) << 8); W.con_dim[idx] = dim; W.con_row[idx] = row0;
+        W.con_dist[idx] = dist; W.con_inc[idx] = sp->mix.includemargin; W.con_mu[idx] = mu;
+        st3(W.con_pos[idx], pt);
+        W.con_solref[idx][0] = sp->mix.solref[0]; W.con_solref[idx][1] = sp->mix.solref[1];
+#pragma unroll
+        for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = sp->mix.solimp[q];
+        st3(GQ_BX_CONNRM(W) + 3 * idx, nrm);
+        GQ_BX_WCLS(W)[idx] = GQ_WCLS_SELF;
+      }
+      const int added = popc64(f1 | f3 | f4 | f6);
+      ncon += added;
+      rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
+      if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
+      S.nself += added;
+    }
+  }
+}
+
 /* S6 (BOXES): append the contacts with the world boxes to the list the floor pass left in W (ncon, nefc, invalid,
  * foot_touch are updated; rows / row budget as in the floor pass).  Ends with a barrier. */
 template <bool CONE>
@@ -400,7 +521,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
                                           double bx, double by, float mu_env) {
   const int lane = lane_id();
   WorldAppend S;
-  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0;
+  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) S.ft[k] = uniform(W.foot_touch[k]);
   const int ncon = S.ncon;
@@ -433,8 +554,9 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
       wave_barrier();
     }
   }
+  append_self_contacts<CONE>(W, m, mu_env, S);
   if (lane == 0) {
-    W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid;
+    W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself;
 #pragma unroll
     for (int k = 0; k < 4; k++) W.foot_touch[k] = S.ft[k];
   }

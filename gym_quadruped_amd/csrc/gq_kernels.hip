@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __res
   int pass = c.first_pass;
   bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[blockIdx.x]; /* wave-uniform */
   /* the reset's own step after an explicit gq_reset: the reset kernel left word whether the lift loop is still due */
-  int lift = (!BOXES && c.first_pass && A->s.lift_pending) ? (int)gptr(A->s.lift_pending)[blockIdx.x] : 0;
+  int lift = (c.first_pass && A->s.lift_pending) ? (int)gptr(A->s.lift_pending)[blockIdx.x] : 0;
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
       wave_priority(3); /* reset + step in one launch: this wave is the longest of its SIMD */

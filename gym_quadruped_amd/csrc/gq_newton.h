@@ -250,6 +250,40 @@ __device__ inline void solve_tree_fused(const float (*Sc)[9], const float (*Sb)[
   wave_barrier();
 }
 
+/* out <- H^-1 g for a DENSE symmetric positive definite 18 x 18 matrix given as its packed lower triangle Hd (LDS, entry
+ * (i, j <= i) at i (i + 1) / 2 + j): the Newton step of an env whose contacts couple two legs (robot self-collision), where
+ * M + J'DJ has lost the tree sparsity the fused elimination relies on.  Lane i < 18 holds row i in registers; Gaussian
+ * elimination without pivoting (the matrix is SPD), the pivot row broadcast with v_readlane, every lane below the pivot
+ * updating its own row at once; back substitution the same way.  ~480 VALU, no LDS inside the elimination. */
+__device__ inline void solve_dense_lanes(const float* Hd, const float* g, float* out) {
+  const int lane = lane_id();
+  const int i = lane < GQ_NVD ? lane : 0; /* lanes >= 18 mirror row 0 and are discarded */
+  float row[GQ_NVD], b = g[i];
+#pragma unroll
+  for (int j = 0; j < GQ_NVD; j++) {
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    row[j] = Hd[hi * (hi + 1) / 2 + lo];
+  }
+#pragma unroll
+  for (int k = 0; k < GQ_NVD - 1; k++) {
+    const float inv = fast_rcp(bcast(row[k], k));
+    const float f = lane > k ? row[k] * inv : 0.0f;
+    b -= f * bcast(b, k);
+#pragma unroll
+    for (int j = k + 1; j < GQ_NVD; j++) row[j] -= f * bcast(row[j], k);
+  }
+  float x = 0.0f;
+#pragma unroll
+  for (int k = GQ_NVD - 1; k >= 0; k--) {
+    const float xk = bcast(b, k) * fast_rcp(bcast(row[k], k));
+    x = lane == k ? xk : x;
+    b -= lane < k ? row[k] * xk : 0.0f;
+  }
+  wave_barrier(); /* g may alias out */
+  if (lane < GQ_NVD) out[lane] = x;
+  wave_barrier();
+}
+
 /* single right-hand side solve, leg-parallel: out <- (L'DL)^-1 g ; g, out: LDS [18] (may alias) */
 __device__ inline void solve_tree_one(WaveMem& W, const float* F, const float* g, float* out) {
   const int lane = lane_id();
@@ -402,7 +436,8 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
 #endif
 template <bool DBG, bool CONE>
 __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, int rtype, float rR, float raref,
-                                     float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg, const EllRow E, int prio) {
+                                     float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg, const EllRow E, int prio,
+                                     const bool xleg) {
   const int lane = lane_id();
   /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */
   /* (each use goes through opaque_ptr: otherwise the compiler merges the re-reads, keeps the 18 values live across the
@@ -574,6 +609,33 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     /* ---- Hessian in M's tree-sparse layout: H = M + sum_r w_r J_r' J_r.  117 structurally non-zero entries, two
      * passes of one entry per lane.  Friction-loss rows are +-e_dof: their weight goes straight to the diagonal; limit
      * rows (few) and contact rows are walked generically. */
+    if (xleg) { /* wave-uniform: dense Hessian (packed lower triangle above the rows, GQ_SELF_ROWS) and the lane-parallel dense solve */
+      float* Hd = &W.u.B[GQ_SELF_ROWS][0];
+      for (int pass = 0; pass < 3; pass++) {
+        const int e = pass * GQ_WAVE + lane;
+        if (e < GQ_NVD * (GQ_NVD + 1) / 2) {
+          int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+          if ((i + 1) * (i + 2) / 2 <= e) i++;
+          if (i * (i + 1) / 2 > e) i--;
+          const int j = e - i * (i + 1) / 2;
+          float s0 = 0.0f, s1 = 0.0f;
+          if (i < 6) s0 = W.Mb[i][j];
+          else if (j < 6) s0 = W.Mc[i - 6][j];
+          else if ((i - 6) / 3 == (j - 6) / 3) s0 = W.Mc[i - 6][6 + (j - 6) % 3];
+          if (i == j) { const int fr = m.fl_row_of_dof[i]; if (fr >= 0) s0 += W.force[fr]; }
+          int r = nfl;
+          for (; r + 2 <= nrowh; r += 2) {
+            s0 += W.force[r] * W.u.B[r][i] * W.u.B[r][j];
+            s1 += W.force[r + 1] * W.u.B[r + 1][i] * W.u.B[r + 1][j];
+          }
+          if (r < nrowh) s0 += W.force[r] * W.u.B[r][i] * W.u.B[r][j];
+          Hd[e] = s0 + s1;
+        }
+      }
+      wave_barrier();
+      NW_T(3);
+      solve_dense_lanes(Hd, grad, search);
+    } else {
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       if (hent[pass] >= 0) {
@@ -611,6 +673,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     wave_barrier();
     NW_T(3);
     solve_tree_fused<false>(W.u2.n.Hc, W.u2.n.Hb, nullptr, 0.0f, grad, search);
+    }
     NW_T(4);
     /* ---- exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on phi' */
     float v = 0.0f;

@@ -412,7 +412,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
    * kinematics and collision scan just produced, instead of on a kinematics + scan pass of its own inside reset_wave: on
    * the flat floor a lift by dz moves every distance by dz and leaves everything that S2-S5 computed (all of it relative
    * to the base origin) untouched, so the reset's mj_step simply continues from the lifted pose */
-  if constexpr (!BOXES) if (lift) { /* wave-uniform */
+  if (lift) { /* wave-uniform; only set on scenes without world boxes / height field */
     float dist = 1e30f, margin = 0.0f;
     if (lane < 4) { dist = W.foot_world[lane][2] - m.foot_radius[lane]; margin = m.foot_margin[lane]; }
     else if (lane - 4 < nlg) {
@@ -549,6 +549,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   int ecode = 0, er0 = lane;
   float efri = 0.0f, emu = 0.0f, eR0 = 1.0f, econ_dist = 0.0f, econ_inc = 0.0f;
   int jd = -1, jleg = -1, jdepth = -1;   /* single-entry rows: dof index; contact rows: leg / depth of the body (-1: base) */
+  int jleg1 = -1, jdepth1 = -1;          /* robot-robot contacts (BOXES variants): chain of the contact's FIRST body, entering J with a minus sign */
+  bool internal = false;
   float jsgn = 0.0f;
   bool jcon = false;
   V3 dir = v3(0.0f, 0.0f, 0.0f), w = v3(0.0f, 0.0f, 0.0f);
@@ -566,13 +568,20 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     int c = 0;
     for (int q = 1; q < ncon; q++)
       if (lane >= W.con_row[q]) c = q;
-    const int e = lane - W.con_row[c], dim = W.con_dim[c], body = W.con_body[c];
+    const int e = lane - W.con_row[c], dim = W.con_dim[c];
+    int body = W.con_body[c], body1 = -1;
+    if constexpr (BOXES) { body1 = GQ_CON_BODY1(body); body = GQ_CON_BODY2(body); }
     const float mu = W.con_mu[c];
     rpos = W.con_dist[c]; rmargin = W.con_inc[c];
     rsolref[0] = W.con_solref[c][0]; rsolref[1] = W.con_solref[c][1];
 #pragma unroll
     for (int q = 0; q < 5; q++) rsolimp[q] = W.con_solimp[c][q];
-    const float tran = m.body_invweight0[body][0];
+    float tran = m.body_invweight0[body][0], rotw = m.body_invweight0[body][1];
+    if constexpr (BOXES) if (body1 >= 0) { /* contact between two bodies of the robot: both bodies' weights (mj_makeConstraint) */
+      tran += m.body_invweight0[body1][0]; rotw += m.body_invweight0[body1][1];
+      internal = true;
+      if (body1 > 0) { jleg1 = (body1 - 1) / 3; jdepth1 = (body1 - 1) % 3; }
+    }
     /* contact frame (mju_makeFrame): horizontal floor n = z, t1 = y, t2 = -x; box contacts bring their own normal */
     V3 cn = v3(0.0f, 0.0f, 1.0f), ct1 = v3(0.0f, 1.0f, 0.0f), ct2 = v3(-1.0f, 0.0f, 0.0f);
     if constexpr (BOXES) { cn = ld3(GQ_BX_CONNRM(W) + 3 * c); make_frame(cn, ct1, ct2); }
@@ -585,15 +594,19 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       emu = mu / sqrtf(m.impratio);
       /* torsional / rolling coefficients: same mixing rule as the sliding one (S6), _set_ground_friction overrides
        * floor and feet with [mu, 0.005, 0.0]; clamped at mjMINMU */
-      const int code = W.con_geom[c];
+      const int cword = W.con_geom[c], code = BOXES ? (cword & 0xff) : cword, code1 = BOXES ? ((cword >> 8) & 0xff) - 1 : -1;
       const float mu_env = W.mu_env;
-      const int rule = code < 4 ? m.foot_fric_rule[code] : m.lg[code - 4].fric_rule;
+      const int rule = code1 >= 0 ? (cword >> 16) & 3 : (code < 4 ? m.foot_fric_rule[code] : m.lg[code - 4].fric_rule);
       float fr[3] = {mu, 0.0f, 0.0f};
 #pragma unroll
       for (int q = 1; q < 3; q++) {
         const float ovr = q == 1 ? 0.005f : 0.0f;
         float ff = mu_env >= 0.0f ? ovr : m.floor_friction[q];
-        if constexpr (BOXES) { const int wc = GQ_BX_WCLS(W)[c]; if (wc >= 0) ff = m.boxcls_friction[wc][q]; }
+        if constexpr (BOXES) {
+          const int wc = GQ_BX_WCLS(W)[c];
+          if (wc >= 0) ff = m.boxcls_friction[wc][q];
+          if (code1 >= 0) ff = code1 < 4 ? (mu_env >= 0.0f ? ovr : m.foot_friction[code1][q]) : m.lg[code1 - 4].friction[q]; /* the contact's first geom is a robot geom */
+        }
         const float fg = code < 4 ? (mu_env >= 0.0f ? ovr : m.foot_friction[code][q]) : m.lg[code - 4].friction[q];
         fr[q] = fmaxf(1e-5f, rule == 0 ? fmaxf(ff, fg) : (rule == 1 ? ff : fg));
       }
@@ -601,7 +614,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       rotational = e >= 3;
       const int ax = e % 3; /* 0: n, 1: t1, 2: t2 */
       dir = ax == 0 ? cn : (ax == 1 ? ct1 : ct2);
-      rdiag = rotational ? m.body_invweight0[body][1] : tran;
+      rdiag = rotational ? rotw : tran;
       rdiag_first = tran;                                   /* R of the contact's normal row */
       if (e > 0) { rpos = 0.0f; rmargin = 0.0f; }           /* friction rows carry no penetration */
     } else {
@@ -623,7 +636,15 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   for (int k = 0; k < GQ_NVD; k++) {
     const float* sd = W.cdof[k]; /* wave-uniform LDS reads */
     float v = sd[0] * w.x + sd[1] * w.y + sd[2] * w.z + sd[3] * dir.x + sd[4] * dir.y + sd[5] * dir.z;
-    const bool on_chain = k < 6 ? jcon : (jcon && (k - 6) / 3 == jleg && (k - 6) % 3 <= jdepth);
+    bool on_chain = k < 6 ? jcon : (jcon && (k - 6) / 3 == jleg && (k - 6) % 3 <= jdepth);
+    if constexpr (BOXES) { /* J(second body) - J(first body) at the contact point: the base columns cancel, shared ancestors too */
+      if (k < 6) on_chain = on_chain && !internal;
+      else {
+        const bool on1 = internal && (k - 6) / 3 == jleg1 && (k - 6) % 3 <= jdepth1;
+        v = (on_chain ? v : 0.0f) - (on1 ? v : 0.0f);
+        on_chain = on_chain || on1;
+      }
+    }
     v = on_chain ? v : (k == jd ? jsgn : 0.0f);
     vel += v * W.qvel[k];
     if constexpr (SOLVER == 1) W.u.B[lane][k] = v; /* rows >= nefc are all-zero: rtype NONE sets no descriptor */
@@ -663,8 +684,11 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
     GQ_TICK(8);
     const EllRow ell = {ecode, er0, efri, emu, 1.0f / eR0};
+    /* a contact between two different legs couples them in the Hessian M + J'DJ, which then no longer has M's tree
+     * sparsity: such an env takes the dense Newton step */
+    const bool xleg = BOXES && ballot(internal && jleg1 >= 0 && jleg >= 0 && jleg1 != jleg) != 0;
     const float fN = newton_solve<DBG, CONE>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
-                                  timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint);
+                                  timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint, xleg);
     if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)(iter < 2 ? 0 : (iter > 2 ? 3 : 2));
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
@@ -1151,8 +1175,9 @@ __device__ inline int reset_wave(const ResetArgs& a, WaveMem& W) {
   int failed = 0;
   /* scenes without world boxes / height field: the lift loop runs inside the reset's own mj_step (step_wave, S6) on that
    * step's kinematics and collision scan - this function only writes the spawn state and says that a lift is due */
-  const int lift_due = (!BOXES && !explicit_state) ? 1 : 0;
-  if (BOXES && !explicit_state) {
+  const bool flat_scene = !BOXES || (m.nbox == 0 && m.hf_nrow == 0); /* BOXES variants also serve flat scenes with robot self-collision */
+  const int lift_due = (flat_scene && !explicit_state) ? 1 : 0;
+  if (!flat_scene && !explicit_state) {
     stage_kinematics(W, m);
     wave_barrier();
     stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), true);

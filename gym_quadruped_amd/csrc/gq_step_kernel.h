@@ -111,6 +111,7 @@ struct WaveMem {
   float bias[18], act[18], smooth[18], qacc_smooth[18], qfrc_c[18], qacc[18], qacc_int[18];
   /* contacts */
   int32_t ncon, nefc, nlim, invalid;
+  int32_t nself;               /* number of robot-robot contacts in the list (S6, BOXES variants) */
   int32_t foot_touch[4];
   int32_t con_geom[GQ_MAXCON], con_body[GQ_MAXCON], con_dim[GQ_MAXCON], con_row[GQ_MAXCON];
   float con_dist[GQ_MAXCON], con_pos[GQ_MAXCON][3], con_mu[GQ_MAXCON], con_inc[GQ_MAXCON];

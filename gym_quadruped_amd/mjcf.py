@@ -269,6 +269,9 @@ class ModelDesc:
     # statistics
     meaninertia: float
     total_mass: float
+    # <contact><exclude body1= body2=/> pairs (body ids)
+    exclude_body1: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0, np.int32))
+    exclude_body2: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0, np.int32))
 
     # ---- (de)serialisation: plain JSON tables
     def to_json(self) -> str:
@@ -287,6 +290,8 @@ class ModelDesc:
         d = json.loads(text)
         kw = {}
         for f in dataclasses.fields(cls):
+            if f.name not in d:   # field added after the table was written: dataclass default
+                continue
             v = d[f.name]
             if isinstance(v, dict) and 'dtype' in v:
                 v = np.asarray(v['data'], dtype=np.int32 if v['dtype'] == 'i4' else np.float64).reshape(v['shape'])
@@ -434,6 +439,8 @@ class _Compiler:
             sensors=sensors,
             key_qpos=arr(key_qpos).reshape(len(key_qpos), self.nq) if key_qpos else np.zeros((0, self.nq)),
             key_names=key_names, meaninertia=0.0, total_mass=float(np.sum(B['mass'])),
+            exclude_body1=arr([B['names'].index(e.attrib['body1']) for c in root.findall('contact') for e in c.findall('exclude')], np.int32),
+            exclude_body2=arr([B['names'].index(e.attrib['body2']) for c in root.findall('contact') for e in c.findall('exclude')], np.int32),
         )
         set_const(md)
         return md

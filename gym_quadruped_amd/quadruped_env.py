@@ -81,6 +81,7 @@ class QuadrupedEnv(AccessorsMixin):
         mjcf_path: str | None = None,
         env_id_offset: int = 0,
         accessors: bool = False,
+        self_collision: bool | None = None,
     ):
         self._save_hyperparameters(constructor_params=locals().copy())
         log.info(f'Initializing {robot} environment with scene {scene}.')
@@ -115,7 +116,7 @@ class QuadrupedEnv(AccessorsMixin):
                                    terrain_limits=self.terrain_limits, timestep=sim_dt, solver={'pgs': 0, 'newton': 1}[solver],
                                    iterations=solver_iterations, tolerance=solver_tolerance, noise_floor=solver_noise_floor,
                                    floor=self.scene_desc.get('floor'), boxes=self.scene_desc.get('boxes'),
-                                   hfield=self.scene_desc.get('hfield'))
+                                   hfield=self.scene_desc.get('hfield'), self_collision=self_collision)
         self._sim_dt = float(sim_dt)
 
         # leg index maps (reference :189-212)

@@ -54,6 +54,7 @@ typedef struct {
   double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
   double tiegap; /* depth gap to the second deepest vertex of the geom's cloud (test diagnostics) */
   int geom, body, dim, efc_address;
+  int geom1, body1; /* the other geom: -1 / 0 for a world geom (floor, box, height field), else a robot geom and its body */
 } Contact;
 
 typedef struct GqOracle {
@@ -452,6 +453,66 @@ static void contact_param(const GqOracle* o, int w, int g, Contact* c) {
 }
 
 
+/* mj_contactParam for two ROBOT geoms g1 < g2 (self-collision) */
+static void contact_param_pair(const GqOracle* o, int g1, int g2, Contact* c) {
+  const GqModelDesc* m = &o->d;
+  double f1[3], f2[3], fri[3];
+  memcpy(f1, m->geom_friction + 3 * g1, sizeof f1); memcpy(f2, m->geom_friction + 3 * g2, sizeof f2);
+  if (o->friction >= 0) { /* _set_ground_friction rewrites the feet geoms (quadruped_env.py:1277-1298) */
+    if (is_foot(m, g1)) { f1[0] = o->friction; f1[1] = 0.005; f1[2] = 0.0; }
+    if (is_foot(m, g2)) { f2[0] = o->friction; f2[1] = 0.005; f2[2] = 0.0; }
+  }
+  const int p1 = m->geom_priority[g1], p2 = m->geom_priority[g2];
+  if (p1 == p2) {
+    c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+    for (int k = 0; k < 3; k++) fri[k] = f1[k] > f2[k] ? f1[k] : f2[k];
+    double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2], mix;
+    if (s1 >= MINVAL && s2 >= MINVAL) mix = s1 / (s1 + s2);
+    else if (s1 < MINVAL && s2 < MINVAL) mix = 0.5;
+    else mix = s1 < MINVAL ? 0.0 : 1.0;
+    const double* r1 = m->geom_solref + 2 * g1; const double* r2 = m->geom_solref + 2 * g2;
+    if (r1[0] > 0 && r2[0] > 0)
+      for (int k = 0; k < 2; k++) c->solref[k] = mix * r1[k] + (1 - mix) * r2[k];
+    else
+      for (int k = 0; k < 2; k++) c->solref[k] = r1[k] < r2[k] ? r1[k] : r2[k];
+    for (int k = 0; k < 5; k++) c->solimp[k] = mix * m->geom_solimp[5 * g1 + k] + (1 - mix) * m->geom_solimp[5 * g2 + k];
+  } else {
+    const int g = p1 > p2 ? g1 : g2;
+    c->dim = m->geom_condim[g];
+    memcpy(fri, p1 > p2 ? f1 : f2, sizeof fri);
+    memcpy(c->solref, m->geom_solref + 2 * g, sizeof c->solref);
+    memcpy(c->solimp, m->geom_solimp + 5 * g, sizeof c->solimp);
+  }
+  c->friction[0] = c->friction[1] = fri[0]; c->friction[2] = fri[1]; c->friction[3] = c->friction[4] = fri[2];
+  for (int k = 0; k < 5; k++) c->friction[k] = fmax(MINMU, c->friction[k]);
+  const double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]), gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+  c->includemargin = margin - gap;
+  c->mu = 0;
+}
+
+/* closest points of segments p1 + s (q1 - p1) and p2 + t (q2 - p2), s, t in [0, 1] (Ericson, Real-Time Collision
+ * Detection 5.1.9); degenerate segments (spheres) included */
+static void closest_seg_seg(const double* p1, const double* q1, const double* p2, const double* q2, double* c1, double* c2) {
+  double d1[3], d2[3], r[3];
+  for (int k = 0; k < 3; k++) { d1[k] = q1[k] - p1[k]; d2[k] = q2[k] - p2[k]; r[k] = p1[k] - p2[k]; }
+  const double a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), EPS = 1e-12;
+  double s, t;
+  if (a <= EPS && e <= EPS) { s = t = 0; }
+  else if (a <= EPS) { s = 0; t = fmin(fmax(f / e, 0), 1); }
+  else {
+    const double c = dot3(d1, r);
+    if (e <= EPS) { t = 0; s = fmin(fmax(-c / a, 0), 1); }
+    else {
+      const double b = dot3(d1, d2), den = a * e - b * b;
+      s = den > EPS * a * e ? fmin(fmax((b * f - c * e) / den, 0), 1) : 0; /* parallel: any s; 0 */
+      t = (b * s + f) / e;
+      if (t < 0) { t = 0; s = fmin(fmax(-c / a, 0), 1); }
+      else if (t > 1) { t = 1; s = fmin(fmax((b - c) / a, 0), 1); }
+    }
+  }
+  for (int k = 0; k < 3; k++) { c1[k] = p1[k] + s * d1[k]; c2[k] = p2[k] + t * d2[k]; }
+}
+
 /* ------------------------------------------------------------------ height field (MuJoCo hfield geom, identity orientation)
  * Grid cell (c, r) is split like MuJoCo's prism strip: vertices (c,r), (c,r+1), (c+1,r), (c+1,r+1), i.e. the diagonal
  * runs from (c,r+1) to (c+1,r).  MuJoCo (mjc_ConvexHField) emits one contact per prism under the geom's bounding box;
@@ -552,7 +613,7 @@ static void gqo_collision(GqOracle* o) {
     }
     if (best >= margin) continue;
     Contact* c = &o->contact[o->ncon++];
-    c->geom = g; c->body = m->geom_bodyid[g];
+    c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0;
     c->dist = best;
     c->tiegap = second - best;
     /* contact point midway between the surfaces: (vertex - r*n) - n*dist/2 */
@@ -601,7 +662,7 @@ static void gqo_collision(GqOracle* o) {
       }
       if (best >= margin) continue;
       Contact* c = &o->contact[o->ncon++];
-      c->geom = g; c->body = m->geom_bodyid[g]; c->dist = best; c->tiegap = second - best;
+      c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = best; c->tiegap = second - best;
       for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - bn[k] * (r + 0.5 * best); /* midway between the surfaces */
       memcpy(c->frame, bn, sizeof bn);
       make_frame(c->frame);
@@ -635,12 +696,33 @@ static void gqo_collision(GqOracle* o) {
         }
       if (best >= margin) continue;
       Contact* c = &o->contact[o->ncon++];
-      c->geom = g; c->body = m->geom_bodyid[g]; c->dist = best; c->tiegap = second - best;
+      c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = best; c->tiegap = second - best;
       for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - bn[k] * (r + 0.5 * best);
       memcpy(c->frame, bn, sizeof bn);
       make_frame(c->frame);
       contact_param(o, m->nbox, g, c);
     }
+  /* robot self-collision: the statically filtered geom pairs (GqModelDesc::selfpair_*), capsule proxies in the body
+   * frames, one contact per pair at the closest points of the two segments; normal from geom1 to geom2, contact point
+   * midway between the surfaces (MuJoCo's convention for every pair routine).  Coincident axes (no normal) yield no contact. */
+  for (int p = 0; p < m->nselfpair && o->ncon < NCON; p++) {
+    const int g1 = m->selfpair_geom1[p], g2 = m->selfpair_geom2[p], b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+    const double* k1 = m->geom_capsule + 7 * g1; const double* k2 = m->geom_capsule + 7 * g2;
+    double a0[3], a1[3], e0[3], e1[3], c1[3], c2[3], d[3];
+    mulmatvec3(a0, o->xmat[b1], k1); mulmatvec3(a1, o->xmat[b1], k1 + 3);
+    mulmatvec3(e0, o->xmat[b2], k2); mulmatvec3(e1, o->xmat[b2], k2 + 3);
+    for (int k = 0; k < 3; k++) { a0[k] += o->xpos[b1][k]; a1[k] += o->xpos[b1][k]; e0[k] += o->xpos[b2][k]; e1[k] += o->xpos[b2][k]; }
+    closest_seg_seg(a0, a1, e0, e1, c1, c2);
+    for (int k = 0; k < 3; k++) d[k] = c2[k] - c1[k];
+    const double len = sqrt(dot3(d, d)), dist = len - k1[6] - k2[6];
+    const double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+    if (dist >= margin || len < 1e-9) continue;
+    Contact* c = &o->contact[o->ncon++];
+    c->geom = g2; c->body = b2; c->geom1 = g1; c->body1 = b1; c->dist = dist; c->tiegap = 1.0;
+    for (int k = 0; k < 3; k++) { c->frame[k] = d[k] / len; c->pos[k] = c1[k] + c->frame[k] * (k1[6] + 0.5 * dist); }
+    make_frame(c->frame);
+    contact_param_pair(o, g1, g2, c);
+  }
 }
 
 /* ------------------------------------------------------------------ constraint construction */
@@ -699,12 +781,19 @@ static void gqo_make_constraint(GqOracle* o) {
     Contact* con = &o->contact[c];
     double jp[3][NV], jr[3][NV], Jc[6][NV];
     gqo_jac(o, jp, jr, con->pos, con->body);
+    if (con->body1 > 0) { /* contact between two bodies of the robot: J(geom2's body) - J(geom1's body) at the contact point */
+      double jp1[3][NV], jr1[3][NV];
+      gqo_jac(o, jp1, jr1, con->pos, con->body1);
+      for (int k = 0; k < 3; k++)
+        for (int i = 0; i < NV; i++) { jp[k][i] -= jp1[k][i]; jr[k][i] -= jr1[k][i]; }
+    }
     for (int k = 0; k < 3; k++)
       for (int i = 0; i < NV; i++) {
         Jc[k][i] = con->frame[3 * k] * jp[0][i] + con->frame[3 * k + 1] * jp[1][i] + con->frame[3 * k + 2] * jp[2][i];
         Jc[3 + k][i] = con->frame[3 * k] * jr[0][i] + con->frame[3 * k + 1] * jr[1][i] + con->frame[3 * k + 2] * jr[2][i];
       }
     double tran = m->body_invweight0[2 * con->body], rot = m->body_invweight0[2 * con->body + 1];
+    if (con->body1 > 0) { tran += m->body_invweight0[2 * con->body1]; rot += m->body_invweight0[2 * con->body1 + 1]; }
     con->efc_address = o->nefc;
     con->mu = con->friction[0] / sqrt(m->impratio);
     if (con->dim == 1) {
@@ -1400,6 +1489,8 @@ int gqo_get(const GqOracle* o, const char* name, double* out, int max_n) {
   if (!strcmp(name, "contact_mu")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].mu; return n; }
   if (!strcmp(name, "contact_efc_address")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].efc_address; return n; }
   if (!strcmp(name, "contact_friction")) { int n = 5 * o->ncon < max_n ? 5 * o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i / 5].friction[i % 5]; return n; }
+  if (!strcmp(name, "contact_body1")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].body1; return n; }
+  if (!strcmp(name, "contact_geom1")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].geom1; return n; }
   if (!strcmp(name, "contact_body")) { int n = o->ncon < max_n ? o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i].body; return n; }
   if (!strcmp(name, "contact_pos")) { int n = 3 * o->ncon < max_n ? 3 * o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i / 3].pos[i % 3]; return n; }
   if (!strcmp(name, "contact_frame")) { int n = 9 * o->ncon < max_n ? 9 * o->ncon : max_n; for (int i = 0; i < n; i++) out[i] = o->contact[i / 9].frame[i % 9]; return n; }
@@ -1466,6 +1557,7 @@ int gqo_get_obs(const GqOracle* o, const double* cmd /*[4]*/, const int* legs_or
   }
   *invalid_contact = 0;
   for (int c = 0; c < o->ncon; c++) {
+    if (o->contact[c].body1 > 0) continue; /* contact between two bodies of the robot: "do nothing for now" (quadruped_env.py:1245-1246, :841) */
     int g = o->contact[c].geom, b = m->geom_bodyid[g], leg = -1;
     for (int l = 0; l < 4; l++)
       if (m->geom_bodyid[m->feet_geomid[l]] == b) leg = l;

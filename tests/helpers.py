@@ -30,7 +30,7 @@ DBG_SIZE = _o
 
 
 def marshalled(robot='mini_cheetah', solver=0, iterations=100, tolerance=1e-8, timestep=0.002,
-               terrain_limits=(1e4, -1e4, 1e4, -1e4), noise_floor=0.0, boxes=None, hfield=None):
+               terrain_limits=(1e4, -1e4, 1e4, -1e4), noise_floor=0.0, boxes=None, hfield=None, self_collision=None):
     cfg = get_robot_config(robot)
     md = load_compiled(Path(cfg.mjcf_filename).stem)
     qpos0 = md.qpos0.copy()
@@ -38,7 +38,7 @@ def marshalled(robot='mini_cheetah', solver=0, iterations=100, tolerance=1e-8, t
         qpos0[7:] = np.asarray(cfg.qpos0_js, dtype=np.float64)
     return MarshalledModel(md, qpos0=qpos0, feet_geom_names=cfg.feet_geom_names, terrain_limits=terrain_limits,
                            timestep=timestep, solver=solver, iterations=iterations, tolerance=tolerance,
-                           noise_floor=noise_floor, boxes=boxes, hfield=hfield)
+                           noise_floor=noise_floor, boxes=boxes, hfield=hfield, self_collision=self_collision)
 
 
 def random_states(md, n, rng, z_range=(0.18, 0.45), contact_bias=True):
@@ -181,7 +181,7 @@ class ParityTally:
         if o.ncon and o.get('contact_tiegap').min() < self.tie_threshold:
             self.tie += 1          # two hull vertices of (numerically) equal depth: fp32 / fp64 may pick either
             return 'tie'
-        if not oracle_fits_row_budget(o, self.cone):
+        if not oracle_fits_self_budget(o, self.cone):
             self.budget += 1       # robot lying on the ground with more contacts than one wave's 63 rows
             assert nefc_kernel <= GQ_MAXEFC and nefc_kernel < o.nefc, (e, nefc_kernel, o.nefc)
             return 'budget'
@@ -217,3 +217,45 @@ def oracle_reset_lift(o, q0, v0, hip_height):
             return z, it
         z += 1.1 * np.abs(dist[calf]).max()
         it += 1
+
+
+GQ_SELF_ROWS = 54   # csrc/gq_model_dev.h
+
+
+def oracle_fits_self_budget(o, cone):
+    """oracle_fits_row_budget, plus the tighter cap (GQ_SELF_ROWS rows + virtual rows) the kernel applies to robot-robot
+    contacts so that the dense Newton Hessian fits above the rows."""
+    if not oracle_fits_row_budget(o, cone):
+        return False
+    if o.ncon == 0 or not (o.get('contact_body1') > 0).any():
+        return True
+    dims = o.get('contact_dim').astype(int)
+    reserve = int(sum(d - 1 for d in dims if d > 1)) if cone else 0
+    return o.nefc + reserve <= GQ_SELF_ROWS
+
+
+def self_contact_states(md, n, rng, o, z=(0.5, 0.9), want_cross=None):
+    """Random poses with wide joint excursions (legs folded across each other), kept when the oracle finds a robot-robot
+    contact (want_cross: also require / forbid a contact between two different legs)."""
+    out_q, out_v = [], []
+    leg = lambda b: (b - 2) // 3 if b >= 2 else -1
+    tries = 0
+    while len(out_q) < n and tries < 20000:
+        tries += 1
+        q, v = random_states(md, 1, rng, z_range=z)
+        q, v = q[0], v[0]
+        q[7:] = md.key_qpos[0][7:] + rng.uniform(-1.6, 1.6, 12)
+        o.set_state(q, v, np.zeros(18), np.zeros(18), 0.0, -1.0); o.forward(np.zeros(12), stage=1)
+        if not o.ncon:
+            continue
+        b1, b2 = o.get('contact_body1').astype(int), o.get('contact_body').astype(int)
+        if not (b1 > 0).any():
+            continue
+        cross = any(x > 0 and leg(x) >= 0 and leg(x) != leg(y) for x, y in zip(b1, b2))
+        if want_cross is not None and cross != want_cross:
+            continue
+        out_q.append(q); out_v.append(v)
+    assert len(out_q) == n, f'only {len(out_q)} self-contact states found'
+    return np.stack(out_q), np.stack(out_v)
+
+

@@ -61,8 +61,8 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
       __shared__ gq::WaveMem W;
       int pass = call.first_pass;
       bool respawn = call.auto_reset == 2 && f.s.pending[e];
-      const bool boxes = M.nbox > 0 || M.hf_nrow > 0;
-      int lift = (!boxes && call.first_pass && lift_pending) ? (int)lift_pending[e] : 0;
+      const bool boxes = M.nbox > 0 || M.hf_nrow > 0 || M.nbp > 0;
+      int lift = (call.first_pass && lift_pending) ? (int)lift_pending[e] : 0;
       for (;;) {
         if (respawn) {
           lift = boxes ? gq::reset_wave<true>(f.r, W) : gq::reset_wave<false>(f.r, W);
@@ -100,7 +100,7 @@ extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mas
     if (mask && !mask[e]) continue;
     emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
       __shared__ gq::WaveMem W;
-      if ((M.nbox > 0 || M.hf_nrow > 0)) gq::reset_wave<true>(a, W); else gq::reset_wave<false>(a, W);
+      if ((M.nbox > 0 || M.hf_nrow > 0 || M.nbp > 0)) gq::reset_wave<true>(a, W); else gq::reset_wave<false>(a, W);
     });
   }
   return 0;

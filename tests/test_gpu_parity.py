@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import ALL_OBS, ParityTally, marshalled, random_states, split_obs
+from helpers import ALL_OBS, ParityTally, marshalled, random_states, self_contact_states, split_obs
 
 pytestmark = pytest.mark.gpu
 
@@ -694,3 +694,54 @@ def test_subset_of_observables_equals_the_full_set():
             assert torch.equal(term, term_i)
             for k in subsets[i]:
                 assert torch.equal(o[k], ref[k]), (t, k)
+
+
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo', 'go2', 'go1', 'hyqreal1'])
+def test_robot_self_collision_step_parity(robot):
+    """Robot-robot contacts (MuJoCo's default contype = conaffinity = 1: legs hit each other and the trunk; capsule proxies,
+    gym_quadruped_amd/selfcol.py) on the GPU against the fp64 oracle: every test state has at least one such contact, about
+    half of them between two different legs (dense Newton step), mixed with floor contacts."""
+    from oracle.oracle import Oracle
+    n = 160
+    env = _make_env(n, iters=100, tol=1e-8, solver='newton', robot=robot)
+    o = Oracle(marshalled(robot, solver=1, iterations=100, tolerance=1e-12))
+    hip = env.robot_cfg.hip_height
+    rng = np.random.default_rng(5)
+    qa, va = self_contact_states(env.mjModel, n // 2, rng, o, z=(0.7 * hip, 1.3 * hip), want_cross=True)
+    qb, vb = self_contact_states(env.mjModel, n - n // 2, rng, o, z=(0.7 * hip, 2.5 * hip), want_cross=None)
+    qpos, qvel = np.concatenate([qa, qb]), np.concatenate([va, vb]).astype(np.float32)
+    warm = np.zeros((n, 18), np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 30).astype(np.float32)
+    cmd = np.tile(np.array([0.4, -0.2, 0.0, 0.1], np.float32), (n, 1))
+    env._qpos.copy_(torch.as_tensor(qpos)); env._qvel.copy_(torch.as_tensor(qvel)); env._warm.copy_(torch.as_tensor(warm))
+    env._cmd.copy_(torch.as_tensor(cmd)); env._friction.fill_(0.8)
+    env.enable_debug(n)
+    obs, rew, term, trunc, info = env.step(torch.as_tensor(ctrl))
+    torch.cuda.synchronize()
+    dbg = env.debug_internals(n, ['qacc', 'niter', 'nefc', 'ncon'])
+    qp, qv, ob = env.qpos.cpu().numpy(), env.qvel.cpu().numpy(), env._obs_buf.cpu().numpy()
+    tg, ig = term.cpu().numpy(), info['invalid_contacts'].cpu().numpy()
+    cone = env.mjModel.cone == 1
+    tally = ParityTally(cone, 3e-7)
+    nself = ncross = 0
+    leg = lambda b: (b - 2) // 3 if b >= 2 else -1
+    ea, ev = [], []
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e], warm[e], np.zeros(18), 0.0, 0.8); o.step(ctrl[e].astype(np.float64))
+        if tally.classify(e, o, dbg[e]['nefc'][0]) != 'ok':
+            continue
+        assert int(dbg[e]['ncon'][0]) == o.ncon
+        b1, b2 = o.get('contact_body1').astype(int), o.get('contact_body').astype(int)
+        nself += int((b1 > 0).any()); ncross += int(any(x > 0 and leg(x) >= 0 and leg(x) != leg(y) for x, y in zip(b1, b2)))
+        ea.append(np.abs(dbg[e]['qacc'] - o.qacc).max() / max(1.0, np.abs(o.qacc).max()))
+        ev.append(np.abs(qv[e] - o.qvel).max())
+        assert np.abs(qp[e] - o.qpos).max() < 3.5e-6
+        ref, t, inv = o.get_obs(ALL_OBS, cmd[e]); got = split_obs(ob[e], ALL_OBS)
+        for k in ('contact_state', 'feet_vel', 'base_lin_acc'):   # robot-robot contacts set no foot contact state and no termination
+            assert np.abs(got[k] - ref[k]).max() < 5e-3 * max(1.0, np.abs(ref[k]).max()), (e, k)
+        assert bool(tg[e]) == t and bool(ig[e]) == inv
+    p99 = lambda x: float(np.percentile(x, 99))
+    assert p99(ea) < (1e-4 if cone else 2e-5) * 5 and max(ea) < 2e-3, (p99(ea), max(ea))
+    assert p99(ev) < (7e-4 if cone else 5e-5) * 5 and max(ev) < 5e-3, (p99(ev), max(ev))
+    tally.finish(f'self-collision one-step parity {robot}', min_checked=0.5, max_tie=0.15, max_budget=0.5)
+    assert nself >= 0.9 * tally.checked and ncross >= 0.25 * tally.checked, (nself, ncross, tally.checked)

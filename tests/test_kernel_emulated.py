@@ -3,7 +3,7 @@ the CPU oracle: same parity contract as tests/test_gpu_parity.py, runnable witho
 import numpy as np
 import pytest
 
-from helpers import ALL_OBS, dbg, default_reset_cfg, emu_reset, emu_step, marshalled, oracle_reset_lift, random_states, split_obs
+from helpers import ALL_OBS, dbg, default_reset_cfg, emu_reset, emu_step, marshalled, oracle_fits_self_budget, oracle_reset_lift, random_states, self_contact_states, split_obs
 from oracle.oracle import Oracle
 from philox_ref import draws
 
@@ -473,3 +473,43 @@ def test_general_impedance_power_matches_oracle():
         np.testing.assert_allclose(dbg(rec, 'efc_aref')[:nefc], o.efc_aref, atol=3e-4 * max(1.0, np.abs(o.efc_aref).max()))
         assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 2e-4 * max(1.0, np.abs(o.qacc).max()), e
     assert rows > 40
+
+
+@pytest.mark.parametrize('robot,want_cross', [('mini_cheetah', True), ('aliengo', False), ('aliengo', True), ('go2', True), ('go1', None)])
+def test_robot_self_collision_matches_oracle(robot, want_cross):
+    """Robot-robot contacts (MuJoCo's default contype = conaffinity = 1; capsule proxies, selfcol.py): pair filter, broad
+    and narrow phase, two-body Jacobian rows, and the Newton step - tree-sparse when the contact stays inside one leg or
+    touches the trunk, dense when it couples two legs - against the oracle: contact list, J, R, aref, forces, qacc."""
+    n = 10
+    mm = marshalled(robot, solver=1, iterations=100, tolerance=1e-10, noise_floor=0.0)
+    o = Oracle(marshalled(robot, solver=1, iterations=100, tolerance=1e-12))
+    rng = np.random.default_rng(7)
+    qpos, qvel = self_contact_states(mm.md, n, rng, o, want_cross=want_cross)
+    qvel = qvel.astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 20).astype(np.float32)
+    st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), debug_envs=n, friction=np.full(n, 0.7, np.float32))
+    nself = nchecked = 0
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e], np.zeros(18), np.zeros(18), 0.0, 0.7); o.step(ctrl[e].astype(np.float64))
+        rec = st['debug'][e]
+        ne = o.nefc
+        if not oracle_fits_self_budget(o, mm.md.cone == 1):
+            continue
+        nchecked += 1
+        nself += int((o.get('contact_body1') > 0).sum())
+        assert int(dbg(rec, 'nefc')[0]) == ne and int(dbg(rec, 'ncon')[0]) == o.ncon, (e, dbg(rec, 'nefc')[0], ne)
+        np.testing.assert_allclose(dbg(rec, 'efc_J').reshape(64, 18)[:ne], o.efc_J, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(dbg(rec, 'efc_R')[:ne], o.efc_R, rtol=2e-4)
+        np.testing.assert_allclose(dbg(rec, 'efc_aref')[:ne], o.efc_aref, rtol=2e-4, atol=5e-2)
+        assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 2e-4 * max(1.0, np.abs(o.qacc).max()), (e, dbg(rec, 'niter'))
+        fmax = max(1.0, np.abs(o.efc_force).max())
+        assert np.abs(dbg(rec, 'efc_force')[:ne] - o.efc_force).max() < (2e-3 if mm.md.cone == 0 else 2e-2) * fmax
+        assert np.abs(st['qvel'][e] - o.qvel).max() < 5e-4 and np.abs(st['qpos'][e] - o.qpos).max() < 2e-6
+        # internal forces: no net force on the base dofs from a robot-robot contact row (Newton's third law)
+        J = o.efc_J
+        b1 = o.get('contact_body1').astype(int); adr = o.get('contact_efc_address').astype(int); dims = o.get('contact_dim').astype(int)
+        for c in range(o.ncon):
+            if b1[c] > 0:
+                nr = dims[c] if mm.md.cone == 1 else (1 if dims[c] == 1 else 2 * (dims[c] - 1))
+                assert np.abs(J[adr[c]:adr[c] + nr, :6]).max() < 1e-12
+    assert nchecked >= n // 2 and nself > 0
