@@ -164,6 +164,7 @@ def main():
     ap.add_argument('--solver', choices=['newton', 'pgs'], default='newton')
     ap.add_argument('--scene', default='flat', help="headline metric: flat; box scenes (random_boxes, stairs, ...) for the secondary configs")
     ap.add_argument('--robot', default='mini_cheetah', help='headline metric: mini_cheetah; other registry robots for the secondary configs')
+    ap.add_argument('--no-self-collision', action='store_true', help='switch robot self-collision off (MuJoCo default and default here: on)')
     ap.add_argument('--imu', action='store_true', help='BASELINE config 5: IMU plug-in (6 observables; robots that expose accelerometer + gyro sensors)')
     ap.add_argument('--heightmap', action='store_true', help='BASELINE config 5: a 5x5 HeightMap @ 0.1 m updated every step')
     args = ap.parse_args()
@@ -203,7 +204,7 @@ def main():
         obs_names = obs_names + IMU.ALL_OBS
     env = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device, sensors=sensors, sensors_kwargs=sensors_kwargs,
                        auto_reset=False if (args.no_auto_reset or args.auto_reset == 'off') else args.auto_reset, solver=args.solver, solver_iterations=100, solver_tolerance=1e-8,
-                       seed=1000, env_id_offset=shard.env_offset)  # shards: disjoint global env ids -> disjoint RNG counters
+                       seed=1000, env_id_offset=shard.env_offset, self_collision=False if args.no_self_collision else None)  # shards: disjoint global env ids -> disjoint RNG counters
     env.reset(random=True)
     g = torch.Generator(device=device).manual_seed(rank)
     pool = [torch.randn(n, 12, generator=g, device=device) * 50 for _ in range(64)]
@@ -219,13 +220,19 @@ def main():
     # shape runs 300 steps of the same kernel and is thrown away, so that a --steps 20 --warmup 5 run measures the same
     # clocks and caches as a --steps 2000 one; the measured env then does exactly --warmup untimed steps
     scratch = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device, sensors=sensors, sensors_kwargs=sensors_kwargs,
-                           auto_reset='next_step', solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=999)
+                           auto_reset='next_step', solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=999,
+                           self_collision=False if args.no_self_collision else None)
     scratch.reset(random=True)
     for i in range(300):
         scratch.step(pool[i % 64])
     torch.cuda.synchronize(device)
     scratch.close()
     del scratch
+    hm = None
+    if args.heightmap:   # examples/aliengo_with_heightmap.py:25
+        from gym_quadruped_amd.sensors import HeightMap
+        hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)
+        yaw0 = torch.zeros(n, device=device)
     for i in range(args.warmup):
         env.step(pool[i % 64])
     # timed region: exactly K steps bracketed by barrier + synchronize
@@ -267,7 +274,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'{args.robot} {args.scene}, {n} envs/GPU, random-action rollout (50*N(0,1) torques), '
                                    f'{"ALL_OBS" if args.obs == "all" else "_DEFAULT_OBS"} ({env._obs_dim} scalars), '
-                                   f'auto-reset on termination ({env.auto_reset_mode}), sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8'
+                                   f'auto-reset on termination ({env.auto_reset_mode}), sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8, robot self-collision {"off" if args.no_self_collision or args.solver == "pgs" else "on"}'
                                    + (', IMU plug-in' if args.imu else '') + (', 5x5 HeightMap every step' if args.heightmap else ''),
                        'envs_per_gpu': n, 'total_envs': total_envs, 'parallelism': f'env-shards x{world} (no collectives)',
                        'state_finite': finite},

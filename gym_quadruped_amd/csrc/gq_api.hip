@@ -17,7 +17,7 @@
 #include "gq_step_kernel.h"
 #include "gq_step_body.h"
 
-extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, hipStream_t stream);
+extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, int self, hipStream_t stream);
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, int boxes, hipStream_t stream);
 extern "C" void gq_launch_heightmap(const GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
                                     float dist_x, float dist_y, float* out, hipStream_t stream);
@@ -49,6 +49,7 @@ struct GqBatch {
   uint8_t* lift_pending;/* device [N]: reset kernel -> the reset's own step: lift loop still due */
   uint8_t* load_hint;   /* device [N]: per-env solver load of the previous step (scheduling hint of the step kernel) */
   int stop_stage;       /* profiling aid: GQ_STOP_STAGE at batch creation */
+  int force_self;       /* profiling aid: GQ_FORCE_SELF=1 runs the self-collision kernel variant even for a model without pairs */
   /* argument block of step_kernel: device copy, host shadow of what the device holds, pinned staging ring for the
    * (rare) stream-ordered re-upload */
   gq::FusedArgs* dev_args;
@@ -142,6 +143,7 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   HIP_TRY_OR_DESTROY(hipMalloc(&b->load_hint, (size_t)n_envs), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipMemset(b->load_hint, 0, (size_t)n_envs), gq_batch_destroy(b));
   { const char* s = getenv("GQ_STOP_STAGE"); b->stop_stage = s ? atoi(s) : 0; }
+  { const char* s = getenv("GQ_FORCE_SELF"); b->force_self = (s && atoi(s)) ? 1 : 0; }
   HIP_TRY_OR_DESTROY(hipMalloc(&b->dev_args, sizeof(gq::FusedArgs)), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipHostMalloc(&b->staging, sizeof(gq::FusedArgs) * GQ_ARG_SLOTS, hipHostMallocDefault), gq_batch_destroy(b));
   b->staging_next = 0; b->shadow_valid = false;
@@ -277,7 +279,7 @@ int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqOb
   gq::StepCall c{};
   c.ctrl = ctrl; c.mask = mask; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
   c.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; c.first_pass = 0; c.stop_stage = b->stop_stage;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0 || b->model->host.nbp > 0), (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }
@@ -294,14 +296,14 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   fill_reset_args(&r, b, mask, qpos_new, qvel_new, cfg, st, out, episode, lift_failed);
   r.clear_terminated = out.terminated; r.clear_truncated = out.truncated; r.clear_invalid = out.invalid_contact;
   r.lift_pending = b->lift_pending;
-  gq_launch_reset(&r, b->host.n_envs, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0 || b->model->host.nbp > 0), (hipStream_t)hip_stream);
+  gq_launch_reset(&r, b->host.n_envs, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */
   const int rc = ensure_args(b, st, out, episode, lift_failed, nullptr, (hipStream_t)hip_stream);
   if (rc != GQ_OK) return rc;
   gq::StepCall c{};
   c.mask = mask; c.first_pass = 1; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0 || b->model->host.nbp > 0), (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

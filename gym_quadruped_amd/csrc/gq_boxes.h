@@ -422,103 +422,182 @@ __device__ __forceinline__ void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& 
 #define GQ_WCLS_SELF (-2)
 
 /* S6, robot self-collision (mj_collision between two bodies of the robot; gym_quadruped_amd/selfcol.py has the pair
- * filter and the capsule proxies).  Broad phase: lane = body pair, bounding spheres of the bodies' proxies (two ballots
- * for <= 66 pairs).  Narrow phase per near body pair (wave-uniform loop): lane = geom pair, closest points of the two
- * capsule axes; one contact per pair, normal from geom1 to geom2, point midway between the surfaces.  Contacts are
- * appended after the world contacts in (body pair, geom1, geom2) order - MuJoCo's order - under the same row budget, capped at
- * GQ_SELF_ROWS rows so that the dense Newton Hessian of such an env fits above them. */
-template <bool CONE>
-__device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S) {
+ * filter and the capsule proxies).  The proxies' end points are taken to the world once (lane = collision item); then
+ * lane = geom pair, 64 pairs per pass: closest points of the two capsule axes, one contact per pair, normal from geom1 to
+ * geom2, point midway between the surfaces.  Models with more than 128 pairs first run a body-pair broad phase (bounding
+ * spheres of the bodies' proxies) and skip the passes whose pairs all belong to far-apart bodies.  Contacts are
+ * appended after the world contacts in (body pair, geom1, geom2) order - MuJoCo's order - under the same row budget. */
+/* model words of the self-collision stage that do not depend on the state: fetched at the start of S6, so that their
+ * memory latency is spent under the floor scan instead of in front of the pair test */
+struct SelfPrefetch { float caps[7]; int32_t body, it1[2], it2[2], bp[2]; };
+__device__ __forceinline__ SelfPrefetch self_prefetch(const GQ_MODEL GqDevModel& m) {
   const int lane = lane_id();
-  const int nbp = m.nbp;
-  if (nbp == 0) return;
+  SelfPrefetch P;
+  const int it = lane < 4 + m.nlg ? lane : 0;
+#pragma unroll
+  for (int i = 0; i < 7; i++) P.caps[i] = m.item_caps[it][i];
+  P.body = m.item_body[it];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int p = h * GQ_WAVE + lane < m.nsp ? h * GQ_WAVE + lane : 0;
+    P.it1[h] = m.sp[p].it1; P.it2[h] = m.sp[p].it2; P.bp[h] = m.sp[p].bp;
+  }
+  return P;
+}
+
+template <bool CONE>
+__device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre) {
+  const int lane = lane_id();
+  const int nsp = m.nsp;
+  if (nsp == 0) return;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  uint64_t near[2];
-#pragma unroll
-  for (int half = 0; half < 2; half++) {
-    const int p = half * GQ_WAVE + lane;
-    bool nr = false;
-    if (p < nbp) {
-      const GQ_MODEL GqDevBodyPair& P = m.bp[p];
-      const V3 c1 = ld3(W.xpos[P.b1]) + matvec(W.xmat[P.b1], ld3(m.body_sph[P.b1]));
-      const V3 c2 = ld3(W.xpos[P.b2]) + matvec(W.xmat[P.b2], ld3(m.body_sph[P.b2]));
-      const V3 d = c2 - c1;
-      const float rr = m.body_sph[P.b1][3] + m.body_sph[P.b2][3] + m.self_margin;
-      nr = dot(d, d) < rr * rr;
-    }
-    near[half] = ballot(nr);
+  /* world end points of every item's proxy capsule, once: lane = collision item; scratch in the J block, which is free
+   * until S7 (the spatial-dynamics scratch it overlays is dead since S5) */
+  /* per item: end points p0, p1, radius, and the bounding sphere (centre, radius) the first pass tests */
+  float(*cw)[12] = reinterpret_cast<float(*)[12]>(&W.u.B[0][0]);
+  if (lane < 4 + m.nlg) {
+    const int b = pre.body;
+    const V3 o = ld3(W.xpos[b]);
+    const V3 e0 = o + matvec(W.xmat[b], v3(pre.caps[0], pre.caps[1], pre.caps[2])), e1 = o + matvec(W.xmat[b], v3(pre.caps[3], pre.caps[4], pre.caps[5]));
+    const V3 hh = 0.5f * (e1 - e0);
+    st3(cw[lane], e0); st3(cw[lane] + 3, e1);
+    cw[lane][6] = pre.caps[6];
+    st3(cw[lane] + 8, e0 + hh);
+    cw[lane][11] = sqrtf(dot(hh, hh)) + pre.caps[6];
   }
+  /* models with many pairs: body-pair broad phase, so that passes whose pairs all belong to far-apart bodies are skipped */
+  uint64_t near[2] = {~0ull, ~0ull};
+  if (nsp > 2 * GQ_WAVE) {
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int p = half * GQ_WAVE + lane;
+      bool nr = false;
+      if (p < m.nbp) {
+        const GQ_MODEL GqDevBodyPair& P = m.bp[p];
+        const V3 d = ld3(W.xpos[P.b2]) + matvec(W.xmat[P.b2], ld3(m.body_sph[P.b2])) - ld3(W.xpos[P.b1]) - matvec(W.xmat[P.b1], ld3(m.body_sph[P.b1]));
+        const float rr = m.body_sph[P.b1][3] + m.body_sph[P.b2][3] + m.self_margin;
+        nr = dot(d, d) < rr * rr;
+      }
+      near[half] = ballot(nr);
+    }
+  }
+  if (m.self_cut == 1) { wave_barrier(); return; }
+  wave_barrier();
+  /* pass A, lane = geom pair, 64 pairs per pass: bounding spheres of the two capsules.  The survivors' pair indices are
+   * compacted into a list (scratch behind the end points, pair order kept), so that the closest-point test runs once over
+   * the candidates instead of once per pass - and not at all in the many poses where no pair comes close */
+  int32_t* list = reinterpret_cast<int32_t*>(&W.u.B[30][0]);
+  int ncand = 0;
 #pragma unroll 1
-  for (int half = 0; half < 2; half++) {
-    uint64_t todo = near[half];
-    while (todo) { /* wave-uniform */
-      const int p = half * GQ_WAVE + ffs64(todo);
-      todo &= todo - 1;
-      const GQ_MODEL GqDevBodyPair& P = m.bp[p];
-      const int b1 = P.b1, b2 = P.b2;
-      bool touching = false;
-      float dist = 0.0f, mu = 0.0f;
-      V3 nrm = v3(0.0f, 0.0f, 1.0f), pt = v3(0.0f, 0.0f, 0.0f);
-      int it1 = 0, it2 = 0, dim = 3;
-      const GQ_MODEL GqDevSelfPair* sp = &m.sp[P.first];
-      if (lane < P.count) {
-        sp = &m.sp[P.first + lane];
-        it1 = sp->it1; it2 = sp->it2; dim = sp->mix.dim;
-        const GQ_MODEL float* k1 = m.item_caps[it1];
-        const GQ_MODEL float* k2 = m.item_caps[it2];
-        const V3 o1 = ld3(W.xpos[b1]), o2 = ld3(W.xpos[b2]);
-        const V3 a0 = o1 + matvec(W.xmat[b1], ld3(k1)), a1 = o1 + matvec(W.xmat[b1], ld3(k1 + 3));
-        const V3 e0 = o2 + matvec(W.xmat[b2], ld3(k2)), e1 = o2 + matvec(W.xmat[b2], ld3(k2 + 3));
-        V3 c1, c2;
-        closest_seg_seg(a0, a1, e0, e1, c1, c2);
-        const V3 d = c2 - c1;
-        const float l2 = dot(d, d), len = sqrtf(l2);
-        dist = len - k1[6] - k2[6];
-        touching = dist < sp->mix.margin && len >= 1e-9f;
-        if (touching) {
-          nrm = (1.0f / len) * d;
-          pt = c1 + (k1[6] + 0.5f * dist) * nrm;
-          /* sliding friction: _set_ground_friction rewrites the feet (quadruped_env.py:1277-1298) */
-          const float f1 = it1 < 4 ? (mu_env >= 0.0f ? mu_env : m.foot_friction[it1][0]) : m.lg[it1 - 4].friction[0];
-          const float f2 = it2 < 4 ? (mu_env >= 0.0f ? mu_env : m.foot_friction[it2][0]) : m.lg[it2 - 4].friction[0];
-          mu = fmaxf(1e-5f, sp->mix.rule == 0 ? fmaxf(f1, f2) : (sp->mix.rule == 1 ? f1 : f2));
-        }
+  for (int p0 = 0; p0 < nsp; p0 += GQ_WAVE) {
+    const int p = p0 + lane;
+    bool cand = p < nsp;
+    if (cand) {
+      int it1, it2, bp; /* the first two passes come prefetched */
+      if (p0 == 0) { it1 = pre.it1[0]; it2 = pre.it2[0]; bp = pre.bp[0]; }
+      else if (p0 == GQ_WAVE) { it1 = pre.it1[1]; it2 = pre.it2[1]; bp = pre.bp[1]; }
+      else { const GQ_MODEL GqDevSelfPair& P = m.sp[p]; it1 = P.it1; it2 = P.it2; bp = P.bp; }
+      cand = (near[bp >> 6] >> (bp & 63)) & 1;
+      if (cand) {
+        const float* k1 = cw[it1] + 8;
+        const float* k2 = cw[it2] + 8;
+        const V3 dm = ld3(k2) - ld3(k1);
+        const float reach = k1[3] + k2[3] + m.self_margin;
+        cand = dot(dm, dm) < reach * reach;
       }
-      const uint64_t touch_mask = ballot(touching);
-      if (touch_mask == 0) continue;
-      int& ncon = S.ncon; int& rows = S.rows; int& reserve = S.reserve;
-      const int idx = ncon + popc64(touch_mask & lt);
-      const bool kept = touching && idx < GQ_MAXCON;
-      const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
-      const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4), m6 = ballot(kept && need == 6);
-      const int row0 = rows + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
-      const int res = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) + (need > 1 ? need - 1 : 0) : 0;
-      const bool fits = kept && row0 + need + res <= GQ_SELF_ROWS;
-      const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4), f6 = ballot(fits && need == 6);
-      if (fits) {
-        W.con_geom[idx] = it2 | ((it1 + 1) << 8) | (sp->mix.rule << 16); W.con_body[idx] = b2 | ((b1 + 1) << 8); W.con_dim[idx] = dim; W.con_row[idx] = row0;
-        W.con_dist[idx] = dist; W.con_inc[idx] = sp->mix.includemargin; W.con_mu[idx] = mu;
-        st3(W.con_pos[idx], pt);
-        W.con_solref[idx][0] = sp->mix.solref[0]; W.con_solref[idx][1] = sp->mix.solref[1];
-#pragma unroll
-        for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = sp->mix.solimp[q];
-        st3(GQ_BX_CONNRM(W) + 3 * idx, nrm);
-        GQ_BX_WCLS(W)[idx] = GQ_WCLS_SELF;
-      }
-      const int added = popc64(f1 | f3 | f4 | f6);
-      ncon += added;
-      rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
-      if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
-      S.nself += added;
     }
+    const uint64_t cm = ballot(cand);
+    if (cm == 0) continue;
+    const int at = ncand + popc64(cm & lt);
+    if (cand && at < 2 * GQ_WAVE) list[at] = p;
+    ncand += popc64(cm);
   }
+  if (ncand == 0 || m.self_cut == 2) return;
+  if (ncand > 2 * GQ_WAVE) ncand = 2 * GQ_WAVE; /* more than 128 close pairs: the robot is a knot; the row budget is long spent */
+  wave_barrier();
+#pragma unroll 1
+  for (int c0 = 0; c0 < ncand; c0 += GQ_WAVE) { /* pass B, lane = candidate pair */
+    const bool cand = c0 + lane < ncand;
+    const int p = cand ? list[c0 + lane] : 0;
+    bool touching = false;
+    float dist = 0.0f;
+    V3 nrm = v3(0.0f, 0.0f, 1.0f), pt = v3(0.0f, 0.0f, 0.0f);
+    int it1 = 0, it2 = 0;
+    if (cand) {
+      it1 = m.sp[p].it1; it2 = m.sp[p].it2;
+      const float* k1 = cw[it1];
+      const float* k2 = cw[it2];
+      V3 c1, c2;
+      closest_seg_seg(ld3(k1), ld3(k1 + 3), ld3(k2), ld3(k2 + 3), c1, c2);
+      const V3 d = c2 - c1;
+      const float l2 = dot(d, d), len = sqrtf(l2);
+      dist = len - k1[6] - k2[6];
+      touching = dist < m.sp[p].mix.margin && len >= 1e-9f;
+      if (touching) { nrm = (1.0f / len) * d; pt = c1 + (k1[6] + 0.5f * dist) * nrm; }
+    }
+    const uint64_t touch_mask = ballot(touching);
+    if (touch_mask == 0 || m.self_cut == 4) continue;
+    /* (rare) append the touching pairs, in pair order */
+    const GQ_MODEL GqDevSelfPair& P = m.sp[touching ? p : 0];
+    const int dim = P.mix.dim;
+    float mu = 0.0f;
+    if (touching) { /* sliding friction: _set_ground_friction rewrites the feet (quadruped_env.py:1277-1298) */
+      const float f1 = it1 < 4 ? (mu_env >= 0.0f ? mu_env : m.foot_friction[it1][0]) : m.lg[it1 - 4].friction[0];
+      const float f2 = it2 < 4 ? (mu_env >= 0.0f ? mu_env : m.foot_friction[it2][0]) : m.lg[it2 - 4].friction[0];
+      mu = fmaxf(1e-5f, P.mix.rule == 0 ? fmaxf(f1, f2) : (P.mix.rule == 1 ? f1 : f2));
+    }
+    int& ncon = S.ncon; int& rows = S.rows; int& reserve = S.reserve;
+    const int idx = ncon + popc64(touch_mask & lt);
+    const bool kept = touching && idx < GQ_MAXCON;
+    const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
+    const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4), m6 = ballot(kept && need == 6);
+    const int row0 = rows + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
+    const int res = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) + (need > 1 ? need - 1 : 0) : 0;
+    const bool fits = kept && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
+    const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4), f6 = ballot(fits && need == 6);
+    if (fits) {
+      const int b1 = m.item_body[it1], b2 = m.item_body[it2];
+      W.con_geom[idx] = it2 | ((it1 + 1) << 8) | (P.mix.rule << 16); W.con_body[idx] = b2 | ((b1 + 1) << 8); W.con_dim[idx] = dim; W.con_row[idx] = row0;
+      W.con_dist[idx] = dist; W.con_inc[idx] = P.mix.includemargin; W.con_mu[idx] = mu;
+      st3(W.con_pos[idx], pt);
+      W.con_solref[idx][0] = P.mix.solref[0]; W.con_solref[idx][1] = P.mix.solref[1];
+#pragma unroll
+      for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = P.mix.solimp[q];
+      st3(GQ_BX_CONNRM(W) + 3 * idx, nrm);
+      GQ_BX_WCLS(W)[idx] = GQ_WCLS_SELF;
+    }
+    const int added = popc64(f1 | f3 | f4 | f6);
+    ncon += added;
+    rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
+    if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
+    S.nself += added;
+  }
+}
+
+/* S6 for a scene without world boxes / height field but with robot self-collision: general frames for the floor
+ * contacts the floor pass left in W, then the robot-robot contacts.  Ends with a barrier. */
+template <bool CONE>
+__device__ inline void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre) {
+  const int lane = lane_id();
+  WorldAppend S;
+  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = 0; S.reserve = 0; S.nself = 0;
+  const int ncon = S.ncon;
+  if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
+    st3(GQ_BX_CONNRM(W) + 3 * lane, v3(0.0f, 0.0f, 1.0f));
+    GQ_BX_WCLS(W)[lane] = -1;
+  }
+  if constexpr (CONE)
+    for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
+  append_self_contacts<CONE>(W, m, mu_env, S, pre);
+  if (lane == 0) { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; }
+  wave_barrier();
 }
 
 /* S6 (BOXES): append the contacts with the world boxes to the list the floor pass left in W (ncon, nefc, invalid,
  * foot_touch are updated; rows / row budget as in the floor pass).  Ends with a barrier. */
-template <bool CONE>
+template <bool CONE, bool SELF>
 __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
-                                          double bx, double by, float mu_env) {
+                                          double bx, double by, float mu_env, const SelfPrefetch& pre) {
   const int lane = lane_id();
   WorldAppend S;
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0;
@@ -554,7 +633,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
       wave_barrier();
     }
   }
-  append_self_contacts<CONE>(W, m, mu_env, S);
+  if constexpr (SELF) append_self_contacts<CONE>(W, m, mu_env, S, pre);
   if (lane == 0) {
     W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself;
 #pragma unroll

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 static void quat2mat(const double* q, double* m) {
   double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -250,6 +251,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
   /* robot self-collision: proxy capsules per collision item, geom pairs (already filtered and ordered by the caller,
    * gym_quadruped_amd/selfcol.py) grouped by body pair, contact parameters mixed per pair (mj_contactParam) */
   M.nbp = 0; M.nsp = 0; M.self_margin = 0.0f;
+  { const char* e = std::getenv("GQ_SELF_CUT"); M.self_cut = e ? std::atoi(e) : 0; }
   for (int b = 0; b < GQ_NB; b++) for (int i = 0; i < 4; i++) M.body_sph[b][i] = 0.0f;
   if (d->nselfpair > 0) {
     if (!d->selfpair_geom1 || !d->selfpair_geom2 || !d->geom_capsule) FAIL("self-collision pairs given without selfpair_geom1 / selfpair_geom2 / geom_capsule");
@@ -296,7 +298,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       GqDevBodyPair& P = M.bp[M.nbp - 1];
       if (++P.count > 64) FAIL("more than 64 geom pairs between two bodies");
       GqDevSelfPair& S = M.sp[p];
-      S.it1 = item_of_geom[g1]; S.it2 = item_of_geom[g2];
+      S.it1 = item_of_geom[g1]; S.it2 = item_of_geom[g2]; S.bp = M.nbp - 1;
       WorldGeom w{d->geom_condim[g1], d->geom_priority[g1], d->geom_solmix[g1], d->geom_margin[g1], d->geom_gap[g1], d->geom_solref + 2 * g1, d->geom_solimp + 5 * g1};
       Mixed mx = mix_with(d, w, g2);
       if (mx.dim != 1 && mx.dim != 3 && !(d->cone == 1 && mx.dim == 6)) FAIL("self-contact dimension %d not supported", mx.dim);

@@ -13,7 +13,7 @@ namespace gq {
  * then the reset's own mj_step as a second pass through step_wave; no extra launches, but the launch lasts as long as
  * its two-pass waves.  Next-step mode: the env waits (pending flag) and spends its next launch on reset_wave + the
  * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
-template <int SOLVER, int MODE, bool CONE, bool BOXES>
+template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF>
 __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
   if (c.mask && !gptr(c.mask)[blockIdx.x]) return; /* wave-uniform */
   __shared__ WaveMem W;
@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __res
       lift = reset_wave<BOXES>(A->r, W);
       pass = c.auto_reset;
     }
-    const int term = step_wave<SOLVER, MODE, CONE, BOXES>(A->s, c, W, pass, lift);
+    const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF>(A->s, c, W, pass, lift);
     if (pass != 0 || c.auto_reset != 1 || !term) break;
     respawn = true;
   }
@@ -104,19 +104,22 @@ extern "C" void gq_launch_heightmap(const GQ_GLOBAL GqDevModel* model, const dou
                      dist_x, dist_y, out);
 }
 
-extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, hipStream_t stream) {
+extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, int self, hipStream_t stream) {
   /* 0: production; 1: debug record + stage timers; 2: stage cut (GQ_STOP_STAGE / gq_debug_stop_stage) - the early returns
-   * of the cut cost the production kernel ~8 % when merely compiled in, hence a variant of their own */
+   * of the cut cost the production kernel ~8 % when merely compiled in, hence a variant of their own.
+   * Scene variants: flat (no world geoms beyond the floor), flat + robot self-collision, world boxes / height field (always
+   * with the self-collision stage compiled in; a model without pairs skips it at run time). */
   const int mode = c->debug != nullptr ? 1 : (c->stop_stage != 0 ? 2 : 0);
-#define GQ_LAUNCH(S, M, C) do { if (boxes) hipLaunchKernelGGL((gq::step_kernel<S, M, C, true>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c); \
-                                else hipLaunchKernelGGL((gq::step_kernel<S, M, C, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c); } while (0)
+#define GQ_LAUNCH(S, M, C) do { if (boxes) hipLaunchKernelGGL((gq::step_kernel<S, M, C, true, true>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c); \
+                                else if (self) hipLaunchKernelGGL((gq::step_kernel<S, M, C, false, true>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c); \
+                                else hipLaunchKernelGGL((gq::step_kernel<S, M, C, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c); } while (0)
 #define GQ_LAUNCH_MODE(S, C) do { if (mode == 1) GQ_LAUNCH(S, 1, C); else if (mode == 2) GQ_LAUNCH(S, 2, C); else GQ_LAUNCH(S, 0, C); } while (0)
   if (solver == 1 && cone) GQ_LAUNCH_MODE(1, true);
   else if (solver == 1) GQ_LAUNCH_MODE(1, false);
-  else { /* PGS: floor plane only (gq_model_create rejects world boxes with solver 0) */
-    if (mode == 1) hipLaunchKernelGGL((gq::step_kernel<0, 1, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
-    else if (mode == 2) hipLaunchKernelGGL((gq::step_kernel<0, 2, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
-    else hipLaunchKernelGGL((gq::step_kernel<0, 0, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
+  else { /* PGS: floor plane only (gq_model_create rejects world boxes / self-collision with solver 0) */
+    if (mode == 1) hipLaunchKernelGGL((gq::step_kernel<0, 1, false, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
+    else if (mode == 2) hipLaunchKernelGGL((gq::step_kernel<0, 2, false, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
+    else hipLaunchKernelGGL((gq::step_kernel<0, 0, false, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
   }
 #undef GQ_LAUNCH_MODE
 #undef GQ_LAUNCH

@@ -250,19 +250,32 @@ __device__ inline void solve_tree_fused(const float (*Sc)[9], const float (*Sb)[
   wave_barrier();
 }
 
-/* out <- H^-1 g for a DENSE symmetric positive definite 18 x 18 matrix given as its packed lower triangle Hd (LDS, entry
- * (i, j <= i) at i (i + 1) / 2 + j): the Newton step of an env whose contacts couple two legs (robot self-collision), where
- * M + J'DJ has lost the tree sparsity the fused elimination relies on.  Lane i < 18 holds row i in registers; Gaussian
- * elimination without pivoting (the matrix is SPD), the pivot row broadcast with v_readlane, every lane below the pivot
- * updating its own row at once; back substitution the same way.  ~480 VALU, no LDS inside the elimination. */
-__device__ inline void solve_dense_lanes(const float* Hd, const float* g, float* out) {
+/* Newton step of an env whose contacts couple two legs (robot self-collision): M + J'DJ has lost the tree sparsity the
+ * fused elimination relies on, so the system is solved DENSE, lane-parallel.  Lane i < 18 holds row i of H in registers:
+ * the tree-sparse part comes from the Hessian the regular assembly just wrote (Hc / Hb: it walks every row, so base and
+ * same-leg entries already contain the coupling rows' share), the entries between two different legs - zero in M - are
+ * summed here over the robot-robot rows [r0, r1) only (the only rows that touch two legs; W.force holds the row weights).
+ * Then Gaussian elimination without pivoting (H is SPD): the pivot row is broadcast with v_readlane and every lane below
+ * the pivot updates its own row at once; back substitution the same way.  Out of line on purpose: its registers are saved
+ * at the call site, inside the rare branch, instead of being reserved across the whole Newton loop. */
+__device__ __forceinline__ void newton_dense_step(WaveMem& W, int r0, int r1, const float* g, float* out) {
   const int lane = lane_id();
   const int i = lane < GQ_NVD ? lane : 0; /* lanes >= 18 mirror row 0 and are discarded */
   float row[GQ_NVD], b = g[i];
+  const int li = i < 6 ? -1 : (i - 6) / 3;
 #pragma unroll
   for (int j = 0; j < GQ_NVD; j++) {
     const int hi = i > j ? i : j, lo = i > j ? j : i;
-    row[j] = Hd[hi * (hi + 1) / 2 + lo];
+    float v = 0.0f;
+    if (hi < 6) v = W.u2.n.Hb[hi][lo];
+    else if (lo < 6) v = W.u2.n.Hc[hi - 6][lo];
+    else if ((hi - 6) / 3 == (lo - 6) / 3) v = W.u2.n.Hc[hi - 6][6 + (lo - 6) % 3];
+    row[j] = v;
+  }
+  for (int r = r0; r < r1; r++) { /* wave-uniform: cross-leg entries */
+    const float a = W.force[r] * W.u.B[r][i];
+#pragma unroll
+    for (int j = 6; j < GQ_NVD; j++) row[j] += ((j - 6) / 3 != li && li >= 0) ? a * W.u.B[r][j] : 0.0f;
   }
 #pragma unroll
   for (int k = 0; k < GQ_NVD - 1; k++) {
@@ -281,6 +294,118 @@ __device__ inline void solve_dense_lanes(const float* Hd, const float* g, float*
   }
   wave_barrier(); /* g may alias out */
   if (lane < GQ_NVD) out[lane] = x;
+  wave_barrier();
+}
+
+/* solve_tree_fused for TWO right-hand sides of the same tree-sparse system (out = S^-1 g, out2 = S^-1 g2): the elimination
+ * of the matrix is shared, each extra right-hand side costs ~70 FMAs.  Used by the Sherman-Morrison step of an env with ONE
+ * active row that couples two legs (newton_solve). */
+__device__ inline void solve_tree_fused2(const float (*Sc)[9], const float (*Sb)[6], const float* g, float* out, const float* g2, float* out2) {
+  const int lane = lane_id();
+  { /* every lane runs the same instruction stream (lanes >= 4 mirror leg 0 and are discarded at the end): no branch, and the
+     * cross-lane sums are called from wave-uniform control flow */
+    const int hh = 3 * (lane < 4 ? lane : 0), t = hh + 1, c = hh + 2; /* joint indices of the leg (dof = 6 + joint) */
+    float rc[9], rt[8], rh[7], bb[21], gb[6], hb[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { rc[j] = Sc[c][j]; rt[j] = Sc[t][j]; rh[j] = Sc[hh][j]; }
+    rc[6] = Sc[c][6]; rc[7] = Sc[c][7]; rc[8] = Sc[c][8];
+    rt[6] = Sc[t][6]; rt[7] = Sc[t][7];
+    rh[6] = Sc[hh][6];
+    float gc = g[6 + c], gt = g[6 + t], gh = g[6 + hh];
+    float hc = g2[6 + c], ht = g2[6 + t], hhh = g2[6 + hh];
+    /* base block and right-hand side: lane 0 carries S_bb and g_b, the others start from zero (summed below) */
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      gb[i] = lane == 0 ? g[i] : 0.0f; hb[i] = lane == 0 ? g2[i] : 0.0f;
+#pragma unroll
+      for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] = lane == 0 ? Sb[i][j] : 0.0f;
+    }
+    /* eliminate the calf: rows thigh, hip, base */
+    const float ic = fast_rcp(rc[8]);
+    {
+      float f = rc[7] * ic;
+#pragma unroll
+      for (int j = 0; j <= 7; j++) rt[j] -= rc[j] * f;
+      gt -= gc * f; ht -= hc * f;
+      f = rc[6] * ic;
+#pragma unroll
+      for (int j = 0; j <= 6; j++) rh[j] -= rc[j] * f;
+      gh -= gc * f; hhh -= hc * f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        f = rc[i] * ic;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rc[j] * f;
+        gb[i] -= gc * f; hb[i] -= hc * f;
+      }
+    }
+    const float it = fast_rcp(rt[7]);
+    {
+      float f = rt[6] * it;
+#pragma unroll
+      for (int j = 0; j <= 6; j++) rh[j] -= rt[j] * f;
+      gh -= gt * f; hhh -= ht * f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        f = rt[i] * it;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rt[j] * f;
+        gb[i] -= gt * f; hb[i] -= ht * f;
+      }
+    }
+    const float ih = fast_rcp(rh[6]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const float f = rh[i] * ih;
+#pragma unroll
+      for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rh[j] * f;
+      gb[i] -= gh * f; hb[i] -= hhh * f;
+    }
+    /* Schur complement of the base: sum of the four legs */
+#pragma unroll
+    for (int q = 0; q < 21; q++) bb[q] = quad_sum(bb[q]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { gb[i] = quad_sum(gb[i]); hb[i] = quad_sum(hb[i]); }
+    /* 6x6 base system, redundantly on each of the four lanes: elimination from the last row up (same order as the tree) */
+    float xb[6], yb[6];
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+      const float inv = fast_rcp(bb[k * (k + 1) / 2 + k]);
+#pragma unroll
+      for (int i = 0; i < k; i++) {
+        const float f = bb[k * (k + 1) / 2 + i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= bb[k * (k + 1) / 2 + j] * f;
+        gb[i] -= gb[k] * f; hb[i] -= hb[k] * f;
+      }
+      gb[k] *= inv; hb[k] *= inv; /* gb[k] now holds (g_k - sum_{j<k} S_kj x_j ... ) / S_kk once the x_j below are known */
+      bb[k * (k + 1) / 2 + k] = inv;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      float s = gb[k], s2 = hb[k];
+#pragma unroll
+      for (int j = 0; j < k; j++) { const float cf = bb[k * (k + 1) / 2 + j] * bb[k * (k + 1) / 2 + k]; s -= cf * xb[j]; s2 -= cf * yb[j]; }
+      xb[k] = s; yb[k] = s2;
+    }
+    /* back-substitution up the leg: hip, thigh, calf */
+    float xh = gh, xt = gt, xc = gc, yh = hhh, yt = ht, yc = hc;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { xh -= rh[j] * xb[j]; yh -= rh[j] * yb[j]; }
+    xh *= ih; yh *= ih;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { xt -= rt[j] * xb[j]; yt -= rt[j] * yb[j]; }
+    xt = (xt - rt[6] * xh) * it; yt = (yt - rt[6] * yh) * it;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { xc -= rc[j] * xb[j]; yc -= rc[j] * yb[j]; }
+    xc = (xc - rc[6] * xh - rc[7] * xt) * ic; yc = (yc - rc[6] * yh - rc[7] * yt) * ic;
+    wave_barrier(); /* g may alias out: every lane has read its right-hand side */
+    if (lane < 4) { out[6 + hh] = xh; out[6 + t] = xt; out[6 + c] = xc; out2[6 + hh] = yh; out2[6 + t] = yt; out2[6 + c] = yc; }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) { out[j] = xb[j]; out2[j] = yb[j]; }
+    }
+  }
   wave_barrier();
 }
 
@@ -437,7 +562,7 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
 template <bool DBG, bool CONE>
 __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, int rtype, float rR, float raref,
                                      float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg, const EllRow E, int prio,
-                                     const bool xleg) {
+                                     const bool xrow, const int xrow0) {
   const int lane = lane_id();
   /* the row's J lives in LDS (W.u.B[lane]) and is re-read where needed: 18 fewer registers across the iterations */
   /* (each use goes through opaque_ptr: otherwise the compiler merges the re-reads, keeps the 18 values live across the
@@ -551,7 +676,20 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     if (iter > 0 && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(gterm)) { exit_code = 4; break; }
     if (lane < GQ_NVD) grad[lane] = -gd; /* right-hand side of H search = -grad */
     wave_barrier();
-    W.force[lane] = wact; /* Hessian weights of the rows replace the forces */
+    /* a contact between two different legs couples them in H = M + J'DJ, which then no longer has M's tree sparsity - but
+     * only while one of its rows is active (wave-uniform tests; robot-robot rows are the last ones, + their virtual rows).
+     * ONE active coupling row c (the common case with frictionless leg geoms): H = H0 + w c c' with H0 tree-sparse, solved
+     * by Sherman-Morrison on two tree solves that share their elimination.  More: the dense lane-parallel step. */
+    bool xl = false, xsm = false;
+    int xr = 0;
+    if (xrow0 > 0) {
+      const uint64_t xm = ballot(xrow && (wact != 0.0f || (CONE && zone == 2)));
+      xl = xm != 0;
+      xsm = !CONE && popc64(xm) == 1;
+      xr = xsm ? ffs64(xm) : 0;
+    }
+    const float xw = xsm ? bcast(wact, xr) : 0.0f;
+    W.force[lane] = (xsm && lane == xr) ? 0.0f : wact; /* Hessian weights of the rows replace the forces */
     wave_barrier();
     int nrowh = nefc; /* rows the Hessian assembly walks */
     if constexpr (CONE) {
@@ -609,33 +747,6 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     /* ---- Hessian in M's tree-sparse layout: H = M + sum_r w_r J_r' J_r.  117 structurally non-zero entries, two
      * passes of one entry per lane.  Friction-loss rows are +-e_dof: their weight goes straight to the diagonal; limit
      * rows (few) and contact rows are walked generically. */
-    if (xleg) { /* wave-uniform: dense Hessian (packed lower triangle above the rows, GQ_SELF_ROWS) and the lane-parallel dense solve */
-      float* Hd = &W.u.B[GQ_SELF_ROWS][0];
-      for (int pass = 0; pass < 3; pass++) {
-        const int e = pass * GQ_WAVE + lane;
-        if (e < GQ_NVD * (GQ_NVD + 1) / 2) {
-          int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-          if ((i + 1) * (i + 2) / 2 <= e) i++;
-          if (i * (i + 1) / 2 > e) i--;
-          const int j = e - i * (i + 1) / 2;
-          float s0 = 0.0f, s1 = 0.0f;
-          if (i < 6) s0 = W.Mb[i][j];
-          else if (j < 6) s0 = W.Mc[i - 6][j];
-          else if ((i - 6) / 3 == (j - 6) / 3) s0 = W.Mc[i - 6][6 + (j - 6) % 3];
-          if (i == j) { const int fr = m.fl_row_of_dof[i]; if (fr >= 0) s0 += W.force[fr]; }
-          int r = nfl;
-          for (; r + 2 <= nrowh; r += 2) {
-            s0 += W.force[r] * W.u.B[r][i] * W.u.B[r][j];
-            s1 += W.force[r + 1] * W.u.B[r + 1][i] * W.u.B[r + 1][j];
-          }
-          if (r < nrowh) s0 += W.force[r] * W.u.B[r][i] * W.u.B[r][j];
-          Hd[e] = s0 + s1;
-        }
-      }
-      wave_barrier();
-      NW_T(3);
-      solve_dense_lanes(Hd, grad, search);
-    } else {
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       if (hent[pass] >= 0) {
@@ -672,8 +783,17 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     }
     wave_barrier();
     NW_T(3);
-    solve_tree_fused<false>(W.u2.n.Hc, W.u2.n.Hb, nullptr, 0.0f, grad, search);
-    }
+    if (xsm) {
+      float* z1 = W.u2.n.nw[1];
+      solve_tree_fused2(W.u2.n.Hc, W.u2.n.Hb, grad, search, W.u.B[xr], z1);
+      const float cr = lane < GQ_NVD ? W.u.B[xr][lane] : 0.0f;
+      const float cz0 = wave_sum(lane < GQ_NVD ? cr * search[lane] : 0.0f), cz1 = wave_sum(lane < GQ_NVD ? cr * z1[lane] : 0.0f);
+      const float lam = cz0 / (1.0f / xw + cz1);
+      wave_barrier();
+      if (lane < GQ_NVD) search[lane] -= lam * z1[lane];
+      wave_barrier();
+    } else if (xl) newton_dense_step(W, xrow0, nrowh, grad, search);
+    else solve_tree_fused<false>(W.u2.n.Hc, W.u2.n.Hb, nullptr, 0.0f, grad, search);
     NW_T(4);
     /* ---- exact line search on phi(alpha) = cost(qacc + alpha search): safeguarded Newton on phi' */
     float v = 0.0f;

@@ -202,8 +202,9 @@ __device__ inline void resample_wave(const StepArgs& a, const int env) {
  * stage timers and the GQ_STOP_STAGE cut compiled in - the production variant carries none of it (no timer
  * accumulators or row data kept live for the record: they cost registers inside the solver loop).
  * CONE: elliptic friction cones (Newton only): contacts take dim rows [n, t1, t2, torsion, roll1, roll2].
- * BOXES: the scene has static world boxes (gq_boxes.h; Newton only): contacts carry their own normal. */
-template <int SOLVER, int MODE, bool CONE, bool BOXES>
+ * BOXES: the scene has static world boxes (gq_boxes.h; Newton only): contacts carry their own normal.
+ * SELF: robot self-collision (Newton only): contacts between two bodies of the robot, general frames, two-body rows. */
+template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF>
 __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
@@ -211,6 +212,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   opaque(lane_o); opaque_s(env_o);
   const int lane = lane_o, env = env_o;
   constexpr bool DBG = MODE == 1;
+  constexpr bool GEN = BOXES || SELF; /* contacts carry their own frame and may join two bodies of the robot */
   const GQ_MODEL GqDevModel& m = *mptr(a.model);
   const float h = m.timestep;
   /* the record describes the forward pass whose results the caller sees: the user's step, the reset's own step of
@@ -406,6 +408,8 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   GQ_TICK(5);
   /* ================================================================ S6: collision with the floor (z = 0) */
   const int nlg = m.nlg;
+  SelfPrefetch self_pre;
+  if constexpr (SELF) self_pre = self_prefetch(m);
   stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), false);
   /* reset on a scene without world boxes / height field: the lift loop of QuadrupedEnv.reset (quadruped_env.py:376-388:
    * z += 1.1 max|dist| until no foot-body contact, <= 100 iterations) runs HERE, on the distances this step's own
@@ -525,7 +529,10 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   if constexpr (BOXES) {
     const double bx0 = W.bxy[0], by0 = W.bxy[1]; /* base x/y of this forward pass, f64 */
     const float mu_b = W.mu_env;
-    stage_box_contacts<CONE>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), bx0, by0, mu_b);
+    stage_box_contacts<CONE, SELF>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), bx0, by0, mu_b, self_pre);
+  } else if constexpr (SELF) {
+    const float mu_b = W.mu_env;
+    stage_self_contacts<CONE>(W, m, mu_b, self_pre);
   }
   const int nefc = uniform(W.nefc), ncon = uniform(W.ncon), nlim = uniform(W.nlim), nfl = m.nfl; /* SGPRs */
   if (timing) { /* body poses go to the debug record now: xmat's LDS is reused by the Newton solver */
@@ -549,7 +556,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   int ecode = 0, er0 = lane;
   float efri = 0.0f, emu = 0.0f, eR0 = 1.0f, econ_dist = 0.0f, econ_inc = 0.0f;
   int jd = -1, jleg = -1, jdepth = -1;   /* single-entry rows: dof index; contact rows: leg / depth of the body (-1: base) */
-  int jleg1 = -1, jdepth1 = -1;          /* robot-robot contacts (BOXES variants): chain of the contact's FIRST body, entering J with a minus sign */
+  int jleg1 = -1, jdepth1 = -1;          /* robot-robot contacts (SELF variants): chain of the contact's FIRST body, entering J with a minus sign */
   bool internal = false;
   float jsgn = 0.0f;
   bool jcon = false;
@@ -570,21 +577,21 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       if (lane >= W.con_row[q]) c = q;
     const int e = lane - W.con_row[c], dim = W.con_dim[c];
     int body = W.con_body[c], body1 = -1;
-    if constexpr (BOXES) { body1 = GQ_CON_BODY1(body); body = GQ_CON_BODY2(body); }
+    if constexpr (GEN) { body1 = GQ_CON_BODY1(body); body = GQ_CON_BODY2(body); }
     const float mu = W.con_mu[c];
     rpos = W.con_dist[c]; rmargin = W.con_inc[c];
     rsolref[0] = W.con_solref[c][0]; rsolref[1] = W.con_solref[c][1];
 #pragma unroll
     for (int q = 0; q < 5; q++) rsolimp[q] = W.con_solimp[c][q];
     float tran = m.body_invweight0[body][0], rotw = m.body_invweight0[body][1];
-    if constexpr (BOXES) if (body1 >= 0) { /* contact between two bodies of the robot: both bodies' weights (mj_makeConstraint) */
+    if constexpr (GEN) if (body1 >= 0) { /* contact between two bodies of the robot: both bodies' weights (mj_makeConstraint) */
       tran += m.body_invweight0[body1][0]; rotw += m.body_invweight0[body1][1];
       internal = true;
       if (body1 > 0) { jleg1 = (body1 - 1) / 3; jdepth1 = (body1 - 1) % 3; }
     }
     /* contact frame (mju_makeFrame): horizontal floor n = z, t1 = y, t2 = -x; box contacts bring their own normal */
     V3 cn = v3(0.0f, 0.0f, 1.0f), ct1 = v3(0.0f, 1.0f, 0.0f), ct2 = v3(-1.0f, 0.0f, 0.0f);
-    if constexpr (BOXES) { cn = ld3(GQ_BX_CONNRM(W) + 3 * c); make_frame(cn, ct1, ct2); }
+    if constexpr (GEN) if (GQ_BX_WCLS(W)[c] != -1) { cn = ld3(GQ_BX_CONNRM(W) + 3 * c); make_frame(cn, ct1, ct2); } /* floor contacts keep the fixed frame */
     dir = cn;
     bool rotational = false;
     if (dim == 1) { rtype = ROW_CONTACT1; rdiag = tran; }
@@ -594,7 +601,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       emu = mu / sqrtf(m.impratio);
       /* torsional / rolling coefficients: same mixing rule as the sliding one (S6), _set_ground_friction overrides
        * floor and feet with [mu, 0.005, 0.0]; clamped at mjMINMU */
-      const int cword = W.con_geom[c], code = BOXES ? (cword & 0xff) : cword, code1 = BOXES ? ((cword >> 8) & 0xff) - 1 : -1;
+      const int cword = W.con_geom[c], code = GEN ? (cword & 0xff) : cword, code1 = GEN ? ((cword >> 8) & 0xff) - 1 : -1;
       const float mu_env = W.mu_env;
       const int rule = code1 >= 0 ? (cword >> 16) & 3 : (code < 4 ? m.foot_fric_rule[code] : m.lg[code - 4].fric_rule);
       float fr[3] = {mu, 0.0f, 0.0f};
@@ -602,7 +609,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       for (int q = 1; q < 3; q++) {
         const float ovr = q == 1 ? 0.005f : 0.0f;
         float ff = mu_env >= 0.0f ? ovr : m.floor_friction[q];
-        if constexpr (BOXES) {
+        if constexpr (GEN) {
           const int wc = GQ_BX_WCLS(W)[c];
           if (wc >= 0) ff = m.boxcls_friction[wc][q];
           if (code1 >= 0) ff = code1 < 4 ? (mu_env >= 0.0f ? ovr : m.foot_friction[code1][q]) : m.lg[code1 - 4].friction[q]; /* the contact's first geom is a robot geom */
@@ -636,19 +643,24 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   for (int k = 0; k < GQ_NVD; k++) {
     const float* sd = W.cdof[k]; /* wave-uniform LDS reads */
     float v = sd[0] * w.x + sd[1] * w.y + sd[2] * w.z + sd[3] * dir.x + sd[4] * dir.y + sd[5] * dir.z;
-    bool on_chain = k < 6 ? jcon : (jcon && (k - 6) / 3 == jleg && (k - 6) % 3 <= jdepth);
-    if constexpr (BOXES) { /* J(second body) - J(first body) at the contact point: the base columns cancel, shared ancestors too */
-      if (k < 6) on_chain = on_chain && !internal;
-      else {
-        const bool on1 = internal && (k - 6) / 3 == jleg1 && (k - 6) % 3 <= jdepth1;
-        v = (on_chain ? v : 0.0f) - (on1 ? v : 0.0f);
-        on_chain = on_chain || on1;
-      }
-    }
+    const bool on_chain = k < 6 ? (jcon && !internal) : (jcon && (k - 6) / 3 == jleg && (k - 6) % 3 <= jdepth); /* robot-robot rows: the base columns cancel */
     v = on_chain ? v : (k == jd ? jsgn : 0.0f);
     vel += v * W.qvel[k];
     if constexpr (SOLVER == 1) W.u.B[lane][k] = v; /* rows >= nefc are all-zero: rtype NONE sets no descriptor */
     else J[k] = v;
+  }
+  if constexpr (SELF) if (uniform(W.nself) > 0) { /* wave-uniform, rare: J(second body) - J(first body) at the contact point -
+                                                     * the chain of the contact's first body enters with a minus sign (dofs the
+                                                     * two chains share cancel) */
+#pragma unroll
+    for (int k = 6; k < GQ_NVD; k++) {
+      const float* sd = W.cdof[k];
+      const bool on1 = internal && (k - 6) / 3 == jleg1 && (k - 6) % 3 <= jdepth1;
+      const float v1 = on1 ? sd[0] * w.x + sd[1] * w.y + sd[2] * w.z + sd[3] * dir.x + sd[4] * dir.y + sd[5] * dir.z : 0.0f;
+      vel -= v1 * W.qvel[k];
+      if constexpr (SOLVER == 1) W.u.B[lane][k] -= v1;
+      else J[k] -= v1;
+    }
   }
   float rR = 1.0f, raref = 0.0f;
   if (rtype == ROW_FRICTION) { rR = flR; raref = -flB * vel; }
@@ -686,10 +698,15 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     const EllRow ell = {ecode, er0, efri, emu, 1.0f / eR0};
     /* a contact between two different legs couples them in the Hessian M + J'DJ, which then no longer has M's tree
      * sparsity: such an env takes the dense Newton step */
-    const bool xleg = BOXES && ballot(internal && jleg1 >= 0 && jleg >= 0 && jleg1 != jleg) != 0;
+    const bool xrow = SELF && internal && jleg1 >= 0 && jleg >= 0 && jleg1 != jleg && m.self_cut != 3;
+    const bool xleg = SELF && ballot(xrow) != 0;
+    if constexpr (DBG && SELF) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 31] = (float)(uniform(W.nself) + (xleg ? 100 : 0));
     const float fN = newton_solve<DBG, CONE>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
-                                  timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint, xleg);
-    if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)(iter < 2 ? 0 : (iter > 2 ? 3 : 2));
+                                  timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint, xrow,
+                                  xleg ? uniform(W.con_row[ncon - uniform(W.nself)]) : 0);
+    /* a coupled-leg Newton step (Sherman-Morrison / dense) is the most expensive thing a wave can do, and leg-leg contacts
+     * persist over several steps: such an env keeps top issue priority */
+    if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)((xleg && iter >= 2) ? 3 : (iter < 2 ? 0 : (iter > 2 ? 3 : 2)));
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
@@ -1006,7 +1023,9 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
         const float f0 = W.force[r0], f1 = W.force[r0 + 1], f2 = W.force[r0 + 2], f3 = W.force[r0 + 3], mu = W.con_mu[c];
         fn = f0 + f1 + f2 + f3; ft1 = mu * (f0 - f1); ft2 = mu * (f2 - f3);
       }
-      if constexpr (BOXES) { /* frame' * f with the contact's own frame */
+      bool own_frame = false;
+      if constexpr (GEN) own_frame = GQ_BX_WCLS(W)[c] != -1;
+      if (own_frame) { /* frame' * f with the contact's own frame */
         const V3 cn = ld3(GQ_BX_CONNRM(W) + 3 * c);
         V3 ct1, ct2;
         make_frame(cn, ct1, ct2);

@@ -219,7 +219,7 @@ def oracle_reset_lift(o, q0, v0, hip_height):
         it += 1
 
 
-GQ_SELF_ROWS = 54   # csrc/gq_model_dev.h
+GQ_SELF_ROWS = 64
 
 
 def oracle_fits_self_budget(o, cone):
@@ -231,7 +231,7 @@ def oracle_fits_self_budget(o, cone):
         return True
     dims = o.get('contact_dim').astype(int)
     reserve = int(sum(d - 1 for d in dims if d > 1)) if cone else 0
-    return o.nefc + reserve <= GQ_SELF_ROWS
+    return o.nefc + reserve <= GQ_SELF_ROWS   # = the general budget since the dense step works out of registers
 
 
 def self_contact_states(md, n, rng, o, z=(0.5, 0.9), want_cross=None):

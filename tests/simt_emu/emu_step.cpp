@@ -61,7 +61,7 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
       __shared__ gq::WaveMem W;
       int pass = call.first_pass;
       bool respawn = call.auto_reset == 2 && f.s.pending[e];
-      const bool boxes = M.nbox > 0 || M.hf_nrow > 0 || M.nbp > 0;
+      const bool boxes = M.nbox > 0 || M.hf_nrow > 0, self = M.nsp > 0;
       int lift = (call.first_pass && lift_pending) ? (int)lift_pending[e] : 0;
       for (;;) {
         if (respawn) {
@@ -69,9 +69,10 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
           pass = call.auto_reset;
         }
         int term;
-        if (M.solver != 1) term = gq::step_wave<0, 1, false, false>(f.s, call, W, pass, lift);
-        else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true>(f.s, call, W, pass, lift) : gq::step_wave<1, 1, false, true>(f.s, call, W, pass, lift);
-        else term = M.cone ? gq::step_wave<1, 1, true, false>(f.s, call, W, pass, lift) : gq::step_wave<1, 1, false, false>(f.s, call, W, pass, lift);
+        if (M.solver != 1) term = gq::step_wave<0, 1, false, false, false>(f.s, call, W, pass, lift);
+        else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true, true>(f.s, call, W, pass, lift) : gq::step_wave<1, 1, false, true, true>(f.s, call, W, pass, lift);
+        else if (self) term = M.cone ? gq::step_wave<1, 1, true, false, true>(f.s, call, W, pass, lift) : gq::step_wave<1, 1, false, false, true>(f.s, call, W, pass, lift);
+        else term = M.cone ? gq::step_wave<1, 1, true, false, false>(f.s, call, W, pass, lift) : gq::step_wave<1, 1, false, false, false>(f.s, call, W, pass, lift);
         if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
       }
@@ -100,7 +101,7 @@ extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mas
     if (mask && !mask[e]) continue;
     emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
       __shared__ gq::WaveMem W;
-      if ((M.nbox > 0 || M.hf_nrow > 0 || M.nbp > 0)) gq::reset_wave<true>(a, W); else gq::reset_wave<false>(a, W);
+      if ((M.nbox > 0 || M.hf_nrow > 0)) gq::reset_wave<true>(a, W); else gq::reset_wave<false>(a, W);
     });
   }
   return 0;

@@ -26,6 +26,15 @@ for p in $PARTS; do
           timeout 600 python bench.py --robot hyqreal1 --scene random_boxes --imu --heightmap --no-cpu-baseline > $OUT/bench_cfg5_hyqreal1_boxes_imu_hm.json 2> $OUT/bench_cfg5.err
           timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_like_20steps.json 2> $OUT/bench_20.err;;
     parity) timeout 1500 python tests/reports/newton_parity_report.py 512 > $OUT/newton_parity_report.txt 2>&1;;
+    selfab) timeout 600 python bench.py --no-cpu-baseline --no-secondary > $OUT/bench_self_on.json 2> $OUT/bench_self_on.err
+            timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-self-collision > $OUT/bench_self_off.json 2> $OUT/bench_self_off.err
+            GQ_FORCE_SELF=1 timeout 600 python bench.py --no-cpu-baseline --no-secondary --no-self-collision > $OUT/bench_self_variant_nopairs.json 2> $OUT/bench_self_variant_nopairs.err
+            for f in self_on self_off self_variant_nopairs; do python -c "import json; d=json.load(open('$OUT/bench_$f.json')); print('$f', round(d['value']/1e6,2), 'M', round(d['roofline']['kernel_ms']*1e3,1), 'us kernel')"; done;;
+    stages) timeout 600 python tools/perf_probe.py stages 256 > $OUT/stages256.txt 2>&1
+            timeout 600 python tools/perf_probe.py stages 4096 > $OUT/stages4096.txt 2>&1;;
+    selfcut) for c in 0 2 4; do GQ_SELF_CUT=$c timeout 600 python bench.py --no-cpu-baseline --no-secondary > $OUT/bench_selfcut$c.json 2> $OUT/bench_selfcut$c.err; python -c "import json; d=json.load(open('$OUT/bench_selfcut$c.json')); print('self cut $c', round(d['value']/1e6,2), 'M', round(d['roofline']['kernel_ms']*1e3,1), 'us kernel')"; done;;
+    timeline) timeout 600 python tools/wave_timeline.py 4096 > $OUT/wave_timeline.txt 2>&1
+              timeout 600 python tools/wave_timeline.py 4096 mini_cheetah noself > $OUT/wave_timeline_noself.txt 2>&1;;
     nscan) timeout 900 python tools/nscan.py > $OUT/nscan.txt 2>&1;;
     profiles) timeout 2400 bash tools/run_profiles.sh $TAG > $OUT/run_profiles.txt 2>&1;;
   esac

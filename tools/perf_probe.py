@@ -40,9 +40,9 @@ if __name__ == '__main__' and len(sys.argv) == 1:
 
 def stage_times(n=4096, iters=100, tol=1e-8, solver='newton', robot='mini_cheetah'):
     env = QuadrupedEnv(robot, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', solver=solver, solver_iterations=iters, solver_tolerance=tol, seed=1)
-    env.reset()
+    env.reset(random=True)
     g = torch.Generator(device='cuda').manual_seed(0)
-    for i in range(60): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)
+    for i in range(300): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)   # the benchmark's steady state
     env.enable_debug(n)
     env.step(torch.randn(n, 12, generator=g, device='cuda') * 50); torch.cuda.synchronize()
     d = env.debug_internals(n, ['timer', 'niter', 'nefc'])
@@ -61,7 +61,7 @@ def stage_times(n=4096, iters=100, tol=1e-8, solver='newton', robot='mini_cheeta
         prev = 0.0; parts = []
         for k in order:
             parts.append(T[e, k] - prev); prev = T[e, k]
-        print(f'   env {e:5d}: {T[e,13]:8.0f} | ' + ' '.join(f'{x:6.0f}' for x in parts) + f' | niter {nit[e]:.0f} nefc {ne[e]:.0f}')
+        print(f'   env {e:5d}: {T[e,13]:8.0f} | ' + ' '.join(f'{x:6.0f}' for x in parts) + f' | niter {nit[e]:.0f} nefc {ne[e]:.0f} self {T[e,31]:.0f} ls trials {T[e,29]:.0f} full {T[e,30]:.0f} exit {T[e,23]:.0f} | newton parts ' + ' '.join(f'{T[e,j]:.0f}' for j in range(16, 23)))
     h, edges = np.histogram(T[:, 13], bins=12)
     print('  histogram of totals:', ' '.join(f'{int(lo/1000)}k:{c}' for lo, c in zip(edges[:-1], h)))
     hn = np.bincount(nit.astype(int)); print('  niter histogram:', hn.tolist())
@@ -69,6 +69,11 @@ def stage_times(n=4096, iters=100, tol=1e-8, solver='newton', robot='mini_cheeta
         for nm, k in zip(['setup', 'state+cost', 'gradient', 'hessian', 'solve', 'ls prep', 'ls trials+upd'], range(16, 23)):
             print(f'    newton {nm:13s} {T[:, k].mean():9.0f} {np.percentile(T[:, k], 95):9.0f} {T[:, k].max():9.0f}   per-iter {T[:, k].sum() / max(1, nit.sum()):7.0f}')
         print(f'    line-search trials per iteration {T[:, 29].sum() / max(1, nit.sum()):.2f}; full-step shortcuts per iteration {T[:, 30].sum() / max(1, nit.sum()):.2f}')
+        xl = T[:, 31] >= 100; ns = T[:, 31] % 100
+        for nm, sel in (('no robot-robot contact', ns == 0), ('robot-robot contact, tree step', (ns > 0) & ~xl), ('cross-leg contact, dense step', xl)):
+            if sel.sum():
+                print(f'    {nm:32s}: {sel.sum():5d} waves, niter mean {nit[sel].mean():.2f} max {nit[sel].max():.0f}, nefc mean {ne[sel].mean():.1f}, total {T[sel, 13].mean():8.0f} cycles, '
+                      f'S6b {(T[sel, 6] - T[sel, 14]).mean():6.0f} S7 {(T[sel, 7] - T[sel, 6]).mean():6.0f} solver {(T[sel, 9] - T[sel, 8]).mean():7.0f}; per iteration: hessian {T[sel, 19].sum() / nit[sel].sum():6.0f} solve {T[sel, 20].sum() / nit[sel].sum():6.0f}')
         for k in range(2, int(nit.max()) + 1):
             sel = nit == k
             if sel.sum():

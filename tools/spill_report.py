@@ -12,7 +12,7 @@ ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / 'gym_quadruped_amd' / 'csrc'
 
 
-def main(solver='1'):
+def main(solver='1', SELF='0'):
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / 'k.s'
         subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', f'-I{ROOT}/include', f'-I{CSRC}',
@@ -26,7 +26,7 @@ def main(solver='1'):
                 continue
             m = re.match(r'^(_Z\w+):', line)
             if m:
-                infn = m.group(1).startswith(f'_ZN2gq11step_kernelILi{solver}ELi0ELb0ELb0EEE')
+                infn = m.group(1).startswith(f'_ZN2gq11step_kernelILi{solver}ELi0ELb0ELb0ELb{SELF}EEE')
                 continue
             m = re.match(r'\s*\.loc\s+(\d+)\s+(\d+)', line)
             if m:
@@ -41,4 +41,4 @@ def main(solver='1'):
 
 
 if __name__ == '__main__':
-    main(*(sys.argv[1:2] or ['1']))
+    main(*(sys.argv[1:3] or ['1']))

@@ -9,10 +9,11 @@ from gym_quadruped_amd.quadruped_env import QuadrupedEnv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 robot = sys.argv[2] if len(sys.argv) > 2 else 'mini_cheetah'
-env = QuadrupedEnv(robot, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', seed=1)
-env.reset()
+selfcol = None if (len(sys.argv) <= 3 or sys.argv[3] != 'noself') else False
+env = QuadrupedEnv(robot, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', seed=1, self_collision=selfcol)
+env.reset(random=True)
 g = torch.Generator(device='cuda').manual_seed(0)
-for i in range(60): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)
+for i in range(300): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)
 env.enable_debug(n)
 pend = env._terminated.clone().cpu().numpy().astype(bool) if hasattr(env, '_terminated') else np.zeros(n, bool)
 env.step(torch.randn(n, 12, generator=g, device='cuda') * 50); torch.cuda.synchronize()
@@ -35,10 +36,13 @@ if pend.sum(): print(f'  pending:  {pend.sum():5d} waves, lifetime mean {dur[pen
 for hv in range(4):
     sel = hint == hv
     if sel.sum(): print(f'  hint {hv}: {sel.sum():5d} waves, niter histogram {np.bincount(nit[sel], minlength=7).tolist()}, lifetime mean {dur[sel].mean():6.1f}')
+xl = T[:, 31] >= 100; ns = (T[:, 31] % 100).astype(int)
+for nm, sel in (('no robot-robot contact', (ns == 0) & ~pend), ('robot-robot contact, tree step', (ns > 0) & ~xl & ~pend), ('cross-leg contact (Sherman-Morrison / dense step)', xl & ~pend)):
+    if sel.sum(): print(f'  {nm:50s}: {sel.sum():5d} waves, niter mean {nit[sel].mean():.2f} max {nit[sel].max()}, lifetime mean {dur[sel].mean():6.1f} p99 {np.percentile(dur[sel], 99):6.1f} max {dur[sel].max():6.1f} us, end max {t1[sel].max():6.1f}')
 busy = np.array([((t0 <= t) & (t1 > t)).sum() for t in np.arange(0, t1.max(), 2.0)])
 print('resident waves every 2 us:', busy.tolist())
 last = np.argsort(-t1)[:12]
 print('last waves to finish (end us | start | niter nefc pending | co-resident waves on the SIMD: their niter):')
 for e in last:
     co = np.where(slot == slot[e])[0]
-    print(f'  env {e:5d}: {t1[e]:6.1f} | {t0[e]:5.1f} | {nit[e]} {int(d[e]["nefc"][0]):2d} {int(pend[e])} hint {hint[e]} | ' + ' '.join(f'{nit[c]}{"r" if pend[c] else ""}h{hint[c]}@{t1[c]:.0f}' for c in co if c != e))
+    print(f'  env {e:5d}: {t1[e]:6.1f} | {t0[e]:5.1f} | {nit[e]} {int(d[e]["nefc"][0]):2d} {int(pend[e])} hint {hint[e]} self {int(T[e, 31])} | ' + ' '.join(f'{nit[c]}{"r" if pend[c] else ""}h{hint[c]}@{t1[c]:.0f}' for c in co if c != e))
