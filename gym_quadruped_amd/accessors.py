@@ -79,6 +79,55 @@ class AccessorsMixin:
         if getattr(self, '_rec_tensor', None) is not None:
             self._rec_filled_at = int(self._launches)
 
+    # ------------------------------------------------------------------ the MuJoCo entry points of the lower boundary, batched
+    def mj_jac(self, point, body, qpos=None):
+        """``mujoco.mj_jac(m, d, jacp, jacr, point, body)`` (reference :728-735) for every env at pose ``qpos`` (default: the
+        current state): ``point`` [N, 3] world coordinates, ``body`` MuJoCo body id or name.  Returns (jacp, jacr), each
+        [N, 3, 18] float32.  One production kernel launch (``gq_jac``), no inspection record."""
+        if isinstance(body, str):
+            body = self.mjModel.body_names.index(body)
+        N, dev = self.num_envs, self.device
+        q = self._qpos if qpos is None else torch.as_tensor(qpos, dtype=torch.float64, device=dev).reshape(-1, 19).expand(N, 19).contiguous()
+        p = torch.as_tensor(point, dtype=torch.float64, device=dev).reshape(-1, 3).expand(N, 3).contiguous()
+        jp = torch.empty(N, 3, 18, dtype=torch.float32, device=dev); jr = torch.empty_like(jp)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self._L.gq_jac(self._hbatch, q.data_ptr(), int(body), p.data_ptr(), jp.data_ptr(), jr.data_ptr(), stream), 'gq_jac')
+        return jp, jr
+
+    def mj_ray(self, pnt, vec, return_geom=False):
+        """``mujoco.mj_ray`` against the static geoms of the scene (floor, world boxes, height field; reference
+        sensors/heightmap.py:90-99 uses flg_static=1): ``pnt`` [N, R, 3] world origins, ``vec`` [N, R, 3] directions.
+        Returns distances [N, R] in units of |vec| (-1: no hit) and, if asked, the geom hit (0 floor, 1 + box, 1 + nbox
+        height field, -1 none)."""
+        N, dev = self.num_envs, self.device
+        o = torch.as_tensor(pnt, dtype=torch.float64, device=dev).reshape(N, -1, 3).contiguous()
+        d = torch.as_tensor(vec, dtype=torch.float32, device=dev).reshape(N, -1, 3).contiguous()
+        R = o.shape[1]
+        dist = torch.empty(N, R, dtype=torch.float32, device=dev)
+        geom = torch.empty(N, R, dtype=torch.int32, device=dev) if return_geom else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self._L.gq_ray(self._hbatch, o.data_ptr(), d.data_ptr(), int(R), dist.data_ptr(), None if geom is None else geom.data_ptr(), stream), 'gq_ray')
+        return (dist, geom) if return_geom else dist
+
+    def mj_forward(self, ctrl=None, stage=0):
+        """``mujoco.mj_forward`` (stage 0, reference :1321) / ``mujoco.mj_step1`` (stage 1, :376, :384) for every env without
+        advancing the state; the results are read like the reference reads mjData afterwards - through the dynamics
+        accessors (legs_mass_matrix, legs_qfrc_bias, feet_jacobians, hip_positions, com, ...) or ``debug_internals``.  Uses
+        the instrumented kernel variant for all envs (~20 % slower than step's production kernel)."""
+        if getattr(self, '_rec_tensor', None) is None:
+            try:
+                self._record('M')
+            except _lib.GqError:
+                pass
+        c = None if ctrl is None else torch.as_tensor(ctrl, dtype=torch.float32, device=self.device).reshape(-1, self.mjModel.nu).expand(self.num_envs, -1).contiguous()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._L.gq_forward(self._hbatch, int(stage), None if c is None else c.data_ptr(), self._st, self._out, stream), 'gq_forward')
+        self._launches += 1
+        self._note_step()
+
+    def mj_step1(self):
+        self.mj_forward(stage=1)
+
     # ------------------------------------------------------------------ observation-backed getters
     def base_lin_vel(self, frame='world'):
         return self._acc('base_lin_vel' + self._frame(frame))

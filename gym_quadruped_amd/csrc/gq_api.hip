@@ -19,6 +19,8 @@
 
 extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, int self, hipStream_t stream);
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, int boxes, hipStream_t stream);
+extern "C" void gq_launch_jac(const GqDevModel* model, const double* qpos, int body, const double* point, float* jacp, float* jacr, int n_envs, hipStream_t stream);
+extern "C" void gq_launch_ray(const GqDevModel* model, const double* origin, const float* dir, int total, float* dist, int32_t* geom, hipStream_t stream);
 extern "C" void gq_launch_heightmap(const GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
                                     float dist_x, float dist_y, float* out, hipStream_t stream);
 
@@ -321,6 +323,40 @@ int gq_heightmap(GqBatch* b, const double* center, const float* yaw, int rows, i
   if (!b || !center || !yaw || !out || rows <= 0 || cols <= 0) { SET_ERR("gq_heightmap: bad argument"); return GQ_EINVAL; }
   DeviceGuard guard(b->model->device);
   gq_launch_heightmap(b->model->dev, center, yaw, b->host.n_envs, rows, cols, dist_x, dist_y, out, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  return GQ_OK;
+}
+
+int gq_jac(GqBatch* b, const double* qpos, int body, const double* point, float* jacp, float* jacr, void* hip_stream) {
+  if (!b || !qpos || !point || (!jacp && !jacr)) { SET_ERR("gq_jac: null argument"); return GQ_EINVAL; }
+  if (body < 1 || body > GQ_NB) { SET_ERR("gq_jac: body id %d out of range (1 = base .. %d)", body, GQ_NB); return GQ_EINVAL; }
+  DeviceGuard guard(b->model->device);
+  gq_launch_jac(b->model->dev, qpos, body, point, jacp, jacr, b->host.n_envs, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  return GQ_OK;
+}
+
+int gq_ray(GqBatch* b, const double* origin, const float* dir, int n_rays, float* dist, int32_t* geom, void* hip_stream) {
+  if (!b || !origin || !dir || !dist || n_rays <= 0) { SET_ERR("gq_ray: bad argument"); return GQ_EINVAL; }
+  DeviceGuard guard(b->model->device);
+  gq_launch_ray(b->model->dev, origin, dir, b->host.n_envs * n_rays, dist, geom, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  return GQ_OK;
+}
+
+int gq_forward(GqBatch* b, int stage, const float* ctrl, GqState st, GqObsOut out, void* hip_stream) {
+  if (!b || !st.qpos || !st.qvel || !st.qacc || !st.qacc_warmstart || !st.time || !out.obs || !out.reward || !out.terminated ||
+      !out.truncated || !out.invalid_contact || !out.step_num) { SET_ERR("gq_forward: null tensor"); return GQ_EINVAL; }
+  if (stage != 0 && stage != 1) { SET_ERR("gq_forward: stage must be 0 (mj_forward) or 1 (mj_step1)"); return GQ_EINVAL; }
+  if (b->host.debug_envs <= 0 || !b->debug) { SET_ERR("gq_forward: no inspection record to write to (call gq_debug_enable first)"); return GQ_EINVAL; }
+  if (b->model->host.solver != 1) { SET_ERR("gq_forward needs the Newton solver (solver = 1)"); return GQ_EINVAL; }
+  DeviceGuard guard(b->model->device);
+  const int rc = ensure_args(b, st, out, nullptr, nullptr, nullptr, (hipStream_t)hip_stream);
+  if (rc != GQ_OK) return rc;
+  gq::StepCall c{};
+  c.ctrl = ctrl; c.debug = b->debug; c.forward = stage == 1 ? 1 : 2;
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0),
+                 (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

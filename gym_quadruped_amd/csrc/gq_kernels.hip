@@ -95,6 +95,134 @@ __global__ void heightmap_kernel(const GQ_GLOBAL GqDevModel* model, const double
   o[0] = (float)px; o[1] = (float)py; o[2] = (float)(pz - dist);
 }
 
+/* mj_jac for one world point per env (include/gq.h gq_jac): kinematics of the env's pose, then lane = dof writes its
+ * column: free-joint translations e_k, rotations (base axis a) a x (p - base), hinge on the body's chain axis x (p - anchor). */
+__global__ void __launch_bounds__(GQ_WAVE) jac_kernel(const GqDevModel* model, const double* qpos, int body, const double* point, float* jacp, float* jacr) {
+  __shared__ WaveMem W;
+  const int lane = lane_id(), env = (int)blockIdx.x;
+  const GQ_MODEL GqDevModel& m = *mptr(model);
+  double bxy = 0.0;
+  if (lane < 19) {
+    const double q = qpos[(size_t)env * 19 + lane];
+    if (lane < 2) W.bxy[lane] = q;
+    else if (lane == 2) W.basez = (float)q;
+    else if (lane < 7) W.qb[lane - 3] = (float)q;
+    else W.qj[lane - 7] = (float)q;
+  }
+  (void)bxy;
+  wave_barrier();
+  stage_kinematics(W, m);
+  /* the point relative to the base x/y (f64 first, like everything else) */
+  const V3 p = v3((float)(point[(size_t)env * 3] - W.bxy[0]), (float)(point[(size_t)env * 3 + 1] - W.bxy[1]), (float)point[(size_t)env * 3 + 2]);
+  if (lane < GQ_NVD) {
+    const int kb = body - 1; /* kernel body index: 0 base, 1 + 3 leg + link */
+    V3 jp = v3(0.0f, 0.0f, 0.0f), jr = v3(0.0f, 0.0f, 0.0f);
+    if (lane < 3) jp = v3(lane == 0, lane == 1, lane == 2);
+    else if (lane < 6) {
+      const float* R = W.xmat[0];
+      const V3 ax = v3(R[lane - 3], R[3 + lane - 3], R[6 + lane - 3]);
+      jr = ax; jp = cross(ax, p - v3(0.0f, 0.0f, W.basez));
+    } else {
+      const int j = lane - 6, leg = j / 3, depth = j % 3;
+      if (kb > 0 && (kb - 1) / 3 == leg && (kb - 1) % 3 >= depth) {
+        const V3 ax = ld3(W.u.dyn.axis[j]);
+        jr = ax; jp = cross(ax, p - ld3(W.u.dyn.anchor[j]));
+      }
+    }
+    if (jacp) { float* o = jacp + (size_t)env * 54; o[lane] = jp.x; o[18 + lane] = jp.y; o[36 + lane] = jp.z; }
+    if (jacr) { float* o = jacr + (size_t)env * 54; o[lane] = jr.x; o[18 + lane] = jr.y; o[36 + lane] = jr.z; }
+  }
+}
+
+/* mj_ray against the static geoms (include/gq.h gq_ray): one thread per ray; floor plane z = 0, world boxes (slab test in the
+ * box frame), height field (the cells under the ray's ground track are walked, two triangles each). */
+__device__ inline bool ray_triangle(const double* o, const double* d, const double* a, const double* b, const double* c, double& t) {
+  const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+  const double pv[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+  const double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+  if (fabs(det) < 1e-14) return false;
+  const double inv = 1.0 / det, tv[3] = {o[0] - a[0], o[1] - a[1], o[2] - a[2]};
+  const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * inv;
+  if (u < -1e-9 || u > 1.0 + 1e-9) return false;
+  const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+  const double v = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) * inv;
+  if (v < -1e-9 || u + v > 1.0 + 1e-9) return false;
+  t = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * inv;
+  return t >= 0.0;
+}
+__global__ void ray_kernel(const GQ_GLOBAL GqDevModel* model, const double* origin, const float* dir, int total, float* dist_out, int32_t* geom_out) {
+  const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (idx >= total) return;
+  const GQ_GLOBAL GqDevModel& M = *model;
+  const double o[3] = {origin[(size_t)idx * 3], origin[(size_t)idx * 3 + 1], origin[(size_t)idx * 3 + 2]};
+  const double d[3] = {(double)dir[(size_t)idx * 3], (double)dir[(size_t)idx * 3 + 1], (double)dir[(size_t)idx * 3 + 2]};
+  double best = -1.0;
+  int geom = -1;
+  if (d[2] < 0.0 && o[2] >= 0.0) { best = -o[2] / d[2]; geom = 0; }   /* the floor: a one-sided plane, hit from above */
+  for (int b = 0; b < M.nbox; b++) {
+    const GQ_GLOBAL GqDevBox& B = M.box[b];
+    const double r[3] = {o[0] - (double)B.pos[0], o[1] - (double)B.pos[1], o[2] - (double)B.pos[2]};
+    double tin = -1e300, tout = 1e300;
+    bool hit = true;
+    for (int k = 0; k < 3 && hit; k++) {
+      const double ol = (double)B.mat[k] * r[0] + (double)B.mat[3 + k] * r[1] + (double)B.mat[6 + k] * r[2];
+      const double dl = (double)B.mat[k] * d[0] + (double)B.mat[3 + k] * d[1] + (double)B.mat[6 + k] * d[2];
+      const double s = (double)B.size[k];
+      if (fabs(dl) < 1e-14) { hit = fabs(ol) <= s; continue; }
+      double t0 = (-s - ol) / dl, t1 = (s - ol) / dl;
+      if (t0 > t1) { const double tt = t0; t0 = t1; t1 = tt; }
+      if (t0 > tin) tin = t0;
+      if (t1 < tout) tout = t1;
+      hit = tin <= tout;
+    }
+    if (!hit || tout < 0.0) continue;
+    const double t = tin >= 0.0 ? tin : tout; /* origin inside the box: the exit point, like mju_rayGeom */
+    if (best < 0.0 || t < best) { best = t; geom = 1 + b; }
+  }
+  if (M.hf_nrow > 0) {
+    const double sx = M.hf_sx, sy = M.hf_sy, dx = M.hf_dx, dy = M.hf_dy, zmax = (double)M.hf_zmax;
+    const double ol[3] = {o[0] - (double)M.hf_pos[0], o[1] - (double)M.hf_pos[1], o[2] - (double)M.hf_pos[2]};
+    /* parameter interval of the ray inside the field's bounding box [-sx, sx] x [-sy, sy] x [0, zmax] */
+    double t0 = 0.0, t1 = 1e300;
+    bool in = true;
+    const double lo[3] = {-sx, -sy, 0.0}, hi[3] = {sx, sy, zmax};
+    for (int k = 0; k < 3 && in; k++) {
+      if (fabs(d[k]) < 1e-14) { in = ol[k] >= lo[k] && ol[k] <= hi[k]; continue; }
+      double a = (lo[k] - ol[k]) / d[k], b2 = (hi[k] - ol[k]) / d[k];
+      if (a > b2) { const double tt = a; a = b2; b2 = tt; }
+      if (a > t0) t0 = a;
+      if (b2 < t1) t1 = b2;
+      in = t0 <= t1;
+    }
+    if (in) {
+      const int nc = M.hf_ncol, nr = M.hf_nrow;
+      const float* H = M.hf_data;
+      /* walk the cells along the ground track from t0 to t1 (2-D DDA) */
+      double t = t0;
+      const double px = ol[0] + t * d[0], py = ol[1] + t * d[1];
+      int c = (int)floor((px + sx) / dx), r = (int)floor((py + sy) / dy);
+      c = c < 0 ? 0 : (c > nc - 2 ? nc - 2 : c); r = r < 0 ? 0 : (r > nr - 2 ? nr - 2 : r);
+      const int stc = d[0] > 0 ? 1 : -1, str = d[1] > 0 ? 1 : -1;
+      for (int it = 0; it < nc + nr + 2; it++) {
+        const double x0 = -sx + dx * c, y0 = -sy + dy * r, x1 = x0 + dx, y1 = y0 + dy;
+        const double h00 = H[r * nc + c], h10 = H[r * nc + c + 1], h01 = H[(r + 1) * nc + c], h11 = H[(r + 1) * nc + c + 1];
+        const double A[3] = {x0, y0, h00}, B[3] = {x1, y0, h10}, Cc[3] = {x0, y1, h01}, D[3] = {x1, y1, h11};
+        double th, tb = -1.0;
+        if (ray_triangle(ol, d, A, B, Cc, th)) tb = th;
+        if (ray_triangle(ol, d, D, Cc, B, th) && (tb < 0.0 || th < tb)) tb = th;
+        if (tb >= 0.0) { if (best < 0.0 || tb < best) { best = tb; geom = 1 + M.nbox; } break; }
+        /* next cell: the nearer of the two cell borders the track crosses */
+        const double tx = fabs(d[0]) < 1e-14 ? 1e300 : ((stc > 0 ? x1 : x0) - ol[0]) / d[0];
+        const double ty = fabs(d[1]) < 1e-14 ? 1e300 : ((str > 0 ? y1 : y0) - ol[1]) / d[1];
+        if (tx < ty) { c += stc; t = tx; } else { r += str; t = ty; }
+        if (t > t1 || c < 0 || r < 0 || c > nc - 2 || r > nr - 2) break;
+      }
+    }
+  }
+  dist_out[idx] = (float)best;
+  if (geom_out) geom_out[idx] = geom;
+}
+
 }  // namespace gq
 
 extern "C" void gq_launch_heightmap(const GQ_GLOBAL GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
@@ -123,6 +251,12 @@ extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall
   }
 #undef GQ_LAUNCH_MODE
 #undef GQ_LAUNCH
+}
+extern "C" void gq_launch_jac(const GqDevModel* model, const double* qpos, int body, const double* point, float* jacp, float* jacr, int n_envs, hipStream_t stream) {
+  hipLaunchKernelGGL(gq::jac_kernel, dim3(n_envs), dim3(GQ_WAVE), 0, stream, model, qpos, body, point, jacp, jacr);
+}
+extern "C" void gq_launch_ray(const GQ_GLOBAL GqDevModel* model, const double* origin, const float* dir, int total, float* dist, int32_t* geom, hipStream_t stream) {
+  hipLaunchKernelGGL(gq::ray_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, model, origin, dir, total, dist, geom);
 }
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, int boxes, hipStream_t stream) {
   if (boxes) hipLaunchKernelGGL(gq::reset_kernel<true>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);

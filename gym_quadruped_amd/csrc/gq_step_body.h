@@ -251,12 +251,17 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   /* scheduling hint: an env whose previous step needed several Newton iterations will most likely need them again; its
    * wave gets issue priority from the start (the launch lasts as long as its slowest wave) */
   const int prio_hint = pass != 0 ? 3 : ((SOLVER == 1 && a.load_hint) ? (int)gptr(a.load_hint)[env] : 0);
+  bool fwd_only = false; /* gq_forward (mj_step1 / mj_forward): no state is advanced */
+  if constexpr (DBG) fwd_only = call.forward != 0;
   if (lane == 0) {
     W.mu_env = a.friction ? gptr(a.friction)[env] : -1.0f;
     const int32_t sn = gptr(a.step_num)[env];
-    W.step_old = sn; gptr(a.step_num)[env] = sn + 1;
-    if (a.step_prev) gptr(a.step_prev)[env] = sn;
-    gptr(a.time)[env] = gptr(a.time)[env] + h;
+    W.step_old = sn;
+    if (!fwd_only) {
+      gptr(a.step_num)[env] = sn + 1;
+      if (a.step_prev) gptr(a.step_prev)[env] = sn;
+      gptr(a.time)[env] = gptr(a.time)[env] + h;
+    }
   }
   wave_barrier();
 
@@ -691,6 +696,35 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   const bool active = lane < nefc;
   float b_i = 0.0f;
   int iter = 0;
+  /* inspection record of this forward pass (instrumented variant): `solved` = the solver and the accelerations are done */
+  auto dump_record = [&](const bool solved, const float raref_, const float rR_, const int rtype_, const int iter_) {
+    if constexpr (DBG) if (call.debug && rec_pass && env < mptr(a.batch)->debug_envs) {
+    float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
+    for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = m_entry(W, k / 18, k % 18);
+    if (lane < 18) {
+      D[GQ_DBG_BIAS + lane] = W.bias[lane]; D[GQ_DBG_SMOOTH + lane] = W.smooth[lane];
+      D[GQ_DBG_QACC_SMOOTH + lane] = W.qacc_smooth[lane]; D[GQ_DBG_QFRC_C + lane] = W.qfrc_c[lane];
+      D[GQ_DBG_QACC + lane] = W.qacc[lane];
+    }
+    if (lane == 0) { D[GQ_DBG_NEFC] = (float)nefc; D[GQ_DBG_NCON] = (float)ncon; D[GQ_DBG_NITER] = (float)iter_; }
+    for (int k = 0; k < GQ_NVD; k++) D[GQ_DBG_EFC_J + lane * 18 + k] = W.u.B[lane][k];
+    if constexpr (SOLVER == 1) { /* efc_b = J qacc_smooth - aref: only the record wants it, the primal solver never forms it */
+      b_i = -raref_;
+      for (int k = 0; k < GQ_NVD; k++) b_i += W.u.B[lane][k] * W.qacc_smooth[k];
+    }
+    D[GQ_DBG_EFC_AREF + lane] = raref_; D[GQ_DBG_EFC_R + lane] = rR_; D[GQ_DBG_EFC_B + lane] = b_i;
+    D[GQ_DBG_EFC_FORCE + lane] = W.force[lane]; D[GQ_DBG_EFC_TYPE + lane] = (float)rtype_;
+    if (lane < GQ_MAXCON) { D[GQ_DBG_CON_DIST + lane] = lane < ncon ? W.con_dist[lane] : 0.0f; D[GQ_DBG_CON_GEOM + lane] = lane < ncon ? (float)W.con_geom[lane] : -1.0f; }
+    if (lane < 12) D[GQ_DBG_FOOT_POS + lane] = W.foot_world[lane / 3][lane % 3];
+      }
+    (void)solved;
+  };
+  if constexpr (DBG) if (call.forward == 1) { /* mj_step1: position and velocity stages are done (constraint rows incl. aref) */
+    if constexpr (SOLVER == 1) wave_barrier();
+    dump_record(false, raref, rR, rtype, 0);
+    return 0;
+  }
+
   if constexpr (SOLVER == 1) {
     /* ================================================================ S8/S9 (Newton): primal solve, no dual operator */
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
@@ -841,24 +875,10 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   wave_barrier();
 
   }
-  if constexpr (DBG) if (call.debug && rec_pass && env < mptr(a.batch)->debug_envs) {
-    float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
-    for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = m_entry(W, k / 18, k % 18);
-    if (lane < 18) {
-      D[GQ_DBG_BIAS + lane] = W.bias[lane]; D[GQ_DBG_SMOOTH + lane] = W.smooth[lane];
-      D[GQ_DBG_QACC_SMOOTH + lane] = W.qacc_smooth[lane]; D[GQ_DBG_QFRC_C + lane] = W.qfrc_c[lane];
-      D[GQ_DBG_QACC + lane] = W.qacc[lane];
-    }
-    if (lane == 0) { D[GQ_DBG_NEFC] = (float)nefc; D[GQ_DBG_NCON] = (float)ncon; D[GQ_DBG_NITER] = (float)iter; }
-    for (int k = 0; k < GQ_NVD; k++) D[GQ_DBG_EFC_J + lane * 18 + k] = W.u.B[lane][k];
-    if constexpr (SOLVER == 1) { /* efc_b = J qacc_smooth - aref: only the record wants it, the primal solver never forms it */
-      b_i = -raref;
-      for (int k = 0; k < GQ_NVD; k++) b_i += W.u.B[lane][k] * W.qacc_smooth[k];
-    }
-    D[GQ_DBG_EFC_AREF + lane] = raref; D[GQ_DBG_EFC_R + lane] = rR; D[GQ_DBG_EFC_B + lane] = b_i;
-    D[GQ_DBG_EFC_FORCE + lane] = W.force[lane]; D[GQ_DBG_EFC_TYPE + lane] = (float)rtype;
-    if (lane < GQ_MAXCON) { D[GQ_DBG_CON_DIST + lane] = lane < ncon ? W.con_dist[lane] : 0.0f; D[GQ_DBG_CON_GEOM + lane] = lane < ncon ? (float)W.con_geom[lane] : -1.0f; }
-    if (lane < 12) D[GQ_DBG_FOOT_POS + lane] = W.foot_world[lane / 3][lane % 3];
+  dump_record(true, raref, rR, rtype, iter);
+  if constexpr (DBG) if (fwd_only) { /* mj_forward: the acceleration is the result; nothing is integrated, no observation row */
+    if (lane < GQ_NVD) gptr(a.qacc)[(size_t)env * 18 + lane] = W.qacc[lane];
+    return 0;
   }
 
   GQ_TICK(10);

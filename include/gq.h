@@ -14,9 +14,11 @@
  *     _get_obs / _check_* epilogue quadruped_env.py:277-285, :1146-1257)
  *   mujoco.mj_step1                quadruped_env.py:376    gq_reset (lift loop)
  *   mj_resetDataKeyframe + reset   quadruped_env.py:343-397 gq_reset
- *   mujoco.mj_jac                  quadruped_env.py:728    gq_step obs epilogue
- *   mujoco.mj_contactForce         quadruped_env.py:852    gq_step obs epilogue
- *   mujoco.mj_fullM                quadruped_env.py:940    gq_step obs epilogue
+ *   mujoco.mj_jac                  quadruped_env.py:728    gq_jac (+ gq_step obs epilogue for the feet)
+ *   mujoco.mj_step1 / mj_forward   quadruped_env.py:376,384,1321  gq_forward
+ *   mujoco.mj_ray                  sensors/heightmap.py:90-99     gq_ray (general rays), gq_heightmap (the HeightMap grid)
+ *   mujoco.mj_contactForce         quadruped_env.py:852    gq_step obs epilogue; per contact: gq_forward record "efc_force"
+ *   mujoco.mj_fullM                quadruped_env.py:940    gq_step obs epilogue; full matrix: gq_forward record "M"
  *
  * Conventions
  *  - plain C, no exceptions cross the boundary; every function returns 0 on
@@ -327,6 +329,28 @@ int gq_batch_set_pending(GqBatch* b, const uint8_t* flags, void* hip_stream);
  * out: device [N][rows][cols][3] f32 hit points ((-1,-1,-1)-style misses cannot occur over the infinite floor). */
 int gq_heightmap(GqBatch* b, const double* center, const float* yaw, int rows, int cols, float dist_x, float dist_y,
                  float* out, void* hip_stream);
+
+/* mujoco.mj_jac(m, d, jacp, jacr, point, body) (quadruped_env.py:728-735) for every env: translational and rotational
+ * Jacobian of the world point `point` moving with body `body` (MuJoCo body id: 1 = base, 2 + 3 leg + link), at the pose
+ * `qpos`.  qpos: device [N][19] f64; point: device [N][3] f64 (world); jacp / jacr: device [N][3][18] f32, either may be
+ * NULL (like mj_jac's).  One wavefront per env: kinematics, then lane = dof.  Production kernel, no inspection record. */
+int gq_jac(GqBatch* b, const double* qpos, int body, const double* point, float* jacp, float* jacr, void* hip_stream);
+
+/* mujoco.mj_ray(m, d, pnt, vec, geomgroup, flg_static = 1, bodyexclude, geomid) (sensors/heightmap.py:90-99) against the
+ * STATIC geoms of the scene - floor plane, world boxes, height field - for n_rays rays per env: origin: device
+ * [N][n_rays][3] f64 (world), dir: device [N][n_rays][3] f32 (any length; the result is in units of |dir|, as mj_ray's),
+ * dist: device [N][n_rays] f32 out, -1 where nothing is hit; geom: device [N][n_rays] i32 out or NULL (0 floor,
+ * 1 + box index, 1 + nbox for the height field, -1 none).  One thread per ray. */
+int gq_ray(GqBatch* b, const double* origin, const float* dir, int n_rays, float* dist, int32_t* geom, void* hip_stream);
+
+/* mujoco.mj_step1 (quadruped_env.py:376, :384: position + velocity stages) and mujoco.mj_forward (:1321: through the
+ * accelerations) for every env WITHOUT advancing the state: stage 1 = mj_step1 (kinematics, inertias, collision,
+ * constraint rows incl. aref; bias forces), stage 0 = mj_forward (+ actuation, solver: st.qacc is written).  qpos / qvel /
+ * time / step_num / warm start / observations are left untouched.  The results - what the reference reads from mjData after
+ * these calls (xpos, xmat, M, qfrc_bias, contact list, efc_J / aref / R / force, qacc) - land in the inspection record
+ * (gq_debug_enable must have been called for the envs of interest; fields: gq_debug_field / gq_debug_device_buffer).  Runs
+ * the instrumented kernel variant: ~20 % slower than gq_step's production kernel and one 8.4 KB record per env. */
+int gq_forward(GqBatch* b, int stage, const float* ctrl, GqState st, GqObsOut out, void* hip_stream);
 
 /* debug / inspection: last forward pass internals of env `env` copied to host (doubles).
  * name in {"M","qfrc_bias","qfrc_smooth","qacc_smooth","qfrc_constraint","efc_J","efc_aref","efc_R","efc_b",
