@@ -147,6 +147,27 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
         out[key] = {'value': n * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps,
                     'obs_dim': env._obs_dim, 'solver': solver, 'bytes_per_env_step': algorithmic_bytes_per_env_step(env._obs_dim)}
         env.close()
+    # the same workload as an OPEN-LOOP rollout (QuadrupedEnv.rollout / gq_rollout): 2 shards of envs on 2 HIP streams, no
+    # cross-env barrier between steps - what a random-action / dataset-recording rollout can use and a policy loop cannot.
+    # Measured on MI355X: 1 shard 63.2, 2 shards 67.5, 4 shards 36.4, 8 shards 26.8 M env-steps/s (tools/rollout_trace.py):
+    # overlapping launches share the SIMDs, so each still lasts as long as its slowest wave under full contention, and more
+    # than two queues serialise
+    env = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), scene='flat', num_envs=n, device=device, auto_reset='next_step',
+                       solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000, self_collision=False if args.no_self_collision else None)
+    env.reset(random=True)
+    acts = torch.stack(pool)                       # [64, n, 12]
+    for _ in range(4):
+        env.rollout(acts, shards=2)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    reps = 8
+    for _ in range(reps):
+        env.rollout(acts, shards=2)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    out['pipelined_rollout'] = {'value': n * reps * 64 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / (reps * 64) * 1e3, 'steps': reps * 64, 'shards': 2,
+                                'note': 'open-loop: each shard of 2048 envs chains its steps on its own stream (gq_step_range); same kernels and results as the step loop'}
+    env.close()
     return out
 
 

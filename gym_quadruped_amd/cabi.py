@@ -49,7 +49,7 @@ class GqModelDesc(C.Structure):
         ('hfield_friction', C.c_double * 3), ('hfield_margin', C.c_double), ('hfield_gap', C.c_double),
         ('hfield_solmix', C.c_double), ('hfield_solref', C.c_double * 2), ('hfield_solimp', C.c_double * 5),
         ('hfield_condim', C.c_int32), ('hfield_priority', C.c_int32),
-        ('nselfpair', C.c_int32), ('selfpair_geom1', _I), ('selfpair_geom2', _I), ('geom_capsule', _D),
+        ('nselfpair', C.c_int32), ('selfpair_geom1', _I), ('selfpair_geom2', _I), ('geom_capsule', _D), ('geom_type', _I),
     ]
 
 

@@ -60,6 +60,7 @@ struct GqBatch {
   int staging_next;
   bool shadow_valid;
   float* imu_bias;      /* caller-owned device [N][6], set by gq_batch_set_imu */
+  hipStream_t shard_stream[8]; hipEvent_t shard_event[8]; hipEvent_t fork_event; int n_shard_streams; /* gq_rollout */
   int32_t* h9;          /* caller-owned device [N][6] resampling counters, set by gq_batch_set_resampling */
   float* ext_dist;      /* caller-owned device [N][6] */
   int debug_cap;
@@ -159,6 +160,8 @@ int gq_batch_destroy(GqBatch* b) {
   DeviceGuard guard(b->model->device);
   hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->lift_pending); hipFree(b->load_hint); hipFree(b->dev_args);
   if (b->staging) hipHostFree(b->staging);
+  for (int i = 0; i < b->n_shard_streams; i++) { hipStreamDestroy(b->shard_stream[i]); hipEventDestroy(b->shard_event[i]); }
+  if (b->n_shard_streams) hipEventDestroy(b->fork_event);
   if (b->debug) hipFree(b->debug);
   delete b;
   return GQ_OK;
@@ -268,22 +271,78 @@ static void fill_reset_args(gq::ResetArgs* a, GqBatch* b, const uint8_t* mask, c
   a->cfg.cmd_reset = b->host.rs_cmd_reset;
 }
 
-int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
-            int32_t* episode, uint8_t* lift_failed, void* hip_stream) {
+static int step_launch(GqBatch* b, int env0, int count, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
+                       int32_t* episode, uint8_t* lift_failed, void* hip_stream, const char* who) {
   if (!b || !st.qpos || !st.qvel || !st.qacc || !st.qacc_warmstart || !st.time || !out.obs || !out.reward ||
       !out.terminated || !out.truncated || !out.invalid_contact || !out.step_num) {
-    SET_ERR("gq_step: null tensor"); return GQ_EINVAL;
+    SET_ERR("%s: null tensor", who); return GQ_EINVAL;
   }
+  if (env0 < 0 || count < 0 || env0 + count > b->host.n_envs) { SET_ERR("%s: env range [%d, %d) outside the batch of %d", who, env0, env0 + count, b->host.n_envs); return GQ_EINVAL; }
   DeviceGuard guard(b->model->device);
-  if (auto_reset && (!episode || !st.cmd)) { SET_ERR("gq_step: auto-reset needs the episode counters and the command tensor"); return GQ_EINVAL; }
+  if (auto_reset && (!episode || !st.cmd)) { SET_ERR("%s: auto-reset needs the episode counters and the command tensor", who); return GQ_EINVAL; }
   const int rc = ensure_args(b, st, out, episode, lift_failed, auto_reset, (hipStream_t)hip_stream);
   if (rc != GQ_OK) return rc;
+  if (count == 0) return GQ_OK;
   gq::StepCall c{};
-  c.ctrl = ctrl; c.mask = mask; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
+  c.ctrl = ctrl; c.mask = mask; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr; c.env0 = env0;
   c.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; c.first_pass = 0; c.stop_stage = b->stop_stage;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, count, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
+}
+
+int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
+            int32_t* episode, uint8_t* lift_failed, void* hip_stream) {
+  return step_launch(b, 0, b ? b->host.n_envs : 0, ctrl, mask, st, out, auto_reset, episode, lift_failed, hip_stream, "gq_step");
+}
+
+int gq_step_range(GqBatch* b, int env0, int count, const float* ctrl, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
+                  int32_t* episode, uint8_t* lift_failed, void* hip_stream) {
+  return step_launch(b, env0, count, ctrl, nullptr, st, out, auto_reset, episode, lift_failed, hip_stream, "gq_step_range");
+}
+
+int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
+               int32_t* episode, uint8_t* lift_failed, float* obs_seq, void* hip_stream) {
+  if (!b || !ctrl_seq || n_steps < 0) { SET_ERR("gq_rollout: bad argument"); return GQ_EINVAL; }
+  if (shards < 1) shards = 1;
+  if (shards > 8) shards = 8;
+  if (shards > b->host.n_envs) shards = b->host.n_envs;
+  int rc = step_launch(b, 0, 0, nullptr, nullptr, st, out, auto_reset, episode, lift_failed, hip_stream, "gq_rollout"); /* validate + bind */
+  if (rc != GQ_OK) return rc;
+  DeviceGuard guard(b->model->device);
+  while (b->n_shard_streams < shards) {
+    const int i = b->n_shard_streams;
+    if (i == 0) HIP_TRY(hipEventCreateWithFlags(&b->fork_event, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&b->shard_stream[i], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&b->shard_event[i], hipEventDisableTiming));
+    b->n_shard_streams = i + 1;
+  }
+  const int N = b->host.n_envs, od = b->host.obs_dim;
+  HIP_TRY(hipEventRecord(b->fork_event, (hipStream_t)hip_stream));
+  for (int s = 0; s < shards; s++) HIP_TRY(hipStreamWaitEvent(b->shard_stream[s], b->fork_event, 0));
+  gq::StepCall c{};
+  c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
+  c.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; c.stop_stage = b->stop_stage;
+  for (int k = 0; k < n_steps; k++) {
+    c.ctrl = ctrl_seq + (size_t)k * N * 12;
+    for (int s = 0; s < shards; s++) {
+      const int e0 = (int)((long long)s * N / shards), e1 = (int)((long long)(s + 1) * N / shards);
+      c.env0 = e0;
+      gq_launch_step(b->dev_args, &c, e1 - e0, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0),
+                     (b->model->host.nsp > 0 || b->force_self), b->shard_stream[s]);
+      if (obs_seq) HIP_TRY(hipMemcpyAsync(obs_seq + ((size_t)k * N + e0) * od, out.obs + (size_t)e0 * od, (size_t)(e1 - e0) * od * sizeof(float), hipMemcpyDeviceToDevice, b->shard_stream[s]));
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  for (int s = 0; s < shards; s++) {
+    HIP_TRY(hipEventRecord(b->shard_event[s], b->shard_stream[s]));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, b->shard_event[s], 0));
+  }
+  return GQ_OK;
+}
+
+int gq_batch_bind(GqBatch* b, GqState st, GqObsOut out, const GqResetCfg* auto_reset, int32_t* episode, uint8_t* lift_failed, void* hip_stream) {
+  return step_launch(b, 0, 0, nullptr, nullptr, st, out, auto_reset, episode, lift_failed, hip_stream, "gq_batch_bind");
 }
 
 int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const float* qvel_new, const GqResetCfg* cfg,

@@ -15,16 +15,17 @@ namespace gq {
  * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
 template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF>
 __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
-  if (c.mask && !gptr(c.mask)[blockIdx.x]) return; /* wave-uniform */
+  const int env = (int)blockIdx.x + c.env0;
+  if (c.mask && !gptr(c.mask)[env]) return; /* wave-uniform */
   __shared__ WaveMem W;
   int pass = c.first_pass;
-  bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[blockIdx.x]; /* wave-uniform */
+  bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[env]; /* wave-uniform */
   /* the reset's own step after an explicit gq_reset: the reset kernel left word whether the lift loop is still due */
-  int lift = (c.first_pass && A->s.lift_pending) ? (int)gptr(A->s.lift_pending)[blockIdx.x] : 0;
+  int lift = (c.first_pass && A->s.lift_pending) ? (int)gptr(A->s.lift_pending)[env] : 0;
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
       wave_priority(3); /* reset + step in one launch: this wave is the longest of its SIMD */
-      lift = reset_wave<BOXES>(A->r, W);
+      lift = reset_wave<BOXES>(A->r, W, c.env0);
       pass = c.auto_reset;
     }
     const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF>(A->s, c, W, pass, lift);

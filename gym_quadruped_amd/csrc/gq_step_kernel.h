@@ -59,6 +59,7 @@ struct StepCall {
   float* debug;         /* debug record block or NULL */
   int32_t auto_reset;   /* 0 off, 1 same-step (second pass in this launch), 2 next-step (pending flag, one pass per launch) */
   int32_t first_pass;   /* 0: user step; 1: the reset's own step (gq_reset) */
+  int32_t env0;         /* first env of this launch (gq_step_range); env = env0 + blockIdx.x */
   int32_t forward;      /* gq_forward (instrumented variant only): 1 = mj_step1 (return after the constraint rows), 2 = mj_forward (return
                          * after the accelerations); nothing but qacc and the inspection record is written */
   int32_t stop_stage;   /* profiling aid (env GQ_STOP_STAGE, tools/stage_insts.sh): return after stage marker i; 0 = run everything */

@@ -593,7 +593,8 @@ class _Compiler:
                 key, loc, r = ('c', size[0], size[1]), np.array([[0, 0, -size[1]], [0, 0, size[1]]]), size[0]
             elif t == GEOM_BOX:
                 key = ('b',) + tuple(size)
-                loc = np.array([[sx * size[0], sy * size[1], sz * size[2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+                # corner i = (x sign: bit 0, y sign: bit 1, z sign: bit 2): the order mjraw_PlaneBox walks the corners in
+                loc = np.array([[sx * size[0], sy * size[1], sz * size[2]] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)])
                 r = 0.0
             elif t == GEOM_CYLINDER:
                 key = ('y', size[0], size[1])

@@ -179,6 +179,10 @@ typedef struct GqModelDesc {
   const int32_t* selfpair_geom1; /* [nselfpair] */
   const int32_t* selfpair_geom2;
   const double* geom_capsule;    /* [ngeom][7] */
+  /* MuJoCo geom type (mjtGeom: 2 sphere, 3 capsule, 5 cylinder, 6 box, 7 mesh) of every geom: selects the multi-point rule
+   * of the plane narrow phase (plane-capsule: both end spheres; plane-box: the corners below the centre, at most 4;
+   * plane-cylinder / plane-mesh: the support vertex) */
+  const int32_t* geom_type;      /* [ngeom] */
 } GqModelDesc;
 
 typedef struct GqModel GqModel;
@@ -303,6 +307,23 @@ int gq_batch_set_resampling(GqBatch* b, const GqResampleCfg* cfg, const GqResetC
  * episode / lift_failed as in gq_reset (may be NULL when auto_reset is NULL). */
 int gq_step(GqBatch* b, const float* ctrl, const uint8_t* mask, GqState st, GqObsOut out,
             const GqResetCfg* auto_reset, int32_t* episode, uint8_t* lift_failed, void* hip_stream);
+
+/* gq_step for the envs [env0, env0 + count) only (grid = count wavefronts); every tensor is still the full batch's.  This is
+ * what an open-loop rollout is pipelined with: the batch is cut into a few shards, each shard's steps are chained on a HIP
+ * stream of its own, and - envs being independent - no launch ever waits for another shard's stragglers
+ * (QuadrupedEnv.rollout).  The argument block must already be bound to these tensors: call gq_batch_bind (or any gq_step)
+ * on a stream the shard streams are ordered after. */
+int gq_step_range(GqBatch* b, int env0, int count, const float* ctrl, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
+                  int32_t* episode, uint8_t* lift_failed, void* hip_stream);
+/* K steps of every env with the action sequence ctrl_seq (device [K][N][nu] f32), equivalent to K gq_step calls but
+ * pipelined over `shards` groups of envs on library-owned HIP streams (forked from / joined to hip_stream with events): no
+ * launch waits for another group's stragglers or for the gap between two dependent launches.  obs_seq: device
+ * [K][N][obs_dim] f32 receiving every step's observation rows, or NULL (the row tensor then holds the last step's). */
+int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
+               int32_t* episode, uint8_t* lift_failed, float* obs_seq, void* hip_stream);
+/* upload the device-resident argument block for (st, out, auto_reset, episode, lift_failed) if it changed; no launch */
+int gq_batch_bind(GqBatch* b, GqState st, GqObsOut out, const GqResetCfg* auto_reset, int32_t* episode, uint8_t* lift_failed,
+                  void* hip_stream);
 
 /* QuadrupedEnv.reset (quadruped_env.py:309-406) for the envs with mask != 0 (mask NULL = all), two launches:
  *  1. state write: explicit qpos_new/qvel_new when given (:389-391), otherwise keyframe 0 (+ joint noise, random

@@ -602,25 +602,49 @@ static void gqo_collision(GqOracle* o) {
     double r = m->cloud_radius[cl];
     /* bounding-sphere cull (mj broadphase equivalent for a plane) */
     if (o->geom_xpos[g][2] - m->geom_rbound[g] > margin) continue;
-    double best = 1e300, second = 1e300, bv[3] = {0, 0, 0};
-    for (int v = 0; v < m->cloud_vertnum[cl]; v++) {
-      double w[3];
-      mulmatvec3(w, o->geom_xmat[g], m->vert_pos + 3 * (m->cloud_vertadr[cl] + v));
-      for (int k = 0; k < 3; k++) w[k] += o->geom_xpos[g][k];
-      double dist = w[2] - r;
-      if (dist < best) { second = best; best = dist; memcpy(bv, w, sizeof bv); }
-      else if (dist < second) second = dist;
+    /* ONE point per (plane, geom) pair: the support vertex.  MuJoCo's plane routines return several for everything but a
+     * sphere (mjraw_PlaneCapsule both end spheres, mjraw_PlaneBox the corners below the box centre, at most 4, in corner
+     * order; mjc_PlaneConvex further support vertices of a mesh).  They are restated here behind GQO_PLANE_MULTIPOINT=1 and
+     * were tried in the kernel (round 2): the calf geoms of these robots reach the ground next to the foot spheres (aliengo's
+     * calf box: 4 corners + the foot = 5 contacts per standing leg, 20 per robot, 80 pyramid rows), which does not fit the
+     * 12 contacts / 63 rows one wavefront carries (lane = constraint row), so a standing robot lost its hind legs' contacts.
+     * The single support point per pair stays until the row capacity is lifted (known deviations). */
+    const int nv = m->cloud_vertnum[cl], type = m->geom_type ? m->geom_type[g] : (nv == 1 ? 2 : (nv == 2 ? 3 : 7));
+    static double wv[4096][3];
+    double dv[4096];
+    double best = 1e300, second = 1e300;
+    int bi = -1;
+    for (int v = 0; v < nv && v < 4096; v++) {
+      mulmatvec3(wv[v], o->geom_xmat[g], m->vert_pos + 3 * (m->cloud_vertadr[cl] + v));
+      for (int k = 0; k < 3; k++) wv[v][k] += o->geom_xpos[g][k];
+      dv[v] = wv[v][2] - r;
+      if (dv[v] < best) { second = best; best = dv[v]; bi = v; }
+      else if (dv[v] < second) second = dv[v];
     }
     if (best >= margin) continue;
-    Contact* c = &o->contact[o->ncon++];
-    c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0;
-    c->dist = best;
-    c->tiegap = second - best;
-    /* contact point midway between the surfaces: (vertex - r*n) - n*dist/2 */
-    for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - normal[k] * (r + 0.5 * best);
-    memcpy(c->frame, normal, sizeof normal);
-    make_frame(c->frame);
-    contact_param(o, -1, g, c);
+    int pick[4], npick = 0;
+    double tiegap = second - best;
+    static int multipoint = -1; /* GQO_PLANE_MULTIPOINT=1: MuJoCo's several points per plane-capsule / plane-box pair (experiment, see below) */
+    if (multipoint < 0) { const char* e = getenv("GQO_PLANE_MULTIPOINT"); multipoint = e ? atoi(e) : 0; }
+    if (multipoint && (type == 3 || nv <= 2)) { /* sphere / capsule: every end sphere within the margin */
+      for (int v = 0; v < nv; v++) if (dv[v] < margin) pick[npick++] = v;
+      tiegap = 1.0;
+    } else if (multipoint && type == 6 && nv == 8) { /* box: corners below the centre */
+      for (int v = 0; v < 8 && npick < 4; v++)
+        if (dv[v] < margin && wv[v][2] - o->geom_xpos[g][2] <= 0) pick[npick++] = v;
+      tiegap = 1.0;
+    } else pick[npick++] = bi; /* the support (deepest) vertex */
+    for (int q = 0; q < npick && o->ncon < NCON; q++) {
+      const int v = pick[q];
+      Contact* c = &o->contact[o->ncon++];
+      c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0;
+      c->dist = dv[v];
+      c->tiegap = tiegap;
+      for (int k = 0; k < 3; k++) c->pos[k] = wv[v][k] - normal[k] * (r + 0.5 * dv[v]);
+      memcpy(c->frame, normal, sizeof normal);
+      make_frame(c->frame);
+      contact_param(o, -1, g, c);
+    }
   }
   /* world boxes (geoms 1..nbox of the world body).  Sphere geoms: exact sphere-box distance (mjc_SphereBox: clamp the
    * centre into the box; inside, leave through the nearest face).  Every other robot geom: the same test for each vertex

@@ -268,3 +268,30 @@ def test_state_dict_round_trip_includes_imu_bias_and_resampling_state():
     # reset() zeroes the control set-point the getter reports (reference :334)
     a.reset(random=True)
     assert not bool(a.torque_ctrl_setpoint.any())
+
+
+def test_pipelined_rollout_equals_the_step_loop():
+    """QuadrupedEnv.rollout (gq_step_range on one stream per shard of envs) must leave exactly the state of the plain step loop
+    - auto-resets, command redraws and IMU walks included - and deliver every step's observation rows."""
+    from gym_quadruped_amd.sensors import IMU
+    n, K = 1024, 60
+    kw = dict(accel_name='imu_acc', gyro_name='imu_gyro', imu_site_name='imu', accel_noise=0.01, gyro_noise=0.02, accel_bias_rate=0.03, gyro_bias_rate=0.04, seed=5)
+    mk = lambda: _env('aliengo', n, state_obs_names=('qpos', 'qvel', 'contact_forces') + IMU.ALL_OBS, sensors=(IMU,), sensors_kwargs=(kw,), solver='newton',
+                      auto_reset='next_step', seed=9, base_vel_command_type='random+reset')
+    a, b = mk(), mk()
+    a.reset(random=True); b.reset(random=True)
+    a._h9[:, 1] = 25; b._h9[:, 1] = 25          # command redraws inside the rollout
+    g = torch.Generator(device='cuda:0').manual_seed(1)
+    acts = torch.randn(K, n, 12, generator=g, device='cuda:0') * 40
+    rows = []
+    for k in range(K):
+        o, _, term, _, _ = a.step(acts[k])
+        rows.append(a._obs_buf.clone())
+    out = torch.zeros(K, n, b._obs_dim, device='cuda:0')
+    b.rollout(acts, shards=4, obs_out=out)
+    torch.cuda.synchronize()
+    for k in ('_qpos', '_qvel', '_warm', '_time', '_step_num', '_episode', '_cmd', '_h9', '_terminated', '_obs_buf'):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert torch.equal(a.sensors[0].bias_state, b.sensors[0].bias_state)
+    assert torch.equal(torch.stack(rows), out)
+    assert int(a._episode.max()) > 1, 'the rollout must contain auto-resets'
