@@ -36,7 +36,11 @@ for p in $PARTS; do
     timeline) timeout 600 python tools/wave_timeline.py 4096 > $OUT/wave_timeline.txt 2>&1
               timeout 600 python tools/wave_timeline.py 4096 mini_cheetah noself > $OUT/wave_timeline_noself.txt 2>&1;;
     nscan) timeout 900 python tools/nscan.py > $OUT/nscan.txt 2>&1;;
-    profiles) timeout 2400 bash tools/run_profiles.sh $TAG > $OUT/run_profiles.txt 2>&1;;
+    profiles) timeout 1500 bash tools/run_profiles.sh $TAG pmc > $OUT/run_profiles.txt 2>&1
+              timeout 600 bash tools/run_profiles.sh ${TAG}_noself nopmc --no-self-collision >> $OUT/run_profiles.txt 2>&1
+              timeout 600 bash tools/run_profiles.sh ${TAG}_cfg3 nopmc --robot aliengo --scene perlin >> $OUT/run_profiles.txt 2>&1
+              timeout 600 bash tools/run_profiles.sh ${TAG}_cfg4 nopmc --robot go2 >> $OUT/run_profiles.txt 2>&1
+              timeout 900 bash tools/run_profiles.sh ${TAG}_cfg5 nopmc --robot hyqreal1 --scene random_boxes --imu --heightmap >> $OUT/run_profiles.txt 2>&1;;
   esac
 done
 tail -5 $OUT/pytest_gpu.txt 2>/dev/null; cat $OUT/bench.json 2>/dev/null | head -c 600
