@@ -263,19 +263,29 @@ __device__ __forceinline__ void newton_dense_step(WaveMem& W, int r0, int r1, co
   const int i = lane < GQ_NVD ? lane : 0; /* lanes >= 18 mirror row 0 and are discarded */
   float row[GQ_NVD], b = g[i];
   const int li = i < 6 ? -1 : (i - 6) / 3;
+  /* every load below is unconditional (a clamped address, the value masked afterwards): conditional loads compile to one
+   * exec-masked branch and one exposed LDS latency EACH - 12 in a row per coupling row made this step cost 28k cycles */
+  const float* Hc0 = &W.u2.n.Hc[0][0];
+  const float* Hb0 = &W.u2.n.Hb[0][0];
 #pragma unroll
   for (int j = 0; j < GQ_NVD; j++) {
     const int hi = i > j ? i : j, lo = i > j ? j : i;
-    float v = 0.0f;
-    if (hi < 6) v = W.u2.n.Hb[hi][lo];
-    else if (lo < 6) v = W.u2.n.Hc[hi - 6][lo];
-    else if ((hi - 6) / 3 == (lo - 6) / 3) v = W.u2.n.Hc[hi - 6][6 + (lo - 6) % 3];
-    row[j] = v;
+    if (j < 6) { /* compile-time: column in the base block */
+      row[j] = hi < 6 ? Hb0[hi * 6 + lo] : Hc0[(hi - 6) * 9 + lo];
+    } else {
+      const bool same = (hi - 6) / 3 == (lo - 6) / 3;
+      const int a_c = (hi - 6) * 9 + (lo < 6 ? lo : 6 + (lo - 6) % 3); /* lo < 6 only when i < 6: base row, leg column */
+      const float v = Hc0[hi >= 6 ? a_c : 0];
+      row[j] = (lo < 6 || same) ? v : 0.0f;
+    }
   }
   for (int r = r0; r < r1; r++) { /* wave-uniform: cross-leg entries */
-    const float a = W.force[r] * W.u.B[r][i];
+    float bj[12];
 #pragma unroll
-    for (int j = 6; j < GQ_NVD; j++) row[j] += ((j - 6) / 3 != li && li >= 0) ? a * W.u.B[r][j] : 0.0f;
+    for (int j = 0; j < 12; j++) bj[j] = W.u.B[r][6 + j];
+    const float a = li >= 0 ? W.force[r] * W.u.B[r][i] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 12; j++) row[6 + j] += (j / 3 != li) ? a * bj[j] : 0.0f;
   }
 #pragma unroll
   for (int k = 0; k < GQ_NVD - 1; k++) {
@@ -613,6 +623,16 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     const int frp1 = (e < 117 && da == db) ? m.fl_row_of_dof[da] + 1 : 0;
     hent[pass] = e < 117 ? (da | (db << 8) | (slot << 16) | (frp1 << 24)) : -1;
   }
+  /* H without the elliptic virtual rows, kept in REGISTERS across the iterations (two entries per lane) together with the
+   * weight every row currently has in it: an iteration adds  dw_r J_r' J_r  for the rows whose weight CHANGED - all active
+   * rows in the first iteration (from M), the one to three rows that switched piece afterwards - instead of walking every
+   * row for every entry every time. */
+  float hbase[2], wprev = 0.0f;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int da = hent[pass] & 0xff, db = (hent[pass] >> 8) & 0xff, slot = (hent[pass] >> 16) & 0xff;
+    hbase[pass] = hent[pass] < 0 ? 0.0f : (slot < 108 ? W.Mc[slot / 9][slot % 9] : W.Mb[da][db]);
+  }
   long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = (DBG && tdbg) ? cycles() : 0;
   if constexpr (DBG) if (tdbg && lane == 0) { tdbg[29] = 0.0f; tdbg[30] = 0.0f; } /* line-search trials, full-step shortcuts */
 #define NW_T(i) do { if constexpr (DBG) if (tdbg) { const long long tn = cycles(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
@@ -689,7 +709,13 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       xr = xsm ? ffs64(xm) : 0;
     }
     const float xw = xsm ? bcast(wact, xr) : 0.0f;
-    W.force[lane] = (xsm && lane == xr) ? 0.0f : wact; /* Hessian weights of the rows replace the forces */
+    /* Hessian weight of the row (the Sherman-Morrison row stays out of the tree-sparse part) and its change since the last
+     * assembly; the CHANGES replace the forces in W.force */
+    const float wh = (xsm && lane == xr) ? 0.0f : wact;
+    const float dw = lane < nefc ? wh - wprev : 0.0f;
+    wprev = wh;
+    const uint64_t chg = ballot(dw != 0.0f);
+    W.force[lane] = dw;
     wave_barrier();
     int nrowh = nefc; /* rows the Hessian assembly walks */
     if constexpr (CONE) {
@@ -744,41 +770,57 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       wave_barrier();
     }
     NW_T(2);
-    /* ---- Hessian in M's tree-sparse layout: H = M + sum_r w_r J_r' J_r.  117 structurally non-zero entries, two
-     * passes of one entry per lane.  Friction-loss rows are +-e_dof: their weight goes straight to the diagonal; limit
-     * rows (few) and contact rows are walked generically. */
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      if (hent[pass] >= 0) {
-        const int da = hent[pass] & 0xff, db = (hent[pass] >> 8) & 0xff, slot = (hent[pass] >> 16) & 0xff;
-        float s0 = slot < 108 ? W.Mc[slot / 9][slot % 9] : W.Mb[da][db], s1 = 0.0f;
-        if (da == db) {
-          const int fr = (hent[pass] >> 24) - 1;
-          if (fr >= 0) s0 += W.force[fr];
-          for (int r = nfl; r < nsingle; r++) s1 += W.force[r] * W.u.B[r][da] * W.u.B[r][da];
-        }
+    /* ---- Hessian in M's tree-sparse layout: H = M + sum_r w_r J_r' J_r.  117 structurally non-zero entries, two per
+     * lane.  Friction-loss rows are +-e_dof: their weight change goes straight to the diagonal; the changed limit / contact
+     * rows are walked wave-uniformly (row index and weight change in SGPRs, the two J entries of each of the lane's
+     * entries from LDS), two rows per trip so that their reads are in flight together. */
+    {
+      const int e0 = hent[0] < 0 ? 0 : hent[0], e1 = hent[1] < 0 ? 0 : hent[1];
+      const int da0 = e0 & 0xff, db0 = (e0 >> 8) & 0xff, da1 = e1 & 0xff, db1 = (e1 >> 8) & 0xff;
+      const uint64_t flm = nfl >= 64 ? ~0ull : ((1ull << nfl) - 1ull);
+      if (chg & flm) {
+        const int f0 = (e0 >> 24) - 1, f1 = (e1 >> 24) - 1;
+        if (f0 >= 0) hbase[0] += W.force[f0];
+        if (f1 >= 0) hbase[1] += W.force[f1];
+      }
+      uint64_t mk = chg & ~flm;
+      while (mk) {
+        const int ra = ffs64(mk);
+        mk &= mk - 1;
+        const bool two = mk != 0;
+        const int rb = two ? ffs64(mk) : ra;
+        mk &= mk - 1; /* 0 stays 0 */
+        const float wa = bcast(dw, ra), wb = two ? bcast(dw, rb) : 0.0f;
+        const float a00 = W.u.B[ra][da0], a01 = W.u.B[ra][db0], a10 = W.u.B[ra][da1], a11 = W.u.B[ra][db1];
+        const float b00 = W.u.B[rb][da0], b01 = W.u.B[rb][db0], b10 = W.u.B[rb][da1], b11 = W.u.B[rb][db1];
+        hbase[0] += wa * a00 * a01 + wb * b00 * b01;
+        hbase[1] += wa * a10 * a11 + wb * b10 * b11;
+      }
+      float hv0 = hbase[0], hv1 = hbase[1];
+      if constexpr (CONE) { /* the virtual rows of the middle-zone contacts are rebuilt every iteration */
         float s2 = 0.0f, s3 = 0.0f;
-        if constexpr (!CONE) {
-          int r = nsingle;
-          for (; r + 2 <= nrowh; r += 2) {
-            s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
-            s1 += W.force[r + 1] * W.u.B[r + 1][da] * W.u.B[r + 1][db];
-          }
-          if (r < nrowh) s0 += W.force[r] * W.u.B[r][da] * W.u.B[r][db];
-        } else
-        for (int r = nsingle; r < nrowh; r += GQ_HCHUNK) { /* chunks of rows: three LDS reads per row in flight together */
-          float w[GQ_HCHUNK], av[GQ_HCHUNK], cv[GQ_HCHUNK];
-#pragma unroll
-          for (int u = 0; u < GQ_HCHUNK; u++) {
-            const int ru = r + u < 64 ? r + u : 63;
-            w[u] = r + u < nrowh ? W.force[ru] : 0.0f; av[u] = W.u.B[ru][da]; cv[u] = W.u.B[ru][db];
-          }
-#pragma unroll
-          for (int u = 0; u < GQ_HCHUNK; u += 4) { s0 += w[u] * av[u] * cv[u]; s1 += w[u + 1] * av[u + 1] * cv[u + 1]; s2 += w[u + 2] * av[u + 2] * cv[u + 2]; s3 += w[u + 3] * av[u + 3] * cv[u + 3]; }
+        for (int r = nefc; r < nrowh; r += 2) {
+          const int r1 = r + 1 < 64 ? r + 1 : 63;
+          const float w0 = W.force[r], w1 = r + 1 < nrowh ? W.force[r1] : 0.0f;
+          const float a00 = W.u.B[r][da0], a01 = W.u.B[r][db0], a10 = W.u.B[r][da1], a11 = W.u.B[r][db1];
+          const float b00 = W.u.B[r1][da0], b01 = W.u.B[r1][db0], b10 = W.u.B[r1][da1], b11 = W.u.B[r1][db1];
+          hv0 += w0 * a00 * a01; s2 += w1 * b00 * b01;
+          hv1 += w0 * a10 * a11; s3 += w1 * b10 * b11;
         }
-        const float hv = (s0 + s1) + (s2 + s3);
-        if (slot < 108) W.u2.n.Hc[slot / 9][slot % 9] = hv;
-        else { W.u2.n.Hb[da][db] = hv; W.u2.n.Hb[db][da] = hv; }
+        hv0 += s2; hv1 += s3;
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {
+        if (hent[pass] >= 0) {
+          const int da = hent[pass] & 0xff, db = (hent[pass] >> 8) & 0xff, slot = (hent[pass] >> 16) & 0xff;
+          const float hv = pass ? hv1 : hv0;
+          if (slot < 108) W.u2.n.Hc[slot / 9][slot % 9] = hv;
+          else { W.u2.n.Hb[da][db] = hv; W.u2.n.Hb[db][da] = hv; }
+        }
+      }
+      if (xl && !xsm) { /* the dense step reads the coupling rows' WEIGHTS from W.force (virtual rows above nefc hold theirs) */
+        wave_barrier();
+        if (lane < nefc) W.force[lane] = wh;
       }
     }
     wave_barrier();

@@ -35,6 +35,11 @@ for p in $PARTS; do
     selfcut) for c in 0 2 4; do GQ_SELF_CUT=$c timeout 600 python bench.py --no-cpu-baseline --no-secondary > $OUT/bench_selfcut$c.json 2> $OUT/bench_selfcut$c.err; python -c "import json; d=json.load(open('$OUT/bench_selfcut$c.json')); print('self cut $c', round(d['value']/1e6,2), 'M', round(d['roofline']['kernel_ms']*1e3,1), 'us kernel')"; done;;
     timeline) timeout 600 python tools/wave_timeline.py 4096 > $OUT/wave_timeline.txt 2>&1
               timeout 600 python tools/wave_timeline.py 4096 mini_cheetah noself > $OUT/wave_timeline_noself.txt 2>&1;;
+    robots) for r in go2 aliengo hyqreal1; do
+              timeout 600 python tools/wave_timeline.py 4096 $r > $OUT/wave_timeline_$r.txt 2>&1
+              timeout 600 python tools/wave_timeline.py 4096 $r noself > $OUT/wave_timeline_${r}_noself.txt 2>&1
+              timeout 600 python tools/perf_probe.py stages 4096 $r > $OUT/stages4096_$r.txt 2>&1
+            done;;
     nscan) timeout 900 python tools/nscan.py > $OUT/nscan.txt 2>&1;;
     profiles) timeout 1500 bash tools/run_profiles.sh $TAG pmc > $OUT/run_profiles.txt 2>&1
               timeout 600 bash tools/run_profiles.sh ${TAG}_noself nopmc --no-self-collision >> $OUT/run_profiles.txt 2>&1
