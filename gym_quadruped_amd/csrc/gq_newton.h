@@ -726,46 +726,73 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
        * b_k = sum_j fri_j p_kj J_j (weight Dm kappa).  dim 3: p = (-u_2, u_1);  dim 6: columns 2..5 of the Householder
        * reflection that maps e_1 to -+u.  (Formed as diag - w w' the projector loses definiteness by ~1e-7 Dm kappa, which
        * is comparable to the inertia of a light leg.) */
-      const int ncon = W.ncon;
-      for (int c = 0; c < ncon; c++) { /* wave-uniform */
-        const int r0 = uniform(W.con_row[c]), dim = uniform(W.con_dim[c]);
-        if (dim == 1) continue;
-        if (bcast(zone, r0) != 2) continue;
-        const float mu_c = bcast(E.mu, r0), Tc = sqrtf(bcast(TT, r0)), qc = mu_c * bcast(y0, r0) - mu_c * Tc;
-        const float Dm = bcast(E.D0, r0) / (mu_c * mu_c * (1.0f + mu_c * mu_c)), wk = Dm * (-mu_c * qc) / Tc;
-        float uh[6], fr[6], Jr[6]; /* [0] unused for uh / fr */
+      /* Built lane-parallel (a wave-uniform loop over the contacts with v_readlane broadcasts was 7k cycles per iteration for
+       * a wave alone on its SIMD).  Every virtual row is a combination  sum_i coef_i J[r0 + i]  of its contact's rows:
+       * (1) the head lanes of the middle-zone contacts count the virtual rows (ballots, no scan: a contact has 2 or 5);
+       * (2) row lane r0 + i writes ITS coefficient of each of its contact's virtual rows into the (still unused) storage of
+       *     that virtual row, the head lane adds r0, dim and the weight;
+       * (3) the nvirt x 18 outputs are spread over all 64 lanes (registers), and written back after a barrier. */
+      const int e = E.code & 15, dimc = E.code >> 4;
+      const bool mid = E.code != 0 && zone == 2, head = mid && e == 0;
+      const uint64_t m3 = ballot(head && dimc == 3), m6 = ballot(head && dimc == 6);
+      if ((m3 | m6) != 0) { /* wave-uniform */
+        const uint64_t below = (1ull << (E.r0 & 63)) - 1ull;
+        const int vb = nefc + 2 * popc64(m3 & below) + 5 * popc64(m6 & below); /* first virtual row of the lane's contact */
+        const int nvirt = 2 * popc64(m3) + 5 * popc64(m6);
+        const int mdim = m6 ? 6 : 3;
+        float uh[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; /* u_j of the lane's contact ([0] unused) */
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-          uh[i] = (i >= 1 && i < dim) ? bcast(uhat, r0 + i) : 0.0f;
-          fr[i] = (i >= 1 && i < dim) ? bcast(E.fri, r0 + i) : 0.0f;
-          Jr[i] = (i < dim && lane < GQ_NVD) ? W.u.B[r0 + i][lane] : 0.0f;
-        }
-        float av = mu_c * Jr[0];
+        for (int j = 1; j < 6; j++)
+          if (j < mdim) { const float t = shfl_idx(uhat, E.r0 + j); uh[j] = j < dimc ? t : 0.0f; }
+        if (mid) {
+          const float Tc = sqrtf(TT), qc = E.mu * y0 - E.mu * Tc;
+          const float Dm = E.D0 / (E.mu * E.mu * (1.0f + E.mu * E.mu)), wk = Dm * (-E.mu * qc) / Tc;
+          W.u.B[vb][e] = e == 0 ? E.mu : -E.mu * E.fri * uhat;
+          if (dimc == 3) {
+            W.u.B[vb + 1][e] = e == 0 ? 0.0f : (e == 1 ? -uh[2] * E.fri : uh[1] * E.fri);
+          } else {
+            const float sg = uh[1] < 0.0f ? -1.0f : 1.0f, inv = 1.0f / (1.0f + fabsf(uh[1])); /* 2 / (h'h), h'h = 2 (1 + |u_1|) */
+            const float hve = e == 0 ? 0.0f : uhat + (e == 1 ? sg : 0.0f);
 #pragma unroll
-        for (int i = 1; i < 6; i++) av -= mu_c * fr[i] * uh[i] * Jr[i];
-        if (lane < GQ_NVD) W.u.B[nrowh][lane] = av;
-        if (lane == 0) W.force[nrowh] = Dm;
-        nrowh++;
-        if (dim == 3) {
-          if (lane < GQ_NVD) W.u.B[nrowh][lane] = -uh[2] * fr[1] * Jr[1] + uh[1] * fr[2] * Jr[2];
-          if (lane == 0) W.force[nrowh] = wk;
-          nrowh++;
-        } else {
-          const float sg = uh[1] < 0.0f ? -1.0f : 1.0f;
-          float hv[6];
-#pragma unroll
-          for (int i = 1; i < 6; i++) hv[i] = uh[i] + (i == 1 ? sg : 0.0f);
-          const float inv = 1.0f / (1.0f + fabsf(uh[1])); /* 2 / (h'h), h'h = 2 (1 + |u_1|) */
-#pragma unroll
-          for (int k = 2; k < 6; k++) {
-            float bv = 0.0f;
-#pragma unroll
-            for (int i = 1; i < 6; i++) bv += ((i == k ? 1.0f : 0.0f) - hv[i] * hv[k] * inv) * fr[i] * Jr[i];
-            if (lane < GQ_NVD) W.u.B[nrowh][lane] = bv;
-            if (lane == 0) W.force[nrowh] = wk;
-            nrowh++;
+            for (int k = 2; k < 6; k++) W.u.B[vb + k - 1][e] = e == 0 ? 0.0f : ((e == k ? 1.0f : 0.0f) - hve * uh[k] * inv) * E.fri;
+          }
+          if (e == 0) {
+            for (int k = 0; k < dimc - 1; k++) {
+              W.u.B[vb + k][6] = __builtin_bit_cast(float, E.r0 | (dimc << 8));
+              W.force[vb + k] = k == 0 ? Dm : wk;
+            }
           }
         }
+        wave_barrier();
+        const int total = nvirt * GQ_NVD;
+        float outv[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          outv[k] = 0.0f;
+          if (64 * k < total) { /* wave-uniform */
+            const int o = lane + 64 * k < total ? lane + 64 * k : total - 1;
+            const int v = (o * 3641) >> 16, d = o - GQ_NVD * v; /* o / 18 for o < 1024 */
+            const float* Tv = W.u.B[nefc + v];
+            const int meta = __builtin_bit_cast(int, Tv[6]), r0 = meta & 0xff, dv = meta >> 8;
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+              if (i < mdim) { /* wave-uniform */
+                const int ri = r0 + i < 64 ? r0 + i : 63;
+                const float c = Tv[i], Jv = W.u.B[ri][d];
+                acc += i < dv ? c * Jv : 0.0f;
+              }
+            outv[k] = acc;
+          }
+        }
+        wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+          if (64 * k < total && lane + 64 * k < total) {
+            const int o = lane + 64 * k, v = (o * 3641) >> 16, d = o - GQ_NVD * v;
+            W.u.B[nefc + v][d] = outv[k];
+          }
+        nrowh = nefc + nvirt;
       }
       wave_barrier();
     }
