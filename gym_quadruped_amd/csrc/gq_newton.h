@@ -566,6 +566,13 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
 #define GQ_HCHUNK 4
 #endif
 /* relative tolerance of the line search on phi' (MuJoCo: opt.ls_tolerance = 0.01) */
+/* relative step below which the iterate has converged to fp32 working precision (see the use site) */
+#ifndef GQ_STEP_FLOOR
+#define GQ_STEP_FLOOR 1e-6f
+#endif
+#ifndef GQ_LS_TRIALS
+#define GQ_LS_TRIALS 16
+#endif
 #ifndef GQ_LS_TOL
 #define GQ_LS_TOL 1e-2f
 #endif
@@ -646,6 +653,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     for (int k = 0; k < GQ_NVD; k++) y += J[k] * W.qacc[k];
   }
   /* md = M (qacc - qacc_smooth) = M qacc - qfrc_smooth, advanced with the iterate; zero at the starting point */
+  float gnorm2_prev = 0.0f, pred_prev = 1.0f;
   for (;; iter++) {
     /* a wave that needs many iterations decides when the launch ends: it moves ahead of the waves it shares the SIMD with */
     if (iter + 1 > prio && iter > 0) { prio = iter + 1; wave_priority(prio); }
@@ -659,6 +667,15 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       const float f2 = ell_state(E, y, rD, c2, w2, zone, uhat, TT, y0);
       if (E.code) { f = f2; ci = c2; wact = w2; }
     }
+#ifdef GQ_EMU_TRACE
+    if constexpr (CONE) if (getenv("GQ_EMU_TRACE") && E.code != 0 && (E.code & 15) == 0) printf("   it %d contact r0 %d dim %d zone %d N %.6e T %.6e mu %.4f y0 %.6e f %.4e\n", iter, E.r0, E.code >> 4, zone, (double)(E.mu * y0), (double)sqrtf(TT), (double)E.mu, (double)y0, (double)f);
+#endif
+#ifdef GQ_EMU_TRACE
+    if (getenv("GQ_EMU_TRACE")) {
+      const float cc = wave_sum(lane < nefc ? ci : 0.0f), cg = wave_sum(lane < GQ_NVD ? 0.5f * md * (W.qacc[lane] - W.qacc_smooth[lane]) : 0.0f);
+      if (lane == 0) printf("   it %d cost %.9e (constraint %.9e gauss %.9e) scaled %.6e\n", iter, (double)(cc + cg), (double)cc, (double)cg, (double)(scale * (cc + cg)));
+    }
+#endif
     W.force[lane] = f; /* row forces, read column-wise for J'f below */
     if (lane < GQ_NVD) Mdq[lane] = md;
     wave_barrier();
@@ -694,6 +711,14 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     /* fp32 floor (GqModelDesc.noise_floor): the gradient is a difference of two vectors; once it is down at their
      * round-off a further Newton step only chases noise */
     if (iter > 0 && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(gterm)) { exit_code = 4; break; }
+    /* stagnation at working precision: close to the solution (the last step promised less than 1e-6, scaled like
+     * `tolerance`) Newton's gradient collapses from one iterate to the next; one that did not even halve is rounding noise
+     * of the stiff rows' residuals (elliptic models, impratio 100: the iterates then cycle between neighbouring fp32
+     * states, every step still "promising" a few 1e-8 - above `tolerance` - until the iteration cap). */
+    if constexpr (CONE) { /* (pyramidal problems are piecewise quadratic: the converged-step test below ends them exactly) */
+      if (iter > 0 && pred_prev < 1e-6f && gnorm2 >= 0.25f * gnorm2_prev) { exit_code = 8; break; }
+      gnorm2_prev = gnorm2;
+    }
     if (lane < GQ_NVD) grad[lane] = -gd; /* right-hand side of H search = -grad */
     wave_barrier();
     /* a contact between two different legs couples them in H = M + J'DJ, which then no longer has M's tree sparsity - but
@@ -702,7 +727,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
      * by Sherman-Morrison on two tree solves that share their elimination.  More: the dense lane-parallel step. */
     bool xl = false, xsm = false;
     int xr = 0;
-    if (xrow0 > 0) {
+    if (xrow0 >= 0) { /* -1: no contact couples two legs (0 is a valid first row: models without friction loss) */
       const uint64_t xm = ballot(xrow && (wact != 0.0f || (CONE && zone == 2)));
       xl = xm != 0;
       xsm = !CONE && popc64(xm) == 1;
@@ -902,20 +927,71 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     float h0 = wave_sum(p2 + d2);
     if (!(g0 < 0.0f)) { exit_code = 5; break; } /* not a descent direction: converged to working precision */
     alpha = -g0 / h0;
-    for (int ls = 0; ls < 10; ls++) {
+    /* Newton on phi' while it makes progress; phi' is only piecewise smooth (a row changing piece, an elliptic contact whose
+     * tangential residual passes near zero), and across a kink whose slopes differ by more than 2x Newton steps from the
+     * two sides overshoot each other for ever inside the bracket.  So once a bracket exists, a trial that did not halve
+     * |phi'| is followed by the bracket's midpoint.  If the trials run out, the step is the bracket's lower end: phi' < 0
+     * there, so the cost did go down (the unverified last candidate could sit beyond the minimiser far enough to RAISE the
+     * cost - spot cycled on that until the iteration cap, with a wrong qacc). */
+    float gprev = fabsf(g0);
+    bool done = false;
+    for (int ls = 0; ls < GQ_LS_TRIALS; ls++) {
       if constexpr (DBG) if (tdbg && lane == 0) tdbg[29] += 1.0f;
       row_dd(rtype, y + alpha * v, v, rR, rD, rfloss, d1, d2);
       if constexpr (CONE) if (E.code) ell_dd(E, alpha, y, v, rD, TT, y0, UV, VV, N1, d1, d2);
       const float ga = wave_sum(p1 + alpha * p2 + d1);
       const float ha = wave_sum(p2 + d2);
-      if (fabsf(ga) <= GQ_LS_TOL * fabsf(g0)) { first_try = ls == 0; break; } /* an approximate line search, like MuJoCo's */
+      if (fabsf(ga) <= GQ_LS_TOL * fabsf(g0)) { first_try = ls == 0; done = true; break; } /* an approximate line search, like MuJoCo's */
       if (ga < 0.0f) lo = alpha; else hi = alpha;
       float an = alpha - ga / ha;
-      if (!(an > lo) || (hi > 0.0f && !(an < hi))) an = hi > 0.0f ? 0.5f * (lo + hi) : 2.0f * alpha;
+      const bool outside = !(an > lo) || (hi > 0.0f && !(an < hi));
+      if (hi > 0.0f) { if (outside || fabsf(ga) > 0.5f * gprev) an = 0.5f * (lo + hi); }
+      else if (outside) an = 2.0f * alpha;
+      gprev = fabsf(ga);
       alpha = an;
     }
+    if (!done) alpha = lo > 0.0f ? lo : alpha; /* lo == 0: every trial overshot; the last midpoint is the best guess */
     }
     wave_barrier();
+#ifdef GQ_EMU_TRACE
+    if (getenv("GQ_EMU_TRACE")) {
+      auto costat = [&](float al) {
+        float c1, w1; row_law(rtype, y + al * v, rR, rD, rfloss, c1, w1);
+        if constexpr (CONE) { int z2; float t1, t2, t3, c2, w2; ell_state(E, y + al * v, rD, c2, w2, z2, t1, t2, t3); if (E.code) c1 = c2; }
+        const float pp1 = lane < GQ_NVD ? search[lane] * md : 0.0f, pp2 = lane < GQ_NVD ? search[lane] * ms : 0.0f;
+        return wave_sum((lane < nefc ? c1 : 0.0f) + al * pp1 + 0.5f * al * al * pp2);
+      };
+      if (iter == 3) for (int gi = 0; gi <= 16; gi++) {
+        const float al = 0.05f * gi, hh = 2e-4f;
+        float e1, e2; row_dd(rtype, y + al * v, v, rR, rD, rfloss, e1, e2);
+        if constexpr (CONE) if (E.code) ell_dd(E, al, y, v, rD, TT, y0, UV, VV, N1, e1, e2);
+        const float pp1 = lane < GQ_NVD ? search[lane] * md : 0.0f, pp2 = lane < GQ_NVD ? search[lane] * ms : 0.0f;
+        const float an = wave_sum(pp1 + al * pp2 + e1), nu = (costat(al + hh) - costat(al - hh)) / (2 * hh);
+        /* per contact */
+        const float e1c = ell_seg_sum(E, e1) + shfl_idx(e1, E.r0);
+        float c1, w1; row_law(rtype, y + (al + hh) * v, rR, rD, rfloss, c1, w1); float cA = c1;
+        if constexpr (CONE) { int z2; float t1, t2, t3, c2, w2; ell_state(E, y + (al + hh) * v, rD, c2, w2, z2, t1, t2, t3); if (E.code) cA = c2; }
+        row_law(rtype, y + (al - hh) * v, rR, rD, rfloss, c1, w1); float cB = c1; int zz = 0;
+        if constexpr (CONE) { float t1, t2, t3, c2, w2; ell_state(E, y + (al - hh) * v, rD, c2, w2, zz, t1, t2, t3); if (E.code) cB = c2; }
+        const float dnum = (cA - cB) / (2 * hh);
+        const float dnc = ell_seg_sum(E, dnum) + shfl_idx(dnum, E.r0);
+        if (gi == 1 && lane < nefc) printf("        row %d type %d code %d y %.5e v %.5e cA %.6e cB %.6e dnum %.4e e1 %.4e\n", lane, rtype, E.code, (double)y, (double)v, (double)cA, (double)cB, (double)dnum, (double)e1);
+        if (lane == 0) printf("     alpha %.2f analytic %.5e numeric %.5e\n", (double)al, (double)an, (double)nu);
+        if (E.code && (E.code & 15) == 0) printf("        contact r0 %d zone %d analytic %.5e numeric %.5e\n", E.r0, zz, (double)e1c, (double)dnc);
+      }
+      const float h = 1e-3f * fmaxf(alpha, 1e-3f);
+      const float c0 = costat(0.0f), cm = costat(alpha - h), cp = costat(alpha + h), ca = costat(alpha), ch = costat(1e-3f);
+      if (lane == 0) printf("   linesearch check: cost(0) %.7e cost(alpha) %.7e  numeric phi'(alpha) %.4e  numeric phi'(0) %.4e vs g0 %.4e\n", (double)c0, (double)ca, (double)((cp - cm) / (2 * h)), (double)((ch - c0) / 1e-3f), (double)g0);
+    }
+    if (lane == 0 && getenv("GQ_EMU_TRACE")) printf("it %d gnorm %.6e g0 %.6e alpha %.6e first %d scale*pred %.3e  lo %.3e hi %.3e\n", iter, (double)sqrtf(gnorm2), (double)g0, (double)alpha, (int)first_try, (double)(scale * (-0.5f * g0 * alpha)), (double)lo, (double)hi);
+#endif
+    /* fp32 resolution of the iterate: a step that moves no component by more than GQ_STEP_FLOOR (relative, 1 for small
+     * components - the metric of the parity tests) is the last one.  Newton converges quadratically, so what remains
+     * after such a step is far below it; without this test a stiff elliptic problem (impratio 100) can sit at a gradient
+     * of 1e-7 of its starting value - rounding noise of the residuals, yet above `tolerance` and above the noise floor
+     * of the gradient's two terms - and repeat a step that no longer changes qacc until the iteration cap (go1: one env
+     * in 10 000 env-steps, 100 iterations, 1.1 ms for the whole launch). */
+    const bool tiny_step = CONE && ballot(lane < GQ_NVD && fabsf(alpha * search[lane]) > GQ_STEP_FLOOR * fmaxf(1.0f, fabsf(W.qacc[lane]))) == 0;
     if (lane < GQ_NVD) { W.qacc[lane] += alpha * search[lane]; md += alpha * ms; }
     const float ynew = y + alpha * v;
     /* the cost is piecewise quadratic.  A full Newton step (accepted at the first trial) that leaves every row on the
@@ -931,7 +1007,9 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     wave_barrier();
     NW_T(6);
     /* improvement of this step from the line-search model (exact for a quadratic phi): phi(0) - phi(alpha) = -g0 alpha / 2 */
-    const bool small_step = scale * (-0.5f * g0 * alpha) < m.tolerance;
+    const float pred = scale * (-0.5f * g0 * alpha);
+    if constexpr (CONE) pred_prev = pred;
+    const bool small_step = pred < m.tolerance || tiny_step;
     if ((first_try && ballot(moved) == 0) || small_step) {
       float ci, wact;
       f = row_law(rtype, y, rR, rD, rfloss, ci, wact);
@@ -942,7 +1020,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       }
       if (lane < GQ_NVD) Mdq[lane] = md;
       iter++;
-      exit_code = small_step ? 1 : 6;
+      exit_code = tiny_step ? 7 : (small_step ? 1 : 6);
       break;
     }
   }

@@ -737,7 +737,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     if constexpr (DBG && SELF) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 31] = (float)(uniform(W.nself) + (xleg ? 100 : 0));
     const float fN = newton_solve<DBG, CONE>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
                                   timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint, xrow,
-                                  xleg ? uniform(W.con_row[ncon - uniform(W.nself)]) : 0);
+                                  xleg ? uniform(W.con_row[ncon - uniform(W.nself)]) : -1);
     /* a coupled-leg Newton step (Sherman-Morrison / dense) is the most expensive thing a wave can do, and leg-leg contacts
      * persist over several steps: such an env keeps top issue priority */
     if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)((xleg && iter >= 2) ? 3 : (iter < 2 ? 0 : (iter > 2 ? 3 : 2)));

@@ -696,7 +696,7 @@ def test_subset_of_observables_equals_the_full_set():
                 assert torch.equal(o[k], ref[k]), (t, k)
 
 
-@pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo', 'go2', 'go1', 'hyqreal1'])
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'aliengo', 'go2', 'go1', 'hyqreal1', 'b2', 'spot'])
 def test_robot_self_collision_step_parity(robot):
     """Robot-robot contacts (MuJoCo's default contype = conaffinity = 1: legs hit each other and the trunk; capsule proxies,
     gym_quadruped_amd/selfcol.py) on the GPU against the fp64 oracle: every test state has at least one such contact, about
@@ -734,8 +734,9 @@ def test_robot_self_collision_step_parity(robot):
         b1, b2 = o.get('contact_body1').astype(int), o.get('contact_body').astype(int)
         nself += int((b1 > 0).any()); ncross += int(any(x > 0 and leg(x) >= 0 and leg(x) != leg(y) for x, y in zip(b1, b2)))
         ea.append(np.abs(dbg[e]['qacc'] - o.qacc).max() / max(1.0, np.abs(o.qacc).max()))
-        ev.append(np.abs(qv[e] - o.qvel).max())
-        assert np.abs(qp[e] - o.qpos).max() < 3.5e-6
+        ev.append(np.abs(qv[e] - o.qvel).max() / max(1.0, 0.002 * np.abs(o.qacc).max()))   # relative to the step's velocity change once that exceeds 1
+        # deeply interpenetrating random states reach |qacc| of 1e5 rad/s^2: the position error is dt^2 times the (relative) qacc error
+        assert np.abs(qp[e] - o.qpos).max() < 3.5e-6 + 4e-6 * (2e-4 if cone else 2e-5) * max(1.0, np.abs(o.qacc).max())
         ref, t, inv = o.get_obs(ALL_OBS, cmd[e]); got = split_obs(ob[e], ALL_OBS)
         for k in ('contact_state', 'feet_vel', 'base_lin_acc'):   # robot-robot contacts set no foot contact state and no termination
             assert np.abs(got[k] - ref[k]).max() < 5e-3 * max(1.0, np.abs(ref[k]).max()), (e, k)
@@ -745,3 +746,28 @@ def test_robot_self_collision_step_parity(robot):
     assert p99(ev) < (7e-4 if cone else 5e-5) * 5 and max(ev) < 5e-3, (p99(ev), max(ev))
     tally.finish(f'self-collision one-step parity {robot}', min_checked=0.5, max_tie=0.15, max_budget=0.5)
     assert nself >= 0.9 * tally.checked and ncross >= 0.25 * tally.checked, (nself, ncross, tally.checked)
+
+
+@pytest.mark.parametrize('robot', ['go1', 'spot', 'b2'])
+def test_newton_ends_on_captured_hard_states(robot):
+    """The captured go1 states of tests/golden/newton_stagnation_go1.npz (see the emulated twin of this test): the solve
+    ends far below the iteration cap, at the oracle's solution."""
+    from pathlib import Path
+    z = np.load(Path(__file__).parent / 'golden' / f'newton_stagnation_{robot}.npz')
+    n = len(z['qpos'])
+    env = _make_env(n, solver='newton', iters=100, tol=1e-8, robot=robot)
+    env.reset(qpos=z['qpos'], qvel=z['qvel'])
+    env._qpos.copy_(torch.as_tensor(z['qpos'])); env._qvel.copy_(torch.as_tensor(z['qvel']))
+    env._warm.copy_(torch.as_tensor(z['warm'])); env._applied.copy_(torch.as_tensor(z['applied'])); env._time.zero_()
+    env._friction.copy_(torch.as_tensor(z['friction']))
+    env.enable_debug(n)
+    env.step(torch.as_tensor(z['ctrl']))
+    torch.cuda.synchronize()
+    d = env.debug_internals(n, ['niter', 'qacc'])
+    o = _oracle(env)
+    for e in range(n):
+        o.set_state(z['qpos'][e], z['qvel'][e].astype(np.float64), z['warm'][e].astype(np.float64), z['applied'][e].astype(np.float64), 0.0, float(z['friction'][e]))
+        o.step(z['ctrl'][e].astype(np.float64))
+        assert d[e]['niter'][0] <= 20, (e, d[e]['niter'][0], o.solver_niter)
+        qa = np.array(o.qacc)
+        assert np.abs(d[e]['qacc'] - qa).max() <= 2e-5 * max(1.0, np.abs(qa).max()), e

@@ -1,5 +1,6 @@
 """The UNMODIFIED HIP kernel bodies (csrc/gq_step_body.h) executed by the host SIMT emulator (tests/simt_emu) against
 the CPU oracle: same parity contract as tests/test_gpu_parity.py, runnable without a GPU."""
+from pathlib import Path
 import numpy as np
 import pytest
 
@@ -475,7 +476,7 @@ def test_general_impedance_power_matches_oracle():
     assert rows > 40
 
 
-@pytest.mark.parametrize('robot,want_cross', [('mini_cheetah', True), ('aliengo', False), ('aliengo', True), ('go2', True), ('go1', None)])
+@pytest.mark.parametrize('robot,want_cross', [('mini_cheetah', True), ('aliengo', False), ('aliengo', True), ('go2', True), ('go1', None), ('b2', True)])
 def test_robot_self_collision_matches_oracle(robot, want_cross):
     """Robot-robot contacts (MuJoCo's default contype = conaffinity = 1; capsule proxies, selfcol.py): pair filter, broad
     and narrow phase, two-body Jacobian rows, and the Newton step - tree-sparse when the contact stays inside one leg or
@@ -513,3 +514,28 @@ def test_robot_self_collision_matches_oracle(robot, want_cross):
                 nr = dims[c] if mm.md.cone == 1 else (1 if dims[c] == 1 else 2 * (dims[c] - 1))
                 assert np.abs(J[adr[c]:adr[c] + nr, :6]).max() < 1e-12
     assert nchecked >= n // 2 and nself > 0
+
+
+@pytest.mark.parametrize('robot', ['go1', 'spot', 'b2'])
+def test_newton_ends_on_captured_hard_states(robot):
+    """States captured from benchmark rollouts on the GPU (tools/capture_stuck.py -> tests/golden/newton_stagnation_*.npz)
+    on which the fp32 Newton solver ran into the iteration cap (100 iterations = 1.1 ms for the whole launch):
+    go1 - cycling between neighbouring fp32 iterates at a gradient of 1e-7 of its starting value (stagnation exit);
+    spot - a line search whose Newton trials overshot each other across a kink of phi' and whose unverified last candidate
+    raised the cost (bracketed secant, lower bracket end on exhaustion) - qacc was WRONG there;
+    b2 - two contacts between different legs in a model without friction-loss rows: first coupling row 0 was read as "no
+    coupling" and the tree-sparse solve was used on a Hessian that is not tree-sparse.
+    All must end within the order of the fp64 oracle's iteration count, at the oracle's solution."""
+    z = np.load(Path(__file__).parent / 'golden' / f'newton_stagnation_{robot}.npz')
+    mm = marshalled(robot, solver=1, iterations=100, tolerance=1e-8)
+    o = Oracle(mm)
+    n = len(z['qpos'])
+    st = emu_step(mm, z['ctrl'].copy(), z['qpos'].copy(), z['qvel'].copy(), warm=z['warm'].copy(), applied=z['applied'].copy(),
+                  friction=z['friction'].copy(), debug_envs=n)
+    for e in range(n):
+        o.set_state(z['qpos'][e], z['qvel'][e].astype(np.float64), z['warm'][e].astype(np.float64), z['applied'][e].astype(np.float64), 0.0, float(z['friction'][e]))
+        o.step(z['ctrl'][e].astype(np.float64))
+        nit = int(dbg(st['debug'][e], 'niter')[0])
+        assert nit <= 20, (e, nit, o.solver_niter)
+        qa = np.array(o.qacc)
+        assert np.abs(st['qacc'][e] - qa).max() <= 2e-5 * max(1.0, np.abs(qa).max()), (e, nit)   # spot (condim 6, impratio 100): 8e-6; the others below 1e-6
