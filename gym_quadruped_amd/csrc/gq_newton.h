@@ -667,15 +667,6 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       const float f2 = ell_state(E, y, rD, c2, w2, zone, uhat, TT, y0);
       if (E.code) { f = f2; ci = c2; wact = w2; }
     }
-#ifdef GQ_EMU_TRACE
-    if constexpr (CONE) if (getenv("GQ_EMU_TRACE") && E.code != 0 && (E.code & 15) == 0) printf("   it %d contact r0 %d dim %d zone %d N %.6e T %.6e mu %.4f y0 %.6e f %.4e\n", iter, E.r0, E.code >> 4, zone, (double)(E.mu * y0), (double)sqrtf(TT), (double)E.mu, (double)y0, (double)f);
-#endif
-#ifdef GQ_EMU_TRACE
-    if (getenv("GQ_EMU_TRACE")) {
-      const float cc = wave_sum(lane < nefc ? ci : 0.0f), cg = wave_sum(lane < GQ_NVD ? 0.5f * md * (W.qacc[lane] - W.qacc_smooth[lane]) : 0.0f);
-      if (lane == 0) printf("   it %d cost %.9e (constraint %.9e gauss %.9e) scaled %.6e\n", iter, (double)(cc + cg), (double)cc, (double)cg, (double)(scale * (cc + cg)));
-    }
-#endif
     W.force[lane] = f; /* row forces, read column-wise for J'f below */
     if (lane < GQ_NVD) Mdq[lane] = md;
     wave_barrier();
@@ -953,36 +944,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     if (!done) alpha = lo > 0.0f ? lo : alpha; /* lo == 0: every trial overshot; the last midpoint is the best guess */
     }
     wave_barrier();
-#ifdef GQ_EMU_TRACE
-    if (getenv("GQ_EMU_TRACE")) {
-      auto costat = [&](float al) {
-        float c1, w1; row_law(rtype, y + al * v, rR, rD, rfloss, c1, w1);
-        if constexpr (CONE) { int z2; float t1, t2, t3, c2, w2; ell_state(E, y + al * v, rD, c2, w2, z2, t1, t2, t3); if (E.code) c1 = c2; }
-        const float pp1 = lane < GQ_NVD ? search[lane] * md : 0.0f, pp2 = lane < GQ_NVD ? search[lane] * ms : 0.0f;
-        return wave_sum((lane < nefc ? c1 : 0.0f) + al * pp1 + 0.5f * al * al * pp2);
-      };
-      if (iter == 3) for (int gi = 0; gi <= 16; gi++) {
-        const float al = 0.05f * gi, hh = 2e-4f;
-        float e1, e2; row_dd(rtype, y + al * v, v, rR, rD, rfloss, e1, e2);
-        if constexpr (CONE) if (E.code) ell_dd(E, al, y, v, rD, TT, y0, UV, VV, N1, e1, e2);
-        const float pp1 = lane < GQ_NVD ? search[lane] * md : 0.0f, pp2 = lane < GQ_NVD ? search[lane] * ms : 0.0f;
-        const float an = wave_sum(pp1 + al * pp2 + e1), nu = (costat(al + hh) - costat(al - hh)) / (2 * hh);
-        /* per contact */
-        const float e1c = ell_seg_sum(E, e1) + shfl_idx(e1, E.r0);
-        float c1, w1; row_law(rtype, y + (al + hh) * v, rR, rD, rfloss, c1, w1); float cA = c1;
-        if constexpr (CONE) { int z2; float t1, t2, t3, c2, w2; ell_state(E, y + (al + hh) * v, rD, c2, w2, z2, t1, t2, t3); if (E.code) cA = c2; }
-        row_law(rtype, y + (al - hh) * v, rR, rD, rfloss, c1, w1); float cB = c1; int zz = 0;
-        if constexpr (CONE) { float t1, t2, t3, c2, w2; ell_state(E, y + (al - hh) * v, rD, c2, w2, zz, t1, t2, t3); if (E.code) cB = c2; }
-        const float dnum = (cA - cB) / (2 * hh);
-        const float dnc = ell_seg_sum(E, dnum) + shfl_idx(dnum, E.r0);
-        if (gi == 1 && lane < nefc) printf("        row %d type %d code %d y %.5e v %.5e cA %.6e cB %.6e dnum %.4e e1 %.4e\n", lane, rtype, E.code, (double)y, (double)v, (double)cA, (double)cB, (double)dnum, (double)e1);
-        if (lane == 0) printf("     alpha %.2f analytic %.5e numeric %.5e\n", (double)al, (double)an, (double)nu);
-        if (E.code && (E.code & 15) == 0) printf("        contact r0 %d zone %d analytic %.5e numeric %.5e\n", E.r0, zz, (double)e1c, (double)dnc);
-      }
-      const float h = 1e-3f * fmaxf(alpha, 1e-3f);
-      const float c0 = costat(0.0f), cm = costat(alpha - h), cp = costat(alpha + h), ca = costat(alpha), ch = costat(1e-3f);
-      if (lane == 0) printf("   linesearch check: cost(0) %.7e cost(alpha) %.7e  numeric phi'(alpha) %.4e  numeric phi'(0) %.4e vs g0 %.4e\n", (double)c0, (double)ca, (double)((cp - cm) / (2 * h)), (double)((ch - c0) / 1e-3f), (double)g0);
-    }
+#ifdef GQ_EMU_TRACE /* host emulator only (tests/simt_emu, -DGQ_EMU_TRACE): one line per Newton iteration */
     if (lane == 0 && getenv("GQ_EMU_TRACE")) printf("it %d gnorm %.6e g0 %.6e alpha %.6e first %d scale*pred %.3e  lo %.3e hi %.3e\n", iter, (double)sqrtf(gnorm2), (double)g0, (double)alpha, (int)first_try, (double)(scale * (-0.5f * g0 * alpha)), (double)lo, (double)hi);
 #endif
     /* fp32 resolution of the iterate: a step that moves no component by more than GQ_STEP_FLOOR (relative, 1 for small
