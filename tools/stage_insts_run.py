@@ -7,7 +7,8 @@ ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
 stop = os.environ.pop('GQ_STOP_STAGE', '0')
 from gym_quadruped_amd.quadruped_env import QuadrupedEnv
 n = 4096
-kw = dict(state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', seed=1000)
+kw = dict(state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', seed=1000,
+          self_collision=False if os.environ.get('GQ_STAGE_NOSELF') else None)
 full = QuadrupedEnv('mini_cheetah', **kw)                 # GQ_STOP_STAGE unset: complete steps build the state
 full.reset(random=True)
 g = torch.Generator(device='cuda').manual_seed(0)
