@@ -771,3 +771,47 @@ def test_newton_ends_on_captured_hard_states(robot):
         assert d[e]['niter'][0] <= 20, (e, d[e]['niter'][0], o.solver_niter)
         qa = np.array(o.qacc)
         assert np.abs(d[e]['qacc'] - qa).max() <= 2e-5 * max(1.0, np.abs(qa).max()), e
+
+
+@pytest.mark.parametrize('robot,scene', [('mini_cheetah', 'flat'), ('go2', 'flat'), ('aliengo', 'flat'), ('hyqreal1', 'flat')])
+def test_step_parity_on_benchmark_rollout_states(robot, scene):
+    """One-step parity on the states the BENCHMARK visits (random torques 50 N(0,1), auto-reset, 120 steps in: robots falling,
+    lying, tangled - the distribution the random-state tests do not draw): a sample of envs is stepped by the kernel and by
+    the fp64 oracle from the same (qpos, qvel, friction, ctrl); contact sets must agree (0 mismatches), qacc within the
+    one-step tolerances of the report."""
+    n, nsample = 1024, 160
+    env = _make_env(n, solver='newton', iters=100, tol=1e-8, robot=robot, scene=scene, auto_reset='next_step')
+    env.reset(random=True)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for _ in range(120):
+        env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)
+    pend = env._terminated.cpu().numpy().astype(bool)          # these envs spend the next launch on their auto-reset
+    idx = np.where(~pend)[0][:nsample]
+    qpos, qvel = env._qpos.cpu().numpy().copy(), env._qvel.cpu().numpy().copy()
+    warm, app, fr = env._warm.cpu().numpy().copy(), env._applied.cpu().numpy().copy(), env._friction.cpu().numpy().copy()
+    a = torch.randn(n, 12, generator=g, device='cuda') * 50
+    env.enable_debug(n)
+    env.step(a)
+    torch.cuda.synchronize()
+    ctrl = a.cpu().numpy()
+    d = env.debug_internals(n, ['qacc', 'nefc', 'ncon', 'niter'])
+    qv = env.qvel.cpu().numpy()
+    o = _oracle(env)
+    cone = env.mjModel.cone == 1
+    tally = ParityTally(cone, 3e-7)
+    ea, ev, nit = [], [], []
+    for e in idx:
+        o.set_state(qpos[e], qvel[e].astype(np.float64), warm[e].astype(np.float64), app[e].astype(np.float64), 0.0, float(fr[e]))
+        o.step(ctrl[e].astype(np.float64))
+        if tally.classify(e, o, d[e]['nefc'][0]) != 'ok':
+            continue
+        assert int(d[e]['ncon'][0]) == o.ncon
+        ea.append(np.abs(d[e]['qacc'] - o.qacc).max() / max(1.0, np.abs(o.qacc).max()))
+        ev.append(np.abs(qv[e] - o.qvel).max() / max(1.0, 0.002 * np.abs(o.qacc).max()))
+        nit.append((int(d[e]['niter'][0]), o.solver_niter))
+    p99 = lambda x: float(np.percentile(x, 99))
+    print(f'{robot} {scene}: qacc rel p50 {np.median(ea):.2e} p99 {p99(ea):.2e} max {max(ea):.2e}; qvel p99 {p99(ev):.2e} max {max(ev):.2e}; '
+          f'niter kernel mean {np.mean([x[0] for x in nit]):.2f} oracle {np.mean([x[1] for x in nit]):.2f}')
+    assert p99(ea) < (1e-4 if cone else 2e-5) and max(ea) < 2e-3, (p99(ea), max(ea))
+    assert p99(ev) < (7e-4 if cone else 5e-5) and max(ev) < 5e-3, (p99(ev), max(ev))
+    tally.finish(f'benchmark-state one-step parity {robot} {scene}', min_checked=0.4, max_tie=0.2, max_budget=0.6)

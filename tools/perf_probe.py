@@ -38,8 +38,8 @@ if __name__ == '__main__' and len(sys.argv) == 1:
         run(n, 100, 1e-8)
 
 
-def stage_times(n=4096, iters=100, tol=1e-8, solver='newton', robot='mini_cheetah'):
-    env = QuadrupedEnv(robot, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', solver=solver, solver_iterations=iters, solver_tolerance=tol, seed=1)
+def stage_times(n=4096, iters=100, tol=1e-8, solver='newton', robot='mini_cheetah', scene='flat'):
+    env = QuadrupedEnv(robot, scene=scene, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', solver=solver, solver_iterations=iters, solver_tolerance=tol, seed=1)
     env.reset(random=True)
     g = torch.Generator(device='cuda').manual_seed(0)
     for i in range(300): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)   # the benchmark's steady state
@@ -84,4 +84,4 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'stages':
     robot = [x for x in sys.argv[2:] if not x.isdigit()]
     for n in (int(x) for x in ([x for x in sys.argv[2:] if x.isdigit()] or ['4096'])):
         for sv in ('newton',):
-            print(sv, robot); stage_times(n, solver=sv, robot=(robot or ['mini_cheetah'])[0])
+            print(sv, robot); stage_times(n, solver=sv, robot=(robot or ['mini_cheetah'])[0], scene=(robot + ['flat', 'flat'])[1])
