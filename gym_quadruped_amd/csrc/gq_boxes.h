@@ -129,7 +129,26 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
     const V3 t = matTvec(B.mat, og);
     float best = 1e30f;
     V3 bn = v3(0.0f, 0.0f, 1.0f), bc = v3(0.0f, 0.0f, 0.0f);
-    for (int v0 = 0; v0 < G.cloud_num; v0 += GQ_WAVE) { /* wave-uniform trip count */
+    /* large clouds (hull meshes of several hundred vertices): lane = 64-vertex chunk, its box (geom frame, host table) taken
+     * into the box frame and held against the world box; only chunks that can come within the contact margin are scanned.
+     * A vertex farther than the margin makes no contact and lifts nothing, so the result is the full scan's. */
+    uint64_t chunks = 1;
+    if (G.chunk_adr >= 0) { /* wave-uniform */
+      const int nchunk = (G.cloud_num + GQ_WAVE - 1) / GQ_WAVE;
+      bool keep = false;
+      if (lane < nchunk) {
+        const int ia = G.chunk_adr + 2 * lane;
+        const V3 cc = t + matvec(A, v3(vx[ia], vy[ia], vz[ia])), hh = v3(vx[ia + 1], vy[ia + 1], vz[ia + 1]);
+        const V3 ee = v3(fabsf(A[0]) * hh.x + fabsf(A[1]) * hh.y + fabsf(A[2]) * hh.z, fabsf(A[3]) * hh.x + fabsf(A[4]) * hh.y + fabsf(A[5]) * hh.z,
+                         fabsf(A[6]) * hh.x + fabsf(A[7]) * hh.y + fabsf(A[8]) * hh.z);
+        const V3 gap = v3(fmaxf(0.0f, fabsf(cc.x) - bs.x - ee.x), fmaxf(0.0f, fabsf(cc.y) - bs.y - ee.y), fmaxf(0.0f, fabsf(cc.z) - bs.z - ee.z));
+        keep = sqrtf(dot(gap, gap)) - G.radius < m.boxmix[B.cls][4 + g].margin + 1e-5f;
+      }
+      chunks = ballot(keep);
+    }
+    while (chunks) { /* wave-uniform */
+      const int v0 = GQ_WAVE * ffs64(chunks);
+      chunks &= chunks - 1;
       const int i = G.cloud_adr + v0 + lane;
       const bool in = v0 + lane < G.cloud_num;
       const int ii = in ? i : G.cloud_adr;

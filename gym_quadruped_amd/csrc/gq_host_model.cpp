@@ -196,6 +196,21 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
         if (c > hi[i]) hi[i] = c;
       }
     for (int i = 0; i < 3; i++) { G.aabb_c[i] = (float)(0.5 * (lo[i] + hi[i])); G.aabb_h[i] = (float)(0.5 * (hi[i] - lo[i]) * 1.0001 + 1e-7); }
+    G.chunk_adr = -1;
+    if (G.cloud_num > 64) { /* boxes of the 64-vertex chunks (mjcf.sort_cloud_vertices made them compact), appended to the vertex arrays */
+      G.chunk_adr = (int)vx->size();
+      for (int v0 = 0; v0 < G.cloud_num; v0 += 64) {
+        double clo[3] = {1e30, 1e30, 1e30}, chi[3] = {-1e30, -1e30, -1e30};
+        for (int v = v0; v < G.cloud_num && v < v0 + 64; v++)
+          for (int i = 0; i < 3; i++) {
+            double c = d->vert_pos[3 * (G.cloud_adr + v) + i];
+            if (c < clo[i]) clo[i] = c;
+            if (c > chi[i]) chi[i] = c;
+          }
+        vx->push_back((float)(0.5 * (clo[0] + chi[0]))); vy->push_back((float)(0.5 * (clo[1] + chi[1]))); vz->push_back((float)(0.5 * (clo[2] + chi[2])));
+        vx->push_back((float)(0.5 * (chi[0] - clo[0]) * 1.0001 + 1e-6)); vy->push_back((float)(0.5 * (chi[1] - clo[1]) * 1.0001 + 1e-6)); vz->push_back((float)(0.5 * (chi[2] - clo[2]) * 1.0001 + 1e-6));
+      }
+    }
     Mixed mx = mix_with_floor(d, g);
     if (mx.dim != 1 && mx.dim != 3 && !(d->cone == 1 && mx.dim == 6)) FAIL("contact dimension %d of geom %d not supported (1, 3; 6 with elliptic cones)", mx.dim, g);
     G.dim = mx.dim; G.fric_rule = mx.rule; G.margin = (float)mx.margin; G.includemargin = (float)mx.includemargin;

@@ -24,6 +24,8 @@
 struct GqDevGeom {          /* a robot collision geom that is not a foot sphere */
   int32_t body;             /* 0..12 */
   int32_t cloud_adr, cloud_num;
+  int32_t chunk_adr;        /* clouds of more than one 64-vertex chunk: index (into the vertex arrays) of the chunk boxes -
+                             * entry 2k = centre, 2k + 1 = half extents of vertices [64k, 64k + 64) in the geom frame; else -1 */
   float radius;             /* inflation (capsule) */
   float pos[3];             /* geom frame in body frame */
   float mat[9];

@@ -726,9 +726,30 @@ def set_const(md: ModelDesc):
     md.body_invweight0 = biw
 
 
+CLOUD_CHUNK = 64   # = one wavefront: the kernels scan a cloud in chunks of this many consecutive vertices
+
+
+def sort_cloud_vertices(md: 'ModelDesc') -> 'ModelDesc':
+    """Order the vertices of every hull cloud larger than one chunk along the cloud's principal axis (stable, idempotent), so
+    that a chunk of CLOUD_CHUNK consecutive vertices is a compact slice of the hull: the kernels bound each chunk by its box
+    and skip the chunks that cannot reach the world geom under test (csrc/gq_boxes.h).  The SET of vertices - all that the
+    deepest-vertex rule depends on - is unchanged; kernel and oracle read the same (sorted) table."""
+    vp = np.array(md.vert_pos, dtype=np.float64)
+    for c in range(len(md.cloud_vertnum)):
+        a, n = int(md.cloud_vertadr[c]), int(md.cloud_vertnum[c])
+        if n <= CLOUD_CHUNK:
+            continue
+        v = vp[a:a + n]
+        _, _, vt = np.linalg.svd(v - v.mean(0), full_matrices=False)
+        ax = vt[0] * (1.0 if vt[0][np.argmax(np.abs(vt[0]))] > 0 else -1.0)   # sign fixed: deterministic
+        vp[a:a + n] = v[np.argsort(np.round(v @ ax, 9), kind='stable')]
+    md.vert_pos = vp
+    return md
+
+
 def compile_mjcf(xml_path, mesh_hulls=True) -> ModelDesc:
     """Compile an MJCF file (robot alone, or a scene that <include>s the robot) into a :class:`ModelDesc`."""
-    return _Compiler(Path(xml_path), mesh_hulls=mesh_hulls).compile()
+    return sort_cloud_vertices(_Compiler(Path(xml_path), mesh_hulls=mesh_hulls).compile())
 
 
 _MODEL_DIR = Path(__file__).parent / 'model_data'
@@ -739,4 +760,4 @@ def load_compiled(robot_file_stem: str) -> ModelDesc:
     p = _MODEL_DIR / f'{robot_file_stem}.json'
     if not p.exists():
         raise FileNotFoundError(f'no compiled model table {p}; run tools/compile_models.py or pass mjcf_path=')
-    return ModelDesc.from_json(p.read_text())
+    return sort_cloud_vertices(ModelDesc.from_json(p.read_text()))
