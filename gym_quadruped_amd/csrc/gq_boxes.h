@@ -50,21 +50,47 @@ __device__ __forceinline__ void make_frame(V3 n, V3& t1, V3& t2) {
   t2 = cross(n, t1);
 }
 
-/* bit mask (two words) of the boxes whose bounding sphere meets the robot's; base = (0, 0, basez) in kernel coordinates */
-__device__ inline void box_candidates(const WaveMem& W, const GQ_MODEL GqDevModel& m, double bx, double by, float zoff, uint64_t cand[2]) {
+/* bit mask (two words) of the boxes that may touch a collision item: lane = box; first the robot's bounding sphere against
+ * the box (cheap, most boxes of a scene fail it), then - for the lanes that passed - the bounding sphere of every item (feet,
+ * link geoms; (cg, rg) = item_sphere of lane = geom, broadcast in a wave-uniform loop) against the box.  The per-box work
+ * of the callers is a serial, latency-bound loop (model loads, scans, barriers): a dense box scene puts 10-18 boxes inside
+ * the robot's sphere but only 2-5 near an item.  base = (0, 0, basez) in kernel coordinates; zoff lifts the robot. */
+__device__ inline void box_candidates(const WaveMem& W, const GQ_MODEL GqDevModel& m, double bx, double by, float zoff, uint64_t cand[2], V3 cg, float rg) {
   const int lane = lane_id();
-#pragma unroll
+  const int nlg = m.nlg;
+#pragma unroll 1
   for (int half = 0; half < 2; half++) {
     const int b = half * GQ_WAVE + lane;
     bool near = false;
+    V3 bp = v3(0.0f, 0.0f, 0.0f), bs = v3(1.0f, 1.0f, 1.0f);
+    float Bm[9] = {1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
     if (b < m.nbox) {
       const GQ_MODEL GqDevBox& B = m.box[b];
       /* robot bounding sphere against the box itself (not its bounding sphere: the boxes are flat slabs) */
-      const V3 cb = v3((float)(bx - (double)B.pos[0]), (float)(by - (double)B.pos[1]), W.basez + zoff - B.pos[2]);
+      bp = v3((float)((double)B.pos[0] - bx), (float)((double)B.pos[1] - by), B.pos[2] - zoff);
+      bs = ld3(B.size);
+#pragma unroll
+      for (int i = 0; i < 9; i++) Bm[i] = B.mat[i];
       V3 nn;
-      near = sphere_box(matTvec(B.mat, cb), ld3(B.size), m.robot_radius, nn) < 0.05f;
+      near = sphere_box(matTvec(Bm, v3(0.0f, 0.0f, W.basez) - bp), bs, m.robot_radius, nn) < 0.05f;
     }
-    cand[half] = ballot(near);
+    uint64_t coarse = ballot(near);
+    if (coarse != 0) { /* wave-uniform */
+      bool hit = false;
+      for (int k = 0; k < 4; k++) { /* feet */
+        V3 nn;
+        hit = hit || sphere_box(matTvec(Bm, ld3(W.foot_world[k]) - bp), bs, m.foot_radius[k], nn) < 0.05f;
+      }
+      for (int k = 0; k < nlg; k++) { /* link geoms */
+        const float rk = bcast(rg, k);
+        if (rk < 0.0f) continue; /* wave-uniform: no geom / not a calf geom in the lift loop */
+        const V3 ck = v3(bcast(cg.x, k), bcast(cg.y, k), bcast(cg.z, k));
+        V3 nn;
+        hit = hit || sphere_box(matTvec(Bm, ck - bp), bs, rk, nn) < 0.05f;
+      }
+      coarse = ballot(near && hit);
+    }
+    cand[half] = coarse;
   }
 }
 
@@ -630,9 +656,9 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
   uint64_t cand[2];
-  box_candidates(W, m, bx, by, 0.0f, cand);
   V3 cg; float rg;
   item_sphere(W, m, false, cg, rg);
+  box_candidates(W, m, bx, by, 0.0f, cand, cg, rg);
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
     uint64_t todo = cand[half];

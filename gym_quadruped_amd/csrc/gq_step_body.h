@@ -1245,7 +1245,7 @@ __device__ inline int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 
         float pen = (dist + dz < margin) ? fabsf(dist + dz) : 0.0f;
         float clear = 0.0f; /* lift that takes the touching item above the box altogether */
         uint64_t cand[2];
-        box_candidates(W, m, spawn_x, spawn_y, dz, cand); /* around the lifted base */
+        box_candidates(W, m, spawn_x, spawn_y, dz, cand, calf_c, calf_r); /* around the lifted base; calf items only */
         for (int half = 0; half < 2; half++) {
           uint64_t todo = cand[half];
           while (todo) { /* wave-uniform */
@@ -1284,6 +1284,9 @@ __device__ inline int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 
         pen = wave_max(pen);
         failed = pen > 0.0f;
         if (!failed || it == 100) break;
+#ifdef GQ_EMU_TRACE
+        if (lane == 0 && getenv("GQ_EMU_TRACE")) printf("lift it %d dz %.4f pen %.5f cand %d\n", it, (double)dz, (double)pen, popc64(cand[0]) + popc64(cand[1]));
+#endif
         dz += it < GQ_LIFT_RULE_ITERS ? 1.1f * pen : fmaxf(1.1f * pen, wave_max(clear));
       }
     }
