@@ -335,6 +335,59 @@ __device__ inline bool hfield_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m
   const uint64_t feet = ballot(foot_near);
   dist = 1e30f; nrm = v3(0.0f, 0.0f, 1.0f); pt = v3(0.0f, 0.0f, 0.0f);
   if ((todo | feet) == 0) return false;
+  if (m.self_cut == 10) return false; /* profiling aid (GQ_SELF_CUT): 10 stop after the bounding tests, 11 no flattened pass, 12 no serial scans, 13 no foot narrow phase */
+  if (m.self_cut == 11) todo &= ~m.flat_mask;
+  if (m.self_cut == 12) todo &= m.flat_mask;
+  /* small clouds (boxes, capsules: a handful of vertices each) are evaluated FLATTENED: lane = (geom, vertex) slot of the host
+   * table, every needed geom of a pass at once - one memory latency per pass for vertex, cell and elevations instead of one
+   * per geom, and no 64-lane scan of 8 vertices; then lane = geom picks the deepest of its slots (first in vertex order, as
+   * the serial scan does) out of LDS and fetches that slot's normal and point with ds_bpermute */
+  if (todo & m.flat_mask) { /* wave-uniform */
+    float* S = W.force; /* 64 floats of scratch: the solver's row forces do not exist yet */
+    const uint64_t flat = todo & m.flat_mask;
+    todo &= ~m.flat_mask;
+    for (int p0 = 0; p0 < m.flat_n; p0 += GQ_WAVE) { /* wave-uniform */
+      const int slot = p0 + lane;
+      const int g = slot < m.flat_n ? (int)m.flat_geom[slot] : 255;
+      const bool live = g != 255 && ((flat >> (g & 63)) & 1ull);
+      float dv = 1e30f;
+      V3 bn = v3(0.0f, 0.0f, 1.0f), bc = v3(0.0f, 0.0f, 0.0f);
+      if (live) {
+        const GQ_MODEL GqDevGeom& G = m.lg[g];
+        const int iv = m.flat_vert[slot];
+        const float* Rb = W.xmat[G.body];
+        const V3 u = ld3(G.pos) + matvec(G.mat, v3(vx[iv], vy[iv], vz[iv]));
+        const V3 c = ld3(W.xpos[G.body]) + matvec(Rb, u) - hp;
+        HfTri t;
+        if (hf_triangle_under(m, H, ref, c.x, c.y, t)) { dv = dot(c - t.a, t.n) - G.radius; bn = t.n; bc = c; }
+      }
+      S[lane] = dv;
+      wave_barrier();
+      float best = 1e30f;
+      int arg = lane;
+      bool mine = false;
+      if (lane < nlg) {
+        const GQ_MODEL GqDevGeom& G = m.lg[lane];
+        mine = ((flat >> lane) & 1ull) && G.flat_adr >= p0 && G.flat_adr < p0 + GQ_WAVE;
+        if (mine) {
+          const int a0 = G.flat_adr - p0;
+          for (int k = 0; k < G.cloud_num; k++) {
+            const float dk = S[a0 + k];
+            if (dk < best) { best = dk; arg = a0 + k; }
+          }
+        }
+      }
+      const V3 n_w = v3(shfl_idx(bn.x, arg), shfl_idx(bn.y, arg), shfl_idx(bn.z, arg));
+      const V3 c_w = v3(shfl_idx(bc.x, arg), shfl_idx(bc.y, arg), shfl_idx(bc.z, arg));
+      if (mine) {
+        const GQ_MODEL GqDevGeom& G = m.lg[lane];
+        W.u2.c.lg_dist[lane] = best;
+        st3(W.u2.c.lg_pt[lane], hp + c_w - (G.radius + 0.5f * best) * n_w);
+        st3(GQ_BX_LGNRM(W) + 3 * lane, n_w);
+      }
+      wave_barrier(); /* S is rewritten by the next pass */
+    }
+  }
   while (todo) { /* wave-uniform */
     const int g = ffs64(todo);
     todo &= todo - 1;
@@ -374,7 +427,7 @@ __device__ inline bool hfield_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m
   if (lane < 4 + nlg) {
     const int code = m.con_order[lane];
     if (code < 4) {
-      if ((feet >> code) & 1) {
+      if (((feet >> code) & 1) && m.self_cut != 13) {
         V3 n; float d;
         if (sphere_hfield(m, H, ref, ld3(W.foot_world[code]) - hp, m.foot_radius[code], fmaxf(m.boxmix[cls][code].margin, 0.0f) + 1e-4f, d, n)) {
           dist = d; nrm = n; pt = ld3(W.foot_world[code]) - (m.foot_radius[code] + 0.5f * d) * n;

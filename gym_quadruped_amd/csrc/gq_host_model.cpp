@@ -196,7 +196,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
         if (c > hi[i]) hi[i] = c;
       }
     for (int i = 0; i < 3; i++) { G.aabb_c[i] = (float)(0.5 * (lo[i] + hi[i])); G.aabb_h[i] = (float)(0.5 * (hi[i] - lo[i]) * 1.0001 + 1e-7); }
-    G.chunk_adr = -1;
+    G.chunk_adr = -1; G.flat_adr = -1;
     if (G.cloud_num > 64) { /* boxes of the 64-vertex chunks (mjcf.sort_cloud_vertices made them compact), appended to the vertex arrays */
       G.chunk_adr = (int)vx->size();
       for (int v0 = 0; v0 < G.cloud_num; v0 += 64) {
@@ -217,6 +217,21 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     for (int i = 0; i < 3; i++) G.friction[i] = (float)d->geom_friction[3 * g + i];
     for (int i = 0; i < 2; i++) G.solref[i] = (float)mx.solref[i];
     for (int i = 0; i < 5; i++) G.solimp[i] = (float)mx.solimp[i];
+  }
+  { /* flattened table of the small clouds */
+    int slot = 0;
+    M.flat_mask = 0;
+    for (int i = 0; i < GQ_MAXFLAT; i++) { M.flat_geom[i] = 255; M.flat_vert[i] = 0; }
+    for (int lg = 0; lg < M.nlg; lg++) {
+      GqDevGeom& G = M.lg[lg];
+      if (G.cloud_num > GQ_FLAT_MAXV || G.cloud_adr + G.cloud_num > 65535) continue;
+      if (slot % 64 + G.cloud_num > 64) slot = (slot / 64 + 1) * 64;
+      if (slot + G.cloud_num > GQ_MAXFLAT) break;
+      G.flat_adr = slot;
+      M.flat_mask |= 1ull << lg;
+      for (int v = 0; v < G.cloud_num; v++) { M.flat_geom[slot] = (uint8_t)lg; M.flat_vert[slot] = (uint16_t)(G.cloud_adr + v); slot++; }
+    }
+    M.flat_n = slot;
   }
   /* static world boxes: geometry per box, contact parameters per class of identical boxes x collision item */
   if (d->nbox < 0 || d->nbox > GQ_MAXBOX) FAIL("scene has %d world boxes, at most %d are supported", d->nbox, GQ_MAXBOX);

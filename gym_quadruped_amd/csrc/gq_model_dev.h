@@ -11,6 +11,8 @@
 #define GQ_NB 13        /* moving bodies: 0 = base, 1 + 3*leg + link */
 #define GQ_NVD 18       /* dofs: 0..5 base, 6 + 3*leg + link */
 #define GQ_NJ 12        /* hinge joints */
+#define GQ_FLAT_MAXV 16 /* a cloud of at most this many vertices goes into the flattened small-cloud table */
+#define GQ_MAXFLAT 192  /* slots of that table: three passes of one wavefront */
 #define GQ_MAXLG 38     /* max link (non-foot) collision geoms */
 #define GQ_MAXCON 12    /* max simultaneous contacts fed to the solver */
 #define GQ_MAXBOX 128    /* static world boxes of the scene (random_boxes: 100, stairs: 50) */
@@ -24,6 +26,7 @@
 struct GqDevGeom {          /* a robot collision geom that is not a foot sphere */
   int32_t body;             /* 0..12 */
   int32_t cloud_adr, cloud_num;
+  int32_t flat_adr;         /* small clouds (<= GQ_FLAT_MAXV vertices): first slot in GqDevModel::flat_*, else -1 */
   int32_t chunk_adr;        /* clouds of more than one 64-vertex chunk: index (into the vertex arrays) of the chunk boxes -
                              * entry 2k = centre, 2k + 1 = half extents of vertices [64k, 64k + 64) in the geom frame; else -1 */
   float radius;             /* inflation (capsule) */
@@ -105,6 +108,13 @@ struct GqDevModel {
   float hf_pos[3], hf_sx, hf_sy, hf_dx, hf_dy, hf_inv_dx, hf_inv_dy;
   float hf_maxslope, hf_zmax;       /* largest |dh| / distance along any cell edge or diagonal; highest elevation */
   const float* hf_data;             /* [nrow][ncol], device memory owned by the GqModel */
+  /* small vertex clouds (boxes, capsules, cylinders: <= GQ_FLAT_MAXV vertices) flattened onto lanes: slot -> (link geom,
+   * vertex); a geom's slots are consecutive and never straddle a multiple of 64 (padding slots have geom 255), so one pass
+   * of the wavefront evaluates the vertices of up to 64 / cloud size geoms at once (hfield_item_scan) */
+  uint64_t flat_mask;                      /* link geoms that own slots */
+  int32_t flat_n;                          /* slots in use (padding included) */
+  uint16_t flat_vert[GQ_MAXFLAT];          /* index into the vertex arrays */
+  uint8_t flat_geom[GQ_MAXFLAT];
   /* env */
   double terrain_limits[4];
   float key_qpos[19];            /* keyframe 0 */
