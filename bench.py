@@ -188,7 +188,8 @@ def main():
     ap.add_argument('--no-self-collision', action='store_true', help='switch robot self-collision off (MuJoCo default and default here: on)')
     ap.add_argument('--imu', action='store_true', help='BASELINE config 5: IMU plug-in (6 observables; robots that expose accelerometer + gyro sensors)')
     ap.add_argument('--heightmap', action='store_true', help='BASELINE config 5: a 5x5 HeightMap @ 0.1 m updated every step')
-    args = ap.parse_args()
+    ap.add_argument('--dist-backend', default='nccl', help=argparse.SUPPRESS)   # test hook: 'gloo' together with GQ_BENCH_SHARE_DEVICE=1 runs the
+    args = ap.parse_args()                                                       # N-rank protocol with every rank on GPU 0 (one-GPU boxes)
 
     from gym_quadruped_amd.sharding import aggregate_throughput, shard_plan
     rank = int(os.environ.get('RANK', 0))
@@ -207,8 +208,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if os.environ.get('GQ_BENCH_SHARE_DEVICE') == '1':
+            local_rank = 0   # protocol test: all ranks on one GPU (the throughput it prints is NOT a scaling number)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     device = torch.device(f'cuda:{local_rank}')
     torch.cuda.set_device(device)
 
@@ -274,7 +280,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if args.dist_backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kernel_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in ev if p is not None]))
