@@ -42,7 +42,7 @@ def main(solver='1'):
                 continue
             m = re.match(r'^(_Z\w+):', line)
             if m:
-                infn = m.group(1).startswith(f'_ZN2gq11step_kernelILi{solver}ELi0ELb0ELb0EEE')
+                infn = m.group(1).startswith(f'_ZN2gq11step_kernelILi{solver}ELi0ELb0ELb0ELb1EEE')
                 continue
             m = re.match(r'\s*\.loc\s+(\d+)\s+(\d+)', line)
             if m:
