@@ -59,9 +59,9 @@ def pmc_traffic():
 def kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
-    for f in sorted((ROOT / 'gym_quadruped_amd' / 'csrc').glob('*')):
-        if f.suffix in ('.h', '.hip', '.cpp') or f.name == 'Makefile':
-            h.update(f.read_bytes())
+    # the DEVICE side of the step kernel (and the flags it is built with): the host API / model lowering do not move its traffic
+    for name in ('Makefile', 'gq_boxes.h', 'gq_device.h', 'gq_kernels.hip', 'gq_model_dev.h', 'gq_newton.h', 'gq_step_body.h', 'gq_step_kernel.h'):
+        h.update((ROOT / 'gym_quadruped_amd' / 'csrc' / name).read_bytes())
     return h.hexdigest()[:16]
 
 

@@ -449,6 +449,18 @@ int gq_debug_device_buffer(GqBatch* b, float** dev, int32_t* n_envs, int32_t* st
   return GQ_OK;
 }
 
+int gq_full_mass(GqBatch* b, int n_envs, float* M, void* hip_stream) {
+  if (!b || !M || n_envs <= 0) { SET_ERR("gq_full_mass: null / empty argument"); return GQ_EINVAL; }
+  if (!b->debug || n_envs > b->host.debug_envs) {
+    SET_ERR("gq_full_mass: the inspection record covers %d envs, %d requested (gq_debug_enable first, then gq_step / gq_forward)", b->host.debug_envs, n_envs);
+    return GQ_EINVAL;
+  }
+  DeviceGuard guard(b->model->device);
+  HIP_TRY(hipMemcpy2DAsync(M, 324 * sizeof(float), b->debug + GQ_DBG_M, GQ_DBG_SIZE * sizeof(float), 324 * sizeof(float), (size_t)n_envs,
+                           hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+  return GQ_OK;
+}
+
 int gq_debug_get(GqBatch* b, int env, const char* name, double* out, int max_n) {
   if (!b || !name || !out || env < 0 || env >= b->host.debug_envs || !b->debug) { SET_ERR("gq_debug_get: bad argument / debug not enabled"); return GQ_EINVAL; }
   for (const auto& f : kDbg)

@@ -373,6 +373,12 @@ int gq_ray(GqBatch* b, const double* origin, const float* dir, int n_rays, float
  * the instrumented kernel variant: ~20 % slower than gq_step's production kernel and one 8.4 KB record per env. */
 int gq_forward(GqBatch* b, int stage, const float* ctrl, GqState st, GqObsOut out, void* hip_stream);
 
+/* mujoco.mj_fullM(m, M, d.qM) (quadruped_env.py:557, :884: legs_mass_matrix, get_base_inertia): the dense joint-space
+ * inertia of the LAST forward pass (gq_step or gq_forward) of the first n_envs envs, M: device [n_envs][18][18] f32.
+ * Like qM in mjData it is a by-product of that pass: it comes out of the inspection record, so gq_debug_enable(b, >= n_envs)
+ * must have been called before the pass.  Asynchronous on hip_stream (a strided device-to-device copy, no kernel). */
+int gq_full_mass(GqBatch* b, int n_envs, float* M, void* hip_stream);
+
 /* debug / inspection: last forward pass internals of env `env` copied to host (doubles).
  * name in {"M","qfrc_bias","qfrc_smooth","qacc_smooth","qfrc_constraint","efc_J","efc_aref","efc_R","efc_b",
  * "efc_force","efc_type","contact_dist","contact_geom","xpos","xmat","geom_xpos"}; returns count written. */

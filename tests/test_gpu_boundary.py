@@ -160,3 +160,33 @@ def test_gq_forward_is_mj_forward_without_side_effects():
     _lib.check(env._L.gq_step(env._hbatch, None, None, env._st, env._out, None, None, None, stream), 'gq_step with NULL ctrl')
     torch.cuda.synchronize()
     assert torch.isfinite(env.qpos).all()
+
+
+def test_gq_full_mass_is_mj_fullM_of_the_last_forward_pass():
+    """gq_full_mass (mj_fullM(model, M, data.qM), quadruped_env.py:557 / :884): the dense joint-space inertia of the last
+    forward pass against the oracle's M; symmetric, positive definite; refused when the inspection record is not enabled."""
+    import ctypes as C
+    from gym_quadruped_amd import _lib
+    from oracle.oracle import Oracle
+    n = 48
+    env = _env('aliengo', n)
+    rng = np.random.default_rng(11)
+    qpos, qvel = random_states(env.mjModel, n, rng, z_range=(0.3, 0.6))
+    env._qpos.copy_(torch.as_tensor(qpos)); env._qvel.copy_(torch.as_tensor(qvel.astype(np.float32)))
+    L = _lib.lib()
+    M = torch.zeros(n, 18, 18, device='cuda')
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.gq_full_mass(env._hbatch, n, M.data_ptr(), stream) != 0          # no inspection record yet
+    env.enable_debug(n)
+    env.mj_forward(torch.zeros(n, 12, device='cuda'))
+    _lib.check(L.gq_full_mass(env._hbatch, n, M.data_ptr(), stream), 'gq_full_mass')
+    torch.cuda.synchronize()
+    Mg = M.cpu().numpy()
+    o = Oracle(marshalled('aliengo', solver=1))
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e], np.zeros(18), np.zeros(18), 0.0, -1.0)
+        o.forward(np.zeros(12), stage=1)
+        Mo = np.asarray(o.M).reshape(18, 18)
+        assert np.abs(Mg[e] - Mo).max() < 1e-4 * np.abs(Mo).max(), e
+        assert np.abs(Mg[e] - Mg[e].T).max() < 1e-6 * np.abs(Mo).max() and np.linalg.eigvalsh(Mg[e].astype(np.float64)).min() > 0
+    assert L.gq_full_mass(env._hbatch, n + 1, M.data_ptr(), stream) != 0      # more envs than the record covers
