@@ -279,7 +279,24 @@ __device__ __forceinline__ void newton_dense_step(WaveMem& W, int r0, int r1, co
       row[j] = (lo < 6 || same) ? v : 0.0f;
     }
   }
-  for (int r = r0; r < r1; r++) { /* wave-uniform: cross-leg entries */
+  /* which rows of [r0, r1) really couple two legs with a non-zero weight?  lane = row looks at its own J row (the range also
+   * holds same-leg / leg-trunk contacts, inactive rows and - elliptic cones - the virtual rows of every middle-zone contact:
+   * 20-30 rows, of which 3-8 matter) */
+  uint64_t xm = (r1 >= 64 ? ~0ull : ((1ull << r1) - 1ull)) & ~((1ull << r0) - 1ull); /* a short range is walked as it is */
+  if (r1 - r0 > 4) {
+    bool cross = false;
+    if (lane >= r0 && lane < r1 && W.force[lane] != 0.0f) {
+      const float* J = W.u.B[opaque_lane(lane)];
+      int nl = 0;
+#pragma unroll
+      for (int l = 0; l < 4; l++) nl += (J[6 + 3 * l] != 0.0f || J[7 + 3 * l] != 0.0f || J[8 + 3 * l] != 0.0f) ? 1 : 0;
+      cross = nl >= 2;
+    }
+    xm = ballot(cross);
+  }
+  while (xm) { /* wave-uniform: cross-leg entries */
+    const int r = ffs64(xm);
+    xm &= xm - 1;
     float bj[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) bj[j] = W.u.B[r][6 + j];
