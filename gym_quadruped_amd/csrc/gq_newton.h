@@ -308,9 +308,15 @@ __device__ __forceinline__ void newton_dense_step(WaveMem& W, int r0, int r1, co
   for (int k = 0; k < GQ_NVD - 1; k++) {
     const float inv = fast_rcp(bcast(row[k], k));
     const float f = lane > k ? row[k] * inv : 0.0f;
-    b -= f * bcast(b, k);
+    /* the pivot row is broadcast first (v_readlane -> SGPR), the updates follow: interleaved, every FMA waited one s_nop for
+     * the SGPR its readlane had just written */
+    float pv[GQ_NVD];
+    const float pb = bcast(b, k);
 #pragma unroll
-    for (int j = k + 1; j < GQ_NVD; j++) row[j] -= f * bcast(row[j], k);
+    for (int j = k + 1; j < GQ_NVD; j++) pv[j] = bcast(row[j], k);
+    b -= f * pb;
+#pragma unroll
+    for (int j = k + 1; j < GQ_NVD; j++) row[j] -= f * pv[j];
   }
   float x = 0.0f;
 #pragma unroll
