@@ -212,3 +212,33 @@ def test_dataset_hparams_encoding_follows_the_reference_conventions():
     json.dumps(enc)   # everything is JSON-serialisable
     with pytest.raises(TypeError):
         _hparams_to_jsonable({'bad': object()})
+
+
+def test_cloud_vertices_are_sorted_into_compact_chunks():
+    """mjcf.sort_cloud_vertices: the hull clouds the kernels scan in 64-vertex chunks are ordered along their principal axis -
+    same vertex SET (the deepest-vertex rule does not depend on the order), idempotent, and the chunks really are compact
+    slices (what makes the per-chunk boxes of csrc/gq_host_model.cpp worth testing against a world box)."""
+    import json
+    from pathlib import Path
+    from gym_quadruped_amd.mjcf import CLOUD_CHUNK, ModelDesc, load_compiled, sort_cloud_vertices
+    for stem in ('mini_cheetah', 'hyqreal1'):
+        raw = ModelDesc.from_json((Path(__file__).parents[1] / 'gym_quadruped_amd' / 'model_data' / f'{stem}.json').read_text())
+        md = load_compiled(stem)
+        before = np.array(md.vert_pos).copy()
+        sort_cloud_vertices(md)
+        assert np.array_equal(before, md.vert_pos)                      # idempotent
+        big = 0
+        for c in range(len(md.cloud_vertnum)):
+            a, n = int(md.cloud_vertadr[c]), int(md.cloud_vertnum[c])
+            v0, v1 = np.asarray(raw.vert_pos)[a:a + n], np.asarray(md.vert_pos)[a:a + n]
+            assert sorted(map(tuple, np.round(v0, 12))) == sorted(map(tuple, np.round(v1, 12)))   # same set
+            if n <= CLOUD_CHUNK:
+                assert np.array_equal(v0, v1)
+                continue
+            big += 1
+            ext = np.ptp(v1, axis=0).max()
+            ax = np.linalg.svd(v1 - v1.mean(0))[2][0]
+            chunk_ext = np.median([np.ptp(v1[k:k + CLOUD_CHUNK] @ ax) for k in range(0, n, CLOUD_CHUNK)])
+            assert chunk_ext < 0.35 * ext, (stem, c, chunk_ext, ext)     # a typical chunk spans a fraction of the hull's long axis
+                                                                         # (hull vertices crowd at the ends: the chunk across the sparse middle is long)
+        assert big >= 3
