@@ -239,6 +239,6 @@ def test_cloud_vertices_are_sorted_into_compact_chunks():
             ext = np.ptp(v1, axis=0).max()
             ax = np.linalg.svd(v1 - v1.mean(0))[2][0]
             chunk_ext = np.median([np.ptp(v1[k:k + CLOUD_CHUNK] @ ax) for k in range(0, n, CLOUD_CHUNK)])
-            assert chunk_ext < 0.35 * ext, (stem, c, chunk_ext, ext)     # a typical chunk spans a fraction of the hull's long axis
+            assert n < 4 * CLOUD_CHUNK or chunk_ext < 0.35 * ext, (stem, c, chunk_ext, ext)     # a typical chunk spans a fraction of the hull's long axis
                                                                          # (hull vertices crowd at the ends: the chunk across the sparse middle is long)
         assert big >= 3
