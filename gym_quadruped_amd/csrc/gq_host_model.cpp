@@ -135,6 +135,26 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       M.fl_row_of_dof[i] = M.nfl; M.fl_dof[M.nfl++] = i;
     }
   }
+  for (int pass = 0; pass < 2; pass++) /* entries of the tree-sparse Newton Hessian, two per lane (gq_newton.h) */
+    for (int lane = 0; lane < 64; lane++) {
+      const int e = pass * 64 + lane;
+      int da = 0, db = 0, slot = 0;
+      if (e < 96) {
+        const int leg = e / 24, q = e % 24;
+        const int dep = q < 7 ? 0 : (q < 15 ? 1 : 2), col = q - (dep == 0 ? 0 : (dep == 1 ? 7 : 15));
+        const int j = 3 * leg + dep;
+        da = 6 + j; db = col < 6 ? col : 6 + 3 * leg + (col - 6);
+        slot = j * 9 + col;
+      } else {
+        const int q = e - 96;
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= q) i++;
+        da = i; db = q - i * (i + 1) / 2;
+        slot = 108 + 6 * da + db;
+      }
+      const int frp1 = (e < 117 && da == db) ? M.fl_row_of_dof[da] + 1 : 0;
+      M.newton_hent[pass][lane] = e < 117 ? (da | (db << 8) | (slot << 16) | (frp1 << 24)) : -1;
+    }
   for (int u = 0; u < d->nu; u++) {
     int j = d->actuator_trnid[u] - 1;
     if (j < 0 || j >= GQ_NJ) FAIL("actuator %d drives joint %d (must be a leg hinge)", u, d->actuator_trnid[u]);

@@ -69,6 +69,10 @@ struct GqDevModel {
   float dof_solref[GQ_NVD][2], dof_solimp[GQ_NVD][5];
   int32_t fl_dof[GQ_NVD];        /* dofs that own a friction-loss row, compacted; nfl of them */
   int32_t fl_row_of_dof[GQ_NVD]; /* inverse map: friction-loss row of dof d, -1 if it has none */
+  /* Newton: the two entries of the tree-sparse Hessian lane l assembles (pass 0: entry l, pass 1: entry 64 + l), packed
+   * da | db << 8 | slot << 16 | (1 + friction-loss row of a diagonal entry's dof) << 24; -1: none.  Leg rows: hip 7, thigh 8,
+   * calf 9 entries -> 24 per leg (slots of Hc); entries 96..116: lower triangle of the base block (slot 108 + 6 da + db) */
+  int32_t newton_hent[2][64];
   /* friction-loss rows are state independent up to their velocity term (pos = margin = 0): R and the damping gain B of
    * aref = -B vel are folded on the host (mj_makeImpedance at x = 0) - one 16-byte load per row instead of a three-level
    * chain fl_dof -> dof -> solref / solimp */

@@ -628,31 +628,11 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
   float f = 0.0f;
   int iter = 0, exit_code = 0; /* why the loop ended (debug record, timer slot 23) */
   const int fl_row = lane < GQ_NVD ? m.fl_row_of_dof[lane] : -1;
-  /* the two Hessian entries this lane assembles every iteration (pass 0: entry lane, pass 1: entry 64 + lane), packed
-   * da | db << 8 | slot << 16; -1: none.  Leg rows: hip 7, thigh 8, calf 9 entries -> 24 per leg (slots of Hc);
-   * entries 96..116: lower triangle of the base block (slot 108 + 6 da + db). */
+  /* the two Hessian entries this lane assembles every iteration: a host table (GqDevModel::newton_hent) - decoding the entry
+   * index per lane cost ~80 instructions per step */
   int hent[2];
 #pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int e = pass * 64 + lane;
-    int da = 0, db = 0, slot = 0;
-    if (e < 96) {
-      const int leg = e / 24, q = e % 24;
-      const int dep = q < 7 ? 0 : (q < 15 ? 1 : 2), col = q - (dep == 0 ? 0 : (dep == 1 ? 7 : 15));
-      const int j = 3 * leg + dep;
-      da = 6 + j; db = col < 6 ? col : 6 + 3 * leg + (col - 6);
-      slot = j * 9 + col;
-    } else {
-      const int q = e - 96;
-      int i = 0;
-      while ((i + 1) * (i + 2) / 2 <= q) i++;
-      da = i; db = q - i * (i + 1) / 2;
-      slot = 108 + 6 * da + db;
-    }
-    /* bits 24-30: 1 + friction-loss row of a diagonal entry's dof (0: none) - read from the model once, not per iteration */
-    const int frp1 = (e < 117 && da == db) ? m.fl_row_of_dof[da] + 1 : 0;
-    hent[pass] = e < 117 ? (da | (db << 8) | (slot << 16) | (frp1 << 24)) : -1;
-  }
+  for (int pass = 0; pass < 2; pass++) hent[pass] = m.newton_hent[pass][lane];
   /* H without the elliptic virtual rows, kept in REGISTERS across the iterations (two entries per lane) together with the
    * weight every row currently has in it: an iteration adds  dw_r J_r' J_r  for the rows whose weight CHANGED - all active
    * rows in the first iteration (from M), the one to three rows that switched piece afterwards - instead of walking every
