@@ -123,6 +123,8 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+/* cos(2 pi x), x in turns (v_cos_f32; absolute error ~1e-6 on [0, 1)) */
+__device__ __forceinline__ float fast_cos_turns(float x) { return __builtin_amdgcn_cosf(x); }
 /* a^p / b^q for a, b in (0, 1]: exp2(p log2 a - q log2 b) on the transcendental unit (v_log_f32 / v_exp_f32, ~1 ulp each;
  * the library powf is 600 instructions of special-case handling that these arguments never reach) */
 __device__ __forceinline__ float fast_pow_ratio(float a, float p, float b, float q) {

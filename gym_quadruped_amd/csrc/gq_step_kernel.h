@@ -236,7 +236,8 @@ __device__ inline uint32_t philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uin
 __device__ __forceinline__ float philox_normal(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
   const uint32_t x0 = philox4x32(c0, c1, c2, c3, k0, k1, 0), x1 = philox4x32(c0, c1, c2, c3, k0, k1, 1);
   const float u1 = ((float)(x0 >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = (float)(x1 >> 8) * (1.0f / 16777216.0f);
-  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+  return sqrtf(-2.0f * logf(u1)) * fast_cos_turns(u2); /* cos(2 pi u2): v_cos_f32 takes its argument in turns (libm's cosf brought 110
+                                                         * instructions of Payne-Hanek range reduction into every kernel variant) */
 }
 
 /* dof tree of the fixed topology: parent of dof d */
