@@ -168,6 +168,33 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
     out['pipelined_rollout'] = {'value': n * reps * 64 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / (reps * 64) * 1e3, 'steps': reps * 64, 'shards': 2,
                                 'note': 'open-loop: each shard of 2048 envs chains its steps on its own stream (gq_step_range); same kernels and results as the step loop'}
     env.close()
+    # two independent QuadrupedEnv batches on two HIP streams of this process (examples/two_stream_rollout.py): each batch's
+    # launch tail runs under the other batch's bulk.  2 x n envs = twice the per-GPU env count of the headline - reported as
+    # what one GPU delivers when the env count is free, not as the headline metric
+    envs, streams = [], []
+    for k in range(2):
+        st = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(st):
+            e = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), scene='flat', num_envs=n, device=device, auto_reset='next_step',
+                             solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000 + k, env_id_offset=k * n,
+                             self_collision=False if args.no_self_collision else None)
+            e.reset(random=True)
+        envs.append(e); streams.append(st)
+    torch.cuda.synchronize(device)
+    def both(nsteps):
+        for i in range(nsteps):
+            for k in range(2):
+                with torch.cuda.stream(streams[k]):
+                    envs[k].step(pool[(i + 7 * k) % 64])
+        torch.cuda.synchronize(device)
+    both(warmup)
+    t0 = time.perf_counter()
+    both(steps)
+    dt = time.perf_counter() - t0
+    out['two_batches_two_streams'] = {'value': 2 * n * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'total_envs': 2 * n,
+                                      'note': 'two independent batches of envs_per_gpu envs each, one HIP stream each, same process and GPU'}
+    for e in envs:
+        e.close()
     return out
 
 
