@@ -21,7 +21,7 @@ extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, int boxes, hipStream_t stream);
 extern "C" void gq_launch_jac(const GqDevModel* model, const double* qpos, int body, const double* point, float* jacp, float* jacr, int n_envs, hipStream_t stream);
 extern "C" void gq_launch_ray(const GqDevModel* model, const double* origin, const float* dir, int total, float* dist, int32_t* geom, hipStream_t stream);
-extern "C" void gq_launch_heightmap(const GqDevModel* model, const double* center, const float* yaw, int n_envs, int rows, int cols,
+extern "C" void gq_launch_heightmap(const GqDevModel* model, const double* center, int center_stride, const float* yaw, int yaw_stride, int n_envs, int rows, int cols,
                                     float dist_x, float dist_y, float* out, hipStream_t stream);
 
 #define GQ_ARG_SLOTS 8
@@ -381,7 +381,16 @@ int gq_heightmap(GqBatch* b, const double* center, const float* yaw, int rows, i
                  float* out, void* hip_stream) {
   if (!b || !center || !yaw || !out || rows <= 0 || cols <= 0) { SET_ERR("gq_heightmap: bad argument"); return GQ_EINVAL; }
   DeviceGuard guard(b->model->device);
-  gq_launch_heightmap(b->model->dev, center, yaw, b->host.n_envs, rows, cols, dist_x, dist_y, out, (hipStream_t)hip_stream);
+  gq_launch_heightmap(b->model->dev, center, 3, yaw, 1, b->host.n_envs, rows, cols, dist_x, dist_y, out, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  return GQ_OK;
+}
+
+int gq_heightmap_strided(GqBatch* b, const double* center, int center_stride, const float* yaw, int yaw_stride, int rows, int cols, float dist_x,
+                         float dist_y, float* out, void* hip_stream) {
+  if (!b || !center || !yaw || !out || rows <= 0 || cols <= 0 || center_stride < 0 || yaw_stride < 0) { SET_ERR("gq_heightmap_strided: bad argument"); return GQ_EINVAL; }
+  DeviceGuard guard(b->model->device);
+  gq_launch_heightmap(b->model->dev, center, center_stride, yaw, yaw_stride, b->host.n_envs, rows, cols, dist_x, dist_y, out, (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }

@@ -24,11 +24,17 @@ class HeightMap:
     def create_sensor_matrix(self, center, yaw=0.0):
         """center: [N,3] (e.g. env.qpos[:, 0:3]); yaw: [N] or float.  Returns [N, rows, cols, 1, 3] hit points."""
         env = self.mj_data
-        c = torch.as_tensor(center, dtype=torch.float64, device=env.device).reshape(-1, 3).expand(env.num_envs, 3).contiguous()
-        y = torch.as_tensor(yaw, dtype=torch.float32, device=env.device).reshape(-1).expand(env.num_envs).contiguous()
+        # views (env.qpos[:, 0:3], a column of the observation row, one broadcast yaw) are read in place through their row stride:
+        # .contiguous() would put a staging copy per argument on the stream in front of the ray kernel
+        c = torch.as_tensor(center, dtype=torch.float64, device=env.device).reshape(-1, 3)
+        c = c.expand(env.num_envs, 3)
+        if c.stride(1) != 1:
+            c = c.contiguous()
+        y = torch.as_tensor(yaw, dtype=torch.float32, device=env.device).reshape(-1).expand(env.num_envs)
+        self._keep = (c, y)   # alive until the next call: the launch is asynchronous
         stream = torch.cuda.current_stream(env.device).cuda_stream
-        _lib.check(_lib.lib().gq_heightmap(env._hbatch, c.data_ptr(), y.data_ptr(), self.num_rows, self.num_cols,
-                                           self.dist_x, self.dist_y, self.sensor_data_matrix.data_ptr(), stream), 'gq_heightmap')
+        _lib.check(_lib.lib().gq_heightmap_strided(env._hbatch, c.data_ptr(), int(c.stride(0)), y.data_ptr(), int(y.stride(0)), self.num_rows, self.num_cols,
+                                                   self.dist_x, self.dist_y, self.sensor_data_matrix.data_ptr(), stream), 'gq_heightmap_strided')
         return self.sensor_data_matrix
 
     def update_height_map(self, center, yaw=0.0):

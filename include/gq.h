@@ -350,6 +350,10 @@ int gq_batch_set_pending(GqBatch* b, const uint8_t* flags, void* hip_stream);
  * out: device [N][rows][cols][3] f32 hit points ((-1,-1,-1)-style misses cannot occur over the infinite floor). */
 int gq_heightmap(GqBatch* b, const double* center, const float* yaw, int rows, int cols, float dist_x, float dist_y,
                  float* out, void* hip_stream);
+/* gq_heightmap with row strides (in elements) for `center` and `yaw`: views such as qpos[:, 0:3] (stride 19) or a column of the
+ * observation row (stride obs_dim) are read in place - no staging copy on the caller's stream.  yaw_stride 0 = one yaw for all. */
+int gq_heightmap_strided(GqBatch* b, const double* center, int center_stride, const float* yaw, int yaw_stride, int rows, int cols,
+                         float dist_x, float dist_y, float* out, void* hip_stream);
 
 /* mujoco.mj_jac(m, d, jacp, jacr, point, body) (quadruped_env.py:728-735) for every env: translational and rotational
  * Jacobian of the world point `point` moving with body `body` (MuJoCo body id: 1 = base, 2 + 3 leg + link), at the pose
