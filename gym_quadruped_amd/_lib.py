@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-from .cabi import GqImuCfg, GqModelDesc, GqObsOut, GqResampleCfg, GqResetCfg, GqState
+from .cabi import GQ_ABI_VERSION, GqImuCfg, GqModelDesc, GqObsOut, GqResampleCfg, GqResetCfg, GqState
 
 _LIB = None
 import os
@@ -13,7 +13,7 @@ import os
 # GQ_LIBGQ_PATH: developer override used for A/B timing of two kernel builds inside one GPU session
 LIB_PATH = Path(os.environ.get('GQ_LIBGQ_PATH', Path(__file__).parent / 'libgq.so'))
 
-EXPORTS = ['gq_last_error', 'gq_version', 'gq_obs_dim', 'gq_model_create', 'gq_model_destroy', 'gq_batch_create',
+EXPORTS = ['gq_last_error', 'gq_version', 'gq_struct_sizes', 'gq_obs_dim', 'gq_model_create', 'gq_model_destroy', 'gq_batch_create',
            'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_batch_set_imu', 'gq_batch_set_pending', 'gq_batch_set_resampling', 'gq_heightmap', 'gq_heightmap_strided', 'gq_step_range', 'gq_batch_bind', 'gq_rollout', 'gq_jac', 'gq_ray', 'gq_forward', 'gq_full_mass', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get', 'gq_debug_device_buffer', 'gq_debug_field', 'gq_debug_stop_stage']
 
 
@@ -31,6 +31,15 @@ def lib():
     import torch  # noqa: F401  - load torch's HIP runtime first so libgq.so binds to the same one
     L = C.CDLL(str(LIB_PATH))
     L.gq_last_error.restype = C.c_char_p
+    # a stale libgq.so (built from an older include/gq.h) would shift every by-value struct argument: refuse it here
+    if not hasattr(L, 'gq_struct_sizes') or L.gq_version() != GQ_ABI_VERSION:
+        raise GqError(f'{LIB_PATH} implements ABI {L.gq_version()}, this binding expects {GQ_ABI_VERSION}: rebuild the library '
+                      f'(make -C gym_quadruped_amd/csrc)')
+    sizes = (C.c_int32 * 6)()
+    L.gq_struct_sizes(sizes)
+    mirror = [C.sizeof(t) for t in (GqModelDesc, GqState, GqObsOut, GqResetCfg, GqResampleCfg, GqImuCfg)]
+    if list(sizes) != mirror:
+        raise GqError(f'struct layouts differ between {LIB_PATH} {list(sizes)} and gym_quadruped_amd/cabi.py {mirror}')
     L.gq_model_create.argtypes = [C.POINTER(GqModelDesc), C.c_int, C.POINTER(C.c_void_p)]
     L.gq_model_destroy.argtypes = [C.c_void_p]
     L.gq_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]

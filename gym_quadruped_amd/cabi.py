@@ -12,6 +12,7 @@ import numpy as np
 from .mjcf import ModelDesc
 
 GQ_NLEG = 4
+GQ_ABI_VERSION = 300   # include/gq.h
 
 _I = C.POINTER(C.c_int32)
 _D = C.POINTER(C.c_double)
@@ -19,6 +20,7 @@ _D = C.POINTER(C.c_double)
 
 class GqModelDesc(C.Structure):
     _fields_ = [
+        ('struct_size', C.c_int32),
         ('nq', C.c_int32), ('nv', C.c_int32), ('nu', C.c_int32), ('nbody', C.c_int32), ('njnt', C.c_int32),
         ('ngeom', C.c_int32), ('ncloud', C.c_int32), ('nvert', C.c_int32),
         ('timestep', C.c_double), ('gravity', C.c_double * 3), ('cone', C.c_int32), ('impratio', C.c_double),
@@ -108,6 +110,7 @@ class MarshalledModel:
         self.md = md
         self._keep = []
         d = GqModelDesc()
+        d.struct_size = C.sizeof(GqModelDesc)
         nvert = int(md.vert_pos.shape[0])
         for k in ('nq', 'nv', 'nu', 'nbody', 'njnt', 'ngeom'):
             setattr(d, k, int(getattr(md, k)))

@@ -77,7 +77,13 @@ struct DeviceGuard {
 extern "C" {
 
 const char* gq_last_error(void) { return g_err; }
-int gq_version(void) { return 100; }
+int gq_version(void) { return GQ_ABI_VERSION; }
+int gq_struct_sizes(int32_t out[6]) {
+  if (!out) { SET_ERR("gq_struct_sizes: null argument"); return GQ_EINVAL; }
+  out[0] = (int32_t)sizeof(GqModelDesc); out[1] = (int32_t)sizeof(GqState); out[2] = (int32_t)sizeof(GqObsOut);
+  out[3] = (int32_t)sizeof(GqResetCfg); out[4] = (int32_t)sizeof(GqResampleCfg); out[5] = (int32_t)sizeof(GqImuCfg);
+  return GQ_OK;
+}
 int gq_obs_dim(int obs_id) { return gq_obs_dim_host(obs_id); }
 int gq_model_destroy(GqModel* m);
 int gq_batch_destroy(GqBatch* b);
@@ -91,6 +97,10 @@ int gq_batch_destroy(GqBatch* b);
 
 int gq_model_create(const GqModelDesc* desc, int device, GqModel** out) {
   if (!desc || !out) { SET_ERR("gq_model_create: null argument"); return GQ_EINVAL; }
+  if (desc->struct_size != (int32_t)sizeof(GqModelDesc)) {
+    SET_ERR("gq_model_create: GqModelDesc.struct_size is %d, this library (ABI %d) expects %d - header and library do not match", desc->struct_size, GQ_ABI_VERSION, (int)sizeof(GqModelDesc));
+    return GQ_EINVAL;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { SET_ERR("no HIP device visible"); return GQ_ENODEVICE; }
   if (device < 0 || device >= ndev) { SET_ERR("device %d out of range (have %d)", device, ndev); return GQ_EINVAL; }

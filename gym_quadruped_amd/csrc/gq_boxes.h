@@ -700,7 +700,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
   WorldAppend S;
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) S.ft[k] = uniform(W.foot_touch[k]);
+  for (int k = 0; k < 4; k++) S.ft[k] = (uniform(W.foot_touch) >> k) & 1;
   const int ncon = S.ncon;
   if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
     st3(GQ_BX_CONNRM(W) + 3 * lane, v3(0.0f, 0.0f, 1.0f));
@@ -734,8 +734,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
   if constexpr (SELF) append_self_contacts<CONE>(W, m, mu_env, S, pre);
   if (lane == 0) {
     W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself;
-#pragma unroll
-    for (int k = 0; k < 4; k++) W.foot_touch[k] = S.ft[k];
+    W.foot_touch = S.ft[0] | (S.ft[1] << 1) | (S.ft[2] << 2) | (S.ft[3] << 3);
   }
   wave_barrier();
 }

@@ -90,6 +90,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(readlane<15>(v), readlane<31>(v)), fmaxf(readlane<47>(v), readlane<63>(v)));
 }
 
+/* inclusive prefix sum over the lanes (lane l gets v_0 + .. + v_l): row_shr ladder with zero fill inside the rows of 16, then
+ * the totals of the lower rows (lanes 15 / 31 / 47, v_readlane) are added to the upper ones */
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += dpp_mov_zero<0x111>(v); v += dpp_mov_zero<0x112>(v); v += dpp_mov_zero<0x114>(v); v += dpp_mov_zero<0x118>(v);
+  const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+  const int row = (int)threadIdx.x >> 4;
+  return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+}
+
 /* sum over the four lanes of the lane's quad, result in all four (two quad_perm DPP butterflies: [1,0,3,2], [2,3,0,1]) */
 __device__ __forceinline__ float quad_sum(float v) {
   v += dpp_mov<0xB1>(v); /* every source lane of a quad_perm is inside the quad: the plain form folds into v_add_f32_dpp */

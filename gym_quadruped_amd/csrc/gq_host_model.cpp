@@ -217,6 +217,23 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       }
     for (int i = 0; i < 3; i++) { G.aabb_c[i] = (float)(0.5 * (lo[i] + hi[i])); G.aabb_h[i] = (float)(0.5 * (hi[i] - lo[i]) * 1.0001 + 1e-7); }
     G.chunk_adr = -1; G.flat_adr = -1;
+    { /* primitive geoms: exact sizes for the plane narrow phase, read back from the cloud the MJCF compiler lowered them to */
+      const int nv = G.cloud_num, type = d->geom_type ? d->geom_type[g] : (nv == 1 ? 2 : (nv == 2 ? 3 : 7));
+      const double* V = d->vert_pos + 3 * G.cloud_adr;
+      G.ptype = 0; G.psize[0] = G.psize[1] = G.psize[2] = 0.0f;
+      if (type == 2 && nv == 1 && V[0] == 0 && V[1] == 0 && V[2] == 0) { G.ptype = 2; G.psize[0] = G.radius; }
+      else if (type == 3 && nv == 2 && V[0] == 0 && V[1] == 0 && V[3] == 0 && V[4] == 0 && V[2] == -V[5] && V[5] >= 0) {
+        G.ptype = 3; G.psize[0] = G.radius; G.psize[1] = (float)V[5];
+      } else if (type == 6 && nv == 8) {
+        bool ok = V[21] > 0 && V[22] > 0 && V[23] > 0;
+        for (int i = 0; i < 8 && ok; i++)
+          ok = V[3 * i] == ((i & 1) ? V[21] : -V[21]) && V[3 * i + 1] == ((i & 2) ? V[22] : -V[22]) && V[3 * i + 2] == ((i & 4) ? V[23] : -V[23]);
+        if (ok) { G.ptype = 6; for (int i = 0; i < 3; i++) G.psize[i] = (float)V[21 + i]; }
+      } else if (type == 5 && nv == 32 && V[1] == 0 && V[0] > 0 && V[2] < 0) {
+        G.ptype = 5; G.psize[0] = (float)V[0]; G.psize[1] = (float)-V[2];
+      }
+      if (type != 7 && type != 2 && G.ptype == 0) FAIL("geom %d: type %d with an unexpected vertex cloud (%d vertices)", g, type, nv);
+    }
     if (G.cloud_num > 64) { /* boxes of the 64-vertex chunks (mjcf.sort_cloud_vertices made them compact), appended to the vertex arrays */
       G.chunk_adr = (int)vx->size();
       for (int v0 = 0; v0 < G.cloud_num; v0 += 64) {

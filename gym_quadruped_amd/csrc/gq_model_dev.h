@@ -30,6 +30,11 @@ struct GqDevGeom {          /* a robot collision geom that is not a foot sphere 
   int32_t chunk_adr;        /* clouds of more than one 64-vertex chunk: index (into the vertex arrays) of the chunk boxes -
                              * entry 2k = centre, 2k + 1 = half extents of vertices [64k, 64k + 64) in the geom frame; else -1 */
   float radius;             /* inflation (capsule) */
+  /* plane narrow phase (MuJoCo's mjraw_Plane* routines, evaluated by ONE lane): 0 = hull cloud, support vertex found by the
+   * 64-lane scan (mjc_PlaneConvex's first point); 2 sphere; 3 capsule: psize = (radius, half length); 5 cylinder: psize =
+   * (radius, half length); 6 box: psize = half extents */
+  int32_t ptype;
+  float psize[3];
   float pos[3];             /* geom frame in body frame */
   float mat[9];
   float aabb_c[3], aabb_h[3]; /* AABB of the cloud in the geom frame */

@@ -100,7 +100,7 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
     d0 = W.xpos[G.body][2] + dot(nb, ld3(G.pos));
     const float lower = d0 + dot(ng, ld3(G.aabb_c)) - (fabsf(ng.x) * G.aabb_h[0] + fabsf(ng.y) * G.aabb_h[1] + fabsf(ng.z) * G.aabb_h[2]) - G.radius;
     const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
-    needs = lower < G.margin && (!calf_only || calf);
+    needs = G.ptype == 0 && lower < G.margin && (!calf_only || calf); /* primitive geoms are evaluated lane-locally (floor_candidates) */
     if (!needs) W.u2.c.lg_dist[lane] = 1e30f;
   }
   uint64_t todo = ballot(needs);
@@ -141,6 +141,84 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
     }
   }
   wave_barrier();
+}
+
+/* Candidate contact points of collision item `code` (k < 4: foot k, else 4 + link geom) with the floor plane z = 0, evaluated
+ * by ONE lane - MuJoCo's plane routines per geom type (restated in oracle/gq_oracle.c::gqo_collision):
+ *   sphere    mjraw_PlaneSphere   one point
+ *   capsule   mjraw_PlaneCapsule  both end spheres, the +axis end first; first tangent of the frame = the capsule axis made
+ *                                 orthogonal to the normal
+ *   box       mjraw_PlaneBox      the corners at or below the box centre, in corner order, at most 4
+ *   cylinder  mjc_PlaneCylinder   lowest rim point of the near cap, the rim point under it on the far cap, two more points of
+ *                                 the near cap at +-120 degrees
+ *   hull      mjc_PlaneConvex     the support vertex (found by the 64-lane scan of stage_collision_scan)
+ * n candidates in MuJoCo's order: reference point pt[k] (sphere centre / corner / rim point) and distance dist[k] = pt.z - r.
+ * Whether a candidate IS a contact is its own `dist < margin` test - equivalent to the routines' early exits, because the first
+ * candidate of a cylinder is never farther than the others.  A lift by dz moves every pt.z and dist by dz. */
+struct FloorCand { int n; float r, t1c, t1s; float dist[4]; V3 pt[4]; };
+__device__ inline void floor_candidates(const WaveMem& W, const GQ_MODEL GqDevModel& m, const int code, FloorCand& C) {
+  C.n = 0; C.r = 0.0f; C.t1c = 0.0f; C.t1s = 1.0f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { C.dist[k] = 1e30f; C.pt[k] = v3(0.0f, 0.0f, 0.0f); }
+  if (code < 4) {
+    C.n = 1; C.r = m.foot_radius[code]; C.pt[0] = ld3(W.foot_world[code]); C.dist[0] = C.pt[0].z - C.r;
+    return;
+  }
+  const int g = code - 4;
+  const GQ_MODEL GqDevGeom& G = m.lg[g];
+  const int ptype = G.ptype;
+  if (ptype == 0) { C.n = 1; C.r = G.radius; C.pt[0] = ld3(W.u2.c.lg_pt[g]); C.dist[0] = W.u2.c.lg_dist[g]; return; }
+  const float* Rb = W.xmat[G.body];
+  const V3 c = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos));
+  float A[9]; /* geom frame in the world: Rb Rg */
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) A[3 * i + j] = Rb[3 * i] * G.mat[j] + Rb[3 * i + 1] * G.mat[3 + j] + Rb[3 * i + 2] * G.mat[6 + j];
+  if (ptype == 2) { C.n = 1; C.r = G.psize[0]; C.pt[0] = c; C.dist[0] = c.z - C.r; }
+  else if (ptype == 3) {
+    const V3 ax = v3(A[2], A[5], A[8]);
+    const float hl = G.psize[1];
+    C.n = 2; C.r = G.psize[0];
+    C.pt[0] = c + hl * ax; C.pt[1] = c - hl * ax;
+    C.dist[0] = C.pt[0].z - C.r; C.dist[1] = C.pt[1].z - C.r;
+    const float l2 = ax.x * ax.x + ax.y * ax.y;
+    if (l2 > 1e-30f) { const float inv = fast_rsqrt(l2); C.t1c = ax.x * inv; C.t1s = ax.y * inv; }
+    else { C.t1c = 1.0f; C.t1s = 0.0f; } /* mju_normalize3 of a null vector */
+  } else if (ptype == 6) {
+    const V3 ux = G.psize[0] * v3(A[0], A[3], A[6]), uy = G.psize[1] * v3(A[1], A[4], A[7]), uz = G.psize[2] * v3(A[2], A[5], A[8]);
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const V3 off = ((i & 1) ? ux : -1.0f * ux) + ((i & 2) ? uy : -1.0f * uy) + ((i & 4) ? uz : -1.0f * uz);
+      const bool ok = off.z <= 0.0f && n < 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (ok && n == k) { C.pt[k] = c + off; C.dist[k] = c.z + off.z; }
+      n += ok ? 1 : 0;
+    }
+    C.n = n;
+  } else if (ptype == 5) {
+    V3 ax = v3(A[2], A[5], A[8]);
+    float prjaxis = ax.z;
+    if (prjaxis > 0.0f) { ax = -1.0f * ax; prjaxis = -prjaxis; } /* the axis points towards the plane */
+    const float rad = G.psize[0], hl = G.psize[1];
+    V3 vec = prjaxis * ax - v3(0.0f, 0.0f, 1.0f); /* -normal without its component along the axis */
+    const float len2 = dot(vec, vec);
+    if (len2 >= 1e-30f) vec = (rad * fast_rsqrt(len2)) * vec;
+    else vec = rad * v3(A[0], A[3], A[6]); /* disk parallel to the plane: the cylinder's x axis */
+    const float prjvec = vec.z;
+    const V3 axs = hl * ax;
+    prjaxis *= hl;
+    C.n = 4;
+    C.pt[0] = c + vec + axs; C.dist[0] = c.z + prjaxis + prjvec;
+    C.pt[1] = c + vec - axs; C.dist[1] = c.z - prjaxis + prjvec;
+    V3 v1 = cross(vec, axs);
+    const float n1 = dot(v1, v1);
+    v1 = n1 > 1e-30f ? (rad * 0.8660254037844386f * fast_rsqrt(n1)) * v1 : v3(rad * 0.8660254037844386f, 0.0f, 0.0f);
+    C.pt[2] = c + v1 + axs - 0.5f * vec; C.pt[3] = c - v1 + axs - 0.5f * vec;
+    C.dist[2] = C.dist[3] = c.z + prjaxis - 0.5f * prjvec;
+  }
 }
 
 /* _sample_ref_vel (quadruped_env.py:1046-1072) and _sample_external_disturbances (:1074-1139) for the wave's env when their
@@ -232,6 +310,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   }
   GQ_TICK(15); /* marker 15: nothing done yet - the launch floor */
   /* ================================================================ S0: load the env's state rows */
+  float applied_l = 0.0f; /* qfrc_applied of the lane's dof: read and consumed by the same lane (no LDS copy) */
   if (lane < 19) {
     double q = gptr(a.qpos)[(size_t)env * 19 + lane];
     if (lane < 2) W.bxy[lane] = q;
@@ -242,7 +321,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   if (lane < 18) {
     W.qvel[lane] = gptr(a.qvel)[(size_t)env * 18 + lane];
     W.warm[lane] = gptr(a.warm)[(size_t)env * 18 + lane];
-    W.applied[lane] = a.applied ? gptr(a.applied)[(size_t)env * 18 + lane] : 0.0f;
+    applied_l = a.applied ? gptr(a.applied)[(size_t)env * 18 + lane] : 0.0f;
   }
   if (lane < 12) W.ctrl[lane] = (call.ctrl && pass == 0) ? gptr(call.ctrl)[(size_t)env * 12 + lane] : 0.0f;
   if (lane < 4) W.cmd[lane] = a.cmd ? gptr(a.cmd)[(size_t)env * 4 + lane] : 0.0f;
@@ -282,7 +361,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     W.act[lane] = act;
     const float damp = m.dof_damping[lane];
     if constexpr (SOLVER == 1) W.F[0][lane] = h * damp; /* the Newton path stores no factor: F keeps h*damping for the Euler system (S10) */
-    W.smooth[lane] = -damp * W.qvel[lane] + act + W.applied[lane];
+    W.smooth[lane] = -damp * W.qvel[lane] + act + applied_l;
   }
   if constexpr (SOLVER == 1) wave_priority(prio_hint);
   if constexpr (DBG) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 28] = (float)prio_hint;
@@ -421,71 +500,76 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
    * kinematics and collision scan just produced, instead of on a kinematics + scan pass of its own inside reset_wave: on
    * the flat floor a lift by dz moves every distance by dz and leaves everything that S2-S5 computed (all of it relative
    * to the base origin) untouched, so the reset's mj_step simply continues from the lifted pose */
-  if (lift) { /* wave-uniform; only set on scenes without world boxes / height field */
-    float dist = 1e30f, margin = 0.0f;
-    if (lane < 4) { dist = W.foot_world[lane][2] - m.foot_radius[lane]; margin = m.foot_margin[lane]; }
-    else if (lane - 4 < nlg) {
-      const GQ_MODEL GqDevGeom& G = m.lg[lane - 4];
-      if (G.body > 0 && (G.body - 1) % 3 == 2) { dist = W.u2.c.lg_dist[lane - 4]; margin = G.margin; }
+  /* lane = collision item in MuJoCo's order (increasing geom id; con_order interleaves feet and link geoms): its candidate
+   * contact points with the floor, up to four (floor_candidates) */
+  const int nitem = 4 + nlg;
+  FloorCand FC;
+  FC.n = 0; FC.r = 0.0f; FC.t1c = 0.0f; FC.t1s = 1.0f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { FC.dist[k] = 1e30f; FC.pt[k] = v3(0.0f, 0.0f, 0.0f); }
+  int code = 0, body = 0, dim = 3, fric_rule = 0;
+  bool calf = false;
+  float cmargin = 0.0f, inc = 0.0f, fgeom = 0.0f;
+  const GQ_MODEL float* solref = m.foot_solref[0];
+  const GQ_MODEL float* solimp = m.foot_solimp[0];
+  if (lane < nitem) {
+    code = m.con_order[lane];
+    floor_candidates(W, m, code, FC);
+    if (code < 4) {
+      const int k = code;
+      cmargin = m.foot_margin[k]; body = 3 + 3 * m.foot_leg[k]; dim = m.foot_dim[k]; inc = m.foot_includemargin[k]; calf = true;
+      fgeom = m.foot_friction[k][0]; fric_rule = m.foot_fric_rule[k];
+      solref = m.foot_solref[k]; solimp = m.foot_solimp[k];
+    } else {
+      const GQ_MODEL GqDevGeom& G = m.lg[code - 4];
+      cmargin = G.margin; body = G.body; dim = G.dim; inc = G.includemargin; calf = G.body > 0 && (G.body - 1) % 3 == 2;
+      fgeom = G.friction[0]; fric_rule = G.fric_rule;
+      solref = G.solref; solimp = G.solimp;
     }
+  }
+  if (lift) { /* wave-uniform; only set on scenes without world boxes / height field */
+    /* the reference lifts by 1.1 max |contact.dist| over EVERY contact of the calf bodies with the ground (feet_contact_state
+     * lists them all, quadruped_env.py:378-385) until none is left */
     float dz = 0.0f;
     for (int it = 0; it < 100; it++) {
-      const bool touching = dist + dz < margin;
+      float pen = 0.0f;
+      bool touching = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool tk = calf && k < FC.n && FC.dist[k] + dz < cmargin;
+        touching = touching || tk;
+        pen = tk ? fmaxf(pen, fabsf(FC.dist[k] + dz)) : pen;
+      }
       if (ballot(touching) == 0) break;
-      dz += 1.1f * wave_max(touching ? fabsf(dist + dz) : 0.0f);
+      dz += 1.1f * wave_max(pen);
     }
-    const int failed = ballot(dist + dz < margin) != 0;
+    bool still = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) still = still || (calf && k < FC.n && FC.dist[k] + dz < cmargin);
+    const int failed = ballot(still) != 0;
     wave_barrier();
     if (lane == 0) { W.basez += dz; if (a.lift_failed) gptr(a.lift_failed)[env] = (uint8_t)failed; }
     if (lane < GQ_NB) W.xpos[lane][2] += dz;
     if (lane < 4) W.foot_world[lane][2] += dz;
-    if (lane < nlg && W.u2.c.lg_dist[lane] < 1e29f) { W.u2.c.lg_dist[lane] += dz; W.u2.c.lg_pt[lane][2] += dz; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { FC.dist[k] += dz; FC.pt[k].z += dz; }
     wave_barrier();
   }
   GQ_TICK(14);
-  /* contact list in MuJoCo's order (increasing geom id; con_order interleaves feet and link geoms), capped.
-   * Lane `it` evaluates collision item `it`; ranks and row offsets come from ballots (no serial section). */
+  /* contact list in MuJoCo's order, capped.  Lane `it` owns the (up to four) contacts of collision item `it`; ranks and row
+   * offsets come from one wave prefix sum over (contacts, rows, reserved virtual rows) packed into an int - no serial section. */
   {
-    const int nitem = 4 + nlg;
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    bool touching = false, calf = false;
-    int code = 0, body = 0, dim = 3;
-    float dist = 0.0f, inc = 0.0f, mu = 0.0f, px = 0.0f, py = 0.0f, pz = 0.0f;
-    const GQ_MODEL float* solref = m.foot_solref[0];
-    const GQ_MODEL float* solimp = m.foot_solimp[0];
-    if (lane < nitem) {
-      code = m.con_order[lane];
-      const float mu_env = W.mu_env;
-      const float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0];
-      if (code < 4) {
-        const int k = code;
-        dist = W.foot_world[k][2] - m.foot_radius[k];
-        touching = dist < m.foot_margin[k];
-        body = 3 + 3 * m.foot_leg[k]; dim = m.foot_dim[k]; inc = m.foot_includemargin[k]; calf = true;
-        px = W.foot_world[k][0]; py = W.foot_world[k][1]; pz = W.foot_world[k][2] - (m.foot_radius[k] + 0.5f * dist);
-        /* friction mixing; _set_ground_friction overrides floor and feet with [mu, 0.005, 0] (quadruped_env.py:1292) */
-        const float fg = mu_env >= 0.0f ? mu_env : m.foot_friction[k][0];
-        const int rule = m.foot_fric_rule[k];
-        mu = fmaxf(1e-5f, rule == 0 ? fmaxf(ff, fg) : (rule == 1 ? ff : fg)); /* mjMINMU */
-        solref = m.foot_solref[k]; solimp = m.foot_solimp[k];
-      } else {
-        const int g = code - 4;
-        const GQ_MODEL GqDevGeom& G = m.lg[g];
-        dist = W.u2.c.lg_dist[g];
-        touching = dist < G.margin;
-        body = G.body; dim = G.dim; inc = G.includemargin; calf = G.body > 0 && (G.body - 1) % 3 == 2;
-        px = W.u2.c.lg_pt[g][0]; py = W.u2.c.lg_pt[g][1]; pz = W.u2.c.lg_pt[g][2] - (G.radius + 0.5f * dist);
-        const float fg = G.friction[0];
-        mu = fmaxf(1e-5f, G.fric_rule == 0 ? fmaxf(ff, fg) : (G.fric_rule == 1 ? ff : fg));
-        solref = G.solref; solimp = G.solimp;
-      }
-    }
-    const uint64_t touch_mask = ballot(touching);
+    bool tk[4];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { tk[k] = lane < nitem && k < FC.n && FC.dist[k] < cmargin; cnt += tk[k] ? 1 : 0; }
+    const bool touching = cnt > 0;
     /* _check_for_invalid_contacts (quadruped_env.py:1228-1248): body-level test, before any capping */
     const int invalid = ballot(touching && !calf) != 0;
-    int ft[4];
+    int ftm = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) ft[k] = ballot(touching && body == 3 + 3 * m.foot_leg[k]) != 0;
+    for (int k = 0; k < 4; k++) ftm |= (ballot(touching && body == 3 + 3 * m.foot_leg[k]) != 0) ? (1 << k) : 0;
     /* joint limits: lane j < 12 owns hinge j (lower side first, then upper) */
     bool lim_lo = false, lim_hi = false;
     float dlo = 0.0f, dhi = 0.0f;
@@ -502,32 +586,44 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       if (lim_hi && at < GQ_NJ) { W.u2.c.lim_jnt[at] = lane; W.u2.c.lim_side[at] = -1.0f; W.u2.c.lim_dist[at] = dhi; }
       if (nl > GQ_NJ) nl = GQ_NJ;
     }
-    /* row budget: friction rows, limit rows, then whole contacts in order while they fit (a prefix of the list) */
-    const int idx = popc64(touch_mask & lt);
-    const bool kept = touching && idx < GQ_MAXCON;
-    /* pyramidal: 2 (dim - 1) edge rows; elliptic: dim rows + (dim - 1) rows of LDS above nefc reserved per cone contact
-     * for the virtual rows of its Hessian block (gq_newton.h) */
+    /* row budget: friction rows, limit rows, then whole contacts in order while they fit (a prefix of the list).
+     * pyramidal: 2 (dim - 1) edge rows; elliptic: dim rows + (dim - 1) rows of LDS above nefc reserved per cone contact for
+     * the virtual rows of its Hessian block (gq_newton.h) */
     const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
-    const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4),
-                   m6 = ballot(kept && need == 6);
-    const int row0 = m.nfl + nl + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
-    const int reserve = CONE ? 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) + (need > 1 ? need - 1 : 0) : 0;
-    const bool fits = kept && row0 + need + reserve <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
-    const uint64_t fit_mask = ballot(fits);
-    const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4),
-                   f6 = ballot(fits && need == 6);
-    if (fits) {
-      W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
-      W.con_dist[idx] = dist; W.con_inc[idx] = inc; W.con_mu[idx] = mu;
-      W.con_pos[idx][0] = px; W.con_pos[idx][1] = py; W.con_pos[idx][2] = pz;
-      W.con_solref[idx][0] = solref[0]; W.con_solref[idx][1] = solref[1];
+    const int vres = (CONE && need > 1) ? need - 1 : 0;
+    /* <= 42 items x 4 contacts x 6 rows: the three running sums stay inside their bit fields (8 / 10 / 10 bits) */
+    const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
+    const int excl = wave_incl_scan(packed) - packed;
+    const int idx0 = excl & 0xff, rows0 = m.nfl + nl + ((excl >> 8) & 0x3ff), res0 = (excl >> 18) & 0x3ff;
+    const float mu_env = W.mu_env;
+    const float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0];
+    /* friction mixing; _set_ground_friction overrides floor and feet with [mu, 0.005, 0] (quadruped_env.py:1292) */
+    const float fg = (code < 4 && mu_env >= 0.0f) ? mu_env : fgeom;
+    const float mu = fmaxf(1e-5f, fric_rule == 0 ? fmaxf(ff, fg) : (fric_rule == 1 ? ff : fg)); /* mjMINMU */
+    int nfit = 0, j = 0;
 #pragma unroll
-      for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = solimp[q];
+    for (int k = 0; k < 4; k++) {
+      if (tk[k]) { /* the lane's j-th contact */
+        const int idx = idx0 + j, row0 = rows0 + j * need, res = res0 + (j + 1) * vres;
+        const bool fits = idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
+        if (fits) {
+          const float dist = FC.dist[k];
+          W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
+          W.con_dist[idx] = dist; W.con_inc[idx] = inc; W.con_mu[idx] = mu;
+          W.con_pos[idx][0] = FC.pt[k].x; W.con_pos[idx][1] = FC.pt[k].y; W.con_pos[idx][2] = FC.pt[k].z - (FC.r + 0.5f * dist);
+          W.con_solref[idx][0] = solref[0]; W.con_solref[idx][1] = solref[1];
+#pragma unroll
+          for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = solimp[q];
+          W.con_t1[idx][0] = FC.t1c; W.con_t1[idx][1] = FC.t1s;
+          nfit++;
+        }
+        j++;
+      }
     }
+    const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8)), 63);
     if (lane == 0) {
-      W.ncon = popc64(fit_mask); W.nlim = nl; W.nefc = m.nfl + nl + popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6); W.invalid = invalid;
-#pragma unroll
-      for (int k = 0; k < 4; k++) W.foot_touch[k] = ft[k];
+      W.ncon = tot & 0xff; W.nlim = nl; W.nefc = m.nfl + nl + (tot >> 8); W.invalid = invalid;
+      W.foot_touch = ftm;
     }
   }
   wave_barrier();
@@ -595,8 +691,10 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       if (body1 > 0) { jleg1 = (body1 - 1) / 3; jdepth1 = (body1 - 1) % 3; }
     }
     /* contact frame (mju_makeFrame): horizontal floor n = z, t1 = y, t2 = -x; box contacts bring their own normal */
-    V3 cn = v3(0.0f, 0.0f, 1.0f), ct1 = v3(0.0f, 1.0f, 0.0f), ct2 = v3(-1.0f, 0.0f, 0.0f);
-    if constexpr (GEN) if (GQ_BX_WCLS(W)[c] != -1) { cn = ld3(GQ_BX_CONNRM(W) + 3 * c); make_frame(cn, ct1, ct2); } /* floor contacts keep the fixed frame */
+    /* floor: n = z, t1 = (cos, sin, 0) as the narrow phase left it (default y; a capsule's axis), t2 = n x t1 */
+    const float t1c = W.con_t1[c][0], t1s = W.con_t1[c][1];
+    V3 cn = v3(0.0f, 0.0f, 1.0f), ct1 = v3(t1c, t1s, 0.0f), ct2 = v3(-t1s, t1c, 0.0f);
+    if constexpr (GEN) if (GQ_BX_WCLS(W)[c] != -1) { cn = ld3(GQ_BX_CONNRM(W) + 3 * c); make_frame(cn, ct1, ct2); } /* world boxes, height field, robot-robot: mju_makeFrame of their own normal */
     dir = cn;
     bool rotational = false;
     if (dim == 1) { rtype = ROW_CONTACT1; rdiag = tran; }
@@ -1050,9 +1148,12 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
         V3 ct1, ct2;
         make_frame(cn, ct1, ct2);
         cf = cf + fn * cn + ft1 * ct1 + ft2 * ct2;
-      } else cf = cf + v3(-ft2, ft1, fn); /* n = z, t1 = y, t2 = -x */
+      } else { /* floor: n = z, t1 = (cos, sin, 0), t2 = (-sin, cos, 0) */
+        const float t1c = W.con_t1[c][0], t1s = W.con_t1[c][1];
+        cf = cf + v3(ft1 * t1c - ft2 * t1s, ft1 * t1s + ft2 * t1c, fn);
+      }
     }
-    if (W.foot_touch[lane]) cs = 1.0f; /* contact detected but dropped by the row budget */
+    if ((W.foot_touch >> lane) & 1) cs = 1.0f; /* contact detected but dropped by the row budget */
     /* slot of this foot in legs_order-dependent observables is resolved by obs_map; canonical order = FL FR RL RR */
     st3(ob + OB_FEET_POS + 3 * lane, pworld);
     st3(ob + OB_FEET_POS_B + 3 * lane, matTvec(Rn, prel_new));
@@ -1221,17 +1322,27 @@ __device__ inline int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 
     wave_barrier();
     stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), true);
     /* distances and margins of everything attached to a calf body (feet_contact_state is body-level) */
-    float dist = 1e30f, margin = 0.0f;
-    if (lane < 4) { dist = W.foot_world[lane][2] - m.foot_radius[lane]; margin = m.foot_margin[lane]; }
-    else if (lane - 4 < m.nlg) { dist = W.u2.c.lg_dist[lane - 4]; margin = m.lg[lane - 4].margin; }
+    /* floor: lane = collision item (feet 0-3, then the link geoms), every candidate point of the plane narrow phase */
+    FloorCand FC;
+    FC.n = 0;
+    float margin = 0.0f;
+    if (lane < 4 + m.nlg) {
+      const bool calf_item = lane < 4 || (m.lg[lane - 4].body > 0 && (m.lg[lane - 4].body - 1) % 3 == 2);
+      if (calf_item) { floor_candidates(W, m, lane, FC); margin = lane < 4 ? m.foot_margin[lane] : m.lg[lane - 4].margin; }
+    }
+    auto floor_pen = [&](const float dzz) { /* largest |dist| among the item's floor contacts at lift dzz (0: none) */
+      float pen = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) pen = (k < FC.n && FC.dist[k] + dzz < margin) ? fmaxf(pen, fabsf(FC.dist[k] + dzz)) : pen;
+      return pen;
+    };
     if constexpr (!BOXES) {
       for (int it = 0; it < 100; it++) {
-        const bool touching = dist + dz < margin;
-        if (ballot(touching) == 0) break;
-        float pen = wave_max(touching ? fabsf(dist + dz) : 0.0f);
+        const float pen = wave_max(floor_pen(dz));
+        if (!(pen > 0.0f)) break;
         dz += 1.1f * pen;
       }
-      failed = ballot(dist + dz < margin) != 0;
+      failed = wave_max(floor_pen(dz)) > 0.0f;
     } else {
       /* with world boxes a lift changes the box distances unevenly: every iteration re-evaluates the calf-body items against
        * the floor (shifted) and against the boxes near the lifted robot, like the reference's mj_step1 per iteration */
@@ -1242,7 +1353,7 @@ __device__ inline int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 
       V3 calf_c; float calf_r;
       item_sphere(W, m, true, calf_c, calf_r);
       for (int it = 0; it <= 100; it++) {
-        float pen = (dist + dz < margin) ? fabsf(dist + dz) : 0.0f;
+        float pen = floor_pen(dz);
         float clear = 0.0f; /* lift that takes the touching item above the box altogether */
         uint64_t cand[2];
         box_candidates(W, m, spawn_x, spawn_y, dz, cand, calf_c, calf_r); /* around the lifted base; calf items only */

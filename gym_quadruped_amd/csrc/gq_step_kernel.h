@@ -101,7 +101,7 @@ struct WaveDyn {
 struct WaveMem {
   double bxy[2];               /* base x, y of this forward pass (f64, never enters fp32 arithmetic) */
   float mu_env; int32_t step_old; /* the env's friction override (-1: none) and its step counter before this step */
-  float qj[12], qb[4], basez, qvel[18], ctrl[12], warm[18], applied[18], cmd[4];
+  float qj[12], qb[4], basez, qvel[18], ctrl[12], warm[18], cmd[4];
   float xpos[GQ_NB][3];
   union { float xmat[GQ_NB][9]; float acc2[5][21]; };   /* acc2: Newton factor/solve exchange (xmat is dead after S6) */
   float cdof[GQ_NVD][6];
@@ -115,10 +115,12 @@ struct WaveMem {
   /* contacts */
   int32_t ncon, nefc, nlim, invalid;
   int32_t nself;               /* number of robot-robot contacts in the list (S6, BOXES variants) */
-  int32_t foot_touch[4];
+  int32_t foot_touch;          /* bit k: foot k's body touches a world geom (also when the contact fell to the row budget) */
   int32_t con_geom[GQ_MAXCON], con_body[GQ_MAXCON], con_dim[GQ_MAXCON], con_row[GQ_MAXCON];
   float con_dist[GQ_MAXCON], con_pos[GQ_MAXCON][3], con_mu[GQ_MAXCON], con_inc[GQ_MAXCON];
   float con_solref[GQ_MAXCON][2], con_solimp[GQ_MAXCON][5];
+  float con_t1[GQ_MAXCON][2];  /* floor contacts: first tangent (cos, sin, 0) of the contact frame - (0, 1) = mju_makeFrame's default
+                                * y axis; mjraw_PlaneCapsule aligns it with the capsule axis */
   float foot_world[4][3];
   union {                                               /* collision / limit scratch (S6-S7)  |  Newton scratch (S9) */
     struct { int32_t lim_jnt[GQ_NJ]; float lim_side[GQ_NJ], lim_dist[GQ_NJ]; float lg_dist[GQ_MAXLG], lg_pt[GQ_MAXLG][3]; } c;

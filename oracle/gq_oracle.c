@@ -40,8 +40,8 @@
 #define NB 14
 #define NJ 13
 #define NG 96
-#define NCON 48
-#define NEFC 512
+#define NCON 160
+#define NEFC 1024
 #define MINVAL 1e-15
 #define MINIMP 0.0001
 #define MINMU 1e-5
@@ -166,6 +166,10 @@ static char g_err[256];
 const char* gqo_last_error(void) { return g_err; }
 
 int gqo_create(const GqModelDesc* desc, GqOracle** out) {
+  if (desc->struct_size != (int32_t)sizeof(GqModelDesc)) {
+    snprintf(g_err, sizeof g_err, "oracle: GqModelDesc.struct_size %d, expected %d (include/gq.h ABI %d)", desc->struct_size, (int)sizeof(GqModelDesc), GQ_ABI_VERSION);
+    return GQ_EINVAL;
+  }
   if (desc->nq != NQ || desc->nv != NV || desc->nu > NU || desc->nbody > NB || desc->njnt > NJ || desc->ngeom > NG) {
     snprintf(g_err, sizeof g_err, "oracle: unsupported sizes nq=%d nv=%d nu=%d nbody=%d ngeom=%d", desc->nq, desc->nv,
              desc->nu, desc->nbody, desc->ngeom);
@@ -381,20 +385,37 @@ static void gqo_jac(const GqOracle* o, double jacp[3][NV], double jacr[3][NV], c
   }
 }
 
-/* ------------------------------------------------------------------ mj_collision: floor plane (z = 0) vs robot geoms.
- * plane-sphere is exact (mjc_PlaneSphere).  Other robot geoms are vertex clouds (+radius); this round keeps ONE
- * contact per geom at its deepest vertex, where MuJoCo's plane-box / plane-capsule / plane-mesh routines may
- * return several (documented deviation). */
-static void make_frame(double* f) { /* mju_makeFrame with only the x axis given */
+/* ------------------------------------------------------------------ mj_collision: floor plane (z = 0) vs robot geoms,
+ * MuJoCo's plane routines restated per geom type (engine_collision_primitive.c / engine_collision_convex.c):
+ *   sphere    mjraw_PlaneSphere   one point, exact
+ *   capsule   mjraw_PlaneCapsule  both end spheres (the +axis end first), every one within the margin; the contact frame's
+ *                                 first tangent is the capsule axis made orthogonal to the normal
+ *   box       mjraw_PlaneBox      the corners at or below the box centre that are within the margin, in corner order
+ *                                 (x sign = bit 0, y sign = bit 1, z sign = bit 2), at most 4
+ *   cylinder  mjc_PlaneCylinder   analytic: the lowest rim point of the end cap nearer the plane, the rim point under it on
+ *                                 the other cap, and two more points of the near cap at +-120 degrees (at most 4)
+ *   mesh      mjc_PlaneConvex     the support vertex of the hull (MuJoCo adds up to three neighbouring hull vertices inside
+ *                                 the margin; not restated - documented deviation)
+ * mju_makeFrame: the normal is the frame's x axis; the y axis is the one the routine supplied (capsule) or (0,1,0) /
+ * (0,0,1), made orthogonal to x; z = x cross y. */
+static void make_frame(double* f) { /* f[0..2] normal, f[3..5] tangent hint or zero */
   double n = sqrt(dot3(f, f));
   for (int k = 0; k < 3; k++) f[k] /= n;
-  f[3] = f[4] = f[5] = 0;
-  if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+  if (sqrt(dot3(f + 3, f + 3)) < 0.5) {
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+  }
   double t = dot3(f, f + 3);
   for (int k = 0; k < 3; k++) f[3 + k] -= t * f[k];
   n = sqrt(dot3(f + 3, f + 3));
-  for (int k = 0; k < 3; k++) f[3 + k] /= n;
+  if (n < MINVAL) { f[3] = 1; f[4] = 0; f[5] = 0; } /* mju_normalize3 of a null vector */
+  else for (int k = 0; k < 3; k++) f[3 + k] /= n;
   cross3(f + 6, f, f + 3);
+}
+static void set_frame(Contact* c, const double* normal, const double* tangent_hint) {
+  memcpy(c->frame, normal, 3 * sizeof(double));
+  for (int k = 0; k < 3; k++) c->frame[3 + k] = tangent_hint ? tangent_hint[k] : 0.0;
+  make_frame(c->frame);
 }
 
 static int is_foot(const GqModelDesc* m, int g) {
@@ -602,47 +623,92 @@ static void gqo_collision(GqOracle* o) {
     double r = m->cloud_radius[cl];
     /* bounding-sphere cull (mj broadphase equivalent for a plane) */
     if (o->geom_xpos[g][2] - m->geom_rbound[g] > margin) continue;
-    /* ONE point per (plane, geom) pair: the support vertex.  MuJoCo's plane routines return several for everything but a
-     * sphere (mjraw_PlaneCapsule both end spheres, mjraw_PlaneBox the corners below the box centre, at most 4, in corner
-     * order; mjc_PlaneConvex further support vertices of a mesh).  They are restated here behind GQO_PLANE_MULTIPOINT=1 and
-     * were tried in the kernel (round 2): the calf geoms of these robots reach the ground next to the foot spheres (aliengo's
-     * calf box: 4 corners + the foot = 5 contacts per standing leg, 20 per robot, 80 pyramid rows), which does not fit the
-     * 12 contacts / 63 rows one wavefront carries (lane = constraint row), so a standing robot lost its hind legs' contacts.
-     * The single support point per pair stays until the row capacity is lifted (known deviations). */
     const int nv = m->cloud_vertnum[cl], type = m->geom_type ? m->geom_type[g] : (nv == 1 ? 2 : (nv == 2 ? 3 : 7));
-    static double wv[4096][3];
-    double dv[4096];
-    double best = 1e300, second = 1e300;
-    int bi = -1;
-    for (int v = 0; v < nv && v < 4096; v++) {
-      mulmatvec3(wv[v], o->geom_xmat[g], m->vert_pos + 3 * (m->cloud_vertadr[cl] + v));
-      for (int k = 0; k < 3; k++) wv[v][k] += o->geom_xpos[g][k];
-      dv[v] = wv[v][2] - r;
-      if (dv[v] < best) { second = best; best = dv[v]; bi = v; }
-      else if (dv[v] < second) second = dv[v];
+    const double* gp = o->geom_xpos[g]; const double* gm = o->geom_xmat[g];
+    const double* V = m->vert_pos + 3 * m->cloud_vertadr[cl];
+    double pdist[4], ppos[4][3], hint[3] = {0, 0, 0}, tiegap = 1.0;
+    int np = 0, use_hint = 0;
+    if (type == 3 && nv == 2) { /* mjraw_PlaneCapsule: the cloud holds (-axis end, +axis end); MuJoCo tests the + end first */
+      for (int q = 0; q < 2; q++) {
+        const int v = 1 - q;
+        double w[3];
+        mulmatvec3(w, gm, V + 3 * v);
+        const double dist = w[2] + gp[2] - r;
+        if (dist >= margin) continue;
+        pdist[np] = dist;
+        for (int k = 0; k < 3; k++) ppos[np][k] = w[k] + gp[k] - normal[k] * (r + 0.5 * dist);
+        np++;
+      }
+      hint[0] = gm[2]; hint[1] = gm[5]; hint[2] = gm[8]; use_hint = 1;
+    } else if (type == 6 && nv == 8) { /* mjraw_PlaneBox */
+      const double dist0 = gp[2];
+      for (int v = 0; v < 8 && np < 4; v++) {
+        double w[3];
+        mulmatvec3(w, gm, V + 3 * v);
+        const double ldist = w[2];
+        if (dist0 + ldist >= margin || ldist > 0) continue;
+        pdist[np] = dist0 + ldist;
+        for (int k = 0; k < 3; k++) ppos[np][k] = w[k] + gp[k] - normal[k] * 0.5 * pdist[np];
+        np++;
+      }
+    } else if (type == 5 && nv == 32) { /* mjc_PlaneCylinder; radius and half length from the prism the cloud holds */
+      const double rad = sqrt(V[0] * V[0] + V[1] * V[1]), hl = fabs(V[2]);
+      double axis[3] = {gm[2], gm[5], gm[8]}, vec[3], prjaxis = axis[2];
+      if (prjaxis > 0) { for (int k = 0; k < 3; k++) axis[k] = -axis[k]; prjaxis = -prjaxis; }
+      const double dist0 = gp[2];
+      for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - normal[k];
+      const double len2 = dot3(vec, vec);
+      if (len2 >= MINVAL * MINVAL) { const double sc = rad / sqrt(len2); for (int k = 0; k < 3; k++) vec[k] *= sc; }
+      else { vec[0] = gm[0] * rad; vec[1] = gm[3] * rad; vec[2] = gm[6] * rad; } /* disk parallel to the plane: the cylinder's x axis */
+      const double prjvec = vec[2];
+      for (int k = 0; k < 3; k++) axis[k] *= hl;
+      prjaxis *= hl;
+      if (dist0 + prjaxis + prjvec < margin) {
+        pdist[np] = dist0 + prjaxis + prjvec;
+        for (int k = 0; k < 3; k++) ppos[np][k] = gp[k] + vec[k] + axis[k] - normal[k] * 0.5 * pdist[np];
+        np++;
+        if (dist0 - prjaxis + prjvec < margin) {
+          pdist[np] = dist0 - prjaxis + prjvec;
+          for (int k = 0; k < 3; k++) ppos[np][k] = gp[k] + vec[k] - axis[k] - normal[k] * 0.5 * pdist[np];
+          np++;
+        }
+        const double prjvec1 = -0.5 * prjvec;
+        if (dist0 + prjaxis + prjvec1 < margin) { /* two more points of the near cap: the triangle's other corners */
+          double vec1[3];
+          cross3(vec1, vec, axis);
+          const double n1 = sqrt(dot3(vec1, vec1));
+          if (n1 < MINVAL) { vec1[0] = 1; vec1[1] = 0; vec1[2] = 0; } else for (int k = 0; k < 3; k++) vec1[k] /= n1;
+          for (int k = 0; k < 3; k++) vec1[k] *= rad * sqrt(3.0) / 2;
+          for (int sgn = 1; sgn >= -1; sgn -= 2) {
+            pdist[np] = dist0 + prjaxis + prjvec1;
+            for (int k = 0; k < 3; k++) ppos[np][k] = gp[k] + sgn * vec1[k] + axis[k] - 0.5 * vec[k] - normal[k] * 0.5 * pdist[np];
+            np++;
+          }
+        }
+      }
+    } else { /* sphere: exact; mesh (and anything else): the support vertex of the cloud */
+      double best = 1e300, second = 1e300, bw[3] = {0, 0, 0};
+      for (int v = 0; v < nv; v++) {
+        double w[3];
+        mulmatvec3(w, gm, V + 3 * v);
+        const double dv = w[2] + gp[2] - r;
+        if (dv < best) { second = best; best = dv; for (int k = 0; k < 3; k++) bw[k] = w[k] + gp[k]; }
+        else if (dv < second) second = dv;
+      }
+      if (best < margin) {
+        pdist[0] = best;
+        for (int k = 0; k < 3; k++) ppos[0][k] = bw[k] - normal[k] * (r + 0.5 * best);
+        np = 1;
+        tiegap = second - best;
+      }
     }
-    if (best >= margin) continue;
-    int pick[4], npick = 0;
-    double tiegap = second - best;
-    static int multipoint = -1; /* GQO_PLANE_MULTIPOINT=1: MuJoCo's several points per plane-capsule / plane-box pair (experiment, see below) */
-    if (multipoint < 0) { const char* e = getenv("GQO_PLANE_MULTIPOINT"); multipoint = e ? atoi(e) : 0; }
-    if (multipoint && (type == 3 || nv <= 2)) { /* sphere / capsule: every end sphere within the margin */
-      for (int v = 0; v < nv; v++) if (dv[v] < margin) pick[npick++] = v;
-      tiegap = 1.0;
-    } else if (multipoint && type == 6 && nv == 8) { /* box: corners below the centre */
-      for (int v = 0; v < 8 && npick < 4; v++)
-        if (dv[v] < margin && wv[v][2] - o->geom_xpos[g][2] <= 0) pick[npick++] = v;
-      tiegap = 1.0;
-    } else pick[npick++] = bi; /* the support (deepest) vertex */
-    for (int q = 0; q < npick && o->ncon < NCON; q++) {
-      const int v = pick[q];
+    for (int q = 0; q < np && o->ncon < NCON; q++) {
       Contact* c = &o->contact[o->ncon++];
       c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0;
-      c->dist = dv[v];
+      c->dist = pdist[q];
       c->tiegap = tiegap;
-      for (int k = 0; k < 3; k++) c->pos[k] = wv[v][k] - normal[k] * (r + 0.5 * dv[v]);
-      memcpy(c->frame, normal, sizeof normal);
-      make_frame(c->frame);
+      memcpy(c->pos, ppos[q], sizeof c->pos);
+      set_frame(c, normal, use_hint ? hint : NULL);
       contact_param(o, -1, g, c);
     }
   }
@@ -688,8 +754,7 @@ static void gqo_collision(GqOracle* o) {
       Contact* c = &o->contact[o->ncon++];
       c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = best; c->tiegap = second - best;
       for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - bn[k] * (r + 0.5 * best); /* midway between the surfaces */
-      memcpy(c->frame, bn, sizeof bn);
-      make_frame(c->frame);
+      set_frame(c, bn, NULL);
       contact_param(o, w, g, c);
     }
   }
@@ -722,8 +787,7 @@ static void gqo_collision(GqOracle* o) {
       Contact* c = &o->contact[o->ncon++];
       c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = best; c->tiegap = second - best;
       for (int k = 0; k < 3; k++) c->pos[k] = bv[k] - bn[k] * (r + 0.5 * best);
-      memcpy(c->frame, bn, sizeof bn);
-      make_frame(c->frame);
+      set_frame(c, bn, NULL);
       contact_param(o, m->nbox, g, c);
     }
   /* robot self-collision: the statically filtered geom pairs (GqModelDesc::selfpair_*), capsule proxies in the body
@@ -743,8 +807,9 @@ static void gqo_collision(GqOracle* o) {
     if (dist >= margin || len < 1e-9) continue;
     Contact* c = &o->contact[o->ncon++];
     c->geom = g2; c->body = b2; c->geom1 = g1; c->body1 = b1; c->dist = dist; c->tiegap = 1.0;
-    for (int k = 0; k < 3; k++) { c->frame[k] = d[k] / len; c->pos[k] = c1[k] + c->frame[k] * (k1[6] + 0.5 * dist); }
-    make_frame(c->frame);
+    double nrm[3];
+    for (int k = 0; k < 3; k++) { nrm[k] = d[k] / len; c->pos[k] = c1[k] + nrm[k] * (k1[6] + 0.5 * dist); }
+    set_frame(c, nrm, NULL);
     contact_param_pair(o, g1, g2, c);
   }
 }

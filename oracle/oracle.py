@@ -95,7 +95,7 @@ class Oracle:
         self.L.gqo_step(self.h, _p(c))
 
     def get(self, name, n=None):
-        buf = np.zeros(n if n is not None else 512 * 18, dtype=np.float64)
+        buf = np.zeros(n if n is not None else 1024 * 18, dtype=np.float64)
         k = self.L.gqo_get(self.h, name.encode(), _p(buf), buf.size)
         if k < 0:
             raise KeyError(self.L.gqo_last_error().decode())

@@ -56,6 +56,7 @@ static inline float wave_sum(float v) { uint32_t u; memcpy(&u, &v, 4); const uin
 static inline float wave_min(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::min(r, t); } return r; }
 static inline float wave_max(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = -INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::max(r, t); } return r; }
 static inline float quad_sum(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); const int q = lane_id() & ~3; float r = 0; for (int i = 0; i < 4; i++) { float t; memcpy(&t, &s[q + i], 4); r += t; } return r; }
+static inline int wave_incl_scan(int v) { const uint32_t* s = exchange((uint32_t)v); int r = 0; for (int i = 0; i <= lane_id(); i++) r += (int)s[i]; return r; }
 static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 static inline void opaque(int&) {}

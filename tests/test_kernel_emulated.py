@@ -4,7 +4,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from helpers import ALL_OBS, dbg, default_reset_cfg, emu_reset, emu_step, marshalled, oracle_fits_self_budget, oracle_reset_lift, random_states, self_contact_states, split_obs
+from helpers import ALL_OBS, ParityTally, dbg, default_reset_cfg, emu_reset, emu_step, marshalled, oracle_fits_self_budget, oracle_reset_lift, random_states, self_contact_states, split_obs
 from oracle.oracle import Oracle
 from philox_ref import draws
 
@@ -130,17 +130,21 @@ def test_imu_truth_noise_and_bias_walk():
     imu = GqImuCfg(site_pos=(C.c_double * 3)(*pos), site_quat=(C.c_double * 4)(*quat), accel_noise=0.01, gyro_noise=0.02,
                    accel_bias_rate=0.03, gyro_bias_rate=0.04, seed=777)
     rng = np.random.default_rng(5)
-    n = 6
-    qpos, qvel = random_states(mm.md, n, rng, z_range=(0.25, 0.5))
+    n = 8
+    qpos, qvel = random_states(mm.md, n, rng, z_range=(0.3, 0.5))
     qvel = qvel.astype(np.float32)
     ctrl = (rng.normal(0, 1, (n, 12)) * 20).astype(np.float32)
     b0 = rng.normal(0, 0.1, (n, 6)).astype(np.float32)
     names = ['qpos'] + list(IMU_OBS)
     st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), obs_names=names, imu=imu, imu_bias=b0.copy(), step_num=np.arange(n) + 10,
                   episode=np.arange(n))
+    compared = 0
     for e in range(n):
         o.set_state(qpos[e], qvel[e], np.zeros(18), np.zeros(18), 0, -1)
         o.step(ctrl[e].astype(np.float64))
+        if not oracle_fits_self_budget(o, mm.md.cone):
+            continue   # more contacts than one wavefront's rows: the accelerations differ by construction
+        compared += 1
         got = split_obs(st['obs'][e], names)
         z = imu_normals(777, e, 10 + e, e)
         an, ab, gn, gb = z[0:3] * 0.01, b0[e, :3] + z[3:6] * 0.03, z[6:9] * 0.02, b0[e, 3:] + z[9:12] * 0.04
@@ -150,6 +154,7 @@ def test_imu_truth_noise_and_bias_walk():
         np.testing.assert_allclose(got['imu_acc_noise'], an, atol=1e-7); np.testing.assert_allclose(got['imu_gyro_noise'], gn, atol=1e-7)
         np.testing.assert_allclose(got['imu_acc_bias'], ab, atol=1e-6); np.testing.assert_allclose(got['imu_gyro_bias'], gb, atol=1e-6)
         np.testing.assert_allclose(st['imu_bias'][e], np.r_[ab, gb], atol=1e-6)
+    assert compared >= n // 2
     # free fall: the accelerometer reads zero (and +g once something holds the base still: a = 0 -> reading = -gravity)
     mm2 = marshalled('aliengo', solver=1)
     o2 = Oracle(mm2)
@@ -197,7 +202,7 @@ def test_auto_reset_same_step_and_next_step_agree():
 def test_elliptic_cone_step_matches_converged_oracle(robot):
     """Elliptic friction cones (cone="elliptic", impratio 100; go2 feet are condim 6: torsional + rolling rows): rows,
     regularisation and the Newton solution of the kernel against the fp64 oracle converged to 1e-12."""
-    n = 16
+    n = 24
     mm = marshalled(robot, solver=1, iterations=100, tolerance=1e-8, noise_floor=1e-5)
     mmN = marshalled(robot, solver=1, iterations=200, tolerance=1e-13)
     rng = np.random.default_rng(5)
@@ -210,12 +215,13 @@ def test_elliptic_cone_step_matches_converged_oracle(robot):
     st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), warm=warm.copy(), friction=fric.copy(), debug_envs=n)
     o = Oracle(mmN)
     ncon = nchecked = 0
+    tally = ParityTally(cone=True, tie_threshold=3e-7)
     for e in range(n):
         o.set_state(qpos[e], qvel[e].astype(np.float64), warm[e].astype(np.float64), np.zeros(18), 0.0, float(fric[e]))
         o.step(ctrl[e].astype(np.float64))
         rec = st['debug'][e]
         nefc = int(dbg(rec, 'nefc')[0])
-        if (o.ncon and o.get('contact_tiegap').min() < 3e-7) or nefc != o.nefc:
+        if tally.classify(e, o, nefc) != 'ok':
             continue
         nchecked += 1; ncon += o.ncon
         J = dbg(rec, 'efc_J').reshape(64, 18)[:nefc]
@@ -230,7 +236,9 @@ def test_elliptic_cone_step_matches_converged_oracle(robot):
         got = split_obs(st['obs'][e], ALL_OBS)
         for k in ('contact_forces:base', 'contact_forces', 'feet_vel', 'contact_state'):
             assert np.abs(got[k] - ref[k]).max() < 2e-3 * max(1.0, np.abs(ref[k]).max()), (e, k)
-    assert nchecked >= n // 2 and ncon >= nchecked
+    # go2: 12 friction-loss rows + four condim-6 feet (6 rows + 5 reserved virtual rows each) leave 8 of the 64 slots
+    tally.finish(f'elliptic {robot}', min_checked=0.4, max_tie=0.1, max_budget=0.6)
+    assert ncon >= nchecked
 
 
 def test_divergence_guard_freezes_and_flags_the_env():
@@ -299,11 +307,12 @@ def test_world_box_slab_equals_raised_floor_in_the_kernel():
     from gym_quadruped_amd.terrain import _box
     H = 1.37
     slab = _box([0.0, 0.0, H - 1.0], [0.0, 0.0, 0.0], [12.0, 12.0, 2.0])
-    mmF = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-8)
-    mmB = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-8, boxes=[slab])
+    # a hull robot (see test_flat_height_field_equals_raised_floor_in_the_kernel): one point per geom on the floor and on a box
+    mmF = marshalled('mini_cheetah', solver=1, iterations=100, tolerance=1e-8)
+    mmB = marshalled('mini_cheetah', solver=1, iterations=100, tolerance=1e-8, boxes=[slab])
     rng = np.random.default_rng(3)
     n = 8
-    qpos, qvel = random_states(mmF.md, n, rng, z_range=(0.3, 0.45))
+    qpos, qvel = random_states(mmF.md, n, rng, z_range=(0.18, 0.3))
     qvel = qvel.astype(np.float32)
     ctrl = (rng.normal(0, 1, (n, 12)) * 10).astype(np.float32)
     a = emu_step(mmF, ctrl, qpos.copy(), qvel.copy(), debug_envs=n)
@@ -398,11 +407,13 @@ def test_perlin_height_field_step_matches_oracle(robot):
 def test_flat_height_field_equals_raised_floor_in_the_kernel():
     H = 1.37
     flat = dict(data=np.zeros((17, 17), np.float32), size=(8.0, 8.0, 1.0, 0.01), pos=(0.0, 0.0, H))
-    mmF = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-8)
-    mmH = marshalled('aliengo', solver=1, iterations=100, tolerance=1e-8, hfield=flat)
+    # a hull robot: its geoms meet the plane and the height field alike in ONE point (the primitive geoms of aliengo take the
+    # multi-point plane routines on the floor and the single-point cloud rule on a height field)
+    mmF = marshalled('mini_cheetah', solver=1, iterations=100, tolerance=1e-8)
+    mmH = marshalled('mini_cheetah', solver=1, iterations=100, tolerance=1e-8, hfield=flat)
     rng = np.random.default_rng(3)
     n = 8
-    qpos, qvel = random_states(mmF.md, n, rng, z_range=(0.3, 0.45))
+    qpos, qvel = random_states(mmF.md, n, rng, z_range=(0.18, 0.3))
     qvel = qvel.astype(np.float32)
     ctrl = (rng.normal(0, 1, (n, 12)) * 10).astype(np.float32)
     a = emu_step(mmF, ctrl, qpos.copy(), qvel.copy(), debug_envs=n)
@@ -539,3 +550,66 @@ def test_newton_ends_on_captured_hard_states(robot):
         assert nit <= 20, (e, nit, o.solver_niter)
         qa = np.array(o.qacc)
         assert np.abs(st['qacc'][e] - qa).max() <= 2e-5 * max(1.0, np.abs(qa).max()), (e, nit)   # spot (condim 6, impratio 100): 8e-6; the others below 1e-6
+
+
+@pytest.mark.parametrize('robot', ['aliengo', 'go1', 'b2', 'hyqreal2', 'go2'])
+def test_plane_multipoint_contacts_match_oracle(robot):
+    """MuJoCo's multi-point plane routines in the kernel (csrc/gq_step_body.h floor_candidates: box corners, both capsule end
+    spheres with the axis-aligned frame, the cylinder's four rim points) against the oracle's restatement on poses that put
+    trunk, hip and thigh geoms on the floor: contact list (order, distances), rows, frames (through J) and the Newton solution.
+    States whose oracle row count exceeds one wavefront's budget are held to the PREFIX rule: the kernel's rows equal the
+    oracle's first rows."""
+    from test_oracle_invariants import _lying_states
+    mm = marshalled(robot, solver=1, iterations=100, tolerance=1e-8, noise_floor=1e-5, self_collision=False)
+    mmN = marshalled(robot, solver=1, iterations=200, tolerance=1e-13, self_collision=False)
+    md, o = mm.md, Oracle(mmN)
+    rng = np.random.default_rng(23)
+    hip = float(mm.desc.key_qpos[2])
+    cone = bool(md.cone)
+    # keep poses with a multi-point contact of a primitive geom, up to n of them
+    n, Q = 20, []
+    for q in _lying_states(md, 4000, rng, (0.25 * hip, 0.9 * hip)):
+        o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12), stage=1)
+        if not o.ncon or o.ncon > 10:
+            continue
+        g = o.get('contact_geom').astype(int)
+        if max(np.bincount(g)) >= 2:
+            Q.append(q)
+        if len(Q) == n:
+            break
+    assert len(Q) == n
+    qpos = np.stack(Q)
+    qvel = rng.normal(0, 0.5, (n, 18)).astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 10).astype(np.float32)
+    st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), debug_envs=n)
+    tally = ParityTally(cone=cone, tie_threshold=3e-7)
+    types = set()
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e].astype(np.float64), np.zeros(18), np.zeros(18)); o.step(ctrl[e].astype(np.float64))
+        rec = st['debug'][e]
+        nefc, ncon = int(dbg(rec, 'nefc')[0]), int(dbg(rec, 'ncon')[0])
+        cls = tally.classify(e, o, nefc)
+        if cls in ('tie', 'mismatch'):
+            continue
+        # contact list and rows: all of them ('ok') or the kernel's prefix of the oracle's list ('budget')
+        og = o.get('contact_geom').astype(int)
+        np.testing.assert_allclose(dbg(rec, 'contact_dist')[:ncon], o.get('contact_dist')[:ncon], atol=2e-6)
+        J = dbg(rec, 'efc_J').reshape(64, 18)[:nefc]
+        np.testing.assert_allclose(J, o.efc_J[:nefc], atol=3e-5 * max(1.0, np.abs(o.efc_J[:nefc]).max()))
+        np.testing.assert_allclose(dbg(rec, 'efc_R')[:nefc], o.efc_R[:nefc], rtol=3e-4)
+        np.testing.assert_allclose(dbg(rec, 'efc_aref')[:nefc], o.efc_aref[:nefc], atol=3e-4 * max(1.0, np.abs(o.efc_aref[:nefc]).max()))
+        ref, t, inv = o.get_obs(ALL_OBS, np.zeros(4))
+        assert bool(st['terminated'][e]) == t and bool(st['invalid'][e]) == inv   # body-level test, taken before any capping
+        if cls != 'ok':
+            continue
+        types |= {int(md.geom_type[g]) for g in og if np.count_nonzero(og == g) > 1}
+        assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 2e-4 * max(1.0, np.abs(o.qacc).max()), (e, dbg(rec, 'niter'))
+        fmax = max(1.0, np.abs(o.efc_force).max())
+        assert np.abs(dbg(rec, 'efc_force')[:nefc] - o.efc_force).max() < 2e-3 * fmax
+        assert np.abs(st['qvel'][e] - o.qvel).max() < 5e-4 and np.abs(st['qpos'][e] - o.qpos).max() < 2e-6
+        got = split_obs(st['obs'][e], ALL_OBS)
+        for k in ('contact_forces', 'contact_forces:base', 'contact_state'):
+            assert np.abs(got[k] - ref[k]).max() < 2e-3 * max(1.0, np.abs(ref[k]).max(), 0.05 * 9.81 * md.total_mass), (e, k)
+    tally.finish(f'plane multi-point {robot}', min_checked=0.4, max_tie=0.1, max_budget=0.6)
+    have = {int(t) for g, t in enumerate(md.geom_type) if md.geom_bodyid[g] != 0 and md.geom_cloudid[g] >= 0 and t in (3, 5, 6)}
+    assert types == have, (types, have)   # every primitive type of the robot produced a multi-point contact that was compared

@@ -347,3 +347,84 @@ def test_sloped_height_field_normals_and_cone():
     c = list(o2.get('contact_geom').astype(int)).index(mm2.md.geom_names.index('FL'))
     np.testing.assert_allclose(o2.contact_frame[c][0], [0, 0, 1], atol=1e-9)
     np.testing.assert_allclose(o2.get('contact_dist')[c], -0.001, atol=1e-9)
+
+
+def _lying_states(md, n, rng, z):
+    """Random orientations at low height: trunk, hips and thighs reach the floor (what the plane routines for boxes,
+    capsules and cylinders are for)."""
+    from scipy.spatial.transform import Rotation
+    q = np.tile(md.key_qpos[0], (n, 1))
+    q[:, 7:] += rng.uniform(-0.5, 0.5, (n, 12))
+    q[:, 2] = rng.uniform(*z, n)
+    q[:, 3:7] = Rotation.random(n, random_state=int(rng.integers(1 << 30))).as_quat(scalar_first=True)
+    return q
+
+
+@pytest.mark.parametrize('robot', ['aliengo', 'go1', 'go2', 'b2', 'hyqreal2'])
+def test_plane_routines_against_brute_force_geometry(robot):
+    """mjraw_PlaneBox / PlaneCapsule / mjc_PlaneCylinder as restated in gqo_collision, checked against the geometry itself:
+    every contact point lies on its geom's surface at the stated distance; a box reports exactly its corners at or below the
+    centre that are inside the margin (at most 4); a capsule both end spheres inside the margin, +axis end first, frame
+    tangent = the axis projected onto the floor; a cylinder's first point is the lowest point of a densely sampled rim, the
+    second the point under it on the other cap, the last two the other corners of the near cap's inscribed triangle."""
+    mm = marshalled(robot, solver=1, self_collision=False)
+    md, o = mm.md, Oracle(mm)
+    rng = np.random.default_rng(17)
+    hip = float(mm.desc.key_qpos[2])
+    Q = _lying_states(md, 300, rng, (0.05, 0.6 * hip))
+    seen = {3: 0, 5: 0, 6: 0}
+    multi = {3: 0, 5: 0, 6: 0}
+    for q in Q:
+        o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12), stage=1)
+        if not o.ncon:
+            continue
+        geoms, dist = o.get('contact_geom').astype(int), o.get('contact_dist')
+        pos, frame = o.contact_pos, o.contact_frame
+        gx, gm = o.geom_xpos, o.geom_xmat
+        world = o.get('contact_geom1') < 0
+        for g in np.unique(geoms[world]):
+            t = int(md.geom_type[g])
+            if t not in seen:
+                continue
+            idx = np.nonzero((geoms == g) & world)[0]
+            assert len(idx) <= (2 if t == 3 else 4) and np.all(np.diff(idx) == 1)
+            seen[t] += 1; multi[t] += len(idx) > 1
+            R, c = gm[g], gx[g]
+            margin = max(md.geom_margin[g], 0.0)
+            cl = md.geom_cloudid[g]
+            V = md.vert_pos[md.cloud_vertadr[cl]:md.cloud_vertadr[cl] + md.cloud_vertnum[cl]]
+            assert np.allclose(frame[idx, 0], [0, 0, 1])
+            # the surface point of every contact: midway point pushed back by dist / 2
+            surf = pos[idx] + np.outer(0.5 * dist[idx], [0, 0, 1])
+            np.testing.assert_allclose(surf[:, 2], dist[idx], atol=1e-12)
+            if t == 6:
+                corners = c + V @ R.T
+                want = [i for i in range(8) if corners[i, 2] <= c[2] and corners[i, 2] < margin][:4]
+                np.testing.assert_allclose(surf, corners[want], atol=1e-12)
+            elif t == 3:
+                r = md.cloud_radius[cl]
+                ends = c + V[::-1] @ R.T                  # +axis end first
+                want = [i for i in range(2) if ends[i, 2] - r < margin]
+                np.testing.assert_allclose(surf, ends[want] - [0, 0, r], atol=1e-12)
+                ax = R[:, 2] - np.array([0, 0, R[2, 2]])
+                np.testing.assert_allclose(frame[idx, 1], np.tile(ax / np.linalg.norm(ax), (len(idx), 1)), atol=1e-9)
+            else:
+                rad, hl = np.hypot(V[0, 0], V[0, 1]), abs(V[0, 2])
+                loc = (surf - c) @ R                      # contact surface points in the geom frame: on a rim
+                np.testing.assert_allclose(np.hypot(loc[:, 0], loc[:, 1]), rad, atol=1e-9)
+                np.testing.assert_allclose(np.abs(loc[:, 2]), hl, atol=1e-9)
+                th = np.linspace(0, 2 * np.pi, 20001)
+                rim = np.stack([rad * np.cos(th), rad * np.sin(th)], 1)
+                low = min((c + np.c_[rim, np.full(len(th), s * hl)] @ R.T)[:, 2].min() for s in (-1, 1))
+                assert abs(dist[idx[0]] - low) < 1e-7     # the first point is the deepest point of the cylinder
+                if len(idx) > 1 and abs(loc[1, 2] + loc[0, 2]) < 1e-9:   # second point: same rim angle, other cap
+                    np.testing.assert_allclose(loc[1, :2], loc[0, :2], atol=1e-9)
+                if len(idx) >= 3:                          # the near cap's other two points sit at +-120 degrees
+                    a0 = np.arctan2(loc[0, 1], loc[0, 0])
+                    for k in (-2, -1):
+                        d = (np.arctan2(loc[k, 1], loc[k, 0]) - a0 + np.pi) % (2 * np.pi) - np.pi
+                        assert abs(abs(d) - 2 * np.pi / 3) < 1e-6 and abs(loc[k, 2] - loc[0, 2]) < 1e-9
+    have = {int(t) for g, t in enumerate(md.geom_type) if md.geom_bodyid[g] != 0 and md.geom_cloudid[g] >= 0}
+    for t in (3, 5, 6):
+        if t in have:
+            assert seen[t] >= 10 and multi[t] >= 3, (robot, t, seen, multi)
