@@ -57,7 +57,7 @@ extern "C" {
 /* ABI revision of this header.  gq_version() returns the revision the LIBRARY was built from: a binding compares the two
  * before its first call (gym_quadruped_amd/_lib.py does), and gq_struct_sizes() lets it check its own mirror of every struct
  * that crosses the boundary.  History: 100 round 1; 300 = GqModelDesc.struct_size + the self-collision / geom_type tables,
- * GqObsOut.step_num_prev, gq_heightmap_strided, gq_contact_force, gq_step_outputs (round 3). */
+ * GqObsOut.step_num_prev, strided HeightMap views, the round-3 entry points. */
 #define GQ_ABI_VERSION 300
 
 typedef struct GqModelDesc {
