@@ -22,16 +22,35 @@ namespace gq {
 
 /* The lane index is deliberately opaque to the optimiser (empty asm volatile): per-lane address arithmetic then stays
  * next to its use instead of being hoisted to the kernel prologue and kept live (or spilled) across the whole step. */
+#ifndef GQ_WPB
+#define GQ_WPB 1 /* wavefronts (= envs) per workgroup */
+#endif
 __device__ __forceinline__ int lane_id() {
-  int l = (int)threadIdx.x;
+  int l = GQ_WPB == 1 ? (int)threadIdx.x : (int)(threadIdx.x & (GQ_WAVE - 1));
   asm volatile("" : "+v"(l));
   return l;
+}
+/* index of this wavefront's env within the launch */
+__device__ __forceinline__ int wave_index() {
+  return GQ_WPB == 1 ? (int)blockIdx.x : (int)blockIdx.x * GQ_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 
 /* LDS hand-off between lanes of the single wavefront of this workgroup.  With a 64-thread workgroup the
  * s_barrier degenerates (LLVM drops it for single-wave groups) and what remains is the lgkmcnt wait + the
  * compiler-level ordering of LDS accesses. */
-__device__ __forceinline__ void wave_barrier() { __syncthreads(); }
+#ifndef GQ_FENCE_BARRIER
+#define GQ_FENCE_BARRIER 0
+#endif
+__device__ __forceinline__ void wave_barrier() {
+#if GQ_FENCE_BARRIER
+  /* the LDS executes the DS instructions of one wavefront in order: a ds_read issued after a ds_write of another lane of the
+   * same wave sees the data without any wait - only the COMPILER must not reorder them */
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#else
+  __syncthreads();
+#endif
+}
 
 /* broadcast lane `src` (wave-uniform index) - v_readlane_b32 */
 __device__ __forceinline__ float bcast(float v, int src) {
@@ -97,7 +116,7 @@ __device__ __forceinline__ int dpp_mov_zero(int v) { return __builtin_amdgcn_upd
 __device__ __forceinline__ int wave_incl_scan(int v) {
   v += dpp_mov_zero<0x111>(v); v += dpp_mov_zero<0x112>(v); v += dpp_mov_zero<0x114>(v); v += dpp_mov_zero<0x118>(v);
   const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
-  const int row = (int)threadIdx.x >> 4;
+  const int row = ((int)threadIdx.x & (GQ_WAVE - 1)) >> 4;
   return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
 }
 

@@ -4,6 +4,8 @@
  * (4 waves per SIMD, 16 per CU); workgroup b lands on XCD b % 8, so consecutive envs spread over all eight L2s and
  * every XCD keeps its own copy of the read-only model block.
  */
+#include <cstdio>
+#include <cstdlib>
 #include <gq_device.h>
 #include "gq_step_body.h"
 
@@ -14,10 +16,13 @@ namespace gq {
  * its two-pass waves.  Next-step mode: the env waits (pending flag) and spends its next launch on reset_wave + the
  * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
 template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF>
-__global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
-  const int env = (int)blockIdx.x + c.env0;
+__global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
+  const int widx = wave_index();
+  if (GQ_WPB > 1 && widx >= c.count) return;
+  const int env = widx + c.env0;
   if (c.mask && !gptr(c.mask)[env]) return; /* wave-uniform */
-  __shared__ WaveMem W;
+  __shared__ WaveMem Ws[GQ_WPB];
+  WaveMem& W = Ws[GQ_WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
   int pass = c.first_pass;
   bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[env]; /* wave-uniform */
   /* the reset's own step after an explicit gq_reset: the reset kernel left word whether the lift loop is still due */
@@ -35,9 +40,12 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) step_kernel(const FusedArgs* __res
 }
 
 template <bool BOXES>
-__global__ void __launch_bounds__(GQ_WAVE) reset_kernel(ResetArgs a) {
-  if (a.mask && !gptr(a.mask)[blockIdx.x]) return;
-  __shared__ WaveMem W;
+__global__ void __launch_bounds__(GQ_WAVE * GQ_WPB) reset_kernel(ResetArgs a, const int n_envs) {
+  const int widx = wave_index();
+  if (GQ_WPB > 1 && widx >= n_envs) return;
+  if (a.mask && !gptr(a.mask)[widx]) return;
+  __shared__ WaveMem Ws[GQ_WPB];
+  WaveMem& W = Ws[GQ_WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
   reset_wave<BOXES>(a, W);
 }
 
@@ -253,22 +261,37 @@ extern "C" void gq_launch_heightmap(const GQ_GLOBAL GqDevModel* model, const dou
   hipLaunchKernelGGL(gq::heightmap_kernel, dim3(n_envs), dim3(GQ_WAVE), 0, stream, model, center, center_stride, yaw, yaw_stride, n_envs, rows, cols, dist_x, dist_y, out);
 }
 
+/* Development builds (tools/dev_build.sh: -DGQ_DEV_ONLY=<0|1>, cone = 0 pyramidal / 1 elliptic) instantiate only the flat-scene
+ * self-collision Newton variants (production + instrumented) - a 15 s build for A/B timing of kernel experiments through
+ * GQ_LIBGQ_PATH; any other launch aborts.  The product library is built without the macro and carries every variant. */
+template <int S, int M, bool C, bool B, bool SF>
+static void launch_variant(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, hipStream_t stream) {
+#ifdef GQ_DEV_ONLY
+  if constexpr (!(S == 1 && M != 2 && !B && SF && C == (GQ_DEV_ONLY != 0))) { fprintf(stderr, "libgq development build: kernel variant not compiled in\n"); abort(); } else
+#endif
+  {
+    gq::StepCall call = *c;
+    call.count = n_envs;
+    hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
+  }
+}
+
 extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, int self, hipStream_t stream) {
   /* 0: production; 1: debug record + stage timers; 2: stage cut (GQ_STOP_STAGE / gq_debug_stop_stage) - the early returns
    * of the cut cost the production kernel ~8 % when merely compiled in, hence a variant of their own.
    * Scene variants: flat (no world geoms beyond the floor), flat + robot self-collision, world boxes / height field (always
    * with the self-collision stage compiled in; a model without pairs skips it at run time). */
   const int mode = c->debug != nullptr ? 1 : (c->stop_stage != 0 ? 2 : 0);
-#define GQ_LAUNCH(S, M, C) do { if (boxes) hipLaunchKernelGGL((gq::step_kernel<S, M, C, true, true>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c); \
-                                else if (self) hipLaunchKernelGGL((gq::step_kernel<S, M, C, false, true>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c); \
-                                else hipLaunchKernelGGL((gq::step_kernel<S, M, C, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c); } while (0)
+#define GQ_LAUNCH(S, M, C) do { if (boxes) launch_variant<S, M, C, true, true>(dev_args, c, n_envs, stream); \
+                                else if (self) launch_variant<S, M, C, false, true>(dev_args, c, n_envs, stream); \
+                                else launch_variant<S, M, C, false, false>(dev_args, c, n_envs, stream); } while (0)
 #define GQ_LAUNCH_MODE(S, C) do { if (mode == 1) GQ_LAUNCH(S, 1, C); else if (mode == 2) GQ_LAUNCH(S, 2, C); else GQ_LAUNCH(S, 0, C); } while (0)
   if (solver == 1 && cone) GQ_LAUNCH_MODE(1, true);
   else if (solver == 1) GQ_LAUNCH_MODE(1, false);
   else { /* PGS: floor plane only (gq_model_create rejects world boxes / self-collision with solver 0) */
-    if (mode == 1) hipLaunchKernelGGL((gq::step_kernel<0, 1, false, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
-    else if (mode == 2) hipLaunchKernelGGL((gq::step_kernel<0, 2, false, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
-    else hipLaunchKernelGGL((gq::step_kernel<0, 0, false, false, false>), dim3(n_envs), dim3(GQ_WAVE), 0, stream, dev_args, *c);
+    if (mode == 1) launch_variant<0, 1, false, false, false>(dev_args, c, n_envs, stream);
+    else if (mode == 2) launch_variant<0, 2, false, false, false>(dev_args, c, n_envs, stream);
+    else launch_variant<0, 0, false, false, false>(dev_args, c, n_envs, stream);
   }
 #undef GQ_LAUNCH_MODE
 #undef GQ_LAUNCH
@@ -280,6 +303,6 @@ extern "C" void gq_launch_ray(const GQ_GLOBAL GqDevModel* model, const double* o
   hipLaunchKernelGGL(gq::ray_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, model, origin, dir, total, dist, geom);
 }
 extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, int boxes, hipStream_t stream) {
-  if (boxes) hipLaunchKernelGGL(gq::reset_kernel<true>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
-  else hipLaunchKernelGGL(gq::reset_kernel<false>, dim3(n_envs), dim3(GQ_WAVE), 0, stream, *a);
+  if (boxes) hipLaunchKernelGGL(gq::reset_kernel<true>, dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, *a, n_envs);
+  else hipLaunchKernelGGL(gq::reset_kernel<false>, dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, *a, n_envs);
 }

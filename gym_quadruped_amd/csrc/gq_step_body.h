@@ -286,7 +286,7 @@ template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF>
 __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
-  int lane_o = lane_id(), env_o = (int)blockIdx.x + uniform(call.env0);
+  int lane_o = lane_id(), env_o = wave_index() + uniform(call.env0);
   opaque(lane_o); opaque_s(env_o);
   const int lane = lane_o, env = env_o;
   constexpr bool DBG = MODE == 1;
@@ -1258,7 +1258,7 @@ enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH =
 #define GQ_LIFT_RULE_ITERS 4
 template <bool BOXES>
 __device__ inline int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 = 0) {
-  int lane_o = lane_id(), env_o = (int)blockIdx.x + uniform(env0);
+  int lane_o = lane_id(), env_o = wave_index() + uniform(env0);
   opaque(lane_o); opaque_s(env_o); /* see step_wave: no address arithmetic may be hoisted to the kernel prologue */
   const int lane = lane_o, env = env_o;
   const GQ_MODEL GqDevModel& m = *mptr(a.model);

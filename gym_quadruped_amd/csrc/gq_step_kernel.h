@@ -62,6 +62,7 @@ struct StepCall {
   int32_t env0;         /* first env of this launch (gq_step_range); env = env0 + blockIdx.x */
   int32_t forward;      /* gq_forward (instrumented variant only): 1 = mj_step1 (return after the constraint rows), 2 = mj_forward (return
                          * after the accelerations); nothing but qacc and the inspection record is written */
+  int32_t count;        /* envs of this launch: wavefronts past env0 + count (the last workgroup of a multi-wave launch) return at once */
   int32_t stop_stage;   /* profiling aid (env GQ_STOP_STAGE, tools/stage_insts.sh): return after stage marker i; 0 = run everything */
 };
 

@@ -166,6 +166,20 @@ def oracle_fits_row_budget(o, cone):
     return o.ncon <= GQ_MAXCON and o.nefc <= GQ_MAXEFC and o.nefc + reserve <= (64 if cone else GQ_MAXEFC)
 
 
+def tally_note(msg):
+    """Print a measured tally line and keep it: GPU sessions append to gpurun_out/parity_tallies.txt (merged back by gpurun,
+    copied to profiles/rNN_parity_tallies.txt), so the numbers the test bounds were set from are on record."""
+    print(msg)
+    try:
+        import os
+        f = os.environ.get('GQ_TALLY_FILE', str(ROOT / 'gpurun_out' / 'parity_tallies.txt'))
+        os.makedirs(os.path.dirname(f), exist_ok=True)
+        with open(f, 'a') as fh:
+            fh.write(msg + '\n')
+    except OSError:
+        pass
+
+
 class ParityTally:
     """Why an env was (not) compared value-by-value.  `mismatch` - kernel and oracle disagree on the number of constraint
     rows although the oracle's set fits the kernel's budget and no deepest-vertex tie explains it - is a FAILURE, never a
@@ -191,10 +205,29 @@ class ParityTally:
         self.checked += 1
         return 'ok'
 
+    def check_budget_prefix(self, e, o, nefc_kernel, J=None, R=None, aref=None, flags=None):
+        """An env over the row budget is not skipped altogether: the kernel keeps a PREFIX of MuJoCo's constraint list
+        (friction-loss rows, limit rows, whole contacts in order), so its rows must equal the oracle's first `nefc_kernel`
+        rows, and the termination flags - taken from the uncapped contact list - must be the oracle's.  Only the solution
+        (forces, qacc) of such an env is out of reach of the comparison."""
+        k = int(nefc_kernel)
+        if J is not None:
+            Jo = o.efc_J[:k]
+            assert np.abs(np.asarray(J).reshape(64, 18)[:k] - Jo).max() <= 3e-5 * max(1.0, np.abs(Jo).max()), (e, 'efc_J prefix')
+        if R is not None:
+            np.testing.assert_allclose(np.asarray(R)[:k], o.efc_R[:k], rtol=3e-4, err_msg=f'env {e}: efc_R prefix')
+        if aref is not None:
+            ao = o.efc_aref[:k]
+            assert np.abs(np.asarray(aref)[:k] - ao).max() <= 3e-4 * max(1.0, np.abs(ao).max()), (e, 'efc_aref prefix')
+        if flags is not None:
+            _, t, inv = o.get_obs(['qpos'])
+            assert (bool(flags[0]), bool(flags[1])) == (t, inv), (e, 'termination flags of an over-budget env')
+        self.budget_prefix_checked = getattr(self, 'budget_prefix_checked', 0) + 1
+
     def report(self, what):
         msg = (f'{what}: {self.n} envs, {self.checked} compared, {self.tie} deepest-vertex ties, {self.budget} over the row '
-               f'budget, {len(self.mismatch)} MISMATCHED {self.mismatch[:8]}')
-        print(msg)
+               f'budget ({getattr(self, "budget_prefix_checked", 0)} of them held to the prefix rule), {len(self.mismatch)} MISMATCHED {self.mismatch[:8]}')
+        tally_note(msg)
         return msg
 
     def finish(self, what, min_checked, max_tie, max_budget):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import ALL_OBS, ParityTally, marshalled, random_states, self_contact_states, split_obs
+from helpers import ALL_OBS, ParityTally, marshalled, random_states, self_contact_states, split_obs, tally_note
 
 pytestmark = pytest.mark.gpu
 
@@ -232,7 +232,7 @@ def test_newton_step_matches_converged_oracle(robot):
     env.enable_debug(n)
     obs, rew, term, trunc, info = env.step(torch.as_tensor(ctrl))
     torch.cuda.synchronize()
-    dbg = env.debug_internals(n, ['qacc', 'niter', 'nefc'])
+    dbg = env.debug_internals(n, ['qacc', 'niter', 'nefc', 'efc_J', 'efc_R', 'efc_aref'])
     o = Oracle(mmN)
     qp, qv, ob = env.qpos.cpu().numpy(), env.qvel.cpu().numpy(), env._obs_buf.cpu().numpy()
     tg, ig = term.cpu().numpy(), info['invalid_contacts'].cpu().numpy()
@@ -244,7 +244,10 @@ def test_newton_step_matches_converged_oracle(robot):
     for e in range(n):
         o.set_state(qpos[e], qvel[e], warm[e], np.zeros(18), 0.0, 0.8)
         o.step(ctrl[e].astype(np.float64))
-        if tally.classify(e, o, dbg[e]['nefc'][0]) != 'ok':
+        cls = tally.classify(e, o, dbg[e]['nefc'][0])
+        if cls == 'budget':   # more rows than one wavefront carries: the kernel's rows are the oracle's first rows, the flags the oracle's
+            tally.check_budget_prefix(e, o, dbg[e]['nefc'][0], dbg[e]['efc_J'], dbg[e]['efc_R'], dbg[e]['efc_aref'], (tg[e], ig[e]))
+        if cls != 'ok':
             continue   # tie / over the row budget: counted and bounded below; a row-count mismatch fails the test
         ncon += o.ncon
         ea.append(np.abs(dbg[e]['qacc'] - o.qacc).max() / max(1.0, np.abs(o.qacc).max()))
@@ -264,9 +267,12 @@ def test_newton_step_matches_converged_oracle(robot):
           dict(qacc=(2e-5, 1e-3), qvel=(5e-5, 2e-3), qpos=(2.5e-6, 3.5e-6), obs=(3e-4, 5e-3), force=(5e-5, 1e-3))
     for name, err in (('qacc', ea), ('qvel', ev), ('qpos', ep), ('obs', eo), ('force', ef)):
         assert p99(err) < lim[name][0] and max(err) < lim[name][1], (robot, name, p99(err), max(err))
-    # robots with many small collision geoms (go1 / go2: 38 / 27 link geoms) exceed the 64-row budget when lying flat
-    tally.finish(f'newton one-step parity {robot}', min_checked=0.8 if env.mjModel.cone == 0 else 0.6, max_tie=0.1,
-                 max_budget=0.15 if env.mjModel.cone == 0 else 0.4)
+    # These random states press trunk and thighs into the floor; with MuJoCo's multi-point plane routines a lying box-geom
+    # robot carries 4 contacts per box (measured over-budget share on MI355X, profiles/r03_parity_tallies.txt: mini_cheetah 0,
+    # aliengo 0.16, hyqreal2 0.18, b2 0.24, go1 / go2 <= 0.4).  The benchmark's own states (test_step_parity_on_benchmark_
+    # rollout_states) stay inside the budget; here the over-budget envs are held to the prefix rule instead of being skipped.
+    tally.finish(f'newton one-step parity {robot}', min_checked=0.7 if env.mjModel.cone == 0 else 0.5, max_tie=0.1,
+                 max_budget=0.3 if env.mjModel.cone == 0 else 0.5)
     assert ncon > 0.8 * n
 
 
@@ -773,7 +779,8 @@ def test_newton_ends_on_captured_hard_states(robot):
         assert np.abs(d[e]['qacc'] - qa).max() <= 2e-5 * max(1.0, np.abs(qa).max()), e
 
 
-@pytest.mark.parametrize('robot,scene', [('mini_cheetah', 'flat'), ('go2', 'flat'), ('aliengo', 'flat'), ('hyqreal1', 'flat')])
+@pytest.mark.parametrize('robot,scene', [('mini_cheetah', 'flat'), ('go2', 'flat'), ('aliengo', 'flat'), ('hyqreal1', 'flat'), ('b2', 'flat'),
+                                         ('go1', 'flat'), ('aliengo', 'perlin'), ('hyqreal1', 'random_boxes')])   # BASELINE configs 2-5 (+ b2, go1)
 def test_step_parity_on_benchmark_rollout_states(robot, scene):
     """One-step parity on the states the BENCHMARK visits (random torques 50 N(0,1), auto-reset, 120 steps in: robots falling,
     lying, tangled - the distribution the random-state tests do not draw): a sample of envs is stepped by the kernel and by
@@ -794,24 +801,30 @@ def test_step_parity_on_benchmark_rollout_states(robot, scene):
     env.step(a)
     torch.cuda.synchronize()
     ctrl = a.cpu().numpy()
-    d = env.debug_internals(n, ['qacc', 'nefc', 'ncon', 'niter'])
+    d = env.debug_internals(int(idx.max()) + 1, ['qacc', 'nefc', 'ncon', 'niter', 'efc_J', 'efc_R', 'efc_aref'])
     qv = env.qvel.cpu().numpy()
+    tg, ig = env._terminated.cpu().numpy(), env._invalid.cpu().numpy()
     o = _oracle(env)
     cone = env.mjModel.cone == 1
-    tally = ParityTally(cone, 3e-7)
+    tally = ParityTally(cone, 3e-7 if scene == 'flat' else 3e-6)
     ea, ev, nit = [], [], []
     for e in idx:
         o.set_state(qpos[e], qvel[e].astype(np.float64), warm[e].astype(np.float64), app[e].astype(np.float64), 0.0, float(fr[e]))
         o.step(ctrl[e].astype(np.float64))
-        if tally.classify(e, o, d[e]['nefc'][0]) != 'ok':
+        cls = tally.classify(e, o, d[e]['nefc'][0])
+        if cls == 'budget':
+            tally.check_budget_prefix(e, o, d[e]['nefc'][0], d[e]['efc_J'], d[e]['efc_R'], d[e]['efc_aref'], (tg[e], ig[e]))
+        if cls != 'ok':
             continue
         assert int(d[e]['ncon'][0]) == o.ncon
         ea.append(np.abs(d[e]['qacc'] - o.qacc).max() / max(1.0, np.abs(o.qacc).max()))
         ev.append(np.abs(qv[e] - o.qvel).max() / max(1.0, 0.002 * np.abs(o.qacc).max()))
         nit.append((int(d[e]['niter'][0]), o.solver_niter))
     p99 = lambda x: float(np.percentile(x, 99))
-    print(f'{robot} {scene}: qacc rel p50 {np.median(ea):.2e} p99 {p99(ea):.2e} max {max(ea):.2e}; qvel p99 {p99(ev):.2e} max {max(ev):.2e}; '
+    tally_note(f'benchmark-state errors {robot} {scene}: qacc rel p50 {np.median(ea):.2e} p99 {p99(ea):.2e} max {max(ea):.2e}; qvel p99 {p99(ev):.2e} max {max(ev):.2e}; '
           f'niter kernel mean {np.mean([x[0] for x in nit]):.2f} oracle {np.mean([x[1] for x in nit]):.2f}')
     assert p99(ea) < (1e-4 if cone else 2e-5) and max(ea) < 2e-3, (p99(ea), max(ea))
     assert p99(ev) < (7e-4 if cone else 5e-5) and max(ev) < 5e-3, (p99(ev), max(ev))
-    tally.finish(f'benchmark-state one-step parity {robot} {scene}', min_checked=0.4, max_tie=0.2, max_budget=0.6)
+    # measured on MI355X (profiles/r03_parity_tallies.txt): 0 of 160 over the row budget for every robot on flat; ties only on
+    # hull robots.  A regression that drops contacts shows up as budget / mismatch counts far above these bounds.
+    tally.finish(f'benchmark-state one-step parity {robot} {scene}', min_checked=0.85, max_tie=0.12, max_budget=0.03)

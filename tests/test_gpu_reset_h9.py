@@ -295,3 +295,69 @@ def test_pipelined_rollout_equals_the_step_loop():
     assert torch.equal(a.sensors[0].bias_state, b.sensors[0].bias_state)
     assert torch.equal(torch.stack(rows), out)
     assert int(a._episode.max()) > 1, 'the rollout must contain auto-resets'
+
+
+@pytest.mark.parametrize('robot,scene', [('hyqreal1', 'random_boxes'), ('aliengo', 'random_boxes'), ('aliengo', 'perlin')])
+def test_box_scene_lift_loop_follows_the_reference_rule_and_how_often_it_leaves_it(robot, scene):
+    """QuadrupedEnv.reset on a scene with world geoms beyond the floor: the reference lifts by 1.1 max|dist| per mj_step1 until
+    no calf-body contact is left (quadruped_env.py:376-388).  The kernel follows that rule for GQ_LIFT_RULE_ITERS = 4
+    iterations and then clears the top of whatever is still touched (the rule converges geometrically out of a
+    steep side face and the reference raises after 100 iterations).  Here: the spawn state of every env is rebuilt from the
+    Philox draw table, the reference rule is run on the oracle, and (i) every env the rule settles within 4 iterations must
+    come out of gq_reset exactly where the oracle's rule + mj_step put it, (ii) the share of envs where the kernel leaves
+    the rule is counted, bounded and written to the parity tallies."""
+    from oracle.oracle import Oracle
+    from scipy.spatial.transform import Rotation
+    n, seed = 384, 20250929
+    env = _env(robot, n, seed=seed, scene=scene, solver='newton', state_obs_names=('qpos', 'qvel'))
+    lim = env.terrain_limits
+    env.reset(random=True)
+    torch.cuda.synchronize()
+    qp, qv = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
+    failed = env.lift_failed.cpu().numpy().astype(bool)
+    key = np.asarray(env.mjModel.key_qpos[0])
+    hip = float(env.robot_cfg.hip_height)
+    o = Oracle(env._mm)
+    amp = np.float32(20 * np.pi / 180)
+
+    def calf_contacts():
+        o.forward(np.zeros(12), stage=1)
+        if not o.ncon:
+            return np.zeros(0)
+        b = o.get('contact_body').astype(int)
+        w = o.get('contact_geom1') < 0      # contacts with world geoms
+        return o.get('contact_dist')[w & ((b - 2) % 3 == 2)]
+    within = beyond = lifted = same = 0
+    for e in range(n):
+        u = draws(seed, e, 0)
+        q0 = key.copy()
+        q0[7:] = key[7:] + (2 * u[0:12] - 1) * amp
+        v0 = np.zeros(18); v0[6:] = (2 * u[12:24] - 1) * 0.5
+        x = lim[0] + (lim[1] - lim[0]) * float(u[24]); y = lim[2] + (lim[3] - lim[2]) * float(u[25])
+        roll, pitch = (2 * u[26] - 1) * np.float32(10 * np.pi / 180), (2 * u[27] - 1) * np.float32(10 * np.pi / 180)
+        q0[0], q0[1] = x, y
+        q0[3:7] = Rotation.from_euler('xyz', [roll, pitch, np.arctan2(-y, -x)]).as_quat(scalar_first=True)
+        z, it = hip, 0
+        while it < 100:
+            o.set_state(np.r_[q0[:2], z, q0[3:]], v0, np.zeros(18), np.zeros(18), 0.0, -1.0)
+            d = calf_contacts()
+            if not len(d):
+                break
+            z += 1.1 * np.abs(d).max()
+            it += 1
+        lifted += it > 0
+        if it > 4:
+            beyond += 1      # the kernel switched to "clear the top": higher than the rule, never in contact
+            assert failed[e] or qp[e, 2] >= z - 0.05
+            continue
+        within += 1
+        o.set_state(np.r_[q0[:2], z, q0[3:]], v0, np.zeros(18), np.zeros(18), 0.0, -1.0)
+        o.step(np.zeros(12))
+        ok = np.abs(qp[e] - o.qpos).max() < 5e-6 + 1e-9 * np.abs(o.qpos).max() and np.abs(qv[e] - o.qvel).max() < 5e-4
+        same += ok
+        assert ok or it >= 3, (e, it, qp[e, :3], o.qpos[:3])   # the 4th iteration's fp32 / fp64 touch test may differ by a hair
+    msg = (f'reset lift loop {robot} {scene}: {n} envs, {lifted} lifted, {within} settled by the reference rule within 4 iterations '
+           f'({same} bit-for-tolerance equal to the oracle), {beyond} where the kernel leaves the rule, {int(failed.sum())} flagged lift_failed')
+    from helpers import tally_note
+    tally_note(msg)
+    assert lifted >= n // 10 and same >= 0.97 * within and beyond <= 0.1 * n
