@@ -33,6 +33,7 @@ extern int emu_phase[GQ_WAVE];
 
 namespace gq {
 static inline int lane_id() { return (int)threadIdx.x; }
+static inline int wave_index() { return (int)blockIdx.x; }
 static inline void wave_barrier() { emu_yield(); }
 
 /* deposit a 32-bit value, rendezvous, return pointer to the 64 deposited values (valid until next primitive) */
