@@ -39,7 +39,7 @@ __device__ __forceinline__ int wave_index() {
  * s_barrier degenerates (LLVM drops it for single-wave groups) and what remains is the lgkmcnt wait + the
  * compiler-level ordering of LDS accesses. */
 #ifndef GQ_FENCE_BARRIER
-#define GQ_FENCE_BARRIER 0
+#define GQ_FENCE_BARRIER 1
 #endif
 __device__ __forceinline__ void wave_barrier() {
 #if GQ_FENCE_BARRIER

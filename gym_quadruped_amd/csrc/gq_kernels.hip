@@ -24,16 +24,21 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
   __shared__ WaveMem Ws[GQ_WPB];
   WaveMem& W = Ws[GQ_WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
   int pass = c.first_pass;
+  /* the flags and the env's rows are fetched together: one memory round trip in front of the step (a respawning env - rare -
+   * throws the rows away and fetches the ones reset_wave wrote) */
   bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[env]; /* wave-uniform */
   /* the reset's own step after an explicit gq_reset: the reset kernel left word whether the lift loop is still due */
   int lift = (c.first_pass && A->s.lift_pending) ? (int)gptr(A->s.lift_pending)[env] : 0;
+  int hint = load_rows<SOLVER>(A->s, c, W, env, pass == 0);
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
       wave_priority(3); /* reset + step in one launch: this wave is the longest of its SIMD */
+      wave_barrier();   /* the rows just staged in LDS are dead: reset_wave reuses the region */
       lift = reset_wave<BOXES>(A->r, W, c.env0);
       pass = c.auto_reset;
+      hint = load_rows<SOLVER>(A->s, c, W, env, false);
     }
-    const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF>(A->s, c, W, pass, lift);
+    const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF>(A->s, c, W, pass, lift, hint);
     if (pass != 0 || c.auto_reset != 1 || !term) break;
     respawn = true;
   }

@@ -272,6 +272,44 @@ __device__ inline void resample_wave(const StepArgs& a, const int env) {
   }
 }
 
+/* S0: the env's state rows and per-env scalars, global memory -> LDS, plus the solver-load hint of the env's previous step
+ * (returned).  EVERY load of a wave's prologue is issued here in one batch - one memory round trip, which the kernel overlaps
+ * with its own look at the pending-reset flag; nothing loaded here stays in a register (an in-kernel respawn overwrites the rows
+ * and simply calls this again).  qfrc_applied waits in W.smooth (the actuation block adds the rest to it), the clock in
+ * W.force[0] (free until the solver).  user_ctrl: the caller's actions (pass 0); resets step with zero control. */
+template <int SOLVER>
+__device__ inline int load_rows(const StepArgs& a, const StepCall& call, WaveMem& W, const int env, const bool user_ctrl) {
+  const int lane = lane_id();
+  double q = 0.0;
+  float qv = 0.0f, wm = 0.0f, ap = 0.0f, ct = 0.0f, cm = 0.0f, mu = -1.0f, tm = 0.0f;
+  int sn = 0, hint = 0;
+  if (lane < 19) q = gptr(a.qpos)[(size_t)env * 19 + lane];
+  if (lane < 18) {
+    qv = gptr(a.qvel)[(size_t)env * 18 + lane];
+    wm = gptr(a.warm)[(size_t)env * 18 + lane];
+    ap = a.applied ? gptr(a.applied)[(size_t)env * 18 + lane] : 0.0f;
+  }
+  if (lane < 12) ct = (call.ctrl && user_ctrl) ? gptr(call.ctrl)[(size_t)env * 12 + lane] : 0.0f;
+  if (lane < 4) cm = a.cmd ? gptr(a.cmd)[(size_t)env * 4 + lane] : 0.0f;
+  if (lane == 0) {
+    mu = a.friction ? gptr(a.friction)[env] : -1.0f;
+    sn = gptr(a.step_num)[env];
+    tm = gptr(a.time)[env];
+  }
+  if (SOLVER == 1 && a.load_hint) hint = (int)gptr(a.load_hint)[env];
+  if (lane < 19) {
+    if (lane < 2) W.bxy[lane] = q;
+    else if (lane == 2) W.basez = (float)q;
+    else if (lane < 7) W.qb[lane - 3] = (float)q;
+    else W.qj[lane - 7] = (float)q;
+  }
+  if (lane < 18) { W.qvel[lane] = qv; W.warm[lane] = wm; W.smooth[lane] = ap; }
+  if (lane < 12) W.ctrl[lane] = ct;
+  if (lane < 4) W.cmd[lane] = cm;
+  if (lane == 0) { W.mu_env = mu; W.step_old = sn; W.force[0] = tm; }
+  return hint;
+}
+
 /* One mj_step + observation epilogue for this wave's env.  pass 0: the user's step.  pass 1: the reset's own step
  * (zero control, friction committed afterwards, termination flags of pass 0 are kept).  pass 2: the reset's own step of
  * a next-step auto-reset (as pass 1, flags cleared).  Returns `terminated`. */
@@ -283,7 +321,7 @@ __device__ inline void resample_wave(const StepArgs& a, const int env) {
  * BOXES: the scene has static world boxes (gq_boxes.h; Newton only): contacts carry their own normal.
  * SELF: robot self-collision (Newton only): contacts between two bodies of the robot, general frames, two-body rows. */
 template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF>
-__device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift) {
+__device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift, const int hint) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
   int lane_o = lane_id(), env_o = wave_index() + uniform(call.env0);
@@ -309,40 +347,20 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     T[27] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF);          /* XCC_ID */
   }
   GQ_TICK(15); /* marker 15: nothing done yet - the launch floor */
-  /* ================================================================ S0: load the env's state rows */
-  float applied_l = 0.0f; /* qfrc_applied of the lane's dof: read and consumed by the same lane (no LDS copy) */
-  if (lane < 19) {
-    double q = gptr(a.qpos)[(size_t)env * 19 + lane];
-    if (lane < 2) W.bxy[lane] = q;
-    else if (lane == 2) W.basez = (float)q;
-    else if (lane < 7) W.qb[lane - 3] = (float)q;
-    else W.qj[lane - 7] = (float)q;
-  }
-  if (lane < 18) {
-    W.qvel[lane] = gptr(a.qvel)[(size_t)env * 18 + lane];
-    W.warm[lane] = gptr(a.warm)[(size_t)env * 18 + lane];
-    applied_l = a.applied ? gptr(a.applied)[(size_t)env * 18 + lane] : 0.0f;
-  }
-  if (lane < 12) W.ctrl[lane] = (call.ctrl && pass == 0) ? gptr(call.ctrl)[(size_t)env * 12 + lane] : 0.0f;
-  if (lane < 4) W.cmd[lane] = a.cmd ? gptr(a.cmd)[(size_t)env * 4 + lane] : 0.0f;
-  /* per-env scalars that later stages need are fetched with the state rows (one memory round trip for all of them)
-   * and wait in LDS; the clock and the step counter advance here: nothing reads them in between */
+  /* ================================================================ S0: the env's rows wait in LDS (load_rows) */
   /* scheduling hint: an env whose previous step needed several Newton iterations will most likely need them again; its
    * wave gets issue priority from the start (the launch lasts as long as its slowest wave) */
-  const int prio_hint = pass != 0 ? 3 : ((SOLVER == 1 && a.load_hint) ? (int)gptr(a.load_hint)[env] : 0);
+  const int prio_hint = pass != 0 ? 3 : hint;
   bool fwd_only = false; /* gq_forward (mj_step1 / mj_forward): no state is advanced */
   if constexpr (DBG) fwd_only = call.forward != 0;
-  if (lane == 0) {
-    W.mu_env = a.friction ? gptr(a.friction)[env] : -1.0f;
-    const int32_t sn = gptr(a.step_num)[env];
-    W.step_old = sn;
-    if (!fwd_only) {
-      gptr(a.step_num)[env] = sn + 1;
-      if (a.step_prev) gptr(a.step_prev)[env] = sn;
-      gptr(a.time)[env] = gptr(a.time)[env] + h;
-    }
-  }
   wave_barrier();
+  /* the clock and the step counter advance here (stores only: their old values came with the rows) */
+  if (lane == 0 && !fwd_only) {
+    const int32_t sn = W.step_old;
+    gptr(a.step_num)[env] = sn + 1;
+    if (a.step_prev) gptr(a.step_prev)[env] = sn;
+    gptr(a.time)[env] = W.force[0] + h;
+  }
 
   /* actuation (mj_fwdActuation: torque motors) and passive damping depend on ctrl / qvel and model constants only: done
    * here, so that the (two-level dependent) model loads overlap with the kinematics instead of sitting on S5's path */
@@ -361,7 +379,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     W.act[lane] = act;
     const float damp = m.dof_damping[lane];
     if constexpr (SOLVER == 1) W.F[0][lane] = h * damp; /* the Newton path stores no factor: F keeps h*damping for the Euler system (S10) */
-    W.smooth[lane] = -damp * W.qvel[lane] + act + applied_l;
+    W.smooth[lane] = -damp * W.qvel[lane] + act + W.smooth[lane]; /* qfrc_applied waits there */
   }
   if constexpr (SOLVER == 1) wave_priority(prio_hint);
   if constexpr (DBG) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 28] = (float)prio_hint;
