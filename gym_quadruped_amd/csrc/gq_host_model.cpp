@@ -255,6 +255,27 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     for (int i = 0; i < 2; i++) G.solref[i] = (float)mx.solref[i];
     for (int i = 0; i < 5; i++) G.solimp[i] = (float)mx.solimp[i];
   }
+  for (int it = 0; it < nitem; it++) { /* per-item records of the floor pass, in contact order */
+    GqDevItem& I = M.item[it];
+    std::memset(&I, 0, sizeof I);
+    const int code = M.con_order[it];
+    I.code = code;
+    if (code < 4) {
+      const int k = code;
+      I.body = 3 + 3 * M.foot_leg[k]; I.dim = M.foot_dim[k]; I.fric_rule = M.foot_fric_rule[k]; I.ptype = -1; I.calf = 1;
+      I.margin = M.foot_margin[k]; I.inc = M.foot_includemargin[k]; I.friction0 = M.foot_friction[k][0]; I.radius = M.foot_radius[k];
+      for (int i = 0; i < 2; i++) I.solref[i] = M.foot_solref[k][i];
+      for (int i = 0; i < 5; i++) I.solimp[i] = M.foot_solimp[k][i];
+    } else {
+      const GqDevGeom& G = M.lg[code - 4];
+      I.body = G.body; I.dim = G.dim; I.fric_rule = G.fric_rule; I.ptype = G.ptype; I.calf = (G.body > 0 && (G.body - 1) % 3 == 2) ? 1 : 0;
+      I.margin = G.margin; I.inc = G.includemargin; I.friction0 = G.friction[0]; I.radius = G.radius;
+      for (int i = 0; i < 2; i++) I.solref[i] = G.solref[i];
+      for (int i = 0; i < 5; i++) I.solimp[i] = G.solimp[i];
+      for (int i = 0; i < 3; i++) { I.psize[i] = G.psize[i]; I.pos[i] = G.pos[i]; }
+      for (int i = 0; i < 9; i++) I.mat[i] = G.mat[i];
+    }
+  }
   { /* flattened table of the small clouds */
     int slot = 0;
     M.flat_mask = 0;

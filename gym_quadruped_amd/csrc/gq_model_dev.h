@@ -56,6 +56,16 @@ struct GqDevBox { float pos[3], mat[9], size[3], rad; int32_t cls; };
 struct GqDevBodyPair { int32_t b1, b2, first, count; };   /* kernel body indices (0 = base), range of geom pairs */
 struct GqDevSelfPair { int32_t it1, it2, bp; GqDevMix mix; }; /* collision items (k < 4 foot k, else 4 + link geom); mix.rule: 0 max, 1 item1, 2 item2 */ /* mat: columns = box axes in the world; rad: bounding sphere */
 
+/* Everything lane `it` of the floor pass (S6: lane = collision item in MuJoCo's contact order) needs about its item, as ONE
+ * contiguous 128-byte record: a single batch of loads, issued a stage early (the indirection con_order -> lg[] -> fields was two
+ * dependent memory round trips in front of the contact list).  Feet: ptype -1 (sphere centre = WaveMem::foot_world[code]). */
+struct GqDevItem {
+  int32_t code, body, dim, fric_rule, ptype, calf;
+  float margin, inc, friction0, radius;
+  float solref[2], solimp[5];
+  float psize[3], pos[3], mat[9];
+};
+
 struct GqDevModel {
   float timestep, gravity_z, impratio, meaninertia, tolerance, noise_floor;
   int32_t iterations, cone, nlg, nfl, solver;
@@ -97,6 +107,7 @@ struct GqDevModel {
   /* link geoms */
   GqDevGeom lg[GQ_MAXLG];
   int32_t con_order[4 + GQ_MAXLG]; /* collision items by increasing geom id: k<4 foot k, else 4 + link geom */
+  GqDevItem item[4 + GQ_MAXLG];    /* the same items, in that order, flattened for the floor pass */
   /* static world boxes (scene geoms after the floor): collision items are evaluated against every box near the robot */
   int32_t nbox, nboxcls;
   float robot_radius;            /* bound on the distance from the base origin to any point of the robot (broad phase) */

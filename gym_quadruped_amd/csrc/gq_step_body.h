@@ -156,20 +156,40 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
  * Whether a candidate IS a contact is its own `dist < margin` test - equivalent to the routines' early exits, because the first
  * candidate of a cylinder is never farther than the others.  A lift by dz moves every pt.z and dist by dz. */
 struct FloorCand { int n; float r, t1c, t1s; float dist[4]; V3 pt[4]; };
-__device__ inline void floor_candidates(const WaveMem& W, const GQ_MODEL GqDevModel& m, const int code, FloorCand& C) {
+/* the lane's item record (GqDevModel::item), in registers */
+struct ItemRegs {
+  int code, body, dim, fric_rule, ptype, calf;
+  float margin, inc, friction0, radius, solref[2], solimp[5], psize[3];
+  V3 pos;
+  float mat[9];
+};
+__device__ __forceinline__ ItemRegs item_fetch(const GQ_MODEL GqDevModel& m, const int it) {
+  const GQ_MODEL GqDevItem& I = m.item[it];
+  ItemRegs R;
+  R.code = I.code; R.body = I.body; R.dim = I.dim; R.fric_rule = I.fric_rule; R.ptype = I.ptype; R.calf = I.calf;
+  R.margin = I.margin; R.inc = I.inc; R.friction0 = I.friction0; R.radius = I.radius;
+  R.solref[0] = I.solref[0]; R.solref[1] = I.solref[1];
+#pragma unroll
+  for (int q = 0; q < 5; q++) R.solimp[q] = I.solimp[q];
+#pragma unroll
+  for (int q = 0; q < 3; q++) R.psize[q] = I.psize[q];
+  R.pos = ld3(I.pos);
+#pragma unroll
+  for (int q = 0; q < 9; q++) R.mat[q] = I.mat[q];
+  return R;
+}
+__device__ inline void floor_candidates(const WaveMem& W, const ItemRegs& G, FloorCand& C) {
   C.n = 0; C.r = 0.0f; C.t1c = 0.0f; C.t1s = 1.0f;
 #pragma unroll
   for (int k = 0; k < 4; k++) { C.dist[k] = 1e30f; C.pt[k] = v3(0.0f, 0.0f, 0.0f); }
-  if (code < 4) {
-    C.n = 1; C.r = m.foot_radius[code]; C.pt[0] = ld3(W.foot_world[code]); C.dist[0] = C.pt[0].z - C.r;
+  const int ptype = G.ptype;
+  if (ptype < 0) { /* foot sphere */
+    C.n = 1; C.r = G.radius; C.pt[0] = ld3(W.foot_world[G.code]); C.dist[0] = C.pt[0].z - C.r;
     return;
   }
-  const int g = code - 4;
-  const GQ_MODEL GqDevGeom& G = m.lg[g];
-  const int ptype = G.ptype;
-  if (ptype == 0) { C.n = 1; C.r = G.radius; C.pt[0] = ld3(W.u2.c.lg_pt[g]); C.dist[0] = W.u2.c.lg_dist[g]; return; }
+  if (ptype == 0) { const int g = G.code - 4; C.n = 1; C.r = G.radius; C.pt[0] = ld3(W.u2.c.lg_pt[g]); C.dist[0] = W.u2.c.lg_dist[g]; return; }
   const float* Rb = W.xmat[G.body];
-  const V3 c = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos));
+  const V3 c = ld3(W.xpos[G.body]) + matvec(Rb, G.pos);
   float A[9]; /* geom frame in the world: Rb Rg */
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -456,6 +476,9 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
                                                                       * elimination (gq_newton.h) and stores no factor */
 
   GQ_TICK(4);
+  /* the lane's collision item (S6: lane = item) is fetched now: its loads are in flight during the velocity stage */
+  const int nlg = m.nlg;
+  const ItemRegs IT = item_fetch(m, lane < 4 + nlg ? lane : 0);
   /* ================================================================ S5: velocity stage (mj_comVel, mj_rne) */
   if (lane < 4) {
     /* base velocity and bias acceleration, recomputed per leg lane */
@@ -509,7 +532,6 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
 
   GQ_TICK(5);
   /* ================================================================ S6: collision with the floor (z = 0) */
-  const int nlg = m.nlg;
   SelfPrefetch self_pre;
   if constexpr (SELF) self_pre = self_prefetch(m);
   stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), false);
@@ -528,22 +550,14 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   int code = 0, body = 0, dim = 3, fric_rule = 0;
   bool calf = false;
   float cmargin = 0.0f, inc = 0.0f, fgeom = 0.0f;
-  const GQ_MODEL float* solref = m.foot_solref[0];
-  const GQ_MODEL float* solimp = m.foot_solimp[0];
+  float solref[2] = {0.02f, 1.0f}, solimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.0f};
   if (lane < nitem) {
-    code = m.con_order[lane];
-    floor_candidates(W, m, code, FC);
-    if (code < 4) {
-      const int k = code;
-      cmargin = m.foot_margin[k]; body = 3 + 3 * m.foot_leg[k]; dim = m.foot_dim[k]; inc = m.foot_includemargin[k]; calf = true;
-      fgeom = m.foot_friction[k][0]; fric_rule = m.foot_fric_rule[k];
-      solref = m.foot_solref[k]; solimp = m.foot_solimp[k];
-    } else {
-      const GQ_MODEL GqDevGeom& G = m.lg[code - 4];
-      cmargin = G.margin; body = G.body; dim = G.dim; inc = G.includemargin; calf = G.body > 0 && (G.body - 1) % 3 == 2;
-      fgeom = G.friction[0]; fric_rule = G.fric_rule;
-      solref = G.solref; solimp = G.solimp;
-    }
+    floor_candidates(W, IT, FC);
+    code = IT.code; cmargin = IT.margin; body = IT.body; dim = IT.dim; inc = IT.inc; calf = IT.calf != 0;
+    fgeom = IT.friction0; fric_rule = IT.fric_rule;
+    solref[0] = IT.solref[0]; solref[1] = IT.solref[1];
+#pragma unroll
+    for (int q = 0; q < 5; q++) solimp[q] = IT.solimp[q];
   }
   if (lift) { /* wave-uniform; only set on scenes without world boxes / height field */
     /* the reference lifts by 1.1 max |contact.dist| over EVERY contact of the calf bodies with the ground (feet_contact_state
@@ -1346,7 +1360,12 @@ __device__ inline int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 
     float margin = 0.0f;
     if (lane < 4 + m.nlg) {
       const bool calf_item = lane < 4 || (m.lg[lane - 4].body > 0 && (m.lg[lane - 4].body - 1) % 3 == 2);
-      if (calf_item) { floor_candidates(W, m, lane, FC); margin = lane < 4 ? m.foot_margin[lane] : m.lg[lane - 4].margin; }
+      if (calf_item) { /* item records are in contact order: look the lane's item up by its code */
+        int it = 0;
+        for (int q = 0; q < 4 + m.nlg; q++) it = m.item[q].code == lane ? q : it;
+        const ItemRegs IR = item_fetch(m, it);
+        floor_candidates(W, IR, FC); margin = IR.margin;
+      }
     }
     auto floor_pen = [&](const float dzz) { /* largest |dist| among the item's floor contacts at lift dzz (0: none) */
       float pen = 0.0f;
