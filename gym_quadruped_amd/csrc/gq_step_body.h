@@ -155,7 +155,7 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
  * n candidates in MuJoCo's order: reference point pt[k] (sphere centre / corner / rim point) and distance dist[k] = pt.z - r.
  * Whether a candidate IS a contact is its own `dist < margin` test - equivalent to the routines' early exits, because the first
  * candidate of a cylinder is never farther than the others.  A lift by dz moves every pt.z and dist by dz. */
-struct FloorCand { int n; float r, t1c, t1s; float dist[4]; V3 pt[4]; };
+struct FloorCand { int n; float r, t1c, t1s; float dist[4]; V3 pt[4]; int key; }; /* key: 2 bits per candidate = its place in MuJoCo's order */
 /* the lane's item record (GqDevModel::item), in registers */
 struct ItemRegs {
   int code, body, dim, fric_rule, ptype, calf;
@@ -179,7 +179,7 @@ __device__ __forceinline__ ItemRegs item_fetch(const GQ_MODEL GqDevModel& m, con
   return R;
 }
 __device__ inline void floor_candidates(const WaveMem& W, const ItemRegs& G, FloorCand& C) {
-  C.n = 0; C.r = 0.0f; C.t1c = 0.0f; C.t1s = 1.0f;
+  C.n = 0; C.r = 0.0f; C.t1c = 0.0f; C.t1s = 1.0f; C.key = 0xE4; /* places 0, 1, 2, 3 */
 #pragma unroll
   for (int k = 0; k < 4; k++) { C.dist[k] = 1e30f; C.pt[k] = v3(0.0f, 0.0f, 0.0f); }
   const int ptype = G.ptype;
@@ -206,18 +206,30 @@ __device__ inline void floor_candidates(const WaveMem& W, const ItemRegs& G, Flo
     if (l2 > 1e-30f) { const float inv = fast_rsqrt(l2); C.t1c = ax.x * inv; C.t1s = ax.y * inv; }
     else { C.t1c = 1.0f; C.t1s = 0.0f; } /* mju_normalize3 of a null vector */
   } else if (ptype == 6) {
+    /* corner i = centre + s0 ux + s1 uy + s2 uz, sign s_b = bit b of i.  Corners i and 7 - i are opposite (ldist_i = -ldist_(7-i)):
+     * of each of the four pairs (i, 7 - i), i < 4, exactly one lies at or below the centre - so the candidates are one corner
+     * per pair, kept in PAIR order in the registers; MuJoCo walks the corners by index and keeps the first four that qualify,
+     * i.e. the chosen i < 4 ascending, then the chosen 7 - i ascending: that place goes into `key`, and the contact list ranks
+     * the touching candidates by it (no data movement).  (An exact tie ldist_i = 0 makes both corners of a pair qualify in
+     * MuJoCo; here the lower index is taken - measure zero.) */
     const V3 ux = G.psize[0] * v3(A[0], A[3], A[6]), uy = G.psize[1] * v3(A[1], A[4], A[7]), uz = G.psize[2] * v3(A[2], A[5], A[8]);
-    int n = 0;
+    bool low[4];
+    int nlow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const V3 off = ((i & 1) ? ux : -1.0f * ux) + ((i & 2) ? uy : -1.0f * uy) + ((i & 4) ? uz : -1.0f * uz);
-      const bool ok = off.z <= 0.0f && n < 4;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (ok && n == k) { C.pt[k] = c + off; C.dist[k] = c.z + off.z; }
-      n += ok ? 1 : 0;
+    for (int i = 0; i < 4; i++) {
+      const V3 off = ((i & 1) ? ux : -1.0f * ux) + ((i & 2) ? uy : -1.0f * uy) - uz;
+      low[i] = off.z <= 0.0f;
+      const V3 o = low[i] ? off : -1.0f * off;
+      C.pt[i] = c + o; C.dist[i] = c.z + o.z;
+      nlow += low[i] ? 1 : 0;
     }
-    C.n = n;
+    int key = 0, seen = 0, after = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { if (low[i]) { key |= seen << (2 * i); seen++; } }
+#pragma unroll
+    for (int i = 3; i >= 0; i--) { if (!low[i]) { key |= (nlow + after) << (2 * i); after++; } } /* 7 - i ascending = i descending */
+    C.key = key;
+    C.n = 4;
   } else if (ptype == 5) {
     V3 ax = v3(A[2], A[5], A[8]);
     float prjaxis = ax.z;
@@ -544,7 +556,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
    * contact points with the floor, up to four (floor_candidates) */
   const int nitem = 4 + nlg;
   FloorCand FC;
-  FC.n = 0; FC.r = 0.0f; FC.t1c = 0.0f; FC.t1s = 1.0f;
+  FC.n = 0; FC.r = 0.0f; FC.t1c = 0.0f; FC.t1s = 1.0f; FC.key = 0xE4;
 #pragma unroll
   for (int k = 0; k < 4; k++) { FC.dist[k] = 1e30f; FC.pt[k] = v3(0.0f, 0.0f, 0.0f); }
   int code = 0, body = 0, dim = 3, fric_rule = 0;
@@ -632,10 +644,13 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     /* friction mixing; _set_ground_friction overrides floor and feet with [mu, 0.005, 0] (quadruped_env.py:1292) */
     const float fg = (code < 4 && mu_env >= 0.0f) ? mu_env : fgeom;
     const float mu = fmaxf(1e-5f, fric_rule == 0 ? fmaxf(ff, fg) : (fric_rule == 1 ? ff : fg)); /* mjMINMU */
-    int nfit = 0, j = 0;
+    int nfit = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      if (tk[k]) { /* the lane's j-th contact */
+      if (tk[k]) { /* the lane's j-th contact in MuJoCo's order: j = touching candidates placed before this one */
+        int j = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) j += (q != k && tk[q] && ((FC.key >> (2 * q)) & 3) < ((FC.key >> (2 * k)) & 3)) ? 1 : 0;
         const int idx = idx0 + j, row0 = rows0 + j * need, res = res0 + (j + 1) * vres;
         const bool fits = idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
         if (fits) {
@@ -649,7 +664,6 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
           W.con_t1[idx][0] = FC.t1c; W.con_t1[idx][1] = FC.t1s;
           nfit++;
         }
-        j++;
       }
     }
     const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8)), 63);
@@ -1356,7 +1370,7 @@ __device__ inline int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 
     /* distances and margins of everything attached to a calf body (feet_contact_state is body-level) */
     /* floor: lane = collision item (feet 0-3, then the link geoms), every candidate point of the plane narrow phase */
     FloorCand FC;
-    FC.n = 0;
+    FC.n = 0; FC.key = 0xE4;
     float margin = 0.0f;
     if (lane < 4 + m.nlg) {
       const bool calf_item = lane < 4 || (m.lg[lane - 4].body > 0 && (m.lg[lane - 4].body - 1) % 3 == 2);
