@@ -14,7 +14,7 @@ import os
 LIB_PATH = Path(os.environ.get('GQ_LIBGQ_PATH', Path(__file__).parent / 'libgq.so'))
 
 EXPORTS = ['gq_last_error', 'gq_version', 'gq_struct_sizes', 'gq_obs_dim', 'gq_model_create', 'gq_model_destroy', 'gq_batch_create',
-           'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_batch_set_imu', 'gq_batch_set_pending', 'gq_batch_set_resampling', 'gq_heightmap', 'gq_heightmap_strided', 'gq_step_range', 'gq_batch_bind', 'gq_rollout', 'gq_jac', 'gq_ray', 'gq_forward', 'gq_full_mass', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get', 'gq_debug_device_buffer', 'gq_debug_field', 'gq_debug_stop_stage']
+           'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_batch_set_imu', 'gq_batch_set_pending', 'gq_batch_set_resampling', 'gq_heightmap', 'gq_heightmap_strided', 'gq_step_range', 'gq_batch_bind', 'gq_rollout', 'gq_jac', 'gq_ray', 'gq_forward', 'gq_full_mass', 'gq_batch_set_outputs', 'gq_contact_force', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get', 'gq_debug_device_buffer', 'gq_debug_field', 'gq_debug_stop_stage']
 
 
 class GqError(RuntimeError):
@@ -64,6 +64,8 @@ def lib():
     L.gq_debug_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int]
     L.gq_obs_dim.argtypes = [C.c_int]
     L.gq_full_mass.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.gq_batch_set_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gq_contact_force.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.gq_debug_device_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.gq_debug_stop_stage.argtypes = [C.c_void_p, C.c_int]
     L.gq_debug_field.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

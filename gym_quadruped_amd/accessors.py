@@ -10,9 +10,11 @@ The reference computes these from ``mjData`` whenever the user asks; right after
   to the row the kernel writes; the user-visible observation dict is unchanged).
 * getters that read MuJoCo internals of the last forward pass - ``mj_fullM`` (``legs_mass_matrix``, ``get_base_inertia``),
   ``qfrc_bias`` / ``qfrc_passive``, ``body(i).xpos`` (``hip_positions``), ``subtree_com`` (``com``), ``mj_jac``
-  (``feet_jacobians``) - read the kernel's inspection record on the device (``gq_debug_device_buffer``).  The first use
-  switches the env to the instrumented kernel variant for all envs (slower: one 8.4 KB record per env-step) and needs
-  one ``step()`` / ``reset()`` afterwards to fill the record.
+  (``feet_jacobians``), ``mjData.contact`` / ``mj_contactForce`` (``contacts``, ``mj_contactForce``) - read two extra rows the
+  PRODUCTION step kernel writes per env when the env was built with ``accessors=True`` (``gq_batch_set_outputs``: the
+  tree-sparse inertia, bias forces, body poses, foot points; the contact list with its forces).  Without
+  ``accessors=True`` they fall back to the kernel's inspection record (instrumented variant, ~18 % slower, one 8.4 KB
+  record per env-step; the first use needs one ``step()`` / ``reset()`` afterwards to fill it).
 
 Like the reference values they describe the LAST forward pass: positions / Jacobians / M of the pose before the
 integration step, velocities of the new state (quirk B3).  Everything has a leading env axis and stays on the GPU.
@@ -60,8 +62,17 @@ class AccessorsMixin:
             raise ValueError(f"Invalid frame: {frame} != 'world' or 'base'")
         return '' if frame == 'world' else ':base'
 
+    _DYN_FIELDS = {'qfrc_bias': ('BIAS', 18), 'xpos': ('XPOS', 39), 'xmat': ('XMAT', 117), 'foot_pos': ('FOOT', 12)}
+
     def _record(self, field):
-        """[N, count] view of a field of the inspection record (instrumented kernel, all envs)."""
+        """[N, count] view of a by-product of the last forward pass: a slice of the production kernel's dynamics row
+        (accessors=True), else of the inspection record (instrumented kernel, all envs)."""
+        if getattr(self, '_dyn', None) is not None:
+            from .cabi import GQ_DYN
+            if field == 'M':
+                return self._dense_mass()
+            key, cnt = self._DYN_FIELDS[field]
+            return self._dyn[:, GQ_DYN[key]:GQ_DYN[key] + cnt]
         if getattr(self, '_rec_tensor', None) is None:
             self.enable_debug(self.num_envs)
             ptr, n, stride = C.c_void_p(), C.c_int32(), C.c_int32()
@@ -74,6 +85,49 @@ class AccessorsMixin:
         off, cnt = C.c_int32(), C.c_int32()
         _lib.check(self._L.gq_debug_field(field.encode(), C.byref(off), C.byref(cnt)), 'gq_debug_field')
         return self._rec_tensor[:, off.value:off.value + cnt.value]
+
+    def _dense_mass(self):
+        """mj_fullM: [N, 324] dense joint-space inertia out of the dynamics row's tree-sparse storage (leg dof 6 + j keeps its
+        base columns and the columns of its own leg up to itself; the base block is full)."""
+        from .cabi import GQ_DYN
+        if getattr(self, '_mass_index', None) is None:
+            src = np.full((18, 18), GQ_DYN['STRIDE'], dtype=np.int64)          # default: a zero column appended below
+            for a in range(6):
+                for b in range(6):
+                    src[a, b] = GQ_DYN['MB'] + 6 * a + b
+            for j in range(12):
+                leg, dep = divmod(j, 3)
+                for k in range(6):
+                    src[6 + j, k] = src[k, 6 + j] = GQ_DYN['MC'] + 9 * j + k
+                for c in range(dep + 1):
+                    src[6 + j, 6 + 3 * leg + c] = src[6 + 3 * leg + c, 6 + j] = GQ_DYN['MC'] + 9 * j + 6 + c
+            self._mass_index = torch.as_tensor(src.ravel(), device=self.device)
+        padded = torch.cat([self._dyn, torch.zeros(self.num_envs, 1, dtype=torch.float32, device=self.device)], dim=1)
+        return padded.index_select(1, self._mass_index)
+
+    def contacts(self):
+        """mjData.contact of the last forward pass as tensors (needs accessors=True): dict with 'ncon' [N] and, per contact
+        slot k < 12 (MuJoCo's order; slots >= ncon are zero), 'geom1' (-1: a world geom), 'geom2', 'dist', 'pos' (x / y relative
+        to the pre-step base x / y), 'frame' [N, 12, 3, 3] (rows: normal, tangent 1, tangent 2), 'dim', 'force' [N, 12, 6]
+        (mj_contactForce: contact-frame force and torque), 'mu'."""
+        if getattr(self, '_contacts', None) is None:
+            raise _lib.GqError('contacts() needs an env built with accessors=True')
+        from .cabi import GQ_CON_MAX, GQ_CON_REC
+        rows = self._contacts
+        rec = rows[:, 8:].reshape(self.num_envs, GQ_CON_MAX, GQ_CON_REC)
+        return dict(ncon=rows[:, 0].to(torch.int32), nefc=rows[:, 1].to(torch.int32), geom1=rec[:, :, 0].to(torch.int32), geom2=rec[:, :, 1].to(torch.int32),
+                    dist=rec[:, :, 2], pos=rec[:, :, 3:6], frame=rec[:, :, 6:15].reshape(self.num_envs, GQ_CON_MAX, 3, 3), dim=rec[:, :, 15].to(torch.int32),
+                    force=rec[:, :, 16:22], mu=rec[:, :, 22])
+
+    def mj_contactForce(self, contact_id: int):
+        """``mujoco.mj_contactForce(m, d, id, result)`` (reference :852) for contact ``contact_id`` of every env: [N, 6] (zeros
+        where the env has fewer contacts).  ``gq_contact_force`` on the contact rows (accessors=True)."""
+        if getattr(self, '_contacts', None) is None:
+            raise _lib.GqError('mj_contactForce needs an env built with accessors=True')
+        out = torch.empty(self.num_envs, 6, dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._L.gq_contact_force(self._hbatch, int(contact_id), out.data_ptr(), stream), 'gq_contact_force')
+        return out
 
     def _note_step(self):
         if getattr(self, '_rec_tensor', None) is not None:

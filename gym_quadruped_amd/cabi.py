@@ -13,6 +13,10 @@ from .mjcf import ModelDesc
 
 GQ_NLEG = 4
 GQ_ABI_VERSION = 300   # include/gq.h
+# optional extra output rows of the step kernel (include/gq.h gq_batch_set_outputs)
+GQ_DYN = dict(MC=0, MB=108, BIAS=144, XPOS=162, XMAT=201, FOOT=318, STRIDE=336)
+GQ_CON_MAX, GQ_CON_REC = 12, 24
+GQ_CON_STRIDE = 8 + GQ_CON_MAX * GQ_CON_REC
 
 _I = C.POINTER(C.c_int32)
 _D = C.POINTER(C.c_double)

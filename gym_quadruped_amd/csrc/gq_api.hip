@@ -64,6 +64,7 @@ struct GqBatch {
   int32_t* h9;          /* caller-owned device [N][6] resampling counters, set by gq_batch_set_resampling */
   float* ext_dist;      /* caller-owned device [N][6] */
   int debug_cap;
+  float* dyn_out; float* con_out;  /* caller-owned device rows registered with gq_batch_set_outputs */
 };
 
 /* the launches must be issued with the batch's device current (the caller's stream belongs to it); restore the caller's
@@ -210,6 +211,23 @@ int gq_batch_set_resampling(GqBatch* b, const GqResampleCfg* cfg, const GqResetC
   return GQ_OK;
 }
 
+int gq_batch_set_outputs(GqBatch* b, float* dyn, float* contacts) {
+  if (!b) { SET_ERR("gq_batch_set_outputs: null batch"); return GQ_EINVAL; }
+  b->dyn_out = dyn; b->con_out = contacts;   /* picked up by the next launch's argument block (ensure_args) */
+  return GQ_OK;
+}
+
+int gq_contact_force(GqBatch* b, int id, float* result, void* hip_stream) {
+  if (!b || !result) { SET_ERR("gq_contact_force: null argument"); return GQ_EINVAL; }
+  if (!b->con_out) { SET_ERR("gq_contact_force: no contact rows registered (gq_batch_set_outputs)"); return GQ_EINVAL; }
+  if (id < 0 || id >= GQ_CON_MAX) { SET_ERR("gq_contact_force: contact id %d out of range (0..%d)", id, GQ_CON_MAX - 1); return GQ_EINVAL; }
+  DeviceGuard guard(b->model->device);
+  /* records past an env's contact count are written as zeros by the kernel */
+  HIP_TRY(hipMemcpy2DAsync(result, 6 * sizeof(float), b->con_out + 8 + id * GQ_CON_REC + 16, GQ_CON_STRIDE * sizeof(float), 6 * sizeof(float),
+                           (size_t)b->host.n_envs, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+  return GQ_OK;
+}
+
 int gq_debug_enable(GqBatch* b, int n_debug_envs) {
   if (!b) return GQ_EINVAL;
   if (n_debug_envs > b->host.n_envs) n_debug_envs = b->host.n_envs;
@@ -243,6 +261,7 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const
   a->friction_next = b->friction_next; a->pending = b->pending; a->load_hint = b->load_hint;
   a->imu_bias = b->imu_bias;
   a->h9 = b->h9; a->ext_dist = b->ext_dist;
+  a->dyn = b->dyn_out; a->contacts = b->con_out;
   a->lift_failed = lift_failed; a->lift_pending = b->lift_pending;
   a->episode_ro = episode;
   a->obs = out.obs; a->reward = out.reward; a->terminated = out.terminated; a->truncated = out.truncated;

@@ -305,6 +305,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     }
     for (k = 0; k < 4; k++) item_geom[k] = d->feet_geomid[k];
   }
+  for (int it = 0; it < 4 + M.nlg; it++) M.item_geomid[it] = item_geom[it];
   int cls_rep[GQ_MAXBOXCLS];
   for (int b = 0; b < d->nbox; b++) {
     GqDevBox& B = M.box[b];

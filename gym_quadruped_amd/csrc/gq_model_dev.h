@@ -108,6 +108,7 @@ struct GqDevModel {
   GqDevGeom lg[GQ_MAXLG];
   int32_t con_order[4 + GQ_MAXLG]; /* collision items by increasing geom id: k<4 foot k, else 4 + link geom */
   GqDevItem item[4 + GQ_MAXLG];    /* the same items, in that order, flattened for the floor pass */
+  int32_t item_geomid[4 + GQ_MAXLG]; /* geom id (GqModelDesc numbering) of collision item k < 4: foot k, else 4 + link geom */
   /* static world boxes (scene geoms after the floor): collision items are evaluated against every box near the robot */
   int32_t nbox, nboxcls;
   float robot_radius;            /* bound on the distance from the base origin to any point of the robot (broad phase) */
@@ -139,6 +140,20 @@ struct GqDevModel {
   double terrain_limits[4];
   float key_qpos[19];            /* keyframe 0 */
 };
+
+/* optional extra output rows of the production step kernel (include/gq.h gq_batch_set_outputs; same values there) */
+#ifndef GQ_DYN_MC
+#define GQ_DYN_MC 0
+#define GQ_DYN_MB 108
+#define GQ_DYN_BIAS 144
+#define GQ_DYN_XPOS 162
+#define GQ_DYN_XMAT 201
+#define GQ_DYN_FOOT 318
+#define GQ_DYN_STRIDE 336
+#define GQ_CON_MAX 12
+#define GQ_CON_REC 24
+#define GQ_CON_STRIDE (8 + GQ_CON_MAX * GQ_CON_REC)
+#endif
 
 #define GQ_NEED_BASE 1    /* base pose / velocity / frame observables (canonical scalars 0..51) */
 #define GQ_NEED_ENERGY 2  /* kinetic_energy, work */

@@ -600,6 +600,23 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
     wave_barrier();
   }
   GQ_TICK(14);
+  /* the dynamics row (gq_batch_set_outputs): what the reference reads from mjData after the step for model-based control -
+   * mj_fullM, qfrc_bias, body poses, the foot points - straight out of LDS, production kernel */
+  if (a.dyn && rec_pass) { /* wave-uniform */
+    GQ_GLOBAL float* D = gptr(a.dyn) + (size_t)env * GQ_DYN_STRIDE;
+    const float* Mc0 = &W.Mc[0][0];
+    const float* Mb0 = &W.Mb[0][0];
+    const float* xp0 = &W.xpos[0][0];
+    const float* xm0 = &W.xmat[0][0];
+    D[GQ_DYN_MC + lane] = Mc0[lane];
+    if (lane < 108 - GQ_WAVE) D[GQ_DYN_MC + GQ_WAVE + lane] = Mc0[GQ_WAVE + lane];
+    if (lane < 36) D[GQ_DYN_MB + lane] = Mb0[lane];
+    if (lane < GQ_NVD) D[GQ_DYN_BIAS + lane] = W.bias[lane];
+    if (lane < 39) D[GQ_DYN_XPOS + lane] = xp0[lane];
+    D[GQ_DYN_XMAT + lane] = xm0[lane];
+    if (lane < 117 - GQ_WAVE) D[GQ_DYN_XMAT + GQ_WAVE + lane] = xm0[GQ_WAVE + lane];
+    if (lane < 12) D[GQ_DYN_FOOT + lane] = (&W.foot_world[0][0])[lane];
+  }
   /* contact list in MuJoCo's order, capped.  Lane `it` owns the (up to four) contacts of collision item `it`; ranks and row
    * offsets come from one wave prefix sum over (contacts, rows, reserved virtual rows) packed into an int - no serial section. */
   {
@@ -1251,6 +1268,41 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
       if (a.pending) gptr(a.pending)[env] = (uint8_t)(pass == 0 ? terminated : 0);
       gptr(a.reward)[env] = 0.0f;
       if (pass != 0 && a.friction && a.friction_next) gptr(const_cast<float*>(a.friction))[env] = gptr(a.friction_next)[env];
+    }
+  }
+  /* the contact row (gq_batch_set_outputs): mjData.contact[] with mj_contactForce, lane = contact */
+  if (a.contacts && rec_pass) { /* wave-uniform */
+    GQ_GLOBAL float* Cn = gptr(a.contacts) + (size_t)env * GQ_CON_STRIDE;
+    if (lane == 0) { Cn[0] = (float)ncon; Cn[1] = (float)nefc; Cn[2] = (float)iter; }
+    if (lane >= ncon && lane < GQ_CON_MAX) { /* no contact: an all-zero record (gq_contact_force returns zeros for it) */
+      GQ_GLOBAL float* R = Cn + 8 + lane * GQ_CON_REC;
+#pragma unroll
+      for (int q = 0; q < GQ_CON_REC; q++) R[q] = 0.0f;
+    }
+    if (lane < ncon) {
+      const int c = lane, r0 = W.con_row[c], dimc = W.con_dim[c];
+      GQ_GLOBAL float* R = Cn + 8 + c * GQ_CON_REC;
+      const int cword = W.con_geom[c], it2 = GEN ? (cword & 0xff) : cword, it1 = GEN ? ((cword >> 8) & 0xff) - 1 : -1;
+      R[0] = it1 >= 0 ? (float)m.item_geomid[it1] : -1.0f;
+      R[1] = (float)m.item_geomid[it2];
+      R[2] = W.con_dist[c];
+      R[3] = W.con_pos[c][0]; R[4] = W.con_pos[c][1]; R[5] = W.con_pos[c][2];
+      V3 cn = v3(0.0f, 0.0f, 1.0f), ct1 = v3(W.con_t1[c][0], W.con_t1[c][1], 0.0f), ct2 = v3(-W.con_t1[c][1], W.con_t1[c][0], 0.0f);
+      if constexpr (GEN) if (GQ_BX_WCLS(W)[c] != -1) { cn = ld3(GQ_BX_CONNRM(W) + 3 * c); make_frame(cn, ct1, ct2); }
+      R[6] = cn.x; R[7] = cn.y; R[8] = cn.z; R[9] = ct1.x; R[10] = ct1.y; R[11] = ct1.z; R[12] = ct2.x; R[13] = ct2.y; R[14] = ct2.z;
+      R[15] = (float)dimc;
+      float f6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (dimc == 1) f6[0] = W.force[r0];
+      else if constexpr (CONE) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) f6[q] = q < dimc ? W.force[r0 + q < 63 ? r0 + q : 63] : 0.0f;
+      } else { /* mju_decodePyramid */
+        const float f0 = W.force[r0], f1 = W.force[r0 + 1], f2 = W.force[r0 + 2], f3 = W.force[r0 + 3], mu = W.con_mu[c];
+        f6[0] = f0 + f1 + f2 + f3; f6[1] = mu * (f0 - f1); f6[2] = mu * (f2 - f3);
+      }
+#pragma unroll
+      for (int q = 0; q < 6; q++) R[16 + q] = f6[q];
+      R[22] = W.con_mu[c]; R[23] = 0.0f;
     }
   }
   GQ_TICK(12);

@@ -51,6 +51,8 @@ struct StepArgs {
   int32_t* step_prev;     /* [N] step counter before this step's increment (info['step_num']), may be NULL */
   int32_t* h9;            /* [N][6] resampling counters {after_vel, before_vel, n_vel, after_dist, before_dist, n_dist}, may be NULL */
   float* ext_dist;        /* [N][6] current disturbance wrench, may be NULL */
+  float* dyn;             /* [N][GQ_DYN_STRIDE] dynamics rows (gq_batch_set_outputs), may be NULL */
+  float* contacts;        /* [N][GQ_CON_STRIDE] contact rows, may be NULL */
   int32_t n_envs;
 };
 struct StepCall {

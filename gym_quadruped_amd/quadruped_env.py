@@ -206,6 +206,15 @@ class QuadrupedEnv(AccessorsMixin):
         self._out = GqObsOut(self._obs_buf.data_ptr(), self._reward.data_ptr(), self._terminated.data_ptr(),
                              self._truncated.data_ptr(), self._invalid.data_ptr(), self._step_num.data_ptr(),
                              self._step_num_prev.data_ptr())
+        # accessors=True: the production kernel also writes the dynamics row (mj_fullM, qfrc_bias, body poses, foot points) and
+        # the contact row (mjData.contact + mj_contactForce) of every step - what the reference's model-based-control getters
+        # read from mjData (accessors.py); no instrumented kernel variant involved
+        self._dyn = self._contacts = None
+        if accessors:
+            from .cabi import GQ_CON_STRIDE, GQ_DYN
+            self._dyn = torch.zeros(N, GQ_DYN['STRIDE'], **f32)
+            self._contacts = torch.zeros(N, GQ_CON_STRIDE, **f32)
+            _lib.check(L.gq_batch_set_outputs(self._hbatch, self._dyn.data_ptr(), self._contacts.data_ptr()), 'gq_batch_set_outputs')
         self._info = _make_info(self)
         self._episode = torch.zeros(N, dtype=torch.int32, device=dev)
         t = self.base_vel_command_type

@@ -17,8 +17,8 @@
  *   mujoco.mj_jac                  quadruped_env.py:728    gq_jac (+ gq_step obs epilogue for the feet)
  *   mujoco.mj_step1 / mj_forward   quadruped_env.py:376,384,1321  gq_forward
  *   mujoco.mj_ray                  sensors/heightmap.py:90-99     gq_ray (general rays), gq_heightmap (the HeightMap grid)
- *   mujoco.mj_contactForce         quadruped_env.py:852    gq_step obs epilogue; per contact: gq_forward record "efc_force"
- *   mujoco.mj_fullM                quadruped_env.py:940    gq_step obs epilogue; full matrix: gq_forward record "M"
+ *   mujoco.mj_contactForce         quadruped_env.py:852    gq_contact_force (contact rows of gq_batch_set_outputs); summed per foot: obs epilogue
+ *   mujoco.mj_fullM                quadruped_env.py:940    dyn rows of gq_batch_set_outputs (production kernel); gq_full_mass (inspection record)
  *
  * Conventions
  *  - plain C, no exceptions cross the boundary; every function returns 0 on
@@ -389,6 +389,36 @@ int gq_ray(GqBatch* b, const double* origin, const float* dir, int n_rays, float
  * (gq_debug_enable must have been called for the envs of interest; fields: gq_debug_field / gq_debug_device_buffer).  Runs
  * the instrumented kernel variant: ~20 % slower than gq_step's production kernel and one 8.4 KB record per env. */
 int gq_forward(GqBatch* b, int stage, const float* ctrl, GqState st, GqObsOut out, void* hip_stream);
+
+/* What the reference reads from mjData AFTER a step for model-based control - mj_fullM (legs_mass_matrix :880-893,
+ * get_base_inertia :543-562), qfrc_bias (:895-905), body(i).xpos / xmat (hip_positions :564-595, com :918-929), the foot
+ * points mj_jac is evaluated at (:681-740) and the contact list with mj_contactForce (:836-870, :852) - written by the
+ * PRODUCTION step kernel as two optional extra rows per env (no instrumented variant, no inspection record):
+ *   dyn      device [N][GQ_DYN_STRIDE] f32 or NULL: the tree-sparse joint-space inertia, qfrc_bias, body poses and foot
+ *            points of the forward pass (positions with x / y relative to the base x / y of that pass, i.e. qpos before the
+ *            step: fp32 never carries the 10 km spawn offsets).  M in mj_fullM's dense form: M[6+j][k<6] = MC[j][k],
+ *            M[6+j][6+3*leg(j)+c] = MC[j][6+c] for c <= depth(j) (symmetric; zero between different legs), M[a][b] = MB[a][b].
+ *   contacts device [N][GQ_CON_STRIDE] f32 or NULL: word 0 = number of contacts kept (<= GQ_CON_MAX), then one
+ *            GQ_CON_REC-float record per contact in MuJoCo's order: geom1 (-1: a world geom - floor, box, height field -
+ *            else the robot geom id), geom2 (robot geom id), dist, pos[3] (x / y relative like dyn), frame[9] (rows: normal,
+ *            tangent 1, tangent 2 = mjContact.frame), dim, force[6] (mj_contactForce: normal, two tangential, torsional, two
+ *            rolling components in the contact frame; zeros beyond dim), friction[0].
+ * Both stay registered until changed (NULL, NULL switches them off); cost when on: ~1.3 KB + ~1.2 KB of stores per env-step. */
+#define GQ_DYN_MC 0
+#define GQ_DYN_MB 108
+#define GQ_DYN_BIAS 144
+#define GQ_DYN_XPOS 162
+#define GQ_DYN_XMAT 201
+#define GQ_DYN_FOOT 318
+#define GQ_DYN_STRIDE 336
+#define GQ_CON_MAX 12
+#define GQ_CON_REC 24
+#define GQ_CON_STRIDE (8 + GQ_CON_MAX * GQ_CON_REC)
+int gq_batch_set_outputs(GqBatch* b, float* dyn, float* contacts);
+/* mujoco.mj_contactForce(m, d, id, result) (quadruped_env.py:852) for contact `id` of every env: result device [N][6] f32,
+ * zeros for the envs with fewer contacts.  Reads the contact rows registered with gq_batch_set_outputs (a strided device
+ * copy, asynchronous on hip_stream). */
+int gq_contact_force(GqBatch* b, int id, float* result, void* hip_stream);
 
 /* mujoco.mj_fullM(m, M, d.qM) (quadruped_env.py:557, :884: legs_mass_matrix, get_base_inertia): the dense joint-space
  * inertia of the LAST forward pass (gq_step or gq_forward) of the first n_envs envs, M: device [n_envs][18][18] f32.

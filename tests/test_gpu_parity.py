@@ -331,9 +331,12 @@ def test_mpc_accessors_match_oracle():
     env.reset(random=True)
     with pytest.raises(Exception):
         QuadrupedEnv('aliengo', state_obs_names=('qpos',), num_envs=2).base_lin_vel('base')   # not assembled, no accessors
+    # accessors=True: the production kernel writes the dynamics / contact rows itself - no inspection record, no instrumented variant
+    rec_env = QuadrupedEnv('aliengo', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, solver='newton', seed=3)   # fallback path
+    rec_env.reset(random=True)
     _ = None
     try:
-        env.legs_mass_matrix          # first use: switches the instrumented kernel on, record still empty
+        rec_env.legs_mass_matrix      # first use without accessors=True: switches the instrumented kernel on, record still empty
     except Exception as e:
         _ = e
     assert _ is not None
@@ -343,9 +346,18 @@ def test_mpc_accessors_match_oracle():
         q0, v0, w0 = env.qpos.cpu().numpy().copy(), env.qvel.cpu().numpy().copy(), env._warm.cpu().numpy().copy()
         fr = env._friction.cpu().numpy().copy()
         obs, *_rest = env.step(act)
+        rec_env.step(act)
     torch.cuda.synchronize()
+    assert getattr(env, '_rec_tensor', None) is None and env._dyn is not None
+    # the two paths agree: same kernel arithmetic, production vs instrumented variant (up to the compiler's contraction choices)
+    for leg in ('FL', 'FR', 'RL', 'RR'):
+        torch.testing.assert_close(env.legs_mass_matrix[leg], rec_env.legs_mass_matrix[leg], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(env.legs_qfrc_bias[leg], rec_env.legs_qfrc_bias[leg], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(env.feet_jacobians('world')[leg], rec_env.feet_jacobians('world')[leg], rtol=1e-5, atol=1e-6)
     md = env.mjModel
     o = Oracle(marshalled('aliengo', solver=1, iterations=100, tolerance=1e-12))
+    con = env.contacts()
+    f_first = env.mj_contactForce(0)
     M_legs, bias, Jp = env.legs_mass_matrix, env.legs_qfrc_bias, env.feet_jacobians('world')
     Jb, Jrb = env.feet_jacobians('base', return_rot_jac=True)
     hips, com, Ib = env.hip_positions('world'), env.com, env.get_base_inertia()
@@ -375,6 +387,24 @@ def test_mpc_accessors_match_oracle():
             np.testing.assert_allclose(grf[leg][e].cpu().numpy(), ref['contact_forces'][sl], atol=2e-3 * max(1.0, np.abs(ref['contact_forces']).max()))
             assert bool(cs[leg][e]) == bool(ref['contact_state'][k])
         np.testing.assert_allclose(Ib[e].cpu().numpy(), M[3:6, 3:6], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(env._record('M')[e].cpu().numpy().reshape(18, 18), M, rtol=1e-4, atol=1e-5)    # mj_fullM, dense
+        # mjData.contact + mj_contactForce (reference :836-870): list order, geoms, distances, frames, forces
+        nc = int(con['ncon'][e])
+        if o.ncon <= 12 and o.nefc <= 63:
+            assert nc == o.ncon
+            if nc:
+                np.testing.assert_array_equal(con['geom2'][e, :nc].cpu().numpy(), o.get('contact_geom').astype(int))
+                np.testing.assert_array_equal(con['geom1'][e, :nc].cpu().numpy(), o.get('contact_geom1').astype(int))
+                np.testing.assert_allclose(con['dist'][e, :nc].cpu().numpy(), o.get('contact_dist'), atol=2e-6)
+                np.testing.assert_allclose(con['frame'][e, :nc].cpu().numpy(), o.contact_frame, atol=2e-5)
+                pos = con['pos'][e, :nc].cpu().numpy().astype(np.float64); pos[:, :2] += q0[e, :2]
+                np.testing.assert_allclose(pos, o.contact_pos, atol=5e-6 * max(1.0, np.abs(o.contact_pos).max()))
+                fo = o.contact_force
+                np.testing.assert_allclose(con['force'][e, :nc].cpu().numpy(), fo, atol=2e-3 * max(1.0, np.abs(fo).max()))
+                np.testing.assert_allclose(f_first[e].cpu().numpy(), fo[0], atol=2e-3 * max(1.0, np.abs(fo).max()))
+            else:
+                assert not f_first[e].any()
+            assert not con['force'][e, nc:].any()
         sc = o.get('subtree_com').reshape(-1, 3)
         com_ref = (np.asarray(md.body_mass)[:, None] * sc).sum(0) / np.asarray(md.body_mass).sum()
         np.testing.assert_allclose(com[e].cpu().numpy(), com_ref, atol=5e-6 * max(1.0, np.abs(com_ref).max()))
