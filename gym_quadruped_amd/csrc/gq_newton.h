@@ -139,27 +139,37 @@ __device__ inline void factor_tree_one(WaveMem& W, const float (*Sc)[9], const f
  * stored: each system is solved for exactly one right-hand side (Newton search direction, qacc_smooth, the Euler
  * system), which is what made storing L and D in LDS, re-reading them and three barriers per solve pure latency.
  * g and out: LDS [18], may alias. */
-template <bool DAMP>
-__device__ inline void solve_tree_fused(const float (*Sc)[9], const float (*Sb)[6], const float* damping, float hd,
-                                        const float* g, float* out) {
+/* STORE: the second quad of lanes (4-7) eliminates the SAME matrix plus damping[] on its diagonal (the Euler system
+ * M + h diag(damping), damping = h * dof_damping in LDS) in the same instruction stream - those lanes are idle anyway - and
+ * leaves its factor in LDS: per leg 24 floats (multipliers of calf / thigh / hip rows, the three pivot reciprocals) in fleg[4][24],
+ * the base block's 15 multipliers + 6 reciprocals in fbase[21].  solve_tree_stored then solves the Euler system by
+ * substitution alone (~100 VALU instead of the ~300 of an elimination). */
+#define GQ_EULER_FLEG(W) (&(W).F[1][0])   /* [4][24]; the GEN variants' per-geom hit normals (S6) are dead by the solver */
+#define GQ_EULER_FBASE(W) (&(W).F[0][56]) /* [21] */
+template <bool DAMP, bool STORE = false>
+__device__ __forceinline__ void solve_tree_fused(const float (*Sc)[9], const float (*Sb)[6], const float* damping, float hd,
+                                        const float* g, float* out, float* fleg = nullptr, float* fbase = nullptr) {
   const int lane = lane_id();
   { /* every lane runs the same instruction stream (lanes >= 4 mirror leg 0 and are discarded at the end): no branch, and the
      * cross-lane sums are called from wave-uniform control flow */
-    const int hh = 3 * (lane < 4 ? lane : 0), t = hh + 1, c = hh + 2; /* joint indices of the leg (dof = 6 + joint) */
+    const int hh = 3 * (STORE ? (lane < 8 ? (lane & 3) : 0) : (lane < 4 ? lane : 0)), t = hh + 1, c = hh + 2; /* joint indices of the leg (dof = 6 + joint) */
+    const bool second = STORE && lane >= 4 && lane < 8;   /* this lane eliminates M + diag(damping) and stores the factor */
+    const bool first = STORE ? (lane & 3) == 0 : lane == 0; /* carries the base block of its quad */
+    if constexpr (STORE) hd = second ? 1.0f : 0.0f;
     float rc[9], rt[8], rh[7], bb[21], gb[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) { rc[j] = Sc[c][j]; rt[j] = Sc[t][j]; rh[j] = Sc[hh][j]; }
     rc[6] = Sc[c][6]; rc[7] = Sc[c][7]; rc[8] = Sc[c][8];
     rt[6] = Sc[t][6]; rt[7] = Sc[t][7];
     rh[6] = Sc[hh][6];
-    if constexpr (DAMP) { rc[8] += hd * damping[6 + c]; rt[7] += hd * damping[6 + t]; rh[6] += hd * damping[6 + hh]; }
+    if constexpr (DAMP || STORE) { rc[8] += hd * damping[6 + c]; rt[7] += hd * damping[6 + t]; rh[6] += hd * damping[6 + hh]; }
     float gc = g[6 + c], gt = g[6 + t], gh = g[6 + hh];
     /* base block and right-hand side: lane 0 carries S_bb and g_b, the others start from zero (summed below) */
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      gb[i] = lane == 0 ? g[i] : 0.0f;
+      gb[i] = (STORE ? first : lane == 0) ? g[i] : 0.0f;
 #pragma unroll
-      for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] = lane == 0 ? Sb[i][j] + ((DAMP && i == j) ? hd * damping[i] : 0.0f) : 0.0f;
+      for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] = (STORE ? first : lane == 0) ? Sb[i][j] + (((DAMP || STORE) && i == j) ? hd * damping[i] : 0.0f) : 0.0f;
     }
     /* eliminate the calf: rows thigh, hip, base */
     const float ic = fast_rcp(rc[8]);
@@ -202,6 +212,16 @@ __device__ inline void solve_tree_fused(const float (*Sc)[9], const float (*Sb)[
       for (int j = 0; j <= i; j++) bb[i * (i + 1) / 2 + j] -= rh[j] * f;
       gb[i] -= gh * f;
     }
+    if constexpr (STORE) if (second) { /* the leg's multipliers and pivot reciprocals */
+      float* F = fleg + 24 * (lane & 3);
+#pragma unroll
+      for (int j = 0; j < 8; j++) F[j] = rc[j] * ic;
+#pragma unroll
+      for (int j = 0; j < 7; j++) F[8 + j] = rt[j] * it;
+#pragma unroll
+      for (int j = 0; j < 6; j++) F[15 + j] = rh[j] * ih;
+      F[21] = ic; F[22] = it; F[23] = ih;
+    }
     /* Schur complement of the base: sum of the four legs */
 #pragma unroll
     for (int q = 0; q < 21; q++) bb[q] = quad_sum(bb[q]);
@@ -221,12 +241,20 @@ __device__ inline void solve_tree_fused(const float (*Sc)[9], const float (*Sb)[
       }
       gb[k] *= inv; /* gb[k] now holds (g_k - sum_{j<k} S_kj x_j ... ) / S_kk once the x_j below are known */
       bb[k * (k + 1) / 2 + k] = inv;
+      if constexpr (STORE) { /* the multipliers l_ki take the place of the eliminated row (it is not read again) */
+#pragma unroll
+        for (int i = 0; i < k; i++) bb[k * (k + 1) / 2 + i] *= inv;
+      }
+    }
+    if constexpr (STORE) if (lane == 4) {
+#pragma unroll
+      for (int q = 0; q < 21; q++) fbase[q] = bb[q]; /* strictly lower entries: multipliers; diagonal: reciprocals */
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       float s = gb[k];
 #pragma unroll
-      for (int j = 0; j < k; j++) s -= bb[k * (k + 1) / 2 + j] * bb[k * (k + 1) / 2 + k] * xb[j];
+      for (int j = 0; j < k; j++) s -= (STORE ? bb[k * (k + 1) / 2 + j] : bb[k * (k + 1) / 2 + j] * bb[k * (k + 1) / 2 + k]) * xb[j];
       xb[k] = s;
     }
     /* back-substitution up the leg: hip, thigh, calf */
@@ -246,6 +274,65 @@ __device__ inline void solve_tree_fused(const float (*Sc)[9], const float (*Sb)[
 #pragma unroll
       for (int j = 0; j < 6; j++) out[j] = xb[j];
     }
+  }
+  wave_barrier();
+}
+
+/* out <- (M + diag(damping))^-1 g by substitution with the factor solve_tree_fused<.., STORE> left in LDS: lanes 0-3 run the
+ * forward pass of their leg (the right-hand side through the eliminations of calf, thigh, hip), the four contributions to the
+ * base right-hand side are summed across the quad, every lane solves the 6x6 base system from the stored multipliers and
+ * substitutes back up its leg.  g and out: LDS [18], may alias. */
+__device__ __forceinline__ void solve_tree_stored(const float* fleg, const float* fbase, const float* g, float* out) {
+  const int lane = lane_id();
+  const int L = lane < 4 ? lane : 0, hh = 3 * L, t = hh + 1, c = hh + 2;
+  const float* F = fleg + 24 * L;
+  float fc[8], ft[7], fh[6], lb[21], gb[6];
+#pragma unroll
+  for (int j = 0; j < 8; j++) fc[j] = F[j];
+#pragma unroll
+  for (int j = 0; j < 7; j++) ft[j] = F[8 + j];
+#pragma unroll
+  for (int j = 0; j < 6; j++) fh[j] = F[15 + j];
+  const float ic = F[21], it = F[22], ih = F[23];
+#pragma unroll
+  for (int q = 0; q < 21; q++) lb[q] = fbase[q];
+  float gc = g[6 + c], gt = g[6 + t], gh = g[6 + hh];
+#pragma unroll
+  for (int i = 0; i < 6; i++) gb[i] = lane == 0 ? g[i] : 0.0f;
+  gt -= gc * fc[7]; gh -= gc * fc[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) gb[i] -= gc * fc[i];
+  gh -= gt * ft[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) gb[i] -= gt * ft[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) gb[i] -= gh * fh[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) gb[i] = quad_sum(gb[i]);
+#pragma unroll
+  for (int k = 5; k >= 0; k--) {
+#pragma unroll
+    for (int i = 0; i < k; i++) gb[i] -= gb[k] * lb[k * (k + 1) / 2 + i];
+    gb[k] *= lb[k * (k + 1) / 2 + k];
+  }
+  float xb[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    float sx = gb[k];
+#pragma unroll
+    for (int j = 0; j < k; j++) sx -= lb[k * (k + 1) / 2 + j] * xb[j];
+    xb[k] = sx;
+  }
+  float xh = gh * ih, xt = gt * it, xc = gc * ic;
+#pragma unroll
+  for (int j = 0; j < 6; j++) { xh -= fh[j] * xb[j]; xt -= ft[j] * xb[j]; xc -= fc[j] * xb[j]; }
+  xt -= ft[6] * xh;
+  xc -= fc[6] * xh + fc[7] * xt;
+  wave_barrier(); /* g may alias out: every lane has read its right-hand side */
+  if (lane < 4) { out[6 + hh] = xh; out[6 + t] = xt; out[6 + c] = xc; }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) out[j] = xb[j];
   }
   wave_barrier();
 }
@@ -622,7 +709,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
    * step's qacc does so for hardly any (torques change every step, the friction-loss rows follow them) - and the
    * comparison itself costs two residual evaluations, a mass-matrix product and two wave reductions.  So the warm start
    * is not consulted by this solver (it is still written, for PGS and for callers that read it). */
-  solve_tree_fused<false>(W.Mc, W.Mb, nullptr, 0.0f, W.smooth, W.qacc_smooth);
+  solve_tree_fused<false, true>(W.Mc, W.Mb, W.F[0], 0.0f, W.smooth, W.qacc_smooth, GQ_EULER_FLEG(W), GQ_EULER_FBASE(W)); /* + the Euler system's factor, by the idle second quad */
   if (lane < GQ_NVD) W.qacc[lane] = W.qacc_smooth[lane];
   wave_barrier();
   float f = 0.0f;

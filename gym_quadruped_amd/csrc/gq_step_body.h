@@ -1005,7 +1005,7 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
      * (M + h D) qacc_int = qfrc_smooth + qfrc_constraint is left */
     if (lane < GQ_NVD) W.act[lane] = W.smooth[lane] + W.qfrc_c[lane];
     wave_barrier();
-    solve_tree_fused<true>(W.Mc, W.Mb, W.F[0], 1.0f, W.act, W.qacc_int); /* h*damping staged in LDS right after S0: no model load on this path */
+    solve_tree_stored(GQ_EULER_FLEG(W), GQ_EULER_FBASE(W), W.act, W.qacc_int); /* factor of M + h diag(damping): left in LDS by the solver's first elimination */
   } else {
   if (lane < GQ_NVD) { /* qfrc_constraint = J' f: four independent partial sums keep the LDS reads pipelined */
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
