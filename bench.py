@@ -168,6 +168,17 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
         env.rollout(acts, shards=2)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
+    # ... and as ONE persistent launch per 64-step sequence (shards=0): every wavefront plays its env's steps back to back
+    for _ in range(4):
+        env.rollout(acts, shards=0)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        env.rollout(acts, shards=0)
+    torch.cuda.synchronize(device)
+    dtp = time.perf_counter() - t1
+    out['persistent_rollout'] = {'value': n * reps * 64 / dtp, 'unit': 'env-steps/s', 'ms_per_step': dtp / (reps * 64) * 1e3, 'steps': reps * 64,
+                                 'note': 'open-loop: one launch per 64-step action sequence, each wavefront steps its env 64 times without a launch boundary (gq_rollout shards=0); same results as the step loop, bit for bit'}
     out['pipelined_rollout'] = {'value': n * reps * 64 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / (reps * 64) * 1e3, 'steps': reps * 64, 'shards': 2,
                                 'note': 'open-loop: each shard of 2048 envs chains its steps on its own stream (gq_step_range); same kernels and results as the step loop'}
     env.close()

@@ -333,6 +333,20 @@ int gq_step_range(GqBatch* b, int env0, int count, const float* ctrl, GqState st
 int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
                int32_t* episode, uint8_t* lift_failed, float* obs_seq, void* hip_stream) {
   if (!b || !ctrl_seq || n_steps < 0) { SET_ERR("gq_rollout: bad argument"); return GQ_EINVAL; }
+  if (shards == 0) { /* persistent: ONE launch, every wavefront plays the whole sequence of its env (StepCall::n_steps) */
+    if (auto_reset && !auto_reset->autoreset_next_step) { SET_ERR("gq_rollout: the persistent rollout (shards = 0) needs next-step auto-reset or none"); return GQ_EINVAL; }
+    int rc0 = step_launch(b, 0, 0, nullptr, nullptr, st, out, auto_reset, episode, lift_failed, hip_stream, "gq_rollout"); /* validate + bind */
+    if (rc0 != GQ_OK) return rc0;
+    if (n_steps == 0) return GQ_OK;
+    DeviceGuard guard0(b->model->device);
+    gq::StepCall c{};
+    c.ctrl = ctrl_seq; c.n_steps = n_steps; c.ctrl_stride = b->host.n_envs * 12; c.obs_seq = obs_seq;
+    c.auto_reset = auto_reset ? 2 : 0; c.stop_stage = b->stop_stage;
+    gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0),
+                   (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return GQ_OK;
+  }
   if (shards < 1) shards = 1;
   if (shards > 8) shards = 8;
   if (shards > b->host.n_envs) shards = b->host.n_envs;

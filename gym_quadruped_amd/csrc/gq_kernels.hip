@@ -15,7 +15,7 @@ namespace gq {
  * then the reset's own mj_step as a second pass through step_wave; no extra launches, but the launch lasts as long as
  * its two-pass waves.  Next-step mode: the env waits (pending flag) and spends its next launch on reset_wave + the
  * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
-template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF>
+template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF, bool PERSIST = false>
 __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
   const int widx = wave_index();
   if (GQ_WPB > 1 && widx >= c.count) return;
@@ -23,6 +23,14 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
   if (c.mask && !gptr(c.mask)[env]) return; /* wave-uniform */
   __shared__ WaveMem Ws[GQ_WPB];
   WaveMem& W = Ws[GQ_WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  for (int kstep = 0;;) { /* one trip, except in a persistent rollout (PERSIST variants, StepCall::n_steps; a variant of their own:
+                           * merely compiling the loop in cost the single-step kernel 2.7 %) */
+  StepCall ck = c;
+  if constexpr (PERSIST) { /* wave-uniform */
+    ck.ctrl = c.ctrl + (size_t)kstep * c.ctrl_stride;
+    if (c.obs_seq) ck.obs_seq = c.obs_seq + (size_t)kstep * A->s.n_envs * mptr(A->s.batch)->obs_dim;
+  }
+  const StepCall& c = ck; /* the body below sees this step's call */
   int pass = c.first_pass;
   /* the flags and the env's rows are fetched together: one memory round trip in front of the step (a respawning env - rare -
    * throws the rows away and fetches the ones reset_wave wrote) */
@@ -41,6 +49,10 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
     const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF>(A->s, c, W, pass, lift, hint);
     if (pass != 0 || c.auto_reset != 1 || !term) break;
     respawn = true;
+  }
+  if (!PERSIST || ++kstep >= c.n_steps) break;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); /* the next step reads the rows this one stored (same wave, same addresses) */
+  wave_barrier();
   }
 }
 
@@ -277,6 +289,13 @@ static void launch_variant(const gq::FusedArgs* dev_args, const gq::StepCall* c,
   {
     gq::StepCall call = *c;
     call.count = n_envs;
+    if constexpr (M == 0) {
+      if (c->n_steps > 1) { /* persistent rollout: production kernel only */
+        hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF, true>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
+        return;
+      }
+    }
+    call.n_steps = 1;
     hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
   }
 }

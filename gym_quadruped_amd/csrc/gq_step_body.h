@@ -310,7 +310,7 @@ __device__ inline void resample_wave(const StepArgs& a, const int env) {
  * and simply calls this again).  qfrc_applied waits in W.smooth (the actuation block adds the rest to it), the clock in
  * W.force[0] (free until the solver).  user_ctrl: the caller's actions (pass 0); resets step with zero control. */
 template <int SOLVER>
-__device__ inline int load_rows(const StepArgs& a, const StepCall& call, WaveMem& W, const int env, const bool user_ctrl) {
+__device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call, WaveMem& W, const int env, const bool user_ctrl) {
   const int lane = lane_id();
   double q = 0.0;
   float qv = 0.0f, wm = 0.0f, ap = 0.0f, ct = 0.0f, cm = 0.0f, mu = -1.0f, tm = 0.0f;
@@ -353,7 +353,7 @@ __device__ inline int load_rows(const StepArgs& a, const StepCall& call, WaveMem
  * BOXES: the scene has static world boxes (gq_boxes.h; Newton only): contacts carry their own normal.
  * SELF: robot self-collision (Newton only): contacts between two bodies of the robot, general frames, two-body rows. */
 template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF>
-__device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift, const int hint) {
+__device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift, const int hint) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
   int lane_o = lane_id(), env_o = wave_index() + uniform(call.env0);
@@ -1309,7 +1309,14 @@ __device__ inline int step_wave(const StepArgs& a, const StepCall& call, WaveMem
   /* gather to the requested observation layout: coalesced row write */
   {
 #pragma unroll
-    for (int i = 0; i < 4; i++) { const int k = lane + GQ_WAVE * i; if (k < od) gptr(a.obs)[(size_t)env * od + k] = ob[omap[i]]; }
+    for (int i = 0; i < 4; i++) {
+      const int k = lane + GQ_WAVE * i;
+      if (k < od) {
+        const float val = ob[omap[i]];
+        gptr(a.obs)[(size_t)env * od + k] = val;
+        if (call.obs_seq) gptr(call.obs_seq)[(size_t)env * od + k] = val; /* persistent rollout: the step's own row of the sequence */
+      }
+    }
   }
   wave_barrier(); /* the obs row overlays u: finish reading it before a second pass reuses the region */
   /* in-episode resampling (quadruped_env.py:292-305): the user's step only; a redraw acts from the next step on */
@@ -1355,7 +1362,7 @@ enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH =
 
 #define GQ_LIFT_RULE_ITERS 4
 template <bool BOXES>
-__device__ inline int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 = 0) {
+__device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 = 0) {
   int lane_o = lane_id(), env_o = wave_index() + uniform(env0);
   opaque(lane_o); opaque_s(env_o); /* see step_wave: no address arithmetic may be hoisted to the kernel prologue */
   const int lane = lane_o, env = env_o;

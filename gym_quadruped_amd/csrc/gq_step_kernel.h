@@ -64,6 +64,12 @@ struct StepCall {
   int32_t env0;         /* first env of this launch (gq_step_range); env = env0 + blockIdx.x */
   int32_t forward;      /* gq_forward (instrumented variant only): 1 = mj_step1 (return after the constraint rows), 2 = mj_forward (return
                          * after the accelerations); nothing but qacc and the inspection record is written */
+  /* persistent open-loop rollout (gq_rollout with shards = 0): every wavefront plays n_steps steps of ITS env back to back - no
+   * launch boundary, hence no wave ever waits for another env's stragglers; step k takes its controls from ctrl + k * ctrl_stride
+   * and, when obs_seq is given, also writes its observation row to obs_seq + (k * n_envs + env) * obs_dim */
+  int32_t n_steps;      /* 0 / 1: a single step */
+  int32_t ctrl_stride;  /* floats between the control rows of consecutive steps */
+  float* obs_seq;
   int32_t count;        /* envs of this launch: wavefronts past env0 + count (the last workgroup of a multi-wave launch) return at once */
   int32_t stop_stage;   /* profiling aid (env GQ_STOP_STAGE, tools/stage_insts.sh): return after stage marker i; 0 = run everything */
 };

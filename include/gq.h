@@ -331,7 +331,9 @@ int gq_step_range(GqBatch* b, int env0, int count, const float* ctrl, GqState st
 /* K steps of every env with the action sequence ctrl_seq (device [K][N][nu] f32), equivalent to K gq_step calls but
  * pipelined over `shards` groups of envs on library-owned HIP streams (forked from / joined to hip_stream with events): no
  * launch waits for another group's stragglers or for the gap between two dependent launches.  obs_seq: device
- * [K][N][obs_dim] f32 receiving every step's observation rows, or NULL (the row tensor then holds the last step's). */
+ * [K][N][obs_dim] f32 receiving every step's observation rows, or NULL (the row tensor then holds the last step's).
+ * shards = 0 selects the PERSISTENT form: one launch in which every wavefront plays all K steps of its env back to back - no
+ * launch boundaries at all, so no env ever waits for the slowest env of a step (needs next-step auto-reset or none). */
 int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
                int32_t* episode, uint8_t* lift_failed, float* obs_seq, void* hip_stream);
 /* upload the device-resident argument block for (st, out, auto_reset, episode, lift_failed) if it changed; no launch */

@@ -270,9 +270,11 @@ def test_state_dict_round_trip_includes_imu_bias_and_resampling_state():
     assert not bool(a.torque_ctrl_setpoint.any())
 
 
-def test_pipelined_rollout_equals_the_step_loop():
-    """QuadrupedEnv.rollout (gq_step_range on one stream per shard of envs) must leave exactly the state of the plain step loop
-    - auto-resets, command redraws and IMU walks included - and deliver every step's observation rows."""
+@pytest.mark.parametrize('shards', [4, 0])
+def test_pipelined_rollout_equals_the_step_loop(shards):
+    """QuadrupedEnv.rollout (shards > 0: gq_step_range on one stream per shard of envs; shards = 0: ONE persistent launch in
+    which every wavefront plays the whole sequence of its env) must leave exactly the state of the plain step loop -
+    auto-resets, command redraws and IMU walks included - and deliver every step's observation rows."""
     from gym_quadruped_amd.sensors import IMU
     n, K = 1024, 60
     kw = dict(accel_name='imu_acc', gyro_name='imu_gyro', imu_site_name='imu', accel_noise=0.01, gyro_noise=0.02, accel_bias_rate=0.03, gyro_bias_rate=0.04, seed=5)
@@ -288,7 +290,7 @@ def test_pipelined_rollout_equals_the_step_loop():
         o, _, term, _, _ = a.step(acts[k])
         rows.append(a._obs_buf.clone())
     out = torch.zeros(K, n, b._obs_dim, device='cuda:0')
-    b.rollout(acts, shards=4, obs_out=out)
+    b.rollout(acts, shards=shards, obs_out=out)
     torch.cuda.synchronize()
     for k in ('_qpos', '_qvel', '_warm', '_time', '_step_num', '_episode', '_cmd', '_h9', '_terminated', '_obs_buf'):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
