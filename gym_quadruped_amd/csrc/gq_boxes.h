@@ -15,6 +15,7 @@
  */
 #pragma once
 #include "gq_step_kernel.h"
+#include "gq_pairs.h"
 
 namespace gq {
 
@@ -112,8 +113,11 @@ __device__ inline void item_sphere(const WaveMem& W, const GQ_MODEL GqDevModel& 
   }
 }
 
+/* IT: the item record of lane `it` (item_fetch(m, it)); H: the item's contact candidates with box b - one for a foot sphere or a
+ * hull cloud (its deepest inflated vertex), up to 2 / 4 for the robot's capsule / box geoms (exact pair routines, gq_pairs.h) */
 __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, int b,
-                                     double bx, double by, float zoff, V3 cg, float rg, float& dist, V3& nrm, V3& pt) {
+                                     double bx, double by, float zoff, V3 cg, float rg, const ItemRegs& IT, PairHit& H) {
+  float dist; V3 nrm, pt;
   const int lane = lane_id();
   const GQ_MODEL GqDevBox& B = m.box[b];
   const V3 bp = v3((float)((double)B.pos[0] - bx), (float)((double)B.pos[1] - by), B.pos[2] - zoff); /* box relative to the base x/y */
@@ -123,10 +127,20 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
   bool needs = false;
   if (lane < nlg) {
     V3 nn; /* bounding sphere of the cloud against the box itself */
-    needs = rg >= 0.0f && sphere_box(matTvec(B.mat, cg - bp), bs, rg, nn) < m.boxmix[B.cls][4 + lane].margin;
+    needs = rg >= 0.0f && m.lg[lane].ptype == 0 && sphere_box(matTvec(B.mat, cg - bp), bs, rg, nn) < m.boxmix[B.cls][4 + lane].margin;
     if (!needs) W.u2.c.lg_dist[lane] = 1e30f;
   }
   uint64_t todo = ballot(needs);
+  /* primitive link geoms (lane = item): bounding sphere of the item against the box; the exact routine runs in phase C */
+  bool prim_near = false;
+  V3 pc = v3(0.0f, 0.0f, 0.0f); /* geom centre in kernel coordinates */
+  if (lane < 4 + nlg && IT.ptype > 0) {
+    pc = ld3(W.xpos[IT.body]) + matvec(W.xmat[IT.body], IT.pos);
+    const float rb = IT.ptype == 6 ? sqrtf(IT.psize[0] * IT.psize[0] + IT.psize[1] * IT.psize[1] + IT.psize[2] * IT.psize[2]) : IT.psize[0] + (IT.ptype == 3 ? IT.psize[1] : 0.0f);
+    V3 nn;
+    prim_near = sphere_box(matTvec(B.mat, pc - bp), bs, rb, nn) < IT.margin + m.boxmix[B.cls][IT.code].margin;
+  }
+  H.n = 0;
   { /* nothing near this box (no link geom, no foot): skip the scan, the barrier and the item pass */
     bool foot_near = false;
     if (lane < 4) {
@@ -134,7 +148,7 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
       foot_near = sphere_box(matTvec(B.mat, ld3(W.foot_world[lane]) - bp), bs, m.foot_radius[lane], nn) < m.boxmix[B.cls][lane].margin;
     }
     dist = 1e30f; nrm = v3(0.0f, 0.0f, 1.0f); pt = v3(0.0f, 0.0f, 0.0f);
-    if ((todo | ballot(foot_near)) == 0) return false;
+    if ((todo | ballot(foot_near) | ballot(prim_near)) == 0) return false;
   }
   while (todo) { /* wave-uniform */
     const int g = ffs64(todo);
@@ -207,8 +221,26 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
       dist = sphere_box(matTvec(B.mat, cw), bs, m.foot_radius[code], n_l);
       nrm = matvec(B.mat, n_l);
       pt = ld3(W.foot_world[code]) - (m.foot_radius[code] + 0.5f * dist) * nrm;
-    } else {
+    } else if (IT.ptype <= 0) {
       dist = W.u2.c.lg_dist[code - 4]; nrm = ld3(GQ_BX_LGNRM(W) + 3 * (code - 4)); pt = ld3(W.u2.c.lg_pt[code - 4]);
+    }
+  }
+  H.n = dist < 1e29f ? 1 : 0; H.dist[0] = dist; H.nrm[0] = nrm; H.pos[0] = pt;
+  if (prim_near) { /* the robot's sphere / capsule / box geoms against the box: exact (mjc_SphereBox / CapsuleBox / BoxBox geometry) */
+    const float marg = m.boxmix[B.cls][IT.code].margin;
+    float Rw[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rw[i] = B.mat[i];
+    const float* Rb = W.xmat[IT.body];
+    float A[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) A[3 * i + j] = Rb[3 * i] * IT.mat[j] + Rb[3 * i + 1] * IT.mat[3 + j] + Rb[3 * i + 2] * IT.mat[6 + j];
+    if (IT.ptype == 6) box_box(bp, Rw, bs, pc, A, v3(IT.psize[0], IT.psize[1], IT.psize[2]), marg, H);
+    else {
+      const V3 ax = IT.ptype == 3 ? IT.psize[1] * v3(A[2], A[5], A[8]) : v3(0.0f, 0.0f, 0.0f);
+      capsule_box(pc - ax, pc + ax, IT.psize[0], bp, Rw, bs, marg, H);
     }
   }
   return true;
@@ -444,17 +476,18 @@ struct WorldAppend { int ncon, rows, invalid, reserve, ft[4], nself; };
 /* append the contacts of the collision items (lane = position in con_order: dist / nrm / pt) with one world geom of
  * contact-parameter class cls; rows / row budget as in the floor pass.  No barrier inside. */
 template <bool CONE>
-__device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, int cls, float mu_env, float dist, V3 nrm, V3 pt, WorldAppend& S) {
+__device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, int cls, float mu_env, const PairHit& H, WorldAppend& S) {
   const int lane = lane_id();
-  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   int& ncon = S.ncon; int& rows = S.rows; int& invalid = S.invalid; int& reserve = S.reserve; int* ft = S.ft;
-  bool touching = false, calf = false;
-  int code = 0, body = 0, dim = 3;
+  bool calf = false;
+  int code = 0, body = 0, dim = 3, cnt = 0;
   float mu = 0.0f;
+  bool tk[4] = {false, false, false, false};
   if (lane < 4 + m.nlg) {
     code = m.con_order[lane];
     const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
-    touching = dist < X.margin;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { tk[k] = k < H.n && H.dist[k] < X.margin; cnt += tk[k] ? 1 : 0; }
     dim = X.dim;
     const float ff = m.boxcls_friction[cls][0]; /* _set_ground_friction leaves unnamed world boxes alone (quirk B8) */
     float fg;
@@ -462,33 +495,42 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
     else { const GQ_MODEL GqDevGeom& G = m.lg[code - 4]; body = G.body; calf = G.body > 0 && (G.body - 1) % 3 == 2; fg = G.friction[0]; }
     mu = fmaxf(1e-5f, X.rule == 0 ? fmaxf(ff, fg) : (X.rule == 1 ? ff : fg));
   }
-  const uint64_t touch_mask = ballot(touching);
-  if (touch_mask == 0) return;
+  const bool touching = cnt > 0;
+  if (ballot(touching) == 0) return;
   invalid |= ballot(touching && !calf) != 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) ft[k] |= ballot(touching && body == 3 + 3 * m.foot_leg[k]) != 0;
-  const int idx = ncon + popc64(touch_mask & lt);
-  const bool kept = touching && idx < GQ_MAXCON;
+  /* ranks and rows: one prefix sum over (contacts, rows, reserved virtual rows), as in the floor pass */
   const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
-  const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4), m6 = ballot(kept && need == 6);
-  const int row0 = rows + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
-  const int res = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) + (need > 1 ? need - 1 : 0) : 0;
-  const bool fits = kept && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
-  const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4), f6 = ballot(fits && need == 6);
-  if (fits) {
-    const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
-    W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
-    W.con_dist[idx] = dist; W.con_inc[idx] = X.includemargin; W.con_mu[idx] = mu;
-    st3(W.con_pos[idx], pt);
-    W.con_solref[idx][0] = X.solref[0]; W.con_solref[idx][1] = X.solref[1];
+  const int vres = (CONE && need > 1) ? need - 1 : 0;
+  const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
+  const int excl = wave_incl_scan(packed) - packed;
+  const int idx0 = ncon + (excl & 0xff), rows0 = rows + ((excl >> 8) & 0x3ff), res0 = reserve + ((excl >> 18) & 0x3ff);
+  int nfit = 0, j = 0;
 #pragma unroll
-    for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = X.solimp[q];
-    st3(GQ_BX_CONNRM(W) + 3 * idx, nrm);
-    GQ_BX_WCLS(W)[idx] = cls;
+  for (int k = 0; k < 4; k++) {
+    if (tk[k]) {
+      const int idx = idx0 + j, row0 = rows0 + j * need, res = res0 + (j + 1) * vres;
+      const bool fits = idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
+      if (fits) {
+        const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
+        W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
+        W.con_dist[idx] = H.dist[k]; W.con_inc[idx] = X.includemargin; W.con_mu[idx] = mu;
+        st3(W.con_pos[idx], H.pos[k]);
+        W.con_solref[idx][0] = X.solref[0]; W.con_solref[idx][1] = X.solref[1];
+#pragma unroll
+        for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = X.solimp[q];
+        st3(GQ_BX_CONNRM(W) + 3 * idx, H.nrm[k]);
+        GQ_BX_WCLS(W)[idx] = cls;
+        nfit++;
+      }
+      j++;
+    }
   }
-  ncon += popc64(f1 | f3 | f4 | f6);
-  rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
-  if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
+  const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8) | ((nfit * vres) << 18)), 63);
+  ncon += tot & 0xff;
+  rows += (tot >> 8) & 0x3ff;
+  if constexpr (CONE) reserve += (tot >> 18) & 0x3ff;
 }
 
 /* closest points of the segments p1 + s d1 and p2 + t d2, s, t in [0, 1] (Ericson, Real-Time Collision Detection 5.1.9;
@@ -527,13 +569,15 @@ __device__ __forceinline__ void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& 
  * appended after the world contacts in (body pair, geom1, geom2) order - MuJoCo's order - under the same row budget. */
 /* model words of the self-collision stage that do not depend on the state: fetched at the start of S6, so that their
  * memory latency is spent under the floor scan instead of in front of the pair test */
-struct SelfPrefetch { float caps[7]; int32_t body, it1[2], it2[2], bp[2]; };
+struct SelfPrefetch { float caps[7], bsph[4]; int32_t body, it1[2], it2[2], bp[2]; };
 __device__ __forceinline__ SelfPrefetch self_prefetch(const GQ_MODEL GqDevModel& m) {
   const int lane = lane_id();
   SelfPrefetch P;
   const int it = lane < 4 + m.nlg ? lane : 0;
 #pragma unroll
   for (int i = 0; i < 7; i++) P.caps[i] = m.item_caps[it][i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) P.bsph[i] = m.item_bsph[it][i];
   P.body = m.item_body[it];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -557,11 +601,10 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     const int b = pre.body;
     const V3 o = ld3(W.xpos[b]);
     const V3 e0 = o + matvec(W.xmat[b], v3(pre.caps[0], pre.caps[1], pre.caps[2])), e1 = o + matvec(W.xmat[b], v3(pre.caps[3], pre.caps[4], pre.caps[5]));
-    const V3 hh = 0.5f * (e1 - e0);
     st3(cw[lane], e0); st3(cw[lane] + 3, e1);
     cw[lane][6] = pre.caps[6];
-    st3(cw[lane] + 8, e0 + hh);
-    cw[lane][11] = sqrtf(dot(hh, hh)) + pre.caps[6];
+    st3(cw[lane] + 8, o + matvec(W.xmat[b], v3(pre.bsph[0], pre.bsph[1], pre.bsph[2]))); /* broad-phase sphere: the primitive itself where the item is one */
+    cw[lane][11] = pre.bsph[3];
   }
   /* models with many pairs: body-pair broad phase, so that passes whose pairs all belong to far-apart bodies are skipped */
   uint64_t near[2] = {~0ull, ~0ull};
@@ -617,58 +660,99 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
   for (int c0 = 0; c0 < ncand; c0 += GQ_WAVE) { /* pass B, lane = candidate pair */
     const bool cand = c0 + lane < ncand;
     const int p = cand ? list[c0 + lane] : 0;
-    bool touching = false;
-    float dist = 0.0f;
-    V3 nrm = v3(0.0f, 0.0f, 1.0f), pt = v3(0.0f, 0.0f, 0.0f);
+    PairHit H;
+    H.n = 0;
     int it1 = 0, it2 = 0;
     if (cand) {
-      it1 = m.sp[p].it1; it2 = m.sp[p].it2;
+      const GQ_MODEL GqDevSelfPair& Pp = m.sp[p];
+      it1 = Pp.it1; it2 = Pp.it2;
+      const int kind = Pp.kind;
+      const float marg = Pp.mix.margin;
       const float* k1 = cw[it1];
       const float* k2 = cw[it2];
-      V3 c1, c2;
-      closest_seg_seg(ld3(k1), ld3(k1 + 3), ld3(k2), ld3(k2 + 3), c1, c2);
-      const V3 d = c2 - c1;
-      const float l2 = dot(d, d), len = sqrtf(l2);
-      dist = len - k1[6] - k2[6];
-      touching = dist < m.sp[p].mix.margin && len >= 1e-9f;
-      if (touching) { nrm = (1.0f / len) * d; pt = c1 + (k1[6] + 0.5f * dist) * nrm; }
+      if (kind == 0) { /* capsule proxies: closest points of the two axes */
+        V3 c1, c2;
+        closest_seg_seg(ld3(k1), ld3(k1 + 3), ld3(k2), ld3(k2 + 3), c1, c2);
+        const V3 d = c2 - c1;
+        const float l2 = dot(d, d), len = sqrtf(l2), dist = len - k1[6] - k2[6];
+        if (dist < marg && len >= 1e-9f) {
+          const V3 nrm = (1.0f / len) * d;
+          H.n = 1; H.dist[0] = dist; H.nrm[0] = nrm; H.pos[0] = c1 + (k1[6] + 0.5f * dist) * nrm;
+        }
+      } else { /* a box is involved: exact routines (gq_pairs.h); the box of kind 1 / 3 is item 1, of kind 2 item 2 */
+        const int ib = kind == 2 ? it2 : it1;
+        const GQ_MODEL GqDevGeom& G = m.lg[ib - 4];
+        const float* Rb = W.xmat[G.body];
+        float A[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) A[3 * i + j] = Rb[3 * i] * G.mat[j] + Rb[3 * i + 1] * G.mat[3 + j] + Rb[3 * i + 2] * G.mat[6 + j];
+        const V3 ca = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos)), ha = ld3(G.psize);
+        if (kind == 3) {
+          const GQ_MODEL GqDevGeom& G2 = m.lg[it2 - 4];
+          const float* Rb2 = W.xmat[G2.body];
+          float A2[9];
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) A2[3 * i + j] = Rb2[3 * i] * G2.mat[j] + Rb2[3 * i + 1] * G2.mat[3 + j] + Rb2[3 * i + 2] * G2.mat[6 + j];
+          box_box(ca, A, ha, ld3(W.xpos[G2.body]) + matvec(Rb2, ld3(G2.pos)), A2, ld3(G2.psize), marg, H);
+        } else {
+          const float* kc = kind == 1 ? k2 : k1; /* the sphere / capsule: its proxy is the geom itself */
+          capsule_box(ld3(kc), ld3(kc + 3), kc[6], ca, A, ha, marg, H);
+          if (kind == 2) { /* normal from the box (item 2) to the capsule (item 1): turn it to run from item 1 to item 2 */
+#pragma unroll
+            for (int k = 0; k < 4; k++) H.nrm[k] = -1.0f * H.nrm[k];
+          }
+        }
+      }
     }
-    const uint64_t touch_mask = ballot(touching);
-    if (touch_mask == 0 || m.self_cut == 4) continue;
-    /* (rare) append the touching pairs, in pair order */
-    const GQ_MODEL GqDevSelfPair& P = m.sp[touching ? p : 0];
+    const int cnt = H.n;
+    if (ballot(cnt > 0) == 0 || m.self_cut == 4) continue;
+    /* (rare) append the touching pairs' points, in pair order */
+    const GQ_MODEL GqDevSelfPair& P = m.sp[cnt > 0 ? p : 0];
     const int dim = P.mix.dim;
     float mu = 0.0f;
-    if (touching) { /* sliding friction: _set_ground_friction rewrites the feet (quadruped_env.py:1277-1298) */
+    if (cnt > 0) { /* sliding friction: _set_ground_friction rewrites the feet (quadruped_env.py:1277-1298) */
       const float f1 = it1 < 4 ? (mu_env >= 0.0f ? mu_env : m.foot_friction[it1][0]) : m.lg[it1 - 4].friction[0];
       const float f2 = it2 < 4 ? (mu_env >= 0.0f ? mu_env : m.foot_friction[it2][0]) : m.lg[it2 - 4].friction[0];
       mu = fmaxf(1e-5f, P.mix.rule == 0 ? fmaxf(f1, f2) : (P.mix.rule == 1 ? f1 : f2));
     }
     int& ncon = S.ncon; int& rows = S.rows; int& reserve = S.reserve;
-    const int idx = ncon + popc64(touch_mask & lt);
-    const bool kept = touching && idx < GQ_MAXCON;
     const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
-    const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4), m6 = ballot(kept && need == 6);
-    const int row0 = rows + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
-    const int res = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) + (need > 1 ? need - 1 : 0) : 0;
-    const bool fits = kept && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
-    const uint64_t f1 = ballot(fits && need == 1), f3 = ballot(fits && need == 3), f4 = ballot(fits && need == 4), f6 = ballot(fits && need == 6);
-    if (fits) {
-      const int b1 = m.item_body[it1], b2 = m.item_body[it2];
-      W.con_geom[idx] = it2 | ((it1 + 1) << 8) | (P.mix.rule << 16); W.con_body[idx] = b2 | ((b1 + 1) << 8); W.con_dim[idx] = dim; W.con_row[idx] = row0;
-      W.con_dist[idx] = dist; W.con_inc[idx] = P.mix.includemargin; W.con_mu[idx] = mu;
-      st3(W.con_pos[idx], pt);
-      W.con_solref[idx][0] = P.mix.solref[0]; W.con_solref[idx][1] = P.mix.solref[1];
+    const int vres = (CONE && need > 1) ? need - 1 : 0;
+    const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
+    const int excl = wave_incl_scan(packed) - packed;
+    const int idx0 = ncon + (excl & 0xff), rows0 = rows + ((excl >> 8) & 0x3ff), res0 = reserve + ((excl >> 18) & 0x3ff);
+    int nfit = 0;
 #pragma unroll
-      for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = P.mix.solimp[q];
-      st3(GQ_BX_CONNRM(W) + 3 * idx, nrm);
-      GQ_BX_WCLS(W)[idx] = GQ_WCLS_SELF;
+    for (int k = 0; k < 4; k++) {
+      if (k < cnt) {
+        const int idx = idx0 + k, row0 = rows0 + k * need, res = res0 + (k + 1) * vres;
+        const bool fits = idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
+        if (fits) {
+          const int b1 = m.item_body[it1], b2 = m.item_body[it2];
+          W.con_geom[idx] = it2 | ((it1 + 1) << 8) | (P.mix.rule << 16); W.con_body[idx] = b2 | ((b1 + 1) << 8); W.con_dim[idx] = dim; W.con_row[idx] = row0;
+          W.con_dist[idx] = H.dist[k]; W.con_inc[idx] = P.mix.includemargin; W.con_mu[idx] = mu;
+          st3(W.con_pos[idx], H.pos[k]);
+          W.con_solref[idx][0] = P.mix.solref[0]; W.con_solref[idx][1] = P.mix.solref[1];
+#pragma unroll
+          for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = P.mix.solimp[q];
+          st3(GQ_BX_CONNRM(W) + 3 * idx, H.nrm[k]);
+          GQ_BX_WCLS(W)[idx] = GQ_WCLS_SELF;
+#ifdef GQ_EMU_TRACE
+          if (getenv("GQ_EMU_TRACE")) printf("self contact idx %d items %d %d kind %d point %d dist %.6f pos %.5f %.5f %.5f nrm %.5f %.5f %.5f\n", idx, it1, it2, (int)m.sp[p].kind, k, (double)H.dist[k], (double)H.pos[k].x, (double)H.pos[k].y, (double)H.pos[k].z, (double)H.nrm[k].x, (double)H.nrm[k].y, (double)H.nrm[k].z);
+#endif
+          nfit++;
+        }
+      }
     }
-    const int added = popc64(f1 | f3 | f4 | f6);
-    ncon += added;
-    rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
-    if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
-    S.nself += added;
+    const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8) | ((nfit * vres) << 18)), 63);
+    ncon += tot & 0xff;
+    rows += (tot >> 8) & 0x3ff;
+    if constexpr (CONE) reserve += (tot >> 18) & 0x3ff;
+    S.nself += tot & 0xff;
   }
 }
 
@@ -695,7 +779,7 @@ __device__ inline void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel
  * foot_touch are updated; rows / row budget as in the floor pass).  Ends with a barrier. */
 template <bool CONE, bool SELF>
 __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
-                                          double bx, double by, float mu_env, const SelfPrefetch& pre) {
+                                          double bx, double by, float mu_env, const SelfPrefetch& pre, const ItemRegs& IT) {
   const int lane = lane_id();
   WorldAppend S;
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0;
@@ -718,16 +802,18 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
     while (todo) { /* wave-uniform */
       const int b = half * GQ_WAVE + ffs64(todo);
       todo &= todo - 1;
-      float dist; V3 nrm, pt;
-      if (!box_item_scan(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, dist, nrm, pt)) continue;
-      append_world_contacts<CONE>(W, m, m.box[b].cls, mu_env, dist, nrm, pt, S);
+      PairHit H;
+      if (!box_item_scan(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, IT, H)) continue;
+      append_world_contacts<CONE>(W, m, m.box[b].cls, mu_env, H, S);
       wave_barrier();
     }
   }
   if (m.hf_nrow > 0) { /* the scene's height field: one more world geom */
     float dist; V3 nrm, pt;
     if (hfield_item_scan(W, m, vx, vy, vz, bx, by, 0.0f, cg, rg, dist, nrm, pt)) {
-      append_world_contacts<CONE>(W, m, m.hf_cls, mu_env, dist, nrm, pt, S);
+      PairHit H;
+      H.n = dist < 1e29f ? 1 : 0; H.dist[0] = dist; H.nrm[0] = nrm; H.pos[0] = pt;
+      append_world_contacts<CONE>(W, m, m.hf_cls, mu_env, H, S);
       wave_barrier();
     }
   }

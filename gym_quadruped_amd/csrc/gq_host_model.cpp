@@ -354,20 +354,31 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       for (int i = 0; i < 7; i++) M.item_caps[it][i] = (float)d->geom_capsule[7 * g + i];
       M.item_body[it] = d->geom_bodyid[g] - 1;
     }
-    for (int b = 0; b < GQ_NB; b++) { /* bounding sphere of the body's capsules: centre = mean of the end points */
+    for (int it = 0; it < 4 + M.nlg; it++) { /* broad-phase sphere of the item: the primitive itself, else its proxy capsule */
+      const float* k = M.item_caps[it];
+      double c[3] = {0.5 * (k[0] + k[3]), 0.5 * (k[1] + k[4]), 0.5 * (k[2] + k[5])};
+      double r = 0.5 * std::sqrt((k[3] - k[0]) * (k[3] - k[0]) + (k[4] - k[1]) * (k[4] - k[1]) + (k[5] - k[2]) * (k[5] - k[2])) + k[6];
+      if (it >= 4 && M.lg[it - 4].ptype == 6) {
+        const GqDevGeom& G = M.lg[it - 4];
+        for (int i = 0; i < 3; i++) c[i] = G.pos[i];
+        r = std::sqrt((double)G.psize[0] * G.psize[0] + (double)G.psize[1] * G.psize[1] + (double)G.psize[2] * G.psize[2]);
+      }
+      for (int i = 0; i < 3; i++) M.item_bsph[it][i] = (float)c[i];
+      M.item_bsph[it][3] = (float)(r * 1.0001 + 1e-6);
+    }
+    for (int b = 0; b < GQ_NB; b++) { /* bounding sphere of the body's items: centre = mean of the item centres */
       double c[3] = {0, 0, 0}; int n = 0;
       for (int it = 0; it < 4 + M.nlg; it++)
-        if (M.item_body[it] == b) { for (int i = 0; i < 3; i++) c[i] += M.item_caps[it][i] + M.item_caps[it][3 + i]; n += 2; }
+        if (M.item_body[it] == b) { for (int i = 0; i < 3; i++) c[i] += M.item_bsph[it][i]; n += 1; }
       if (!n) continue;
       double r = 0;
       for (int i = 0; i < 3; i++) c[i] /= n;
       for (int it = 0; it < 4 + M.nlg; it++)
-        if (M.item_body[it] == b)
-          for (int e = 0; e < 2; e++) {
-            double s = 0;
-            for (int i = 0; i < 3; i++) { const double t = M.item_caps[it][3 * e + i] - c[i]; s += t * t; }
-            r = std::fmax(r, std::sqrt(s) + M.item_caps[it][6]);
-          }
+        if (M.item_body[it] == b) {
+          double s = 0;
+          for (int i = 0; i < 3; i++) { const double t = M.item_bsph[it][i] - c[i]; s += t * t; }
+          r = std::fmax(r, std::sqrt(s) + M.item_bsph[it][3]);
+        }
       for (int i = 0; i < 3; i++) M.body_sph[b][i] = (float)c[i];
       M.body_sph[b][3] = (float)(r * 1.0001 + 1e-6);
     }
@@ -388,6 +399,11 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       if (++P.count > 64) FAIL("more than 64 geom pairs between two bodies");
       GqDevSelfPair& S = M.sp[p];
       S.it1 = item_of_geom[g1]; S.it2 = item_of_geom[g2]; S.bp = M.nbp - 1;
+      { /* pair routine: a box against a sphere / capsule / box is exact (gq_pairs.h); everything else goes by capsule proxies */
+        auto prim = [&](int it) { if (it < 4) return 1; const int pt = M.lg[it - 4].ptype; return pt == 6 ? 2 : ((pt == 2 || pt == 3) ? 1 : 0); };
+        const int k1 = prim(S.it1), k2 = prim(S.it2);
+        S.kind = (k1 == 2 && k2 == 2) ? 3 : ((k1 == 2 && k2 == 1) ? 1 : ((k1 == 1 && k2 == 2) ? 2 : 0));
+      }
       WorldGeom w{d->geom_condim[g1], d->geom_priority[g1], d->geom_solmix[g1], d->geom_margin[g1], d->geom_gap[g1], d->geom_solref + 2 * g1, d->geom_solimp + 5 * g1};
       Mixed mx = mix_with(d, w, g2);
       if (mx.dim != 1 && mx.dim != 3 && !(d->cone == 1 && mx.dim == 6)) FAIL("self-contact dimension %d not supported", mx.dim);

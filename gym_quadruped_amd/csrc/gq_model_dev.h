@@ -54,7 +54,7 @@ struct GqDevBox { float pos[3], mat[9], size[3], rad; int32_t cls; };
 /* robot self-collision (mj_collision between two bodies of the robot): body pairs for the broad phase, geom pairs with
  * their mixed contact parameters for the narrow phase (capsule proxies, gym_quadruped_amd/selfcol.py) */
 struct GqDevBodyPair { int32_t b1, b2, first, count; };   /* kernel body indices (0 = base), range of geom pairs */
-struct GqDevSelfPair { int32_t it1, it2, bp; GqDevMix mix; }; /* collision items (k < 4 foot k, else 4 + link geom); mix.rule: 0 max, 1 item1, 2 item2 */ /* mat: columns = box axes in the world; rad: bounding sphere */
+struct GqDevSelfPair { int32_t it1, it2, bp, kind; GqDevMix mix; }; /* kind: 0 capsule proxies (segment-segment), 1 box (item 1) - sphere / capsule (item 2), 2 sphere / capsule - box, 3 box - box (gq_pairs.h) */ /* collision items (k < 4 foot k, else 4 + link geom); mix.rule: 0 max, 1 item1, 2 item2 */ /* mat: columns = box axes in the world; rad: bounding sphere */
 
 /* Everything lane `it` of the floor pass (S6: lane = collision item in MuJoCo's contact order) needs about its item, as ONE
  * contiguous 128-byte record: a single batch of loads, issued a stage early (the indirection con_order -> lg[] -> fields was two
@@ -122,6 +122,7 @@ struct GqDevModel {
   float body_sph[GQ_NB][4];                /* bounding sphere of the body's proxy capsules: centre (body frame), radius */
   float item_caps[4 + GQ_MAXLG][7];        /* proxy capsule of a collision item in its BODY frame: p0, p1, radius */
   int32_t item_body[4 + GQ_MAXLG];         /* kernel body index of the item */
+  float item_bsph[4 + GQ_MAXLG][4];        /* bounding sphere of the item's TRUE shape where it is a primitive (else of its proxy capsule): centre (body frame), radius */
   GqDevBodyPair bp[GQ_MAXBP];
   GqDevSelfPair sp[GQ_MAXSP];
   /* height field of the scene (0 rows: none): elevations in metres relative to hf_pos[2], row r <-> y, column c <-> x */

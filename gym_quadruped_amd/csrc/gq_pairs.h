@@ -1,0 +1,254 @@
+/*
+ * gq_pairs.h - exact narrow phases of primitive pairs, evaluated by ONE lane: sphere / capsule against box and box against
+ * box (robot-robot contacts and robot geoms on the static world boxes).  MuJoCo runs mjc_SphereBox, mjc_CapsuleBox (<= 2 points)
+ * and mjc_BoxBox (<= 8 points) there; what is computed here is their geometry - exact closest features, separating-axis
+ * penetration - with a manifold of at most 2 / 4 points chosen by the rules below, restated line for line in
+ * oracle/gq_oracle.c (capsule_box, box_box; pinned there against brute-force geometry, tests/test_oracle_invariants.py).
+ * Conventions: box frames as (centre c, matrix R whose COLUMNS are the box axes, row-major float[9], half sizes h); every
+ * routine returns the normal pointing from the (first) box to the other geom, the point midway between the two surfaces and
+ * the signed distance.
+ */
+#pragma once
+#include "gq_step_kernel.h"
+
+namespace gq {
+
+struct PairHit { int n; float dist[4]; V3 pos[4]; V3 nrm[4]; };
+
+/* the lane's item record (GqDevModel::item), in registers */
+struct ItemRegs {
+  int code, body, dim, fric_rule, ptype, calf;
+  float margin, inc, friction0, radius, solref[2], solimp[5], psize[3];
+  V3 pos;
+  float mat[9];
+};
+__device__ __forceinline__ ItemRegs item_fetch(const GQ_MODEL GqDevModel& m, const int it) {
+  const GQ_MODEL GqDevItem& I = m.item[it];
+  ItemRegs R;
+  R.code = I.code; R.body = I.body; R.dim = I.dim; R.fric_rule = I.fric_rule; R.ptype = I.ptype; R.calf = I.calf;
+  R.margin = I.margin; R.inc = I.inc; R.friction0 = I.friction0; R.radius = I.radius;
+  R.solref[0] = I.solref[0]; R.solref[1] = I.solref[1];
+#pragma unroll
+  for (int q = 0; q < 5; q++) R.solimp[q] = I.solimp[q];
+#pragma unroll
+  for (int q = 0; q < 3; q++) R.psize[q] = I.psize[q];
+  R.pos = ld3(I.pos);
+#pragma unroll
+  for (int q = 0; q < 9; q++) R.mat[q] = I.mat[q];
+  return R;
+}
+
+
+/* signed distance of point p (box frame) to the box of half sizes h, outward normal n (box frame); inside: nearest face */
+__device__ __forceinline__ float point_box(V3 p, V3 h, V3& n) {
+  const V3 q = v3(med3(p.x, -h.x, h.x), med3(p.y, -h.y, h.y), med3(p.z, -h.z, h.z));
+  const V3 d = p - q;
+  const float l2 = dot(d, d);
+  if (l2 > 0.0f) { const float inv = fast_rsqrt(l2); n = inv * d; return l2 * inv; }
+  const float ex = h.x - fabsf(p.x), ey = h.y - fabsf(p.y), ez = h.z - fabsf(p.z);
+  if (ex <= ey && ex <= ez) { n = v3(p.x >= 0.0f ? 1.0f : -1.0f, 0.0f, 0.0f); return -ex; }
+  if (ey <= ez) { n = v3(0.0f, p.y >= 0.0f ? 1.0f : -1.0f, 0.0f); return -ey; }
+  n = v3(0.0f, 0.0f, p.z >= 0.0f ? 1.0f : -1.0f);
+  return -ez;
+}
+
+/* capsule (axis p0-p1, radius r; a sphere when p0 == p1) against a box.  Point 1: the axis point closest to the box - the
+ * derivative of the (convex, piecewise quadratic) squared distance along the axis is piecewise linear with kinks where a
+ * coordinate crosses a face plane: evaluated at 0, 1 and the <= 6 kinks, the root lies between the last sample with a
+ * non-positive and the first with a positive derivative.  An axis that passes through the box: the middle of the part
+ * inside, pushed out through its nearest face.  Point 2: the end of the axis farther from point 1 if its own sphere is within the margin. */
+__device__ inline void capsule_box(V3 p0, V3 p1, float r, V3 bc, const float* bR, V3 bh, float margin, PairHit& H) {
+  H.n = 0;
+  const V3 a = matTvec(bR, p0 - bc), b = matTvec(bR, p1 - bc), d = b - a;
+  auto gfun = [&](float sv, float& dep) {
+    const V3 pp = a + sv * d;
+    const V3 qq = v3(med3(pp.x, -bh.x, bh.x), med3(pp.y, -bh.y, bh.y), med3(pp.z, -bh.z, bh.z));
+    dep = fminf(fminf(bh.x - fabsf(pp.x), bh.y - fabsf(pp.y)), bh.z - fabsf(pp.z));
+    return dot(d, pp - qq);
+  };
+  float cand[6];
+  bool cok[6];
+  {
+    const float ax[3] = {a.x, a.y, a.z}, dx[3] = {d.x, d.y, d.z}, hx[3] = {bh.x, bh.y, bh.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int sg = 0; sg < 2; sg++) {
+        const float sv = fabsf(dx[k]) > 1e-12f ? ((sg ? hx[k] : -hx[k]) - ax[k]) / dx[k] : -1.0f;
+        cand[2 * k + sg] = sv; cok[2 * k + sg] = sv > 0.0f && sv < 1.0f;
+      }
+  }
+  float dep0, dep1;
+  const float g0 = gfun(0.0f, dep0), g1 = gfun(1.0f, dep1);
+  const float epsg = 1e-5f * dot(d, d); /* an axis (numerically) parallel to the nearest face: the first end, whatever the round-off says */
+  float lo = 0.0f, glo = g0, hi = 1.0f, ghi = g1;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float di;
+    const float gi = gfun(cok[i] ? cand[i] : 0.0f, di);
+    if (cok[i]) {
+      if (gi < -epsg && cand[i] > lo) { lo = cand[i]; glo = gi; }   /* kinks where the derivative is (numerically) zero bound a flat stretch of */
+      if (gi > epsg && cand[i] < hi) { hi = cand[i]; ghi = gi; }     /* equally close points: the secant across it picks one of them, reproducibly */
+    }
+  }
+  float sstar = g0 >= -epsg ? 0.0f : (g1 <= epsg ? 1.0f : lo + (hi - lo) * (-glo) / (ghi - glo));
+  { /* an axis that passes through the box (slab clipping): the middle of the part inside, pushed out through its nearest face */
+    const float av[3] = {a.x, a.y, a.z}, dv[3] = {d.x, d.y, d.z}, hv[3] = {bh.x, bh.y, bh.z};
+    float tE = 0.0f, tX = 1.0f;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (fabsf(dv[k]) > 1e-12f) { const float s1 = (-hv[k] - av[k]) / dv[k], s2 = (hv[k] - av[k]) / dv[k]; tE = fmaxf(tE, fminf(s1, s2)); tX = fminf(tX, fmaxf(s1, s2)); }
+      else if (fabsf(av[k]) > hv[k]) ok = false;
+    }
+    if (ok && tE < tX) sstar = 0.5f * (tE + tX);
+  }
+  (void)dep0; (void)dep1;
+  const bool sphere = d.x == 0.0f && d.y == 0.0f && d.z == 0.0f;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    float sv = sstar;
+    if (q == 1) { sv = sstar < 0.499f ? 1.0f : 0.0f; /* (a geom placed symmetrically has s* = 1/2 up to round-off: not a threshold to sit on) */ if (fabsf(sv - sstar) <= 1e-3f || sphere || H.n == 0) break; }
+    const V3 pp = a + sv * d;
+    V3 nl;
+    const float dist = point_box(pp, bh, nl) - r;
+    if (dist >= margin) break;
+    const V3 nw = matvec(bR, nl);
+    H.dist[H.n] = dist; H.nrm[H.n] = nw;
+    H.pos[H.n] = bc + matvec(bR, pp) - (r + 0.5f * dist) * nw;
+    H.n++;
+  }
+}
+
+/* projection radius of a box (axes = columns of R, half sizes h) on the unit direction L */
+__device__ __forceinline__ float box_radius(const float* R, V3 h, V3 L) {
+  return h.x * fabsf(R[0] * L.x + R[3] * L.y + R[6] * L.z) + h.y * fabsf(R[1] * L.x + R[4] * L.y + R[7] * L.z) + h.z * fabsf(R[2] * L.x + R[5] * L.y + R[8] * L.z);
+}
+__device__ __forceinline__ V3 box_axis(const float* R, int i) { return v3(R[i], R[3 + i], R[6 + i]); }
+
+/* box A against box B: separating-axis test over the 15 axes; the axis of largest separation gives dist and the normal (an
+ * edge-edge axis only if it beats the best face axis by more than 1e-6 + 5 %).  Face axis: the corners of the other box within
+ * the margin of the reference face whose projection falls inside it (tolerance 1e-6) are the points, in corner order, the
+ * deepest 4 kept; none: the corners of the reference face against the other box; no corner carries the axis depth: one more
+ * point at the other box's support.  Edge axis: one point at the closest points of the two edges.  Normal from A to B. */
+__device__ inline void box_box(V3 ca, const float* Ra, V3 ha, V3 cb, const float* Rb, V3 hb, float margin, PairHit& H) {
+  H.n = 0;
+  const V3 t = cb - ca;
+  float best = -1e30f, beste = -1e30f;
+  V3 bn = v3(0.0f, 0.0f, 1.0f), en = v3(0.0f, 0.0f, 1.0f);
+  int bcode = 0, ei = -1, ej = 0;
+#pragma unroll
+  for (int w = 0; w < 2; w++)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const V3 L = box_axis(w ? Rb : Ra, i);
+      const float tl = dot(t, L), sep = fabsf(tl) - box_radius(Ra, ha, L) - box_radius(Rb, hb, L);
+      if (sep > best + 2e-6f) { best = sep; bcode = 3 * w + i; bn = tl >= 0.0f ? L : -1.0f * L; } /* a later axis must win by more than fp32 noise */
+    }
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      V3 L = cross(box_axis(Ra, i), box_axis(Rb, j));
+      const float l2 = dot(L, L);
+      if (l2 < 1e-2f) continue; /* (nearly) parallel edges: the closest points along them are ill-conditioned and the face axes describe the contact */
+      L = fast_rsqrt(l2) * L;
+      const float tl = dot(t, L), sep = fabsf(tl) - box_radius(Ra, ha, L) - box_radius(Rb, hb, L);
+      if (sep > beste + 2e-6f) { beste = sep; ei = i; ej = j; en = tl >= 0.0f ? L : -1.0f * L; }
+    }
+  const bool edge = ei >= 0 && beste > best + 1e-6f + 0.05f * fabsf(best);
+  const float sep = edge ? beste : best;
+  if (sep >= margin) return;
+  if (edge) {
+    V3 pa = ca, pb = cb;
+    const float hav[3] = {ha.x, ha.y, ha.z}, hbv[3] = {hb.x, hb.y, hb.z};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const V3 aq = box_axis(Ra, q), bq = box_axis(Rb, q);
+      const float da = dot(aq, en), db = dot(bq, en);
+      if (q != ei) pa = pa + (fabsf(da) < 1e-4f ? 0.0f : (da >= 0.0f ? hav[q] : -hav[q])) * aq;
+      if (q != ej) pb = pb + (fabsf(db) < 1e-4f ? 0.0f : (db >= 0.0f ? -hbv[q] : hbv[q])) * bq;
+    }
+    const V3 ua = box_axis(Ra, ei), ub = box_axis(Rb, ej), dp = pb - pa;
+    const float uaub = dot(ua, ub), q1 = dot(ua, dp), q2 = -dot(ub, dp), den = 1.0f - uaub * uaub;
+    float sa = den > 1e-12f ? (q1 + uaub * q2) / den : 0.0f, sb = den > 1e-12f ? (uaub * q1 + q2) / den : 0.0f;
+    sa = med3(sa, -hav[ei], hav[ei]); sb = med3(sb, -hbv[ej], hbv[ej]);
+    H.n = 1; H.dist[0] = sep; H.nrm[0] = en;
+    H.pos[0] = 0.5f * ((pa + sa * ua) + (pb + sb * ub));
+    return;
+  }
+  const bool refB = bcode >= 3;
+  const int ax = bcode % 3;
+  const V3 cr = refB ? cb : ca, hr = refB ? hb : ha, ci = refB ? ca : cb, hi = refB ? ha : hb;
+  const float* Rr = refB ? Rb : Ra;
+  const float* Ri = refB ? Ra : Rb;
+  const V3 nr = refB ? -1.0f * bn : bn; /* outward normal of the reference face, pointing at the other box */
+  const float sgn = dot(box_axis(Rr, ax), nr) >= 0.0f ? 1.0f : -1.0f;
+  const float hrv[3] = {hr.x, hr.y, hr.z};
+  /* candidates: up to 8, kept as (distance, point) with a validity mask; pass 0 incident corners, pass 1 reference-face corners */
+  float cd[8];
+  V3 cp[8];
+  int mask = 0;
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    const V3 loc = v3((v & 1) ? hi.x : -hi.x, (v & 2) ? hi.y : -hi.y, (v & 4) ? hi.z : -hi.z);
+    const V3 w = ci + matvec(Ri, loc);
+    const V3 lr = matTvec(Rr, w - cr);
+    const float lrv[3] = {lr.x, lr.y, lr.z};
+    const float dd = sgn * lrv[ax] - hrv[ax];
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) inside = inside && (k == ax || fabsf(lrv[k]) <= hrv[k] + 1e-6f);
+    cd[v] = dd; cp[v] = w - (0.5f * dd) * nr;
+    if (dd < margin && inside) mask |= 1 << v;
+  }
+  if (mask == 0) {
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+      const float lax = (v & (1 << ax)) ? 1.0f : -1.0f;
+      const V3 loc = v3((v & 1) ? hr.x : -hr.x, (v & 2) ? hr.y : -hr.y, (v & 4) ? hr.z : -hr.z);
+      const V3 w = cr + matvec(Rr, loc);
+      V3 nl;
+      const float dd = point_box(matTvec(Ri, w - ci), hi, nl);
+      cd[v] = dd; cp[v] = w + (0.5f * dd) * nr;
+      if (lax * sgn >= 0.0f && dd < margin) mask |= 1 << v;
+    }
+  }
+  float mincd = 1e30f;
+  int ncand = 0;
+#pragma unroll
+  for (int v = 0; v < 8; v++) { if ((mask >> v) & 1) { mincd = fminf(mincd, cd[v]); ncand++; } }
+  bool extra = ncand == 0 || mincd > sep + 1e-4f;
+  V3 xp = ci;
+  {
+    const float hiv[3] = {hi.x, hi.y, hi.z};
+#pragma unroll
+    for (int q = 0; q < 3; q++) { /* support point; an axis (numerically) parallel to the face contributes its midpoint */
+      const V3 iq = box_axis(Ri, q);
+      const float dq = dot(iq, nr);
+      xp = xp + (fabsf(dq) < 1e-4f ? 0.0f : (dq >= 0.0f ? -hiv[q] : hiv[q])) * iq;
+    }
+    xp = xp - (0.5f * sep) * nr;
+  }
+  if (extra && ncand == 8) { /* (cannot happen: eight corners inside the margin carry the depth) drop the last */
+    mask &= 0x7f; ncand = 7;
+  }
+  /* the deepest 4 in candidate order (the extra point comes last): drop the shallowest while more than 4 are left */
+  int total = ncand + (extra ? 1 : 0);
+  bool keepx = extra;
+#pragma unroll 1
+  for (; total > 4; total--) {
+    float wv = -1e30f;
+    int worst = -1;
+#pragma unroll
+    for (int v = 0; v < 8; v++) if (((mask >> v) & 1) && cd[v] >= wv) { wv = cd[v]; worst = v; }
+    if (keepx && sep >= wv) { keepx = false; }
+    else mask &= ~(1 << worst);
+  }
+#pragma unroll
+  for (int v = 0; v < 8; v++)
+    if (((mask >> v) & 1) && H.n < 4) { H.dist[H.n] = cd[v]; H.pos[H.n] = cp[v]; H.nrm[H.n] = bn; H.n++; }
+  if (keepx && H.n < 4) { H.dist[H.n] = sep; H.pos[H.n] = xp; H.nrm[H.n] = bn; H.n++; }
+}
+
+}  // namespace gq

@@ -156,28 +156,6 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
  * Whether a candidate IS a contact is its own `dist < margin` test - equivalent to the routines' early exits, because the first
  * candidate of a cylinder is never farther than the others.  A lift by dz moves every pt.z and dist by dz. */
 struct FloorCand { int n; float r, t1c, t1s; float dist[4]; V3 pt[4]; int key; }; /* key: 2 bits per candidate = its place in MuJoCo's order */
-/* the lane's item record (GqDevModel::item), in registers */
-struct ItemRegs {
-  int code, body, dim, fric_rule, ptype, calf;
-  float margin, inc, friction0, radius, solref[2], solimp[5], psize[3];
-  V3 pos;
-  float mat[9];
-};
-__device__ __forceinline__ ItemRegs item_fetch(const GQ_MODEL GqDevModel& m, const int it) {
-  const GQ_MODEL GqDevItem& I = m.item[it];
-  ItemRegs R;
-  R.code = I.code; R.body = I.body; R.dim = I.dim; R.fric_rule = I.fric_rule; R.ptype = I.ptype; R.calf = I.calf;
-  R.margin = I.margin; R.inc = I.inc; R.friction0 = I.friction0; R.radius = I.radius;
-  R.solref[0] = I.solref[0]; R.solref[1] = I.solref[1];
-#pragma unroll
-  for (int q = 0; q < 5; q++) R.solimp[q] = I.solimp[q];
-#pragma unroll
-  for (int q = 0; q < 3; q++) R.psize[q] = I.psize[q];
-  R.pos = ld3(I.pos);
-#pragma unroll
-  for (int q = 0; q < 9; q++) R.mat[q] = I.mat[q];
-  return R;
-}
 __device__ inline void floor_candidates(const WaveMem& W, const ItemRegs& G, FloorCand& C) {
   C.n = 0; C.r = 0.0f; C.t1c = 0.0f; C.t1s = 1.0f; C.key = 0xE4; /* places 0, 1, 2, 3 */
 #pragma unroll
@@ -693,7 +671,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   if constexpr (BOXES) {
     const double bx0 = W.bxy[0], by0 = W.bxy[1]; /* base x/y of this forward pass, f64 */
     const float mu_b = W.mu_env;
-    stage_box_contacts<CONE, SELF>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), bx0, by0, mu_b, self_pre);
+    stage_box_contacts<CONE, SELF>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), bx0, by0, mu_b, self_pre, IT);
   } else if constexpr (SELF) {
     const float mu_b = W.mu_env;
     stage_self_contacts<CONE>(W, m, mu_b, self_pre);
@@ -1462,6 +1440,7 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
        * every box still touched (boxes are convex: the pose above them is free) - a handful of scans instead of 100. */
       V3 calf_c; float calf_r;
       item_sphere(W, m, true, calf_c, calf_r);
+      const ItemRegs ITL = item_fetch(m, lane < 4 + m.nlg ? lane : 0); /* lane = position in con_order, as box_item_scan expects */
       for (int it = 0; it <= 100; it++) {
         float pen = floor_pen(dz);
         float clear = 0.0f; /* lift that takes the touching item above the box altogether */
@@ -1472,18 +1451,21 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
           while (todo) { /* wave-uniform */
             const int b = half * GQ_WAVE + ffs64(todo);
             todo &= todo - 1;
-            float bd; V3 bn, bp;
-            if (!box_item_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, bd, bn, bp)) continue;
+            PairHit BH;
+            if (!box_item_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, ITL, BH)) continue;
             if (lane < 4 + m.nlg) {
               const int code = m.con_order[lane];
               const bool calf = code < 4 || (m.lg[code - 4].body > 0 && (m.lg[code - 4].body - 1) % 3 == 2);
-              if (calf && bd < m.boxmix[m.box[b].cls][code].margin) {
-                pen = fmaxf(pen, fabsf(bd));
-                const GQ_MODEL GqDevBox& B = m.box[b];
-                const float ztop = B.pos[2] + fabsf(B.mat[6]) * B.size[0] + fabsf(B.mat[7]) * B.size[1] + fabsf(B.mat[8]) * B.size[2];
-                /* contact point is midway between the surfaces: the item's lowest point is at most |bd| + its radius below */
-                clear = fmaxf(clear, ztop - (bp.z + dz) + fabsf(bd) + 0.02f);
-              }
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                if (calf && k < BH.n && BH.dist[k] < m.boxmix[m.box[b].cls][code].margin) {
+                  const float bd = BH.dist[k];
+                  pen = fmaxf(pen, fabsf(bd));
+                  const GQ_MODEL GqDevBox& B = m.box[b];
+                  const float ztop = B.pos[2] + fabsf(B.mat[6]) * B.size[0] + fabsf(B.mat[7]) * B.size[1] + fabsf(B.mat[8]) * B.size[2];
+                  /* contact point is midway between the surfaces: the item's lowest point is at most |bd| + its radius below */
+                  clear = fmaxf(clear, ztop - (BH.pos[k].z + dz) + fabsf(bd) + 0.02f);
+                }
             }
             wave_barrier();
           }

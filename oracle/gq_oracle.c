@@ -612,6 +612,236 @@ static int sphere_hfield(const GqModelDesc* m, const double* p, double r, double
   return *dist < reach;
 }
 
+/* ------------------------------------------------------------------ exact narrow phases of primitive pairs (robot-robot and
+ * robot - world box): sphere / capsule against box and box against box.  MuJoCo runs mjc_SphereBox, mjc_CapsuleBox (<= 2
+ * points) and mjc_BoxBox (<= 8 points) there; those routines are long and their exact point sets cannot be checked here
+ * (MuJoCo unavailable), so what is restated is the GEOMETRY they compute - exact closest features, separating-axis
+ * penetration - with a contact manifold of at most 2 / 4 points chosen by rules stated below.
+ * Conventions as everywhere in MuJoCo: normal from geom 1 to geom 2, point midway between the surfaces, dist = signed
+ * distance along the normal (negative: penetration).  The routines return the normal pointing FROM THE BOX (first box) TO THE
+ * OTHER geom; callers flip it for the pair's geom order. */
+typedef struct { double dist, pos[3], nrm[3], tie; } PairPt; /* tie: margin by which the discrete choices behind the point were made (nearest face of a point inside a box, separating axis): test diagnostics, like Contact.tiegap */
+
+/* signed distance of point p (box frame) to the box of half sizes h, outward normal n (box frame); inside: nearest face */
+static double g_point_box_tie; /* set by point_box: gap between the nearest and the second nearest face of a point inside the box (1: outside) */
+static double point_box(const double* p, const double* h, double* n) {
+  double q[3], d[3], l2 = 0;
+  g_point_box_tie = 1.0;
+  for (int k = 0; k < 3; k++) { q[k] = fmin(fmax(p[k], -h[k]), h[k]); d[k] = p[k] - q[k]; l2 += d[k] * d[k]; }
+  if (l2 > 0) { const double l = sqrt(l2); for (int k = 0; k < 3; k++) n[k] = d[k] / l; return l; }
+  int ax = 0; double dmin = 1e300, dsec = 1e300;
+  for (int k = 0; k < 3; k++) { const double e = h[k] - fabs(p[k]); if (e < dmin) { dsec = dmin; dmin = e; ax = k; } else if (e < dsec) dsec = e; }
+  n[0] = n[1] = n[2] = 0; n[ax] = p[ax] >= 0 ? 1 : -1;
+  g_point_box_tie = dsec - dmin;
+  return -dmin;
+}
+
+/* capsule (axis p0-p1, radius r; a sphere when p0 == p1) against a box (centre bc, axes = columns of bR, half sizes bh).
+ * Point 1: the point of the axis closest to the box - the distance of p0 + s (p1 - p0) to the box is convex and piecewise
+ * quadratic in s, its derivative piecewise linear with kinks where a coordinate crosses a face plane: evaluated at 0, 1 and
+ * the (<= 6) kinks, the root lies between the last kink with a non-positive and the first with a positive derivative (exact).
+ * An axis that passes through the box: the middle of the part inside, pushed out through its nearest face.
+ * Point 2: the end of the axis farther from point 1, if its own sphere is within the margin of the box (a capsule lying
+ * along a face or an edge is carried at both ends, like mjc_CapsuleBox's two-point case). */
+static int capsule_box(const double* p0, const double* p1, double r, const double* bc, const double* bR, const double* bh, double margin, PairPt* out) {
+  double a[3], b[3], d[3], t0[3], t1[3];
+  for (int k = 0; k < 3; k++) { t0[k] = p0[k] - bc[k]; t1[k] = p1[k] - bc[k]; }
+  mulmatTvec3(a, bR, t0); mulmatTvec3(b, bR, t1);
+  for (int k = 0; k < 3; k++) d[k] = b[k] - a[k];
+  double cand[8]; int nc = 0;
+  cand[nc++] = 0; cand[nc++] = 1;
+  for (int k = 0; k < 3; k++)
+    for (int sg = -1; sg <= 1; sg += 2)
+      if (fabs(d[k]) > 1e-12) { const double sv = (sg * bh[k] - a[k]) / d[k]; if (sv > 0 && sv < 1) cand[nc++] = sv; }
+#define GQO_G(sv, gout, depthout) do { double pp[3], gg = 0, dep = 1e300; for (int k = 0; k < 3; k++) { pp[k] = a[k] + (sv) * d[k]; \
+    const double qq = fmin(fmax(pp[k], -bh[k]), bh[k]); gg += d[k] * (pp[k] - qq); dep = fmin(dep, bh[k] - fabs(pp[k])); } gout = gg; depthout = dep; } while (0)
+  double g0, g1, dep0, dep1, sstar;
+  GQO_G(0.0, g0, dep0); GQO_G(1.0, g1, dep1); (void)dep0; (void)dep1;
+  const double epsg = 1e-5 * dot3(d, d); /* an axis (numerically) parallel to the nearest face: the first end, whatever the round-off says */
+  if (g0 >= -epsg) sstar = 0;
+  else if (g1 <= epsg) sstar = 1;
+  else {
+    double lo = 0, glo = g0, hi = 1, ghi = g1;
+    for (int i = 2; i < nc; i++) {
+      double gi, di; GQO_G(cand[i], gi, di); (void)di;
+      if (gi < -epsg && cand[i] > lo) { lo = cand[i]; glo = gi; }   /* kinks where the derivative is (numerically) zero bound a flat stretch of */
+      if (gi > epsg && cand[i] < hi) { hi = cand[i]; ghi = gi; }     /* equally close points: the secant across it picks one of them, reproducibly */
+    }
+    sstar = lo + (hi - lo) * (-glo) / (ghi - glo);
+  }
+  { /* an axis that passes through the box (slab clipping): the middle of the part inside, pushed out through its nearest face */
+    double tE = 0, tX = 1; int ok = 1;
+    for (int k = 0; k < 3; k++) {
+      if (fabs(d[k]) > 1e-12) { const double s1 = (-bh[k] - a[k]) / d[k], s2 = (bh[k] - a[k]) / d[k]; tE = fmax(tE, fmin(s1, s2)); tX = fmin(tX, fmax(s1, s2)); }
+      else if (fabs(a[k]) > bh[k]) ok = 0;
+    }
+    if (ok && tE < tX) sstar = 0.5 * (tE + tX);
+  }
+#undef GQO_G
+  int n = 0;
+  for (int q = 0; q < 2; q++) {
+    double sv = sstar;
+    if (q == 1) { sv = sstar < 0.499 ? 1.0 : 0.0; /* (a geom placed symmetrically has s* = 1/2 up to round-off: not a threshold to sit on) */ if (fabs(sv - sstar) <= 1e-3 || (d[0] == 0 && d[1] == 0 && d[2] == 0)) break; }
+    double pp[3], nl[3];
+    for (int k = 0; k < 3; k++) pp[k] = a[k] + sv * d[k];
+    const double dist = point_box(pp, bh, nl) - r;
+    if (dist >= margin) { if (q == 0) return 0; break; }
+    PairPt* P = &out[n++];
+    double pw[3];
+    P->tie = g_point_box_tie;
+    mulmatvec3(P->nrm, bR, nl);
+    mulmatvec3(pw, bR, pp);
+    P->dist = dist;
+    for (int k = 0; k < 3; k++) P->pos[k] = bc[k] + pw[k] - P->nrm[k] * (r + 0.5 * dist);
+  }
+  return n;
+}
+
+/* box A against box B (centres, axes = columns of R, half sizes).  Separating-axis test over the 15 axes: the axis of largest
+ * separation (least penetration) gives dist and the normal (an edge-edge axis wins only if it beats the best face axis by more
+ * than 1e-6 + 5 % of its magnitude - resting boxes sit on faces).  Face axis: the corners of the OTHER box within the margin of
+ * the reference face plane whose projection falls inside the reference face (a tolerance of 1e-6) are the contact points, in
+ * corner order, the deepest 4 kept; when there are none (the reference face lies inside the other box's face) the corners of
+ * the reference face are tested against the other box instead.  Edge axis: one point at the closest points of the two edges.
+ * Normal from A to B. */
+static int box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb, double margin, PairPt* out) {
+  double t[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+  double best = -1e300, second = -1e300, bn[3] = {0, 0, 1}; int bcode = -1;
+  double beste = -1e300, en[3] = {0, 0, 1}; int ei = -1, ej = -1;
+  const double* R[2] = {Ra, Rb};
+  for (int w = 0; w < 2; w++)
+    for (int i = 0; i < 3; i++) {
+      double L[3] = {R[w][i], R[w][3 + i], R[w][6 + i]};
+      double tl = dot3(t, L), ra = 0, rb = 0;
+      for (int j = 0; j < 3; j++) {
+        ra += ha[j] * fabs(Ra[j] * L[0] + Ra[3 + j] * L[1] + Ra[6 + j] * L[2]);
+        rb += hb[j] * fabs(Rb[j] * L[0] + Rb[3 + j] * L[1] + Rb[6 + j] * L[2]);
+      }
+      const double sep = fabs(tl) - ra - rb;
+      if (sep > best + 2e-6) { second = best; best = sep; bcode = 3 * w + i; for (int k = 0; k < 3; k++) bn[k] = tl >= 0 ? L[k] : -L[k]; } /* a later axis must win by more than fp32 noise */
+      else if (sep > second) second = sep;
+    }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double A[3] = {Ra[i], Ra[3 + i], Ra[6 + i]}, B[3] = {Rb[j], Rb[3 + j], Rb[6 + j]}, L[3];
+      cross3(L, A, B);
+      const double ln = sqrt(dot3(L, L));
+      if (ln < 0.1) continue; /* (nearly) parallel edges: the closest points along them are ill-conditioned and the face axes describe the contact */
+      for (int k = 0; k < 3; k++) L[k] /= ln;
+      double tl = dot3(t, L), ra = 0, rb = 0;
+      for (int q = 0; q < 3; q++) {
+        ra += ha[q] * fabs(Ra[q] * L[0] + Ra[3 + q] * L[1] + Ra[6 + q] * L[2]);
+        rb += hb[q] * fabs(Rb[q] * L[0] + Rb[3 + q] * L[1] + Rb[6 + q] * L[2]);
+      }
+      const double sep = fabs(tl) - ra - rb;
+      if (sep > beste + 2e-6) { beste = sep; ei = i; ej = j; for (int k = 0; k < 3; k++) en[k] = tl >= 0 ? L[k] : -L[k]; }
+    }
+  const int edge = ei >= 0 && beste > best + 1e-6 + 0.05 * fabs(best);
+  const double sep = edge ? beste : best;
+  if (sep >= margin) return 0;
+  if (edge) { /* closest points of edge i of A and edge j of B: the edges nearest the other box along the axis */
+    double pa[3], pb[3], ua[3] = {Ra[ei], Ra[3 + ei], Ra[6 + ei]}, ub[3] = {Rb[ej], Rb[3 + ej], Rb[6 + ej]};
+    for (int k = 0; k < 3; k++) { pa[k] = ca[k]; pb[k] = cb[k]; }
+    for (int q = 0; q < 3; q++) {
+      if (q != ei) { const double dq = Ra[q] * en[0] + Ra[3 + q] * en[1] + Ra[6 + q] * en[2], sg = fabs(dq) < 1e-4 ? 0 : (dq >= 0 ? 1 : -1); for (int k = 0; k < 3; k++) pa[k] += sg * ha[q] * Ra[3 * k + q]; }
+      if (q != ej) { const double dq = Rb[q] * en[0] + Rb[3 + q] * en[1] + Rb[6 + q] * en[2], sg = fabs(dq) < 1e-4 ? 0 : (dq >= 0 ? -1 : 1); for (int k = 0; k < 3; k++) pb[k] += sg * hb[q] * Rb[3 * k + q]; }
+    }
+    /* lines pa + sa ua, pb + sb ub */
+    double dp[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const double uaub = dot3(ua, ub), q1 = dot3(ua, dp), q2 = -dot3(ub, dp), den = 1 - uaub * uaub;
+    double sa = den > 1e-12 ? (q1 + uaub * q2) / den : 0, sb = den > 1e-12 ? (uaub * q1 + q2) / den : 0;
+    sa = fmin(fmax(sa, -ha[ei]), ha[ei]); sb = fmin(fmax(sb, -hb[ej]), hb[ej]);
+    PairPt* P = &out[0];
+    P->dist = sep; P->tie = fabs(beste - (best + 1e-6 + 0.05 * fabs(best)));
+    for (int k = 0; k < 3; k++) { P->nrm[k] = en[k]; P->pos[k] = 0.5 * ((pa[k] + sa * ua[k]) + (pb[k] + sb * ub[k])); }
+    return 1;
+  }
+  /* face axis: reference box (the one that owns the axis) and the other ("incident") box */
+  const int refB = bcode >= 3, ax = bcode % 3;
+  const double* cr = refB ? cb : ca; const double* Rr = refB ? Rb : Ra; const double* hr = refB ? hb : ha;
+  const double* ci = refB ? ca : cb; const double* Ri = refB ? Ra : Rb; const double* hi = refB ? ha : hb;
+  double nr[3]; /* outward normal of the reference face, pointing at the incident box */
+  for (int k = 0; k < 3; k++) nr[k] = refB ? -bn[k] : bn[k];
+  double cd[8], cp[8][3]; int ncand = 0;
+  for (int pass = 0; pass < 2 && ncand == 0; pass++) {
+    /* pass 0: corners of the incident box against the reference face; pass 1: corners of the reference face against the incident box */
+    for (int v = 0; v < 8; v++) {
+      double loc[3] = {(v & 1) ? 1.0 : -1.0, (v & 2) ? 1.0 : -1.0, (v & 4) ? 1.0 : -1.0}, w[3];
+      if (pass == 0) {
+        for (int k = 0; k < 3; k++) w[k] = ci[k] + Ri[3 * k] * loc[0] * hi[0] + Ri[3 * k + 1] * loc[1] * hi[1] + Ri[3 * k + 2] * loc[2] * hi[2];
+        double rel[3] = {w[0] - cr[0], w[1] - cr[1], w[2] - cr[2]}, lr[3];
+        mulmatTvec3(lr, Rr, rel);
+        const double sgn = (Rr[ax] * nr[0] + Rr[3 + ax] * nr[1] + Rr[6 + ax] * nr[2]) >= 0 ? 1 : -1;
+        const double dd = sgn * lr[ax] - hr[ax];
+        int inside = 1;
+        for (int k = 0; k < 3; k++) if (k != ax && fabs(lr[k]) > hr[k] + 1e-6) inside = 0;
+        if (dd < margin && inside) { cd[ncand] = dd; for (int k = 0; k < 3; k++) cp[ncand][k] = w[k] - nr[k] * 0.5 * dd; ncand++; }
+      } else {
+        const double sgn = (Rr[ax] * nr[0] + Rr[3 + ax] * nr[1] + Rr[6 + ax] * nr[2]) >= 0 ? 1 : -1;
+        if (loc[ax] * sgn < 0) continue; /* only the four corners of the reference face */
+        for (int k = 0; k < 3; k++) w[k] = cr[k] + Rr[3 * k] * loc[0] * hr[0] + Rr[3 * k + 1] * loc[1] * hr[1] + Rr[3 * k + 2] * loc[2] * hr[2];
+        double rel[3] = {w[0] - ci[0], w[1] - ci[1], w[2] - ci[2]}, li[3], nl[3];
+        mulmatTvec3(li, Ri, rel);
+        const double dd = point_box(li, hi, nl);
+        if (dd < margin) { cd[ncand] = dd; for (int k = 0; k < 3; k++) cp[ncand][k] = w[k] + nr[k] * 0.5 * dd; ncand++; }
+      }
+    }
+  }
+  double mincd = 1e300;
+  for (int v = 0; v < ncand; v++) mincd = fmin(mincd, cd[v]);
+  if (ncand == 0 || mincd > sep + 1e-4) { /* no corner carries the penetration the axis test found (faces crossing, edges poking through):
+                                           * one more point at the support of the incident box, at the axis depth */
+    double w[3] = {ci[0], ci[1], ci[2]};
+    for (int q = 0; q < 3; q++) { /* support point; an axis (numerically) parallel to the face contributes its midpoint */
+      const double dq = Ri[q] * nr[0] + Ri[3 + q] * nr[1] + Ri[6 + q] * nr[2], sg = fabs(dq) < 1e-4 ? 0 : (dq >= 0 ? -1 : 1);
+      for (int k = 0; k < 3; k++) w[k] += sg * hi[q] * Ri[3 * k + q];
+    }
+    if (ncand == 8) ncand = 7;
+    cd[ncand] = sep; for (int k = 0; k < 3; k++) cp[ncand][k] = w[k] - nr[k] * 0.5 * sep;
+    ncand++;
+  }
+  /* the deepest 4, in candidate order */
+  int keep[8], nk = 0;
+  for (int v = 0; v < ncand; v++) keep[v] = 1;
+  for (int drop = ncand; drop > 4; drop--) { int worst = -1; double wv = -1e300; for (int v = 0; v < ncand; v++) if (keep[v] && cd[v] >= wv) { wv = cd[v]; worst = v; } keep[worst] = 0; }
+  for (int v = 0; v < ncand; v++)
+    if (keep[v]) { PairPt* P = &out[nk++]; P->dist = cd[v]; P->tie = fmin(fabs(best - second - 2e-6), ei >= 0 ? fabs(beste - (best + 1e-6 + 0.05 * fabs(best))) : 1.0); for (int k = 0; k < 3; k++) { P->pos[k] = cp[v][k]; P->nrm[k] = bn[k]; } }
+  return nk;
+}
+
+/* test hooks (tests/test_oracle_invariants.py checks the pair routines against brute-force geometry): out = n x [dist, pos[3], nrm[3]] */
+int gqo_test_capsule_box(const double* p0, const double* p1, double r, const double* bc, const double* bR, const double* bh, double margin, double* out) {
+  PairPt pts[4];
+  const int n = capsule_box(p0, p1, r, bc, bR, bh, margin, pts);
+  for (int q = 0; q < n; q++) { out[7 * q] = pts[q].dist; memcpy(out + 7 * q + 1, pts[q].pos, 24); memcpy(out + 7 * q + 4, pts[q].nrm, 24); }
+  return n;
+}
+int gqo_test_box_box(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb, double margin, double* out) {
+  PairPt pts[4];
+  const int n = box_box(ca, Ra, ha, cb, Rb, hb, margin, pts);
+  for (int q = 0; q < n; q++) { out[7 * q] = pts[q].dist; memcpy(out + 7 * q + 1, pts[q].pos, 24); memcpy(out + 7 * q + 4, pts[q].nrm, 24); }
+  return n;
+}
+
+/* a robot collision geom as a primitive for the pair routines: 1 sphere / capsule (world end points, radius), 2 box (world
+ * centre, axes, half sizes), 0 anything else (cylinders, hulls: capsule proxy / vertex cloud) */
+typedef struct { int kind; double p0[3], p1[3], r, c[3], R[9], h[3]; } Prim;
+static void prim_of_geom(const GqOracle* o, int g, Prim* P) {
+  const GqModelDesc* m = &o->d;
+  const int cl = m->geom_cloudid[g], nv = m->cloud_vertnum[cl], type = m->geom_type ? m->geom_type[g] : (nv == 1 ? 2 : (nv == 2 ? 3 : 7));
+  const double* V = m->vert_pos + 3 * m->cloud_vertadr[cl];
+  P->kind = 0;
+  if ((type == 2 && nv == 1) || (type == 3 && nv == 2)) {
+    P->kind = 1; P->r = m->cloud_radius[cl];
+    mulmatvec3(P->p0, o->geom_xmat[g], V); mulmatvec3(P->p1, o->geom_xmat[g], V + 3 * (nv - 1));
+    for (int k = 0; k < 3; k++) { P->p0[k] += o->geom_xpos[g][k]; P->p1[k] += o->geom_xpos[g][k]; }
+  } else if (type == 6 && nv == 8) {
+    P->kind = 2;
+    memcpy(P->c, o->geom_xpos[g], sizeof P->c); memcpy(P->R, o->geom_xmat[g], sizeof P->R);
+    for (int k = 0; k < 3; k++) P->h[k] = V[21 + k];
+  }
+}
+
 static void gqo_collision(GqOracle* o) {
   const GqModelDesc* m = &o->d;
   o->ncon = 0;
@@ -726,6 +956,20 @@ static void gqo_collision(GqOracle* o) {
       double dc[3] = {o->geom_xpos[g][0] - bp[0], o->geom_xpos[g][1] - bp[1], o->geom_xpos[g][2] - bp[2]};
       const double brad = sqrt(bs[0] * bs[0] + bs[1] * bs[1] + bs[2] * bs[2]);
       if (sqrt(dot3(dc, dc)) > brad + m->geom_rbound[g] + margin) continue; /* bounding spheres */
+      Prim P;
+      prim_of_geom(o, g, &P);
+      if (P.kind != 0 && !is_foot(m, g)) { /* capsule / box geoms of the robot: exact pair routines (feet keep the sphere path below) */
+        PairPt pts[4];
+        const int np = P.kind == 1 ? capsule_box(P.p0, P.p1, P.r, bp, bm, bs, margin, pts) : box_box(bp, bm, bs, P.c, P.R, P.h, margin, pts);
+        for (int q = 0; q < np && o->ncon < NCON; q++) {
+          Contact* c = &o->contact[o->ncon++];
+          c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = pts[q].dist; c->tiegap = pts[q].tie;
+          memcpy(c->pos, pts[q].pos, sizeof c->pos);
+          set_frame(c, pts[q].nrm, NULL);
+          contact_param(o, w, g, c);
+        }
+        continue;
+      }
       double best = 1e300, second = 1e300, bn[3] = {0, 0, 1}, bv[3] = {0, 0, 0};
       for (int v = 0; v < m->cloud_vertnum[cl]; v++) {
         double wv[3], lc[3], q[3], nl[3], dist;
@@ -795,6 +1039,27 @@ static void gqo_collision(GqOracle* o) {
    * midway between the surfaces (MuJoCo's convention for every pair routine).  Coincident axes (no normal) yield no contact. */
   for (int p = 0; p < m->nselfpair && o->ncon < NCON; p++) {
     const int g1 = m->selfpair_geom1[p], g2 = m->selfpair_geom2[p], b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+    { /* primitive pairs with a box: exact routines (sphere / capsule against box, box against box) */
+      Prim P1, P2;
+      prim_of_geom(o, g1, &P1); prim_of_geom(o, g2, &P2);
+      if ((P1.kind == 2 && P2.kind != 0) || (P2.kind == 2 && P1.kind != 0)) {
+        const double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+        PairPt pts[4];
+        int np, flip = 0;
+        if (P1.kind == 2 && P2.kind == 2) np = box_box(P1.c, P1.R, P1.h, P2.c, P2.R, P2.h, margin, pts);
+        else if (P1.kind == 2) np = capsule_box(P2.p0, P2.p1, P2.r, P1.c, P1.R, P1.h, margin, pts); /* normal box (1) -> capsule (2) */
+        else { np = capsule_box(P1.p0, P1.p1, P1.r, P2.c, P2.R, P2.h, margin, pts); flip = 1; }       /* box is geom 2: flip to 1 -> 2 */
+        for (int q = 0; q < np && o->ncon < NCON; q++) {
+          Contact* c = &o->contact[o->ncon++];
+          c->geom = g2; c->body = b2; c->geom1 = g1; c->body1 = b1; c->dist = pts[q].dist; c->tiegap = pts[q].tie;
+          memcpy(c->pos, pts[q].pos, sizeof c->pos);
+          double nrm[3] = {flip ? -pts[q].nrm[0] : pts[q].nrm[0], flip ? -pts[q].nrm[1] : pts[q].nrm[1], flip ? -pts[q].nrm[2] : pts[q].nrm[2]};
+          set_frame(c, nrm, NULL);
+          contact_param_pair(o, g1, g2, c);
+        }
+        continue;
+      }
+    }
     const double* k1 = m->geom_capsule + 7 * g1; const double* k2 = m->geom_capsule + 7 * g2;
     double a0[3], a1[3], e0[3], e1[3], c1[3], c2[3], d[3];
     mulmatvec3(a0, o->xmat[b1], k1); mulmatvec3(a1, o->xmat[b1], k1 + 3);

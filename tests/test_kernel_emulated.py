@@ -613,3 +613,66 @@ def test_plane_multipoint_contacts_match_oracle(robot):
     tally.finish(f'plane multi-point {robot}', min_checked=0.4, max_tie=0.1, max_budget=0.6)
     have = {int(t) for g, t in enumerate(md.geom_type) if md.geom_bodyid[g] != 0 and md.geom_cloudid[g] >= 0 and t in (3, 5, 6)}
     assert types == have, (types, have)   # every primitive type of the robot produced a multi-point contact that was compared
+
+
+def test_pair_routines_kernel_equals_oracle():
+    """csrc/gq_pairs.h (capsule_box, box_box: fp32, called directly under the emulator) against the oracle's restatement
+    (oracle/gq_oracle.c, fp64) on random and on resting configurations: same number of points, same order, distances /
+    positions / normals to fp32 accuracy.  The oracle versions are pinned against brute-force geometry in
+    tests/test_oracle_invariants.py."""
+    import ctypes as C
+    from scipy.spatial.transform import Rotation
+    from helpers import emu_lib
+    from test_oracle_invariants import _pair_lib, _np_ptr
+    Lo, Le = _pair_lib(), emu_lib()
+    P = C.c_void_p
+    Le.emu_capsule_box.argtypes = [P, P, C.c_float, P, P, P, C.c_float, P]
+    Le.emu_box_box.argtypes = [P, P, P, P, P, P, C.c_float, P]
+    rng = np.random.default_rng(12)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    ncap = nbox = multi = 0
+    for trial in range(1500):
+        h = rng.uniform(0.02, 0.3, 3); R = Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix(); c = rng.uniform(-1, 1, 3)
+        margin = 0.001
+        if trial % 2 == 0:   # capsule - box
+            r = rng.uniform(0.005, 0.05)
+            if trial % 8 == 0:
+                a = np.array([rng.uniform(-h[0], h[0]), rng.uniform(-h[1], h[1]), h[2] + r + rng.uniform(-0.002, 0.0005)])
+                b = np.array([rng.uniform(-h[0], h[0]), rng.uniform(-h[1], h[1]), a[2] + rng.uniform(-2e-4, 2e-4)])
+                p0, p1 = c + R @ a, c + R @ b
+            else:
+                p0 = c + R @ (rng.uniform(-1.3, 1.3, 3) * h); p1 = p0 + rng.normal(0, 0.1, 3)
+            # fp32 inputs for both, so that the comparison is about the arithmetic only
+            p0, p1, cc, Rc, hc = (f32(x).astype(np.float64) for x in (p0, p1, c, R, h))
+            rr = float(np.float32(r))
+            oo, oe = np.zeros(28), np.zeros(28, np.float32)
+            Rc = np.ascontiguousarray(Rc)
+            fa = [f32(x) for x in (p0, p1, cc, Rc, hc)]   # keep the fp32 copies alive across the call
+            no = Lo.gqo_test_capsule_box(_np_ptr(p0), _np_ptr(p1), rr, _np_ptr(cc), _np_ptr(Rc), _np_ptr(hc), margin, _np_ptr(oo))
+            ne = Le.emu_capsule_box(_np_ptr(fa[0]), _np_ptr(fa[1]), rr, _np_ptr(fa[2]), _np_ptr(fa[3]), _np_ptr(fa[4]), margin, _np_ptr(oe))
+            ncap += no > 0
+        else:
+            hb = rng.uniform(0.02, 0.3, 3)
+            if trial % 6 == 1:
+                hb[:2] = rng.uniform(0.2, 0.9, 2) * h[:2]
+                Rb = R @ Rotation.from_euler('z', rng.uniform(-0.3, 0.3)).as_matrix()
+                cb = c + R @ np.array([*(rng.uniform(-0.05, 0.05, 2) * h[:2]), h[2] + hb[2] + rng.uniform(-0.003, 0.0008)])
+            else:
+                Rb = Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix()
+                cb = c + rng.normal(0, 1, 3) * (h + hb) * 0.8
+            cc, Rc, hc, cb, Rb, hb = (f32(x).astype(np.float64) for x in (c, R, h, cb, Rb, hb))
+            oo, oe = np.zeros(28), np.zeros(28, np.float32)
+            Rc, Rb = np.ascontiguousarray(Rc), np.ascontiguousarray(Rb)
+            fa = [f32(x) for x in (cc, Rc, hc, cb, Rb, hb)]
+            no = Lo.gqo_test_box_box(_np_ptr(cc), _np_ptr(Rc), _np_ptr(hc), _np_ptr(cb), _np_ptr(Rb), _np_ptr(hb), margin, _np_ptr(oo))
+            ne = Le.emu_box_box(_np_ptr(fa[0]), _np_ptr(fa[1]), _np_ptr(fa[2]), _np_ptr(fa[3]), _np_ptr(fa[4]), _np_ptr(fa[5]), margin, _np_ptr(oe))
+            nbox += no > 0
+        if no and abs(oo[0::7][:no]).max() > 0.02:
+            continue   # centimetres of overlap: decisions between nearly equal axes / deepest samples may differ; contacts are created at the margin
+        assert no == ne, (trial, no, ne, oo[:7], oe[:7])
+        multi += no > 1
+        for q in range(no):
+            assert abs(oo[7 * q] - oe[7 * q]) < 2e-6, (trial, q, oo[7 * q:7 * q + 7], oe[7 * q:7 * q + 7])
+            np.testing.assert_allclose(oe[7 * q + 1:7 * q + 4], oo[7 * q + 1:7 * q + 4], atol=5e-6, err_msg=f'trial {trial} point {q} pos')
+            np.testing.assert_allclose(oe[7 * q + 4:7 * q + 7], oo[7 * q + 4:7 * q + 7], atol=2e-4, err_msg=f'trial {trial} point {q} normal')
+    assert ncap > 100 and nbox > 100 and multi > 60, (ncap, nbox, multi)

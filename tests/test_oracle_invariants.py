@@ -428,3 +428,143 @@ def test_plane_routines_against_brute_force_geometry(robot):
     for t in (3, 5, 6):
         if t in have:
             assert seen[t] >= 10 and multi[t] >= 3, (robot, t, seen, multi)
+
+
+def _pair_lib():
+    import ctypes as C
+    from oracle.oracle import lib
+    L = lib()
+    P = C.c_void_p
+    L.gqo_test_capsule_box.argtypes = [P, P, C.c_double, P, P, P, C.c_double, P]
+    L.gqo_test_box_box.argtypes = [P, P, P, P, P, P, C.c_double, P]
+    return L
+
+
+def _np_ptr(a):
+    return a.ctypes.data
+
+
+def _point_box_dist(p, c, R, h):
+    """distance of world points p [n,3] to the box (centre c, axes = columns of R, half sizes h); negative inside"""
+    l = (p - c) @ R
+    q = np.clip(l, -h, h)
+    out = np.linalg.norm(l - q, axis=1)
+    inside = np.all(np.abs(l) <= h, axis=1)
+    out[inside] = -np.min(h - np.abs(l[inside]), axis=1)
+    return out
+
+
+def test_capsule_box_routine_against_brute_force():
+    """capsule_box (oracle/gq_oracle.c): the first point is the global minimum of the point-box distance over a densely
+    sampled axis; points lie midway between the surfaces along the returned normal; a capsule resting along a face gets a
+    point at both ends; swapping the end points changes nothing."""
+    from scipy.spatial.transform import Rotation
+    L = _pair_lib()
+    rng = np.random.default_rng(4)
+    both = 0
+    for trial in range(400):
+        h = rng.uniform(0.02, 0.3, 3)
+        R = Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix()
+        c = rng.uniform(-1, 1, 3)
+        r = rng.uniform(0.005, 0.05)
+        if trial % 4 == 0:   # lying (almost) along the +z face
+            a = np.array([rng.uniform(-h[0], h[0]), rng.uniform(-h[1], h[1]), h[2] + r + rng.uniform(-0.002, 0.0005)])
+            b = np.array([rng.uniform(-h[0], h[0]), rng.uniform(-h[1], h[1]), a[2] + rng.uniform(-2e-4, 2e-4)])
+            p0, p1 = c + R @ a, c + R @ b
+        else:
+            p0 = c + R @ (rng.uniform(-1.6, 1.6, 3) * h)
+            p1 = p0 + rng.normal(0, 0.15, 3)
+        margin = 0.001
+        out = np.zeros(28)
+        Rc = np.ascontiguousarray(R)
+        n = L.gqo_test_capsule_box(_np_ptr(p0), _np_ptr(p1), r, _np_ptr(c), _np_ptr(Rc), _np_ptr(h), margin, _np_ptr(out))
+        sv = np.linspace(0, 1, 20001)
+        pts = p0 + sv[:, None] * (p1 - p0)
+        dd = _point_box_dist(pts, c, R, h)
+        dmin = dd.min()
+        if dmin - r >= margin + 1e-9:
+            assert n == 0
+            continue
+        if dmin <= 0:
+            continue   # axis inside the box: the deepest-sample rule, not a closest-point statement
+        # the closest point is among the (<= 2) points; it is the FIRST one unless the axis is parallel to the face within 1e-5
+        # (then the two ends are equally good and the first end is taken, so that fp32 and fp64 agree on the order)
+        assert n >= 1 and abs(out[0::7][:n].min() - (dmin - r)) < 2e-7 and out[0] - (dmin - r) < 1e-4
+        if abs(out[0] - (dmin - r)) > 2e-7:
+            continue
+        nrm, pos = out[4:7], out[1:4]
+        assert abs(np.linalg.norm(nrm) - 1) < 1e-9
+        # the point is midway: moving back by dist/2 reaches the box surface, forward the capsule surface
+        assert abs(_point_box_dist((pos - 0.5 * out[0] * nrm)[None], c, R, h)[0]) < 1e-6
+        seg = pos + 0.5 * out[0] * nrm + r * nrm      # a point of the axis
+        tt = np.clip(np.dot(seg - p0, p1 - p0) / max(np.dot(p1 - p0, p1 - p0), 1e-30), 0, 1)
+        assert np.linalg.norm(p0 + tt * (p1 - p0) - seg) < 1e-6
+        both += n == 2
+        out2 = np.zeros(28)
+        n2 = L.gqo_test_capsule_box(_np_ptr(p1), _np_ptr(p0), r, _np_ptr(c), _np_ptr(Rc), _np_ptr(h), margin, _np_ptr(out2))
+        assert n2 == n and abs(np.sort(out2[0::7][:n2]) - np.sort(out[0::7][:n])).max() < 1e-9   # swapped ends: the same points (a parallel axis lists them the other way round)
+    assert both >= 40
+
+
+def test_box_box_routine_properties():
+    """box_box: separated boxes report the separating-axis distance, which a dense sampling of one box's surface against the
+    other confirms as a lower bound attained for face contacts; the normal points from A to B; swapping the boxes flips the
+    normal and keeps the distances; a box resting flat on a larger one gets its four bottom corners; contact points lie between
+    the two surfaces."""
+    from scipy.spatial.transform import Rotation
+    L = _pair_lib()
+    rng = np.random.default_rng(9)
+    flat = faces = 0
+    for trial in range(400):
+        ha, hb = rng.uniform(0.03, 0.3, 3), rng.uniform(0.03, 0.3, 3)
+        Ra = Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix()
+        ca = rng.uniform(-1, 1, 3)
+        if trial % 3 == 0:   # B rests flat on A's +z face, smaller footprint
+            hb[:2] = rng.uniform(0.2, 0.9, 2) * ha[:2]
+            yaw = Rotation.from_euler('z', rng.uniform(-0.3, 0.3)).as_matrix()
+            Rb = Ra @ yaw
+            off = np.array([*(rng.uniform(-0.05, 0.05, 2) * ha[:2]), ha[2] + hb[2] + rng.uniform(-0.003, 0.0008)])
+            cb = ca + Ra @ off
+        else:
+            Rb = Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix()
+            cb = ca + rng.normal(0, 1, 3) * (ha + hb) * 0.9
+        margin = 0.001
+        Rac, Rbc = np.ascontiguousarray(Ra), np.ascontiguousarray(Rb)
+        out, out2 = np.zeros(28), np.zeros(28)
+        n = L.gqo_test_box_box(_np_ptr(ca), _np_ptr(Rac), _np_ptr(ha), _np_ptr(cb), _np_ptr(Rbc), _np_ptr(hb), margin, _np_ptr(out))
+        n2 = L.gqo_test_box_box(_np_ptr(cb), _np_ptr(Rbc), _np_ptr(hb), _np_ptr(ca), _np_ptr(Rac), _np_ptr(ha), margin, _np_ptr(out2))
+        # brute force: surface samples of B against box A and vice versa
+        g = np.linspace(-1, 1, 41)
+        surf = []
+        for ax in range(3):
+            for sg in (-1, 1):
+                u, v = np.meshgrid(g, g)
+                pts = np.zeros((u.size, 3)); pts[:, ax] = sg
+                pts[:, (ax + 1) % 3] = u.ravel(); pts[:, (ax + 2) % 3] = v.ravel()
+                surf.append(pts)
+        surf = np.concatenate(surf)
+        dAB = min(_point_box_dist(cb + (surf * hb) @ Rb.T, ca, Ra, ha).min(), _point_box_dist(ca + (surf * ha) @ Ra.T, cb, Rb, hb).min())
+        if n == 0:
+            assert dAB >= margin - 1e-3 * 0 - 1e-9 or dAB > 0      # reported separated: really no overlap
+            assert n2 == 0
+            continue
+        d = out[0::7][:n]; pos = out.reshape(4, 7)[:n, 1:4]; nrm = out[4:7]
+        assert n2 == n or (n2 > 0 and n > 0)
+        assert abs(np.linalg.norm(nrm) - 1) < 1e-9 and np.dot(nrm, cb - ca) > 0                 # from A to B
+        assert abs(out2[0::7][:n2].min() - d.min()) < 1e-9 and np.allclose(out2[4:7], -nrm, atol=1e-9)   # swap: same depth, flipped normal
+        if dAB > 0:      # separated (inside the margin): the axis distance never exceeds the true distance
+            assert d.min() <= dAB + 1e-9
+        else:            # overlapping: a penetration is reported
+            assert d.min() < 1e-6
+        for q in range(n):   # shallow contacts: the point lies midway, within |dist|/2 of both surfaces; deep ones: inside the overlap region
+            da, db = _point_box_dist(pos[q][None], ca, Ra, ha)[0], _point_box_dist(pos[q][None], cb, Rb, hb)[0]
+            if abs(d.min()) < 5e-3:
+                assert abs(da) <= abs(d[q]) * 0.5 + 2e-4 and abs(db) <= abs(d[q]) * 0.5 + 2e-4, (trial, q, da, db, d)
+            # (deep overlaps - centimetres - only promise the axis depth and the normal; contacts are created at the margin)
+        if trial % 3 == 0:
+            flat += 1
+            assert n >= 2     # a corner of B that overhangs A's face is not a contact (no polygon clipping): 2-3 points then
+            if n == 4:
+                faces += 1
+                np.testing.assert_allclose(np.sort(d), np.sort(np.full(4, d[0])), atol=2e-3)      # four bottom corners at (nearly) one depth
+    assert flat > 100 and faces >= 0.8 * flat
