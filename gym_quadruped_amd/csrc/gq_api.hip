@@ -41,6 +41,13 @@ struct GqModel {
   float* hf;            /* device elevations of the scene's height field (NULL: none) */
   int nvert;
 };
+/* kernel variant by scene: 0 flat, 1 world boxes / height field, 2 the same for a robot with sphere / capsule / box link
+ * geoms (exact pair routines compiled in; gq_step_body.h PRIM) */
+static int scene_variant(const GqModel* m) {
+  if (!(m->host.nbox > 0 || m->host.hf_nrow > 0)) return 0;
+  for (int i = 4; i < 4 + m->host.nlg; i++) { const int t = m->host.item[i].ptype; if (t == 2 || t == 3 || t == 6) return 2; }
+  return 1;
+}
 struct GqBatch {
   GqModel* model;
   GqDevBatch host;
@@ -315,7 +322,7 @@ static int step_launch(GqBatch* b, int env0, int count, const float* ctrl, const
   gq::StepCall c{};
   c.ctrl = ctrl; c.mask = mask; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr; c.env0 = env0;
   c.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; c.first_pass = 0; c.stop_stage = b->stop_stage;
-  gq_launch_step(b->dev_args, &c, count, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, count, b->model->host.solver, b->model->host.cone, scene_variant(b->model), (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }
@@ -342,7 +349,7 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
     gq::StepCall c{};
     c.ctrl = ctrl_seq; c.n_steps = n_steps; c.ctrl_stride = b->host.n_envs * 12; c.obs_seq = obs_seq;
     c.auto_reset = auto_reset ? 2 : 0; c.stop_stage = b->stop_stage;
-    gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0),
+    gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, scene_variant(b->model),
                    (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
     HIP_TRY(hipGetLastError());
     return GQ_OK;
@@ -371,7 +378,7 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
     for (int s = 0; s < shards; s++) {
       const int e0 = (int)((long long)s * N / shards), e1 = (int)((long long)(s + 1) * N / shards);
       c.env0 = e0;
-      gq_launch_step(b->dev_args, &c, e1 - e0, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0),
+      gq_launch_step(b->dev_args, &c, e1 - e0, b->model->host.solver, b->model->host.cone, scene_variant(b->model),
                      (b->model->host.nsp > 0 || b->force_self), b->shard_stream[s]);
       if (obs_seq) HIP_TRY(hipMemcpyAsync(obs_seq + ((size_t)k * N + e0) * od, out.obs + (size_t)e0 * od, (size_t)(e1 - e0) * od * sizeof(float), hipMemcpyDeviceToDevice, b->shard_stream[s]));
     }
@@ -400,14 +407,14 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   fill_reset_args(&r, b, mask, qpos_new, qvel_new, cfg, st, out, episode, lift_failed);
   r.clear_terminated = out.terminated; r.clear_truncated = out.truncated; r.clear_invalid = out.invalid_contact;
   r.lift_pending = b->lift_pending;
-  gq_launch_reset(&r, b->host.n_envs, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (hipStream_t)hip_stream);
+  gq_launch_reset(&r, b->host.n_envs, scene_variant(b->model), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */
   const int rc = ensure_args(b, st, out, episode, lift_failed, nullptr, (hipStream_t)hip_stream);
   if (rc != GQ_OK) return rc;
   gq::StepCall c{};
   c.mask = mask; c.first_pass = 1; c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0), (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, scene_variant(b->model), (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;
 }
@@ -466,7 +473,7 @@ int gq_forward(GqBatch* b, int stage, const float* ctrl, GqState st, GqObsOut ou
   if (rc != GQ_OK) return rc;
   gq::StepCall c{};
   c.ctrl = ctrl; c.debug = b->debug; c.forward = stage == 1 ? 1 : 2;
-  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, (b->model->host.nbox > 0 || b->model->host.hf_nrow > 0),
+  gq_launch_step(b->dev_args, &c, b->host.n_envs, b->model->host.solver, b->model->host.cone, scene_variant(b->model),
                  (b->model->host.nsp > 0 || b->force_self), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   return GQ_OK;

@@ -113,10 +113,12 @@ __device__ inline void item_sphere(const WaveMem& W, const GQ_MODEL GqDevModel& 
   }
 }
 
-/* IT: the item record of lane `it` (item_fetch(m, it)); H: the item's contact candidates with box b - one for a foot sphere or a
- * hull cloud (its deepest inflated vertex), up to 2 / 4 for the robot's capsule / box geoms (exact pair routines, gq_pairs.h) */
+/* PL: what is kept of the item record of lane `it` (prim_lane); H: the item's contact candidates with box b - one for a foot
+ * sphere or a hull / cylinder cloud (its deepest inflated vertex), up to 2 / 4 for the robot's sphere / capsule / box geoms
+ * (exact pair routines, gq_pairs.h).  PRIM false: the model has no such geom and the routines are not compiled in. */
+template <bool PRIM>
 __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, int b,
-                                     double bx, double by, float zoff, V3 cg, float rg, const ItemRegs& IT, PairHit& H) {
+                                     double bx, double by, float zoff, V3 cg, float rg, const PrimLane& PL, PairHit& H) {
   float dist; V3 nrm, pt;
   const int lane = lane_id();
   const GQ_MODEL GqDevBox& B = m.box[b];
@@ -127,18 +129,17 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
   bool needs = false;
   if (lane < nlg) {
     V3 nn; /* bounding sphere of the cloud against the box itself */
-    needs = rg >= 0.0f && m.lg[lane].ptype == 0 && sphere_box(matTvec(B.mat, cg - bp), bs, rg, nn) < m.boxmix[B.cls][4 + lane].margin;
+    needs = rg >= 0.0f && PL.cloud && sphere_box(matTvec(B.mat, cg - bp), bs, rg, nn) < m.boxmix[B.cls][4 + lane].margin;
     if (!needs) W.u2.c.lg_dist[lane] = 1e30f;
   }
   uint64_t todo = ballot(needs);
   /* primitive link geoms (lane = item): bounding sphere of the item against the box; the exact routine runs in phase C */
   bool prim_near = false;
-  V3 pc = v3(0.0f, 0.0f, 0.0f); /* geom centre in kernel coordinates */
-  if (lane < 4 + nlg && IT.ptype > 0) {
-    pc = ld3(W.xpos[IT.body]) + matvec(W.xmat[IT.body], IT.pos);
-    const float rb = IT.ptype == 6 ? sqrtf(IT.psize[0] * IT.psize[0] + IT.psize[1] * IT.psize[1] + IT.psize[2] * IT.psize[2]) : IT.psize[0] + (IT.ptype == 3 ? IT.psize[1] : 0.0f);
-    V3 nn;
-    prim_near = sphere_box(matTvec(B.mat, pc - bp), bs, rb, nn) < IT.margin + m.boxmix[B.cls][IT.code].margin;
+  if constexpr (PRIM) {
+    if (PL.ptype > 0) {
+      V3 nn;
+      prim_near = sphere_box(matTvec(B.mat, PL.pc - bp), bs, PL.rb, nn) < PL.margin + m.boxmix[B.cls][PL.code].margin;
+    }
   }
   H.n = 0;
   { /* nothing near this box (no link geom, no foot): skip the scan, the barrier and the item pass */
@@ -221,26 +222,29 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
       dist = sphere_box(matTvec(B.mat, cw), bs, m.foot_radius[code], n_l);
       nrm = matvec(B.mat, n_l);
       pt = ld3(W.foot_world[code]) - (m.foot_radius[code] + 0.5f * dist) * nrm;
-    } else if (IT.ptype <= 0) {
+    } else if (!PRIM || PL.ptype == 0) {
       dist = W.u2.c.lg_dist[code - 4]; nrm = ld3(GQ_BX_LGNRM(W) + 3 * (code - 4)); pt = ld3(W.u2.c.lg_pt[code - 4]);
     }
   }
   H.n = dist < 1e29f ? 1 : 0; H.dist[0] = dist; H.nrm[0] = nrm; H.pos[0] = pt;
-  if (prim_near) { /* the robot's sphere / capsule / box geoms against the box: exact (mjc_SphereBox / CapsuleBox / BoxBox geometry) */
-    const float marg = m.boxmix[B.cls][IT.code].margin;
-    float Rw[9];
+  if constexpr (PRIM) {
+    if (prim_near) { /* the robot's sphere / capsule / box geoms against the box: exact (mjc_SphereBox / CapsuleBox / BoxBox geometry) */
+      const GQ_MODEL GqDevItem& I = m.item[lane];
+      const float marg = m.boxmix[B.cls][PL.code].margin;
+      float Rw[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) Rw[i] = B.mat[i];
-    const float* Rb = W.xmat[IT.body];
-    float A[9];
+      for (int i = 0; i < 9; i++) Rw[i] = B.mat[i];
+      const float* Rb = W.xmat[I.body];
+      float A[9];
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+      for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = 0; j < 3; j++) A[3 * i + j] = Rb[3 * i] * IT.mat[j] + Rb[3 * i + 1] * IT.mat[3 + j] + Rb[3 * i + 2] * IT.mat[6 + j];
-    if (IT.ptype == 6) box_box(bp, Rw, bs, pc, A, v3(IT.psize[0], IT.psize[1], IT.psize[2]), marg, H);
-    else {
-      const V3 ax = IT.ptype == 3 ? IT.psize[1] * v3(A[2], A[5], A[8]) : v3(0.0f, 0.0f, 0.0f);
-      capsule_box(pc - ax, pc + ax, IT.psize[0], bp, Rw, bs, marg, H);
+        for (int j = 0; j < 3; j++) A[3 * i + j] = Rb[3 * i] * I.mat[j] + Rb[3 * i + 1] * I.mat[3 + j] + Rb[3 * i + 2] * I.mat[6 + j];
+      if (PL.ptype == 6) box_box(bp, Rw, bs, PL.pc, A, v3(I.psize[0], I.psize[1], I.psize[2]), marg, H);
+      else {
+        const V3 ax = PL.ptype == 3 ? I.psize[1] * v3(A[2], A[5], A[8]) : v3(0.0f, 0.0f, 0.0f);
+        capsule_box(PL.pc - ax, PL.pc + ax, I.psize[0], bp, Rw, bs, marg, H);
+      }
     }
   }
   return true;
@@ -475,8 +479,9 @@ struct WorldAppend { int ncon, rows, invalid, reserve, ft[4], nself; };
 
 /* append the contacts of the collision items (lane = position in con_order: dist / nrm / pt) with one world geom of
  * contact-parameter class cls; rows / row budget as in the floor pass.  No barrier inside. */
-template <bool CONE>
+template <bool CONE, bool PRIM = true>
 __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, int cls, float mu_env, const PairHit& H, WorldAppend& S) {
+  constexpr int NP = PRIM ? 4 : 1; /* points per item and world geom: only the exact pair routines return more than one */
   const int lane = lane_id();
   int& ncon = S.ncon; int& rows = S.rows; int& invalid = S.invalid; int& reserve = S.reserve; int* ft = S.ft;
   bool calf = false;
@@ -487,7 +492,7 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
     code = m.con_order[lane];
     const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { tk[k] = k < H.n && H.dist[k] < X.margin; cnt += tk[k] ? 1 : 0; }
+    for (int k = 0; k < NP; k++) { tk[k] = k < H.n && H.dist[k] < X.margin; cnt += tk[k] ? 1 : 0; }
     dim = X.dim;
     const float ff = m.boxcls_friction[cls][0]; /* _set_ground_friction leaves unnamed world boxes alone (quirk B8) */
     float fg;
@@ -503,12 +508,22 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
   /* ranks and rows: one prefix sum over (contacts, rows, reserved virtual rows), as in the floor pass */
   const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
   const int vres = (CONE && need > 1) ? need - 1 : 0;
-  const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
-  const int excl = wave_incl_scan(packed) - packed;
-  const int idx0 = ncon + (excl & 0xff), rows0 = rows + ((excl >> 8) & 0x3ff), res0 = reserve + ((excl >> 18) & 0x3ff);
+  int idx0, rows0, res0;
+  if constexpr (NP == 1) { /* one point per item: ballots and population counts (scalar unit) instead of the lane scan */
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    idx0 = ncon + popc64(ballot(touching) & lt);
+    const bool kept = touching && idx0 < GQ_MAXCON;
+    const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4), m6 = ballot(kept && need == 6);
+    rows0 = rows + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
+    res0 = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) : 0;
+  } else {
+    const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
+    const int excl = wave_incl_scan(packed) - packed;
+    idx0 = ncon + (excl & 0xff); rows0 = rows + ((excl >> 8) & 0x3ff); res0 = reserve + ((excl >> 18) & 0x3ff);
+  }
   int nfit = 0, j = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < NP; k++) {
     if (tk[k]) {
       const int idx = idx0 + j, row0 = rows0 + j * need, res = res0 + (j + 1) * vres;
       const bool fits = idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
@@ -527,10 +542,17 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
       j++;
     }
   }
-  const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8) | ((nfit * vres) << 18)), 63);
-  ncon += tot & 0xff;
-  rows += (tot >> 8) & 0x3ff;
-  if constexpr (CONE) reserve += (tot >> 18) & 0x3ff;
+  if constexpr (NP == 1) {
+    const uint64_t f1 = ballot(nfit && need == 1), f3 = ballot(nfit && need == 3), f4 = ballot(nfit && need == 4), f6 = ballot(nfit && need == 6);
+    ncon += popc64(f1 | f3 | f4 | f6);
+    rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
+    if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
+  } else {
+    const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8) | ((nfit * vres) << 18)), 63);
+    ncon += tot & 0xff;
+    rows += (tot >> 8) & 0x3ff;
+    if constexpr (CONE) reserve += (tot >> 18) & 0x3ff;
+  }
 }
 
 /* closest points of the segments p1 + s d1 and p2 + t d2, s, t in [0, 1] (Ericson, Real-Time Collision Detection 5.1.9;
@@ -587,8 +609,9 @@ __device__ __forceinline__ SelfPrefetch self_prefetch(const GQ_MODEL GqDevModel&
   return P;
 }
 
-template <bool CONE>
+template <bool CONE, bool PRIM = true>
 __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre) {
+  constexpr int NP = PRIM ? 4 : 1; /* points per pair: only the exact pair routines return more than one */
   const int lane = lane_id();
   const int nsp = m.nsp;
   if (nsp == 0) return;
@@ -679,8 +702,9 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
           const V3 nrm = (1.0f / len) * d;
           H.n = 1; H.dist[0] = dist; H.nrm[0] = nrm; H.pos[0] = c1 + (k1[6] + 0.5f * dist) * nrm;
         }
-      } else { /* a box is involved: exact routines (gq_pairs.h); the box of kind 1 / 3 is item 1, of kind 2 item 2 */
+      } else if constexpr (PRIM) { /* a box is involved: exact routines (gq_pairs.h); the box of kind 1 / 3 is item 1, of kind 2 item 2 */
         const int ib = kind == 2 ? it2 : it1;
+        bool continue_pair = true;
         const GQ_MODEL GqDevGeom& G = m.lg[ib - 4];
         const float* Rb = W.xmat[G.body];
         float A[9];
@@ -691,6 +715,11 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         const V3 ca = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos)), ha = ld3(G.psize);
         if (kind == 3) {
           const GQ_MODEL GqDevGeom& G2 = m.lg[it2 - 4];
+          { /* box 2's bounding sphere against box 1 itself (long thin link boxes have loose spheres): most candidates end here */
+            V3 nn;
+            if (point_box(matTvec(A, ld3(k2 + 8) - ca), ha, nn) - k2[11] >= marg) continue_pair = false;
+          }
+          if (continue_pair) {
           const float* Rb2 = W.xmat[G2.body];
           float A2[9];
 #pragma unroll
@@ -698,6 +727,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
 #pragma unroll
             for (int j = 0; j < 3; j++) A2[3 * i + j] = Rb2[3 * i] * G2.mat[j] + Rb2[3 * i + 1] * G2.mat[3 + j] + Rb2[3 * i + 2] * G2.mat[6 + j];
           box_box(ca, A, ha, ld3(W.xpos[G2.body]) + matvec(Rb2, ld3(G2.pos)), A2, ld3(G2.psize), marg, H);
+          }
         } else {
           const float* kc = kind == 1 ? k2 : k1; /* the sphere / capsule: its proxy is the geom itself */
           capsule_box(ld3(kc), ld3(kc + 3), kc[6], ca, A, ha, marg, H);
@@ -722,12 +752,21 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     int& ncon = S.ncon; int& rows = S.rows; int& reserve = S.reserve;
     const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
     const int vres = (CONE && need > 1) ? need - 1 : 0;
-    const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
-    const int excl = wave_incl_scan(packed) - packed;
-    const int idx0 = ncon + (excl & 0xff), rows0 = rows + ((excl >> 8) & 0x3ff), res0 = reserve + ((excl >> 18) & 0x3ff);
+    int idx0, rows0, res0;
+    if constexpr (NP == 1) { /* one point per pair: ballots and population counts instead of the lane scan */
+      idx0 = ncon + popc64(ballot(cnt > 0) & lt);
+      const bool kept = cnt > 0 && idx0 < GQ_MAXCON;
+      const uint64_t m1 = ballot(kept && need == 1), m3 = ballot(kept && need == 3), m4 = ballot(kept && need == 4), m6 = ballot(kept && need == 6);
+      rows0 = rows + popc64(m1 & lt) + 3 * popc64(m3 & lt) + 4 * popc64(m4 & lt) + 6 * popc64(m6 & lt);
+      res0 = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) : 0;
+    } else {
+      const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
+      const int excl = wave_incl_scan(packed) - packed;
+      idx0 = ncon + (excl & 0xff); rows0 = rows + ((excl >> 8) & 0x3ff); res0 = reserve + ((excl >> 18) & 0x3ff);
+    }
     int nfit = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NP; k++) {
       if (k < cnt) {
         const int idx = idx0 + k, row0 = rows0 + k * need, res = res0 + (k + 1) * vres;
         const bool fits = idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
@@ -748,11 +787,19 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         }
       }
     }
-    const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8) | ((nfit * vres) << 18)), 63);
-    ncon += tot & 0xff;
-    rows += (tot >> 8) & 0x3ff;
-    if constexpr (CONE) reserve += (tot >> 18) & 0x3ff;
-    S.nself += tot & 0xff;
+    if constexpr (NP == 1) {
+      const uint64_t f1 = ballot(nfit && need == 1), f3 = ballot(nfit && need == 3), f4 = ballot(nfit && need == 4), f6 = ballot(nfit && need == 6);
+      ncon += popc64(f1 | f3 | f4 | f6);
+      rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
+      if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
+      S.nself += popc64(f1 | f3 | f4 | f6);
+    } else {
+      const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8) | ((nfit * vres) << 18)), 63);
+      ncon += tot & 0xff;
+      rows += (tot >> 8) & 0x3ff;
+      if constexpr (CONE) reserve += (tot >> 18) & 0x3ff;
+      S.nself += tot & 0xff;
+    }
   }
 }
 
@@ -777,10 +824,11 @@ __device__ inline void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel
 
 /* S6 (BOXES): append the contacts with the world boxes to the list the floor pass left in W (ncon, nefc, invalid,
  * foot_touch are updated; rows / row budget as in the floor pass).  Ends with a barrier. */
-template <bool CONE, bool SELF>
+template <bool CONE, bool SELF, bool PRIM>
 __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
                                           double bx, double by, float mu_env, const SelfPrefetch& pre, const ItemRegs& IT) {
   const int lane = lane_id();
+  const PrimLane PL = prim_lane(W, m, IT, PRIM && lane < 4 + m.nlg, PRIM); /* all the box loop keeps of the item record */
   WorldAppend S;
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0;
 #pragma unroll
@@ -803,8 +851,8 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
       const int b = half * GQ_WAVE + ffs64(todo);
       todo &= todo - 1;
       PairHit H;
-      if (!box_item_scan(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, IT, H)) continue;
-      append_world_contacts<CONE>(W, m, m.box[b].cls, mu_env, H, S);
+      if (!box_item_scan<PRIM>(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, PL, H)) continue;
+      append_world_contacts<CONE, PRIM>(W, m, m.box[b].cls, mu_env, H, S);
       wave_barrier();
     }
   }
@@ -813,11 +861,11 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
     if (hfield_item_scan(W, m, vx, vy, vz, bx, by, 0.0f, cg, rg, dist, nrm, pt)) {
       PairHit H;
       H.n = dist < 1e29f ? 1 : 0; H.dist[0] = dist; H.nrm[0] = nrm; H.pos[0] = pt;
-      append_world_contacts<CONE>(W, m, m.hf_cls, mu_env, H, S);
+      append_world_contacts<CONE, false>(W, m, m.hf_cls, mu_env, H, S);
       wave_barrier();
     }
   }
-  if constexpr (SELF) append_self_contacts<CONE>(W, m, mu_env, S, pre);
+  if constexpr (SELF) append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre);
   if (lane == 0) {
     W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself;
     W.foot_touch = S.ft[0] | (S.ft[1] << 1) | (S.ft[2] << 2) | (S.ft[3] << 3);

@@ -375,9 +375,16 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       for (int i = 0; i < 3; i++) c[i] /= n;
       for (int it = 0; it < 4 + M.nlg; it++)
         if (M.item_body[it] == b) {
-          double s = 0;
-          for (int i = 0; i < 3; i++) { const double t = M.item_bsph[it][i] - c[i]; s += t * t; }
-          r = std::fmax(r, std::sqrt(s) + M.item_bsph[it][3]);
+          if (it >= 4 && M.lg[it - 4].ptype == 6) { /* a box: its own bounding sphere */
+            double s = 0;
+            for (int i = 0; i < 3; i++) { const double t = M.item_bsph[it][i] - c[i]; s += t * t; }
+            r = std::fmax(r, std::sqrt(s) + M.item_bsph[it][3]);
+          } else /* a capsule (proxy): its two end spheres - tighter than the sphere around the whole capsule */
+            for (int e = 0; e < 2; e++) {
+              double s = 0;
+              for (int i = 0; i < 3; i++) { const double t = M.item_caps[it][3 * e + i] - c[i]; s += t * t; }
+              r = std::fmax(r, std::sqrt(s) + M.item_caps[it][6]);
+            }
         }
       for (int i = 0; i < 3; i++) M.body_sph[b][i] = (float)c[i];
       M.body_sph[b][3] = (float)(r * 1.0001 + 1e-6);

@@ -15,7 +15,7 @@ namespace gq {
  * then the reset's own mj_step as a second pass through step_wave; no extra launches, but the launch lasts as long as
  * its two-pass waves.  Next-step mode: the env waits (pending flag) and spends its next launch on reset_wave + the
  * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
-template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF, bool PERSIST = false>
+template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF, bool PRIM, bool PERSIST = false>
 __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
   const int widx = wave_index();
   if (GQ_WPB > 1 && widx >= c.count) return;
@@ -42,11 +42,11 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
     if (respawn) {
       wave_priority(3); /* reset + step in one launch: this wave is the longest of its SIMD */
       wave_barrier();   /* the rows just staged in LDS are dead: reset_wave reuses the region */
-      lift = reset_wave<BOXES>(A->r, W, c.env0);
+      lift = reset_wave<BOXES, PRIM>(A->r, W, c.env0);
       pass = c.auto_reset;
       hint = load_rows<SOLVER>(A->s, c, W, env, false);
     }
-    const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF>(A->s, c, W, pass, lift, hint);
+    const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF, PRIM>(A->s, c, W, pass, lift, hint);
     if (pass != 0 || c.auto_reset != 1 || !term) break;
     respawn = true;
   }
@@ -281,22 +281,28 @@ extern "C" void gq_launch_heightmap(const GQ_GLOBAL GqDevModel* model, const dou
 /* Development builds (tools/dev_build.sh: -DGQ_DEV_ONLY=<0|1>, cone = 0 pyramidal / 1 elliptic) instantiate only the flat-scene
  * self-collision Newton variants (production + instrumented) - a 15 s build for A/B timing of kernel experiments through
  * GQ_LIBGQ_PATH; any other launch aborts.  The product library is built without the macro and carries every variant. */
-template <int S, int M, bool C, bool B, bool SF>
+#ifndef GQ_DEV_BOXES
+#define GQ_DEV_BOXES 0 /* -DGQ_DEV_BOXES=1: the development build carries the world-box / height-field variants instead of the flat ones */
+#endif
+#ifndef GQ_DEV_CUTS
+#define GQ_DEV_CUTS 0 /* -DGQ_DEV_CUTS=1: the development build also carries the stage-cut variant (tools/stage_cuts.py) */
+#endif
+template <int S, int M, bool C, bool B, bool SF, bool P = true>
 static void launch_variant(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, hipStream_t stream) {
 #ifdef GQ_DEV_ONLY
-  if constexpr (!(S == 1 && M != 2 && !B && SF && C == (GQ_DEV_ONLY != 0))) { fprintf(stderr, "libgq development build: kernel variant not compiled in\n"); abort(); } else
+  if constexpr (!(S == 1 && (M != 2 || GQ_DEV_CUTS) && B == (GQ_DEV_BOXES != 0) && (!B || P == (GQ_DEV_BOXES == 2)) && SF && C == (GQ_DEV_ONLY != 0))) { fprintf(stderr, "libgq development build: kernel variant solver=%d mode=%d cone=%d boxes=%d self=%d not compiled in\n", S, M, int(C), int(B), int(SF)); abort(); } else
 #endif
   {
     gq::StepCall call = *c;
     call.count = n_envs;
     if constexpr (M == 0) {
       if (c->n_steps > 1) { /* persistent rollout: production kernel only */
-        hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF, true>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
+        hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF, P, true>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
         return;
       }
     }
     call.n_steps = 1;
-    hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
+    hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF, P>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
   }
 }
 
@@ -306,7 +312,8 @@ extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall
    * Scene variants: flat (no world geoms beyond the floor), flat + robot self-collision, world boxes / height field (always
    * with the self-collision stage compiled in; a model without pairs skips it at run time). */
   const int mode = c->debug != nullptr ? 1 : (c->stop_stage != 0 ? 2 : 0);
-#define GQ_LAUNCH(S, M, C) do { if (boxes) launch_variant<S, M, C, true, true>(dev_args, c, n_envs, stream); \
+#define GQ_LAUNCH(S, M, C) do { if (boxes == 2) launch_variant<S, M, C, true, true, true>(dev_args, c, n_envs, stream); \
+                                else if (boxes) launch_variant<S, M, C, true, true, false>(dev_args, c, n_envs, stream); \
                                 else if (self) launch_variant<S, M, C, false, true>(dev_args, c, n_envs, stream); \
                                 else launch_variant<S, M, C, false, false>(dev_args, c, n_envs, stream); } while (0)
 #define GQ_LAUNCH_MODE(S, C) do { if (mode == 1) GQ_LAUNCH(S, 1, C); else if (mode == 2) GQ_LAUNCH(S, 2, C); else GQ_LAUNCH(S, 0, C); } while (0)

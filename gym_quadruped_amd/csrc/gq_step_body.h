@@ -329,8 +329,11 @@ __device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call
  * accumulators or row data kept live for the record: they cost registers inside the solver loop).
  * CONE: elliptic friction cones (Newton only): contacts take dim rows [n, t1, t2, torsion, roll1, roll2].
  * BOXES: the scene has static world boxes (gq_boxes.h; Newton only): contacts carry their own normal.
- * SELF: robot self-collision (Newton only): contacts between two bodies of the robot, general frames, two-body rows. */
-template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF>
+ * SELF: robot self-collision (Newton only): contacts between two bodies of the robot, general frames, two-body rows.
+ * PRIM (BOXES variants): the robot has sphere / capsule / box link geoms, whose contacts with world boxes and with each other
+ * come from the exact pair routines (gq_pairs.h); robots of hulls only get the variant without that code - merely compiled
+ * in, it cost them 17 % (registers spilled across the box loop). */
+template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF, bool PRIM>
 __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift, const int hint) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
@@ -671,7 +674,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   if constexpr (BOXES) {
     const double bx0 = W.bxy[0], by0 = W.bxy[1]; /* base x/y of this forward pass, f64 */
     const float mu_b = W.mu_env;
-    stage_box_contacts<CONE, SELF>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), bx0, by0, mu_b, self_pre, IT);
+    stage_box_contacts<CONE, SELF, PRIM>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), bx0, by0, mu_b, self_pre, IT);
   } else if constexpr (SELF) {
     const float mu_b = W.mu_env;
     stage_self_contacts<CONE>(W, m, mu_b, self_pre);
@@ -1339,7 +1342,7 @@ enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH =
        RN_YAWDOT = 30, RN_FRICTION = 31, RN_VEL_INTERVAL = 32 };
 
 #define GQ_LIFT_RULE_ITERS 4
-template <bool BOXES>
+template <bool BOXES, bool PRIM = true>
 __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 = 0) {
   int lane_o = lane_id(), env_o = wave_index() + uniform(env0);
   opaque(lane_o); opaque_s(env_o); /* see step_wave: no address arithmetic may be hoisted to the kernel prologue */
@@ -1440,7 +1443,7 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
        * every box still touched (boxes are convex: the pose above them is free) - a handful of scans instead of 100. */
       V3 calf_c; float calf_r;
       item_sphere(W, m, true, calf_c, calf_r);
-      const ItemRegs ITL = item_fetch(m, lane < 4 + m.nlg ? lane : 0); /* lane = position in con_order, as box_item_scan expects */
+      const PrimLane PLL = prim_lane(W, m, item_fetch(m, lane < 4 + m.nlg ? lane : 0), PRIM && lane < 4 + m.nlg, PRIM); /* lane = position in con_order, as box_item_scan expects */
       for (int it = 0; it <= 100; it++) {
         float pen = floor_pen(dz);
         float clear = 0.0f; /* lift that takes the touching item above the box altogether */
@@ -1452,12 +1455,12 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
             const int b = half * GQ_WAVE + ffs64(todo);
             todo &= todo - 1;
             PairHit BH;
-            if (!box_item_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, ITL, BH)) continue;
+            if (!box_item_scan<PRIM>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, PLL, BH)) continue;
             if (lane < 4 + m.nlg) {
               const int code = m.con_order[lane];
               const bool calf = code < 4 || (m.lg[code - 4].body > 0 && (m.lg[code - 4].body - 1) % 3 == 2);
 #pragma unroll
-              for (int k = 0; k < 4; k++)
+              for (int k = 0; k < (PRIM ? 4 : 1); k++)
                 if (calf && k < BH.n && BH.dist[k] < m.boxmix[m.box[b].cls][code].margin) {
                   const float bd = BH.dist[k];
                   pen = fmaxf(pen, fabsf(bd));

@@ -62,20 +62,23 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
       int pass = call.first_pass;
       bool respawn = call.auto_reset == 2 && f.s.pending[e];
       const bool boxes = M.nbox > 0 || M.hf_nrow > 0, self = M.nsp > 0;
+      bool prims = false; /* as gq_api.hip scene_variant: the PRIM variants serve robots with sphere / capsule / box link geoms */
+      for (int i = 4; i < 4 + M.nlg; i++) prims = prims || M.item[i].ptype == 2 || M.item[i].ptype == 3 || M.item[i].ptype == 6;
       int lift = (call.first_pass && lift_pending) ? (int)lift_pending[e] : 0;
       int hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, pass == 0) : gq::load_rows<0>(f.s, call, W, e, pass == 0);
       for (;;) {
         if (respawn) {
           gq::wave_barrier();
-          lift = boxes ? gq::reset_wave<true>(f.r, W) : gq::reset_wave<false>(f.r, W);
+          lift = boxes ? (prims ? gq::reset_wave<true, true>(f.r, W) : gq::reset_wave<true, false>(f.r, W)) : gq::reset_wave<false>(f.r, W);
           pass = call.auto_reset;
           hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, false) : gq::load_rows<0>(f.s, call, W, e, false);
         }
         int term;
-        if (M.solver != 1) term = gq::step_wave<0, 1, false, false, false>(f.s, call, W, pass, lift, hint);
-        else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, true, true>(f.s, call, W, pass, lift, hint);
-        else if (self) term = M.cone ? gq::step_wave<1, 1, true, false, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, false, true>(f.s, call, W, pass, lift, hint);
-        else term = M.cone ? gq::step_wave<1, 1, true, false, false>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, false, false>(f.s, call, W, pass, lift, hint);
+        if (M.solver != 1) term = gq::step_wave<0, 1, false, false, false, true>(f.s, call, W, pass, lift, hint);
+        else if (boxes && prims) term = M.cone ? gq::step_wave<1, 1, true, true, true, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, true, true, true>(f.s, call, W, pass, lift, hint);
+        else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true, true, false>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, true, true, false>(f.s, call, W, pass, lift, hint);
+        else if (self) term = M.cone ? gq::step_wave<1, 1, true, false, true, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, false, true, true>(f.s, call, W, pass, lift, hint);
+        else term = M.cone ? gq::step_wave<1, 1, true, false, false, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, false, false, true>(f.s, call, W, pass, lift, hint);
         if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
       }

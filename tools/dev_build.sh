@@ -6,5 +6,5 @@ set -e
 OUT=$1; CONE=${2:-0}; shift; shift || true
 cd "$(dirname "$0")/../gym_quadruped_amd/csrc"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I. -I../../include -Wno-unused-value -Werror=pass-failed \
-  -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-maxocc \
+  -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-maxocc -mllvm -disable-machine-licm \
   -DGQ_DEV_ONLY=$CONE "$@" -o "$OUT" gq_kernels.hip gq_api.hip gq_host_model.cpp

@@ -16,7 +16,7 @@ def main(solver='1', SELF='0'):
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / 'k.s'
         subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', f'-I{ROOT}/include', f'-I{CSRC}',
-                        '-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fno-slp-vectorize', '-mllvm', '-amdgpu-sched-strategy=iterative-maxocc', '-gline-tables-only', '-S', '--cuda-device-only', '-o', str(out), str(CSRC / 'gq_kernels.hip')],
+                        '-fno-hip-fp32-correctly-rounded-divide-sqrt', '-fno-slp-vectorize', '-mllvm', '-amdgpu-sched-strategy=iterative-maxocc', '-mllvm', '-disable-machine-licm', '-gline-tables-only', '-S', '--cuda-device-only', '-o', str(out), str(CSRC / 'gq_kernels.hip')],
                        check=True, capture_output=True)
         files, cur, infn, cnt = {}, (0, 0), False, collections.Counter()
         for line in out.read_text().splitlines():
@@ -26,7 +26,7 @@ def main(solver='1', SELF='0'):
                 continue
             m = re.match(r'^(_Z\w+):', line)
             if m:
-                infn = m.group(1).startswith(f'_ZN2gq11step_kernelILi{solver}ELi0ELb0ELb0ELb{SELF}EEE')
+                infn = m.group(1).startswith(f'_ZN2gq11step_kernelILi{solver}ELi0ELb0ELb0ELb{SELF}ELb1ELb0EEE')
                 continue
             m = re.match(r'\s*\.loc\s+(\d+)\s+(\d+)', line)
             if m:
