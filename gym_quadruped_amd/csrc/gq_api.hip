@@ -65,6 +65,11 @@ struct GqBatch {
   gq::FusedArgs shadow;
   gq::FusedArgs* staging;   /* pinned host, GQ_ARG_SLOTS entries */
   int staging_next;
+  /* the batch constants (b->dev): a change made by gq_batch_set_resampling travels with the NEXT launch, on that launch's
+   * stream, through its own pinned ring - ordered against everything the caller has queued there */
+  GqDevBatch* batch_staging; /* pinned host, GQ_ARG_SLOTS entries */
+  int batch_staging_next;
+  bool batch_dirty;
   bool shadow_valid;
   float* imu_bias;      /* caller-owned device [N][6], set by gq_batch_set_imu */
   hipStream_t shard_stream[8]; hipEvent_t shard_event[8]; hipEvent_t fork_event; int n_shard_streams; /* gq_rollout */
@@ -168,6 +173,8 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   HIP_TRY_OR_DESTROY(hipMalloc(&b->dev_args, sizeof(gq::FusedArgs)), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipHostMalloc(&b->staging, sizeof(gq::FusedArgs) * GQ_ARG_SLOTS, hipHostMallocDefault), gq_batch_destroy(b));
   b->staging_next = 0; b->shadow_valid = false;
+  HIP_TRY_OR_DESTROY(hipHostMalloc(&b->batch_staging, sizeof(GqDevBatch) * GQ_ARG_SLOTS, hipHostMallocDefault), gq_batch_destroy(b));
+  b->batch_staging_next = 0; b->batch_dirty = false;
   std::memset(&b->shadow, 0, sizeof b->shadow);
   *out = b;
   return GQ_OK;
@@ -178,6 +185,7 @@ int gq_batch_destroy(GqBatch* b) {
   DeviceGuard guard(b->model->device);
   hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->lift_pending); hipFree(b->load_hint); hipFree(b->dev_args);
   if (b->staging) hipHostFree(b->staging);
+  if (b->batch_staging) hipHostFree(b->batch_staging);
   for (int i = 0; i < b->n_shard_streams; i++) { hipStreamDestroy(b->shard_stream[i]); hipEventDestroy(b->shard_event[i]); }
   if (b->n_shard_streams) hipEventDestroy(b->fork_event);
   if (b->debug) hipFree(b->debug);
@@ -191,8 +199,7 @@ int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state) {
   if (!b || !cfg || !bias_state) { SET_ERR("gq_batch_set_imu: null argument"); return GQ_EINVAL; }
   gq_fill_imu(&b->host, cfg);
   b->imu_bias = bias_state;
-  DeviceGuard guard(b->model->device);
-  HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
+  b->batch_dirty = true; /* uploaded by the next launch, stream-ordered (ensure_args) */
   return GQ_OK;
 }
 
@@ -213,8 +220,7 @@ int gq_batch_set_resampling(GqBatch* b, const GqResampleCfg* cfg, const GqResetC
     h.rs_seed_lo = (uint32_t)(cfg->seed & 0xffffffffu); h.rs_seed_hi = (uint32_t)(cfg->seed >> 32);
     b->h9 = counters; b->ext_dist = ext_dist;
   }
-  DeviceGuard guard(b->model->device);
-  HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
+  b->batch_dirty = true; /* uploaded by the next launch, stream-ordered (ensure_args) */
   return GQ_OK;
 }
 
@@ -246,7 +252,7 @@ int gq_debug_enable(GqBatch* b, int n_debug_envs) {
     b->debug_cap = n_debug_envs;
   }
   b->host.debug_envs = n_debug_envs;
-  HIP_TRY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice));
+  b->batch_dirty = true; /* uploaded by the next launch, stream-ordered (ensure_args) */
   return GQ_OK;
 }
 
@@ -278,8 +284,19 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const
 /* Make the device argument block describe (st, out, episode, lift_failed[, auto-reset cfg]).  Steady state: a memcmp.
  * On a change the new block goes through a pinned staging slot with a stream-ordered copy, so launches already queued
  * on `stream` still see the old block.  reset_cfg NULL keeps whatever auto-reset block the device holds. */
+/* batch constants changed since the last launch (gq_batch_set_resampling / _set_imu / gq_debug_enable): stream-ordered upload */
+static int flush_batch(GqBatch* b, hipStream_t stream) {
+  if (!b->batch_dirty) return GQ_OK;
+  if (b->batch_staging_next == GQ_ARG_SLOTS) { HIP_TRY(hipStreamSynchronize(stream)); b->batch_staging_next = 0; }
+  GqDevBatch* slot = b->batch_staging + b->batch_staging_next++;
+  std::memcpy(slot, &b->host, sizeof(GqDevBatch));
+  HIP_TRY(hipMemcpyAsync(b->dev, slot, sizeof(GqDevBatch), hipMemcpyHostToDevice, stream));
+  b->batch_dirty = false;
+  return GQ_OK;
+}
 static int ensure_args(GqBatch* b, const GqState& st, const GqObsOut& out, int32_t* episode, uint8_t* lift_failed,
                        const GqResetCfg* reset_cfg, hipStream_t stream) {
+  { const int rcb = flush_batch(b, stream); if (rcb != GQ_OK) return rcb; }
   gq::FusedArgs want = b->shadow; /* struct copy keeps padding bytes identical for the memcmp */
   fill_step_args(&want.s, b, st, out, episode, lift_failed);
   if (reset_cfg) fill_reset_args(&want.r, b, nullptr, nullptr, nullptr, reset_cfg, st, out, episode, lift_failed);
@@ -316,6 +333,7 @@ static int step_launch(GqBatch* b, int env0, int count, const float* ctrl, const
   if (env0 < 0 || count < 0 || env0 + count > b->host.n_envs) { SET_ERR("%s: env range [%d, %d) outside the batch of %d", who, env0, env0 + count, b->host.n_envs); return GQ_EINVAL; }
   DeviceGuard guard(b->model->device);
   if (auto_reset && (!episode || !st.cmd)) { SET_ERR("%s: auto-reset needs the episode counters and the command tensor", who); return GQ_EINVAL; }
+  if (b->host.rs_cmd_reset && !st.cmd) { SET_ERR("%s: command resampling is on (gq_batch_set_resampling) but the state has no command tensor", who); return GQ_EINVAL; }
   const int rc = ensure_args(b, st, out, episode, lift_failed, auto_reset, (hipStream_t)hip_stream);
   if (rc != GQ_OK) return rc;
   if (count == 0) return GQ_OK;
@@ -369,25 +387,33 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
   }
   const int N = b->host.n_envs, od = b->host.obs_dim;
   HIP_TRY(hipEventRecord(b->fork_event, (hipStream_t)hip_stream));
-  for (int s = 0; s < shards; s++) HIP_TRY(hipStreamWaitEvent(b->shard_stream[s], b->fork_event, 0));
+  /* from here on work may sit on the library's shard streams: whatever fails, the caller's stream is made to wait for them
+   * before the error is returned - the caller may free ctrl_seq / obs_seq as soon as ITS stream is done with them */
+  hipError_t herr = hipSuccess;
+  const char* what = "";
+#define RO_TRY(x) do { if (herr == hipSuccess) { herr = (x); if (herr != hipSuccess) what = #x; } } while (0)
+  for (int s = 0; s < shards; s++) RO_TRY(hipStreamWaitEvent(b->shard_stream[s], b->fork_event, 0));
   gq::StepCall c{};
   c.debug = b->host.debug_envs > 0 ? b->debug : nullptr;
   c.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; c.stop_stage = b->stop_stage;
-  for (int k = 0; k < n_steps; k++) {
+  for (int k = 0; k < n_steps && herr == hipSuccess; k++) {
     c.ctrl = ctrl_seq + (size_t)k * N * 12;
-    for (int s = 0; s < shards; s++) {
+    for (int s = 0; s < shards && herr == hipSuccess; s++) {
       const int e0 = (int)((long long)s * N / shards), e1 = (int)((long long)(s + 1) * N / shards);
       c.env0 = e0;
       gq_launch_step(b->dev_args, &c, e1 - e0, b->model->host.solver, b->model->host.cone, scene_variant(b->model),
                      (b->model->host.nsp > 0 || b->force_self), b->shard_stream[s]);
-      if (obs_seq) HIP_TRY(hipMemcpyAsync(obs_seq + ((size_t)k * N + e0) * od, out.obs + (size_t)e0 * od, (size_t)(e1 - e0) * od * sizeof(float), hipMemcpyDeviceToDevice, b->shard_stream[s]));
+      RO_TRY(hipGetLastError());
+      if (obs_seq) RO_TRY(hipMemcpyAsync(obs_seq + ((size_t)k * N + e0) * od, out.obs + (size_t)e0 * od, (size_t)(e1 - e0) * od * sizeof(float), hipMemcpyDeviceToDevice, b->shard_stream[s]));
     }
   }
-  HIP_TRY(hipGetLastError());
-  for (int s = 0; s < shards; s++) {
-    HIP_TRY(hipEventRecord(b->shard_event[s], b->shard_stream[s]));
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, b->shard_event[s], 0));
+  for (int s = 0; s < shards; s++) { /* join - also on the error path (a stream that cannot even record its event is drained on the host) */
+    hipError_t j = hipEventRecord(b->shard_event[s], b->shard_stream[s]);
+    if (j == hipSuccess) j = hipStreamWaitEvent((hipStream_t)hip_stream, b->shard_event[s], 0);
+    if (j != hipSuccess) { (void)hipStreamSynchronize(b->shard_stream[s]); if (herr == hipSuccess) { herr = j; what = "joining the shard streams"; } }
   }
+#undef RO_TRY
+  if (herr != hipSuccess) { SET_ERR("gq_rollout: HIP error '%s' at %s", hipGetErrorString(herr), what); return GQ_EDEVICE; }
   return GQ_OK;
 }
 
@@ -407,6 +433,7 @@ int gq_reset(GqBatch* b, const uint8_t* mask, const double* qpos_new, const floa
   fill_reset_args(&r, b, mask, qpos_new, qvel_new, cfg, st, out, episode, lift_failed);
   r.clear_terminated = out.terminated; r.clear_truncated = out.truncated; r.clear_invalid = out.invalid_contact;
   r.lift_pending = b->lift_pending;
+  { const int rcb = flush_batch(b, (hipStream_t)hip_stream); if (rcb != GQ_OK) return rcb; }
   gq_launch_reset(&r, b->host.n_envs, scene_variant(b->model), (hipStream_t)hip_stream);
   HIP_TRY(hipGetLastError());
   /* the reset's own mj_step with zero control (quadruped_env.py:334, :397); friction committed after it (:403-404) */

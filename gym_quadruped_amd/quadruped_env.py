@@ -313,12 +313,16 @@ class QuadrupedEnv(AccessorsMixin):
         4096 envs: +6 % with 2 shards; more shards lose (overlapping launches share the SIMDs).
 
         ``obs_out``: optional ``[K, N, obs_dim]`` float32 tensor that receives the observation rows of every step.
+        Host-side sensors get their K ``step()`` calls after the launches (they see the final state only); the per-step
+        profiling events of ``step`` are not recorded.
         Returns the observation dict of the last step (views, like ``step``)."""
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
         if a.dim() != 3 or tuple(a.shape[1:]) != tuple(self._ctrl.shape):
             raise ValueError(f'actions must have shape (K, {self.num_envs}, {self.mjModel.nu}), got {tuple(a.shape)}')
         a = a.contiguous()
         K = int(a.shape[0])
+        if K == 0:
+            raise ValueError('rollout needs at least one step (actions has K == 0)')
         if obs_out is not None and (tuple(obs_out.shape) != (K, self.num_envs, self._obs_dim) or obs_out.dtype != torch.float32 or not obs_out.is_contiguous()):
             raise ValueError(f'obs_out must be a contiguous float32 tensor of shape {(K, self.num_envs, self._obs_dim)}')
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -327,6 +331,9 @@ class QuadrupedEnv(AccessorsMixin):
         self._last_action = a[K - 1]
         self._launches += K
         self._note_step()
+        for sensor in self.sensors:  # host-side sensors advance once per env step, as in the step loop (kernel-side ones: no-op)
+            for _ in range(K):
+                sensor.step()
         return self._obs_views
 
     def reset(self, qpos=None, qvel=None, seed: int | None = None, random: bool = True,
@@ -486,8 +493,13 @@ class QuadrupedEnv(AccessorsMixin):
         d['sensor_bias'] = [sn.bias_state.clone() if hasattr(sn, 'bias_state') else None for sn in self.sensors]
         return d
 
+    _LEGACY_H9 = {'_steps_after_vel': 0, '_steps_before_vel': 1, '_steps_after_dist': 3, '_steps_before_dist': 4}
+
     def load_state_dict(self, d):
         for k, v in d.items():
+            if k in self._LEGACY_H9:  # checkpoints written before the resampling counters moved into one [N, 6] tensor
+                self._h9[:, self._LEGACY_H9[k]].copy_(torch.as_tensor(v, device=self.device).to(torch.int32))
+                continue
             if k == 'rng':
                 self._gen.set_state(v)
             elif k == 'sensor_bias':

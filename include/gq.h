@@ -295,7 +295,8 @@ typedef struct GqResetCfg {
  * from the NEXT step on (:305).  The command redraw uses the knobs of the GqResetCfg passed here (ranges, cmd_* flags);
  * gq_reset / the in-kernel auto-reset restart the command interval of the envs they reset (:1068-1070).
  * Draws: Philox4x32-10, key = seed, counter = (draw / 4, n_*, global env id, 0xc0de) - see tests/philox_ref.py.
- * dist_kind[k]: 0 absent (0.0), 1 constant dist_range[k][0], 2 uniform in dist_range[k].  cfg NULL switches it off. */
+ * dist_kind[k]: 0 absent (0.0), 1 constant dist_range[k][0], 2 uniform in dist_range[k].  cfg NULL switches it off.
+ * The change takes effect with the NEXT launch of this batch and is ordered on that launch's stream (no device access here). */
 typedef struct GqResampleCfg {
   uint64_t seed;
   int32_t cmd_reset;        /* 'reset' in base_vel_command_type (:293) */

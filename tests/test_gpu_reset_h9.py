@@ -297,6 +297,15 @@ def test_pipelined_rollout_equals_the_step_loop(shards):
     assert torch.equal(a.sensors[0].bias_state, b.sensors[0].bias_state)
     assert torch.equal(torch.stack(rows), out)
     assert int(a._episode.max()) > 1, 'the rollout must contain auto-resets'
+    with pytest.raises(ValueError):  # an empty sequence is refused before any launch
+        b.rollout(acts[:0], shards=shards)
+    # a checkpoint written before the resampling counters moved into one [N, 6] tensor still loads (legacy keys -> columns)
+    sd = a.state_dict()
+    h9 = sd.pop('_h9')
+    sd.update({'_steps_after_vel': h9[:, 0].clone(), '_steps_before_vel': h9[:, 1].clone(), '_steps_after_dist': h9[:, 3].clone(), '_steps_before_dist': h9[:, 4].clone()})
+    b._h9[:, [0, 1, 3, 4]] = -7
+    b.load_state_dict(sd)
+    assert torch.equal(b._h9[:, [0, 1, 3, 4]], h9[:, [0, 1, 3, 4]])
 
 
 @pytest.mark.parametrize('robot,scene', [('hyqreal1', 'random_boxes'), ('aliengo', 'random_boxes'), ('aliengo', 'perlin')])

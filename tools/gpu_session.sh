@@ -40,6 +40,11 @@ for p in $PARTS; do
               timeout 600 python tools/wave_timeline.py 4096 $r noself > $OUT/wave_timeline_${r}_noself.txt 2>&1
               timeout 600 python tools/perf_probe.py stages 4096 $r > $OUT/stages4096_$r.txt 2>&1
             done;;
+    extras) for r in go2 hyqreal1 mini_cheetah; do timeout 600 python tools/niter_vs_oracle.py $r 384 2>&1 | grep -v amdgpu.ids > $OUT/niter_vs_oracle_$r.txt; done
+            timeout 600 python tools/stage_cuts.py 4096 > $OUT/stage_cuts4096.txt 2>&1
+            timeout 600 python tools/stage_cuts.py 4096 aliengo > $OUT/stage_cuts4096_aliengo.txt 2>&1
+            timeout 900 python tools/niter_hist.py mini_cheetah aliengo go2 hyqreal1 go1 b2 2>&1 | grep -v amdgpu.ids > $OUT/niter_hist.txt
+            (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o /tmp/fma_issue fma_issue.hip && /tmp/fma_issue) > $OUT/ubench_fma_issue.txt 2>&1;;
     nscan) timeout 900 python tools/nscan.py > $OUT/nscan.txt 2>&1;;
     profiles) timeout 1500 bash tools/run_profiles.sh $TAG pmc > $OUT/run_profiles.txt 2>&1
               timeout 600 bash tools/run_profiles.sh ${TAG}_noself nopmc --no-self-collision >> $OUT/run_profiles.txt 2>&1
