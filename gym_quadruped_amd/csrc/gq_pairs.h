@@ -40,7 +40,7 @@ __device__ __forceinline__ ItemRegs item_fetch(const GQ_MODEL GqDevModel& m, con
 
 
 /* what the world-box scans keep of a lane's item: whether it is a primitive with an exact pair routine (sphere 2, capsule 3,
- * box 6; feet, hull clouds and cylinders - a 32-vertex rim cloud - are not), its centre in kernel coordinates and bounding
+ * box 6; feet, hull clouds and cylinders - two 16-gon rims, 32 vertices - are not), its centre in kernel coordinates and bounding
  * radius.  A handful of registers instead of the whole record: the item's frame and sizes are re-read from the model table
  * in the (rare) exact routine, so that nothing of the record stays live across the box loop. */
 struct PrimLane { int ptype, code; float rb, margin; V3 pc; bool cloud; /* lane = link geom: its contact with a world box comes from the vertex cloud scan */ };
