@@ -464,7 +464,7 @@ def test_step_is_hip_graph_capturable():
 
 
 @pytest.mark.parametrize('robot,scene', [('aliengo', 'random_boxes'), ('hyqreal1', 'random_boxes'), ('mini_cheetah', 'stairs'),
-                                         ('go2', 'random_pyramids'), ('aliengo', 'ramp'), ('b2', 'slippery')])
+                                         ('go2', 'random_pyramids'), ('aliengo', 'ramp'), ('b2', 'slippery'), ('go1', 'random_boxes')])  # go1: 12 cylinder geoms (rim clouds on boxes)
 def test_box_scenes_rollout_and_step_parity(robot, scene):
     """Scenes with static world boxes (terrain.py: random_boxes / random_pyramids procedural, ramp / slippery / stairs static;
     BASELINE config 5 is hyqreal1 on random_boxes): reset inside the scene's limits, a random rollout with next-step
