@@ -85,12 +85,21 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
     st3(W.foot_world[lane], c);
   }
   /* link geoms.  Phase 1, lane = geom: plane normal in the geom frame and the OBB lower bound of the cloud.
-   * Phase 2, only for the geoms whose box can reach the floor (wave-uniform loop over the ballot mask): wave-wide scan
-   * of the vertex cloud for the deepest vertex. */
+   * Phase 2, lane = (surviving geom, 64-vertex chunk of its cloud), four geoms x 16 chunks per pass: lower bound of the chunk's
+   * box (host table behind the vertex arrays; clouds are sorted along their principal axis, so chunks are compact slabs) - a
+   * chunk that cannot come within the contact margin holds no contact and cannot hold the deepest vertex of a geom in contact.
+   * Phase 3, wave-uniform loop over the surviving geoms: wave-wide scan of the surviving chunks (usually one or two of up to
+   * eleven) for the deepest vertex; a geom without surviving chunk makes no contact (distance 1e30).
+   * Phase 4, lane = geom again: the winner's world position.
+   * The scan is a chain of memory round trips - a robot lying on the floor has ten geoms to scan and is also the env whose
+   * Newton solve ends the launch - so a geom's table addresses come from its phase-1 lane (ds_bpermute / v_readlane), not
+   * from scalar loads in front of the vertex loads; every lane keeps the COORDINATES of its best vertex, so the winner needs no
+   * second, dependent fetch; the model reads of the final transform happen once, for all geoms together. */
   const int nlg = m.nlg;
   V3 ng = v3(0.0f, 0.0f, 0.0f);
-  float d0 = 0.0f;
+  float d0 = 0.0f, gmargin = 0.0f, gradius = 0.0f;
   bool needs = false;
+  int cadr = 0, cnum = 0, chk = -1;
   if (lane < nlg) {
     const GQ_MODEL GqDevGeom& G = m.lg[lane];
     const float* Rb = W.xmat[G.body];
@@ -98,46 +107,88 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
     const V3 nb = v3(Rb[6], Rb[7], Rb[8]);
     ng = matTvec(G.mat, nb);
     d0 = W.xpos[G.body][2] + dot(nb, ld3(G.pos));
-    const float lower = d0 + dot(ng, ld3(G.aabb_c)) - (fabsf(ng.x) * G.aabb_h[0] + fabsf(ng.y) * G.aabb_h[1] + fabsf(ng.z) * G.aabb_h[2]) - G.radius;
+    gmargin = G.margin; gradius = G.radius;
+    const float lower = d0 + dot(ng, ld3(G.aabb_c)) - (fabsf(ng.x) * G.aabb_h[0] + fabsf(ng.y) * G.aabb_h[1] + fabsf(ng.z) * G.aabb_h[2]) - gradius;
     const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
-    needs = G.ptype == 0 && lower < G.margin && (!calf_only || calf); /* primitive geoms are evaluated lane-locally (floor_candidates) */
+    needs = G.ptype == 0 && lower < gmargin && (!calf_only || calf); /* primitive geoms are evaluated lane-locally (floor_candidates) */
+    cadr = G.cloud_adr; cnum = G.cloud_num; chk = G.chunk_adr;
     if (!needs) W.u2.c.lg_dist[lane] = 1e30f;
   }
   uint64_t todo = ballot(needs);
-  while (todo) { /* wave-uniform */
-    const int g = ffs64(todo);
-    todo &= todo - 1;
-    const GQ_MODEL GqDevGeom& G = m.lg[g];
-    const float gx = bcast(ng.x, g), gy = bcast(ng.y, g), gz = bcast(ng.z, g), gd0 = bcast(d0, g);
-    float best = 1e30f;
-    int bi = 0;
-    /* the cloud is fetched in chunks of 4 x 64 vertices with all 12 loads of a chunk in flight together (one memory
-     * latency per chunk instead of one per 64 vertices); out-of-range lanes re-read the last vertex */
-    const int last = G.cloud_adr + G.cloud_num - 1;
-    for (int v0 = 0; v0 < G.cloud_num; v0 += 4 * GQ_WAVE) { /* wave-uniform trip count */
-      int idx[4];
-      float px[4], py[4], pz[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = G.cloud_adr + v0 + u * GQ_WAVE + lane;
-        idx[u] = i < last ? i : last;
-        px[u] = vx[idx[u]]; py[u] = vy[idx[u]]; pz[u] = vz[idx[u]];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const float dv = gx * px[u] + gy * py[u] + gz * pz[u];
-        if (dv < best) { best = dv; bi = idx[u]; }
+  if (todo) { /* wave-uniform */
+    /* phase 2: chunk masks, 16 bits per geom, kept by the geom's own lane */
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int cmask = 0;
+    {
+      const int nsurv = popc64(todo);
+      const int rank = popc64(todo & lt); /* of a surviving geom lane */
+      for (int q0 = 0; q0 < nsurv; q0 += 4) { /* wave-uniform */
+        /* the (q0 + lane / 16)-th surviving geom: select by rank (lanes with needs publish rank -> lane through a ballot search) */
+        const int want = q0 + (lane >> 4);
+        int g = 0;
+        { /* position of the want-th set bit of todo (<= 38 geoms: a short wave-uniform walk, lane-local compare) */
+          uint64_t t = todo;
+          int r = 0;
+          while (t) { const int b = ffs64(t); t &= t - 1; if (r == want) g = b; r++; }
+        }
+        const bool have = want < nsurv;
+        const int c = lane & 15;
+        const int gcn = shfl_idx(cnum, g), gck = shfl_idx(chk, g);
+        const float gx = shfl_idx(ng.x, g), gy = shfl_idx(ng.y, g), gz = shfl_idx(ng.z, g), gd = shfl_idx(d0, g), gm = shfl_idx(gmargin, g), gr = shfl_idx(gradius, g);
+        const int nchunk = (gcn + GQ_WAVE - 1) / GQ_WAVE;
+        bool keep = have && c < nchunk;
+        if (keep && gck >= 0) {
+          const int ia = gck + 2 * c;
+          const V3 cc = v3(vx[ia], vy[ia], vz[ia]), hh = v3(vx[ia + 1], vy[ia + 1], vz[ia + 1]);
+          const float lb = gd + gx * cc.x + gy * cc.y + gz * cc.z - (fabsf(gx) * hh.x + fabsf(gy) * hh.y + fabsf(gz) * hh.z) - gr;
+          keep = lb < gm + 1e-5f;
+        }
+        const uint64_t km = ballot(keep);
+        /* hand the 16-bit group to the geom's lane */
+        if (needs && rank >= q0 && rank < q0 + 4) cmask = (int)((km >> (16 * (rank - q0))) & 0xffffull);
       }
     }
-    const float wmin = wave_min(best);
-    const uint64_t who = ballot(best == wmin);
-    bi = bcast(bi, ffs64(who));
-    if (lane == 0) {
-      W.u2.c.lg_dist[g] = wmin + gd0 - G.radius;
+    /* phase 3 */
+    float px[4], py[4], pz[4];
+    for (;;) { /* one trip per geom */
+      const int g = ffs64(todo);
+      todo &= todo - 1;
+      const float gx = bcast(ng.x, g), gy = bcast(ng.y, g), gz = bcast(ng.z, g);
+      const int adr = bcast(cadr, g), last = adr + bcast(cnum, g) - 1;
+      int cm = bcast(cmask, g);
+      float best = 1e30f;
+      V3 bp = v3(0.0f, 0.0f, 0.0f);
+      while (cm) { /* wave-uniform: up to 4 chunks with all 12 loads in flight together; lanes past the end re-read the last vertex */
+        int cu[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { cu[u] = cm ? __builtin_ctz(cm) : -1; cm &= cm - 1; }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (cu[u] >= 0) { /* wave-uniform */
+            const int i = adr + cu[u] * GQ_WAVE + lane;
+            const int ii = i < last ? i : last;
+            px[u] = vx[ii]; py[u] = vy[ii]; pz[u] = vz[ii];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (cu[u] >= 0) {
+            const float dv = gx * px[u] + gy * py[u] + gz * pz[u];
+            if (dv < best) { best = dv; bp = v3(px[u], py[u], pz[u]); } /* (a re-read last vertex never wins a tie: strict <) */
+          }
+      }
+      const float wmin = wave_min(best);
+      const int who = ffs64(ballot(best == wmin));
+      if (lane == who) { W.u2.c.lg_dist[g] = wmin; st3(W.u2.c.lg_pt[g], bp); } /* geom-frame vertex for now; 1e30: no chunk in reach */
+      if (!todo) break;
+    }
+    wave_barrier();
+    if (needs) { /* phase 4, lane = geom */
+      const GQ_MODEL GqDevGeom& G = m.lg[lane];
       const float* Rb = W.xmat[G.body];
-      const V3 vl = v3(vx[bi], vy[bi], vz[bi]);
-      const V3 vb = ld3(G.pos) + matvec(G.mat, vl);
-      st3(W.u2.c.lg_pt[g], ld3(W.xpos[G.body]) + matvec(Rb, vb));
+      const float raw = W.u2.c.lg_dist[lane];
+      const V3 vb = ld3(G.pos) + matvec(G.mat, ld3(W.u2.c.lg_pt[lane]));
+      W.u2.c.lg_dist[lane] = raw < 1e29f ? raw + d0 - gradius : 1e30f;
+      st3(W.u2.c.lg_pt[lane], ld3(W.xpos[G.body]) + matvec(Rb, vb));
     }
   }
   wave_barrier();
