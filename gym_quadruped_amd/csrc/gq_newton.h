@@ -870,10 +870,10 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
           }
         }
         wave_barrier();
-        const int total = nvirt * GQ_NVD;
-        float outv[6];
+        const int total = nvirt * GQ_NVD; /* <= 25 virtual rows (five condim-6 contacts in the middle zone) x 18 = 450 outputs: 8 per lane */
+        float outv[8];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
+        for (int k = 0; k < 8; k++) {
           outv[k] = 0.0f;
           if (64 * k < total) { /* wave-uniform */
             const int o = lane + 64 * k < total ? lane + 64 * k : total - 1;
@@ -893,7 +893,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
         }
         wave_barrier();
 #pragma unroll
-        for (int k = 0; k < 6; k++)
+        for (int k = 0; k < 8; k++)
           if (64 * k < total && lane + 64 * k < total) {
             const int o = lane + 64 * k, v = (o * 3641) >> 16, d = o - GQ_NVD * v;
             W.u.B[nefc + v][d] = outv[k];

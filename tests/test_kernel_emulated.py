@@ -552,6 +552,34 @@ def test_newton_ends_on_captured_hard_states(robot):
         assert np.abs(st['qacc'][e] - qa).max() <= 2e-5 * max(1.0, np.abs(qa).max()), (e, nit)   # spot (condim 6, impratio 100): 8e-6; the others below 1e-6
 
 
+def test_newton_with_22_virtual_rows_go1_on_boxes():
+    """go1 on random_boxes, states captured on the GPU (tools/capture_stuck.py) where the solver needed 31-100 iterations against
+    the oracle's 4-12: four condim-6 feet contacts and one condim-3 contact, all in the middle zone of their elliptic cones,
+    make 4 x 5 + 2 = 22 virtual Hessian rows = 396 outputs, and the lane-parallel construction held 6 x 64 = 384 - the last row
+    kept stale entries, the Hessian was wrong and Newton fell back to the linear rate of a line-searched gradient method.
+    Now 8 per lane.  Each state must end within a few iterations, at the oracle's solution when the contact sets agree."""
+    from gym_quadruped_amd.terrain import generate_terrain
+    from gym_quadruped_amd.robot_cfgs import get_robot_config
+    z = np.load(Path(__file__).parent / 'golden' / 'newton_stagnation_go1_random_boxes.npz')
+    scene, lim = generate_terrain('random_boxes', get_robot_config('go1').hip_height)
+    mm = marshalled('go1', solver=1, iterations=100, tolerance=1e-8, noise_floor=1e-5, boxes=scene['boxes'], terrain_limits=lim)
+    o = Oracle(marshalled('go1', solver=1, iterations=100, tolerance=1e-10, boxes=scene['boxes'], terrain_limits=lim))
+    n = len(z['qpos'])
+    st = emu_step(mm, z['ctrl'].copy(), z['qpos'].copy(), z['qvel'].copy(), warm=z['warm'].copy(), applied=z['applied'].copy(),
+                  friction=z['friction'].copy(), debug_envs=n)
+    same = 0
+    for e in range(n):
+        nit = int(dbg(st['debug'][e], 'niter')[0])
+        assert nit <= 12, (e, nit, int(z['niter_before_fix'][e]))
+        o.set_state(z['qpos'][e], z['qvel'][e].astype(np.float64), z['warm'][e].astype(np.float64), z['applied'][e].astype(np.float64), 0.0, float(z['friction'][e]))
+        o.step(z['ctrl'][e].astype(np.float64))
+        if int(o.nefc) == int(dbg(st['debug'][e], 'nefc')[0]):   # (the others exceed the kernel's row budget: prefix rule, other tests)
+            qa = np.array(o.qacc)
+            assert np.abs(st['qacc'][e] - qa).max() <= 5e-5 * max(1.0, np.abs(qa).max()), (e, nit)
+            same += 1
+    assert same >= 1
+
+
 @pytest.mark.parametrize('robot', ['aliengo', 'go1', 'b2', 'hyqreal2', 'go2'])
 def test_plane_multipoint_contacts_match_oracle(robot):
     """MuJoCo's multi-point plane routines in the kernel (csrc/gq_step_body.h floor_candidates: box corners, both capsule end
