@@ -1637,7 +1637,7 @@ static void gqo_sol_pgs(GqOracle* o, int maxiter, double tol) {
     o->efc_b[i] = s;
   }
   /* warm start: forces from the primal force law at qacc_warmstart; keep only if the dual cost is negative */
-  double jar[NEFC], *f = o->efc_force;
+  double jar[NEFC] = {0}, *f = o->efc_force;
   for (int i = 0; i < nefc; i++) {
     double s = -o->efc_aref[i];
     for (int k = 0; k < NV; k++) s += o->efc_J[i][k] * o->qacc_warmstart[k];
