@@ -475,7 +475,7 @@ __device__ inline bool hfield_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m
 }
 
 /* running totals of the contact list while world geoms are appended to it */
-struct WorldAppend { int ncon, rows, invalid, reserve, ft[4], nself; };
+struct WorldAppend { int ncon, rows, invalid, reserve, ft /* bit k: foot k's calf body touches a world geom */, nself; };
 
 /* append the contacts of the collision items (lane = position in con_order: dist / nrm / pt) with one world geom of
  * contact-parameter class cls; rows / row budget as in the floor pass.  No barrier inside. */
@@ -483,7 +483,7 @@ template <bool CONE, bool PRIM = true>
 __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, int cls, float mu_env, const PairHit& H, WorldAppend& S) {
   constexpr int NP = PRIM ? 4 : 1; /* points per item and world geom: only the exact pair routines return more than one */
   const int lane = lane_id();
-  int& ncon = S.ncon; int& rows = S.rows; int& invalid = S.invalid; int& reserve = S.reserve; int* ft = S.ft;
+  int& ncon = S.ncon; int& rows = S.rows; int& invalid = S.invalid; int& reserve = S.reserve; int& ft = S.ft;
   bool calf = false;
   int code = 0, body = 0, dim = 3, cnt = 0;
   float mu = 0.0f;
@@ -504,7 +504,7 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
   if (ballot(touching) == 0) return;
   invalid |= ballot(touching && !calf) != 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) ft[k] |= ballot(touching && body == 3 + 3 * m.foot_leg[k]) != 0;
+  for (int k = 0; k < 4; k++) ft |= (ballot(touching && body == 3 + 3 * m.foot_leg[k]) != 0 ? 1 : 0) << k;
   /* ranks and rows: one prefix sum over (contacts, rows, reserved virtual rows), as in the floor pass */
   const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
   const int vres = (CONE && need > 1) ? need - 1 : 0;
@@ -831,8 +831,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
   const PrimLane PL = prim_lane(W, m, IT, PRIM && lane < 4 + m.nlg, PRIM); /* all the box loop keeps of the item record */
   WorldAppend S;
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) S.ft[k] = (uniform(W.foot_touch) >> k) & 1;
+  S.ft = uniform(W.foot_touch) & 15;
   const int ncon = S.ncon;
   if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
     st3(GQ_BX_CONNRM(W) + 3 * lane, v3(0.0f, 0.0f, 1.0f));
@@ -868,7 +867,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
   if constexpr (SELF) append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre);
   if (lane == 0) {
     W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself;
-    W.foot_touch = S.ft[0] | (S.ft[1] << 1) | (S.ft[2] << 2) | (S.ft[3] << 3);
+    W.foot_touch = S.ft;
   }
   wave_barrier();
 }

@@ -838,18 +838,20 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
        * (2) row lane r0 + i writes ITS coefficient of each of its contact's virtual rows into the (still unused) storage of
        *     that virtual row, the head lane adds r0, dim and the weight;
        * (3) the nvirt x 18 outputs are spread over all 64 lanes (registers), and written back after a barrier. */
-      const int e = E.code & 15, dimc = E.code >> 4;
-      const bool mid = E.code != 0 && zone == 2, head = mid && e == 0;
+      int ecode = E.code, er0 = E.r0;
+      opaque(ecode); opaque(er0); /* as for the Hessian indices below: keep the derived lane indices / addresses out of the loop's live set */
+      const int e = ecode & 15, dimc = ecode >> 4;
+      const bool mid = ecode != 0 && zone == 2, head = mid && e == 0;
       const uint64_t m3 = ballot(head && dimc == 3), m6 = ballot(head && dimc == 6);
       if ((m3 | m6) != 0) { /* wave-uniform */
-        const uint64_t below = (1ull << (E.r0 & 63)) - 1ull;
+        const uint64_t below = (1ull << (er0 & 63)) - 1ull;
         const int vb = nefc + 2 * popc64(m3 & below) + 5 * popc64(m6 & below); /* first virtual row of the lane's contact */
         const int nvirt = 2 * popc64(m3) + 5 * popc64(m6);
         const int mdim = m6 ? 6 : 3;
         float uh[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; /* u_j of the lane's contact ([0] unused) */
 #pragma unroll
         for (int j = 1; j < 6; j++)
-          if (j < mdim) { const float t = shfl_idx(uhat, E.r0 + j); uh[j] = j < dimc ? t : 0.0f; }
+          if (j < mdim) { const float t = shfl_idx(uhat, er0 + j); uh[j] = j < dimc ? t : 0.0f; }
         if (mid) {
           const float Tc = sqrtf(TT), qc = E.mu * y0 - E.mu * Tc;
           const float Dm = E.D0 / (E.mu * E.mu * (1.0f + E.mu * E.mu)), wk = Dm * (-E.mu * qc) / Tc;
@@ -864,7 +866,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
           }
           if (e == 0) {
             for (int k = 0; k < dimc - 1; k++) {
-              W.u.B[vb + k][6] = __builtin_bit_cast(float, E.r0 | (dimc << 8));
+              W.u.B[vb + k][6] = __builtin_bit_cast(float, er0 | (dimc << 8));
               W.force[vb + k] = k == 0 ? Dm : wk;
             }
           }
@@ -908,7 +910,11 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
      * rows are walked wave-uniformly (row index and weight change in SGPRs, the two J entries of each of the lane's
      * entries from LDS), two rows per trip so that their reads are in flight together. */
     {
-      const int e0 = hent[0] < 0 ? 0 : hent[0], e1 = hent[1] < 0 ? 0 : hent[1];
+      /* (elliptic variants: the decoded indices and LDS addresses below are loop invariants that LLVM hoists out of the Newton
+       * loop and then spills - 17 scratch reloads per iteration; decoding them again from an opaque copy is 12 VALU) */
+      int h0 = hent[0], h1 = hent[1];
+      if constexpr (CONE) { opaque(h0); opaque(h1); }
+      const int e0 = h0 < 0 ? 0 : h0, e1 = h1 < 0 ? 0 : h1;
       const int da0 = e0 & 0xff, db0 = (e0 >> 8) & 0xff, da1 = e1 & 0xff, db1 = (e1 >> 8) & 0xff;
       const uint64_t flm = nfl >= 64 ? ~0ull : ((1ull << nfl) - 1ull);
       if (chg & flm) {
@@ -944,8 +950,9 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       }
 #pragma unroll
       for (int pass = 0; pass < 2; pass++) {
-        if (hent[pass] >= 0) {
-          const int da = hent[pass] & 0xff, db = (hent[pass] >> 8) & 0xff, slot = (hent[pass] >> 16) & 0xff;
+        const int hp = pass ? h1 : h0;
+        if (hp >= 0) {
+          const int da = hp & 0xff, db = (hp >> 8) & 0xff, slot = (hp >> 16) & 0xff;
           const float hv = pass ? hv1 : hv0;
           if (slot < 108) W.u2.n.Hc[slot / 9][slot % 9] = hv;
           else { W.u2.n.Hb[da][db] = hv; W.u2.n.Hb[db][da] = hv; }
