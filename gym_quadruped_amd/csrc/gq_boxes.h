@@ -562,16 +562,17 @@ __device__ __forceinline__ void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& 
   const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), EPS = 1e-12f;
   float s, t;
   if (a <= EPS && e <= EPS) { s = 0.0f; t = 0.0f; }
-  else if (a <= EPS) { s = 0.0f; t = med3(f / e, 0.0f, 1.0f); }
+  else if (a <= EPS) { s = 0.0f; t = med3(fdiv(f, e), 0.0f, 1.0f); }
   else {
     const float c = dot(d1, r);
-    if (e <= EPS) { t = 0.0f; s = med3(-c / a, 0.0f, 1.0f); }
+    if (e <= EPS) { t = 0.0f; s = med3(fdiv(-c, a), 0.0f, 1.0f); }
     else {
       const float b = dot(d1, d2), den = a * e - b * b;
-      s = den > 1e-6f * a * e ? med3((b * f - c * e) / den, 0.0f, 1.0f) : 0.0f; /* (nearly) parallel: any s will do; 0 */
-      t = (b * s + f) / e;
-      if (t < 0.0f) { t = 0.0f; s = med3(-c / a, 0.0f, 1.0f); }
-      else if (t > 1.0f) { t = 1.0f; s = med3((b - c) / a, 0.0f, 1.0f); }
+      s = den > 1e-6f * a * e ? med3(fdiv(b * f - c * e, den), 0.0f, 1.0f) : 0.0f; /* (nearly) parallel: any s will do; 0 */
+      const float ie = fast_rcp(e), ia = fast_rcp(a);
+      t = (b * s + f) * ie;
+      if (t < 0.0f) { t = 0.0f; s = med3(-c * ia, 0.0f, 1.0f); }
+      else if (t > 1.0f) { t = 1.0f; s = med3((b - c) * ia, 0.0f, 1.0f); }
     }
   }
   c1 = p1 + s * d1; c2 = p2 + t * d2;
@@ -697,9 +698,9 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         V3 c1, c2;
         closest_seg_seg(ld3(k1), ld3(k1 + 3), ld3(k2), ld3(k2 + 3), c1, c2);
         const V3 d = c2 - c1;
-        const float l2 = dot(d, d), len = sqrtf(l2), dist = len - k1[6] - k2[6];
+        const float l2 = dot(d, d), len = fast_sqrt(l2), dist = len - k1[6] - k2[6];
         if (dist < marg && len >= 1e-9f) {
-          const V3 nrm = (1.0f / len) * d;
+          const V3 nrm = fast_rcp(len) * d;
           H.n = 1; H.dist[0] = dist; H.nrm[0] = nrm; H.pos[0] = c1 + (k1[6] + 0.5f * dist) * nrm;
         }
       } else if constexpr (PRIM) { /* a box is involved: exact routines (gq_pairs.h); the box of kind 1 / 3 is item 1, of kind 2 item 2 */

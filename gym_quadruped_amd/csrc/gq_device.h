@@ -153,6 +153,13 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+/* a / b as v_rcp_f32 + v_mul_f32 (2 instructions, <= 2 ulp).  The compiler's own fp32 '/' - even with
+ * -fno-hip-fp32-correctly-rounded-divide-sqrt - wraps the reciprocal in v_frexp_mant / v_frexp_exp / v_ldexp range scaling, 8
+ * instructions; the operands on the hot paths (residuals, impedances, squared lengths guarded by epsilons) are nowhere near
+ * the ends of the fp32 range. */
+/* v_sqrt_f32 (1 ulp) without libm's scaling of tiny arguments (sqrtf: v_cmp + 2 v_ldexp + v_cndmask around it) */
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 /* cos(2 pi x), x in turns (v_cos_f32; absolute error ~1e-6 on [0, 1)) */
 __device__ __forceinline__ float fast_cos_turns(float x) { return __builtin_amdgcn_cosf(x); }
 /* a^p / b^q for a, b in (0, 1]: exp2(p log2 a - q log2 b) on the transcendental unit (v_log_f32 / v_exp_f32, ~1 ulp each;

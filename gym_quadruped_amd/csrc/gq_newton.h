@@ -640,13 +640,13 @@ __device__ __forceinline__ int ell_zone(float N, float T, float mu) { /* 0 top, 
  * middle zone: the normal row carries s = Dm q^2 / 2, q = N - mu T:  s' = Dm q q',  s'' = Dm (q'^2 + q q'') */
 __device__ __forceinline__ void ell_dd(const EllRow& E, float alpha, float y, float v, float rD, float TT, float y0, float UV,
                                        float VV, float N1, float& d1, float& d2) {
-  const float Na = E.mu * y0 + alpha * N1, TTa = fmaxf(0.0f, TT + 2.0f * alpha * UV + alpha * alpha * VV), Ta = sqrtf(TTa);
+  const float Na = E.mu * y0 + alpha * N1, TTa = fmaxf(0.0f, TT + 2.0f * alpha * UV + alpha * alpha * VV), Ta = fast_sqrt(TTa);
   const int zone = ell_zone(Na, Ta, E.mu);
   d1 = 0.0f; d2 = 0.0f;
   if (zone == 1) { d1 = rD * (y + alpha * v) * v; d2 = rD * v * v; }
   else if (zone == 2 && (E.code & 15) == 0) {
-    const float Dm = E.D0 / (E.mu * E.mu * (1.0f + E.mu * E.mu)), q = Na - E.mu * Ta;
-    const float Tp = (UV + alpha * VV) / Ta, qp = N1 - E.mu * Tp, Tpp = fmaxf(0.0f, VV - Tp * Tp) / Ta;
+    const float Dm = fdiv(E.D0, E.mu * E.mu * (1.0f + E.mu * E.mu)), q = Na - E.mu * Ta;
+    const float iT = fast_rcp(Ta), Tp = (UV + alpha * VV) * iT, qp = N1 - E.mu * Tp, Tpp = fmaxf(0.0f, VV - Tp * Tp) * iT;
     d1 = Dm * q * qp; d2 = Dm * (qp * qp - q * E.mu * Tpp);
   }
 }
@@ -659,14 +659,14 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
   const float u = e >= 1 ? E.fri * y : 0.0f;
   TT = ell_seg_sum(E, u * u);
   y0 = shfl_idx(y, E.r0);
-  const float N = E.mu * y0, T = sqrtf(TT);
+  const float N = E.mu * y0, T = fast_sqrt(TT);
   zone = ell_zone(N, T, E.mu);
   ci = 0.0f; wact = 0.0f; uhat = 0.0f;
   if (E.code == 0 || zone == 0) return 0.0f;
   if (zone == 1) { ci = 0.5f * rD * y * y; wact = rD; return -rD * y; }
-  const float Dm = E.D0 / (E.mu * E.mu * (1.0f + E.mu * E.mu)), q = N - E.mu * T;
+  const float Dm = fdiv(E.D0, E.mu * E.mu * (1.0f + E.mu * E.mu)), q = N - E.mu * T;
   if (e == 0) { ci = 0.5f * Dm * q * q; return -Dm * q * E.mu; }
-  uhat = u / T;                       /* the middle zone's curvature is carried entirely by the virtual rows */
+  uhat = fdiv(u, T);                   /* the middle zone's curvature is carried entirely by the virtual rows */
   return Dm * q * E.mu * E.fri * uhat;
 }
 
@@ -696,8 +696,8 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
    * whole solve and spills them to scratch - the opposite of the intent) */
 #define JROW() (W.u.B[opaque_lane(lane)]) /* an opaque INDEX (an opaque pointer would lose its LDS address space and turn into flat
                                            * loads); taken ONCE per use site: each expansion re-derives lane * 72 with a slow v_mul_lo_u32 */
-  const float rD = 1.0f / rR;
-  const float scale = 1.0f / (m.meaninertia * 18.0f);
+  const float rD = fast_rcp(rR);
+  const float scale = fast_rcp(m.meaninertia * 18.0f);
   float* dq = W.qacc_int;       /* scratch 18-vectors: free until S10 */
   float* Mdq = W.qfrc_c;
   float* grad = W.act;
@@ -788,7 +788,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       gterm = md * md + (s0 + s1) * (s0 + s1);
     }
     const float gnorm2 = wave_sum(lane < GQ_NVD ? gd * gd : 0.0f);
-    if (scale * sqrtf(gnorm2) < m.tolerance) { exit_code = 3; break; }
+    if (scale * fast_sqrt(gnorm2) < m.tolerance) { exit_code = 3; break; }
     /* fp32 floor (GqModelDesc.noise_floor): the gradient is a difference of two vectors; once it is down at their
      * round-off a further Newton step only chases noise */
     if (iter > 0 && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(gterm)) { exit_code = 4; break; }
@@ -853,13 +853,13 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
         for (int j = 1; j < 6; j++)
           if (j < mdim) { const float t = shfl_idx(uhat, er0 + j); uh[j] = j < dimc ? t : 0.0f; }
         if (mid) {
-          const float Tc = sqrtf(TT), qc = E.mu * y0 - E.mu * Tc;
-          const float Dm = E.D0 / (E.mu * E.mu * (1.0f + E.mu * E.mu)), wk = Dm * (-E.mu * qc) / Tc;
+          const float Tc = fast_sqrt(TT), qc = E.mu * y0 - E.mu * Tc;
+          const float Dm = fdiv(E.D0, E.mu * E.mu * (1.0f + E.mu * E.mu)), wk = fdiv(Dm * (-E.mu * qc), Tc);
           W.u.B[vb][e] = e == 0 ? E.mu : -E.mu * E.fri * uhat;
           if (dimc == 3) {
             W.u.B[vb + 1][e] = e == 0 ? 0.0f : (e == 1 ? -uh[2] * E.fri : uh[1] * E.fri);
           } else {
-            const float sg = uh[1] < 0.0f ? -1.0f : 1.0f, inv = 1.0f / (1.0f + fabsf(uh[1])); /* 2 / (h'h), h'h = 2 (1 + |u_1|) */
+            const float sg = uh[1] < 0.0f ? -1.0f : 1.0f, inv = fast_rcp(1.0f + fabsf(uh[1])); /* 2 / (h'h), h'h = 2 (1 + |u_1|) */
             const float hve = e == 0 ? 0.0f : uhat + (e == 1 ? sg : 0.0f);
 #pragma unroll
             for (int k = 2; k < 6; k++) W.u.B[vb + k - 1][e] = e == 0 ? 0.0f : ((e == k ? 1.0f : 0.0f) - hve * uh[k] * inv) * E.fri;
@@ -970,7 +970,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       solve_tree_fused2(W.u2.n.Hc, W.u2.n.Hb, grad, search, W.u.B[xr], z1);
       const float cr = lane < GQ_NVD ? W.u.B[xr][lane] : 0.0f;
       const float cz0 = wave_sum(lane < GQ_NVD ? cr * search[lane] : 0.0f), cz1 = wave_sum(lane < GQ_NVD ? cr * z1[lane] : 0.0f);
-      const float lam = cz0 / (1.0f / xw + cz1);
+      const float lam = fdiv(cz0, fast_rcp(xw) + cz1);
       wave_barrier();
       if (lane < GQ_NVD) search[lane] -= lam * z1[lane];
       wave_barrier();
@@ -1014,7 +1014,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     g0 = wave_sum(p1 + d1);
     float h0 = wave_sum(p2 + d2);
     if (!(g0 < 0.0f)) { exit_code = 5; break; } /* not a descent direction: converged to working precision */
-    alpha = -g0 / h0;
+    alpha = fdiv(-g0, h0);
     /* Newton on phi' while it makes progress; phi' is only piecewise smooth (a row changing piece, an elliptic contact whose
      * tangential residual passes near zero), and across a kink whose slopes differ by more than 2x Newton steps from the
      * two sides overshoot each other for ever inside the bracket.  So once a bracket exists, a trial that did not halve
@@ -1031,7 +1031,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
       const float ha = wave_sum(p2 + d2);
       if (fabsf(ga) <= GQ_LS_TOL * fabsf(g0)) { first_try = ls == 0; done = true; break; } /* an approximate line search, like MuJoCo's */
       if (ga < 0.0f) lo = alpha; else hi = alpha;
-      float an = alpha - ga / ha;
+      float an = alpha - fdiv(ga, ha);
       const bool outside = !(an > lo) || (hi > 0.0f && !(an < hi));
       if (hi > 0.0f) { if (outside || fabsf(ga) > 0.5f * gprev) an = 0.5f * (lo + hi); }
       else if (outside) an = 2.0f * alpha;
@@ -1059,7 +1059,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
     bool moved = row_piece(rtype, y, rR, rfloss) != row_piece(rtype, ynew, rR, rfloss);
     if constexpr (CONE) if (E.code) { /* the middle zone is not quadratic: a contact there (before or after) always counts as moved */
       const float TTn = fmaxf(0.0f, TT + 2.0f * alpha * UV + alpha * alpha * VV);
-      const int zn = ell_zone(E.mu * y0 + alpha * N1, sqrtf(TTn), E.mu);
+      const int zn = ell_zone(E.mu * y0 + alpha * N1, fast_sqrt(TTn), E.mu);
       moved = zn != zone || zone == 2;
     }
     y = ynew;

@@ -796,7 +796,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     else if constexpr (CONE) {
       rtype = ROW_ELLIPTIC; ecode = e | (dim << 4); er0 = W.con_row[c];
       econ_dist = rpos; econ_inc = rmargin;
-      emu = mu / sqrtf(m.impratio);
+      emu = mu * fast_rsqrt(m.impratio);
       /* torsional / rolling coefficients: same mixing rule as the sliding one (S6), _set_ground_friction overrides
        * floor and feet with [mu, 0.005, 0.0]; clamped at mjMINMU */
       const int cword = W.con_geom[c], code = GEN ? (cword & 0xff) : cword, code1 = GEN ? ((cword >> 8) & 0xff) - 1 : -1;
@@ -828,7 +828,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       dir = cn + sgn * ((e >> 1) == 0 ? ct1 : ct2);
       rdiag = tran + mu * mu * tran;
       rdiag_first = rdiag;
-      rmu = mu / sqrtf(m.impratio);
+      rmu = mu * fast_rsqrt(m.impratio);
     }
     w = cross(ld3(W.con_pos[c]) - v3(0.0f, 0.0f, W.basez), dir); /* O re-read: not kept live across the stages */
     if (rotational) { w = dir; dir = v3(0.0f, 0.0f, 0.0f); } /* torsion / rolling rows act on the angular Jacobian */
@@ -864,23 +864,23 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   if (rtype == ROW_FRICTION) { rR = flR; raref = -flB * vel; }
   else if (rtype != ROW_NONE) {
     float imp = impedance(rsolimp, rpos, rmargin);
-    rR = fmaxf(1e-15f, (1.0f - imp) * rdiag / imp);
+    rR = fmaxf(1e-15f, fdiv((1.0f - imp) * rdiag, imp));
     float dmax = fminf(fmaxf(rsolimp[1], 0.0001f), 0.9999f), K, B;
     if (rsolref[0] > 0.0f) {
       float tc = fmaxf(rsolref[0], 2.0f * h), dr = rsolref[1];
-      K = 1.0f / fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr);
-      B = 2.0f / fmaxf(1e-15f, dmax * tc);
-    } else { K = -rsolref[0] / fmaxf(1e-15f, dmax * dmax); B = -rsolref[1] / fmaxf(1e-15f, dmax); }
+      K = fast_rcp(fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr));
+      B = 2.0f * fast_rcp(fmaxf(1e-15f, dmax * tc));
+    } else { K = fdiv(-rsolref[0], fmaxf(1e-15f, dmax * dmax)); B = fdiv(-rsolref[1], fmaxf(1e-15f, dmax)); }
     raref = -B * vel - K * imp * (rpos - rmargin);
     if (rtype == ROW_PYRAMID) { /* Rpy = 2 mu^2 R(first edge); all edges of a condim-3 contact share diagApprox */
-      float Rfirst = fmaxf(1e-15f, (1.0f - imp) * rdiag_first / imp);
+      float Rfirst = fmaxf(1e-15f, fdiv((1.0f - imp) * rdiag_first, imp));
       rR = fmaxf(1e-15f, 2.0f * rmu * rmu * Rfirst);
     }
     if constexpr (CONE) if (rtype == ROW_ELLIPTIC) {
       /* R_n from the normal row's impedance (penetration of the contact), friction rows R_j = R_n mu^2 / friction_j^2 */
       const float impn = impedance(rsolimp, econ_dist, econ_inc);
-      eR0 = fmaxf(1e-15f, (1.0f - impn) * rdiag_first / impn);
-      if ((ecode & 15) > 0) rR = fmaxf(1e-15f, eR0 * emu * emu / (efri * efri));
+      eR0 = fmaxf(1e-15f, fdiv((1.0f - impn) * rdiag_first, impn));
+      if ((ecode & 15) > 0) rR = fmaxf(1e-15f, fdiv(eR0 * emu * emu, efri * efri));
       else rR = eR0;
     }
   }
@@ -922,7 +922,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     /* ================================================================ S8/S9 (Newton): primal solve, no dual operator */
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
     GQ_TICK(8);
-    const EllRow ell = {ecode, er0, efri, emu, 1.0f / eR0};
+    const EllRow ell = {ecode, er0, efri, emu, fast_rcp(eR0)};
     /* a contact between two different legs couples them in the Hessian M + J'DJ, which then no longer has M's tree
      * sparsity: such an env takes the dense Newton step */
     const bool xrow = SELF && internal && jleg1 >= 0 && jleg >= 0 && jleg1 != jleg && m.self_cut != 3;
@@ -1125,7 +1125,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   Q4 qn;
   {
     V3 w = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
-    float n = sqrtf(dot(w, w));
+    float n = fast_sqrt(dot(w, w));
     Q4 qraw = {W.qb[0], W.qb[1], W.qb[2], W.qb[3]};
     const Q4 qbase = qnormalize(qraw);
     qn = qbase;
@@ -1134,7 +1134,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     if (n > 1e-15f) {
       float ang = h * n, s, c;
       sincos_small(0.5f * ang, s, c);
-      s /= n;
+      s = fdiv(s, n);
       Q4 qr = {c, w.x * s, w.y * s, w.z * s};
       qn = qmul(qbase, qr);
     }

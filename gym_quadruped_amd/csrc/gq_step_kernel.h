@@ -260,12 +260,12 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   float dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f), dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
   float width = fmaxf(1e-15f, solimp[2]), mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f), power = fmaxf(1.0f, solimp[4]);
   if (dmin == dmax || width <= 1e-15f) return 0.5f * (dmin + dmax);
-  float x = fabsf(pos - margin) / width;
+  float x = fdiv(fabsf(pos - margin), width);
   if (x >= 1.0f) return dmax;
   if (x <= 0.0f) return dmin;
   float y;
   if (power == 1.0f) y = x;
-  else if (power == 2.0f) y = x <= mid ? x * x / mid : 1.0f - (1.0f - x) * (1.0f - x) / (1.0f - mid); /* MuJoCo's default */
+  else if (power == 2.0f) y = x <= mid ? fdiv(x * x, mid) : 1.0f - fdiv((1.0f - x) * (1.0f - x), 1.0f - mid); /* MuJoCo's default */
   else if (x <= mid) y = fast_pow_ratio(x, power, mid, power - 1.0f);
   else y = 1.0f - fast_pow_ratio(1.0f - x, power, 1.0f - mid, power - 1.0f);
   return dmin + y * (dmax - dmin);

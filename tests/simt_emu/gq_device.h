@@ -75,6 +75,8 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 #define __builtin_amdgcn_s_getreg(x) 0
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
+static inline float fdiv(float a, float b) { return a / b; }
+static inline float fast_sqrt(float x) { return std::sqrt(x); }
 static inline float fast_cos_turns(float x) { return std::cos(6.283185307179586f * x); }
 static inline float fast_pow_ratio(float a, float p, float b, float q) { return std::exp2(p * std::log2(a) - q * std::log2(b)); }
 static inline float med3(float x, float lo, float hi) { return std::min(std::max(x, lo), hi); }
