@@ -308,6 +308,32 @@ def test_pipelined_rollout_equals_the_step_loop(shards):
     assert torch.equal(b._h9[:, [0, 1, 3, 4]], h9[:, [0, 1, 3, 4]])
 
 
+@pytest.mark.parametrize('robot,scene', [('go2', 'flat'), ('hyqreal1', 'random_boxes'), ('aliengo', 'perlin'), ('b2', 'slippery')])
+def test_persistent_rollout_equals_the_step_loop_on_the_other_kernel_variants(robot, scene):
+    """The persistent rollout (one launch, every wavefront plays all steps of its env) is a kernel variant of its own for every
+    scene / cone / geometry combination: elliptic cones (go2), world boxes without and with primitive link geoms (hyqreal1, b2)
+    and the height field (aliengo perlin) must also end bit-identical to the step loop, in-kernel re-spawns inside the scene
+    included."""
+    n, K = 512, 50
+    mk = lambda: _env(robot, n, scene=scene, state_obs_names=('qpos', 'qvel', 'contact_forces'), solver='newton', auto_reset='next_step', seed=21)
+    a, b = mk(), mk()
+    a.reset(random=True); b.reset(random=True)
+    g = torch.Generator(device='cuda:0').manual_seed(3)
+    acts = torch.randn(K, n, 12, generator=g, device='cuda:0') * 40
+    rows = []
+    for k in range(K):
+        a.step(acts[k])
+        rows.append(a._obs_buf.clone())
+    out = torch.zeros(K, n, b._obs_dim, device='cuda:0')
+    b.rollout(acts, shards=0, obs_out=out)
+    torch.cuda.synchronize()
+    for k in ('_qpos', '_qvel', '_warm', '_time', '_step_num', '_episode', '_cmd', '_terminated', '_lift_failed', '_obs_buf'):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert torch.equal(torch.stack(rows), out)
+    assert torch.isfinite(a.qpos).all()
+    assert robot == 'b2' or int(a._episode.max()) > 1, 'the rollout must contain auto-resets'   # (b2 does not fall within 50 steps)
+
+
 @pytest.mark.parametrize('robot,scene', [('hyqreal1', 'random_boxes'), ('aliengo', 'random_boxes'), ('aliengo', 'perlin')])
 def test_box_scene_lift_loop_follows_the_reference_rule_and_how_often_it_leaves_it(robot, scene):
     """QuadrupedEnv.reset on a scene with world geoms beyond the floor: the reference lifts by 1.1 max|dist| per mj_step1 until
