@@ -182,7 +182,9 @@ typedef struct GqModelDesc {
    * excluded), ordered by (body1, body2, geom1, geom2), and one proxy capsule per collision geom in its BODY frame
    * (p0[3], p1[3], radius): exact for sphere / capsule geoms, the INSCRIBED capsule along the hull's principal axis for box /
    * cylinder / mesh geoms (a contact is found late by the gap between hull and proxy, never invented;
-   * gym_quadruped_amd/selfcol.py).  nselfpair = 0 switches self-collision off (it is ON by default with the Newton solver). */
+   * gym_quadruped_amd/selfcol.py).  The proxies decide pairs of hull / cylinder geoms; a pair of a BOX with a sphere, capsule
+   * or box (geom_type below) is evaluated exactly instead - closest features, separating axes, up to 2 / 4 points
+   * (csrc/gq_pairs.h).  nselfpair = 0 switches self-collision off (it is ON by default with the Newton solver). */
   int32_t nselfpair;
   const int32_t* selfpair_geom1; /* [nselfpair] */
   const int32_t* selfpair_geom2;
@@ -191,6 +193,7 @@ typedef struct GqModelDesc {
    * plane narrow phase, in the kernel (csrc/gq_step_body.h floor_candidates) and in the oracle alike - mjraw_PlaneCapsule:
    * both end spheres, frame aligned with the axis; mjraw_PlaneBox: the corners at or below the centre, at most 4;
    * mjc_PlaneCylinder: up to 4 rim points; mesh: the support vertex of the hull (mjc_PlaneConvex's first point).
+   * It also selects the exact pair routines for sphere / capsule / box geoms against world boxes and against each other.
    * NULL: spheres and capsules are recognised by their clouds (1 / 2 vertices), everything else is a hull. */
   const int32_t* geom_type;      /* [ngeom] */
 } GqModelDesc;
