@@ -73,18 +73,22 @@ class AccessorsMixin:
                 return self._dense_mass()
             key, cnt = self._DYN_FIELDS[field]
             return self._dyn[:, GQ_DYN[key]:GQ_DYN[key] + cnt]
-        if getattr(self, '_rec_tensor', None) is None:
-            self.enable_debug(self.num_envs)
-            ptr, n, stride = C.c_void_p(), C.c_int32(), C.c_int32()
-            _lib.check(self._L.gq_debug_device_buffer(self._hbatch, C.byref(ptr), C.byref(n), C.byref(stride)), 'gq_debug_device_buffer')
-            self._rec_tensor = torch.as_tensor(_DevPtr(ptr.value, (n.value, stride.value)), device=self.device)
-            self._rec_filled_at = None
+        self._ensure_rec_tensor()
         if self._rec_filled_at is None:
             raise _lib.GqError('the inspection record is empty: call step() or reset() once after the first use of a '
                                'dynamics accessor (legs_mass_matrix, legs_qfrc_bias, feet_jacobians, hip_positions, com, ...)')
         off, cnt = C.c_int32(), C.c_int32()
         _lib.check(self._L.gq_debug_field(field.encode(), C.byref(off), C.byref(cnt)), 'gq_debug_field')
         return self._rec_tensor[:, off.value:off.value + cnt.value]
+
+    def _ensure_rec_tensor(self):
+        """Switch the inspection record on for every env (instrumented kernel variant from the next launch on) and map it."""
+        if getattr(self, '_rec_tensor', None) is None:
+            self.enable_debug(self.num_envs)
+            ptr, n, stride = C.c_void_p(), C.c_int32(), C.c_int32()
+            _lib.check(self._L.gq_debug_device_buffer(self._hbatch, C.byref(ptr), C.byref(n), C.byref(stride)), 'gq_debug_device_buffer')
+            self._rec_tensor = torch.as_tensor(_DevPtr(ptr.value, (n.value, stride.value)), device=self.device)
+            self._rec_filled_at = None
 
     def _dense_mass(self):
         """mj_fullM: [N, 324] dense joint-space inertia out of the dynamics row's tree-sparse storage (leg dof 6 + j keeps its
@@ -168,11 +172,10 @@ class AccessorsMixin:
         advancing the state; the results are read like the reference reads mjData afterwards - through the dynamics
         accessors (legs_mass_matrix, legs_qfrc_bias, feet_jacobians, hip_positions, com, ...) or ``debug_internals``.  Uses
         the instrumented kernel variant for all envs (~20 % slower than step's production kernel)."""
-        if getattr(self, '_rec_tensor', None) is None:
-            try:
-                self._record('M')
-            except _lib.GqError:
-                pass
+        # gq_forward writes the inspection record (and, on an accessors=True env, the dynamics / contact rows of the forward
+        # pose): the record must be on whatever backs the getters - not through _record(), which answers from the
+        # dynamics row as soon as there is one and never switches the record on
+        self._ensure_rec_tensor()
         c = None if ctrl is None else torch.as_tensor(ctrl, dtype=torch.float32, device=self.device).reshape(-1, self.mjModel.nu).expand(self.num_envs, -1).contiguous()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._L.gq_forward(self._hbatch, int(stage), None if c is None else c.data_ptr(), self._st, self._out, stream), 'gq_forward')

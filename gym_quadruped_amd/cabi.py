@@ -12,7 +12,7 @@ import numpy as np
 from .mjcf import ModelDesc
 
 GQ_NLEG = 4
-GQ_ABI_VERSION = 300   # include/gq.h
+GQ_ABI_VERSION = 400   # include/gq.h
 # optional extra output rows of the step kernel (include/gq.h gq_batch_set_outputs)
 GQ_DYN = dict(MC=0, MB=108, BIAS=144, XPOS=162, XMAT=201, FOOT=318, STRIDE=336)
 GQ_CON_MAX, GQ_CON_REC = 12, 24
@@ -79,7 +79,16 @@ class GqImuCfg(C.Structure):
 
 class GqObsOut(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('terminated', C.c_void_p), ('truncated', C.c_void_p),
-                ('invalid_contact', C.c_void_p), ('step_num', C.c_void_p), ('step_num_prev', C.c_void_p)]
+                ('invalid_contact', C.c_void_p), ('step_num', C.c_void_p), ('step_num_prev', C.c_void_p), ('contacts_dropped', C.c_void_p)]
+
+
+class GqPolicyPd(C.Structure):
+    _fields_ = [('kp', C.c_float * 12), ('kd', C.c_float * 12), ('q_des', C.c_float * 12)]
+
+
+class GqMailboxView(C.Structure):
+    _fields_ = [('action', C.c_void_p), ('steps_done', C.c_void_p), ('queue_items', C.c_void_p), ('queue_counters', C.c_void_p), ('status', C.c_void_p),
+                ('n_queues', C.c_int32), ('queue_capacity', C.c_int32), ('counter_stride', C.c_int32)]
 
 
 class GqResampleCfg(C.Structure):

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +24,10 @@ extern "C" void gq_launch_jac(const GqDevModel* model, const double* qpos, int b
 extern "C" void gq_launch_ray(const GqDevModel* model, const double* origin, const float* dir, int total, float* dist, int32_t* geom, hipStream_t stream);
 extern "C" void gq_launch_heightmap(const GqDevModel* model, const double* center, int center_stride, const float* yaw, int yaw_stride, int n_envs, int rows, int cols,
                                     float dist_x, float dist_y, float* out, hipStream_t stream);
+
+extern "C" void gq_launch_xcc_probe(int32_t* mask, hipStream_t stream);
+extern "C" void gq_launch_policy_pd(const gq::MailboxDev* mb, const gq::PolicyPdDev* pd, const float* obs, int od, int waves, hipStream_t stream);
+extern "C" int gq_launch_mailbox_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, const gq::MailboxDev* mb, int waves, int solver, int cone, int boxes, int self, hipStream_t stream);
 
 #define GQ_ARG_SLOTS 8
 static thread_local char g_err[512] = "";
@@ -45,7 +50,8 @@ struct GqModel {
  * geoms (exact pair routines compiled in; gq_step_body.h PRIM) */
 static int scene_variant(const GqModel* m) {
   if (!(m->host.nbox > 0 || m->host.hf_nrow > 0)) return 0;
-  for (int i = 4; i < 4 + m->host.nlg; i++) { const int t = m->host.item[i].ptype; if (t == 2 || t == 3 || t == 6) return 2; }
+  /* lg[] is indexed by link geom (item[] is in contact order: feet and link geoms interleaved by geom id) */
+  for (int g = 0; g < m->host.nlg; g++) { const int t = m->host.lg[g].ptype; if (t == 2 || t == 3 || t == 6) return 2; }
   return 1;
 }
 struct GqBatch {
@@ -77,6 +83,17 @@ struct GqBatch {
   float* ext_dist;      /* caller-owned device [N][6] */
   int debug_cap;
   float* dyn_out; float* con_out;  /* caller-owned device rows registered with gq_batch_set_outputs */
+  /* closed-loop persistent rollout (gq_rollout_closed): mailboxes, ready queues, the policy's stream; allocated on first use */
+  struct {
+    gq::MailboxDev host;      /* what the device block holds */
+    gq::MailboxDev* dev;
+    gq::MailboxDev* staging;  /* pinned */
+    int32_t* alive;           /* pinned host word the policy workgroups count themselves into */
+    int32_t* status_host;     /* pinned copy of the status words (gq_rollout_closed_status) */
+    gq::PolicyPdDev* policy_dev; /* device copy of the built-in policy's parameters (inline mode) */
+    hipStream_t stream; hipEvent_t fork, join;
+    bool ready;
+  } mb;
 };
 
 /* the launches must be issued with the batch's device current (the caller's stream belongs to it); restore the caller's
@@ -186,6 +203,11 @@ int gq_batch_destroy(GqBatch* b) {
   hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->lift_pending); hipFree(b->load_hint); hipFree(b->dev_args);
   if (b->staging) hipHostFree(b->staging);
   if (b->batch_staging) hipHostFree(b->batch_staging);
+  if (b->mb.ready) {
+    hipFree(b->mb.host.act); hipFree(b->mb.host.steps_done); hipFree(b->mb.host.issued); hipFree(b->mb.host.q_items); hipFree(b->mb.host.q_ctr);
+    hipFree(b->mb.host.status); hipFree(b->mb.dev); hipFree(b->mb.policy_dev); hipHostFree(b->mb.staging); hipHostFree(b->mb.alive); hipHostFree(b->mb.status_host);
+    hipStreamDestroy(b->mb.stream); hipEventDestroy(b->mb.fork); hipEventDestroy(b->mb.join);
+  }
   for (int i = 0; i < b->n_shard_streams; i++) { hipStreamDestroy(b->shard_stream[i]); hipEventDestroy(b->shard_event[i]); }
   if (b->n_shard_streams) hipEventDestroy(b->fork_event);
   if (b->debug) hipFree(b->debug);
@@ -279,6 +301,7 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const
   a->episode_ro = episode;
   a->obs = out.obs; a->reward = out.reward; a->terminated = out.terminated; a->truncated = out.truncated;
   a->invalid_contact = out.invalid_contact; a->step_num = out.step_num; a->step_prev = out.step_num_prev;
+  a->contacts_dropped = out.contacts_dropped;
   a->n_envs = b->host.n_envs;
 }
 /* Make the device argument block describe (st, out, episode, lift_failed[, auto-reset cfg]).  Steady state: a memcmp.
@@ -358,6 +381,9 @@ int gq_step_range(GqBatch* b, int env0, int count, const float* ctrl, GqState st
 int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
                int32_t* episode, uint8_t* lift_failed, float* obs_seq, void* hip_stream) {
   if (!b || !ctrl_seq || n_steps < 0) { SET_ERR("gq_rollout: bad argument"); return GQ_EINVAL; }
+  /* the persistent kernel exists for the production variant only: with the inspection record or a stage cut active the rollout is
+   * played as the step loop (one shard), so that the record describes the last step and the cut applies to every step */
+  if (shards == 0 && b && (b->host.debug_envs > 0 || b->stop_stage != 0)) shards = 1;
   if (shards == 0) { /* persistent: ONE launch, every wavefront plays the whole sequence of its env (StepCall::n_steps) */
     if (auto_reset && !auto_reset->autoreset_next_step) { SET_ERR("gq_rollout: the persistent rollout (shards = 0) needs next-step auto-reset or none"); return GQ_EINVAL; }
     int rc0 = step_launch(b, 0, 0, nullptr, nullptr, st, out, auto_reset, episode, lift_failed, hip_stream, "gq_rollout"); /* validate + bind */
@@ -414,6 +440,156 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
   }
 #undef RO_TRY
   if (herr != hipSuccess) { SET_ERR("gq_rollout: HIP error '%s' at %s", hipGetErrorString(herr), what); return GQ_EDEVICE; }
+  return GQ_OK;
+}
+
+/* mailboxes, queues and the policy stream of a batch; the XCD census of the device (one probe launch) */
+static int mailbox_setup(GqBatch* b) {
+  if (b->mb.ready) return GQ_OK;
+  const int N = b->host.n_envs;
+  gq::MailboxDev& h = b->mb.host;
+  std::memset(&h, 0, sizeof h);
+  int qcap = 64;
+  while (qcap < N) qcap <<= 1;
+  /* which XCC ids do the workgroups of this device report?  (8 on an MI355X in SPX mode; a partitioned device shows fewer) */
+  int32_t* mask_dev = nullptr;
+  HIP_TRY(hipMalloc(&mask_dev, sizeof(int32_t)));
+  HIP_TRY(hipMemset(mask_dev, 0, sizeof(int32_t)));
+  gq_launch_xcc_probe(mask_dev, 0);
+  int32_t mask = 0;
+  HIP_TRY(hipMemcpy(&mask, mask_dev, sizeof mask, hipMemcpyDeviceToHost));
+  hipFree(mask_dev);
+  if (mask == 0) { SET_ERR("gq_rollout_closed: the XCD probe saw no workgroup"); return GQ_EDEVICE; }
+  int nq = 0;
+  for (int x = 0; x < 16; x++) h.xcc_queue[x] = ((mask >> x) & 1) ? nq++ : 0;
+  h.nq = nq; h.qcap = qcap; h.n_envs = N;
+  HIP_TRY(hipMalloc(&h.act, sizeof(float) * 12 * (size_t)N));
+  HIP_TRY(hipMalloc(&h.steps_done, sizeof(int32_t) * (size_t)N));
+  HIP_TRY(hipMalloc(&h.issued, sizeof(int32_t) * (size_t)N));
+  HIP_TRY(hipMalloc(&h.q_items, sizeof(int32_t) * (size_t)nq * qcap));
+  HIP_TRY(hipMalloc(&h.q_ctr, sizeof(int32_t) * (size_t)nq * 2 * GQ_MB_QSTRIDE));
+  HIP_TRY(hipMalloc(&h.status, sizeof(int32_t) * 8));
+  HIP_TRY(hipMemset(h.status, 0, sizeof(int32_t) * 8));
+  HIP_TRY(hipMalloc(&b->mb.dev, sizeof(gq::MailboxDev)));
+  HIP_TRY(hipMalloc(&b->mb.policy_dev, sizeof(gq::PolicyPdDev)));
+  HIP_TRY(hipHostMalloc(&b->mb.staging, sizeof(gq::MailboxDev), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&b->mb.alive, sizeof(int32_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&b->mb.status_host, sizeof(int32_t) * 8, hipHostMallocDefault));
+  h.alive = b->mb.alive;
+  HIP_TRY(hipStreamCreateWithFlags(&b->mb.stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&b->mb.fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&b->mb.join, hipEventDisableTiming));
+  b->mb.ready = true;
+  return GQ_OK;
+}
+
+int gq_mailbox_get(GqBatch* b, GqMailboxView* out) {
+  if (!b || !out) { SET_ERR("gq_mailbox_get: null argument"); return GQ_EINVAL; }
+  DeviceGuard guard(b->model->device);
+  const int rc = mailbox_setup(b);
+  if (rc != GQ_OK) return rc;
+  const gq::MailboxDev& h = b->mb.host;
+  out->action = h.act; out->steps_done = h.steps_done; out->queue_items = h.q_items; out->queue_counters = h.q_ctr; out->status = h.status;
+  out->n_queues = h.nq; out->queue_capacity = h.qcap; out->counter_stride = GQ_MB_QSTRIDE;
+  return GQ_OK;
+}
+
+int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, int policy_waves, int step_waves, double timeout_s, GqState st, GqObsOut out,
+                      const GqResetCfg* auto_reset, int32_t* episode, uint8_t* lift_failed, float* obs_seq, float* act_seq, void* hip_stream) {
+  if (!b || n_steps < 0 || (mode != GQ_CLOSED_MAILBOX && mode != GQ_CLOSED_INLINE)) { SET_ERR("gq_rollout_closed: bad argument"); return GQ_EINVAL; }
+  if (mode == GQ_CLOSED_INLINE && !pd) { SET_ERR("gq_rollout_closed: the inline mode runs the built-in policy: pd must be given"); return GQ_EINVAL; }
+  if (auto_reset && !auto_reset->autoreset_next_step) { SET_ERR("gq_rollout_closed needs next-step auto-reset or none"); return GQ_EINVAL; }
+  if (b->model->host.solver != 1) { SET_ERR("gq_rollout_closed needs the Newton solver (solver = 1)"); return GQ_EINVAL; }
+  if (b->host.debug_envs > 0 || b->stop_stage != 0) { SET_ERR("gq_rollout_closed runs the production kernel: switch the inspection record / stage cut off first"); return GQ_EINVAL; }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  int rc = step_launch(b, 0, 0, nullptr, nullptr, st, out, auto_reset, episode, lift_failed, hip_stream, "gq_rollout_closed"); /* validate + bind */
+  if (rc != GQ_OK) return rc;
+  DeviceGuard guard(b->model->device);
+  rc = mailbox_setup(b);
+  if (rc != GQ_OK) return rc;
+  if (n_steps == 0) return GQ_OK;
+  const int N = b->host.n_envs, od = b->host.obs_dim;
+  gq::MailboxDev& h = b->mb.host;
+  gq::PolicyPdDev P{};
+  if (pd) { /* the columns of the joint angles / velocities in this batch's observation row */
+    for (int j = 0; j < 12; j++) {
+      P.kp[j] = pd->kp[j]; P.kd[j] = pd->kd[j]; P.qdes[j] = pd->q_des[j]; P.col_q[j] = -1; P.col_qd[j] = -1;
+      for (int c = 0; c < od; c++) {
+        const int src = b->host.obs_map[c];
+        if (P.col_q[j] < 0 && (src == gq::OB_QPOS_JS + j || src == gq::OB_QPOS + 7 + j)) P.col_q[j] = c;
+        if (P.col_qd[j] < 0 && (src == gq::OB_QVEL_JS + j || src == gq::OB_QVEL + 6 + j)) P.col_qd[j] = c;
+      }
+      if (P.col_q[j] < 0 || P.col_qd[j] < 0) { SET_ERR("gq_rollout_closed: the PD policy reads qpos_js / qvel_js (or qpos / qvel): not in this batch's observation row"); return GQ_EINVAL; }
+    }
+    if (policy_waves <= 0) policy_waves = 64; /* lane = env: 4096 envs get a lane each */
+    if (policy_waves > 256) policy_waves = 256;
+  }
+  if (mode == GQ_CLOSED_INLINE) {
+    /* the persistent rollout kernel with the policy evaluated by the stepping wavefront itself: no mailbox, no second kernel */
+    if (b->staging_next == GQ_ARG_SLOTS) { HIP_TRY(hipStreamSynchronize(stream)); b->staging_next = 0; }
+    gq::PolicyPdDev* slot = reinterpret_cast<gq::PolicyPdDev*>(b->staging + b->staging_next++); /* a pinned staging slot of the argument ring */
+    std::memcpy(slot, &P, sizeof P);
+    HIP_TRY(hipMemcpyAsync(b->mb.policy_dev, slot, sizeof P, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(h.status, 0, sizeof(int32_t) * 8, stream));
+    gq::StepCall ci{};
+    ci.n_steps = n_steps; ci.obs_seq = obs_seq; ci.act_seq = act_seq; ci.policy = b->mb.policy_dev;
+    ci.auto_reset = auto_reset ? 2 : 0; ci.stop_stage = 0;
+    gq_launch_step(b->dev_args, &ci, N, b->model->host.solver, b->model->host.cone, scene_variant(b->model), (b->model->host.nsp > 0 || b->force_self), stream);
+    HIP_TRY(hipGetLastError());
+    return GQ_OK;
+  }
+  if (step_waves <= 0 || step_waves > N) step_waves = N; /* more workgroups than free slots is harmless: the late ones find the queues drained */
+  h.n_steps = n_steps; h.obs_seq = obs_seq; h.act_seq = act_seq;
+  h.timeout_ticks = (int64_t)((timeout_s > 0.0 ? timeout_s : 5.0) * 1e8);
+  /* fresh rollout state, ordered on the caller's stream */
+  HIP_TRY(hipMemsetAsync(h.steps_done, 0, sizeof(int32_t) * (size_t)N, stream));
+  HIP_TRY(hipMemsetAsync(h.issued, 0, sizeof(int32_t) * (size_t)N, stream));
+  HIP_TRY(hipMemsetAsync(h.q_items, 0, sizeof(int32_t) * (size_t)h.nq * h.qcap, stream));
+  HIP_TRY(hipMemsetAsync(h.q_ctr, 0, sizeof(int32_t) * (size_t)h.nq * 2 * GQ_MB_QSTRIDE, stream));
+  HIP_TRY(hipMemsetAsync(h.status, 0, sizeof(int32_t) * 8, stream));
+  HIP_TRY(hipStreamSynchronize(stream)); /* the pinned staging block below is reused per call; a rollout is thousands of launches' worth of work */
+  std::memcpy(b->mb.staging, &h, sizeof h);
+  HIP_TRY(hipMemcpyAsync(b->mb.dev, b->mb.staging, sizeof h, hipMemcpyHostToDevice, stream));
+  gq::StepCall c{};
+  c.auto_reset = auto_reset ? 2 : 0;
+  const int boxes = scene_variant(b->model), self = (b->model->host.nsp > 0 || b->force_self);
+  if (pd) {
+    /* the policy must be RESIDENT before the step wavefronts take every slot of the device: launch it first, on its own stream,
+     * and wait until each of its workgroups has reported in */
+    *b->mb.alive = 0;
+    HIP_TRY(hipEventRecord(b->mb.fork, stream));
+    HIP_TRY(hipStreamWaitEvent(b->mb.stream, b->mb.fork, 0));
+    gq_launch_policy_pd(b->mb.dev, &P, out.obs, od, policy_waves, b->mb.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->mb.join, b->mb.stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    while (*(volatile int32_t*)b->mb.alive < policy_waves) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+        /* it cannot start: tell it to leave as soon as it does, and report */
+        int32_t one = 3;
+        (void)hipMemcpyAsync(h.status, &one, sizeof one, hipMemcpyHostToDevice, stream);
+        (void)hipStreamWaitEvent(stream, b->mb.join, 0);
+        SET_ERR("gq_rollout_closed: the policy kernel did not become resident within 2 s (%d of %d workgroups)", (int)*(volatile int32_t*)b->mb.alive, policy_waves);
+        return GQ_EDEVICE;
+      }
+    }
+  }
+  if (!gq_launch_mailbox_step(b->dev_args, &c, b->mb.dev, step_waves, b->model->host.solver, b->model->host.cone, boxes, self, stream)) {
+    SET_ERR("gq_rollout_closed: no mailbox variant of the step kernel for this model in this build"); return GQ_EINVAL;
+  }
+  HIP_TRY(hipGetLastError());
+  if (pd) HIP_TRY(hipStreamWaitEvent(stream, b->mb.join, 0)); /* the caller's stream resumes when both kernels are done */
+  return GQ_OK;
+}
+
+int gq_rollout_closed_status(GqBatch* b, int32_t out[4], void* hip_stream) {
+  if (!b || !out) { SET_ERR("gq_rollout_closed_status: null argument"); return GQ_EINVAL; }
+  if (!b->mb.ready) { out[0] = out[1] = out[2] = out[3] = 0; return GQ_OK; }
+  DeviceGuard guard(b->model->device);
+  HIP_TRY(hipMemcpyAsync(b->mb.status_host, b->mb.host.status, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  for (int i = 0; i < 4; i++) out[i] = b->mb.status_host[i];
+  if (out[0] != 0) { SET_ERR("closed-loop rollout aborted: code %d (1: a step wavefront waited past the deadline for ticket %d; 2: policy lane %d waited past the deadline; 3: policy not resident), %d env-steps were played", out[0], out[1], out[1], out[2]); return GQ_EDEVICE; }
   return GQ_OK;
 }
 

@@ -475,7 +475,7 @@ __device__ inline bool hfield_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m
 }
 
 /* running totals of the contact list while world geoms are appended to it */
-struct WorldAppend { int ncon, rows, invalid, reserve, ft /* bit k: foot k's calf body touches a world geom */, nself; };
+struct WorldAppend { int ncon, rows, invalid, reserve, ft /* bit k: foot k's calf body touches a world geom */, nself, ndrop /* contacts the capacity cut */; };
 
 /* append the contacts of the collision items (lane = position in con_order: dist / nrm / pt) with one world geom of
  * contact-parameter class cls; rows / row budget as in the floor pass.  No barrier inside. */
@@ -508,7 +508,7 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
   /* ranks and rows: one prefix sum over (contacts, rows, reserved virtual rows), as in the floor pass */
   const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
   const int vres = (CONE && need > 1) ? need - 1 : 0;
-  int idx0, rows0, res0;
+  int idx0, rows0, res0, incl_all = 0;
   if constexpr (NP == 1) { /* one point per item: ballots and population counts (scalar unit) instead of the lane scan */
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     idx0 = ncon + popc64(ballot(touching) & lt);
@@ -518,7 +518,8 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
     res0 = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) : 0;
   } else {
     const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
-    const int excl = wave_incl_scan(packed) - packed;
+    incl_all = wave_incl_scan(packed);
+    const int excl = incl_all - packed;
     idx0 = ncon + (excl & 0xff); rows0 = rows + ((excl >> 8) & 0x3ff); res0 = reserve + ((excl >> 18) & 0x3ff);
   }
   int nfit = 0, j = 0;
@@ -547,11 +548,14 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
     ncon += popc64(f1 | f3 | f4 | f6);
     rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
     if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
+    S.ndrop += popc64(ballot(touching)) - popc64(f1 | f3 | f4 | f6);
   } else {
     const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8) | ((nfit * vres) << 18)), 63);
+    const int found = bcast(incl_all, 63) & 0xff; /* every touching point of this world geom */
     ncon += tot & 0xff;
     rows += (tot >> 8) & 0x3ff;
     if constexpr (CONE) reserve += (tot >> 18) & 0x3ff;
+    S.ndrop += found - (tot & 0xff);
   }
 }
 
@@ -753,7 +757,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     int& ncon = S.ncon; int& rows = S.rows; int& reserve = S.reserve;
     const int need = dim == 1 ? 1 : (CONE ? dim : 2 * (dim - 1));
     const int vres = (CONE && need > 1) ? need - 1 : 0;
-    int idx0, rows0, res0;
+    int idx0, rows0, res0, incl_all = 0;
     if constexpr (NP == 1) { /* one point per pair: ballots and population counts instead of the lane scan */
       idx0 = ncon + popc64(ballot(cnt > 0) & lt);
       const bool kept = cnt > 0 && idx0 < GQ_MAXCON;
@@ -762,7 +766,8 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
       res0 = CONE ? reserve + 2 * popc64(m3 & lt) + 5 * popc64(m6 & lt) : 0;
     } else {
       const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
-      const int excl = wave_incl_scan(packed) - packed;
+      incl_all = wave_incl_scan(packed);
+      const int excl = incl_all - packed;
       idx0 = ncon + (excl & 0xff); rows0 = rows + ((excl >> 8) & 0x3ff); res0 = reserve + ((excl >> 18) & 0x3ff);
     }
     int nfit = 0;
@@ -794,12 +799,15 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
       rows += popc64(f1) + 3 * popc64(f3) + 4 * popc64(f4) + 6 * popc64(f6);
       if constexpr (CONE) reserve += 2 * popc64(f3) + 5 * popc64(f6);
       S.nself += popc64(f1 | f3 | f4 | f6);
+      S.ndrop += popc64(ballot(cnt > 0)) - popc64(f1 | f3 | f4 | f6);
     } else {
       const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8) | ((nfit * vres) << 18)), 63);
+      const int found = bcast(incl_all, 63) & 0xff;
       ncon += tot & 0xff;
       rows += (tot >> 8) & 0x3ff;
       if constexpr (CONE) reserve += (tot >> 18) & 0x3ff;
       S.nself += tot & 0xff;
+      S.ndrop += found - (tot & 0xff);
     }
   }
 }
@@ -810,7 +818,7 @@ template <bool CONE>
 __device__ inline void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre) {
   const int lane = lane_id();
   WorldAppend S;
-  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = 0; S.reserve = 0; S.nself = 0;
+  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = 0; S.reserve = 0; S.nself = 0; S.ndrop = 0;
   const int ncon = S.ncon;
   if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
     st3(GQ_BX_CONNRM(W) + 3 * lane, v3(0.0f, 0.0f, 1.0f));
@@ -819,7 +827,7 @@ __device__ inline void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
   append_self_contacts<CONE>(W, m, mu_env, S, pre);
-  if (lane == 0) { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; }
+  if (lane == 0) { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; W.ndrop += S.ndrop; }
   wave_barrier();
 }
 
@@ -831,7 +839,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
   const int lane = lane_id();
   const PrimLane PL = prim_lane(W, m, IT, PRIM && lane < 4 + m.nlg, PRIM); /* all the box loop keeps of the item record */
   WorldAppend S;
-  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0;
+  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0; S.ndrop = 0;
   S.ft = uniform(W.foot_touch) & 15;
   const int ncon = S.ncon;
   if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
@@ -867,7 +875,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
   }
   if constexpr (SELF) append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre);
   if (lane == 0) {
-    W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself;
+    W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself; W.ndrop += S.ndrop;
     W.foot_touch = S.ft;
   }
   wave_barrier();

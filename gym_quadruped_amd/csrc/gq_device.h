@@ -145,6 +145,34 @@ __device__ __forceinline__ int opaque_lane(int l) { asm volatile("" : "+v"(l)); 
 template <class T> __device__ __forceinline__ const T* opaque_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; } /* per-lane pointer */
 __device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); } /* wave-uniform value */
 
+/* ---- mailbox traffic of the closed-loop persistent rollout (gq_kernels.hip mailbox_step_kernel): words that another wavefront -
+ * possibly on another XCD, behind another L2 - reads or writes while this kernel runs.  Agent-scope relaxed atomics: the
+ * loads / stores carry sc1 (served by / written through to the device-coherent level), the read-modify-writes are performed
+ * there.  Ordering is explicit: publish_fence() before the store of a sequence word (every earlier store of this wave has been
+ * acknowledged), the consumer reads data only after it has seen the sequence word. */
+__device__ __forceinline__ int ld_pub(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_pub(const float* p) {
+  return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_pub(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_pub(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int add_pub(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void publish_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* compiler: no store sinks below */
+  __builtin_amdgcn_s_waitcnt(0x0F70);                    /* vmcnt(0): every store of this wave has reached its L2 / memory */
+}
+/* an env of the closed-loop rollout changes hands between wavefronts of ONE XCD (per-XCD ready queues): its rows are coherent in
+ * that XCD's L2; what a new owner must drop is its CU's vector L1 (write-through, not snooped) and the scalar cache */
+__device__ __forceinline__ void adopt_fence() {
+  asm volatile("buffer_inv sc0" ::: "memory");
+  __builtin_amdgcn_s_dcache_inv();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF); } /* HW_REG_XCC_ID */
+__device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(8); }
+
 /* shader clock (s_memtime) for the stage timers of the debug record */
 __device__ __forceinline__ long long cycles() { return (long long)__builtin_readcyclecounter(); }
 

@@ -11,6 +11,29 @@
 
 namespace gq {
 
+/* joint-space PD law of the closed-loop rollouts, every operation rounded on its own (the elementwise torch expression
+ * kp * (q_des - q) - kd * qd gives the same bits) */
+__device__ __forceinline__ float pd_law(float kp, float kd, float qdes, float q, float qd) {
+#pragma clang fp contract(off)
+  const float e = qdes - q;
+  const float up = kp * e;
+  const float ud = kd * qd;
+  return up - ud;
+}
+/* inline mode of the closed-loop rollout: lanes 0-11 turn the observation row this wavefront published at the end of its previous
+ * step (global memory, the batch's own layout) into the control of the step that starts now; replaces what load_rows left in W.ctrl */
+__device__ __forceinline__ void pd_inline(const GQ_MODEL PolicyPdDev& P, const StepArgs& a, const StepCall& c, WaveMem& W, const int env, const int kstep,
+                                          const bool apply /* false: the env spends this step on its re-spawn and ignores the action */) {
+  const int lane = lane_id();
+  if (lane < 12) {
+    const int od = mptr(a.batch)->obs_dim;
+    const GQ_GLOBAL float* row = gptr(a.obs) + (size_t)env * od;
+    const float u = pd_law(P.kp[lane], P.kd[lane], P.qdes[lane], row[P.col_q[lane]], row[P.col_qd[lane]]);
+    if (apply) W.ctrl[lane] = u;
+    if (c.act_seq) gptr(c.act_seq)[((size_t)kstep * a.n_envs + env) * 12 + lane] = u;
+  }
+}
+
 /* step (+ in-kernel auto-reset).  Same-step mode: a terminated env is re-spawned by the same wavefront - reset_wave,
  * then the reset's own mj_step as a second pass through step_wave; no extra launches, but the launch lasts as long as
  * its two-pass waves.  Next-step mode: the env waits (pending flag) and spends its next launch on reset_wave + the
@@ -27,7 +50,7 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
                            * merely compiling the loop in cost the single-step kernel 2.7 %) */
   StepCall ck = c;
   if constexpr (PERSIST) { /* wave-uniform */
-    ck.ctrl = c.ctrl + (size_t)kstep * c.ctrl_stride;
+    ck.ctrl = c.ctrl ? c.ctrl + (size_t)kstep * c.ctrl_stride : nullptr; /* NULL: inline policy (or zero control) */
     if (c.obs_seq) ck.obs_seq = c.obs_seq + (size_t)kstep * A->s.n_envs * mptr(A->s.batch)->obs_dim;
   }
   const StepCall& c = ck; /* the body below sees this step's call */
@@ -38,6 +61,7 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
   /* the reset's own step after an explicit gq_reset: the reset kernel left word whether the lift loop is still due */
   int lift = (c.first_pass && A->s.lift_pending) ? (int)gptr(A->s.lift_pending)[env] : 0;
   int hint = load_rows<SOLVER>(A->s, c, W, env, pass == 0);
+  if constexpr (PERSIST) if (c.policy) pd_inline(*mptr(c.policy), A->s, c, W, env, kstep, !respawn); /* wave-uniform */
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
       wave_priority(3); /* reset + step in one launch: this wave is the longest of its SIMD */
@@ -54,6 +78,111 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); /* the next step reads the rows this one stored (same wave, same addresses) */
   wave_barrier();
   }
+}
+
+/* Closed-loop persistent rollout, the stepping side (protocol: gq_step_kernel.h MailboxDev).  grid = any number of one-wave workgroups:
+ * each pops tickets of ITS XCD's ready queue until every env-step of the rollout has been claimed.  Production Newton variants only. */
+template <int SOLVER, bool CONE, bool BOXES, bool SELF, bool PRIM>
+__global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArgs* __restrict__ A, const StepCall c0, const MailboxDev* __restrict__ MBp) {
+  static_assert(GQ_WPB == 1, "one wavefront per workgroup");
+  __shared__ WaveMem W;
+  const GQ_MODEL MailboxDev& MB = *mptr(MBp);
+  const int q = MB.xcc_queue[xcc_id()];
+  const int N = MB.n_envs, nq = MB.nq, qmask = MB.qcap - 1;
+  const int total = ((N - q + nq - 1) / nq) * MB.n_steps; /* env-steps that will ever pass through this queue */
+  int32_t* const head = MB.q_ctr + (size_t)(2 * q) * GQ_MB_QSTRIDE;
+  int32_t* const items = MB.q_items + (size_t)q * MB.qcap;
+  int played = 0;
+  for (;;) {
+    int ticket = 0;
+    if (lane_id() == 0) ticket = add_pub(head, 1);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket >= total) break;
+    int32_t* const slot = items + (ticket & qmask);
+    int item;
+    const long long t0 = wall_clock64();
+    for (int spin = 0;; spin++) { /* the ticket's env is pushed as soon as the policy has its action */
+      item = __builtin_amdgcn_readfirstlane(ld_pub(slot));
+      if (item != 0) break;
+      nap();
+      if ((spin & 31) == 31) {
+        if (ld_pub(MB.status) != 0) return;
+        if (wall_clock64() - t0 > MB.timeout_ticks) { if (lane_id() == 0) { st_pub(MB.status + 1, ticket); st_pub(MB.status, 1); } return; }
+      }
+    }
+    if (lane_id() == 0) st_pub(slot, 0); /* the slot is free for the push that comes qcap tickets later */
+    const int env = item - 1;
+    adopt_fence();
+    /* the env's step index is only needed to place the row in obs_seq: otherwise that round trip is not taken */
+    const int k = MB.obs_seq ? __builtin_amdgcn_readfirstlane(ld_pub(MB.steps_done + env)) : 0;
+    StepCall ck = c0;
+    ck.env0 = env - (int)blockIdx.x; /* step_wave / reset_wave address env0 + wave index */
+    ck.ctrl = MB.act;
+    ck.obs_seq = MB.obs_seq ? MB.obs_seq + (size_t)k * N * mptr(A->s.batch)->obs_dim : nullptr;
+    const StepCall& c = ck;
+    int pass = 0, lift = 0;
+    bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[env]; /* wave-uniform */
+    int hint = load_rows<SOLVER, true>(A->s, c, W, env, true);
+    if (respawn) {
+      wave_priority(3);
+      wave_barrier();
+      lift = reset_wave<BOXES, PRIM>(A->r, W, c.env0);
+      pass = c.auto_reset;
+      hint = load_rows<SOLVER, true>(A->s, c, W, env, false);
+    }
+    step_wave<SOLVER, 0, CONE, BOXES, SELF, PRIM, true>(A->s, c, W, pass, lift, hint);
+    publish_fence(); /* state rows are in this XCD's L2, the observation row has been written through */
+    if (lane_id() == 0) add_pub(MB.steps_done + env, 1);
+    wave_barrier();
+    played++;
+  }
+  if (lane_id() == 0 && played) add_pub(MB.status + 2, played);
+}
+
+/* the built-in policy of the closed-loop rollout: lane = env (strided), joint-space PD on the published observation rows */
+__global__ void __launch_bounds__(GQ_WAVE) policy_pd_kernel(const MailboxDev* __restrict__ MBp, const PolicyPdDev P, const float* __restrict__ obs, const int od) {
+  const GQ_MODEL MailboxDev& MB = *mptr(MBp);
+  const int g = (int)blockIdx.x * GQ_WAVE + (int)threadIdx.x, G = (int)gridDim.x * GQ_WAVE;
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(MB.alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int N = MB.n_envs, K = MB.n_steps, nq = MB.nq, qmask = MB.qcap - 1;
+  long long t_last = wall_clock64();
+  for (;;) {
+    bool all_done = true, progress = false;
+    for (int e = g; e < N; e += G) {
+      const int k = MB.issued[e];
+      if (k >= K) continue;
+      all_done = false;
+      if (ld_pub(MB.steps_done + e) < k) continue; /* the observation after step k - 1 is not out yet */
+      /* (the observation words are read AFTER the count has been seen: loads of one batch may be served in any order) */
+      const float* row = obs + (size_t)e * od;
+      float qj[12], qd[12];
+#pragma unroll
+      for (int j = 0; j < 12; j++) { qj[j] = ld_pub(row + P.col_q[j]); qd[j] = ld_pub(row + P.col_qd[j]); }
+      /* the action row and the push ticket travel together */
+      const int xq = e % nq;
+      const int s = add_pub(MB.q_ctr + (size_t)(2 * xq + 1) * GQ_MB_QSTRIDE, 1);
+#pragma unroll
+      for (int j = 0; j < 12; j++) {
+        const float a = pd_law(P.kp[j], P.kd[j], P.qdes[j], qj[j], qd[j]);
+        st_pub(MB.act + (size_t)e * 12 + j, a);
+        if (MB.act_seq) MB.act_seq[((size_t)k * N + e) * 12 + j] = a;
+      }
+      publish_fence();
+      st_pub(MB.q_items + (size_t)xq * MB.qcap + (s & qmask), e + 1); /* third: the item - after the action is in place */
+      MB.issued[e] = k + 1;
+      progress = true;
+    }
+    if (all_done) break;
+    if (progress) { t_last = wall_clock64(); continue; }
+    nap();
+    if (ld_pub(MB.status) != 0) break;
+    if (wall_clock64() - t_last > MB.timeout_ticks) { st_pub(MB.status + 1, g); st_pub(MB.status, 2); break; }
+  }
+}
+
+/* which XCDs does this device expose?  bit HW_REG_XCC_ID of *mask is set by every workgroup */
+__global__ void xcc_probe_kernel(int32_t* mask) {
+  if (threadIdx.x == 0) atomicOr(mask, 1 << xcc_id());
 }
 
 template <bool BOXES>
@@ -326,6 +455,30 @@ extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall
   }
 #undef GQ_LAUNCH_MODE
 #undef GQ_LAUNCH
+}
+extern "C" void gq_launch_xcc_probe(int32_t* mask, hipStream_t stream) {
+  hipLaunchKernelGGL(gq::xcc_probe_kernel, dim3(4096), dim3(GQ_WAVE), 0, stream, mask);
+}
+extern "C" void gq_launch_policy_pd(const gq::MailboxDev* mb, const gq::PolicyPdDev* pd, const float* obs, int od, int waves, hipStream_t stream) {
+  hipLaunchKernelGGL(gq::policy_pd_kernel, dim3(waves), dim3(GQ_WAVE), 0, stream, mb, *pd, obs, od);
+}
+/* returns 0 if the scene / solver combination has no mailbox variant compiled in */
+extern "C" int gq_launch_mailbox_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, const gq::MailboxDev* mb, int waves, int solver, int cone, int boxes, int self, hipStream_t stream) {
+#ifdef GQ_DEV_ONLY
+  if (!(solver == 1 && !boxes && self && cone == (GQ_DEV_ONLY != 0))) return 0;
+#endif
+  if (solver != 1) return 0;
+#define GQ_MB_LAUNCH(C, B, SF, P) hipLaunchKernelGGL((gq::mailbox_step_kernel<1, C, B, SF, P>), dim3(waves), dim3(GQ_WAVE), 0, stream, dev_args, *c, mb)
+#ifdef GQ_DEV_ONLY
+  GQ_MB_LAUNCH((GQ_DEV_ONLY != 0), false, true, true);
+#else
+#define GQ_MB_SCENE(C) do { if (boxes == 2) GQ_MB_LAUNCH(C, true, true, true); else if (boxes) GQ_MB_LAUNCH(C, true, true, false); \
+                            else if (self) GQ_MB_LAUNCH(C, false, true, true); else GQ_MB_LAUNCH(C, false, false, true); } while (0)
+  if (cone) GQ_MB_SCENE(true); else GQ_MB_SCENE(false);
+#undef GQ_MB_SCENE
+#endif
+#undef GQ_MB_LAUNCH
+  return 1;
 }
 extern "C" void gq_launch_jac(const GqDevModel* model, const double* qpos, int body, const double* point, float* jacp, float* jacr, int n_envs, hipStream_t stream) {
   hipLaunchKernelGGL(gq::jac_kernel, dim3(n_envs), dim3(GQ_WAVE), 0, stream, model, qpos, body, point, jacp, jacr);

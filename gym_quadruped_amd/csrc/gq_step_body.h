@@ -338,7 +338,7 @@ __device__ inline void resample_wave(const StepArgs& a, const int env) {
  * with its own look at the pending-reset flag; nothing loaded here stays in a register (an in-kernel respawn overwrites the rows
  * and simply calls this again).  qfrc_applied waits in W.smooth (the actuation block adds the rest to it), the clock in
  * W.force[0] (free until the solver).  user_ctrl: the caller's actions (pass 0); resets step with zero control. */
-template <int SOLVER>
+template <int SOLVER, bool PUB = false> /* PUB: the control row is a mailbox another wavefront wrote while this kernel runs (ld_pub) */
 __device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call, WaveMem& W, const int env, const bool user_ctrl) {
   const int lane = lane_id();
   double q = 0.0;
@@ -350,7 +350,10 @@ __device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call
     wm = gptr(a.warm)[(size_t)env * 18 + lane];
     ap = a.applied ? gptr(a.applied)[(size_t)env * 18 + lane] : 0.0f;
   }
-  if (lane < 12) ct = (call.ctrl && user_ctrl) ? gptr(call.ctrl)[(size_t)env * 12 + lane] : 0.0f;
+  if (lane < 12) {
+    if constexpr (PUB) ct = (call.ctrl && user_ctrl) ? ld_pub(call.ctrl + (size_t)env * 12 + lane) : 0.0f;
+    else ct = (call.ctrl && user_ctrl) ? gptr(call.ctrl)[(size_t)env * 12 + lane] : 0.0f;
+  }
   if (lane < 4) cm = a.cmd ? gptr(a.cmd)[(size_t)env * 4 + lane] : 0.0f;
   if (lane == 0) {
     mu = a.friction ? gptr(a.friction)[env] : -1.0f;
@@ -384,7 +387,8 @@ __device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call
  * PRIM (BOXES variants): the robot has sphere / capsule / box link geoms, whose contacts with world boxes and with each other
  * come from the exact pair routines (gq_pairs.h); robots of hulls only get the variant without that code - merely compiled
  * in, it cost them 17 % (registers spilled across the box loop). */
-template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF, bool PRIM>
+template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF, bool PRIM, bool PUB = false> /* PUB: the observation row is published to a
+                                                                                                   * concurrently running reader (st_pub) */
 __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift, const int hint) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
@@ -686,7 +690,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     const int vres = (CONE && need > 1) ? need - 1 : 0;
     /* <= 42 items x 4 contacts x 6 rows: the three running sums stay inside their bit fields (8 / 10 / 10 bits) */
     const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
-    const int excl = wave_incl_scan(packed) - packed;
+    const int incl = wave_incl_scan(packed);
+    const int excl = incl - packed;
     const int idx0 = excl & 0xff, rows0 = m.nfl + nl + ((excl >> 8) & 0x3ff), res0 = (excl >> 18) & 0x3ff;
     const float mu_env = W.mu_env;
     const float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0];
@@ -716,6 +721,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       }
     }
     const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8)), 63);
+    if (lane == GQ_WAVE - 1) W.ndrop = (incl & 0xff) - (tot & 0xff); /* lane 63's inclusive sum = every touching candidate of the floor pass */
     if (lane == 0) {
       W.ncon = tot & 0xff; W.nlim = nl; W.nefc = m.nfl + nl + (tot >> 8); W.invalid = invalid;
       W.foot_touch = ftm;
@@ -1298,11 +1304,16 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
         gptr(a.invalid_contact)[env] = 0; gptr(a.terminated)[env] = 0; gptr(a.truncated)[env] = 0;
       }
       if (a.pending) gptr(a.pending)[env] = (uint8_t)(pass == 0 ? terminated : 0);
+      if (a.contacts_dropped) gptr(a.contacts_dropped)[env] = W.ndrop;
       gptr(a.reward)[env] = 0.0f;
       if (pass != 0 && a.friction && a.friction_next) gptr(const_cast<float*>(a.friction))[env] = gptr(a.friction_next)[env];
     }
   }
   /* the contact row (gq_batch_set_outputs): mjData.contact[] with mj_contactForce, lane = contact */
+  static_assert(GQ_CON_MAX == GQ_MAXCON, "a contact row holds GQ_CON_MAX records: one per solver contact");
+  static_assert(GQ_DYN_MB == GQ_DYN_MC + sizeof(WaveMem::Mc) / 4 && GQ_DYN_BIAS == GQ_DYN_MB + sizeof(WaveMem::Mb) / 4 && GQ_DYN_XPOS == GQ_DYN_BIAS + GQ_NVD &&
+                GQ_DYN_XMAT == GQ_DYN_XPOS + sizeof(WaveMem::xpos) / 4 && GQ_DYN_FOOT == GQ_DYN_XMAT + sizeof(WaveMem::xmat) / 4 &&
+                GQ_DYN_STRIDE >= GQ_DYN_FOOT + sizeof(WaveMem::foot_world) / 4, "dynamics-row offsets follow the WaveMem field sizes");
   if (a.contacts && rec_pass) { /* wave-uniform */
     GQ_GLOBAL float* Cn = gptr(a.contacts) + (size_t)env * GQ_CON_STRIDE;
     if (lane == 0) { Cn[0] = (float)ncon; Cn[1] = (float)nefc; Cn[2] = (float)iter; }
@@ -1345,7 +1356,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       const int k = lane + GQ_WAVE * i;
       if (k < od) {
         const float val = ob[omap[i]];
-        gptr(a.obs)[(size_t)env * od + k] = val;
+        if constexpr (PUB) st_pub(a.obs + (size_t)env * od + k, val);
+        else gptr(a.obs)[(size_t)env * od + k] = val;
         if (call.obs_seq) gptr(call.obs_seq)[(size_t)env * od + k] = val; /* persistent rollout: the step's own row of the sequence */
       }
     }

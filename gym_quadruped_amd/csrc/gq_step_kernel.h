@@ -49,6 +49,7 @@ struct StepArgs {
   uint8_t* lift_failed;   /* [N] out: the reset RuntimeError condition (:387-388), written by the step that performs a lift; may be NULL */
   const uint8_t* lift_pending; /* library scratch [N] written by reset_kernel (see ResetArgs), read by first-pass steps; may be NULL */
   int32_t* step_prev;     /* [N] step counter before this step's increment (info['step_num']), may be NULL */
+  int32_t* contacts_dropped; /* [N] contacts of this step's narrow phase that did not fit the 12-contact / 63-row capacity, may be NULL */
   int32_t* h9;            /* [N][6] resampling counters {after_vel, before_vel, n_vel, after_dist, before_dist, n_dist}, may be NULL */
   float* ext_dist;        /* [N][6] current disturbance wrench, may be NULL */
   float* dyn;             /* [N][GQ_DYN_STRIDE] dynamics rows (gq_batch_set_outputs), may be NULL */
@@ -71,8 +72,40 @@ struct StepCall {
   int32_t ctrl_stride;  /* floats between the control rows of consecutive steps */
   float* obs_seq;
   int32_t count;        /* envs of this launch: wavefronts past env0 + count (the last workgroup of a multi-wave launch) return at once */
+  /* closed loop INSIDE the persistent rollout (gq_rollout_closed, inline mode): the wavefront derives the action of its env's next
+   * step from the observation row it has just written (PolicyPdDev below, device memory); controls are then not read from ctrl */
+  const struct PolicyPdDev* policy;
+  float* act_seq;       /* [n_steps][N][12] every action taken, or NULL */
   int32_t stop_stage;   /* profiling aid (env GQ_STOP_STAGE, tools/stage_insts.sh): return after stage marker i; 0 = run everything */
 };
+
+/* ---- closed-loop persistent rollout (gq_rollout_closed): env-steps are TASKS.  A policy - a kernel of its own on a second stream,
+ * or anything else that follows the protocol - turns the observation an env published after step k - 1 into the action of step k,
+ * writes it into the env's action mailbox and pushes the env onto a ready queue; the wavefronts of ONE persistent step launch pop
+ * ready envs, play one step each (QuadrupedEnv.step() semantics per env, next-step auto-reset included), publish the observation
+ * row and the env's step count, and pop again.  No env waits for another env's Newton tail or for a launch boundary, any number of
+ * envs works with any number of resident wavefronts, and nothing can deadlock: every wait has a deadline that raises the abort word.
+ * One queue per XCD: an env is always stepped by wavefronts of the same XCD, so its state rows stay coherent in that XCD's L2 and
+ * only the mailbox words (actions, observation rows, sequence numbers, queue slots) travel with device-coherent accesses. */
+#define GQ_MB_QSTRIDE 32  /* int32 words between two queue counters: a 128-byte line each */
+struct MailboxDev {
+  float* act;             /* [N][12] action mailbox: written by the policy, read by the wavefront that plays the env's next step */
+  int32_t* steps_done;    /* [N] steps the env has completed in this rollout: published AFTER its observation row */
+  int32_t* issued;        /* [N] actions the built-in policy has issued per env (its private scratch) */
+  int32_t* q_items;       /* [nq][qcap] ring of env + 1 (0: empty slot); qcap is a power of two >= N, an env is queued at most once */
+  int32_t* q_ctr;         /* [nq][2][GQ_MB_QSTRIDE]: pop tickets, push tickets */
+  int32_t* status;        /* [8] word 0: abort code (0 running / fine, 1 a step wavefront waited past the deadline, 2 the policy did),
+                           * word 1: the ticket / policy lane that gave up, word 2: env-steps played */
+  int32_t* alive;         /* pinned host word: policy workgroups that are resident (the host waits for it before the step launch) */
+  float* act_seq;         /* [K][N][12] every action taken, or NULL */
+  float* obs_seq;         /* [K][N][obs_dim] every observation row, or NULL */
+  int32_t n_envs, n_steps, qcap, nq;
+  int32_t xcc_queue[16];  /* HW_REG_XCC_ID -> queue */
+  int64_t timeout_ticks;  /* deadline of every wait, 100 MHz ticks */
+};
+/* built-in policy: joint-space PD towards a posture, torque_j = kp_j (q_des_j - q_j) - kd_j qd_j (rounded after every operation,
+ * like the elementwise torch expression); col_*: columns of the joint angles / velocities in the observation row */
+struct PolicyPdDev { float kp[12], kd[12], qdes[12]; int32_t col_q[12], col_qd[12]; };
 
 /* canonical ALL_OBS scalar offsets (order of QuadrupedEnv.ALL_OBS, quadruped_env.py:35-66,81) */
 enum {
@@ -125,6 +158,7 @@ struct WaveMem {
   int32_t ncon, nefc, nlim, invalid;
   int32_t nself;               /* number of robot-robot contacts in the list (S6, BOXES variants) */
   int32_t foot_touch;          /* bit k: foot k's body touches a world geom (also when the contact fell to the row budget) */
+  int32_t ndrop;               /* contacts found by the narrow phase that the 12-contact / 63-row capacity cut (S6; info["contacts_dropped"]) */
   int32_t con_geom[GQ_MAXCON], con_body[GQ_MAXCON], con_dim[GQ_MAXCON], con_row[GQ_MAXCON];
   float con_dist[GQ_MAXCON], con_pos[GQ_MAXCON][3], con_mu[GQ_MAXCON], con_inc[GQ_MAXCON];
   float con_solref[GQ_MAXCON][2], con_solimp[GQ_MAXCON][5];

@@ -43,8 +43,10 @@ def _make_info(env):
     """``info`` dict of ``step``: 'time', 'step_num' (value before this step's increment, as the reference reports
     it, quadruped_env.py:288-290) and 'invalid_contacts' (bool mask instead of a dict of MjContact objects).  A plain
     dict of persistent tensors: 'step_num' is refreshed in place by every step / reset, so ``get``, ``items``, ``**info``
-    and copies all see it."""
-    return {'time': env._time, 'step_num': env._step_num_prev, 'invalid_contacts': env._invalid_b}
+    and copies all see it.  'contacts_dropped' has no reference counterpart: the number of contacts the narrow phase found in the
+    step that did not enter the constraint set because the env was at the kernel's capacity (12 contacts / 63 rows; MuJoCo's
+    mj_step has no such cap) - 0 on every env means the batch saw all its contacts."""
+    return {'time': env._time, 'step_num': env._step_num_prev, 'invalid_contacts': env._invalid_b, 'contacts_dropped': env._contacts_dropped}
 
 
 class QuadrupedEnv(AccessorsMixin):
@@ -173,6 +175,7 @@ class QuadrupedEnv(AccessorsMixin):
         self._invalid_b = self._invalid.view(torch.bool)
         self._step_num = torch.zeros(N, dtype=torch.int32, device=dev)
         self._step_num_prev = torch.zeros(N, dtype=torch.int32, device=dev)   # info['step_num'], written by the kernel
+        self._contacts_dropped = torch.zeros(N, dtype=torch.int32, device=dev)  # info['contacts_dropped'], written by the kernel
         self._lift_failed = torch.zeros(N, dtype=torch.uint8, device=dev)
         self._mask_all = torch.ones(N, dtype=torch.uint8, device=dev)
         # in-episode resampling state (reference :292-305), advanced by the step kernel's epilogue:
@@ -205,7 +208,7 @@ class QuadrupedEnv(AccessorsMixin):
                            self._applied.data_ptr(), self._time.data_ptr(), self._friction.data_ptr(), self._cmd.data_ptr())
         self._out = GqObsOut(self._obs_buf.data_ptr(), self._reward.data_ptr(), self._terminated.data_ptr(),
                              self._truncated.data_ptr(), self._invalid.data_ptr(), self._step_num.data_ptr(),
-                             self._step_num_prev.data_ptr())
+                             self._step_num_prev.data_ptr(), self._contacts_dropped.data_ptr())
         # accessors=True: the production kernel also writes the dynamics row (mj_fullM, qfrc_bias, body poses, foot points) and
         # the contact row (mjData.contact + mj_contactForce) of every step - what the reference's model-based-control getters
         # read from mjData (accessors.py); no instrumented kernel variant involved
@@ -335,6 +338,61 @@ class QuadrupedEnv(AccessorsMixin):
             for _ in range(K):
                 sensor.step()
         return self._obs_views
+
+    def rollout_closed_loop(self, n_steps: int, kp, kd, q_des=None, *, mode: str = 'inline', record_obs: bool = False, record_actions: bool = False,
+                            policy_waves: int = 0, step_waves: int = 0, timeout_s: float = 5.0, check: bool = True):
+        """``n_steps`` steps of every env with a joint-space PD policy IN the loop and no launch boundary (``gq_rollout_closed``):
+        the device-side form of ``for k: a = kp * (q_des - obs['qpos_js']) - kd * obs['qvel_js']; obs, ... = env.step(a)``
+        (the reference's control loop, README.md:31-33, around quadruped_env.py:251-307).  Env-steps are tasks: a policy kernel on
+        a second stream turns each published observation row into the env's next action and queues the env; the wavefronts of
+        one persistent step launch pop ready envs, step them (next-step auto-reset included) and publish the result.  An env
+        waits for ITS action only - never for the slowest env of a step - so the throughput is that of the open-loop
+        persistent rollout, with the loop closed.  State, flags and observations afterwards equal the step loop's with the same
+        actions, bit for bit.
+
+        mode 'mailbox': the policy is a kernel of its own on a second stream, actions and observations travel through per-env
+        mailboxes and per-XCD ready queues - the general mechanism (any resident policy kernel can take that seat); 'inline': the
+        wavefront that steps an env evaluates the PD law itself - no turn-around latency, the faster form when there are no more
+        envs than wavefront slots (4096 on an MI355X).  Both leave the same bits.
+
+        kp, kd: scalars or 12 values (hinge order of ``qpos[7:]``); q_des: 12 joint angles (default: keyframe 0).
+        Returns a dict with the last observation views under 'obs' and, when asked, 'obs_seq' ``[K, N, obs_dim]`` /
+        'actions' ``[K, N, 12]``.  ``check``: wait for the rollout and raise ``GqError`` if a participant gave up waiting
+        (deadline ``timeout_s`` per wait) instead of leaving that to the caller."""
+        from .cabi import GqPolicyPd
+        K = int(n_steps)
+        if K < 0:
+            raise ValueError('n_steps must be >= 0')
+        qd = self._key_qpos[7:19].float().cpu().numpy() if q_des is None else np.asarray(q_des, dtype=np.float32).reshape(12)
+        pd = GqPolicyPd()
+        pd.kp = (C.c_float * 12)(*np.broadcast_to(np.asarray(kp, dtype=np.float32), (12,)))
+        pd.kd = (C.c_float * 12)(*np.broadcast_to(np.asarray(kd, dtype=np.float32), (12,)))
+        pd.q_des = (C.c_float * 12)(*[float(v) for v in qd])
+        f32 = dict(dtype=torch.float32, device=self.device)
+        obs_seq = torch.empty(K, self.num_envs, self._obs_dim, **f32) if record_obs else None
+        act_seq = torch.empty(K, self.num_envs, self.mjModel.nu, **f32) if record_actions else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if mode not in ('inline', 'mailbox'):
+            raise ValueError("mode must be 'inline' or 'mailbox'")
+        _lib.check(self._L.gq_rollout_closed(self._hbatch, K, int(mode == 'inline'), C.byref(pd), int(policy_waves), int(step_waves), float(timeout_s), self._st, self._out,
+                                             self._auto_cfg, self._episode.data_ptr(), self._lift_failed.data_ptr(),
+                                             None if obs_seq is None else obs_seq.data_ptr(), None if act_seq is None else act_seq.data_ptr(), stream),
+                   'gq_rollout_closed')
+        self._launches += K
+        if check:
+            self.closed_loop_status()
+        for sensor in self.sensors:
+            for _ in range(K):
+                sensor.step()
+        return {'obs': self._obs_views, 'obs_seq': obs_seq, 'actions': act_seq}
+
+    def closed_loop_status(self):
+        """Wait for the last ``rollout_closed_loop`` and return (abort code, detail, env-steps played); raises ``GqError`` if it
+        was aborted (a wait passed its deadline: missing / stuck policy, or the policy kernel could not become resident)."""
+        st = (C.c_int32 * 4)()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._L.gq_rollout_closed_status(self._hbatch, st, stream), 'gq_rollout_closed')
+        return int(st[0]), int(st[1]), int(st[2])
 
     def reset(self, qpos=None, qvel=None, seed: int | None = None, random: bool = True,
               options: dict[str, Any] | None = None, env_ids=None):

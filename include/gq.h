@@ -57,8 +57,9 @@ extern "C" {
 /* ABI revision of this header.  gq_version() returns the revision the LIBRARY was built from: a binding compares the two
  * before its first call (gym_quadruped_amd/_lib.py does), and gq_struct_sizes() lets it check its own mirror of every struct
  * that crosses the boundary.  History: 100 round 1; 300 = GqModelDesc.struct_size + the self-collision / geom_type tables,
- * GqObsOut.step_num_prev, strided HeightMap views, the round-3 entry points. */
-#define GQ_ABI_VERSION 300
+ * GqObsOut.step_num_prev, strided HeightMap views, the round-3 entry points; 400 = the closed-loop persistent rollout
+ * (gq_rollout_closed, gq_mailbox_get), GqObsOut.contacts_dropped. */
+#define GQ_ABI_VERSION 400
 
 typedef struct GqModelDesc {
   int32_t struct_size; /* = sizeof(GqModelDesc) of the caller's header; gq_model_create refuses any other value */
@@ -222,6 +223,9 @@ typedef struct GqObsOut {
   uint8_t* invalid_contact;/* [N]   info['invalid_contacts'] non-empty (:1228-1248)                 */
   int32_t* step_num;       /* [N]   in/out                                                          */
   int32_t* step_num_prev;  /* [N]   out, may be NULL: the counter BEFORE this step's increment = info['step_num'] (:288-290) */
+  int32_t* contacts_dropped;/* [N]  out, may be NULL: contacts the narrow phase found this step that did NOT enter the constraint set
+                            * because the env was at the kernel's capacity (12 contacts / 63 rows; MuJoCo's mj_step, :271, has no
+                            * such cap) - 0 means the step saw every contact                                                   */
 } GqObsOut;
 
 /* observable ids = index into QuadrupedEnv.ALL_OBS (quadruped_env.py:35-66,81) */
@@ -340,6 +344,50 @@ int gq_step_range(GqBatch* b, int env0, int count, const float* ctrl, GqState st
  * launch boundaries at all, so no env ever waits for the slowest env of a step (needs next-step auto-reset or none). */
 int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqState st, GqObsOut out, const GqResetCfg* auto_reset,
                int32_t* episode, uint8_t* lift_failed, float* obs_seq, void* hip_stream);
+/* CLOSED-LOOP persistent rollout: n_steps steps of every env with a policy in the loop and no launch boundary - the form of
+ * `for k: action = policy(obs); obs, ... = env.step(action)` (quadruped_env.py:251-307 called from a control loop, README.md:31-33)
+ * in which env e's step k + 1 waits for env e's action only, never for the slowest env of step k.  Env-steps are tasks:
+ *   policy side   for each env e, for k = 0 .. n_steps - 1:  wait until steps_done[e] >= k (the observation row of e after k steps
+ *                 is in GqObsOut.obs, written through to device-coherent memory); write the 12 torques to action[e][0..12);
+ *                 then push e onto ready queue  e % n_queues:  s = atomic_add(counters[(2 q + 1) * counter_stride], 1);
+ *                 items[q * queue_capacity + (s & (queue_capacity - 1))] = e + 1   (device-scope stores, the item last);
+ *   step side     the wavefronts of ONE launch pop tickets from the queue of their XCD, play one QuadrupedEnv.step() of the popped
+ *                 env each (mj_step, observation / termination epilogue, next-step auto-reset exactly as gq_step), publish the
+ *                 observation row and steps_done[e] = k + 1, and pop again until all N * n_steps env-steps are claimed.
+ * Any number of envs works with any number of resident wavefronts (an env is not bound to a wavefront), and every wait has a
+ * deadline: when it passes, status[0] becomes non-zero, every participant leaves, and gq_rollout_closed_status reports it - a
+ * missing or stuck policy is an error, not a hang.  The final state and flags are those of n_steps gq_step calls with the same
+ * actions, bit for bit.
+ * pd != NULL: the library runs its built-in policy kernel (joint-space PD: torque_j = kp_j (q_des_j - q_j) - kd_j qd_j on the
+ * qpos_js / qvel_js - or qpos / qvel - columns of the observation row, every operation rounded like the elementwise expression)
+ * on a stream of its own, `policy_waves` wavefronts (0: default), launched BEFORE the step kernel and awaited until resident.
+ * pd == NULL: the caller provides the policy side (gq_mailbox_get gives the device pointers) and must have it running.
+ * mode GQ_CLOSED_INLINE: the built-in policy is evaluated by the wavefront that steps the env, right where the observation row is
+ * written (the persistent kernel of gq_rollout(shards = 0) with the action derived instead of read): the turn-around of an action
+ * is zero instead of two trips through device memory, which matters when there are no more envs than wavefront slots - every env
+ * then waits out its own policy latency (measured at 4096 envs: DESIGN.md).  Mailbox mode is the general mechanism: any policy
+ * that can run as a resident kernel; its latency hides behind other envs' steps once there are more envs than slots.
+ * step_waves: workgroups of the step launch (0 = one per env; more than the device can hold at once is harmless).
+ * obs_seq / act_seq: device [K][N][obs_dim] / [K][N][12] f32 records of every observation row / action, or NULL.
+ * Needs the Newton solver, next-step auto-reset (or none) and the production kernel (no inspection record / stage cut).
+ * Asynchronous on hip_stream except for one synchronisation at the start (mailbox reset, policy residency). */
+typedef struct GqPolicyPd { float kp[12], kd[12], q_des[12]; } GqPolicyPd; /* hinge order of qpos[7:] */
+typedef struct GqMailboxView {
+  float* action;            /* device [N][12] */
+  int32_t* steps_done;      /* device [N] */
+  int32_t* queue_items;     /* device [n_queues][queue_capacity] */
+  int32_t* queue_counters;  /* device [n_queues][2][counter_stride]: pop tickets, push tickets */
+  int32_t* status;          /* device [8]: word 0 abort code */
+  int32_t n_queues, queue_capacity, counter_stride;
+} GqMailboxView;
+#define GQ_CLOSED_MAILBOX 0 /* policy = a kernel of its own (built-in PD on a second stream, or the caller's), ready queues */
+#define GQ_CLOSED_INLINE 1  /* the stepping wavefront evaluates the built-in policy itself: no mailbox traffic, no policy kernel */
+int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, int policy_waves, int step_waves, double timeout_s, GqState st, GqObsOut out,
+                      const GqResetCfg* auto_reset, int32_t* episode, uint8_t* lift_failed, float* obs_seq, float* act_seq, void* hip_stream);
+/* waits for hip_stream, then out[0] = abort code (0 = the rollout ran to its end), out[1] = who gave up, out[2] = env-steps played;
+ * returns GQ_EDEVICE with a message when the rollout was aborted */
+int gq_rollout_closed_status(GqBatch* b, int32_t out[4], void* hip_stream);
+int gq_mailbox_get(GqBatch* b, GqMailboxView* out);
 /* upload the device-resident argument block for (st, out, auto_reset, episode, lift_failed) if it changed; no launch */
 int gq_batch_bind(GqBatch* b, GqState st, GqObsOut out, const GqResetCfg* auto_reset, int32_t* episode, uint8_t* lift_failed,
                   void* hip_stream);

@@ -63,7 +63,7 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
       bool respawn = call.auto_reset == 2 && f.s.pending[e];
       const bool boxes = M.nbox > 0 || M.hf_nrow > 0, self = M.nsp > 0;
       bool prims = false; /* as gq_api.hip scene_variant: the PRIM variants serve robots with sphere / capsule / box link geoms */
-      for (int i = 4; i < 4 + M.nlg; i++) prims = prims || M.item[i].ptype == 2 || M.item[i].ptype == 3 || M.item[i].ptype == 6;
+      for (int g = 0; g < M.nlg; g++) prims = prims || M.lg[g].ptype == 2 || M.lg[g].ptype == 3 || M.lg[g].ptype == 6;
       int lift = (call.first_pass && lift_pending) ? (int)lift_pending[e] : 0;
       int hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, pass == 0) : gq::load_rows<0>(f.s, call, W, e, pass == 0);
       for (;;) {

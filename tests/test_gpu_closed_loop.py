@@ -1,0 +1,107 @@
+"""GPU tests of the closed-loop persistent rollout (include/gq.h gq_rollout_closed, QuadrupedEnv.rollout_closed_loop): the
+control loop `a = policy(obs); obs, ... = env.step(a)` around quadruped_env.py:251-307 (README.md:31-33) played without launch
+boundaries - env-steps as tasks, a policy kernel on a second stream, per-XCD ready queues.
+
+* the states, flags and observation rows afterwards equal those of the plain step loop fed with the SAME actions, bit for bit -
+  also when there are four times more envs than the device has wavefront slots (an env is not bound to a wavefront);
+* the recorded actions are the PD law applied to the recorded observations, bit for bit (the loop really is closed);
+* a rollout whose policy never answers ends with an error after the deadline - it does not hang - and the batch stays usable.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+STATE = ('_qpos', '_qvel', '_qacc', '_warm', '_time', '_step_num', '_episode', '_cmd', '_terminated', '_truncated', '_invalid', '_obs_buf', '_friction',
+         '_contacts_dropped')
+
+
+def _env(robot='mini_cheetah', n=4096, scene='flat', **kw):
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    kw.setdefault('state_obs_names', ('qpos_js', 'qvel_js', 'base_lin_vel', 'contact_forces'))
+    return QuadrupedEnv(robot, scene=scene, num_envs=n, device='cuda:0', solver='newton', auto_reset='next_step', **kw)
+
+
+def _twin(robot, n, scene='flat', warm=30, **kw):
+    a, b = _env(robot, n, scene, seed=11, **kw), _env(robot, n, scene, seed=11, **kw)
+    a.reset(random=True); b.reset(random=True)
+    g = torch.Generator(device='cuda:0').manual_seed(2)
+    for _ in range(warm):   # some envs are on the ground, some about to re-spawn
+        act = torch.randn(n, 12, generator=g, device='cuda:0') * 40
+        a.step(act); b.step(act)
+    torch.cuda.synchronize()
+    for k in STATE:
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    return a, b
+
+
+@pytest.mark.parametrize('mode', ['mailbox', 'inline'])
+@pytest.mark.parametrize('robot,scene,n,K', [('mini_cheetah', 'flat', 4096, 120), ('mini_cheetah', 'flat', 16384, 24), ('go2', 'flat', 1000, 60),
+                                              ('aliengo', 'random_boxes', 777, 40)])
+def test_closed_loop_rollout_equals_the_step_loop_with_the_same_actions(robot, scene, n, K, mode):
+    a, b = _twin(robot, n, scene)
+    kp, kd = 25.0, 0.8
+    r = b.rollout_closed_loop(K, kp, kd, mode=mode, record_obs=True, record_actions=True)
+    code, _, played = b.closed_loop_status()
+    assert code == 0 and (mode == 'inline' or played == n * K)
+    acts = r['actions']
+    rows = []
+    for k in range(K):
+        a.step(acts[k])
+        rows.append(a._obs_buf.clone())
+    torch.cuda.synchronize()
+    for k in STATE:
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert torch.equal(torch.stack(rows), r['obs_seq'])
+    assert torch.isfinite(b.qpos).all()
+    assert int(b._episode.max()) > 1, 'the rollout must contain auto-resets'
+    # the loop is closed: action k is the PD law on the observation after step k - 1 (k = 0: the row the rollout started from is gone,
+    # so the check starts at 1), each operation rounded as in the elementwise expression
+    qd = torch.as_tensor(np.asarray(b.mjModel.key_qpos[0][7:19], dtype=np.float32), device='cuda:0')
+    o = r['obs_seq']
+    q, v = o[:-1, :, 0:12], o[:-1, :, 12:24]
+    want = kp * (qd - q) - kd * v
+    assert torch.equal(want, acts[1:])   # (an env that re-spawns in step k ignores its action - next-step auto-reset - but it is derived and recorded)
+    # and the batch is an ordinary batch afterwards
+    a.step(acts[0]); b.step(acts[0])
+    torch.cuda.synchronize()
+    assert torch.equal(a._qpos, b._qpos) and torch.equal(a._obs_buf, b._obs_buf)
+
+
+def test_closed_loop_rollout_with_a_silent_policy_fails_loudly_and_leaves_the_batch_usable():
+    """pd = NULL: the caller promises to run the policy side itself.  Nobody does here: every step wavefront waits for a queue item
+    that never comes, the deadline (0.3 s) passes, the abort word goes up, the launch ends, and the status call reports it."""
+    from gym_quadruped_amd import _lib
+    env = _env('mini_cheetah', 4096)
+    env.reset(random=True)
+    before = env._qpos.clone()
+    stream = torch.cuda.current_stream(env.device).cuda_stream
+    import time
+    t0 = time.perf_counter()
+    _lib.check(env._L.gq_rollout_closed(env._hbatch, 10, 0, None, 0, 0, 0.3, env._st, env._out, env._auto_cfg, env._episode.data_ptr(), env._lift_failed.data_ptr(),
+                                        None, None, stream), 'gq_rollout_closed')
+    with pytest.raises(_lib.GqError, match='aborted'):
+        env.closed_loop_status()
+    assert time.perf_counter() - t0 < 20.0
+    assert torch.equal(before, env._qpos), 'no env was stepped'
+    # a proper closed-loop rollout and a plain step still work on the same batch
+    env.rollout_closed_loop(5, 20.0, 0.5)
+    env.step(torch.zeros(4096, 12, device='cuda:0'))
+    torch.cuda.synchronize()
+    assert torch.isfinite(env.qpos).all() and int(env._step_num.max()) >= 6
+
+
+def test_closed_loop_rollout_refuses_what_it_cannot_do():
+    from gym_quadruped_amd import _lib
+    env = _env('mini_cheetah', 64, state_obs_names=('base_pos',))   # no joint observables in the row: the PD policy has nothing to read
+    env.reset(random=True)
+    with pytest.raises(_lib.GqError, match='qpos_js'):
+        env.rollout_closed_loop(3, 20.0, 0.5)
+    env2 = _env('mini_cheetah', 64)
+    env2.reset(random=True)
+    env2.enable_debug(8)
+    with pytest.raises(_lib.GqError, match='production kernel'):
+        env2.rollout_closed_loop(3, 20.0, 0.5)
