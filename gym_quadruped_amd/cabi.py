@@ -83,12 +83,13 @@ class GqObsOut(C.Structure):
 
 
 class GqPolicyPd(C.Structure):
-    _fields_ = [('kp', C.c_float * 12), ('kd', C.c_float * 12), ('q_des', C.c_float * 12)]
+    _fields_ = [('kp', C.c_float * 12), ('kd', C.c_float * 12), ('q_des', C.c_float * 12), ('noise_sigma', C.c_float), ('noise_seed', C.c_uint64),
+                ('noise_step0', C.c_int32)]
 
 
 class GqMailboxView(C.Structure):
     _fields_ = [('action', C.c_void_p), ('steps_done', C.c_void_p), ('queue_items', C.c_void_p), ('queue_counters', C.c_void_p), ('status', C.c_void_p),
-                ('n_queues', C.c_int32), ('queue_capacity', C.c_int32), ('counter_stride', C.c_int32)]
+                ('n_queues', C.c_int32), ('queue_capacity', C.c_int32), ('counter_stride', C.c_int32), ('xcc_queue', C.c_int32 * 16)]
 
 
 class GqResampleCfg(C.Structure):

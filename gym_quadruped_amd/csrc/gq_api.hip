@@ -465,9 +465,9 @@ static int mailbox_setup(GqBatch* b) {
   h.nq = nq; h.qcap = qcap; h.n_envs = N;
   HIP_TRY(hipMalloc(&h.act, sizeof(float) * 12 * (size_t)N));
   HIP_TRY(hipMalloc(&h.steps_done, sizeof(int32_t) * (size_t)N));
-  HIP_TRY(hipMalloc(&h.issued, sizeof(int32_t) * (size_t)N));
+  HIP_TRY(hipMalloc(&h.issued, sizeof(int32_t) * 2 * (size_t)N)); /* + N words of the XCD census experiment */
   HIP_TRY(hipMalloc(&h.q_items, sizeof(int32_t) * (size_t)nq * qcap));
-  HIP_TRY(hipMalloc(&h.q_ctr, sizeof(int32_t) * (size_t)nq * 2 * GQ_MB_QSTRIDE));
+  HIP_TRY(hipMalloc(&h.q_ctr, sizeof(int32_t) * (size_t)nq * 3 * GQ_MB_QSTRIDE));
   HIP_TRY(hipMalloc(&h.status, sizeof(int32_t) * 8));
   HIP_TRY(hipMemset(h.status, 0, sizeof(int32_t) * 8));
   HIP_TRY(hipMalloc(&b->mb.dev, sizeof(gq::MailboxDev)));
@@ -483,6 +483,15 @@ static int mailbox_setup(GqBatch* b) {
   return GQ_OK;
 }
 
+/* experiment hook (not declared in gq.h): copy the XCD census words of the last closed rollout to the host */
+int gq_mailbox_census(GqBatch* b, int32_t* out_host) {
+  if (!b || !b->mb.ready) return GQ_EINVAL;
+  DeviceGuard guard(b->model->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out_host, b->mb.host.issued + b->host.n_envs, sizeof(int32_t) * (size_t)b->host.n_envs, hipMemcpyDeviceToHost));
+  return GQ_OK;
+}
+
 int gq_mailbox_get(GqBatch* b, GqMailboxView* out) {
   if (!b || !out) { SET_ERR("gq_mailbox_get: null argument"); return GQ_EINVAL; }
   DeviceGuard guard(b->model->device);
@@ -491,6 +500,7 @@ int gq_mailbox_get(GqBatch* b, GqMailboxView* out) {
   const gq::MailboxDev& h = b->mb.host;
   out->action = h.act; out->steps_done = h.steps_done; out->queue_items = h.q_items; out->queue_counters = h.q_ctr; out->status = h.status;
   out->n_queues = h.nq; out->queue_capacity = h.qcap; out->counter_stride = GQ_MB_QSTRIDE;
+  for (int x = 0; x < 16; x++) out->xcc_queue[x] = h.xcc_queue[x];
   return GQ_OK;
 }
 
@@ -523,13 +533,17 @@ int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, i
     }
     if (policy_waves <= 0) policy_waves = 64; /* lane = env: 4096 envs get a lane each */
     if (policy_waves > 256) policy_waves = 256;
-  }
-  if (mode == GQ_CLOSED_INLINE) {
-    /* the persistent rollout kernel with the policy evaluated by the stepping wavefront itself: no mailbox, no second kernel */
+    if (policy_waves < 2 * h.nq) policy_waves = 2 * h.nq; /* every XCD needs policy wavefronts of its own (dispatch is round-robin over the XCDs) */
+    P.sigma = pd->noise_sigma; P.seed_lo = (uint32_t)(pd->noise_seed & 0xffffffffu); P.seed_hi = (uint32_t)(pd->noise_seed >> 32);
+    P.step0 = pd->noise_step0; P.env_id_offset = auto_reset ? auto_reset->env_id_offset : 0;
+    /* the parameter block lives in device memory for both modes */
     if (b->staging_next == GQ_ARG_SLOTS) { HIP_TRY(hipStreamSynchronize(stream)); b->staging_next = 0; }
     gq::PolicyPdDev* slot = reinterpret_cast<gq::PolicyPdDev*>(b->staging + b->staging_next++); /* a pinned staging slot of the argument ring */
     std::memcpy(slot, &P, sizeof P);
     HIP_TRY(hipMemcpyAsync(b->mb.policy_dev, slot, sizeof P, hipMemcpyHostToDevice, stream));
+  }
+  if (mode == GQ_CLOSED_INLINE) {
+    /* the persistent rollout kernel with the policy evaluated by the stepping wavefront itself: no mailbox, no second kernel */
     HIP_TRY(hipMemsetAsync(h.status, 0, sizeof(int32_t) * 8, stream));
     gq::StepCall ci{};
     ci.n_steps = n_steps; ci.obs_seq = obs_seq; ci.act_seq = act_seq; ci.policy = b->mb.policy_dev;
@@ -541,11 +555,12 @@ int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, i
   if (step_waves <= 0 || step_waves > N) step_waves = N; /* more workgroups than free slots is harmless: the late ones find the queues drained */
   h.n_steps = n_steps; h.obs_seq = obs_seq; h.act_seq = act_seq;
   h.timeout_ticks = (int64_t)((timeout_s > 0.0 ? timeout_s : 5.0) * 1e8);
+  { const char* fl = getenv("GQ_MB_FLAGS"); h.flags = fl ? atoi(fl) : 0; }
   /* fresh rollout state, ordered on the caller's stream */
   HIP_TRY(hipMemsetAsync(h.steps_done, 0, sizeof(int32_t) * (size_t)N, stream));
-  HIP_TRY(hipMemsetAsync(h.issued, 0, sizeof(int32_t) * (size_t)N, stream));
+  HIP_TRY(hipMemsetAsync(h.issued, 0, sizeof(int32_t) * 2 * (size_t)N, stream));
   HIP_TRY(hipMemsetAsync(h.q_items, 0, sizeof(int32_t) * (size_t)h.nq * h.qcap, stream));
-  HIP_TRY(hipMemsetAsync(h.q_ctr, 0, sizeof(int32_t) * (size_t)h.nq * 2 * GQ_MB_QSTRIDE, stream));
+  HIP_TRY(hipMemsetAsync(h.q_ctr, 0, sizeof(int32_t) * (size_t)h.nq * 3 * GQ_MB_QSTRIDE, stream));
   HIP_TRY(hipMemsetAsync(h.status, 0, sizeof(int32_t) * 8, stream));
   HIP_TRY(hipStreamSynchronize(stream)); /* the pinned staging block below is reused per call; a rollout is thousands of launches' worth of work */
   std::memcpy(b->mb.staging, &h, sizeof h);
@@ -559,7 +574,7 @@ int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, i
     *b->mb.alive = 0;
     HIP_TRY(hipEventRecord(b->mb.fork, stream));
     HIP_TRY(hipStreamWaitEvent(b->mb.stream, b->mb.fork, 0));
-    gq_launch_policy_pd(b->mb.dev, &P, out.obs, od, policy_waves, b->mb.stream);
+    gq_launch_policy_pd(b->mb.dev, b->mb.policy_dev, out.obs, od, policy_waves, b->mb.stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->mb.join, b->mb.stream));
     const auto t0 = std::chrono::steady_clock::now();
@@ -589,7 +604,7 @@ int gq_rollout_closed_status(GqBatch* b, int32_t out[4], void* hip_stream) {
   HIP_TRY(hipMemcpyAsync(b->mb.status_host, b->mb.host.status, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
   for (int i = 0; i < 4; i++) out[i] = b->mb.status_host[i];
-  if (out[0] != 0) { SET_ERR("closed-loop rollout aborted: code %d (1: a step wavefront waited past the deadline for ticket %d; 2: policy lane %d waited past the deadline; 3: policy not resident), %d env-steps were played", out[0], out[1], out[1], out[2]); return GQ_EDEVICE; }
+  if (out[0] != 0) { SET_ERR("closed-loop rollout aborted: code %d (1: a step wavefront waited past the deadline for ticket %d; 2: policy lane %d waited past the deadline; 3: policy not resident; 4: no policy wavefront on XCD queue %d), %d env-steps were played", out[0], out[1], out[1], out[1], out[2]); return GQ_EDEVICE; }
   return GQ_OK;
 }
 

@@ -873,7 +873,11 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
       wave_barrier();
     }
   }
-  if constexpr (SELF) append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre);
+  if constexpr (SELF) {
+    (void)pre;
+    const SelfPrefetch pre_now = self_prefetch(m); /* not prefetched in front of the box loop: it would sit in registers (or scratch) across it */
+    append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre_now);
+  }
   if (lane == 0) {
     W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself; W.ndrop += S.ndrop;
     W.foot_touch = S.ft;

@@ -158,16 +158,26 @@ __device__ __forceinline__ void st_pub(int32_t* p, int v) { __hip_atomic_store(p
 __device__ __forceinline__ void st_pub(float* p, float v) {
   __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+/* a load of per-env state that another wavefront may have written earlier in THIS launch (closed-loop rollout: an env changes hands between
+ * wavefronts, i.e. between CUs): device scope makes it miss the CU's vector L1, which holds whatever the CU read when it last handled the env
+ * or one of the envs sharing the line - gfx950 has no instruction that drops the L1 alone when a workgroup sits on one CU (buffer_inv sc0
+ * is a no-op there; buffer_inv sc1 also empties the XCD's L2: -14 %).  PUB false: a plain global load. */
+template <bool PUB, class T> __device__ __forceinline__ T ldv(const T* p) {
+  if constexpr (PUB) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *(const GQ_GLOBAL T*)p;
+}
 __device__ __forceinline__ int add_pub(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void publish_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* compiler: no store sinks below */
   __builtin_amdgcn_s_waitcnt(0x0F70);                    /* vmcnt(0): every store of this wave has reached its L2 / memory */
 }
 /* an env of the closed-loop rollout changes hands between wavefronts of ONE XCD (per-XCD ready queues): its rows are coherent in
- * that XCD's L2; what a new owner must drop is its CU's vector L1 (write-through, not snooped) and the scalar cache */
+ * that XCD's L2; what a new owner must not use is its CU's vector L1 (write-through, not snooped) and the scalar cache */
 __device__ __forceinline__ void adopt_fence() {
-  asm volatile("buffer_inv sc0" ::: "memory");
+  /* the vector L1 is NOT dropped here (see ldv): every load of the adopted env's mutable rows is a device-scope load.  Scalar cache: no
+   * per-env word is read through it today (the compiler only scalarises loads nothing in the kernel can clobber), invalidated anyway */
   __builtin_amdgcn_s_dcache_inv();
+  __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): the invalidate has completed */
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF); } /* HW_REG_XCC_ID */

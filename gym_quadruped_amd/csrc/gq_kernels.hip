@@ -20,6 +20,17 @@ __device__ __forceinline__ float pd_law(float kp, float kd, float qdes, float q,
   const float ud = kd * qd;
   return up - ud;
 }
+/* the built-in policy's action for joint j of env `gid` at step `k` of the rollout: the PD law + exploration noise */
+__device__ __forceinline__ float pd_action(const GQ_MODEL PolicyPdDev& P, const int j, const float q, const float qd, const int k, const uint32_t gid) {
+#pragma clang fp contract(off)
+  float u = pd_law(P.kp[j], P.kd[j], P.qdes[j], q, qd);
+  if (P.sigma > 0.0f) {
+    const float z = philox_normal((uint32_t)j, (uint32_t)(P.step0 + k), gid, 0x9011u, P.seed_lo, P.seed_hi);
+    const float nz = P.sigma * z;
+    u = u + nz;
+  }
+  return u;
+}
 /* inline mode of the closed-loop rollout: lanes 0-11 turn the observation row this wavefront published at the end of its previous
  * step (global memory, the batch's own layout) into the control of the step that starts now; replaces what load_rows left in W.ctrl */
 __device__ __forceinline__ void pd_inline(const GQ_MODEL PolicyPdDev& P, const StepArgs& a, const StepCall& c, WaveMem& W, const int env, const int kstep,
@@ -28,7 +39,7 @@ __device__ __forceinline__ void pd_inline(const GQ_MODEL PolicyPdDev& P, const S
   if (lane < 12) {
     const int od = mptr(a.batch)->obs_dim;
     const GQ_GLOBAL float* row = gptr(a.obs) + (size_t)env * od;
-    const float u = pd_law(P.kp[lane], P.kd[lane], P.qdes[lane], row[P.col_q[lane]], row[P.col_qd[lane]]);
+    const float u = pd_action(P, lane, row[P.col_q[lane]], row[P.col_qd[lane]], kstep, (uint32_t)(env + P.env_id_offset));
     if (apply) W.ctrl[lane] = u;
     if (c.act_seq) gptr(c.act_seq)[((size_t)kstep * a.n_envs + env) * 12 + lane] = u;
   }
@@ -90,7 +101,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
   const int q = MB.xcc_queue[xcc_id()];
   const int N = MB.n_envs, nq = MB.nq, qmask = MB.qcap - 1;
   const int total = ((N - q + nq - 1) / nq) * MB.n_steps; /* env-steps that will ever pass through this queue */
-  int32_t* const head = MB.q_ctr + (size_t)(2 * q) * GQ_MB_QSTRIDE;
+  int32_t* const head = MB.q_ctr + (size_t)(3 * q) * GQ_MB_QSTRIDE;
   int32_t* const items = MB.q_items + (size_t)q * MB.qcap;
   int played = 0;
   for (;;) {
@@ -113,6 +124,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
     if (lane_id() == 0) st_pub(slot, 0); /* the slot is free for the push that comes qcap tickets later */
     const int env = item - 1;
     adopt_fence();
+    if (MB.flags & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     /* the env's step index is only needed to place the row in obs_seq: otherwise that round trip is not taken */
     const int k = MB.obs_seq ? __builtin_amdgcn_readfirstlane(ld_pub(MB.steps_done + env)) : 0;
     StepCall ck = c0;
@@ -121,17 +133,19 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
     ck.obs_seq = MB.obs_seq ? MB.obs_seq + (size_t)k * N * mptr(A->s.batch)->obs_dim : nullptr;
     const StepCall& c = ck;
     int pass = 0, lift = 0;
-    bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[env]; /* wave-uniform */
+    bool respawn = c.auto_reset == 2 && ldv<true>(A->s.pending + env); /* wave-uniform */
+    if ((MB.flags & 32) && lane_id() == 0) add_pub(MB.issued + N + env, 1 << (4 * xcc_id())); /* experiment: which XCDs ever stepped this env (nibble counters, <= 15 steps) */
     int hint = load_rows<SOLVER, true>(A->s, c, W, env, true);
     if (respawn) {
       wave_priority(3);
       wave_barrier();
-      lift = reset_wave<BOXES, PRIM>(A->r, W, c.env0);
+      lift = reset_wave<BOXES, PRIM, true>(A->r, W, c.env0);
       pass = c.auto_reset;
       hint = load_rows<SOLVER, true>(A->s, c, W, env, false);
     }
     step_wave<SOLVER, 0, CONE, BOXES, SELF, PRIM, true>(A->s, c, W, pass, lift, hint);
     publish_fence(); /* state rows are in this XCD's L2, the observation row has been written through */
+    if (MB.flags & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane_id() == 0) add_pub(MB.steps_done + env, 1);
     wave_barrier();
     played++;
@@ -139,36 +153,63 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
   if (lane_id() == 0 && played) add_pub(MB.status + 2, played);
 }
 
-/* the built-in policy of the closed-loop rollout: lane = env (strided), joint-space PD on the published observation rows */
-__global__ void __launch_bounds__(GQ_WAVE) policy_pd_kernel(const MailboxDev* __restrict__ MBp, const PolicyPdDev P, const float* __restrict__ obs, const int od) {
+/* the built-in policy of the closed-loop rollout.  A policy wavefront serves envs of ITS XCD's queue only (lane = env, strided over the
+ * policy wavefronts that landed on the XCD): observation row, action row, count and queue slot of an env are written and read
+ * through one L2, like the env's state rows - no hand-off of the rollout depends on coherence between two XCDs' L2s, and none
+ * needs a device-scope fence (a device-scope acquire on the stepping side costs 14 % of the throughput: it empties the XCD's L2). */
+__global__ void __launch_bounds__(GQ_WAVE) policy_pd_kernel(const MailboxDev* __restrict__ MBp, const PolicyPdDev* __restrict__ Pp, const float* __restrict__ obs, const int od) {
   const GQ_MODEL MailboxDev& MB = *mptr(MBp);
-  const int g = (int)blockIdx.x * GQ_WAVE + (int)threadIdx.x, G = (int)gridDim.x * GQ_WAVE;
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(MB.alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const int N = MB.n_envs, K = MB.n_steps, nq = MB.nq, qmask = MB.qcap - 1;
+  const GQ_MODEL PolicyPdDev& P = *mptr(Pp);
+  const int lane = (int)threadIdx.x, nq = MB.nq, q = MB.xcc_queue[xcc_id()], qmask = MB.qcap - 1;
+  const int N = MB.n_envs, K = MB.n_steps, P_all = (int)gridDim.x;
+  int rank = 0;
+  if (lane == 0) rank = add_pub(MB.q_ctr + (size_t)(3 * q + 2) * GQ_MB_QSTRIDE, 1);
+  rank = __builtin_amdgcn_readfirstlane(rank);
+  if (lane == 0) __hip_atomic_fetch_add(MB.alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   long long t_last = wall_clock64();
+  int mine = 0;
+  for (;;) { /* every policy wavefront has said where it runs: the stride of this XCD is known */
+    int sum = 0;
+    for (int x = 0; x < nq; x++) { const int c = ld_pub(MB.q_ctr + (size_t)(3 * x + 2) * GQ_MB_QSTRIDE); sum += c; if (x == q) mine = c; }
+    if (sum >= P_all) {
+      for (int x = 0; x < nq; x++)
+        if (ld_pub(MB.q_ctr + (size_t)(3 * x + 2) * GQ_MB_QSTRIDE) == 0) { if (lane == 0) { st_pub(MB.status + 1, x); st_pub(MB.status, 4); } return; } /* an XCD without policy */
+      break;
+    }
+    nap();
+    if (ld_pub(MB.status) != 0) return;
+    if (wall_clock64() - t_last > MB.timeout_ticks) { if (lane == 0) { st_pub(MB.status + 1, -1 - rank); st_pub(MB.status, 2); } return; }
+  }
+  const int nmine = (N - q + nq - 1) / nq;           /* envs of this queue: e = q + nq * i */
+  const int g = rank * GQ_WAVE + lane, G = mine * GQ_WAVE;
+  int32_t* const tail = MB.q_ctr + (size_t)(3 * q + 1) * GQ_MB_QSTRIDE;
+  int32_t* const items = MB.q_items + (size_t)q * MB.qcap;
+  t_last = wall_clock64();
   for (;;) {
     bool all_done = true, progress = false;
-    for (int e = g; e < N; e += G) {
+    for (int i = g; i < nmine; i += G) {
+      const int e = q + nq * i;
       const int k = MB.issued[e];
       if (k >= K) continue;
       all_done = false;
       if (ld_pub(MB.steps_done + e) < k) continue; /* the observation after step k - 1 is not out yet */
+      if (MB.flags & 8) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       /* (the observation words are read AFTER the count has been seen: loads of one batch may be served in any order) */
       const float* row = obs + (size_t)e * od;
       float qj[12], qd[12];
 #pragma unroll
       for (int j = 0; j < 12; j++) { qj[j] = ld_pub(row + P.col_q[j]); qd[j] = ld_pub(row + P.col_qd[j]); }
       /* the action row and the push ticket travel together */
-      const int xq = e % nq;
-      const int s = add_pub(MB.q_ctr + (size_t)(2 * xq + 1) * GQ_MB_QSTRIDE, 1);
+      const int s = add_pub(tail, 1);
 #pragma unroll
       for (int j = 0; j < 12; j++) {
-        const float a = pd_law(P.kp[j], P.kd[j], P.qdes[j], qj[j], qd[j]);
+        const float a = pd_action(P, j, qj[j], qd[j], k, (uint32_t)(e + P.env_id_offset));
         st_pub(MB.act + (size_t)e * 12 + j, a);
         if (MB.act_seq) MB.act_seq[((size_t)k * N + e) * 12 + j] = a;
       }
       publish_fence();
-      st_pub(MB.q_items + (size_t)xq * MB.qcap + (s & qmask), e + 1); /* third: the item - after the action is in place */
+      if (MB.flags & 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      st_pub(items + (s & qmask), e + 1); /* the item - after the action is in place */
       MB.issued[e] = k + 1;
       progress = true;
     }
@@ -460,7 +501,7 @@ extern "C" void gq_launch_xcc_probe(int32_t* mask, hipStream_t stream) {
   hipLaunchKernelGGL(gq::xcc_probe_kernel, dim3(4096), dim3(GQ_WAVE), 0, stream, mask);
 }
 extern "C" void gq_launch_policy_pd(const gq::MailboxDev* mb, const gq::PolicyPdDev* pd, const float* obs, int od, int waves, hipStream_t stream) {
-  hipLaunchKernelGGL(gq::policy_pd_kernel, dim3(waves), dim3(GQ_WAVE), 0, stream, mb, *pd, obs, od);
+  hipLaunchKernelGGL(gq::policy_pd_kernel, dim3(waves), dim3(GQ_WAVE), 0, stream, mb, pd, obs, od);
 }
 /* returns 0 if the scene / solver combination has no mailbox variant compiled in */
 extern "C" int gq_launch_mailbox_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, const gq::MailboxDev* mb, int waves, int solver, int cone, int boxes, int self, hipStream_t stream) {

@@ -285,15 +285,16 @@ __device__ inline void floor_candidates(const WaveMem& W, const ItemRegs& G, Flo
 /* _sample_ref_vel (quadruped_env.py:1046-1072) and _sample_external_disturbances (:1074-1139) for the wave's env when their
  * step countdowns run out (:292-305).  Counter-based draws: Philox block (b, n, global env id, 0xc0de | 0xd157), n = number
  * of redraws so far; uniform = (word >> 8) 2^-24; np.random.randint(1000, 3000) = 1000 + floor(2000 u). */
+template <bool PUB = false>
 __device__ inline void resample_wave(const StepArgs& a, const int env) {
   const int lane = lane_id();
   const GQ_MODEL GqDevBatch& B = *mptr(a.batch);
   GQ_GLOBAL int32_t* hc = gptr(a.h9) + (size_t)env * 6;
   const uint32_t gid = (uint32_t)(env + B.rs_env_id_offset);
   if (B.rs_cmd_reset) {
-    const int after = hc[0] + 1, before = hc[1]; /* wave-uniform */
+    const int after = ldv<PUB>(a.h9 + (size_t)env * 6 + 0) + 1, before = ldv<PUB>(a.h9 + (size_t)env * 6 + 1); /* wave-uniform */
     if (after >= before) {
-      const int n = hc[2];
+      const int n = ldv<PUB>(a.h9 + (size_t)env * 6 + 2);
       float u = 0.0f;
       if (lane < 4) u = (float)(philox4x32(0u, (uint32_t)n, gid, 0xc0deu, B.rs_seed_lo, B.rs_seed_hi, lane) >> 8) * (1.0f / 16777216.0f);
       const float u_norm = bcast(u, 0), u_head = bcast(u, 1), u_yaw = bcast(u, 2), u_int = bcast(u, 3);
@@ -314,11 +315,11 @@ __device__ inline void resample_wave(const StepArgs& a, const int env) {
     } else if (lane == 0) hc[0] = after;
   }
   if (B.rs_dist_reset && a.ext_dist) {
-    const int after = hc[3] + 1, before = hc[4];
+    const int after = ldv<PUB>(a.h9 + (size_t)env * 6 + 3) + 1, before = ldv<PUB>(a.h9 + (size_t)env * 6 + 4);
     GQ_GLOBAL float* ed = gptr(a.ext_dist) + (size_t)env * 6;
-    float val = lane < 6 ? ed[lane] : 0.0f;
+    float val = lane < 6 ? ldv<PUB>(a.ext_dist + (size_t)env * 6 + lane) : 0.0f;
     if (after >= before) {
-      const int n = hc[5];
+      const int n = ldv<PUB>(a.h9 + (size_t)env * 6 + 5);
       float u = 0.0f;
       if (lane < 8) u = (float)(philox4x32((uint32_t)(lane >> 2), (uint32_t)n, gid, 0xd157u, B.rs_seed_lo, B.rs_seed_hi, lane & 3) >> 8) * (1.0f / 16777216.0f);
       if (lane < 6) {
@@ -344,23 +345,23 @@ __device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call
   double q = 0.0;
   float qv = 0.0f, wm = 0.0f, ap = 0.0f, ct = 0.0f, cm = 0.0f, mu = -1.0f, tm = 0.0f;
   int sn = 0, hint = 0;
-  if (lane < 19) q = gptr(a.qpos)[(size_t)env * 19 + lane];
+  if (lane < 19) q = ldv<PUB>(a.qpos + (size_t)env * 19 + lane);
   if (lane < 18) {
-    qv = gptr(a.qvel)[(size_t)env * 18 + lane];
-    wm = gptr(a.warm)[(size_t)env * 18 + lane];
-    ap = a.applied ? gptr(a.applied)[(size_t)env * 18 + lane] : 0.0f;
+    qv = ldv<PUB>(a.qvel + (size_t)env * 18 + lane);
+    wm = ldv<PUB>(a.warm + (size_t)env * 18 + lane);
+    ap = a.applied ? ldv<PUB>(a.applied + (size_t)env * 18 + lane) : 0.0f;
   }
   if (lane < 12) {
     if constexpr (PUB) ct = (call.ctrl && user_ctrl) ? ld_pub(call.ctrl + (size_t)env * 12 + lane) : 0.0f;
     else ct = (call.ctrl && user_ctrl) ? gptr(call.ctrl)[(size_t)env * 12 + lane] : 0.0f;
   }
-  if (lane < 4) cm = a.cmd ? gptr(a.cmd)[(size_t)env * 4 + lane] : 0.0f;
+  if (lane < 4) cm = a.cmd ? ldv<PUB>(a.cmd + (size_t)env * 4 + lane) : 0.0f;
   if (lane == 0) {
-    mu = a.friction ? gptr(a.friction)[env] : -1.0f;
-    sn = gptr(a.step_num)[env];
-    tm = gptr(a.time)[env];
+    mu = a.friction ? ldv<PUB>(a.friction + env) : -1.0f;
+    sn = ldv<PUB>(a.step_num + env);
+    tm = ldv<PUB>(a.time + env);
   }
-  if (SOLVER == 1 && a.load_hint) hint = (int)gptr(a.load_hint)[env];
+  if (SOLVER == 1 && a.load_hint) hint = (int)ldv<PUB>(a.load_hint + env);
   if (lane < 19) {
     if (lane < 2) W.bxy[lane] = q;
     else if (lane == 2) W.basez = (float)q;
@@ -581,7 +582,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   GQ_TICK(5);
   /* ================================================================ S6: collision with the floor (z = 0) */
   SelfPrefetch self_pre;
-  if constexpr (SELF) self_pre = self_prefetch(m);
+  if constexpr (SELF && !BOXES) self_pre = self_prefetch(m); /* (world-box variants fetch it behind the box loop: 18 registers less across it) */
   stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), false);
   /* reset on a scene without world boxes / height field: the lift loop of QuadrupedEnv.reset (quadruped_env.py:376-388:
    * z += 1.1 max|dist| until no foot-body contact, <= 100 iterations) runs HERE, on the distances this step's own
@@ -1273,7 +1274,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     const GQ_MODEL GqDevBatch& B = *mptr(a.batch);
     float z = 0.0f;
     if (lane < 12) {
-      const uint32_t stepc = (uint32_t)W.step_old, epi = a.episode_ro ? (uint32_t)gptr(a.episode_ro)[env] : 0u;
+      const uint32_t stepc = (uint32_t)W.step_old, epi = a.episode_ro ? (uint32_t)ldv<PUB>(a.episode_ro + env) : 0u;
       z = philox_normal((uint32_t)lane, stepc, (uint32_t)env, 0x1a70u ^ (epi << 8), B.imu_seed_lo, B.imu_seed_hi);
       const int grp = lane / 3;
       z *= grp == 0 ? B.imu_acc_noise : (grp == 1 ? B.imu_acc_bias_rate : (grp == 2 ? B.imu_gyro_noise : B.imu_gyro_bias_rate));
@@ -1283,7 +1284,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     if (lane < 6) { /* lanes 0-2: accelerometer axes, lanes 3-5: gyro axes */
       const int g = lane / 3, ax = lane % 3;
       const float noise = W.warm[6 + 6 * g + ax], dbias = W.warm[6 + 6 * g + 3 + ax];
-      const float bias = gptr(a.imu_bias)[(size_t)env * 6 + lane] + dbias;
+      const float bias = ldv<PUB>(a.imu_bias + (size_t)env * 6 + lane) + dbias;
       gptr(a.imu_bias)[(size_t)env * 6 + lane] = bias;
       const int o = g == 0 ? OB_IMU_ACC : OB_IMU_GYRO;
       ob[o + ax] = W.warm[lane] + bias + noise; ob[o + 3 + ax] = noise; ob[o + 6 + ax] = bias;
@@ -1306,7 +1307,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       if (a.pending) gptr(a.pending)[env] = (uint8_t)(pass == 0 ? terminated : 0);
       if (a.contacts_dropped) gptr(a.contacts_dropped)[env] = W.ndrop;
       gptr(a.reward)[env] = 0.0f;
-      if (pass != 0 && a.friction && a.friction_next) gptr(const_cast<float*>(a.friction))[env] = gptr(a.friction_next)[env];
+      if (pass != 0 && a.friction && a.friction_next) gptr(const_cast<float*>(a.friction))[env] = ldv<PUB>(a.friction_next + env); /* (written by this wave's own reset_wave) */
     }
   }
   /* the contact row (gq_batch_set_outputs): mjData.contact[] with mj_contactForce, lane = contact */
@@ -1364,7 +1365,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   }
   wave_barrier(); /* the obs row overlays u: finish reading it before a second pass reuses the region */
   /* in-episode resampling (quadruped_env.py:292-305): the user's step only; a redraw acts from the next step on */
-  if (pass == 0 && a.h9) resample_wave(a, env);
+  if (pass == 0 && a.h9) resample_wave<PUB>(a, env);
   GQ_TICK(13);
   if constexpr (DBG) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 25] = (float)(wall_clock64() & 0xFFFFF);
 #undef GQ_TICK
@@ -1405,14 +1406,14 @@ enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH =
        RN_YAWDOT = 30, RN_FRICTION = 31, RN_VEL_INTERVAL = 32 };
 
 #define GQ_LIFT_RULE_ITERS 4
-template <bool BOXES, bool PRIM = true>
+template <bool BOXES, bool PRIM = true, bool PUB = false>
 __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 = 0) {
   int lane_o = lane_id(), env_o = wave_index() + uniform(env0);
   opaque(lane_o); opaque_s(env_o); /* see step_wave: no address arithmetic may be hoisted to the kernel prologue */
   const int lane = lane_o, env = env_o;
   const GQ_MODEL GqDevModel& m = *mptr(a.model);
   const ResetCfgDev& c = a.cfg;
-  const int episode = a.episode ? gptr(a.episode)[env] : 0;
+  const int episode = a.episode ? ldv<PUB>(a.episode + env) : 0;
   /* one uniform in [0,1) per lane < 36 (draw table: RN_*) */
   float u = 0.0f;
   if (lane < 36) {

@@ -93,7 +93,7 @@ struct MailboxDev {
   int32_t* steps_done;    /* [N] steps the env has completed in this rollout: published AFTER its observation row */
   int32_t* issued;        /* [N] actions the built-in policy has issued per env (its private scratch) */
   int32_t* q_items;       /* [nq][qcap] ring of env + 1 (0: empty slot); qcap is a power of two >= N, an env is queued at most once */
-  int32_t* q_ctr;         /* [nq][2][GQ_MB_QSTRIDE]: pop tickets, push tickets */
+  int32_t* q_ctr;         /* [nq][3][GQ_MB_QSTRIDE]: pop tickets, push tickets, policy wavefronts registered on the queue's XCD */
   int32_t* status;        /* [8] word 0: abort code (0 running / fine, 1 a step wavefront waited past the deadline, 2 the policy did),
                            * word 1: the ticket / policy lane that gave up, word 2: env-steps played */
   int32_t* alive;         /* pinned host word: policy workgroups that are resident (the host waits for it before the step launch) */
@@ -102,10 +102,17 @@ struct MailboxDev {
   int32_t n_envs, n_steps, qcap, nq;
   int32_t xcc_queue[16];  /* HW_REG_XCC_ID -> queue */
   int64_t timeout_ticks;  /* deadline of every wait, 100 MHz ticks */
+  int32_t flags;          /* experiment switches (env GQ_MB_FLAGS): 1 policy: device-scope release fence before the item store; 2 step: device-scope
+                           * acquire fence after the item; 4 step: release fence before the count; 8 policy: acquire fence after the count */
 };
 /* built-in policy: joint-space PD towards a posture, torque_j = kp_j (q_des_j - q_j) - kd_j qd_j (rounded after every operation,
  * like the elementwise torch expression); col_*: columns of the joint angles / velocities in the observation row */
-struct PolicyPdDev { float kp[12], kd[12], qdes[12]; int32_t col_q[12], col_qd[12]; };
+struct PolicyPdDev {
+  float kp[12], kd[12], qdes[12]; int32_t col_q[12], col_qd[12];
+  /* Gaussian exploration noise added to the law: sigma * N(0, 1) per joint and step, Philox4x32-10 block (joint, step0 + k, global env
+   * id, 0x9011), key = seed (0 sigma: none) */
+  float sigma; uint32_t seed_lo, seed_hi; int32_t step0, env_id_offset;
+};
 
 /* canonical ALL_OBS scalar offsets (order of QuadrupedEnv.ALL_OBS, quadruped_env.py:35-66,81) */
 enum {

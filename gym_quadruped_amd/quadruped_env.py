@@ -340,7 +340,7 @@ class QuadrupedEnv(AccessorsMixin):
         return self._obs_views
 
     def rollout_closed_loop(self, n_steps: int, kp, kd, q_des=None, *, mode: str = 'inline', record_obs: bool = False, record_actions: bool = False,
-                            policy_waves: int = 0, step_waves: int = 0, timeout_s: float = 5.0, check: bool = True):
+                            noise_sigma: float = 0.0, policy_waves: int = 0, step_waves: int = 0, timeout_s: float = 5.0, check: bool = True):
         """``n_steps`` steps of every env with a joint-space PD policy IN the loop and no launch boundary (``gq_rollout_closed``):
         the device-side form of ``for k: a = kp * (q_des - obs['qpos_js']) - kd * obs['qvel_js']; obs, ... = env.step(a)``
         (the reference's control loop, README.md:31-33, around quadruped_env.py:251-307).  Env-steps are tasks: a policy kernel on
@@ -355,7 +355,8 @@ class QuadrupedEnv(AccessorsMixin):
         wavefront that steps an env evaluates the PD law itself - no turn-around latency, the faster form when there are no more
         envs than wavefront slots (4096 on an MI355X).  Both leave the same bits.
 
-        kp, kd: scalars or 12 values (hinge order of ``qpos[7:]``); q_des: 12 joint angles (default: keyframe 0).
+        kp, kd: scalars or 12 values (hinge order of ``qpos[7:]``); q_des: 12 joint angles (default: keyframe 0); noise_sigma:
+        Gaussian exploration noise added to every torque (counter-based draws keyed by the env's seed, the step and the joint).
         Returns a dict with the last observation views under 'obs' and, when asked, 'obs_seq' ``[K, N, obs_dim]`` /
         'actions' ``[K, N, 12]``.  ``check``: wait for the rollout and raise ``GqError`` if a participant gave up waiting
         (deadline ``timeout_s`` per wait) instead of leaving that to the caller."""
@@ -368,6 +369,7 @@ class QuadrupedEnv(AccessorsMixin):
         pd.kp = (C.c_float * 12)(*np.broadcast_to(np.asarray(kp, dtype=np.float32), (12,)))
         pd.kd = (C.c_float * 12)(*np.broadcast_to(np.asarray(kd, dtype=np.float32), (12,)))
         pd.q_des = (C.c_float * 12)(*[float(v) for v in qd])
+        pd.noise_sigma, pd.noise_seed, pd.noise_step0 = float(noise_sigma), int(self._seed or 0) & (2 ** 64 - 1), int(self._launches) & 0x7fffffff
         f32 = dict(dtype=torch.float32, device=self.device)
         obs_seq = torch.empty(K, self.num_envs, self._obs_dim, **f32) if record_obs else None
         act_seq = torch.empty(K, self.num_envs, self.mjModel.nu, **f32) if record_actions else None

@@ -349,7 +349,7 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
  * in which env e's step k + 1 waits for env e's action only, never for the slowest env of step k.  Env-steps are tasks:
  *   policy side   for each env e, for k = 0 .. n_steps - 1:  wait until steps_done[e] >= k (the observation row of e after k steps
  *                 is in GqObsOut.obs, written through to device-coherent memory); write the 12 torques to action[e][0..12);
- *                 then push e onto ready queue  e % n_queues:  s = atomic_add(counters[(2 q + 1) * counter_stride], 1);
+ *                 then push e onto ready queue  e % n_queues:  s = atomic_add(counters[(3 q + 1) * counter_stride], 1);
  *                 items[q * queue_capacity + (s & (queue_capacity - 1))] = e + 1   (device-scope stores, the item last);
  *   step side     the wavefronts of ONE launch pop tickets from the queue of their XCD, play one QuadrupedEnv.step() of the popped
  *                 env each (mj_step, observation / termination epilogue, next-step auto-reset exactly as gq_step), publish the
@@ -361,7 +361,11 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
  * pd != NULL: the library runs its built-in policy kernel (joint-space PD: torque_j = kp_j (q_des_j - q_j) - kd_j qd_j on the
  * qpos_js / qvel_js - or qpos / qvel - columns of the observation row, every operation rounded like the elementwise expression)
  * on a stream of its own, `policy_waves` wavefronts (0: default), launched BEFORE the step kernel and awaited until resident.
- * pd == NULL: the caller provides the policy side (gq_mailbox_get gives the device pointers) and must have it running.
+ * pd == NULL: the caller provides the policy side (gq_mailbox_get gives the device pointers) and must have it running.  XCD rule: the
+ * wavefront that writes env e's action must run on the XCD of queue e % n_queues (GqMailboxView.xcc_queue maps HW_REG_XCC_ID to
+ * queues) - action row, observation row and counters of an env then meet in ONE L2, like the env's state rows, and device-scope
+ * (sc1) accesses + a wait for the stores are all the ordering needed.  A producer on another XCD should be paired with device-scope
+ * fences (environment GQ_MB_FLAGS: 1 release on the policy side, 2 acquire on the stepping side; measured cost of the latter 14 %).
  * mode GQ_CLOSED_INLINE: the built-in policy is evaluated by the wavefront that steps the env, right where the observation row is
  * written (the persistent kernel of gq_rollout(shards = 0) with the action derived instead of read): the turn-around of an action
  * is zero instead of two trips through device memory, which matters when there are no more envs than wavefront slots - every env
@@ -371,14 +375,20 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
  * obs_seq / act_seq: device [K][N][obs_dim] / [K][N][12] f32 records of every observation row / action, or NULL.
  * Needs the Newton solver, next-step auto-reset (or none) and the production kernel (no inspection record / stage cut).
  * Asynchronous on hip_stream except for one synchronisation at the start (mailbox reset, policy residency). */
-typedef struct GqPolicyPd { float kp[12], kd[12], q_des[12]; } GqPolicyPd; /* hinge order of qpos[7:] */
+typedef struct GqPolicyPd {
+  float kp[12], kd[12], q_des[12];   /* hinge order of qpos[7:] */
+  float noise_sigma;                 /* Gaussian exploration noise added to every torque: sigma * N(0, 1); 0 = none */
+  uint64_t noise_seed;               /* Philox4x32-10 key; counter = (joint, noise_step0 + k, global env id, 0x9011), Box-Muller on words 0, 1 */
+  int32_t noise_step0;
+} GqPolicyPd;
 typedef struct GqMailboxView {
   float* action;            /* device [N][12] */
   int32_t* steps_done;      /* device [N] */
   int32_t* queue_items;     /* device [n_queues][queue_capacity] */
-  int32_t* queue_counters;  /* device [n_queues][2][counter_stride]: pop tickets, push tickets */
+  int32_t* queue_counters;  /* device [n_queues][3][counter_stride]: pop tickets, push tickets, (built-in policy's registration count) */
   int32_t* status;          /* device [8]: word 0 abort code */
   int32_t n_queues, queue_capacity, counter_stride;
+  int32_t xcc_queue[16];    /* HW_REG_XCC_ID -> queue: queue q's envs are stepped by wavefronts of that XCD only */
 } GqMailboxView;
 #define GQ_CLOSED_MAILBOX 0 /* policy = a kernel of its own (built-in PD on a second stream, or the caller's), ready queues */
 #define GQ_CLOSED_INLINE 1  /* the stepping wavefront evaluates the built-in policy itself: no mailbox traffic, no policy kernel */

@@ -269,13 +269,47 @@ def oracle_fits_self_budget(o, cone):
     return o.nefc + reserve <= GQ_SELF_ROWS   # = the general budget since the dense step works out of registers
 
 
-def self_contact_states(md, n, rng, o, z=(0.5, 0.9), want_cross=None):
+def within_budget_share(qpos, qvel, o, cone, max_over, rng_order=None):
+    """Indices of a subset of the drawn states in which at most `max_over` (fraction) exceed the kernel's row budget, in draw
+    order: every in-budget state is kept, over-budget ones only while their share allows.  (The kernel keeps a prefix of MuJoCo's
+    constraint list for an over-budget env - checked by ParityTally.check_budget_prefix - but its solution cannot be compared, so a
+    test that draws mostly such states verifies little: VERDICT round 3.)"""
+    fits = []
+    for e in range(len(qpos)):
+        o.set_state(qpos[e], np.asarray(qvel[e], np.float64), np.zeros(18), np.zeros(18), 0.0, 0.8)
+        o.forward(np.zeros(12), stage=1)
+        fits.append(oracle_fits_self_budget(o, cone))
+    fits = np.asarray(fits, bool)
+    return fits
+
+
+def budgeted_states(n, draw, o, cone, max_over=0.08):
+    """n states from draw(k) -> (qpos, qvel) with at most max_over * n of them over the kernel's row budget (by the oracle's
+    own constraint count at the position / velocity stage)."""
+    allow = int(max_over * n)
+    Q, V, over = [], [], 0
+    for _ in range(40):
+        q, v = draw(2 * n)
+        fits = within_budget_share(q, v, o, cone, max_over)
+        for e in range(len(q)):
+            if len(Q) == n:
+                break
+            if fits[e] or over < allow:
+                Q.append(q[e]); V.append(v[e]); over += 0 if fits[e] else 1
+        if len(Q) == n:
+            break
+    assert len(Q) == n, f'only {len(Q)} of {n} states found'
+    return np.stack(Q), np.stack(V)
+
+
+def self_contact_states(md, n, rng, o, z=(0.5, 0.9), want_cross=None, cone=None, max_over=None):
     """Random poses with wide joint excursions (legs folded across each other), kept when the oracle finds a robot-robot
     contact (want_cross: also require / forbid a contact between two different legs)."""
     out_q, out_v = [], []
     leg = lambda b: (b - 2) // 3 if b >= 2 else -1
-    tries = 0
-    while len(out_q) < n and tries < 20000:
+    tries = over = 0
+    allow = n if max_over is None else int(max_over * n)   # over-budget states kept (see budgeted_states)
+    while len(out_q) < n and tries < 60000:
         tries += 1
         q, v = random_states(md, 1, rng, z_range=z)
         q, v = q[0], v[0]
@@ -289,6 +323,10 @@ def self_contact_states(md, n, rng, o, z=(0.5, 0.9), want_cross=None):
         cross = any(x > 0 and leg(x) >= 0 and leg(x) != leg(y) for x, y in zip(b1, b2))
         if want_cross is not None and cross != want_cross:
             continue
+        if max_over is not None and not oracle_fits_self_budget(o, cone):
+            if over >= allow:
+                continue
+            over += 1
         out_q.append(q); out_v.append(v)
     assert len(out_q) == n, f'only {len(out_q)} self-contact states found'
     return np.stack(out_q), np.stack(out_v)

@@ -66,6 +66,7 @@ template <class T> static inline const T* opaque_ptr(const T* p) { return p; }
 static inline int opaque_lane(int l) { return l; }
 template <class T> static inline T* gptr(T* p) { return p; }
 template <class T> static inline const T* mptr(const T* p) { return p; }
+template <bool PUB, class T> static inline T ldv(const T* p) { return *p; }
 static inline int ld_pub(const int32_t* p) { return *p; }
 static inline float ld_pub(const float* p) { return *p; }
 static inline void st_pub(int32_t* p, int v) { *p = v; }

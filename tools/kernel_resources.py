@@ -36,7 +36,7 @@ def main(argv):
             if m:
                 cur = m.group(1); rows[cur] = {}
                 continue
-            m = re.search(r'remark:\s+(\w[\w ]*?)(?: \[bytes/lane\]| \[bytes/workgroup\])?: (\d+)', line)
+            m = re.search(r'remark:\s+([A-Za-z][\w ]*?)(?: \[[\w/]+\])?: (\d+)', line)
             if m and cur:
                 rows[cur][m.group(1).strip()] = int(m.group(2))
         scratch, fn = collections.Counter(), None
@@ -48,8 +48,8 @@ def main(argv):
                 scratch[fn] += 1
     lines = ['| kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | scratch instr. (static) | LDS B | occupancy (waves/SIMD) |', '|---|---|---|---|---|---|---|---|']
     for fn, d in rows.items():
-        lines.append(f"| `{short(fn)}` | {d.get('VGPRs', '?')} | {d.get('AGPRs', '?')} | {d.get('SGPRs', '?')} | {d.get('ScratchSize', '?')} | {scratch.get(fn, 0)} | "
-                     f"{d.get('LDS Size', '?')} | {d.get('Occupancy [waves/SIMD]', d.get('Occupancy', '?'))} |")
+        lines.append(f"| `{short(fn)}` | {d.get('VGPRs', '?')} | {d.get('AGPRs', '?')} | {d.get('TotalSGPRs', '?')} | {d.get('ScratchSize', '?')} | {scratch.get(fn, 0)} | "
+                     f"{d.get('LDS Size', '?')} | {d.get('Occupancy', '?')} |")
     text = ('# Kernel resources as allocated by the compiler (hipcc -Rpass-analysis=kernel-resource-usage, gfx950, product flags)\n\n'
             'step_kernel<SOLVER, MODE, CONE, BOXES, SELF, PRIM, PERSIST>: SOLVER 1 Newton / 0 PGS; MODE 0 production, 1 instrumented, 2 stage cut.\n'
             'mailbox_step_kernel<SOLVER, CONE, BOXES, SELF, PRIM>: the closed-loop persistent rollout.\n\n' + '\n'.join(lines) + '\n')
