@@ -179,6 +179,25 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
     dtp = time.perf_counter() - t1
     out['persistent_rollout'] = {'value': n * reps * 64 / dtp, 'unit': 'env-steps/s', 'ms_per_step': dtp / (reps * 64) * 1e3, 'steps': reps * 64,
                                  'note': 'open-loop: one launch per 64-step action sequence, each wavefront steps its env 64 times without a launch boundary (gq_rollout shards=0); same results as the step loop, bit for bit'}
+    # CLOSED-LOOP persistent rollouts (gq_rollout_closed): a policy in the loop, no launch boundary.  The policy is the library's joint-space
+    # PD law; with Gaussian torque noise of the benchmark's amplitude (sigma 50 N m - an exploring policy) the robots fall and re-spawn as
+    # under the benchmark's random actions, so the figures compare with the headline; without noise the robots stand on four feet - a
+    # different, heavier contact workload (see DESIGN.md section 3 for the like-for-like comparison with the same actions played open loop)
+    K = 512
+    for key, kw in (('closed_loop_inline', dict(mode='inline', noise_sigma=50.0)), ('closed_loop_mailbox', dict(mode='mailbox', noise_sigma=50.0)),
+                    ('closed_loop_inline_standing', dict(mode='inline', noise_sigma=0.0))):
+        env.rollout_closed_loop(256, 25.0, 0.8, **kw)
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        env.rollout_closed_loop(K, 25.0, 0.8, **kw)
+        torch.cuda.synchronize(device)
+        dtc = time.perf_counter() - t2
+        out[key] = {'value': n * K / dtc, 'unit': 'env-steps/s', 'ms_per_step': dtc / K * 1e3, 'steps': K, 'policy': 'joint-space PD kp 25 kd 0.8 towards keyframe 0' +
+                    (', + N(0, 50) torque noise' if kw['noise_sigma'] else ' (robots stand: ~4 feet in contact every step)'),
+                    'mean_feet_in_contact': float(env._obs_views['contact_state'].sum(1).mean()),
+                    'note': {'inline': 'the stepping wavefront evaluates the policy on the observation row it has just written',
+                             'mailbox': 'policy kernel on a second stream; actions / observations through per-env mailboxes, per-XCD ready queues; env-steps are tasks popped by the wavefronts of one persistent launch'}[kw['mode']]
+                            + '; states equal the step loop fed with the same actions bit for bit (tests/test_gpu_closed_loop.py)'}
     out['pipelined_rollout'] = {'value': n * reps * 64 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / (reps * 64) * 1e3, 'steps': reps * 64, 'shards': 2,
                                 'note': 'open-loop: each shard of 2048 envs chains its steps on its own stream (gq_step_range); same kernels and results as the step loop'}
     env.close()
@@ -255,6 +274,9 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if os.environ.get('GQ_BENCH_SHARE_DEVICE') == '1':
             local_rank = 0   # protocol test: all ranks on one GPU (the throughput it prints is NOT a scaling number)
+        if torch.cuda.device_count() < world and os.environ.get('GQ_BENCH_SHARE_DEVICE') != '1':
+            raise SystemExit(f'--gpus {world} needs {world} visible GPUs, this node shows {torch.cuda.device_count()} (GQ_BENCH_SHARE_DEVICE=1 runs the '
+                             f'N-rank protocol on one GPU: a protocol test, not a scaling number)')
         torch.cuda.set_device(local_rank)
         if args.dist_backend == 'nccl':
             dist.init_process_group(backend='nccl', device_id=torch.device(f'cuda:{local_rank}'))

@@ -23,6 +23,9 @@ namespace gq {
 #define GQ_BX_WCLS(W) (reinterpret_cast<int32_t*>(&(W).F[0][32]))   /* [12] world geom of contact c: -1 floor, else box class */
 #define GQ_BX_LGNRM(W) (&(W).F[1][0])                                  /* [GQ_MAXLG][3] normal of the geom's hit on the current box */
 #define GQ_BX_CONNRM(W) (&(W).F[1][3 * GQ_MAXLG])                      /* [12][3] contact normals */
+/* bounding spheres of the link geoms' clouds (item_sphere), [GQ_MAXLG][4]: parked in the (idle until S7) J block behind the region the
+ * kinematics scratch and the self-collision tables use, and re-read per world box - four registers less across the box loop */
+#define GQ_BX_ISPH(W) (&(W).u.B[40][0])
 
 /* sphere of radius r centred at c (box frame) against a box of half extents s: signed distance, outward normal n (box frame) */
 __device__ __forceinline__ float sphere_box(V3 c, V3 s, float r, V3& n) {
@@ -138,7 +141,7 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
   if constexpr (PRIM) {
     if (PL.ptype > 0) {
       V3 nn;
-      prim_near = sphere_box(matTvec(B.mat, PL.pc - bp), bs, PL.rb, nn) < PL.margin + m.boxmix[B.cls][PL.code].margin;
+      prim_near = sphere_box(matTvec(B.mat, ld3(PL.sph) - bp), bs, PL.sph[3], nn) < PL.margin + m.boxmix[B.cls][PL.code].margin;
     }
   }
   H.n = 0;
@@ -240,10 +243,11 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) A[3 * i + j] = Rb[3 * i] * I.mat[j] + Rb[3 * i + 1] * I.mat[3 + j] + Rb[3 * i + 2] * I.mat[6 + j];
-      if (PL.ptype == 6) box_box(bp, Rw, bs, PL.pc, A, v3(I.psize[0], I.psize[1], I.psize[2]), marg, H);
+      const V3 pc = ld3(PL.sph);
+      if (PL.ptype == 6) box_box(bp, Rw, bs, pc, A, v3(I.psize[0], I.psize[1], I.psize[2]), marg, H);
       else {
         const V3 ax = PL.ptype == 3 ? I.psize[1] * v3(A[2], A[5], A[8]) : v3(0.0f, 0.0f, 0.0f);
-        capsule_box(PL.pc - ax, PL.pc + ax, I.psize[0], bp, Rw, bs, marg, H);
+        capsule_box(pc - ax, pc + ax, I.psize[0], bp, Rw, bs, marg, H);
       }
     }
   }
@@ -527,7 +531,8 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
   for (int k = 0; k < NP; k++) {
     if (tk[k]) {
       const int idx = idx0 + j, row0 = rows0 + j * need, res = res0 + (j + 1) * vres;
-      const bool fits = idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
+      /* the list is a PREFIX of MuJoCo's: once a contact has been cut (S.ndrop, wave-uniform), no later one is taken even if it is small enough */
+      const bool fits = S.ndrop == 0 && idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
       if (fits) {
         const GQ_MODEL GqDevMix& X = m.boxmix[cls][code];
         W.con_geom[idx] = code; W.con_body[idx] = body; W.con_dim[idx] = dim; W.con_row[idx] = row0;
@@ -536,7 +541,7 @@ __device__ inline void append_world_contacts(WaveMem& W, const GQ_MODEL GqDevMod
         W.con_solref[idx][0] = X.solref[0]; W.con_solref[idx][1] = X.solref[1];
 #pragma unroll
         for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = X.solimp[q];
-        st3(GQ_BX_CONNRM(W) + 3 * idx, H.nrm[k]);
+        st3(GQ_BX_CONNRM(W) + 3 * idx, hit_nrm(H, k));
         GQ_BX_WCLS(W)[idx] = cls;
         nfit++;
       }
@@ -738,7 +743,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
           capsule_box(ld3(kc), ld3(kc + 3), kc[6], ca, A, ha, marg, H);
           if (kind == 2) { /* normal from the box (item 2) to the capsule (item 1): turn it to run from item 1 to item 2 */
 #pragma unroll
-            for (int k = 0; k < 4; k++) H.nrm[k] = -1.0f * H.nrm[k];
+            for (int k = 0; k < 2; k++) H.nrm[k] = -1.0f * H.nrm[k];
           }
         }
       }
@@ -775,7 +780,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     for (int k = 0; k < NP; k++) {
       if (k < cnt) {
         const int idx = idx0 + k, row0 = rows0 + k * need, res = res0 + (k + 1) * vres;
-        const bool fits = idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
+        const bool fits = S.ndrop == 0 && idx < GQ_MAXCON && row0 + need + res <= (CONE ? 64 : GQ_MAXEFC) && row0 + need <= GQ_MAXEFC;
         if (fits) {
           const int b1 = m.item_body[it1], b2 = m.item_body[it2];
           W.con_geom[idx] = it2 | ((it1 + 1) << 8) | (P.mix.rule << 16); W.con_body[idx] = b2 | ((b1 + 1) << 8); W.con_dim[idx] = dim; W.con_row[idx] = row0;
@@ -784,10 +789,10 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
           W.con_solref[idx][0] = P.mix.solref[0]; W.con_solref[idx][1] = P.mix.solref[1];
 #pragma unroll
           for (int q = 0; q < 5; q++) W.con_solimp[idx][q] = P.mix.solimp[q];
-          st3(GQ_BX_CONNRM(W) + 3 * idx, H.nrm[k]);
+          st3(GQ_BX_CONNRM(W) + 3 * idx, hit_nrm(H, k));
           GQ_BX_WCLS(W)[idx] = GQ_WCLS_SELF;
 #ifdef GQ_EMU_TRACE
-          if (getenv("GQ_EMU_TRACE")) printf("self contact idx %d items %d %d kind %d point %d dist %.6f pos %.5f %.5f %.5f nrm %.5f %.5f %.5f\n", idx, it1, it2, (int)m.sp[p].kind, k, (double)H.dist[k], (double)H.pos[k].x, (double)H.pos[k].y, (double)H.pos[k].z, (double)H.nrm[k].x, (double)H.nrm[k].y, (double)H.nrm[k].z);
+          if (getenv("GQ_EMU_TRACE")) printf("self contact idx %d items %d %d kind %d point %d dist %.6f pos %.5f %.5f %.5f nrm %.5f %.5f %.5f\n", idx, it1, it2, (int)m.sp[p].kind, k, (double)H.dist[k], (double)H.pos[k].x, (double)H.pos[k].y, (double)H.pos[k].z, (double)hit_nrm(H, k).x, (double)hit_nrm(H, k).y, (double)hit_nrm(H, k).z);
 #endif
           nfit++;
         }
@@ -815,10 +820,10 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
 /* S6 for a scene without world boxes / height field but with robot self-collision: general frames for the floor
  * contacts the floor pass left in W, then the robot-robot contacts.  Ends with a barrier. */
 template <bool CONE>
-__device__ inline void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre) {
+__device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre) {
   const int lane = lane_id();
   WorldAppend S;
-  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = 0; S.reserve = 0; S.nself = 0; S.ndrop = 0;
+  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = 0; S.reserve = 0; S.nself = 0; S.ndrop = uniform(W.ndrop);
   const int ncon = S.ncon;
   if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
     st3(GQ_BX_CONNRM(W) + 3 * lane, v3(0.0f, 0.0f, 1.0f));
@@ -827,19 +832,21 @@ __device__ inline void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
   append_self_contacts<CONE>(W, m, mu_env, S, pre);
-  if (lane == 0) { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; W.ndrop += S.ndrop; }
+  if (lane == 0) { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; W.ndrop = S.ndrop; }
   wave_barrier();
 }
 
 /* S6 (BOXES): append the contacts with the world boxes to the list the floor pass left in W (ncon, nefc, invalid,
  * foot_touch are updated; rows / row budget as in the floor pass).  Ends with a barrier. */
+/* (forced inline: out of line - the inliner's choice on some variants - the item record and the prefetch block it takes by reference are
+ * materialised in scratch memory, 200 bytes per lane) */
 template <bool CONE, bool SELF, bool PRIM>
-__device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
+__device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
                                           double bx, double by, float mu_env, const SelfPrefetch& pre, const ItemRegs& IT) {
   const int lane = lane_id();
   const PrimLane PL = prim_lane(W, m, IT, PRIM && lane < 4 + m.nlg, PRIM); /* all the box loop keeps of the item record */
   WorldAppend S;
-  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0; S.ndrop = 0;
+  S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0; S.ndrop = uniform(W.ndrop);
   S.ft = uniform(W.foot_touch) & 15;
   const int ncon = S.ncon;
   if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
@@ -849,9 +856,13 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
   uint64_t cand[2];
-  V3 cg; float rg;
-  item_sphere(W, m, false, cg, rg);
-  box_candidates(W, m, bx, by, 0.0f, cand, cg, rg);
+  {
+    V3 cg; float rg;
+    item_sphere(W, m, false, cg, rg);
+    box_candidates(W, m, bx, by, 0.0f, cand, cg, rg);
+    if (lane < GQ_MAXLG) { st3(GQ_BX_ISPH(W) + 4 * lane, cg); GQ_BX_ISPH(W)[4 * lane + 3] = rg; }
+  }
+  wave_barrier();
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
     uint64_t todo = cand[half];
@@ -859,6 +870,8 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
       const int b = half * GQ_WAVE + ffs64(todo);
       todo &= todo - 1;
       PairHit H;
+      const float* sph = GQ_BX_ISPH(W) + 4 * opaque_lane(lane < GQ_MAXLG ? lane : 0);
+      const V3 cg = ld3(sph); const float rg = sph[3];
       if (!box_item_scan<PRIM>(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, PL, H)) continue;
       append_world_contacts<CONE, PRIM>(W, m, m.box[b].cls, mu_env, H, S);
       wave_barrier();
@@ -866,6 +879,8 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
   }
   if (m.hf_nrow > 0) { /* the scene's height field: one more world geom */
     float dist; V3 nrm, pt;
+    const float* sph = GQ_BX_ISPH(W) + 4 * opaque_lane(lane < GQ_MAXLG ? lane : 0);
+    const V3 cg = ld3(sph); const float rg = sph[3];
     if (hfield_item_scan(W, m, vx, vy, vz, bx, by, 0.0f, cg, rg, dist, nrm, pt)) {
       PairHit H;
       H.n = dist < 1e29f ? 1 : 0; H.dist[0] = dist; H.nrm[0] = nrm; H.pos[0] = pt;
@@ -879,7 +894,7 @@ __device__ inline void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel&
     append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre_now);
   }
   if (lane == 0) {
-    W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself; W.ndrop += S.ndrop;
+    W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself; W.ndrop = S.ndrop;
     W.foot_touch = S.ft;
   }
   wave_barrier();

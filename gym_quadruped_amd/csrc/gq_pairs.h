@@ -13,7 +13,10 @@
 
 namespace gq {
 
-struct PairHit { int n; float dist[4]; V3 pos[4]; V3 nrm[4]; };
+/* (two normals: the <= 2 points of a capsule have one each, the <= 4 of a box-box manifold share nrm[0] - six registers less across the
+ * world-box loop of the step kernel) */
+struct PairHit { int n; float dist[4]; V3 pos[4]; V3 nrm[2]; };
+__device__ __forceinline__ V3 hit_nrm(const PairHit& H, const int k) { return k == 1 ? H.nrm[1] : H.nrm[0]; }
 
 /* the lane's item record (GqDevModel::item), in registers */
 struct ItemRegs {
@@ -43,17 +46,22 @@ __device__ __forceinline__ ItemRegs item_fetch(const GQ_MODEL GqDevModel& m, con
  * box 6; feet, hull clouds and cylinders - two 16-gon rims, 32 vertices - are not), its centre in kernel coordinates and bounding
  * radius.  A handful of registers instead of the whole record: the item's frame and sizes are re-read from the model table
  * in the (rare) exact routine, so that nothing of the record stays live across the box loop. */
-struct PrimLane { int ptype, code; float rb, margin; V3 pc; bool cloud; /* lane = link geom: its contact with a world box comes from the vertex cloud scan */ };
+struct PrimLane { int ptype, code; float margin; bool cloud; /* lane = link geom: its contact with a world box comes from the vertex cloud scan */
+                  const float* sph; /* LDS: the primitive's centre (kernel coordinates) and bounding radius - read per world box instead of riding in four registers */ };
+/* [4 + GQ_MAXLG][4] behind the cloud spheres (GQ_BX_ISPH, gq_boxes.h) in the J block, idle until S7 */
+#define GQ_BX_PSPH(W) (&(W).u.B[49][0])
 __device__ __forceinline__ bool prim_exact(int ptype) { return ptype == 2 || ptype == 3 || ptype == 6; }
-__device__ __forceinline__ PrimLane prim_lane(const WaveMem& W, const GQ_MODEL GqDevModel& m, const ItemRegs& IT, const bool valid, const bool prims) {
+__device__ __forceinline__ PrimLane prim_lane(WaveMem& W, const GQ_MODEL GqDevModel& m, const ItemRegs& IT, const bool valid, const bool prims) {
   PrimLane P;
+  const int lane = lane_id();
   P.cloud = true;
-  if (prims) { const int lane = lane_id(); P.cloud = !prim_exact(m.lg[lane < m.nlg ? lane : 0].ptype); }
+  if (prims) P.cloud = !prim_exact(m.lg[lane < m.nlg ? lane : 0].ptype);
   P.ptype = (valid && prim_exact(IT.ptype)) ? IT.ptype : 0; P.code = IT.code; P.margin = IT.margin;
-  P.pc = v3(0.0f, 0.0f, 0.0f); P.rb = 0.0f;
-  if (P.ptype > 0) {
-    P.pc = ld3(W.xpos[IT.body]) + matvec(W.xmat[IT.body], IT.pos);
-    P.rb = IT.ptype == 6 ? sqrtf(IT.psize[0] * IT.psize[0] + IT.psize[1] * IT.psize[1] + IT.psize[2] * IT.psize[2]) : IT.psize[0] + (IT.ptype == 3 ? IT.psize[1] : 0.0f);
+  float* sph = GQ_BX_PSPH(W) + 4 * (lane < 4 + GQ_MAXLG ? lane : 0);
+  P.sph = sph;
+  if (P.ptype > 0) { /* only this lane reads its slot back: no barrier */
+    st3(sph, ld3(W.xpos[IT.body]) + matvec(W.xmat[IT.body], IT.pos));
+    sph[3] = IT.ptype == 6 ? sqrtf(IT.psize[0] * IT.psize[0] + IT.psize[1] * IT.psize[1] + IT.psize[2] * IT.psize[2]) : IT.psize[0] + (IT.ptype == 3 ? IT.psize[1] : 0.0f);
   }
   return P;
 }
@@ -297,7 +305,8 @@ __device__ inline void box_box(V3 ca, const float* Ra, V3 ha, V3 cb, const float
     else mask &= ~(1 << worst);
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) { H.nrm[k] = bn; H.dist[k] = 0.0f; H.pos[k] = v3(0.0f, 0.0f, 0.0f); }
+  for (int k = 0; k < 4; k++) { H.dist[k] = 0.0f; H.pos[k] = v3(0.0f, 0.0f, 0.0f); }
+  H.nrm[0] = bn; H.nrm[1] = bn;
   int n = 0;
 #pragma unroll 1
   for (; mask != 0; n++) {

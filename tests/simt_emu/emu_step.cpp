@@ -118,12 +118,12 @@ extern "C" int emu_reset(const GqModelDesc* desc, int n_envs, const uint8_t* mas
 extern "C" int emu_capsule_box(const float* p0, const float* p1, float r, const float* bc, const float* bR, const float* bh, float margin, float* out) {
   gq::PairHit H;
   gq::capsule_box(gq::v3(p0[0], p0[1], p0[2]), gq::v3(p1[0], p1[1], p1[2]), r, gq::v3(bc[0], bc[1], bc[2]), bR, gq::v3(bh[0], bh[1], bh[2]), margin, H);
-  for (int q = 0; q < H.n; q++) { out[7 * q] = H.dist[q]; out[7 * q + 1] = H.pos[q].x; out[7 * q + 2] = H.pos[q].y; out[7 * q + 3] = H.pos[q].z; out[7 * q + 4] = H.nrm[q].x; out[7 * q + 5] = H.nrm[q].y; out[7 * q + 6] = H.nrm[q].z; }
+  for (int q = 0; q < H.n; q++) { out[7 * q] = H.dist[q]; out[7 * q + 1] = H.pos[q].x; out[7 * q + 2] = H.pos[q].y; out[7 * q + 3] = H.pos[q].z; out[7 * q + 4] = gq::hit_nrm(H, q).x; out[7 * q + 5] = gq::hit_nrm(H, q).y; out[7 * q + 6] = gq::hit_nrm(H, q).z; }
   return H.n;
 }
 extern "C" int emu_box_box(const float* ca, const float* Ra, const float* ha, const float* cb, const float* Rb, const float* hb, float margin, float* out) {
   gq::PairHit H;
   gq::box_box(gq::v3(ca[0], ca[1], ca[2]), Ra, gq::v3(ha[0], ha[1], ha[2]), gq::v3(cb[0], cb[1], cb[2]), Rb, gq::v3(hb[0], hb[1], hb[2]), margin, H);
-  for (int q = 0; q < H.n; q++) { out[7 * q] = H.dist[q]; out[7 * q + 1] = H.pos[q].x; out[7 * q + 2] = H.pos[q].y; out[7 * q + 3] = H.pos[q].z; out[7 * q + 4] = H.nrm[q].x; out[7 * q + 5] = H.nrm[q].y; out[7 * q + 6] = H.nrm[q].z; }
+  for (int q = 0; q < H.n; q++) { out[7 * q] = H.dist[q]; out[7 * q + 1] = H.pos[q].x; out[7 * q + 2] = H.pos[q].y; out[7 * q + 3] = H.pos[q].z; out[7 * q + 4] = gq::hit_nrm(H, q).x; out[7 * q + 5] = gq::hit_nrm(H, q).y; out[7 * q + 6] = gq::hit_nrm(H, q).z; }
   return H.n;
 }
