@@ -95,8 +95,7 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
  * each pops tickets of ITS XCD's ready queue until every env-step of the rollout has been claimed.  Production Newton variants only. */
 template <int SOLVER, bool CONE, bool BOXES, bool SELF, bool PRIM>
 __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArgs* __restrict__ A, const StepCall c0, const MailboxDev* __restrict__ MBp) {
-  static_assert(GQ_WPB == 1, "one wavefront per workgroup");
-  __shared__ WaveMem W;
+  __shared__ WaveMem W; /* one wavefront per workgroup (the GQ_WPB > 1 experiment builds never launch this kernel) */
   const GQ_MODEL MailboxDev& MB = *mptr(MBp);
   const int q = MB.xcc_queue[xcc_id()];
   const int N = MB.n_envs, nq = MB.nq, qmask = MB.qcap - 1;
@@ -505,6 +504,9 @@ extern "C" void gq_launch_policy_pd(const gq::MailboxDev* mb, const gq::PolicyPd
 }
 /* returns 0 if the scene / solver combination has no mailbox variant compiled in */
 extern "C" int gq_launch_mailbox_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, const gq::MailboxDev* mb, int waves, int solver, int cone, int boxes, int self, hipStream_t stream) {
+#if GQ_WPB != 1
+  return 0;
+#else
 #ifdef GQ_DEV_ONLY
   if (!(solver == 1 && !boxes && self && cone == (GQ_DEV_ONLY != 0))) return 0;
 #endif
@@ -520,6 +522,7 @@ extern "C" int gq_launch_mailbox_step(const gq::FusedArgs* dev_args, const gq::S
 #endif
 #undef GQ_MB_LAUNCH
   return 1;
+#endif
 }
 extern "C" void gq_launch_jac(const GqDevModel* model, const double* qpos, int body, const double* point, float* jacp, float* jacr, int n_envs, hipStream_t stream) {
   hipLaunchKernelGGL(gq::jac_kernel, dim3(n_envs), dim3(GQ_WAVE), 0, stream, model, qpos, body, point, jacp, jacr);
