@@ -35,8 +35,8 @@ LEGS = ('FL', 'FR', 'RL', 'RR')   # canonical kernel order
 class _DevPtr:
     """Minimal __cuda_array_interface__ carrier so torch can wrap library-owned device memory without a copy."""
 
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+    def __init__(self, ptr, shape, typestr='<f4'):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
 
 
 class AccessorsMixin:

@@ -105,3 +105,24 @@ def test_closed_loop_rollout_refuses_what_it_cannot_do():
     env2.enable_debug(8)
     with pytest.raises(_lib.GqError, match='production kernel'):
         env2.rollout_closed_loop(3, 20.0, 0.5)
+
+
+def test_mailbox_view_describes_the_protocol_tables():
+    """gq_mailbox_get: what a caller-provided policy kernel needs - the mailbox / queue pointers, the queue geometry and the XCD -> queue
+    map (the rule of include/gq.h: the producer of env e's action runs on the XCD of queue e mod n_queues)."""
+    from gym_quadruped_amd import _lib
+    from gym_quadruped_amd.cabi import GqMailboxView
+    env = _env('mini_cheetah', 1000)
+    env.reset(random=True)
+    v = GqMailboxView()
+    _lib.check(env._L.gq_mailbox_get(env._hbatch, C.byref(v)), 'gq_mailbox_get')
+    assert v.action and v.steps_done and v.queue_items and v.queue_counters and v.status
+    assert 1 <= v.n_queues <= 16 and v.queue_capacity >= 1000 and v.queue_capacity & (v.queue_capacity - 1) == 0 and v.counter_stride == 32
+    used = sorted(set(v.xcc_queue[x] for x in range(16)))
+    assert used[0] == 0 and used[-1] == v.n_queues - 1
+    # the tables are the ones the library's own rollout uses: after one, every env has published its step count
+    env.rollout_closed_loop(7, 20.0, 0.5, mode='mailbox')
+    torch.cuda.synchronize()
+    from gym_quadruped_amd.accessors import _DevPtr
+    done = torch.as_tensor(_DevPtr(v.steps_done, (1000,), '<i4'), device='cuda:0')
+    assert bool((done == 7).all())
