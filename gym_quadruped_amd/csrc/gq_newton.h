@@ -746,7 +746,11 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
   float gnorm2_prev = 0.0f, pred_prev = 1.0f;
   for (;; iter++) {
     /* a wave that needs many iterations decides when the launch ends: it moves ahead of the waves it shares the SIMD with */
-    if (iter + 1 > prio && iter > 0) { prio = iter + 1; wave_priority(prio); }
+    /* elliptic-cone models run 2.6 iterations on average and up to 14: with the pyramidal rule (priority 3 from the third iteration on) half of
+     * the waves of a launch carried the top priority and it arbitrated nothing; their levels are spread over the iteration count instead
+     * (3 / 5 / 7: go2 +1.8 %, hyqreal1 +2.5 %, spot +1.3 % - profiles/r04_priority_sweep.txt) */
+    if constexpr (CONE) { const int want = iter >= 7 ? 3 : (iter >= 5 ? 2 : (iter >= 3 ? 1 : 0)); if (want > prio) { prio = want; wave_priority(prio); } }
+    else if (iter + 1 > prio && iter > 0) { prio = iter + 1; wave_priority(prio); } /* (finer levels bought the pyramidal models nothing) */
     /* ---- constraint state at the current iterate */
     float ci, wact;
     f = row_law(rtype, y, rR, rD, rfloss, ci, wact);

@@ -940,7 +940,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
                                   xleg ? uniform(W.con_row[ncon - uniform(W.nself)]) : -1);
     /* a coupled-leg Newton step (Sherman-Morrison / dense) is the most expensive thing a wave can do, and leg-leg contacts
      * persist over several steps: such an env keeps top issue priority */
-    if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)((xleg && iter >= 2) ? 3 : (iter < 2 ? 0 : (iter > 2 ? 3 : 2)));
+    if constexpr (CONE) { if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)(iter >= 8 ? 3 : (iter >= 6 ? 2 : (iter >= 4 ? 1 : 0))); } /* see newton_solve */
+    else if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)((xleg && iter >= 2) ? 3 : (iter < 2 ? 0 : (iter > 2 ? 3 : 2)));
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
