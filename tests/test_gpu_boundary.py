@@ -162,6 +162,36 @@ def test_gq_forward_is_mj_forward_without_side_effects():
     assert torch.isfinite(env.qpos).all()
 
 
+def test_mj_forward_on_an_accessors_env_refreshes_the_dynamics_rows():
+    """An env built with accessors=True answers the dynamics getters from the production kernel's rows and has no inspection record
+    until somebody asks for one: mj_forward / mj_step1 must switch the record on themselves (gq_forward writes through it), and the
+    getters afterwards describe the FORWARD pose - here a pose that no step has seen."""
+    from oracle.oracle import Oracle
+    n = 16
+    env = _env('aliengo', n, seed=9, accessors=True)
+    env.reset(random=True)
+    g = torch.Generator(device='cuda:0').manual_seed(3)
+    for _ in range(20):
+        env.step(torch.randn(n, 12, generator=g, device='cuda:0') * 15)
+    M_step = {leg: env.legs_mass_matrix[leg].clone() for leg in ('FL', 'RR')}
+    rng = np.random.default_rng(4)
+    qpos, qvel = random_states(env.mjModel, n, rng, z_range=(0.35, 0.6))
+    env._qpos.copy_(torch.as_tensor(qpos)); env._qvel.copy_(torch.as_tensor(qvel.astype(np.float32)))
+    o = Oracle(marshalled('aliengo', solver=1))
+    for call in (lambda: env.mj_forward(torch.zeros(n, 12, device='cuda:0')), env.mj_step1):
+        call()
+        torch.cuda.synchronize()
+        Ml, hips = env.legs_mass_matrix, env.hip_positions('world')
+        assert not torch.equal(Ml['FL'], M_step['FL'])
+        for e in range(n):
+            o.set_state(qpos[e], qvel[e], np.zeros(18), np.zeros(18), 0.0, -1.0); o.forward(np.zeros(12), stage=1)
+            Mo = np.asarray(o.M).reshape(18, 18)
+            for leg in ('FL', 'RR'):
+                idx = env.legs_qvel_idx[leg]
+                np.testing.assert_allclose(Ml[leg][e].cpu().numpy(), Mo[np.ix_(idx, idx)], rtol=1e-4, atol=1e-6)
+    assert torch.equal(env._qpos.cpu(), torch.as_tensor(qpos)), 'a forward pass does not advance the state'
+
+
 def test_gq_full_mass_is_mj_fullM_of_the_last_forward_pass():
     """gq_full_mass (mj_fullM(model, M, data.qM), quadruped_env.py:557 / :884): the dense joint-space inertia of the last
     forward pass against the oracle's M; symmetric, positive definite; refused when the inspection record is not enabled."""
