@@ -293,7 +293,6 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
   }
   /* static world boxes: geometry per box, contact parameters per class of identical boxes x collision item */
   if (d->nbox < 0 || d->nbox > GQ_MAXBOX) FAIL("scene has %d world boxes, at most %d are supported", d->nbox, GQ_MAXBOX);
-  if (d->nbox > 0 && d->solver != 1) FAIL("scenes with world boxes need the Newton solver (solver = 1): the PGS path handles the floor plane only");
   M.nbox = d->nbox; M.nboxcls = 0;
   int item_geom[4 + GQ_MAXLG];
   {
@@ -345,7 +344,6 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
   if (d->nselfpair > 0) {
     if (!d->selfpair_geom1 || !d->selfpair_geom2 || !d->geom_capsule) FAIL("self-collision pairs given without selfpair_geom1 / selfpair_geom2 / geom_capsule");
     if (d->nselfpair > GQ_MAXSP) FAIL("%d self-collision geom pairs, at most %d are supported", d->nselfpair, GQ_MAXSP);
-    if (d->solver != 1) FAIL("robot self-collision needs the Newton solver (solver = 1): pass self_collision=False with PGS");
     int item_of_geom[1024];
     for (int g = 0; g < 1024; g++) item_of_geom[g] = -1;
     for (int it = 0; it < 4 + M.nlg; it++) {
@@ -426,7 +424,6 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
   if (d->hfield_nrow != 0 || d->hfield_ncol != 0) {
     if (d->hfield_nrow < 2 || d->hfield_ncol < 2 || d->hfield_nrow > 4096 || d->hfield_ncol > 4096) FAIL("height field of %d x %d samples not supported", d->hfield_nrow, d->hfield_ncol);
     if (!d->hfield_data) FAIL("hfield_data is NULL");
-    if (d->solver != 1) FAIL("scenes with a height field need the Newton solver (solver = 1): the PGS path handles the floor plane only");
     if (!(d->hfield_size[0] > 0 && d->hfield_size[1] > 0 && d->hfield_size[2] > 0)) FAIL("hfield_size must be positive");
     if (M.nboxcls >= GQ_MAXBOXCLS) FAIL("no contact-parameter class left for the height field (%d distinct box classes)", M.nboxcls);
     M.hf_nrow = d->hfield_nrow; M.hf_ncol = d->hfield_ncol;

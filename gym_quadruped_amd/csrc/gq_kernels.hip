@@ -488,11 +488,7 @@ extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall
 #define GQ_LAUNCH_MODE(S, C) do { if (mode == 1) GQ_LAUNCH(S, 1, C); else if (mode == 2) GQ_LAUNCH(S, 2, C); else GQ_LAUNCH(S, 0, C); } while (0)
   if (solver == 1 && cone) GQ_LAUNCH_MODE(1, true);
   else if (solver == 1) GQ_LAUNCH_MODE(1, false);
-  else { /* PGS: floor plane only (gq_model_create rejects world boxes / self-collision with solver 0) */
-    if (mode == 1) launch_variant<0, 1, false, false, false>(dev_args, c, n_envs, stream);
-    else if (mode == 2) launch_variant<0, 2, false, false, false>(dev_args, c, n_envs, stream);
-    else launch_variant<0, 0, false, false, false>(dev_args, c, n_envs, stream);
-  }
+  else GQ_LAUNCH_MODE(0, false); /* PGS: pyramidal cones only (gq_model_create rejects elliptic cones with solver 0) */
 #undef GQ_LAUNCH_MODE
 #undef GQ_LAUNCH
 }

@@ -521,8 +521,10 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
 
   GQ_TICK(3);
   /* ================================================================ S4: factorise M and M + h*D */
-  if constexpr (SOLVER == 0) factor_tree_both(W, m.dof_damping, h); /* the Newton path solves its three systems with the fused
-                                                                      * elimination (gq_newton.h) and stores no factor */
+  /* (the Newton path solves its three systems with the fused elimination (gq_newton.h) and stores no factor.  PGS on a scene with world
+   * geoms / robot self-collision: the collision stages use the factors' LDS as scratch (gq_boxes.h GQ_BX_*), so the factors are taken
+   * after the rows are built - see S8) */
+  if constexpr (SOLVER == 0 && !(BOXES || SELF)) factor_tree_both(W, m.dof_damping, h);
 
   GQ_TICK(4);
   /* the lane's collision item (S6: lane = item) is fetched now: its loads are in flight during the velocity stage */
@@ -925,6 +927,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     return 0;
   }
 
+  float pgs_keep = 0.0f;
   if constexpr (SOLVER == 1) {
     /* ================================================================ S8/S9 (Newton): primal solve, no dual operator */
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
@@ -945,6 +948,16 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
+  /* PGS with world geoms / self-collision: the contacts' normals and world classes (48 words, read again by S11) sit where the factors
+   * go - one register per lane carries them across the solve */
+  float keep_scr = 0.0f;
+  if constexpr (BOXES || SELF) {
+    wave_barrier(); /* S7 has read them */
+    if (lane < 36) keep_scr = GQ_BX_CONNRM(W)[lane];
+    else if (lane < 48) keep_scr = __builtin_bit_cast(float, GQ_BX_WCLS(W)[lane - 36]);
+    wave_barrier();
+    factor_tree_both(W, m.dof_damping, h);
+  }
   /* ================================================================ S8: B = M^-1 J' (lane-parallel), A = J B' + R */
   float A[GQ_MAXEFC];
   float diag = 0.0f; /* A_ii = J_i . B_i */
@@ -1037,6 +1050,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   }
   W.force[lane] = active ? f : 0.0f;
   wave_barrier();
+  pgs_keep = keep_scr;
   }
   GQ_TICK(9);
   /* ================================================================ S10: accelerations and integration */
@@ -1074,6 +1088,11 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     }
   }
   wave_barrier();
+  if constexpr (BOXES || SELF) { /* the factors are dead: the contact normals / world classes return for S11 */
+    if (lane < 36) GQ_BX_CONNRM(W)[lane] = pgs_keep;
+    else if (lane < 48) GQ_BX_WCLS(W)[lane - 36] = __builtin_bit_cast(int32_t, pgs_keep);
+    wave_barrier();
+  }
 
   }
   dump_record(true, raref, rR, rtype, iter);

@@ -144,7 +144,7 @@ typedef struct GqModelDesc {
   double meaninertia;
   double key_qpos[19];           /* keyframe 0 (mj_resetDataKeyframe, quadruped_env.py:343) */
   /* solver */
-  int32_t solver;                /* 0 PGS (mj_solPGS, named by the north-star), 1 Newton (mj_solNewton, MuJoCo's default) */
+  int32_t solver;                /* 0 PGS (mj_solPGS, named by the north-star; pyramidal cones, every scene), 1 Newton (mj_solNewton, MuJoCo's default) */
   int32_t iterations;
   double tolerance;
   /* fp32 stopping rule of the Newton solver (no MuJoCo counterpart; 0 = off): after at least one Newton step the

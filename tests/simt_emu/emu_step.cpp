@@ -74,7 +74,12 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
           hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, false) : gq::load_rows<0>(f.s, call, W, e, false);
         }
         int term;
-        if (M.solver != 1) term = gq::step_wave<0, 1, false, false, false, true>(f.s, call, W, pass, lift, hint);
+        if (M.solver != 1) { /* PGS (pyramidal cones only) */
+          if (boxes && prims) term = gq::step_wave<0, 1, false, true, true, true>(f.s, call, W, pass, lift, hint);
+          else if (boxes) term = gq::step_wave<0, 1, false, true, true, false>(f.s, call, W, pass, lift, hint);
+          else if (self) term = gq::step_wave<0, 1, false, false, true, true>(f.s, call, W, pass, lift, hint);
+          else term = gq::step_wave<0, 1, false, false, false, true>(f.s, call, W, pass, lift, hint);
+        }
         else if (boxes && prims) term = M.cone ? gq::step_wave<1, 1, true, true, true, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, true, true, true>(f.s, call, W, pass, lift, hint);
         else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true, true, false>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, true, true, false>(f.s, call, W, pass, lift, hint);
         else if (self) term = M.cone ? gq::step_wave<1, 1, true, false, true, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, false, true, true>(f.s, call, W, pass, lift, hint);

@@ -577,7 +577,7 @@ def test_baseline_config5_hyqreal1_boxes_imu_heightmap():
 def test_api_edge_cases_single_env_action_forms_and_errors():
     """Drop-in edge cases: one env (the reference's shape), [nu] and numpy actions, masked reset leaving other envs alone,
     and the reference's error behaviour (unknown observable / robot / scene names raise ValueError; 'hyqreal' alone is not a
-    registry key; PGS with elliptic cones or box scenes is refused with a reason)."""
+    registry key; PGS with elliptic cones is refused with a reason)."""
     from gym_quadruped_amd import _lib
     from gym_quadruped_amd.quadruped_env import QuadrupedEnv
     env = QuadrupedEnv('mini_cheetah', num_envs=1)
@@ -603,11 +603,65 @@ def test_api_edge_cases_single_env_action_forms_and_errors():
     with pytest.raises(ValueError):
         QuadrupedEnv('mini_cheetah', scene='moon', num_envs=1)
     with pytest.raises(_lib.GqError, match='Newton'):
-        QuadrupedEnv('aliengo', scene='perlin', solver='pgs', num_envs=1)
+        QuadrupedEnv('go2', solver='pgs', num_envs=1)                      # elliptic cones: no per-contact QCQP in the PGS path
     with pytest.raises(_lib.GqError, match='Newton'):
-        QuadrupedEnv('go2', solver='pgs', num_envs=1)
-    with pytest.raises(_lib.GqError, match='Newton'):
-        QuadrupedEnv('aliengo', scene='stairs', solver='pgs', num_envs=1)
+        QuadrupedEnv('hyqreal1', scene='random_boxes', solver='pgs', num_envs=1)
+    QuadrupedEnv('aliengo', scene='stairs', solver='pgs', num_envs=1).close()   # pyramidal cones: PGS serves every scene (round 4)
+
+
+@pytest.mark.parametrize('scene', ['perlin', 'random_boxes'])
+def test_pgs_on_world_geoms_and_self_collision_matches_oracle_pgs(scene):
+    """BASELINE config 3's scene (aliengo, perlin) and a box field under the solver the north-star names: PGS with height field /
+    world boxes / robot self-collision rows.  Same rows as the Newton variant (the oracle builds one constraint list), force and
+    acceleration of the oracle's PGS after the same 40 sweeps, contact forces read back through the parked contact normals; and a
+    200-step rollout at 1024 envs stays finite, re-spawns and reports its capacity cuts."""
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    from oracle.oracle import Oracle
+    n = 48
+    env = QuadrupedEnv('aliengo', scene=scene, state_obs_names=ALL_OBS, num_envs=n, device='cuda:0', solver='pgs', solver_iterations=40,
+                       solver_tolerance=0.0, self_collision=True, auto_reset=False, seed=5)
+    env.reset(random=True)
+    g = torch.Generator(device='cuda:0').manual_seed(1)
+    for _ in range(60):   # fall onto the terrain
+        env.step(torch.randn(n, 12, generator=g, device='cuda:0') * 20)
+    env.enable_debug(n)
+    q0, v0, w0 = env.qpos.cpu().numpy().copy(), env.qvel.cpu().numpy().copy(), env._warm.cpu().numpy().copy()
+    fr = env._friction.cpu().numpy().copy()
+    act = torch.randn(n, 12, generator=g, device='cuda:0') * 20
+    obs, _, term, _, info = env.step(act)
+    torch.cuda.synchronize()
+    dbgs = env.debug_internals(n, ['nefc', 'ncon', 'qacc', 'efc_J', 'efc_aref'])
+    o = Oracle(env._mm)
+    a = act.cpu().numpy().astype(np.float64)
+    checked = world = 0
+    for e in range(n):
+        o.set_state(q0[e], v0[e], w0[e], np.zeros(18), 0.0, float(fr[e])); o.step(a[e])
+        d = dbgs[e]
+        ne = int(d['nefc'][0])
+        if (o.ncon and o.get('contact_tiegap').min() < 3e-6) or ne != o.nefc:
+            assert ne <= o.nefc
+            continue
+        checked += 1
+        world += int((np.abs(o.contact_frame[:, 0, 2] - 1.0) > 1e-6).sum()) if o.ncon else 0
+        np.testing.assert_allclose(d['efc_J'].reshape(64, 18)[:ne], o.efc_J, atol=3e-5 * max(1.0, np.abs(o.efc_J).max()))
+        np.testing.assert_allclose(d['efc_aref'][:ne], o.efc_aref, atol=3e-4 * max(1.0, np.abs(o.efc_aref).max()))
+        assert np.abs(d['qacc'] - o.qacc).max() < 3e-4 * max(1.0, np.abs(o.qacc).max()), e
+        ref, t, inv = o.get_obs(ALL_OBS, np.zeros(4))
+        for k in ('contact_forces', 'contact_state'):
+            got = obs[k][e].cpu().numpy().reshape(-1)
+            assert np.abs(got - np.asarray(ref[k]).reshape(-1)).max() < 1e-2 * max(1.0, np.abs(ref[k]).max(), 0.1 * 9.81 * env.mjModel.total_mass), (e, k)
+        assert bool(term[e]) == t
+    assert checked >= n // 2 and world >= 8, (checked, world)
+    env.close()
+    big = QuadrupedEnv('aliengo', scene=scene, state_obs_names=ALL_OBS, num_envs=1024, device='cuda:0', solver='pgs', self_collision=True,
+                       auto_reset='next_step', seed=2)
+    big.reset(random=True)
+    for _ in range(200):
+        _, _, _, _, info = big.step(torch.randn(1024, 12, generator=g, device='cuda:0') * 50)
+    torch.cuda.synchronize()
+    assert torch.isfinite(big.qpos).all() and torch.isfinite(big.qvel).all()
+    assert int(big._episode.max()) > 1 and int(info['contacts_dropped'].max()) <= 40
+    big.close()
 
 
 def _hfield_height(hf, x, y):

@@ -303,6 +303,59 @@ def test_world_boxes_step_matches_oracle(robot):                # exhaust the 64
     assert nchecked >= n // 2 and nbox_con >= 4, (nchecked, nbox_con)
 
 
+@pytest.mark.parametrize('scene_name', ['random_boxes', 'flat'])
+def test_pgs_with_world_boxes_and_self_collision_matches_oracle_pgs(scene_name):
+    """PGS (the solver the north-star names) beyond the flat floor: world boxes + robot self-collision rows (pyramidal cones; aliengo's
+    box / capsule link geoms take the exact pair routines).  The collision stages use the L'DL factors' LDS as scratch, so this variant
+    factors after the rows are built and carries the contact normals across the solve in a register (gq_step_body.h S8): same rows as
+    the Newton variant, and the force / acceleration of the oracle's PGS after the same number of sweeps."""
+    from gym_quadruped_amd.robot_cfgs import get_robot_config
+    robot = 'aliengo'
+    hip = get_robot_config(robot).hip_height
+    boxes = _random_boxes_scene(hip)[0]['boxes'] if scene_name == 'random_boxes' else None
+    mm = marshalled(robot, solver=0, iterations=40, tolerance=0.0, boxes=boxes, self_collision=True)
+    rng = np.random.default_rng(21)
+    n = 16
+    n = 24 if boxes is not None else 16
+    qpos, qvel = random_states(mm.md, n, rng, z_range=(0.85 * hip, 1.15 * hip) if boxes is not None else (0.6 * hip, 1.0 * hip))
+    if boxes is not None:   # (feet and a link or two on the boxes: a robot lying in the box field exceeds the 12-contact capacity, a case of its own)
+        qpos[:, 0] = rng.uniform(0.5 + 2 * hip, 0.5 + 10 * hip, n); qpos[:, 1] = rng.uniform(-3 + 2 * hip, -3 + 12 * hip, n)
+        qpos[:, 2] += 0.25 * hip
+    if boxes is None:   # legs folded across each other: states in which the oracle finds robot-robot contacts, inside the row capacity
+        qpos, qvel = self_contact_states(mm.md, n, rng, Oracle(marshalled(robot, solver=1, self_collision=True)), z=(0.9 * hip, 1.6 * hip), cone=0, max_over=0.0)
+    qvel = qvel.astype(np.float32)
+    warm = rng.normal(0, 3, (n, 18)).astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 20).astype(np.float32)
+    st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), warm=warm.copy(), debug_envs=n)
+    o = Oracle(mm)
+    nchecked = nself = nworld = 0
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e].astype(np.float64), warm[e].astype(np.float64), np.zeros(18)); o.step(ctrl[e].astype(np.float64))
+        rec = st['debug'][e]
+        nefc = int(dbg(rec, 'nefc')[0])
+        if (o.ncon and o.get('contact_tiegap').min() < 3e-6) or nefc != o.nefc:
+            continue
+        nchecked += 1
+        if o.ncon:
+            nworld += int((np.abs(o.contact_frame[:, 0, 2] - 1.0) > 1e-6).sum())
+            nself += int((o.get('contact_body1')[:o.ncon] > 0).sum())
+        J = dbg(rec, 'efc_J').reshape(64, 18)[:nefc]
+        np.testing.assert_allclose(J, o.efc_J, atol=3e-5 * max(1.0, np.abs(o.efc_J).max()))
+        np.testing.assert_allclose(dbg(rec, 'efc_aref')[:nefc], o.efc_aref, atol=3e-4 * max(1.0, np.abs(o.efc_aref).max()))
+        assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 3e-4 * max(1.0, np.abs(o.qacc).max()), e
+        assert np.abs(st['qvel'][e] - o.qvel).max() < 5e-4
+        ref, t, inv = o.get_obs(ALL_OBS, np.zeros(4))
+        got = split_obs(st['obs'][e], ALL_OBS)
+        for k in ('contact_forces', 'contact_forces:base', 'contact_state'):   # S11 reads the contact normals that were parked in a register
+            assert np.abs(got[k] - ref[k]).max() < 1e-2 * max(1.0, np.abs(ref[k]).max(), 0.1 * 9.81 * mm.md.total_mass), (e, k)
+        assert bool(st['terminated'][e]) == t
+    assert nchecked >= n // 2, nchecked
+    if boxes is not None:
+        assert nworld >= 4, nworld
+    else:
+        assert nself >= 1, nself
+
+
 def test_world_box_slab_equals_raised_floor_in_the_kernel():
     from gym_quadruped_amd.terrain import _box
     H = 1.37
