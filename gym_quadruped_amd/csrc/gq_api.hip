@@ -552,7 +552,9 @@ int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, i
     HIP_TRY(hipGetLastError());
     return GQ_OK;
   }
-  if (step_waves <= 0 || step_waves > N) step_waves = N; /* more workgroups than free slots is harmless: the late ones find the queues drained */
+  if (step_waves <= 0) step_waves = N; /* more workgroups than free slots is harmless: the late ones find the queues drained */
+  if (step_waves < 4 * h.nq) step_waves = 4 * h.nq; /* a wavefront pops from ITS XCD's queue only: every XCD needs stepping wavefronts, also for a batch of
+                                                      * one env (workgroups are dealt round-robin over the XCDs; the surplus finds its queue empty and leaves) */
   h.n_steps = n_steps; h.obs_seq = obs_seq; h.act_seq = act_seq;
   h.timeout_ticks = (int64_t)((timeout_s > 0.0 ? timeout_s : 5.0) * 1e8);
   { const char* fl = getenv("GQ_MB_FLAGS"); h.flags = fl ? atoi(fl) : 0; }

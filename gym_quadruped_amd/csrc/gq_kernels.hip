@@ -465,7 +465,7 @@ static void launch_variant(const gq::FusedArgs* dev_args, const gq::StepCall* c,
     gq::StepCall call = *c;
     call.count = n_envs;
     if constexpr (M == 0) {
-      if (c->n_steps > 1) { /* persistent rollout: production kernel only */
+      if (c->n_steps > 1 || c->policy) { /* persistent rollout (also a one-step one with the policy inline: only this variant evaluates it): production kernel only */
         hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF, P, true>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
         return;
       }

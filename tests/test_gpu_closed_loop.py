@@ -71,6 +71,30 @@ def test_closed_loop_rollout_equals_the_step_loop_with_the_same_actions(robot, s
     assert torch.equal(a._qpos, b._qpos) and torch.equal(a._obs_buf, b._obs_buf)
 
 
+@pytest.mark.parametrize('mode', ['mailbox', 'inline'])
+@pytest.mark.parametrize('n', [1, 7, 63, 65])
+def test_closed_loop_rollout_on_small_batches_and_single_steps(n, mode):
+    """Fewer envs than XCDs (a stepping wavefront pops from ITS XCD's queue only: every XCD needs one, also for one env) and rollouts
+    of ONE step (the inline policy is evaluated by the persistent kernel variant only): equal to the step loop, and the first
+    recorded action is the PD law on the observation the rollout started from."""
+    a, b = _env(n=n, seed=3), _env(n=n, seed=3)
+    a.reset(random=True); b.reset(random=True)
+    kp, kd = 25.0, 0.8
+    qd = torch.as_tensor(np.asarray(b.mjModel.key_qpos[0][7:19], dtype=np.float32), device='cuda:0')
+    for K in (1, 5, 1):
+        before = b._obs_buf.clone()
+        r = b.rollout_closed_loop(K, kp, kd, mode=mode, record_actions=True)
+        code, _, played = b.closed_loop_status()
+        assert code == 0 and (mode == 'inline' or played == n * K)
+        acts = r['actions']
+        assert torch.equal(acts[0], kp * (qd - before[:, 0:12]) - kd * before[:, 12:24])
+        for k in range(K):
+            a.step(acts[k])
+        torch.cuda.synchronize()
+        for f in STATE:
+            assert torch.equal(getattr(a, f), getattr(b, f)), (K, f)
+
+
 def test_closed_loop_rollout_with_a_silent_policy_fails_loudly_and_leaves_the_batch_usable():
     """pd = NULL: the caller promises to run the policy side itself.  Nobody does here: every step wavefront waits for a queue item
     that never comes, the deadline (0.3 s) passes, the abort word goes up, the launch ends, and the status call reports it."""
