@@ -303,6 +303,7 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const
   a->invalid_contact = out.invalid_contact; a->step_num = out.step_num; a->step_prev = out.step_num_prev;
   a->contacts_dropped = out.contacts_dropped;
   a->n_envs = b->host.n_envs;
+  a->timestep = m->host.timestep; a->nlg = m->host.nlg; a->nfl = m->host.nfl; a->pad_ = 0;
 }
 /* Make the device argument block describe (st, out, episode, lift_failed[, auto-reset cfg]).  Steady state: a memcmp.
  * On a change the new block goes through a pinned staging slot with a stream-ordered copy, so launches already queued

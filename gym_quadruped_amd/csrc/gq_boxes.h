@@ -602,10 +602,10 @@ __device__ __forceinline__ void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& 
 /* model words of the self-collision stage that do not depend on the state: fetched at the start of S6, so that their
  * memory latency is spent under the floor scan instead of in front of the pair test */
 struct SelfPrefetch { float caps[7], bsph[4]; int32_t body, it1[2], it2[2], bp[2]; };
-__device__ __forceinline__ SelfPrefetch self_prefetch(const GQ_MODEL GqDevModel& m) {
+__device__ __forceinline__ SelfPrefetch self_prefetch(const GQ_MODEL GqDevModel& m, const int nlg, const int nsp) {
   const int lane = lane_id();
   SelfPrefetch P;
-  const int it = lane < 4 + m.nlg ? lane : 0;
+  const int it = lane < 4 + nlg ? lane : 0;
 #pragma unroll
   for (int i = 0; i < 7; i++) P.caps[i] = m.item_caps[it][i];
 #pragma unroll
@@ -613,24 +613,24 @@ __device__ __forceinline__ SelfPrefetch self_prefetch(const GQ_MODEL GqDevModel&
   P.body = m.item_body[it];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    const int p = h * GQ_WAVE + lane < m.nsp ? h * GQ_WAVE + lane : 0;
+    const int p = h * GQ_WAVE + lane < nsp ? h * GQ_WAVE + lane : 0;
     P.it1[h] = m.sp[p].it1; P.it2[h] = m.sp[p].it2; P.bp[h] = m.sp[p].bp;
   }
   return P;
 }
 
 template <bool CONE, bool PRIM = true>
-__device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre) {
+__device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre, const StepConsts& K, const int nlg) {
   constexpr int NP = PRIM ? 4 : 1; /* points per pair: only the exact pair routines return more than one */
   const int lane = lane_id();
-  const int nsp = m.nsp;
+  const int nsp = K.nsp;
   if (nsp == 0) return;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   /* world end points of every item's proxy capsule, once: lane = collision item; scratch in the J block, which is free
    * until S7 (the spatial-dynamics scratch it overlays is dead since S5) */
   /* per item: end points p0, p1, radius, and the bounding sphere (centre, radius) the first pass tests */
   float(*cw)[12] = reinterpret_cast<float(*)[12]>(&W.u.B[0][0]);
-  if (lane < 4 + m.nlg) {
+  if (lane < 4 + nlg) {
     const int b = pre.body;
     const V3 o = ld3(W.xpos[b]);
     const V3 e0 = o + matvec(W.xmat[b], v3(pre.caps[0], pre.caps[1], pre.caps[2])), e1 = o + matvec(W.xmat[b], v3(pre.caps[3], pre.caps[4], pre.caps[5]));
@@ -649,14 +649,15 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
       if (p < m.nbp) {
         const GQ_MODEL GqDevBodyPair& P = m.bp[p];
         const V3 d = ld3(W.xpos[P.b2]) + matvec(W.xmat[P.b2], ld3(m.body_sph[P.b2])) - ld3(W.xpos[P.b1]) - matvec(W.xmat[P.b1], ld3(m.body_sph[P.b1]));
-        const float rr = m.body_sph[P.b1][3] + m.body_sph[P.b2][3] + m.self_margin;
+        const float rr = m.body_sph[P.b1][3] + m.body_sph[P.b2][3] + K.self_margin;
         nr = dot(d, d) < rr * rr;
       }
       near[half] = ballot(nr);
     }
   }
-  if (m.self_cut == 1) { wave_barrier(); return; }
+  if (K.self_cut == 1) { wave_barrier(); return; }
   wave_barrier();
+  GQ_SUB(W, 1, 10); /* proxy end points */
   /* pass A, lane = geom pair, 64 pairs per pass: bounding spheres of the two capsules.  The survivors' pair indices are
    * compacted into a list (scratch behind the end points, pair order kept), so that the closest-point test runs once over
    * the candidates instead of once per pass - and not at all in the many poses where no pair comes close */
@@ -676,7 +677,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         const float* k1 = cw[it1] + 8;
         const float* k2 = cw[it2] + 8;
         const V3 dm = ld3(k2) - ld3(k1);
-        const float reach = k1[3] + k2[3] + m.self_margin;
+        const float reach = k1[3] + k2[3] + K.self_margin;
         cand = dot(dm, dm) < reach * reach;
       }
     }
@@ -686,7 +687,8 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     if (cand && at < 2 * GQ_WAVE) list[at] = p;
     ncand += popc64(cm);
   }
-  if (ncand == 0 || m.self_cut == 2) return;
+  GQ_SUB(W, 1, 11); /* pair cull */
+  if (ncand == 0 || K.self_cut == 2) return;
   if (ncand > 2 * GQ_WAVE) ncand = 2 * GQ_WAVE; /* more than 128 close pairs: the robot is a knot; the row budget is long spent */
   wave_barrier();
 #pragma unroll 1
@@ -749,7 +751,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
       }
     }
     const int cnt = H.n;
-    if (ballot(cnt > 0) == 0 || m.self_cut == 4) continue;
+    if (ballot(cnt > 0) == 0 || K.self_cut == 4) continue;
     /* (rare) append the touching pairs' points, in pair order */
     const GQ_MODEL GqDevSelfPair& P = m.sp[cnt > 0 ? p : 0];
     const int dim = P.mix.dim;
@@ -820,7 +822,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
 /* S6 for a scene without world boxes / height field but with robot self-collision: general frames for the floor
  * contacts the floor pass left in W, then the robot-robot contacts.  Ends with a barrier. */
 template <bool CONE>
-__device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre) {
+__device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre, const StepConsts& K, const int nlg) {
   const int lane = lane_id();
   WorldAppend S;
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = 0; S.reserve = 0; S.nself = 0; S.ndrop = uniform(W.ndrop);
@@ -831,7 +833,7 @@ __device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL G
   }
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
-  append_self_contacts<CONE>(W, m, mu_env, S, pre);
+  append_self_contacts<CONE>(W, m, mu_env, S, pre, K, nlg);
   if (lane == 0) { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; W.ndrop = S.ndrop; }
   wave_barrier();
 }
@@ -842,7 +844,7 @@ __device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL G
  * materialised in scratch memory, 200 bytes per lane) */
 template <bool CONE, bool SELF, bool PRIM>
 __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
-                                          double bx, double by, float mu_env, const SelfPrefetch& pre, const ItemRegs& IT) {
+                                          double bx, double by, float mu_env, const SelfPrefetch& pre, const ItemRegs& IT, const StepConsts& K, const int nlg) {
   const int lane = lane_id();
   const PrimLane PL = prim_lane(W, m, IT, PRIM && lane < 4 + m.nlg, PRIM); /* all the box loop keeps of the item record */
   WorldAppend S;
@@ -890,8 +892,8 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
   }
   if constexpr (SELF) {
     (void)pre;
-    const SelfPrefetch pre_now = self_prefetch(m); /* not prefetched in front of the box loop: it would sit in registers (or scratch) across it */
-    append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre_now);
+    const SelfPrefetch pre_now = self_prefetch(m, nlg, K.nsp); /* not prefetched in front of the box loop: it would sit in registers (or scratch) across it */
+    append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre_now, K, nlg);
   }
   if (lane == 0) {
     W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself; W.ndrop = S.ndrop;

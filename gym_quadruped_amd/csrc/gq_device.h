@@ -144,6 +144,17 @@ __device__ __forceinline__ void wave_priority(int p) {
 __device__ __forceinline__ int opaque_lane(int l) { asm volatile("" : "+v"(l)); return l; }
 template <class T> __device__ __forceinline__ const T* opaque_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; } /* per-lane pointer */
 __device__ __forceinline__ void opaque_s(int& v) { asm volatile("" : "+s"(v)); } /* wave-uniform value */
+/* pin(): a wave-uniform value the program has just loaded (a pointer out of the device-resident argument block, a model scalar) is
+ * tied to its SGPRs here.  Two things follow, and both are the point.  (1) Every scalar load written in front of a group of pins is
+ * ISSUED before the first pin and all of them are waited for ONCE (the pins are volatile: loads do not sink below them) - instead of one
+ * s_load + s_waitcnt lgkmcnt(0) at each use, which is what the register allocator makes of an invariant load whose value it would have to
+ * keep (it re-materialises the load in front of every use: m.timestep was fetched five times between the Euler step and the observation
+ * row, each time with its own exposed scalar-cache round trip).  (2) From here on the value is the asm's result, which cannot be
+ * re-materialised: it stays in its SGPRs (or a v_writelane slot) until its last use. */
+template <class T> __device__ __forceinline__ void pin(T*& p) { asm volatile("" : "+s"(p)); }
+__device__ __forceinline__ void pin(int& v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+s"(v)); }
 
 /* ---- mailbox traffic of the closed-loop persistent rollout (gq_kernels.hip mailbox_step_kernel): words that another wavefront -
  * possibly on another XCD, behind another L2 - reads or writes while this kernel runs.  Agent-scope relaxed atomics: the

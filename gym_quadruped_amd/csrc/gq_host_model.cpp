@@ -163,6 +163,62 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     M.act_ctrllimited[j] = d->actuator_ctrllimited[u]; M.act_forcelimited[j] = d->actuator_forcelimited[u];
     for (int k = 0; k < 2; k++) { M.act_ctrlrange[j][k] = (float)d->actuator_ctrlrange[2 * u + k]; M.act_forcerange[j][k] = (float)d->actuator_forcerange[2 * u + k]; }
   }
+  /* per-lane records (gq_model_dev.h): the tables above, folded per dof / link / body / hinge */
+  for (int i = 0; i < GQ_NVD; i++) {
+    GqDevDofRec& D = M.dof_rec[i];
+    D.act_u = -1; D.flags = 0; D.c_lo = D.f_lo = D.a_lo = 0.0f; D.c_hi = D.f_hi = D.a_hi = 0.0f; D.gear = 0.0f;
+    D.damping = M.dof_damping[i]; D.armature = M.dof_armature[i]; D.fl_row = M.fl_row_of_dof[i];
+    if (i >= 6) {
+      const int j = i - 6;
+      D.act_u = M.act_of_jnt[j];
+      if (D.act_u >= 0) {
+        D.gear = M.act_gear[j];
+        if (M.act_ctrllimited[j]) { D.flags |= 1; D.c_lo = M.act_ctrlrange[j][0]; D.c_hi = M.act_ctrlrange[j][1]; }
+        if (M.act_forcelimited[j]) { D.flags |= 2; D.f_lo = M.act_forcerange[j][0]; D.f_hi = M.act_forcerange[j][1]; }
+      }
+      if (M.jnt_actfrclimited[j]) { D.flags |= 4; D.a_lo = M.jnt_actfrcrange[j][0]; D.a_hi = M.jnt_actfrcrange[j][1]; }
+    }
+  }
+  for (int j = 0; j < GQ_NJ; j++) {
+    GqDevLinkRec& L = M.link_rec[j];
+    const int s = j + 2; /* descriptor body of link j (body 0 = world, 1 = base) */
+    double R0[9];
+    quat2mat(d->body_quat + 4 * s, R0);
+    for (int k = 0; k < 4; k++) L.bq[k] = M.body_quat[1 + j][k];
+    for (int k = 0; k < 3; k++) {
+      L.ax[k] = M.jnt_axis[j][k]; L.jp[k] = M.jnt_pos[j][k];
+      const double* jp = d->jnt_pos + 3 * (j + 1); const double* ja = d->jnt_axis + 3 * (j + 1);
+      L.aloc[k] = (float)(d->body_pos[3 * s + k] + R0[3 * k] * jp[0] + R0[3 * k + 1] * jp[1] + R0[3 * k + 2] * jp[2]);
+      L.r0ax[k] = (float)(R0[3 * k] * ja[0] + R0[3 * k + 1] * ja[1] + R0[3 * k + 2] * ja[2]);
+    }
+    L.qpos0 = M.qpos0[j]; L.pad0 = L.pad1 = L.pad2 = 0.0f;
+    GqDevLimRec& Q = M.lim_rec[j];
+    Q.limited = M.jnt_limited[j]; Q.lo = M.jnt_range[j][0]; Q.hi = M.jnt_range[j][1]; Q.margin = M.jnt_margin[j];
+  }
+  for (int b = 0; b < GQ_NB; b++) {
+    GqDevBodyRec& Br = M.body_rec[b];
+    for (int k = 0; k < 3; k++) Br.ipos[k] = M.body_ipos[b][k];
+    Br.mass = M.body_mass[b];
+    for (int k = 0; k < 6; k++) Br.I[k] = M.body_I[b][k];
+    Br.pad[0] = Br.pad[1] = 0.0f;
+  }
+  for (int pass = 0; pass < 3; pass++) /* entries of the joint-space inertia, three per lane (step kernel S3) */
+    for (int lane = 0; lane < 64; lane++) {
+      const int e = pass * 64 + lane;
+      int dd = 0, sa = 0, valid = 0;
+      if (e < 108) {
+        const int j = e / 9, col = e % 9, leg = j / 3, dep = j % 3;
+        dd = 6 + j;
+        if (col < 6) { sa = col; valid = 1; }
+        else if (col - 6 <= dep) { sa = 6 + 3 * leg + (col - 6); valid = 1; }
+      } else if (e < 144) {
+        const int i = (e - 108) / 6, jj = (e - 108) % 6;
+        dd = i > jj ? i : jj; sa = i > jj ? jj : i; valid = 1;
+      }
+      const int body = dd < 6 ? 0 : dd - 5;
+      M.s3_ent[pass][lane] = dd | (sa << 8) | (body << 16) | (valid << 24);
+      M.s3_arm[pass][lane] = (valid && dd == sa) ? M.dof_armature[dd] : 0.0f;
+    }
   for (int k = 0; k < 3; k++) M.floor_friction[k] = (float)d->floor_friction[k];
   for (int k = 0; k < 4; k++) M.terrain_limits[k] = d->terrain_limits[k];
   for (int k = 0; k < 19; k++) M.key_qpos[k] = (float)d->key_qpos[k];
@@ -472,6 +528,8 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       }
     M.robot_radius = (float)(reach + grb);
   }
+  for (int k = 0; k < 4; k++) M.hot_foot_leg[k] = M.foot_leg[k];
+  M.hot_nsp = M.nsp; M.hot_self_cut = M.self_cut; M.hot_floor_mu = M.floor_friction[0]; M.hot_self_margin = M.self_margin;
   return 0;
 }
 

@@ -51,12 +51,16 @@ __device__ __forceinline__ void pd_inline(const GQ_MODEL PolicyPdDev& P, const S
  * reset's mj_step instead of a user step - every wave runs exactly one mj_step per launch. */
 template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF, bool PRIM, bool PERSIST = false>
 __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedArgs* __restrict__ A, const StepCall c) {
+  const long long t_entry = (GQ_TICKSET && MODE == 1) ? cycles() : 0; /* sub-stage builds (gq_step_kernel.h GQ_TICKSET) count from here */
   const int widx = wave_index();
   if (GQ_WPB > 1 && widx >= c.count) return;
   const int env = widx + c.env0;
   if (c.mask && !gptr(c.mask)[env]) return; /* wave-uniform */
   __shared__ WaveMem Ws[GQ_WPB];
   WaveMem& W = Ws[GQ_WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+#if GQ_TICKSET
+  if (lane_id() == 0) W.tk_T = nullptr;
+#endif
   for (int kstep = 0;;) { /* one trip, except in a persistent rollout (PERSIST variants, StepCall::n_steps; a variant of their own:
                            * merely compiling the loop in cost the single-step kernel 2.7 %) */
   StepCall ck = c;
@@ -68,10 +72,11 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
   int pass = c.first_pass;
   /* the flags and the env's rows are fetched together: one memory round trip in front of the step (a respawning env - rare -
    * throws the rows away and fetches the ones reset_wave wrote) */
-  bool respawn = c.auto_reset == 2 && gptr(A->s.pending)[env]; /* wave-uniform */
+  WaveCtx C;
+  int hint = load_rows<SOLVER>(A->s, c, W, env, pass == 0, C);
+  bool respawn = c.auto_reset == 2 && C.pend; /* wave-uniform */
   /* the reset's own step after an explicit gq_reset: the reset kernel left word whether the lift loop is still due */
-  int lift = (c.first_pass && A->s.lift_pending) ? (int)gptr(A->s.lift_pending)[env] : 0;
-  int hint = load_rows<SOLVER>(A->s, c, W, env, pass == 0);
+  int lift = c.first_pass ? C.lift : 0;
   if constexpr (PERSIST) if (c.policy) pd_inline(*mptr(c.policy), A->s, c, W, env, kstep, !respawn); /* wave-uniform */
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
@@ -79,9 +84,9 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
       wave_barrier();   /* the rows just staged in LDS are dead: reset_wave reuses the region */
       lift = reset_wave<BOXES, PRIM>(A->r, W, c.env0);
       pass = c.auto_reset;
-      hint = load_rows<SOLVER>(A->s, c, W, env, false);
+      hint = load_rows<SOLVER>(A->s, c, W, env, false, C);
     }
-    const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF, PRIM>(A->s, c, W, pass, lift, hint);
+    const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF, PRIM>(A->s, c, W, pass, lift, hint, C, t_entry);
     if (pass != 0 || c.auto_reset != 1 || !term) break;
     respawn = true;
   }
@@ -96,6 +101,9 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
 template <int SOLVER, bool CONE, bool BOXES, bool SELF, bool PRIM>
 __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArgs* __restrict__ A, const StepCall c0, const MailboxDev* __restrict__ MBp) {
   __shared__ WaveMem W; /* one wavefront per workgroup (the GQ_WPB > 1 experiment builds never launch this kernel) */
+#if GQ_TICKSET
+  if (lane_id() == 0) W.tk_T = nullptr;
+#endif
   const GQ_MODEL MailboxDev& MB = *mptr(MBp);
   const int q = MB.xcc_queue[xcc_id()];
   const int N = MB.n_envs, nq = MB.nq, qmask = MB.qcap - 1;
@@ -132,17 +140,18 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
     ck.obs_seq = MB.obs_seq ? MB.obs_seq + (size_t)k * N * mptr(A->s.batch)->obs_dim : nullptr;
     const StepCall& c = ck;
     int pass = 0, lift = 0;
-    bool respawn = c.auto_reset == 2 && ldv<true>(A->s.pending + env); /* wave-uniform */
     if ((MB.flags & 32) && lane_id() == 0) add_pub(MB.issued + N + env, 1 << (4 * xcc_id())); /* experiment: which XCDs ever stepped this env (nibble counters, <= 15 steps) */
-    int hint = load_rows<SOLVER, true>(A->s, c, W, env, true);
+    WaveCtx C;
+    int hint = load_rows<SOLVER, true>(A->s, c, W, env, true, C);
+    bool respawn = c.auto_reset == 2 && C.pend; /* wave-uniform */
     if (respawn) {
       wave_priority(3);
       wave_barrier();
       lift = reset_wave<BOXES, PRIM, true>(A->r, W, c.env0);
       pass = c.auto_reset;
-      hint = load_rows<SOLVER, true>(A->s, c, W, env, false);
+      hint = load_rows<SOLVER, true>(A->s, c, W, env, false, C);
     }
-    step_wave<SOLVER, 0, CONE, BOXES, SELF, PRIM, true>(A->s, c, W, pass, lift, hint);
+    step_wave<SOLVER, 0, CONE, BOXES, SELF, PRIM, true>(A->s, c, W, pass, lift, hint, C);
     publish_fence(); /* state rows are in this XCD's L2, the observation row has been written through */
     if (MB.flags & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane_id() == 0) add_pub(MB.steps_done + env, 1);
@@ -232,6 +241,9 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB) reset_kernel(ResetArgs a, co
   if (a.mask && !gptr(a.mask)[widx]) return;
   __shared__ WaveMem Ws[GQ_WPB];
   WaveMem& W = Ws[GQ_WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+#if GQ_TICKSET
+  if (lane_id() == 0) W.tk_T = nullptr;
+#endif
   reset_wave<BOXES>(a, W);
 }
 
@@ -317,6 +329,9 @@ __global__ void __launch_bounds__(GQ_WAVE) heightmap_kernel(const GQ_GLOBAL GqDe
 __global__ void __launch_bounds__(GQ_WAVE) jac_kernel(const GqDevModel* model, const double* qpos, int body, const double* point, float* jacp, float* jacr) {
   __shared__ WaveMem W;
   const int lane = lane_id(), env = (int)blockIdx.x;
+#if GQ_TICKSET
+  if (lane == 0) W.tk_T = nullptr;
+#endif
   const GQ_MODEL GqDevModel& m = *mptr(model);
   double bxy = 0.0;
   if (lane < 19) {
@@ -328,7 +343,7 @@ __global__ void __launch_bounds__(GQ_WAVE) jac_kernel(const GqDevModel* model, c
   }
   (void)bxy;
   wave_barrier();
-  stage_kinematics(W, m);
+  stage_kinematics(W, link_fetch(m, lane));
   /* the point relative to the base x/y (f64 first, like everything else) */
   const V3 p = v3((float)(point[(size_t)env * 3] - W.bxy[0]), (float)(point[(size_t)env * 3 + 1] - W.bxy[1]), (float)point[(size_t)env * 3 + 2]);
   if (lane < GQ_NVD) {

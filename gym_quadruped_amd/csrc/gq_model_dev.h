@@ -66,9 +66,44 @@ struct GqDevItem {
   float psize[3], pos[3], mat[9];
 };
 
+/* Per-lane model records (round 5): everything ONE lane of a stage needs about its dof / link / body / hinge as one contiguous,
+ * 16-byte aligned record, so that the stage's model constants arrive with one batch of wide loads issued a stage EARLY (with the
+ * env's state rows in the prologue, or in front of the previous stage's arithmetic) instead of one dependent memory round trip per
+ * field in front of the arithmetic that needs it (the actuation block alone was nine: act_of_jnt -> ctrllimited -> ctrlrange -> ...).
+ * The scalar tables they are folded from stay in the struct for the accessor kernels and the emulator's checks. */
+struct alignas(16) GqDevDofRec {   /* lane = dof d: actuation (mj_fwdActuation), passive damping, armature, friction-loss row */
+  int32_t act_u;                   /* ctrl index driving the dof's hinge, -1: none (base dofs, unactuated hinges) */
+  int32_t flags;                   /* bit 0 ctrllimited, 1 forcelimited, 2 actfrclimited */
+  float c_lo, c_hi, f_lo, f_hi, gear, a_lo, a_hi;
+  float damping, armature;
+  int32_t fl_row;                  /* friction-loss row of the dof, -1: none */
+};
+struct alignas(16) GqDevLinkRec {  /* lane = link j (hinge j, body 1 + j): local transform of mj_kinematics */
+  float bq[4];                     /* body_quat */
+  float ax[3], qpos0;              /* joint axis (body frame), reference angle */
+  float jp[3], pad0;               /* joint anchor (body frame) */
+  float aloc[3], pad1;             /* anchor in the PARENT frame: body_pos + R(body_quat) jnt_pos (state independent, folded on the host) */
+  float r0ax[3], pad2;             /* axis in the parent frame: R(body_quat) jnt_axis */
+};
+struct alignas(16) GqDevBodyRec { float ipos[3], mass, I[6], pad[2]; };   /* lane = body: spatial inertia (mj_comPos / mj_crb inputs) */
+struct alignas(16) GqDevLimRec { int32_t limited; float lo, hi, margin; }; /* lane = hinge: joint-limit test of S6 */
+
 struct GqDevModel {
   float timestep, gravity_z, impratio, meaninertia, tolerance, noise_floor;
   int32_t iterations, cone, nlg, nfl, solver;
+  /* copies of the wave-uniform scalars S5 - S9 read, next to the ones above: the step kernel fetches all of them with two wide scalar
+   * loads (StepConsts) instead of one load per field scattered over the struct */
+  int32_t hot_foot_leg[4], hot_nsp, hot_self_cut;
+  float hot_floor_mu, hot_self_margin;
+  GqDevDofRec dof_rec[GQ_NVD];
+  GqDevLinkRec link_rec[GQ_NJ];
+  GqDevBodyRec body_rec[GQ_NB];
+  GqDevLimRec lim_rec[GQ_NJ];
+  /* S3 (mj_crb), lane-parallel over the 144 stored entries of the tree-sparse joint-space inertia (Mc[12][9] | Mb[6][6], flat index
+   * e = lane + 64 pass): entry e is  S_sa . (Ic_body S_dd)  (+ armature on the diagonal) with dd the deeper dof of the pair.
+   * s3_ent: dd | sa << 8 | body(dd) << 16 | valid << 24 (slots above a link's own depth are structural zeros); s3_arm: armature or 0 */
+  int32_t s3_ent[3][64];
+  float s3_arm[3][64];
   /* bodies */
   float body_pos[GQ_NB][3], body_quat[GQ_NB][4], body_ipos[GQ_NB][3], body_mass[GQ_NB];
   float body_I[GQ_NB][6];        /* inertia tensor in the BODY frame: xx yy zz xy xz yz */

@@ -696,7 +696,7 @@ __device__ __forceinline__ float ell_state(const EllRow& E, float y, float rD, f
 #define GQ_LS_TOL 1e-2f
 #endif
 template <bool DBG, bool CONE>
-__device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, int rtype, float rR, float raref,
+__device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int fl_row_pre, const int (&hent_pre)[2], int rtype, float rR, float raref,
                                      float rfloss, int nefc, int nfl, int nsingle, int& niter, float* tdbg, const EllRow E, int prio,
                                      const bool xrow, const int xrow0) {
   const int lane = lane_id();
@@ -706,7 +706,7 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
 #define JROW() (W.u.B[opaque_lane(lane)]) /* an opaque INDEX (an opaque pointer would lose its LDS address space and turn into flat
                                            * loads); taken ONCE per use site: each expansion re-derives lane * 72 with a slow v_mul_lo_u32 */
   const float rD = fast_rcp(rR);
-  const float scale = fast_rcp(m.meaninertia * 18.0f);
+  const float scale = m.nw_scale;
   float* dq = W.qacc_int;       /* scratch 18-vectors: free until S10 */
   float* Mdq = W.qfrc_c;
   float* grad = W.act;
@@ -723,12 +723,12 @@ __device__ inline float newton_solve(WaveMem& W, const GQ_MODEL GqDevModel& m, i
   wave_barrier();
   float f = 0.0f;
   int iter = 0, exit_code = 0; /* why the loop ended (debug record, timer slot 23) */
-  const int fl_row = lane < GQ_NVD ? m.fl_row_of_dof[lane] : -1;
+  const int fl_row = lane < GQ_NVD ? fl_row_pre : -1; /* (the dof's record: fetched at the start of the step) */
   /* the two Hessian entries this lane assembles every iteration: a host table (GqDevModel::newton_hent) - decoding the entry
    * index per lane cost ~80 instructions per step */
   int hent[2];
 #pragma unroll
-  for (int pass = 0; pass < 2; pass++) hent[pass] = m.newton_hent[pass][lane];
+  for (int pass = 0; pass < 2; pass++) hent[pass] = hent_pre[pass]; /* (fetched in front of S5) */
   /* H without the elliptic virtual rows, kept in REGISTERS across the iterations (two entries per lane) together with the
    * weight every row currently has in it: an iteration adds  dw_r J_r' J_r  for the rows whose weight CHANGED - all active
    * rows in the first iteration (from M), the one to three rows that switched piece afterwards - instead of walking every

@@ -20,7 +20,7 @@ __device__ __forceinline__ float m_entry(const WaveMem& W, int i, int j) {
 }
 
 /* S1 (mj_kinematics): lanes 0-3 walk the leg chains; returns the normalised base quaternion (all lanes) */
-__device__ inline Q4 stage_kinematics(WaveMem& W, const GQ_MODEL GqDevModel& m) {
+__device__ inline Q4 stage_kinematics(WaveMem& W, const GqDevLinkRec L) { /* (by value: the callee is out of line, a reference would put the record in scratch memory) */
   const int lane = lane_id();
   Q4 qbase = {W.qb[0], W.qb[1], W.qb[2], W.qb[3]};
   qbase = qnormalize(qbase);
@@ -30,23 +30,24 @@ __device__ inline Q4 stage_kinematics(WaveMem& W, const GQ_MODEL GqDevModel& m) 
   }
   /* phase 1, lane = link (12 lanes): local transform of the link in its parent's frame - all model reads and the
    * sin/cos of the joint angle happen here, in parallel */
-  if (lane < GQ_NJ) {
-    const int b = 1 + lane, j = lane;
-    const Q4 bq = {m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2], m.body_quat[b][3]};
-    const V3 bp = ld3(m.body_pos[b]), jp = ld3(m.jnt_pos[j]), ax = ld3(m.jnt_axis[j]);
-    float R0[9], R1[9], sn, cs;
-    q2mat(R0, bq);
-    sincos_small(0.5f * (W.qj[j] - m.qpos0[j]), sn, cs);
+  if (lane < GQ_NJ) { /* (the link's record - body_quat, joint axis / anchor, and the state-independent anchor and axis in the parent
+                       * frame, folded on the host - came with the prologue's loads: no model read in front of the sin/cos) */
+    const int j = lane;
+    const Q4 bq = {L.bq[0], L.bq[1], L.bq[2], L.bq[3]};
+    const V3 jp = ld3(L.jp), ax = ld3(L.ax);
+    float R1[9], sn, cs;
+    sincos_small(0.5f * (W.qj[j] - L.qpos0), sn, cs);
     const Q4 qr = {cs, ax.x * sn, ax.y * sn, ax.z * sn};
     const Q4 ql = qmul(bq, qr);
     q2mat(R1, ql);
-    const V3 aloc = bp + matvec(R0, jp);            /* joint anchor in the parent frame */
+    const V3 aloc = ld3(L.aloc);                    /* joint anchor in the parent frame */
     const V3 ploc = aloc - matvec(R1, jp);          /* child origin: rotation about the anchor keeps it fixed */
     float* o = W.u.dyn.fkloc[lane];
     o[0] = ql.w; o[1] = ql.x; o[2] = ql.y; o[3] = ql.z;
-    st3(o + 4, ploc); st3(o + 7, aloc); st3(o + 10, matvec(R0, ax));
+    st3(o + 4, ploc); st3(o + 7, aloc); st3(o + 10, ld3(L.r0ax));
   }
   wave_barrier();
+  GQ_SUB(W, 1, 2); /* kinematics phase 1 */
   /* phase 2, lane = leg: compose the three local transforms down the chain */
   if (lane < 4) {
     float Rp[9];
@@ -76,12 +77,19 @@ __device__ inline Q4 stage_kinematics(WaveMem& W, const GQ_MODEL GqDevModel& m) 
 
 /* S6 (mj_collision, floor plane z = 0): foot sphere centres and, per link geom, the deepest cloud vertex.
  * calf_only restricts the scan to geoms of the calf bodies (reset lift loop, quadruped_env.py:376-388). */
+struct FootRec { int leg; float pos[3]; }; /* lane = foot: its leg and the sphere centre in the calf frame (fetched a stage early by the caller) */
+template <class M> __device__ __forceinline__ FootRec foot_fetch(const M& m, const int lane) {
+  const int k = lane < 4 ? lane : 3;
+  FootRec r;
+  r.leg = m.foot_leg[k]; r.pos[0] = m.foot_pos[k][0]; r.pos[1] = m.foot_pos[k][1]; r.pos[2] = m.foot_pos[k][2];
+  return r;
+}
 __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
-                                            bool calf_only) {
+                                            bool calf_only, const FootRec FR) {
   const int lane = lane_id();
   if (lane < 4) { /* feet: exact plane-sphere */
-    const int leg = m.foot_leg[lane], b = 3 + 3 * leg;
-    V3 c = ld3(W.xpos[b]) + matvec(W.xmat[b], ld3(m.foot_pos[lane]));
+    const int b = 3 + 3 * FR.leg;
+    V3 c = ld3(W.xpos[b]) + matvec(W.xmat[b], ld3(FR.pos));
     st3(W.foot_world[lane], c);
   }
   /* link geoms.  Phase 1, lane = geom: plane normal in the geom frame and the OBB lower bound of the cloud.
@@ -334,34 +342,100 @@ __device__ inline void resample_wave(const StepArgs& a, const int env) {
   }
 }
 
+/* What a wave carries from its prologue into the step: the model / batch pointers and the scalars every stage reads (in SGPRs, pinned).
+ * (The per-lane model records are NOT carried: kept in registers across the re-spawn branch between load_rows and step_wave they were
+ * spilled to scratch memory at their definition - step_wave fetches them in one batch as its first act.) */
+struct WaveCtx {
+  const GqDevModel* model; const GqDevBatch* batch;
+  float h; int nlg, nfl;
+#if GQ_TICKSET == 3
+  long long tk[4]; /* prologue stamps (development builds) */
+#endif
+  int pend, lift; /* the env's pending-respawn flag (next-step auto-reset) and lift-pending flag (gq_reset's own step): fetched with the rows */
+};
+template <class M> __device__ __forceinline__ GqDevDofRec dof_fetch(const M& m, const int lane) {
+  const int d = lane < GQ_NVD ? lane : GQ_NVD - 1;
+  GqDevDofRec r;
+  r.act_u = m.dof_rec[d].act_u; r.flags = m.dof_rec[d].flags; r.c_lo = m.dof_rec[d].c_lo; r.c_hi = m.dof_rec[d].c_hi;
+  r.f_lo = m.dof_rec[d].f_lo; r.f_hi = m.dof_rec[d].f_hi; r.gear = m.dof_rec[d].gear; r.a_lo = m.dof_rec[d].a_lo;
+  r.a_hi = m.dof_rec[d].a_hi; r.damping = m.dof_rec[d].damping; r.armature = m.dof_rec[d].armature; r.fl_row = m.dof_rec[d].fl_row;
+  return r;
+}
+template <class M> __device__ __forceinline__ GqDevBodyRec body_fetch(const M& m, const int lane) {
+  const int b = lane < GQ_NB ? lane : GQ_NB - 1;
+  GqDevBodyRec r;
+#pragma unroll
+  for (int k = 0; k < 3; k++) r.ipos[k] = m.body_rec[b].ipos[k];
+  r.mass = m.body_rec[b].mass;
+#pragma unroll
+  for (int k = 0; k < 6; k++) r.I[k] = m.body_rec[b].I[k];
+  r.pad[0] = r.pad[1] = 0.0f;
+  return r;
+}
+template <class M> __device__ __forceinline__ GqDevLinkRec link_fetch(const M& m, const int lane) {
+  const int j = lane < GQ_NJ ? lane : GQ_NJ - 1;
+  GqDevLinkRec r;
+#pragma unroll
+  for (int k = 0; k < 4; k++) r.bq[k] = m.link_rec[j].bq[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { r.ax[k] = m.link_rec[j].ax[k]; r.jp[k] = m.link_rec[j].jp[k]; r.aloc[k] = m.link_rec[j].aloc[k]; r.r0ax[k] = m.link_rec[j].r0ax[k]; }
+  r.qpos0 = m.link_rec[j].qpos0; r.pad0 = r.pad1 = r.pad2 = 0.0f;
+  return r;
+}
+
 /* S0: the env's state rows and per-env scalars, global memory -> LDS, plus the solver-load hint of the env's previous step
- * (returned).  EVERY load of a wave's prologue is issued here in one batch - one memory round trip, which the kernel overlaps
- * with its own look at the pending-reset flag; nothing loaded here stays in a register (an in-kernel respawn overwrites the rows
- * and simply calls this again).  qfrc_applied waits in W.smooth (the actuation block adds the rest to it), the clock in
- * W.force[0] (free until the solver).  user_ctrl: the caller's actions (pass 0); resets step with zero control. */
+ * (returned) and the wave's context C.  The prologue is ONE chain of three round trips, each a single batch (round 5; it was a
+ * dozen: every pointer of the argument block was fetched and waited for in front of the load that used it, the pending flag was
+ * waited for before the rows were requested, and the model constants of the first stages were fetched where they were used):
+ *   1. the sixteen prologue pointers of the argument block: two wide scalar loads, one wait (pin);
+ *   2. EVERY vector load of the prologue - pending / lift flags, state rows, scalars, the solver-load hint - plus the scalar load of
+ *      the model's constants;
+ *   3. the rows go to LDS.
+ * Nothing loaded here stays in a register except C (an in-kernel respawn overwrites the rows and simply calls this again).
+ * qfrc_applied waits in W.smooth (the actuation block adds the rest to it), the clock in W.force[0] (free until the solver).
+ * user_ctrl: the caller's actions (pass 0); resets step with zero control. */
 template <int SOLVER, bool PUB = false> /* PUB: the control row is a mailbox another wavefront wrote while this kernel runs (ld_pub) */
-__device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call, WaveMem& W, const int env, const bool user_ctrl) {
+__device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call, WaveMem& W, const int env, const bool user_ctrl, WaveCtx& C) {
   const int lane = lane_id();
-  double q = 0.0;
-  float qv = 0.0f, wm = 0.0f, ap = 0.0f, ct = 0.0f, cm = 0.0f, mu = -1.0f, tm = 0.0f;
-  int sn = 0, hint = 0;
-  if (lane < 19) q = ldv<PUB>(a.qpos + (size_t)env * 19 + lane);
-  if (lane < 18) {
-    qv = ldv<PUB>(a.qvel + (size_t)env * 18 + lane);
-    wm = ldv<PUB>(a.warm + (size_t)env * 18 + lane);
-    ap = a.applied ? ldv<PUB>(a.applied + (size_t)env * 18 + lane) : 0.0f;
+  /* ---- 1: pointers */
+  const GqDevModel* model = a.model; const GqDevBatch* batch = a.batch;
+  const double* qpos = a.qpos; const float* qvel = a.qvel; const float* warm = a.warm; const float* applied = a.applied;
+  const float* time = a.time; const float* friction = a.friction; const float* cmd = a.cmd;
+  const uint8_t* pending = a.pending; const uint8_t* hintp = a.load_hint; const int32_t* step_num = a.step_num; const uint8_t* liftp = a.lift_pending;
+  const float* ctrl = call.ctrl;
+  float hs = a.timestep; int nlg = a.nlg, nfl = a.nfl; /* (copies in the argument block: they arrive with the pointers, not behind the model pointer) */
+  int auto_reset = call.auto_reset, first_pass = call.first_pass; /* (kernel arguments: pinned too, or each use re-reads the kernarg segment) */
+  pin(auto_reset); pin(first_pass);
+  pin(model); pin(batch); pin(qpos); pin(qvel); pin(warm); pin(applied); pin(time); pin(friction); pin(cmd);
+  pin(pending); pin(hintp); pin(step_num); pin(liftp); pin(ctrl);
+  pin(hs); pin(nlg); pin(nfl);
+#if GQ_TICKSET == 3
+  C.tk[0] = cycles();
+#endif
+  /* ---- 2: one batch of loads */
+  int pend = 0, lift = 0;
+  if (auto_reset == 2 && pending) pend = (int)ldv<PUB>(pending + env);
+  if (first_pass && liftp) lift = (int)ldv<PUB>(liftp + env);
+  const int l19 = lane < 19 ? lane : 18, l18 = lane < 18 ? lane : 17, l12 = lane < 12 ? lane : 11, l4 = lane < 4 ? lane : 3;
+  const double q = ldv<PUB>(qpos + (size_t)env * 19 + l19);
+  const float qv = ldv<PUB>(qvel + (size_t)env * 18 + l18), wm = ldv<PUB>(warm + (size_t)env * 18 + l18);
+  float ap = 0.0f, ct = 0.0f, cm = 0.0f, mu = -1.0f;
+  if (applied) ap = ldv<PUB>(applied + (size_t)env * 18 + l18);
+  if (ctrl && user_ctrl) {
+    if constexpr (PUB) ct = ld_pub(ctrl + (size_t)env * 12 + l12);
+    else ct = gptr(ctrl)[(size_t)env * 12 + l12];
   }
-  if (lane < 12) {
-    if constexpr (PUB) ct = (call.ctrl && user_ctrl) ? ld_pub(call.ctrl + (size_t)env * 12 + lane) : 0.0f;
-    else ct = (call.ctrl && user_ctrl) ? gptr(call.ctrl)[(size_t)env * 12 + lane] : 0.0f;
-  }
-  if (lane < 4) cm = a.cmd ? ldv<PUB>(a.cmd + (size_t)env * 4 + lane) : 0.0f;
-  if (lane == 0) {
-    mu = a.friction ? ldv<PUB>(a.friction + env) : -1.0f;
-    sn = ldv<PUB>(a.step_num + env);
-    tm = ldv<PUB>(a.time + env);
-  }
-  if (SOLVER == 1 && a.load_hint) hint = (int)ldv<PUB>(a.load_hint + env);
+  if (cmd) cm = ldv<PUB>(cmd + (size_t)env * 4 + l4);
+  if (friction) mu = ldv<PUB>(friction + env);
+  const int sn = ldv<PUB>(step_num + env);
+  const float tm = ldv<PUB>(time + env);
+  int hint = 0;
+  if (SOLVER == 1 && hintp) hint = (int)ldv<PUB>(hintp + env);
+#if GQ_TICKSET == 3
+  C.tk[1] = cycles();
+#endif
+  C.model = model; C.batch = batch; C.h = hs; C.nlg = nlg; C.nfl = nfl;
+  /* ---- 3: rows -> LDS */
   if (lane < 19) {
     if (lane < 2) W.bxy[lane] = q;
     else if (lane == 2) W.basez = (float)q;
@@ -372,6 +446,12 @@ __device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call
   if (lane < 12) W.ctrl[lane] = ct;
   if (lane < 4) W.cmd[lane] = cm;
   if (lane == 0) { W.mu_env = mu; W.step_old = sn; W.force[0] = tm; }
+  C.pend = uniform(pend); C.lift = uniform(lift);
+  hint = uniform(hint);
+#if GQ_TICKSET == 3
+  __builtin_amdgcn_s_waitcnt(0);
+  C.tk[2] = cycles();
+#endif
   return hint;
 }
 
@@ -390,7 +470,7 @@ __device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call
  * in, it cost them 17 % (registers spilled across the box loop). */
 template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF, bool PRIM, bool PUB = false> /* PUB: the observation row is published to a
                                                                                                    * concurrently running reader (st_pub) */
-__device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift, const int hint) {
+__device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift, const int hint, const WaveCtx& C, const long long t_entry = 0) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
   int lane_o = lane_id(), env_o = wave_index() + uniform(call.env0);
@@ -398,14 +478,18 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   const int lane = lane_o, env = env_o;
   constexpr bool DBG = MODE == 1;
   constexpr bool GEN = BOXES || SELF; /* contacts carry their own frame and may join two bodies of the robot */
-  const GQ_MODEL GqDevModel& m = *mptr(a.model);
-  const float h = m.timestep;
+  const GQ_MODEL GqDevModel& m = *mptr(C.model);
+  const GQ_MODEL GqDevBatch& Bt = *mptr(C.batch);
+  const float h = C.h;
   /* the record describes the forward pass whose results the caller sees: the user's step, the reset's own step of
    * gq_reset, or the reset step of a next-step auto-reset - not the second pass of a same-step auto-reset */
   const bool rec_pass = pass == call.first_pass || pass == 2;
-  const bool timing = DBG && call.debug && rec_pass && env < mptr(a.batch)->debug_envs;
-  const long long t_start = timing ? cycles() : 0;
-#define GQ_TICK(i) do { if constexpr (DBG) { \
+  const bool timing = DBG && call.debug && rec_pass && env < Bt.debug_envs;
+  const long long t_start = timing ? ((GQ_TICKSET && t_entry) ? t_entry : cycles()) : 0; /* sub-stage builds count from kernel entry */
+#if GQ_TICKSET
+  if (lane == 0) { W.tk_T = timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr; W.tk_t0 = t_start; }
+#endif
+#define GQ_TICK(i) do { if constexpr (DBG && (GQ_TICKSET == 0 || (i) == 13 || (i) == 15)) { \
     if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + (i)] = (float)(cycles() - t_start); } \
     if constexpr (MODE == 2) { if (call.stop_stage == (i) && pass != 1) return 0; } } while (0)
 
@@ -416,6 +500,14 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     T[27] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF);          /* XCC_ID */
   }
   GQ_TICK(15); /* marker 15: nothing done yet - the launch floor */
+#if GQ_TICKSET == 3
+  if (timing && lane == 0) { float* T_ = call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER; T_[1] = (float)(C.tk[0] - t_start); T_[2] = (float)(C.tk[1] - t_start); T_[3] = (float)(C.tk[2] - t_start); T_[4] = (float)(cycles() - t_start); }
+#endif
+  /* the per-lane model records of the first three stages, one batch of wide loads (lane = dof: actuation, damping, armature; lane = link:
+   * local transform; lane = body: inertia): they were nine + five + three dependent memory round trips in front of their arithmetic */
+  const GqDevDofRec Drec = dof_fetch(m, lane);
+  const GqDevLinkRec Lrec = link_fetch(m, lane);
+  const GqDevBodyRec Brec = body_fetch(m, lane);
   /* ================================================================ S0: the env's rows wait in LDS (load_rows) */
   /* scheduling hint: an env whose previous step needed several Newton iterations will most likely need them again; its
    * wave gets issue priority from the start (the launch lasts as long as its slowest wave) */
@@ -423,46 +515,55 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   bool fwd_only = false; /* gq_forward (mj_step1 / mj_forward): no state is advanced */
   if constexpr (DBG) fwd_only = call.forward != 0;
   wave_barrier();
+  GQ_SUB(W, 1, 0); /* kernel entry -> rows in LDS */
+  GQ_SUB(W, 3, 4);
   /* the clock and the step counter advance here (stores only: their old values came with the rows) */
-  if (lane == 0 && !fwd_only) {
-    const int32_t sn = W.step_old;
-    gptr(a.step_num)[env] = sn + 1;
-    if (a.step_prev) gptr(a.step_prev)[env] = sn;
-    gptr(a.time)[env] = W.force[0] + h;
+  {
+    int32_t* s_num = a.step_num; int32_t* s_prev = a.step_prev; float* s_time = a.time;
+    pin(s_num); pin(s_prev); pin(s_time);
+    if (lane == 0 && !fwd_only) {
+      const int32_t sn = W.step_old;
+      gptr(s_num)[env] = sn + 1;
+      if (s_prev) gptr(s_prev)[env] = sn;
+      gptr(s_time)[env] = W.force[0] + h;
+    }
   }
 
   /* actuation (mj_fwdActuation: torque motors) and passive damping depend on ctrl / qvel and model constants only: done
    * here, so that the (two-level dependent) model loads overlap with the kinematics instead of sitting on S5's path */
-  if (lane < GQ_NVD) {
+  if (lane < GQ_NVD) { /* (the dof's record came with the prologue's loads; the limits are selects, not branches) */
+    const GqDevDofRec& D = Drec;
     float act = 0.0f;
-    if (lane >= 6) {
-      const int j = lane - 6, u = m.act_of_jnt[j];
-      if (u >= 0) {
-        float c = W.ctrl[u];
-        if (m.act_ctrllimited[j]) c = fminf(fmaxf(c, m.act_ctrlrange[j][0]), m.act_ctrlrange[j][1]);
-        if (m.act_forcelimited[j]) c = fminf(fmaxf(c, m.act_forcerange[j][0]), m.act_forcerange[j][1]);
-        act = m.act_gear[j] * c;
-      }
-      if (m.jnt_actfrclimited[j]) act = fminf(fmaxf(act, m.jnt_actfrcrange[j][0]), m.jnt_actfrcrange[j][1]);
+    {
+      const int u = D.act_u;
+      float c = W.ctrl[u >= 0 ? u : 0];
+      c = (D.flags & 1) ? fminf(fmaxf(c, D.c_lo), D.c_hi) : c;
+      c = (D.flags & 2) ? fminf(fmaxf(c, D.f_lo), D.f_hi) : c;
+      act = u >= 0 ? D.gear * c : 0.0f;
+      act = (D.flags & 4) ? fminf(fmaxf(act, D.a_lo), D.a_hi) : act;
     }
     W.act[lane] = act;
-    const float damp = m.dof_damping[lane];
+    const float damp = D.damping;
     if constexpr (SOLVER == 1) W.F[0][lane] = h * damp; /* the Newton path stores no factor: F keeps h*damping for the Euler system (S10) */
     W.smooth[lane] = -damp * W.qvel[lane] + act + W.smooth[lane]; /* qfrc_applied waits there */
   }
+  GQ_SUB(W, 1, 1); /* actuation + passive */
   if constexpr (SOLVER == 1) wave_priority(prio_hint);
   if constexpr (DBG) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 28] = (float)prio_hint;
-  stage_kinematics(W, m);
+  stage_kinematics(W, Lrec);
 
-  GQ_TICK(1);
+  GQ_TICK(1); GQ_SUB(W, 1, 3);
   /* ================================================================ S2: spatial inertias about O = base origin */
+  int s3e[3]; float s3a[3]; /* the lane's three entries of S3: fetched now, in flight during S2 */
+#pragma unroll
+  for (int p = 0; p < 3; p++) { s3e[p] = m.s3_ent[p][lane]; s3a[p] = m.s3_arm[p][lane]; }
   const V3 O = v3(0.0f, 0.0f, W.basez);
   if (lane < GQ_NB) {
     const int b = lane;
     const float* R = W.xmat[b];
-    V3 d = ld3(W.xpos[b]) + matvec(R, ld3(m.body_ipos[b])) - O;
+    V3 d = ld3(W.xpos[b]) + matvec(R, ld3(Brec.ipos)) - O;
     /* I_w = R Ib R' */
-    const GQ_MODEL float* Ib = m.body_I[b];
+    const float* Ib = Brec.I;
     float A[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]}, T[9], Iw[9];
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -472,7 +573,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int c = 0; c < 3; c++) Iw[3 * r + c] = T[3 * r] * R[3 * c] + T[3 * r + 1] * R[3 * c + 1] + T[3 * r + 2] * R[3 * c + 2];
-    float mb = m.body_mass[b], dd = dot(d, d);
+    float mb = Brec.mass, dd = dot(d, d);
     float* ci = W.u.dyn.cinert[b];
     ci[0] = Iw[0] + mb * (dd - d.x * d.x); ci[1] = Iw[4] + mb * (dd - d.y * d.y); ci[2] = Iw[8] + mb * (dd - d.z * d.z);
     ci[3] = Iw[1] - mb * d.x * d.y; ci[4] = Iw[2] - mb * d.x * d.z; ci[5] = Iw[5] - mb * d.y * d.z;
@@ -504,22 +605,29 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   if (lane < 10) W.u.dyn.crb[0][lane] = W.u.dyn.cinert[0][lane] + W.u.dyn.crb[1][lane] + W.u.dyn.crb[4][lane] + W.u.dyn.crb[7][lane] + W.u.dyn.crb[10][lane];
   wave_barrier();
 
-  GQ_TICK(2);
+  GQ_TICK(2); GQ_SUB(W, 1, 4);
   /* ================================================================ S3: joint-space inertia */
-  if (lane < GQ_NVD) {
-    float buf[6];
-    mul_inert(buf, W.u.dyn.crb[dof_body(lane)], W.cdof[lane]);
-    for (int j = lane; j >= 0; j = dof_parent(j)) {
-      const float* s = W.cdof[j];
-      float v = s[0] * buf[0] + s[1] * buf[1] + s[2] * buf[2] + s[3] * buf[3] + s[4] * buf[4] + s[5] * buf[5];
-      if (j == lane) v += m.dof_armature[lane];
-      if (lane < 6) { W.Mb[lane][j] = v; W.Mb[j][lane] = v; }
-      else W.Mc[lane - 6][j < 6 ? j : 6 + (j - 6) % 3] = v;
+  /* lane = stored entry (three per lane: 108 of the legs' rows + the full 6x6 base block), all of them independent - every lane's LDS
+   * reads are in flight together.  (Round 4: lane = dof walked up its ancestors in a divergent loop, one LDS round trip and two
+   * exec-mask branches per ancestor: 5 k cycles for a lone wave.)  Same operands in the same order: the values are the old ones. */
+  {
+    static_assert(sizeof(WaveMem::Mc) == 108 * 4 && offsetof(WaveMem, Mb) == offsetof(WaveMem, Mc) + sizeof(WaveMem::Mc), "S3 writes Mc | Mb as one flat array");
+    float* M0 = &W.Mc[0][0];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      if (p < 2 || lane < 144 - 2 * GQ_WAVE) {
+        const int ent = s3e[p], dd = ent & 0xff, sa = (ent >> 8) & 0xff, bd = (ent >> 16) & 0xff;
+        float buf[6];
+        mul_inert(buf, W.u.dyn.crb[bd], W.cdof[dd]);
+        const float* sv = W.cdof[sa];
+        const float v = sv[0] * buf[0] + sv[1] * buf[1] + sv[2] * buf[2] + sv[3] * buf[3] + sv[4] * buf[4] + sv[5] * buf[5];
+        M0[lane + GQ_WAVE * p] = (ent >> 24) ? v + s3a[p] : 0.0f;
+      }
     }
   }
   wave_barrier();
 
-  GQ_TICK(3);
+  GQ_TICK(3); GQ_SUB(W, 1, 5);
   /* ================================================================ S4: factorise M and M + h*D */
   /* (the Newton path solves its three systems with the fused elimination (gq_newton.h) and stores no factor.  PGS on a scene with world
    * geoms / robot self-collision: the collision stages use the factors' LDS as scratch (gq_boxes.h GQ_BX_*), so the factors are taken
@@ -528,8 +636,28 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
 
   GQ_TICK(4);
   /* the lane's collision item (S6: lane = item) is fetched now: its loads are in flight during the velocity stage */
-  const int nlg = m.nlg;
+  const int nlg = C.nlg;
   const ItemRegs IT = item_fetch(m, lane < 4 + nlg ? lane : 0);
+  /* with it, everything else S6 - S9 read from the model per lane (joint-limit record, friction-loss row, the lane's two Hessian entries,
+   * the foot record) and per wave (StepConsts: scalar loads, pinned) - one batch in front of the velocity stage */
+  const FootRec FRec = foot_fetch(m, lane);
+  const int l12_ = lane < GQ_NJ ? lane : GQ_NJ - 1, l18_ = lane < GQ_NVD ? lane : GQ_NVD - 1;
+  const int lim_on = m.lim_rec[l12_].limited; const float lim_lo_ = m.lim_rec[l12_].lo, lim_hi_ = m.lim_rec[l12_].hi, lim_mg = m.lim_rec[l12_].margin;
+  const int flr_dof = m.fl_row[l18_].dof; const float flr_R = m.fl_row[l18_].R, flr_B = m.fl_row[l18_].B, flr_floss = m.fl_row[l18_].floss;
+  int hent_pre[2];
+  if constexpr (SOLVER == 1) { hent_pre[0] = m.newton_hent[0][lane]; hent_pre[1] = m.newton_hent[1][lane]; } else { hent_pre[0] = hent_pre[1] = 0; }
+  StepConsts K;
+  {
+    int fl0 = m.hot_foot_leg[0], fl1 = m.hot_foot_leg[1], fl2 = m.hot_foot_leg[2], fl3 = m.hot_foot_leg[3], its = m.iterations, nsp = m.hot_nsp, scut = m.hot_self_cut;
+    float fmu = m.hot_floor_mu, imr = m.impratio, gz = m.gravity_z, mi = m.meaninertia, tol = m.tolerance, nf = m.noise_floor, smg = m.hot_self_margin;
+    const GQ_MODEL float* vxq = mptr(a.vx); const GQ_MODEL float* vyq = mptr(a.vy); const GQ_MODEL float* vzq = mptr(a.vz);
+    pin(fl0); pin(fl1); pin(fl2); pin(fl3); pin(its); pin(nsp); pin(scut); pin(fmu); pin(imr); pin(gz); pin(mi); pin(tol); pin(nf); pin(smg);
+    pin(vxq); pin(vyq); pin(vzq);
+    K.foot_leg[0] = fl0; K.foot_leg[1] = fl1; K.foot_leg[2] = fl2; K.foot_leg[3] = fl3; K.iterations = its; K.nsp = nsp; K.self_cut = scut;
+    K.floor_mu = fmu; K.impratio_rs = fast_rsqrt(imr); K.gravity_z = gz; K.nw_scale = fast_rcp(mi * 18.0f); K.tolerance = tol; K.noise_floor = nf; K.self_margin = smg;
+    K.vx = vxq; K.vy = vyq; K.vz = vzq;
+  }
+  const GQ_MODEL float* vx_p = K.vx; const GQ_MODEL float* vy_p = K.vy; const GQ_MODEL float* vz_p = K.vz;
   /* ================================================================ S5: velocity stage (mj_comVel, mj_rne) */
   if (lane < 4) {
     /* base velocity and bias acceleration, recomputed per leg lane */
@@ -540,7 +668,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       V3 ww = matvec(R, wl), vl = v3(W.qvel[0], W.qvel[1], W.qvel[2]);
       st3(vb, ww); st3(vb + 3, vl);
       V3 al = cross(vl, ww);
-      ab[0] = ab[1] = ab[2] = 0.0f; ab[3] = al.x; ab[4] = al.y; ab[5] = al.z - m.gravity_z;
+      ab[0] = ab[1] = ab[2] = 0.0f; ab[3] = al.x; ab[4] = al.y; ab[5] = al.z - K.gravity_z;
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 6; k++) { W.u.dyn.cvel[0][k] = vb[k]; W.u.dyn.cacc[0][k] = ab[k]; }
@@ -581,11 +709,12 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     W.smooth[lane] -= bias; /* passive + actuation + applied were put there right after S0 */
   }
 
-  GQ_TICK(5);
+  GQ_TICK(5); GQ_SUB(W, 1, 6);
   /* ================================================================ S6: collision with the floor (z = 0) */
   SelfPrefetch self_pre;
-  if constexpr (SELF && !BOXES) self_pre = self_prefetch(m); /* (world-box variants fetch it behind the box loop: 18 registers less across it) */
-  stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), false);
+  if constexpr (SELF && !BOXES) self_pre = self_prefetch(m, nlg, K.nsp); /* (world-box variants fetch it behind the box loop: 18 registers less across it) */
+  stage_collision_scan(W, m, vx_p, vy_p, vz_p, false, FRec);
+  GQ_SUB(W, 1, 7); /* hull cloud scan */
   /* reset on a scene without world boxes / height field: the lift loop of QuadrupedEnv.reset (quadruped_env.py:376-388:
    * z += 1.1 max|dist| until no foot-body contact, <= 100 iterations) runs HERE, on the distances this step's own
    * kinematics and collision scan just produced, instead of on a kinematics + scan pass of its own inside reset_wave: on
@@ -638,7 +767,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     for (int k = 0; k < 4; k++) { FC.dist[k] += dz; FC.pt[k].z += dz; }
     wave_barrier();
   }
-  GQ_TICK(14);
+  GQ_TICK(14); GQ_SUB(W, 1, 8); /* floor candidates (+ lift) */
   /* the dynamics row (gq_batch_set_outputs): what the reference reads from mjData after the step for model-based control -
    * mj_fullM, qfrc_bias, body poses, the foot points - straight out of LDS, production kernel */
   if (a.dyn && rec_pass) { /* wave-uniform */
@@ -669,14 +798,14 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     const int invalid = ballot(touching && !calf) != 0;
     int ftm = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) ftm |= (ballot(touching && body == 3 + 3 * m.foot_leg[k]) != 0) ? (1 << k) : 0;
+    for (int k = 0; k < 4; k++) ftm |= (ballot(touching && body == 3 + 3 * K.foot_leg[k]) != 0) ? (1 << k) : 0;
     /* joint limits: lane j < 12 owns hinge j (lower side first, then upper) */
     bool lim_lo = false, lim_hi = false;
     float dlo = 0.0f, dhi = 0.0f;
-    if (lane < GQ_NJ && m.jnt_limited[lane]) {
+    if (lane < GQ_NJ && lim_on) {
       const float q = W.qj[lane];
-      dlo = q - m.jnt_range[lane][0]; dhi = m.jnt_range[lane][1] - q;
-      lim_lo = dlo < m.jnt_margin[lane]; lim_hi = dhi < m.jnt_margin[lane];
+      dlo = q - lim_lo_; dhi = lim_hi_ - q;
+      lim_lo = dlo < lim_mg; lim_hi = dhi < lim_mg;
     }
     const uint64_t mlo = ballot(lim_lo), mhi = ballot(lim_hi);
     int nl = popc64(mlo) + popc64(mhi);
@@ -695,9 +824,9 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     const int packed = cnt | ((cnt * need) << 8) | ((cnt * vres) << 18);
     const int incl = wave_incl_scan(packed);
     const int excl = incl - packed;
-    const int idx0 = excl & 0xff, rows0 = m.nfl + nl + ((excl >> 8) & 0x3ff), res0 = (excl >> 18) & 0x3ff;
+    const int idx0 = excl & 0xff, rows0 = C.nfl + nl + ((excl >> 8) & 0x3ff), res0 = (excl >> 18) & 0x3ff;
     const float mu_env = W.mu_env;
-    const float ff = mu_env >= 0.0f ? mu_env : m.floor_friction[0];
+    const float ff = mu_env >= 0.0f ? mu_env : K.floor_mu;
     /* friction mixing; _set_ground_friction overrides floor and feet with [mu, 0.005, 0] (quadruped_env.py:1292) */
     const float fg = (code < 4 && mu_env >= 0.0f) ? mu_env : fgeom;
     const float mu = fmaxf(1e-5f, fric_rule == 0 ? fmaxf(ff, fg) : (fric_rule == 1 ? ff : fg)); /* mjMINMU */
@@ -726,27 +855,28 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8)), 63);
     if (lane == GQ_WAVE - 1) W.ndrop = (incl & 0xff) - (tot & 0xff); /* lane 63's inclusive sum = every touching candidate of the floor pass */
     if (lane == 0) {
-      W.ncon = tot & 0xff; W.nlim = nl; W.nefc = m.nfl + nl + (tot >> 8); W.invalid = invalid;
+      W.ncon = tot & 0xff; W.nlim = nl; W.nefc = C.nfl + nl + (tot >> 8); W.invalid = invalid;
       W.foot_touch = ftm;
     }
   }
   wave_barrier();
+  GQ_SUB(W, 1, 9); /* floor contact list, limits */
   if constexpr (BOXES) {
     const double bx0 = W.bxy[0], by0 = W.bxy[1]; /* base x/y of this forward pass, f64 */
     const float mu_b = W.mu_env;
-    stage_box_contacts<CONE, SELF, PRIM>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), bx0, by0, mu_b, self_pre, IT);
+    stage_box_contacts<CONE, SELF, PRIM>(W, m, vx_p, vy_p, vz_p, bx0, by0, mu_b, self_pre, IT, K, nlg);
   } else if constexpr (SELF) {
     const float mu_b = W.mu_env;
-    stage_self_contacts<CONE>(W, m, mu_b, self_pre);
+    stage_self_contacts<CONE>(W, m, mu_b, self_pre, K, nlg);
   }
-  const int nefc = uniform(W.nefc), ncon = uniform(W.ncon), nlim = uniform(W.nlim), nfl = m.nfl; /* SGPRs */
+  const int nefc = uniform(W.nefc), ncon = uniform(W.ncon), nlim = uniform(W.nlim), nfl = C.nfl; /* SGPRs */
   if (timing) { /* body poses go to the debug record now: xmat's LDS is reused by the Newton solver */
     float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
     if (lane < 39) D[GQ_DBG_XPOS + lane] = W.xpos[lane / 3][lane % 3];
     for (int k = lane; k < 117; k += GQ_WAVE) D[GQ_DBG_XMAT + k] = W.xmat[k / 9][k % 9];
   }
 
-  GQ_TICK(6);
+  GQ_TICK(6); GQ_SUB(W, 1, 12); GQ_SUB(W, 2, 0);
   /* ================================================================ S7: constraint rows, lane = row */
   /* per-lane row descriptor first (what kind of row, which dof / contact direction), then ONE unrolled sweep over the
    * 18 dofs produces the J entries for every row kind at once: J[k] = cdof[k] . [p x dir ; dir] on the contact's chain,
@@ -767,8 +897,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   bool jcon = false;
   V3 dir = v3(0.0f, 0.0f, 0.0f), w = v3(0.0f, 0.0f, 0.0f);
   if (lane < nfl) {
-    rtype = ROW_FRICTION; rfloss = m.fl_row[lane].floss; flR = m.fl_row[lane].R; flB = m.fl_row[lane].B;
-    jd = m.fl_row[lane].dof; jsgn = 1.0f;
+    rtype = ROW_FRICTION; rfloss = flr_floss; flR = flr_R; flB = flr_B;
+    jd = flr_dof; jsgn = 1.0f;
   } else if (lane < nfl + nlim) {
     const int r = lane - nfl, j = W.u2.c.lim_jnt[r], d = 6 + j;
     rtype = ROW_LIMIT; rpos = W.u2.c.lim_dist[r]; rmargin = m.jnt_margin[j]; rdiag = m.dof_invweight0[d];
@@ -805,7 +935,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     else if constexpr (CONE) {
       rtype = ROW_ELLIPTIC; ecode = e | (dim << 4); er0 = W.con_row[c];
       econ_dist = rpos; econ_inc = rmargin;
-      emu = mu * fast_rsqrt(m.impratio);
+      emu = mu * K.impratio_rs;
       /* torsional / rolling coefficients: same mixing rule as the sliding one (S6), _set_ground_friction overrides
        * floor and feet with [mu, 0.005, 0.0]; clamped at mjMINMU */
       const int cword = W.con_geom[c], code = GEN ? (cword & 0xff) : cword, code1 = GEN ? ((cword >> 8) & 0xff) - 1 : -1;
@@ -837,15 +967,58 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       dir = cn + sgn * ((e >> 1) == 0 ? ct1 : ct2);
       rdiag = tran + mu * mu * tran;
       rdiag_first = rdiag;
-      rmu = mu * fast_rsqrt(m.impratio);
+      rmu = mu * K.impratio_rs;
     }
     w = cross(ld3(W.con_pos[c]) - v3(0.0f, 0.0f, W.basez), dir); /* O re-read: not kept live across the stages */
     if (rotational) { w = dir; dir = v3(0.0f, 0.0f, 0.0f); } /* torsion / rolling rows act on the angular Jacobian */
     jcon = true;
     if (body > 0) { jleg = (body - 1) / 3; jdepth = (body - 1) % 3; }
   }
+  GQ_SUB(W, 2, 1); /* row descriptors */
   float J[SOLVER == 1 ? 1 : GQ_NVD];
   float vel = 0.0f;
+  if constexpr (SOLVER == 1) {
+    /* Newton: the row goes straight to LDS.  A contact row has at most nine non-zeros - the six base dofs and the dofs of the contact
+     * body's own leg down to its depth - so the sweep walks those nine (six wave-uniform reads of cdof, three per-lane gathers) over a
+     * zero-filled row instead of all eighteen dofs with a three-way select each (round 4: 324 instructions, 3.6 k cycles for a lone wave);
+     * single-entry rows (friction loss, limits) drop their +-1 on top.  Same products in the same order: the values are the old ones. */
+    float* Jr = W.u.B[lane];
+#pragma unroll
+    for (int k = 0; k < GQ_NVD; k++) Jr[k] = 0.0f; /* (rows >= nefc stay all-zero: rtype NONE sets no descriptor) */
+    const bool base_on = jcon && !internal; /* robot-robot rows: the base columns cancel */
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const float* sd = W.cdof[k]; /* wave-uniform LDS reads */
+      float v = sd[0] * w.x + sd[1] * w.y + sd[2] * w.z + sd[3] * dir.x + sd[4] * dir.y + sd[5] * dir.z;
+      v = base_on ? v : 0.0f;
+      vel += v * W.qvel[k];
+      Jr[k] = v;
+    }
+    {
+      const int k0 = 6 + 3 * (jleg < 0 ? 0 : jleg);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const float* sd = W.cdof[k0 + i]; /* per-lane gather */
+        float v = sd[0] * w.x + sd[1] * w.y + sd[2] * w.z + sd[3] * dir.x + sd[4] * dir.y + sd[5] * dir.z;
+        v = (jcon && jleg >= 0 && i <= jdepth) ? v : 0.0f;
+        vel += v * W.qvel[k0 + i];
+        Jr[k0 + i] = v;
+      }
+    }
+    if (jd >= 0) { Jr[jd] = jsgn; vel += jsgn * W.qvel[jd]; } /* (LDS executes a lane's writes in order: this lands on top of the zero) */
+    if constexpr (SELF) if (uniform(W.nself) > 0) { /* wave-uniform, rare: J(second body) - J(first body) at the contact point - the chain of
+                                                     * the contact's first body enters with a minus sign (dofs the two chains share cancel) */
+      const int k1 = 6 + 3 * (jleg1 < 0 ? 0 : jleg1);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const float* sd = W.cdof[k1 + i];
+        const bool on1 = internal && jleg1 >= 0 && i <= jdepth1;
+        const float v1 = on1 ? sd[0] * w.x + sd[1] * w.y + sd[2] * w.z + sd[3] * dir.x + sd[4] * dir.y + sd[5] * dir.z : 0.0f;
+        vel -= v1 * W.qvel[k1 + i];
+        Jr[k1 + i] -= v1;
+      }
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < GQ_NVD; k++) {
     const float* sd = W.cdof[k]; /* wave-uniform LDS reads */
@@ -869,6 +1042,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       else J[k] -= v1;
     }
   }
+  }
+  GQ_SUB(W, 2, 2); /* J sweep */
   float rR = 1.0f, raref = 0.0f;
   if (rtype == ROW_FRICTION) { rR = flR; raref = -flB * vel; }
   else if (rtype != ROW_NONE) {
@@ -894,13 +1069,13 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     }
   }
 
-  GQ_TICK(7);
+  GQ_TICK(7); GQ_SUB(W, 2, 3); /* impedance, R, aref */
   const bool active = lane < nefc;
   float b_i = 0.0f;
   int iter = 0;
   /* inspection record of this forward pass (instrumented variant): `solved` = the solver and the accelerations are done */
   auto dump_record = [&](const bool solved, const float raref_, const float rR_, const int rtype_, const int iter_) {
-    if constexpr (DBG) if (call.debug && rec_pass && env < mptr(a.batch)->debug_envs) {
+    if constexpr (DBG) if (call.debug && rec_pass && env < Bt.debug_envs) {
     float* D = call.debug + (size_t)env * GQ_DBG_SIZE;
     for (int k = lane; k < 324; k += GQ_WAVE) D[GQ_DBG_M + k] = m_entry(W, k / 18, k % 18);
     if (lane < 18) {
@@ -928,6 +1103,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   }
 
   float pgs_keep = 0.0f;
+  int hint_out = 0; /* solver load of this step: the env's issue-priority hint for its next one */
   if constexpr (SOLVER == 1) {
     /* ================================================================ S8/S9 (Newton): primal solve, no dual operator */
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
@@ -935,16 +1111,17 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     const EllRow ell = {ecode, er0, efri, emu, fast_rcp(eR0)};
     /* a contact between two different legs couples them in the Hessian M + J'DJ, which then no longer has M's tree
      * sparsity: such an env takes the dense Newton step */
-    const bool xrow = SELF && internal && jleg1 >= 0 && jleg >= 0 && jleg1 != jleg && m.self_cut != 3;
+    const bool xrow = SELF && internal && jleg1 >= 0 && jleg >= 0 && jleg1 != jleg && K.self_cut != 3;
     const bool xleg = SELF && ballot(xrow) != 0;
     if constexpr (DBG && SELF) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 31] = (float)(uniform(W.nself) + (xleg ? 100 : 0));
-    const float fN = newton_solve<DBG, CONE>(W, m, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
+    const float fN = newton_solve<DBG, CONE>(W, K, Drec.fl_row, hent_pre, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
                                   timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint, xrow,
                                   xleg ? uniform(W.con_row[ncon - uniform(W.nself)]) : -1);
     /* a coupled-leg Newton step (Sherman-Morrison / dense) is the most expensive thing a wave can do, and leg-leg contacts
      * persist over several steps: such an env keeps top issue priority */
-    if constexpr (CONE) { if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)(iter >= 8 ? 3 : (iter >= 6 ? 2 : (iter >= 4 ? 1 : 0))); } /* see newton_solve */
-    else if (a.load_hint && lane == 0) gptr(a.load_hint)[env] = (uint8_t)((xleg && iter >= 2) ? 3 : (iter < 2 ? 0 : (iter > 2 ? 3 : 2)));
+    /* (stored with the epilogue's batch of pointers, below) */
+    if constexpr (CONE) hint_out = iter >= 8 ? 3 : (iter >= 6 ? 2 : (iter >= 4 ? 1 : 0)); /* see newton_solve */
+    else hint_out = (xleg && iter >= 2) ? 3 : (iter < 2 ? 0 : (iter > 2 ? 3 : 2));
     W.force[lane] = active ? fN : 0.0f;
     wave_barrier();
   } else {
@@ -1021,12 +1198,12 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     if (cost > 0.0f) { f = 0.0f; r = b_i; }
   }
   if (!active) r = 0.0f;
-  const float scale = 1.0f / (m.meaninertia * 18.0f);
+  const float scale = K.nw_scale;
   /* fold R into the diagonal: lane i's own column entry becomes (A+R)_ii, so the residual update below is one
    * uniform FMA for every lane */
 #pragma unroll
   for (int j = 0; j < GQ_MAXEFC; j++) A[j] = (j == lane) ? ARii : A[j];
-  for (; iter < m.iterations; iter++) {
+  for (; iter < K.iterations; iter++) {
     float imp_acc = 0.0f;
     int lane_s = lane;
     opaque(lane_s); /* keeps the 63 (lane == i) predicates from being hoisted out of the sweep loop as live masks */
@@ -1046,13 +1223,13 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       }
     }
     float improvement = wave_sum(imp_acc);
-    if (improvement * scale < m.tolerance) { iter++; break; }
+    if (improvement * scale < K.tolerance) { iter++; break; }
   }
   W.force[lane] = active ? f : 0.0f;
   wave_barrier();
   pgs_keep = keep_scr;
   }
-  GQ_TICK(9);
+  GQ_TICK(9); GQ_SUB(W, 2, 4); /* solver */
   /* ================================================================ S10: accelerations and integration */
   if constexpr (SOLVER == 1) {
     /* qacc and qfrc_constraint (= M (qacc - qacc_smooth)) come out of the Newton solve; only the Euler system
@@ -1101,17 +1278,29 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     return 0;
   }
 
-  GQ_TICK(10);
+  GQ_TICK(10); GQ_SUB(W, 2, 5); /* Euler system */
+  /* ---- the epilogue's pointers and batch / model scalars: ONE batch of scalar loads, pinned (round 5; every store below used to fetch
+   * its pointer - and the time step, five times - in front of itself: ~25 exposed scalar-cache round trips between here and the end) */
+  double* e_qpos = a.qpos; float* e_qvel = a.qvel; float* e_qacc = a.qacc; float* e_warm = a.warm; float* e_obs = a.obs; float* e_reward = a.reward;
+  uint8_t* e_term = a.terminated; uint8_t* e_trunc = a.truncated; uint8_t* e_inval = a.invalid_contact; uint8_t* e_pending = a.pending;
+  int32_t* e_dropped = a.contacts_dropped; float* e_imu_bias = a.imu_bias; float* e_contacts = a.contacts; int32_t* e_h9 = a.h9;
+  float* e_obs_seq = call.obs_seq; uint8_t* e_hint = a.load_hint;
+  int od = Bt.obs_dim, obs_need = Bt.obs_need, imu_en = Bt.imu_enabled;
+  double tlim0 = m.terrain_limits[0], tlim1 = m.terrain_limits[1], tlim2 = m.terrain_limits[2], tlim3 = m.terrain_limits[3];
+  pin(e_qpos); pin(e_qvel); pin(e_qacc); pin(e_warm); pin(e_obs); pin(e_reward); pin(e_term); pin(e_trunc); pin(e_inval); pin(e_pending);
+  pin(e_dropped); pin(e_imu_bias); pin(e_contacts); pin(e_h9); pin(e_obs_seq); pin(e_hint); pin(od); pin(obs_need); pin(imu_en);
+  pin(tlim0); pin(tlim1); pin(tlim2); pin(tlim3);
   /* the output layout (column -> canonical scalar) of this lane's columns: fetched now, used by the gather at the end */
-  const int od = mptr(a.batch)->obs_dim, obs_need = mptr(a.batch)->obs_need;
-  int omap[4];
+  int omap[4], s3k[3];
 #pragma unroll
-  for (int i = 0; i < 4; i++) { const int k = lane + GQ_WAVE * i; omap[i] = k < od ? mptr(a.batch)->obs_map[k] : 0; }
+  for (int i = 0; i < 4; i++) { const int k = lane + GQ_WAVE * i; omap[i] = k < od ? Bt.obs_map[k] : 0; }
+#pragma unroll
+  for (int p = 0; p < 3; p++) s3k[p] = (SOLVER == 1 && (obs_need & GQ_NEED_ENERGY)) ? m.s3_ent[p][lane] : 0; /* the energy sums walk M's stored entries */
   /* IMU ground truth (mj_sensorAcc / mj_sensorVel of this forward pass: OLD pose and velocity, this step's qacc).
    * accelerometer = site-frame acceleration of the site point minus gravity; gyro = site-frame angular velocity */
-  const bool imu_on = a.imu_bias != nullptr && mptr(a.batch)->imu_enabled;
+  const bool imu_on = e_imu_bias != nullptr && imu_en;
   if (imu_on && lane == 0) {
-    const GQ_MODEL GqDevBatch& B = *mptr(a.batch);
+    const GQ_MODEL GqDevBatch& B = Bt;
     Q4 qo = {W.qb[0], W.qb[1], W.qb[2], W.qb[3]};
     float Ro[9];
     q2mat(Ro, qnormalize(qo));
@@ -1119,7 +1308,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     const V3 ww = matvec(Ro, wb), aw = matvec(Ro, v3(W.qacc[3], W.qacc[4], W.qacc[5]));
     const V3 r = matvec(Ro, ld3(B.imu_pos));
     V3 ap = v3(W.qacc[0], W.qacc[1], W.qacc[2]) + cross(aw, r) + cross(ww, cross(ww, r));
-    ap.z -= m.gravity_z;
+    ap.z -= K.gravity_z;
     const V3 acc_s = matTvec(B.imu_mat, matTvec(Ro, ap)), gyr_s = matTvec(B.imu_mat, wb);
     W.warm[0] = acc_s.x; W.warm[1] = acc_s.y; W.warm[2] = acc_s.z; W.warm[3] = gyr_s.x; W.warm[4] = gyr_s.y; W.warm[5] = gyr_s.z;
   }
@@ -1134,9 +1323,9 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     if (diverged) { W.qacc[lane] = 0.0f; W.qacc_int[lane] = 0.0f; }
     vnew = W.qvel[lane] + h * W.qacc_int[lane];
     if (!(fabsf(vnew) < 1e10f)) vnew = 0.0f;
-    gptr(a.qvel)[(size_t)env * 18 + lane] = vnew;
-    gptr(a.qacc)[(size_t)env * 18 + lane] = W.qacc[lane];
-    gptr(a.warm)[(size_t)env * 18 + lane] = W.qacc[lane];
+    gptr(e_qvel)[(size_t)env * 18 + lane] = vnew;
+    gptr(e_qacc)[(size_t)env * 18 + lane] = W.qacc[lane];
+    gptr(e_warm)[(size_t)env * 18 + lane] = W.qacc[lane];
   }
   /* base x,y stay in f64 (uniform: every lane reads the same two words) and never enter fp32 arithmetic; they wait
    * in LDS since S0, so they do not occupy registers across the solver */
@@ -1146,8 +1335,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   wave_barrier();
   /* positions */
   const double bxn_d = bx_d + (double)h * (double)W.qvel[0], byn_d = by_d + (double)h * (double)W.qvel[1];
-  if (lane == 0) gptr(a.qpos)[(size_t)env * 19 + 0] = bxn_d;
-  if (lane == 1) gptr(a.qpos)[(size_t)env * 19 + 1] = byn_d;
+  if (lane == 0) gptr(e_qpos)[(size_t)env * 19 + 0] = bxn_d;
+  if (lane == 1) gptr(e_qpos)[(size_t)env * 19 + 1] = byn_d;
   const float znew = W.basez + h * W.qvel[2];
   Q4 qn;
   {
@@ -1167,18 +1356,18 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     }
     qn = qnormalize(qn);
   }
-  if (lane == 2) gptr(a.qpos)[(size_t)env * 19 + 2] = (double)znew;
+  if (lane == 2) gptr(e_qpos)[(size_t)env * 19 + 2] = (double)znew;
   if (lane >= 3 && lane < 7) {
     float qc = lane == 3 ? qn.w : (lane == 4 ? qn.x : (lane == 5 ? qn.y : qn.z));
-    gptr(a.qpos)[(size_t)env * 19 + lane] = (double)qc;
+    gptr(e_qpos)[(size_t)env * 19 + lane] = (double)qc;
   }
   float qjn = 0.0f;
   if (lane >= 7 && lane < 19) {
     qjn = W.qj[lane - 7] + h * W.qvel[lane - 1];
-    gptr(a.qpos)[(size_t)env * 19 + lane] = (double)qjn;
+    gptr(e_qpos)[(size_t)env * 19 + lane] = (double)qjn;
   }
 
-  GQ_TICK(11);
+  GQ_TICK(11); GQ_SUB(W, 2, 6); /* integration + state stores */
   /* ================================================================ S11: observations (new qpos/qvel, old kinematics) */
   float Rn[9];
   q2mat(Rn, qn);
@@ -1218,22 +1407,39 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     st3(ob + OB_ANG_VEL_B, wloc); st3(ob + OB_ANG_VEL_ERR_B, matTvec(Rn, ta) - wloc);
   }
   }
+  GQ_SUB(W, 2, 7); /* base observables */
   if (lane < GQ_NVD) ob[OB_QVEL + lane] = W.qvel[lane];
   if (lane < 12) { ob[OB_TAU + lane] = W.ctrl[lane]; ob[OB_QVEL_JS + lane] = W.qvel[6 + lane]; }
   if (lane >= 7 && lane < 19) { ob[OB_QPOS + lane] = qjn; ob[OB_QPOS_JS + lane - 7] = qjn; }
   /* kinetic energy 1/2 v'Mv and work (M qacc).v with the OLD mass matrix, NEW velocity, qacc of this step */
   if (obs_need & GQ_NEED_ENERGY) {
     float ke_part = 0.0f, wk_part = 0.0f;
-    if (lane < GQ_NVD) {
+    if constexpr (SOLVER == 1) {
+      /* v'Mv summed over the STORED entries of M, lane = entry (S3's table: three per lane; a leg's off-diagonal entries are stored once
+       * and count twice, the base block is stored in full), and (M qacc).v with  M qacc = qfrc_smooth + qfrc_constraint,  which S10 left in
+       * W.act for the Euler system - no matrix-vector product at all (round 4: two 27-term row products per dof lane behind two
+       * divergent branches, 2.9 k cycles for a lone wave).  Equal to the explicit products up to the solver's residual. */
+      const float* M0 = &W.Mc[0][0];
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        if (p < 2 || lane < 144 - 2 * GQ_WAVE) {
+          const int ent = s3k[p], dd = ent & 0xff, sa = (ent >> 8) & 0xff;
+          const float coef = (ent >> 24) ? ((p < 2 && (p == 0 || lane < 108 - GQ_WAVE) && dd != sa) ? 1.0f : 0.5f) : 0.0f;
+          ke_part += coef * M0[lane + GQ_WAVE * p] * W.qvel[dd] * W.qvel[sa];
+        }
+      }
+      if (lane < GQ_NVD) wk_part = diverged ? 0.0f : W.act[lane] * W.qvel[lane]; /* (a frozen env: qacc was zeroed) */
+    } else if (lane < GQ_NVD) {
       const float mv = mul_m_row(W, W.qvel, lane), ma = mul_m_row(W, W.qacc, lane);
       ke_part = 0.5f * W.qvel[lane] * mv; wk_part = ma * W.qvel[lane];
     }
     float ke = wave_sum(ke_part), wk = wave_sum(wk_part);
     if (lane == 0) { ob[OB_KE] = ke; ob[OB_WORK] = wk; }
   }
+  GQ_SUB(W, 2, 8); /* joint observables + energy */
   /* feet: lane k < 4 = foot k in FL FR RL RR order */
   if ((obs_need & (GQ_NEED_FEET | GQ_NEED_CONTACT)) && lane < 4) {
-    const int leg = m.foot_leg[lane], body = 3 + 3 * leg;
+    const int leg = FRec.leg, body = 3 + 3 * leg;
     V3 pw = ld3(W.foot_world[lane]); /* relative to the OLD base x/y */
     /* spatial velocity of the calf with old cdof and new qvel (J_old * qvel_new) */
     float sv[6] = {0, 0, 0, 0, 0, 0};
@@ -1288,10 +1494,11 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     st3(ob + OB_CONTACT_F_B + 3 * lane, matTvec(Rn, cf));
   }
   wave_barrier();
+  GQ_SUB(W, 2, 9); /* feet + contact forces */
   /* IMU.step (sensors/imu.py:102-139): noise ~ N(0, sigma), bias += N(0, rate), measurement = truth + bias + noise.
    * lanes 0-11 draw: acc noise xyz, acc bias step xyz, gyro noise xyz, gyro bias step xyz */
   if (imu_on) {
-    const GQ_MODEL GqDevBatch& B = *mptr(a.batch);
+    const GQ_MODEL GqDevBatch& B = Bt;
     float z = 0.0f;
     if (lane < 12) {
       const uint32_t stepc = (uint32_t)W.step_old, epi = a.episode_ro ? (uint32_t)ldv<PUB>(a.episode_ro + env) : 0u;
@@ -1304,8 +1511,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     if (lane < 6) { /* lanes 0-2: accelerometer axes, lanes 3-5: gyro axes */
       const int g = lane / 3, ax = lane % 3;
       const float noise = W.warm[6 + 6 * g + ax], dbias = W.warm[6 + 6 * g + 3 + ax];
-      const float bias = ldv<PUB>(a.imu_bias + (size_t)env * 6 + lane) + dbias;
-      gptr(a.imu_bias)[(size_t)env * 6 + lane] = bias;
+      const float bias = ldv<PUB>(e_imu_bias + (size_t)env * 6 + lane) + dbias;
+      gptr(e_imu_bias)[(size_t)env * 6 + lane] = bias;
       const int o = g == 0 ? OB_IMU_ACC : OB_IMU_GYRO;
       ob[o + ax] = W.warm[lane] + bias + noise; ob[o + 3 + ax] = noise; ob[o + 6 + ax] = bias;
     }
@@ -1313,20 +1520,20 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   /* termination (quadruped_env.py:283-285): non-foot contact with the ground, or base outside the terrain */
   int terminated = 0;
   {
-    const bool oob = bxn_d > m.terrain_limits[0] || bxn_d < m.terrain_limits[1] || byn_d > m.terrain_limits[2] ||
-                     byn_d < m.terrain_limits[3];
+    const bool oob = bxn_d > tlim0 || bxn_d < tlim1 || byn_d > tlim2 || byn_d < tlim3;
     terminated = W.invalid || oob || diverged;
     if (lane == 0) {
       if (pass == 0) { /* the flags of the user's step survive an in-kernel auto-reset */
-        gptr(a.invalid_contact)[env] = (uint8_t)W.invalid;
-        gptr(a.terminated)[env] = (uint8_t)terminated;
-        gptr(a.truncated)[env] = (uint8_t)diverged;
+        gptr(e_inval)[env] = (uint8_t)W.invalid;
+        gptr(e_term)[env] = (uint8_t)terminated;
+        gptr(e_trunc)[env] = (uint8_t)diverged;
       } else if (pass == 2) { /* reset() reports no termination (quadruped_env.py:406 returns the observation only) */
-        gptr(a.invalid_contact)[env] = 0; gptr(a.terminated)[env] = 0; gptr(a.truncated)[env] = 0;
+        gptr(e_inval)[env] = 0; gptr(e_term)[env] = 0; gptr(e_trunc)[env] = 0;
       }
-      if (a.pending) gptr(a.pending)[env] = (uint8_t)(pass == 0 ? terminated : 0);
-      if (a.contacts_dropped) gptr(a.contacts_dropped)[env] = W.ndrop;
-      gptr(a.reward)[env] = 0.0f;
+      if (e_pending) gptr(e_pending)[env] = (uint8_t)(pass == 0 ? terminated : 0);
+      if (e_dropped) gptr(e_dropped)[env] = W.ndrop;
+      if (SOLVER == 1 && e_hint) gptr(e_hint)[env] = (uint8_t)hint_out;
+      gptr(e_reward)[env] = 0.0f;
       if (pass != 0 && a.friction && a.friction_next) gptr(const_cast<float*>(a.friction))[env] = ldv<PUB>(a.friction_next + env); /* (written by this wave's own reset_wave) */
     }
   }
@@ -1335,8 +1542,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   static_assert(GQ_DYN_MB == GQ_DYN_MC + sizeof(WaveMem::Mc) / 4 && GQ_DYN_BIAS == GQ_DYN_MB + sizeof(WaveMem::Mb) / 4 && GQ_DYN_XPOS == GQ_DYN_BIAS + GQ_NVD &&
                 GQ_DYN_XMAT == GQ_DYN_XPOS + sizeof(WaveMem::xpos) / 4 && GQ_DYN_FOOT == GQ_DYN_XMAT + sizeof(WaveMem::xmat) / 4 &&
                 GQ_DYN_STRIDE >= GQ_DYN_FOOT + sizeof(WaveMem::foot_world) / 4, "dynamics-row offsets follow the WaveMem field sizes");
-  if (a.contacts && rec_pass) { /* wave-uniform */
-    GQ_GLOBAL float* Cn = gptr(a.contacts) + (size_t)env * GQ_CON_STRIDE;
+  if (e_contacts && rec_pass) { /* wave-uniform */
+    GQ_GLOBAL float* Cn = gptr(e_contacts) + (size_t)env * GQ_CON_STRIDE;
     if (lane == 0) { Cn[0] = (float)ncon; Cn[1] = (float)nefc; Cn[2] = (float)iter; }
     if (lane >= ncon && lane < GQ_CON_MAX) { /* no contact: an all-zero record (gq_contact_force returns zeros for it) */
       GQ_GLOBAL float* R = Cn + 8 + lane * GQ_CON_REC;
@@ -1369,7 +1576,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       R[22] = W.con_mu[c]; R[23] = 0.0f;
     }
   }
-  GQ_TICK(12);
+  GQ_TICK(12); GQ_SUB(W, 2, 10); /* IMU, termination, flags */
   /* gather to the requested observation layout: coalesced row write */
   {
 #pragma unroll
@@ -1377,15 +1584,17 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       const int k = lane + GQ_WAVE * i;
       if (k < od) {
         const float val = ob[omap[i]];
-        if constexpr (PUB) st_pub(a.obs + (size_t)env * od + k, val);
-        else gptr(a.obs)[(size_t)env * od + k] = val;
-        if (call.obs_seq) gptr(call.obs_seq)[(size_t)env * od + k] = val; /* persistent rollout: the step's own row of the sequence */
+        if constexpr (PUB) st_pub(e_obs + (size_t)env * od + k, val);
+        else gptr(e_obs)[(size_t)env * od + k] = val;
+        if (e_obs_seq) gptr(e_obs_seq)[(size_t)env * od + k] = val; /* persistent rollout: the step's own row of the sequence */
       }
     }
   }
+  GQ_SUB(W, 2, 11); /* gather */
   wave_barrier(); /* the obs row overlays u: finish reading it before a second pass reuses the region */
   /* in-episode resampling (quadruped_env.py:292-305): the user's step only; a redraw acts from the next step on */
-  if (pass == 0 && a.h9) resample_wave<PUB>(a, env);
+  if (pass == 0 && e_h9) resample_wave<PUB>(a, env);
+  GQ_SUB(W, 2, 12); /* resampling */
   GQ_TICK(13);
   if constexpr (DBG) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 25] = (float)(wall_clock64() & 0xFFFFF);
 #undef GQ_TICK
@@ -1488,9 +1697,9 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
   const bool flat_scene = !BOXES || (m.nbox == 0 && m.hf_nrow == 0); /* BOXES variants also serve flat scenes with robot self-collision */
   const int lift_due = (flat_scene && !explicit_state) ? 1 : 0;
   if (!flat_scene && !explicit_state) {
-    stage_kinematics(W, m);
+    stage_kinematics(W, link_fetch(m, lane));
     wave_barrier();
-    stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), true);
+    stage_collision_scan(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), true, foot_fetch(m, lane));
     /* distances and margins of everything attached to a calf body (feet_contact_state is body-level) */
     /* floor: lane = collision item (feet 0-3, then the link geoms), every candidate point of the plane narrow phase */
     FloorCand FC;

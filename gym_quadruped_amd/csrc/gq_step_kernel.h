@@ -27,6 +27,7 @@
 #pragma once
 #include <gq_device.h> /* angle brackets: the include path decides (csrc/ for the product, tests/simt_emu/ for the emulator) */
 #include "gq_model_dev.h"
+#include <cstddef>
 
 namespace gq {
 
@@ -34,21 +35,27 @@ namespace gq {
  * pointers where it uses them (scalar loads).  Passed by value, the ~60 pointers of a fused step + reset were preloaded
  * into SGPRs at kernel entry and immediately spilled lane-by-lane into VGPRs (v_writelane / v_readlane: ~10 % of the
  * kernel's VALU issue slots).  What changes from call to call travels by value in StepCall. */
+/* Field order (round 5): the sixteen pointers a wave's PROLOGUE reads (load_rows) are the first 128 bytes - two s_load_dwordx16 - and the
+ * ones its EPILOGUE stores through follow in one block (EpiPtrs in gq_step_body.h); the block is filled by name (gq_api.hip). */
 struct StepArgs {
   const GqDevModel* model;
   const GqDevBatch* batch;
   const float* vx; const float* vy; const float* vz; /* cloud vertices SoA */
-  double* qpos; float* qvel; float* qacc; float* warm; const float* applied; float* time; const float* friction;
+  double* qpos; float* qvel; float* warm; const float* applied; float* time; const float* friction;
   const float* cmd;
+  uint8_t* pending;       /* library scratch [N]: env terminated and waits for its next-step auto-reset (may be NULL) */
+  uint8_t* load_hint;     /* library scratch [N]: Newton iterations of the env's previous step, capped (may be NULL) */
+  int32_t* step_num;
+  const uint8_t* lift_pending; /* library scratch [N] written by reset_kernel (see ResetArgs), read by first-pass steps; may be NULL */
+  float timestep; int32_t nlg, nfl, pad_; /* copies of the model's scalars every stage reads: they arrive with the pointers, not behind the model pointer */
+  /* ---- epilogue */
+  float* qacc;
+  float* obs; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* invalid_contact;
+  int32_t* step_prev;     /* [N] step counter before this step's increment (info['step_num']), may be NULL */
   float* imu_bias;        /* [N][6] accelerometer / gyro bias random walks (in/out), NULL = no IMU */
   const int32_t* episode_ro; /* [N] episode counters (RNG counter word), may be NULL */
   float* friction_next;   /* library scratch [N]: friction drawn at reset, committed after the reset's own step (:403-404) */
-  uint8_t* pending;       /* library scratch [N]: env terminated and waits for its next-step auto-reset (may be NULL) */
-  uint8_t* load_hint;     /* library scratch [N]: Newton iterations of the env's previous step, capped (may be NULL) */
-  float* obs; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* invalid_contact; int32_t* step_num;
   uint8_t* lift_failed;   /* [N] out: the reset RuntimeError condition (:387-388), written by the step that performs a lift; may be NULL */
-  const uint8_t* lift_pending; /* library scratch [N] written by reset_kernel (see ResetArgs), read by first-pass steps; may be NULL */
-  int32_t* step_prev;     /* [N] step counter before this step's increment (info['step_num']), may be NULL */
   int32_t* contacts_dropped; /* [N] contacts of this step's narrow phase that did not fit the 12-contact / 63-row capacity, may be NULL */
   int32_t* h9;            /* [N][6] resampling counters {after_vel, before_vel, n_vel, after_dist, before_dist, n_dist}, may be NULL */
   float* ext_dist;        /* [N][6] current disturbance wrench, may be NULL */
@@ -114,6 +121,13 @@ struct PolicyPdDev {
   float sigma; uint32_t seed_lo, seed_hi; int32_t step0, env_id_offset;
 };
 
+/* wave-uniform model scalars of S5 - S9 (and the cloud pointers): one batch of scalar loads in front of S5, pinned */
+struct StepConsts {
+  int foot_leg[4], iterations, nsp, self_cut;
+  float floor_mu, impratio_rs /* 1 / sqrt(impratio) */, gravity_z, nw_scale /* 1 / (meaninertia nv) */, tolerance, noise_floor, self_margin;
+  const GQ_MODEL float* vx; const GQ_MODEL float* vy; const GQ_MODEL float* vz;
+};
+
 /* canonical ALL_OBS scalar offsets (order of QuadrupedEnv.ALL_OBS, quadruped_env.py:35-66,81) */
 enum {
   OB_BASE_POS = 0, OB_LIN_VEL = 3, OB_LIN_VEL_ERR = 6, OB_LIN_ACC = 9, OB_ANG_VEL = 12, OB_ANG_VEL_ERR = 15,
@@ -147,7 +161,21 @@ struct WaveDyn {
   };
   float cfrc[GQ_NB][6];
 };
+/* Development aid (tools/dev_build.sh ... -DGQ_TICKSET=<n>, instrumented variant only): the 13 stage stamps of the debug record are moved to
+ * the sub-stage points GQ_SUB(W, n, k) of set n - a finer cut of one half of the step for tools/perf_probe.py substages.  0: not compiled in. */
+#ifndef GQ_TICKSET
+#define GQ_TICKSET 0
+#endif
+#if GQ_TICKSET
+#define GQ_SUB(W, SET, K) do { if constexpr (GQ_TICKSET == (SET)) { if ((W).tk_T && lane_id() == 0) { constexpr int ord_[13] = {1, 2, 3, 4, 5, 14, 6, 7, 8, 9, 10, 11, 12}; \
+    (W).tk_T[ord_[K]] = (float)((long long)__builtin_readcyclecounter() - (W).tk_t0); } } } while (0)
+#else
+#define GQ_SUB(W, SET, K) do { } while (0)
+#endif
 struct WaveMem {
+#if GQ_TICKSET
+  float* tk_T; long long tk_t0;
+#endif
   double bxy[2];               /* base x, y of this forward pass (f64, never enters fp32 arithmetic) */
   float mu_env; int32_t step_old; /* the env's friction override (-1: none) and its step counter before this step */
   float qj[12], qb[4], basez, qvel[18], ctrl[12], warm[18], cmd[4];

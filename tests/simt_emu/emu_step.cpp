@@ -45,6 +45,7 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
   a.terminated = terminated; a.truncated = truncated; a.invalid_contact = invalid_contact; a.step_num = step_num;
   a.n_envs = n_envs; a.imu_bias = imu ? imu_bias : nullptr; a.episode_ro = episode;
   a.lift_failed = lift_failed; a.lift_pending = lift_pending;
+  a.timestep = M.timestep; a.nlg = M.nlg; a.nfl = M.nfl;
   gq::StepCall call{};
   call.ctrl = ctrl; call.mask = mask; call.debug = debug;
   call.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; call.first_pass = first_pass;
@@ -60,30 +61,31 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
     emu_run_wave((unsigned)e, (unsigned)n_envs, [&]() {
       __shared__ gq::WaveMem W;
       int pass = call.first_pass;
-      bool respawn = call.auto_reset == 2 && f.s.pending[e];
+      gq::WaveCtx C;
       const bool boxes = M.nbox > 0 || M.hf_nrow > 0, self = M.nsp > 0;
       bool prims = false; /* as gq_api.hip scene_variant: the PRIM variants serve robots with sphere / capsule / box link geoms */
       for (int g = 0; g < M.nlg; g++) prims = prims || M.lg[g].ptype == 2 || M.lg[g].ptype == 3 || M.lg[g].ptype == 6;
-      int lift = (call.first_pass && lift_pending) ? (int)lift_pending[e] : 0;
-      int hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, pass == 0) : gq::load_rows<0>(f.s, call, W, e, pass == 0);
+      int hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, pass == 0, C) : gq::load_rows<0>(f.s, call, W, e, pass == 0, C);
+      bool respawn = call.auto_reset == 2 && C.pend;
+      int lift = call.first_pass ? C.lift : 0;
       for (;;) {
         if (respawn) {
           gq::wave_barrier();
           lift = boxes ? (prims ? gq::reset_wave<true, true>(f.r, W) : gq::reset_wave<true, false>(f.r, W)) : gq::reset_wave<false>(f.r, W);
           pass = call.auto_reset;
-          hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, false) : gq::load_rows<0>(f.s, call, W, e, false);
+          hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, false, C) : gq::load_rows<0>(f.s, call, W, e, false, C);
         }
         int term;
         if (M.solver != 1) { /* PGS (pyramidal cones only) */
-          if (boxes && prims) term = gq::step_wave<0, 1, false, true, true, true>(f.s, call, W, pass, lift, hint);
-          else if (boxes) term = gq::step_wave<0, 1, false, true, true, false>(f.s, call, W, pass, lift, hint);
-          else if (self) term = gq::step_wave<0, 1, false, false, true, true>(f.s, call, W, pass, lift, hint);
-          else term = gq::step_wave<0, 1, false, false, false, true>(f.s, call, W, pass, lift, hint);
+          if (boxes && prims) term = gq::step_wave<0, 1, false, true, true, true>(f.s, call, W, pass, lift, hint, C);
+          else if (boxes) term = gq::step_wave<0, 1, false, true, true, false>(f.s, call, W, pass, lift, hint, C);
+          else if (self) term = gq::step_wave<0, 1, false, false, true, true>(f.s, call, W, pass, lift, hint, C);
+          else term = gq::step_wave<0, 1, false, false, false, true>(f.s, call, W, pass, lift, hint, C);
         }
-        else if (boxes && prims) term = M.cone ? gq::step_wave<1, 1, true, true, true, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, true, true, true>(f.s, call, W, pass, lift, hint);
-        else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true, true, false>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, true, true, false>(f.s, call, W, pass, lift, hint);
-        else if (self) term = M.cone ? gq::step_wave<1, 1, true, false, true, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, false, true, true>(f.s, call, W, pass, lift, hint);
-        else term = M.cone ? gq::step_wave<1, 1, true, false, false, true>(f.s, call, W, pass, lift, hint) : gq::step_wave<1, 1, false, false, false, true>(f.s, call, W, pass, lift, hint);
+        else if (boxes && prims) term = M.cone ? gq::step_wave<1, 1, true, true, true, true>(f.s, call, W, pass, lift, hint, C) : gq::step_wave<1, 1, false, true, true, true>(f.s, call, W, pass, lift, hint, C);
+        else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true, true, false>(f.s, call, W, pass, lift, hint, C) : gq::step_wave<1, 1, false, true, true, false>(f.s, call, W, pass, lift, hint, C);
+        else if (self) term = M.cone ? gq::step_wave<1, 1, true, false, true, true>(f.s, call, W, pass, lift, hint, C) : gq::step_wave<1, 1, false, false, true, true>(f.s, call, W, pass, lift, hint, C);
+        else term = M.cone ? gq::step_wave<1, 1, true, false, false, true>(f.s, call, W, pass, lift, hint, C) : gq::step_wave<1, 1, false, false, false, true>(f.s, call, W, pass, lift, hint, C);
         if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
       }

@@ -62,6 +62,7 @@ static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline int ffs64(uint64_t m) { return __builtin_ctzll(m); }
 static inline void opaque(int&) {}
 static inline void opaque_s(int&) {}
+template <class T> static inline void pin(T&) {}
 template <class T> static inline const T* opaque_ptr(const T* p) { return p; }
 static inline int opaque_lane(int l) { return l; }
 template <class T> static inline T* gptr(T* p) { return p; }

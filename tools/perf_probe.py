@@ -85,3 +85,35 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'stages':
     for n in (int(x) for x in ([x for x in sys.argv[2:] if x.isdigit()] or ['4096'])):
         for sv in ('newton',):
             print(sv, robot); stage_times(n, solver=sv, robot=(robot or ['mini_cheetah'])[0], scene=(robot + ['flat', 'flat'])[1])
+
+
+SUBSETS = {
+    3: ['entry -> pointer batch in', 'vector loads issued + model scalars', 'rows in LDS (all loads landed)', 'step_wave entry', 'records issued, barrier', '-', '-', '-', '-', '-', '-', '-', '-', '(rest)'],
+    1: ['entry->rows in LDS', 'actuation+passive', 'kin phase 1 (lane=link)', 'kin phase 2 (chains)', 'S2 inertias', 'S3 mass matrix', 'S5 rne',
+        'S6a hull scan', 'floor candidates', 'floor list + limits', 'self: end points', 'self: pair cull', 'self: rest', '(S7 .. end)'],
+    2: ['(entry .. S6)', 'S7 row descriptors', 'S7 J sweep', 'S7 impedance/aref', 'S9 solver', 'S10 Euler system', 'integrate + state stores',
+        'S11 base obs', 'S11 joints + energy', 'S11 feet + forces', 'S11 imu/term/flags', 'gather', 'resample', '(end)'],
+}
+
+
+def substage_times(which, n=256, robot='mini_cheetah', scene='flat'):
+    """Sub-stage cut of a library built with -DGQ_TICKSET=<which> (tools/dev_build.sh): the 13 stage stamps sit at the GQ_SUB points of that set."""
+    env = QuadrupedEnv(robot, scene=scene, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', seed=1)
+    env.reset(random=True)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for i in range(300): env.step(torch.randn(n, 12, generator=g, device='cuda') * 50)
+    env.enable_debug(n)
+    env.step(torch.randn(n, 12, generator=g, device='cuda') * 50); torch.cuda.synchronize()
+    d = env.debug_internals(n, ['timer', 'niter', 'nefc'])
+    T = np.stack([x['timer'] for x in d]); nit = np.array([x['niter'][0] for x in d])
+    order = [1, 2, 3, 4, 5, 14, 6, 7, 8, 9, 10, 11, 12, 13]
+    print(f'sub-stage set {which}, {robot} {scene}, {n} envs: cycles from kernel entry (mean / p95 / max); niter mean {nit.mean():.2f}')
+    prev = np.zeros(n)
+    for nm, k in zip(SUBSETS[which], order):
+        dt = T[:, k] - prev; prev = T[:, k]
+        print(f'  {nm:28s} {dt.mean():9.0f} {np.percentile(dt, 95):9.0f} {dt.max():9.0f}')
+    print(f'  total                        {T[:, 13].mean():9.0f}')
+
+
+if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[1] == 'sub':
+    substage_times(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 256, *(sys.argv[4:6]))
