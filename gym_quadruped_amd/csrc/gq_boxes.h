@@ -630,14 +630,15 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
    * until S7 (the spatial-dynamics scratch it overlays is dead since S5) */
   /* per item: end points p0, p1, radius, and the bounding sphere (centre, radius) the first pass tests */
   float(*cw)[12] = reinterpret_cast<float(*)[12]>(&W.u.B[0][0]);
-  if (lane < 4 + nlg) {
+  { /* lane = item; lanes past the last item repeat item 0 (self_prefetch fetched its record for them): no exec-mask block */
+    const int it = lane < 4 + nlg ? lane : 0;
     const int b = pre.body;
     const V3 o = ld3(W.xpos[b]);
     const V3 e0 = o + matvec(W.xmat[b], v3(pre.caps[0], pre.caps[1], pre.caps[2])), e1 = o + matvec(W.xmat[b], v3(pre.caps[3], pre.caps[4], pre.caps[5]));
-    st3(cw[lane], e0); st3(cw[lane] + 3, e1);
-    cw[lane][6] = pre.caps[6];
-    st3(cw[lane] + 8, o + matvec(W.xmat[b], v3(pre.bsph[0], pre.bsph[1], pre.bsph[2]))); /* broad-phase sphere: the primitive itself where the item is one */
-    cw[lane][11] = pre.bsph[3];
+    st3(cw[it], e0); st3(cw[it] + 3, e1);
+    cw[it][6] = pre.caps[6];
+    st3(cw[it] + 8, o + matvec(W.xmat[b], v3(pre.bsph[0], pre.bsph[1], pre.bsph[2]))); /* broad-phase sphere: the primitive itself where the item is one */
+    cw[it][11] = pre.bsph[3];
   }
   /* models with many pairs: body-pair broad phase, so that passes whose pairs all belong to far-apart bodies are skipped */
   uint64_t near[2] = {~0ull, ~0ull};
@@ -666,20 +667,18 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
 #pragma unroll 1
   for (int p0 = 0; p0 < nsp; p0 += GQ_WAVE) {
     const int p = p0 + lane;
-    bool cand = p < nsp;
-    if (cand) {
+    bool cand;
+    { /* branch-free: lanes past the last pair test pair 0 (the prefetch's fall-back) and are masked */
       int it1, it2, bp; /* the first two passes come prefetched */
       if (p0 == 0) { it1 = pre.it1[0]; it2 = pre.it2[0]; bp = pre.bp[0]; }
       else if (p0 == GQ_WAVE) { it1 = pre.it1[1]; it2 = pre.it2[1]; bp = pre.bp[1]; }
-      else { const GQ_MODEL GqDevSelfPair& P = m.sp[p]; it1 = P.it1; it2 = P.it2; bp = P.bp; }
-      cand = (near[bp >> 6] >> (bp & 63)) & 1;
-      if (cand) {
-        const float* k1 = cw[it1] + 8;
-        const float* k2 = cw[it2] + 8;
-        const V3 dm = ld3(k2) - ld3(k1);
-        const float reach = k1[3] + k2[3] + K.self_margin;
-        cand = dot(dm, dm) < reach * reach;
-      }
+      else { const GQ_MODEL GqDevSelfPair& P = m.sp[p < nsp ? p : 0]; it1 = P.it1; it2 = P.it2; bp = P.bp; }
+      const bool nr = (near[(bp >> 6) & 1] >> (bp & 63)) & 1;
+      const float* k1 = cw[it1] + 8;
+      const float* k2 = cw[it2] + 8;
+      const V3 dm = ld3(k2) - ld3(k1);
+      const float reach = k1[3] + k2[3] + K.self_margin;
+      cand = p < nsp && nr && dot(dm, dm) < reach * reach;
     }
     const uint64_t cm = ballot(cand);
     if (cm == 0) continue;
@@ -827,14 +826,15 @@ __device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL G
   WorldAppend S;
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = 0; S.reserve = 0; S.nself = 0; S.ndrop = uniform(W.ndrop);
   const int ncon = S.ncon;
-  if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
-    st3(GQ_BX_CONNRM(W) + 3 * lane, v3(0.0f, 0.0f, 1.0f));
-    GQ_BX_WCLS(W)[lane] = -1;
+  { /* floor contacts: normal z, world geom = floor - written for every slot of the list (contacts appended below overwrite theirs) */
+    const int lc = lane < GQ_MAXCON ? lane : GQ_MAXCON - 1;
+    st3(GQ_BX_CONNRM(W) + 3 * lc, v3(0.0f, 0.0f, 1.0f));
+    GQ_BX_WCLS(W)[lc] = -1;
   }
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
   append_self_contacts<CONE>(W, m, mu_env, S, pre, K, nlg);
-  if (lane == 0) { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; W.ndrop = S.ndrop; }
+  { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; W.ndrop = S.ndrop; } /* (every lane: the same words) */
   wave_barrier();
 }
 
@@ -851,9 +851,10 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = uniform(W.invalid); S.reserve = 0; S.nself = 0; S.ndrop = uniform(W.ndrop);
   S.ft = uniform(W.foot_touch) & 15;
   const int ncon = S.ncon;
-  if (lane < ncon) { /* floor contacts: normal z, world geom = floor */
-    st3(GQ_BX_CONNRM(W) + 3 * lane, v3(0.0f, 0.0f, 1.0f));
-    GQ_BX_WCLS(W)[lane] = -1;
+  { /* floor contacts: normal z, world geom = floor - written for every slot of the list (contacts appended below overwrite theirs) */
+    const int lc = lane < GQ_MAXCON ? lane : GQ_MAXCON - 1;
+    st3(GQ_BX_CONNRM(W) + 3 * lc, v3(0.0f, 0.0f, 1.0f));
+    GQ_BX_WCLS(W)[lc] = -1;
   }
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }

@@ -137,7 +137,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
   }
   for (int pass = 0; pass < 2; pass++) /* entries of the tree-sparse Newton Hessian, two per lane (gq_newton.h) */
     for (int lane = 0; lane < 64; lane++) {
-      const int e = pass * 64 + lane;
+      const int e = pass * 64 + lane < 117 ? pass * 64 + lane : 116; /* the spare slots repeat the last entry: every lane of the solver has two entries and none needs a branch */
       int da = 0, db = 0, slot = 0;
       if (e < 96) {
         const int leg = e / 24, q = e % 24;
@@ -153,7 +153,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
         slot = 108 + 6 * da + db;
       }
       const int frp1 = (e < 117 && da == db) ? M.fl_row_of_dof[da] + 1 : 0;
-      M.newton_hent[pass][lane] = e < 117 ? (da | (db << 8) | (slot << 16) | (frp1 << 24)) : -1;
+      M.newton_hent[pass][lane] = da | (db << 8) | (slot << 16) | (frp1 << 24);
     }
   for (int u = 0; u < d->nu; u++) {
     int j = d->actuator_trnid[u] - 1;
@@ -211,8 +211,9 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
         dd = 6 + j;
         if (col < 6) { sa = col; valid = 1; }
         else if (col - 6 <= dep) { sa = 6 + 3 * leg + (col - 6); valid = 1; }
-      } else if (e < 144) {
-        const int i = (e - 108) / 6, jj = (e - 108) % 6;
+      } else { /* (slots past entry 143 repeat it: the kernel's lanes run unconditionally, mirror lanes store what lane 15 stores) */
+        const int ee = e < 144 ? e : 143;
+        const int i = (ee - 108) / 6, jj = (ee - 108) % 6;
         dd = i > jj ? i : jj; sa = i > jj ? jj : i; valid = 1;
       }
       const int body = dd < 6 ? 0 : dd - 5;

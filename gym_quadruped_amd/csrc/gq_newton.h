@@ -719,11 +719,12 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
    * comparison itself costs two residual evaluations, a mass-matrix product and two wave reductions.  So the warm start
    * is not consulted by this solver (it is still written, for PGS and for callers that read it). */
   solve_tree_fused<false, true>(W.Mc, W.Mb, W.F[0], 0.0f, W.smooth, W.qacc_smooth, GQ_EULER_FLEG(W), GQ_EULER_FBASE(W)); /* + the Euler system's factor, by the idle second quad */
-  if (lane < GQ_NVD) W.qacc[lane] = W.qacc_smooth[lane];
+  const int ld = lane < GQ_NVD ? lane : GQ_NVD - 1; /* mirror lanes (gq_step_body.h): lanes >= 18 repeat dof 17's reads, arithmetic and stores */
+  W.qacc[ld] = W.qacc_smooth[ld];
   wave_barrier();
   float f = 0.0f;
   int iter = 0, exit_code = 0; /* why the loop ended (debug record, timer slot 23) */
-  const int fl_row = lane < GQ_NVD ? fl_row_pre : -1; /* (the dof's record: fetched at the start of the step) */
+  const int fl_row = fl_row_pre; /* (the dof's record: fetched at the start of the step, with the clamped lane) */
   /* the two Hessian entries this lane assembles every iteration: a host table (GqDevModel::newton_hent) - decoding the entry
    * index per lane cost ~80 instructions per step */
   int hent[2];
@@ -735,9 +736,9 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
    * row for every entry every time. */
   float hbase[2], wprev = 0.0f;
 #pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int da = hent[pass] & 0xff, db = (hent[pass] >> 8) & 0xff, slot = (hent[pass] >> 16) & 0xff;
-    hbase[pass] = hent[pass] < 0 ? 0.0f : (slot < 108 ? W.Mc[slot / 9][slot % 9] : W.Mb[da][db]);
+  for (int pass = 0; pass < 2; pass++) { /* (every lane has two entries: the table's spare slots repeat entry 116; Mc | Mb are one flat array, slot = its index) */
+    const int slot = (hent[pass] >> 16) & 0xff;
+    hbase[pass] = (&W.Mc[0][0])[slot];
   }
   long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = (DBG && tdbg) ? cycles() : 0;
   if constexpr (DBG) if (tdbg && lane == 0) { tdbg[29] = 0.0f; tdbg[30] = 0.0f; } /* line-search trials, full-step shortcuts */
@@ -771,7 +772,7 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
       if (E.code) { f = f2; ci = c2; wact = w2; }
     }
     W.force[lane] = f; /* row forces, read column-wise for J'f below */
-    if (lane < GQ_NVD) Mdq[lane] = md;
+    Mdq[ld] = md;
     wave_barrier();
     /* (MuJoCo's improvement test compares successive costs; in fp32 their round-off - 1e-7 of a cost dominated by stiff
      * contact rows - is far above `tolerance`, so the test is applied to the decrease predicted by the line search,
@@ -780,19 +781,19 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
     NW_T(1);
     /* ---- gradient = M dq - J' f  (lane = dof walks its column of J in LDS) */
     float gd = 0.0f, gterm = 0.0f;
-    if (lane < GQ_NVD) {
+    { /* lane = dof, mirror lanes (masked in the sums below) */
       /* friction-loss rows are e_dof: their force lands on one dof, only limit / contact rows are walked */
       /* rows in chunks of four, all eight LDS reads of a chunk in flight together (one LDS latency per chunk instead of
        * one per row); rows past nefc hold zero forces (lanes >= nefc write 0) and row indices stay below 64 */
       float s0 = fl_row >= 0 ? W.force[fl_row] : 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
       if constexpr (!CONE) { /* pyramidal models: mostly 0-8 contact rows, the two-row walk is cheaper there */
         int r = nfl;
-        for (; r + 2 <= nefc; r += 2) { s0 += W.u.B[r][lane] * W.force[r]; s1 += W.u.B[r + 1][lane] * W.force[r + 1]; }
-        if (r < nefc) s0 += W.u.B[r][lane] * W.force[r];
+        for (; r + 2 <= nefc; r += 2) { s0 += W.u.B[r][ld] * W.force[r]; s1 += W.u.B[r + 1][ld] * W.force[r + 1]; }
+        if (r < nefc) s0 += W.u.B[r][ld] * W.force[r];
       } else
       for (int r = nfl; r < nefc; r += 4) {
         const int r1 = r + 1 < 64 ? r + 1 : 63, r2 = r + 2 < 64 ? r + 2 : 63, r3 = r + 3 < 64 ? r + 3 : 63;
-        const float b0 = W.u.B[r][lane], b1 = W.u.B[r1][lane], b2 = W.u.B[r2][lane], b3 = W.u.B[r3][lane];
+        const float b0 = W.u.B[r][ld], b1 = W.u.B[r1][ld], b2 = W.u.B[r2][ld], b3 = W.u.B[r3][ld];
         const float f0 = W.force[r], f1 = r + 1 < nefc ? W.force[r1] : 0.0f, f2 = r + 2 < nefc ? W.force[r2] : 0.0f, f3 = r + 3 < nefc ? W.force[r3] : 0.0f;
         s0 += b0 * f0; s1 += b1 * f1; s2 += b2 * f2; s3 += b3 * f3;
       }
@@ -804,7 +805,7 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
     if (scale * fast_sqrt(gnorm2) < m.tolerance) { exit_code = 3; break; }
     /* fp32 floor (GqModelDesc.noise_floor): the gradient is a difference of two vectors; once it is down at their
      * round-off a further Newton step only chases noise */
-    if (iter > 0 && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(gterm)) { exit_code = 4; break; }
+    if (iter > 0 && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(lane < GQ_NVD ? gterm : 0.0f)) { exit_code = 4; break; }
     /* stagnation at working precision: close to the solution (the last step promised less than 1e-6, scaled like
      * `tolerance`) Newton's gradient collapses from one iterate to the next; one that did not even halve is rounding noise
      * of the stiff rows' residuals (elliptic models, impratio 100: the iterates then cycle between neighbouring fp32
@@ -813,7 +814,7 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
       if (iter > 0 && pred_prev < 1e-6f && gnorm2 >= 0.25f * gnorm2_prev) { exit_code = 8; break; }
       gnorm2_prev = gnorm2;
     }
-    if (lane < GQ_NVD) grad[lane] = -gd; /* right-hand side of H search = -grad */
+    grad[ld] = -gd; /* right-hand side of H search = -grad */
     wave_barrier();
     /* a contact between two different legs couples them in H = M + J'DJ, which then no longer has M's tree sparsity - but
      * only while one of its rows is active (wave-uniform tests; robot-robot rows are the last ones, + their virtual rows).
@@ -927,7 +928,7 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
        * loop and then spills - 17 scratch reloads per iteration; decoding them again from an opaque copy is 12 VALU) */
       int h0 = hent[0], h1 = hent[1];
       if constexpr (CONE) { opaque(h0); opaque(h1); }
-      const int e0 = h0 < 0 ? 0 : h0, e1 = h1 < 0 ? 0 : h1;
+      const int e0 = h0, e1 = h1;
       const int da0 = e0 & 0xff, db0 = (e0 >> 8) & 0xff, da1 = e1 & 0xff, db1 = (e1 >> 8) & 0xff;
       const uint64_t flm = nfl >= 64 ? ~0ull : ((1ull << nfl) - 1ull);
       if (chg & flm) {
@@ -962,14 +963,13 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
         hv0 += s2; hv1 += s3;
       }
 #pragma unroll
-      for (int pass = 0; pass < 2; pass++) {
+      for (int pass = 0; pass < 2; pass++) { /* Hc | Hb are one flat array like Mc | Mb; a base entry is stored on both sides of the diagonal, a leg entry twice in place */
         const int hp = pass ? h1 : h0;
-        if (hp >= 0) {
-          const int da = hp & 0xff, db = (hp >> 8) & 0xff, slot = (hp >> 16) & 0xff;
-          const float hv = pass ? hv1 : hv0;
-          if (slot < 108) W.u2.n.Hc[slot / 9][slot % 9] = hv;
-          else { W.u2.n.Hb[da][db] = hv; W.u2.n.Hb[db][da] = hv; }
-        }
+        const int da = hp & 0xff, db = (hp >> 8) & 0xff, slot = (hp >> 16) & 0xff;
+        const float hv = pass ? hv1 : hv0;
+        float* H0 = &W.u2.n.Hc[0][0];
+        H0[slot] = hv;
+        H0[slot < 108 ? slot : 108 + 6 * db + da] = hv;
       }
       if (xl && !xsm) { /* the dense step reads the coupling rows' WEIGHTS from W.force (virtual rows above nefc hold theirs) */
         wave_barrier();
@@ -997,8 +997,7 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
 #pragma unroll
       for (int k = 0; k < GQ_NVD; k++) v += J[k] * search[k];
     }
-    float ms = 0.0f;
-    if (lane < GQ_NVD) ms = mul_m_row(W, search, lane);
+    const float ms = mul_m_row(W, search, ld);
     float alpha = 0.0f, lo = 0.0f, hi = -1.0f; /* hi < 0: no upper bracket yet */
     bool first_try = false;
     float g0 = 0.0f, UV = 0.0f, VV = 0.0f, N1 = 0.0f;
@@ -1013,7 +1012,7 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
     else {
     /* phi'(alpha) = sum over lanes of (s.Mdq + alpha s.Ms) [dof lanes] + d1(alpha) [row lanes]: the quadratic part rides
      * in the same reduction as the rows' derivatives */
-    const float p1 = lane < GQ_NVD ? search[lane] * md : 0.0f, p2 = lane < GQ_NVD ? search[lane] * ms : 0.0f;
+    const float p1 = lane < GQ_NVD ? search[ld] * md : 0.0f, p2 = lane < GQ_NVD ? search[ld] * ms : 0.0f;
     float d1, d2;
     row_dd(rtype, y, v, rR, rD, rfloss, d1, d2);
     /* elliptic contacts: along the line T(alpha)^2 = TT + 2 alpha UV + alpha^2 VV and N(alpha) = N + alpha N1, so three
@@ -1086,8 +1085,10 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
      * of 1e-7 of its starting value - rounding noise of the residuals, yet above `tolerance` and above the noise floor
      * of the gradient's two terms - and repeat a step that no longer changes qacc until the iteration cap (go1: one env
      * in 10 000 env-steps, 100 iterations, 1.1 ms for the whole launch). */
-    const bool tiny_step = CONE && ballot(lane < GQ_NVD && fabsf(alpha * search[lane]) > GQ_STEP_FLOOR * fmaxf(1.0f, fabsf(W.qacc[lane]))) == 0;
-    if (lane < GQ_NVD) { W.qacc[lane] += alpha * search[lane]; md += alpha * ms; }
+    const float qa_old = W.qacc[ld], qa_new = qa_old + alpha * search[ld];
+    const bool tiny_step = CONE && ballot(lane < GQ_NVD && fabsf(alpha * search[ld]) > GQ_STEP_FLOOR * fmaxf(1.0f, fabsf(qa_old))) == 0;
+    if constexpr (!CONE) wave_barrier(); /* (the ballot is one for the emulator: read above, write below) */
+    W.qacc[ld] = qa_new; md += alpha * ms;
     const float ynew = y + alpha * v;
     /* the cost is piecewise quadratic.  A full Newton step (accepted at the first trial) that leaves every row on the
      * piece it was linearised on has reached the minimiser of a model that IS the cost there: converged, and the
@@ -1113,7 +1114,7 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
         const float f2 = ell_state(E, y, rD, ci, wact, z2, t1, t2, t3);
         if (E.code) f = f2;
       }
-      if (lane < GQ_NVD) Mdq[lane] = md;
+      Mdq[ld] = md;
       iter++;
       exit_code = tiny_step ? 7 : (small_step ? 1 : 6);
       break;

@@ -24,15 +24,15 @@ __device__ inline Q4 stage_kinematics(WaveMem& W, const GqDevLinkRec L) { /* (by
   const int lane = lane_id();
   Q4 qbase = {W.qb[0], W.qb[1], W.qb[2], W.qb[3]};
   qbase = qnormalize(qbase);
-  if (lane == 0) {
+  { /* (every lane: same words, same values) */
     W.xpos[0][0] = 0.0f; W.xpos[0][1] = 0.0f; W.xpos[0][2] = W.basez;
     q2mat(W.xmat[0], qbase);
   }
   /* phase 1, lane = link (12 lanes): local transform of the link in its parent's frame - all model reads and the
    * sin/cos of the joint angle happen here, in parallel */
-  if (lane < GQ_NJ) { /* (the link's record - body_quat, joint axis / anchor, and the state-independent anchor and axis in the parent
-                       * frame, folded on the host - came with the prologue's loads: no model read in front of the sin/cos) */
-    const int j = lane;
+  { /* lane = link, mirror lanes (the link's record - body_quat, joint axis / anchor, and the state-independent anchor and axis in the parent
+     * frame, folded on the host - came in one batch: no model read in front of the sin/cos) */
+    const int j = lane < GQ_NJ ? lane : GQ_NJ - 1;
     const Q4 bq = {L.bq[0], L.bq[1], L.bq[2], L.bq[3]};
     const V3 jp = ld3(L.jp), ax = ld3(L.ax);
     float R1[9], sn, cs;
@@ -42,21 +42,22 @@ __device__ inline Q4 stage_kinematics(WaveMem& W, const GqDevLinkRec L) { /* (by
     q2mat(R1, ql);
     const V3 aloc = ld3(L.aloc);                    /* joint anchor in the parent frame */
     const V3 ploc = aloc - matvec(R1, jp);          /* child origin: rotation about the anchor keeps it fixed */
-    float* o = W.u.dyn.fkloc[lane];
+    float* o = W.u.dyn.fkloc[j];
     o[0] = ql.w; o[1] = ql.x; o[2] = ql.y; o[3] = ql.z;
     st3(o + 4, ploc); st3(o + 7, aloc); st3(o + 10, ld3(L.r0ax));
   }
   wave_barrier();
   GQ_SUB(W, 1, 2); /* kinematics phase 1 */
   /* phase 2, lane = leg: compose the three local transforms down the chain */
-  if (lane < 4) {
+  { /* lane = leg, mirror lanes */
+    const int leg = lane < 4 ? lane : 3;
     float Rp[9];
     q2mat(Rp, qbase);
     V3 pp = v3(0.0f, 0.0f, W.basez);
     Q4 pq = qbase;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      const int b = 1 + 3 * lane + i, j = 3 * lane + i;
+      const int b = 1 + 3 * leg + i, j = 3 * leg + i;
       const float* o = W.u.dyn.fkloc[j];
       const Q4 ql = {o[0], o[1], o[2], o[3]};
       st3(W.u.dyn.anchor[j], pp + matvec(Rp, ld3(o + 7)));   /* anchor/axis do not overlay fkloc */
@@ -87,10 +88,10 @@ template <class M> __device__ __forceinline__ FootRec foot_fetch(const M& m, con
 __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
                                             bool calf_only, const FootRec FR) {
   const int lane = lane_id();
-  if (lane < 4) { /* feet: exact plane-sphere */
+  { /* feet: exact plane-sphere; lane = foot, mirror lanes (the record is fetched with the clamped lane) */
     const int b = 3 + 3 * FR.leg;
     V3 c = ld3(W.xpos[b]) + matvec(W.xmat[b], ld3(FR.pos));
-    st3(W.foot_world[lane], c);
+    st3(W.foot_world[lane < 4 ? lane : 3], c);
   }
   /* link geoms.  Phase 1, lane = geom: plane normal in the geom frame and the OBB lower bound of the cloud.
    * Phase 2, lane = (surviving geom, 64-vertex chunk of its cloud), four geoms x 16 chunks per pass: lower bound of the chunk's
@@ -108,8 +109,9 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
   float d0 = 0.0f, gmargin = 0.0f, gradius = 0.0f;
   bool needs = false;
   int cadr = 0, cnum = 0, chk = -1;
-  if (lane < nlg) {
-    const GQ_MODEL GqDevGeom& G = m.lg[lane];
+  if (nlg > 0) { /* wave-uniform; lane = geom, mirror lanes (they never join the scan: `needs` is masked) */
+    const int lg_ = lane < nlg ? lane : nlg - 1;
+    const GQ_MODEL GqDevGeom& G = m.lg[lg_];
     const float* Rb = W.xmat[G.body];
     /* plane normal in the geom frame: n_g = Rg' Rb' n, n = (0,0,1) */
     const V3 nb = v3(Rb[6], Rb[7], Rb[8]);
@@ -118,9 +120,9 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
     gmargin = G.margin; gradius = G.radius;
     const float lower = d0 + dot(ng, ld3(G.aabb_c)) - (fabsf(ng.x) * G.aabb_h[0] + fabsf(ng.y) * G.aabb_h[1] + fabsf(ng.z) * G.aabb_h[2]) - gradius;
     const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
-    needs = G.ptype == 0 && lower < gmargin && (!calf_only || calf); /* primitive geoms are evaluated lane-locally (floor_candidates) */
+    needs = lane < nlg && G.ptype == 0 && lower < gmargin && (!calf_only || calf); /* primitive geoms are evaluated lane-locally (floor_candidates) */
     cadr = G.cloud_adr; cnum = G.cloud_num; chk = G.chunk_adr;
-    if (!needs) W.u2.c.lg_dist[lane] = 1e30f;
+    W.u2.c.lg_dist[lg_] = 1e30f; /* (a geom that is scanned gets its distance from phase 3) */
   }
   uint64_t todo = ballot(needs);
   if (todo) { /* wave-uniform */
@@ -521,17 +523,24 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   {
     int32_t* s_num = a.step_num; int32_t* s_prev = a.step_prev; float* s_time = a.time;
     pin(s_num); pin(s_prev); pin(s_time);
-    if (lane == 0 && !fwd_only) {
+    if (!fwd_only) { /* (every lane stores the same word: no exec-mask block - see the note on mirror lanes below) */
       const int32_t sn = W.step_old;
       gptr(s_num)[env] = sn + 1;
       if (s_prev) gptr(s_prev)[env] = sn;
       gptr(s_time)[env] = W.force[0] + h;
     }
   }
+  /* MIRROR LANES (round 5).  A block `if (lane < N) { ... LDS[lane] = f(LDS[lane]) }` costs a lone wavefront ~50 cycles of exec-mask
+   * bookkeeping (v_cmp, s_and_saveexec, s_cbranch_execz, s_or: profiles/r05_issue_model_lone_wave.txt) around a handful of 4-cycle
+   * instructions, and a step had ~200 of them.  Where a block has no cross-lane primitive inside, it now runs UNCONDITIONALLY with
+   * the lane index clamped: lanes >= N repeat lane N - 1's reads, arithmetic and stores - same addresses, same values, which the LDS and
+   * the memory pipeline take at the cost of one lane's (measured).  A block that reads and rewrites the same word puts a wave_barrier()
+   * between the read and the write (free on the GPU; the host emulator runs its lanes one after the other between barriers). */
+  const int ld = lane < GQ_NVD ? lane : GQ_NVD - 1, lj = lane < GQ_NJ ? lane : GQ_NJ - 1, lb = lane < GQ_NB ? lane : GQ_NB - 1, lq = lane < 4 ? lane : 3;
 
   /* actuation (mj_fwdActuation: torque motors) and passive damping depend on ctrl / qvel and model constants only: done
    * here, so that the (two-level dependent) model loads overlap with the kinematics instead of sitting on S5's path */
-  if (lane < GQ_NVD) { /* (the dof's record came with the prologue's loads; the limits are selects, not branches) */
+  { /* lane = dof (mirror lanes) - the dof's record came in one batch; the limits are selects, not branches */
     const GqDevDofRec& D = Drec;
     float act = 0.0f;
     {
@@ -542,10 +551,12 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       act = u >= 0 ? D.gear * c : 0.0f;
       act = (D.flags & 4) ? fminf(fmaxf(act, D.a_lo), D.a_hi) : act;
     }
-    W.act[lane] = act;
+    W.act[ld] = act;
     const float damp = D.damping;
-    if constexpr (SOLVER == 1) W.F[0][lane] = h * damp; /* the Newton path stores no factor: F keeps h*damping for the Euler system (S10) */
-    W.smooth[lane] = -damp * W.qvel[lane] + act + W.smooth[lane]; /* qfrc_applied waits there */
+    if constexpr (SOLVER == 1) W.F[0][ld] = h * damp; /* the Newton path stores no factor: F keeps h*damping for the Euler system (S10) */
+    const float sm_new = -damp * W.qvel[ld] + act + W.smooth[ld]; /* qfrc_applied waits there */
+    wave_barrier();
+    W.smooth[ld] = sm_new;
   }
   GQ_SUB(W, 1, 1); /* actuation + passive */
   if constexpr (SOLVER == 1) wave_priority(prio_hint);
@@ -558,8 +569,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
 #pragma unroll
   for (int p = 0; p < 3; p++) { s3e[p] = m.s3_ent[p][lane]; s3a[p] = m.s3_arm[p][lane]; }
   const V3 O = v3(0.0f, 0.0f, W.basez);
-  if (lane < GQ_NB) {
-    const int b = lane;
+  { /* lane = body, mirror lanes */
+    const int b = lb;
     const float* R = W.xmat[b];
     V3 d = ld3(W.xpos[b]) + matvec(R, ld3(Brec.ipos)) - O;
     /* I_w = R Ib R' */
@@ -579,30 +590,32 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     ci[3] = Iw[1] - mb * d.x * d.y; ci[4] = Iw[2] - mb * d.x * d.z; ci[5] = Iw[5] - mb * d.y * d.z;
     ci[6] = mb * d.x; ci[7] = mb * d.y; ci[8] = mb * d.z; ci[9] = mb;
   }
-  /* motion subspaces */
-  if (lane < GQ_NVD) {
-    float* s = W.cdof[lane];
-    if (lane < 3) { s[0] = s[1] = s[2] = 0.0f; s[3] = lane == 0; s[4] = lane == 1; s[5] = lane == 2; }
-    else if (lane < 6) { /* body-fixed rotation axes through O: linear part vanishes */
-      const float* R = W.xmat[0];
-      s[0] = R[lane - 3]; s[1] = R[3 + lane - 3]; s[2] = R[6 + lane - 3]; s[3] = s[4] = s[5] = 0.0f;
-    }
+  /* motion subspaces: lanes 0-5 the base dofs (translations e_k; body-fixed rotation axes through O, whose linear part vanishes), selects */
+  {
+    const int d6 = lane < 6 ? lane : 5, c3 = d6 < 3 ? 0 : d6 - 3;
+    const float* R = W.xmat[0];
+    const float r0 = R[c3], r1 = R[3 + c3], r2 = R[6 + c3];
+    const bool tr = d6 < 3;
+    float* s = W.cdof[d6];
+    s[0] = tr ? 0.0f : r0; s[1] = tr ? 0.0f : r1; s[2] = tr ? 0.0f : r2;
+    s[3] = d6 == 0 ? 1.0f : 0.0f; s[4] = d6 == 1 ? 1.0f : 0.0f; s[5] = d6 == 2 ? 1.0f : 0.0f;
   }
   wave_barrier();
-  if (lane >= 6 && lane < GQ_NVD) {
-    const int j = lane - 6;
+  { /* lane - 6 = hinge, mirror lanes on both sides */
+    const int j = lane < 6 ? 0 : (lane < GQ_NVD ? lane - 6 : GQ_NJ - 1);
     V3 ax = ld3(W.u.dyn.axis[j]);
-    st3(W.cdof[lane], ax);
-    st3(W.cdof[lane] + 3, cross(ax, O - ld3(W.u.dyn.anchor[j])));
+    st3(W.cdof[6 + j], ax);
+    st3(W.cdof[6 + j] + 3, cross(ax, O - ld3(W.u.dyn.anchor[j])));
   }
   /* composite inertias: everything is about the same point in the same axes, so they are plain sums */
-  if (lane < 40) {
-    const int leg = lane / 10, k = lane % 10, b0 = 1 + 3 * leg;
+  {
+    const int l40 = lane < 40 ? lane : 39;
+    const int leg = l40 / 10, k = l40 % 10, b0 = 1 + 3 * leg;
     float c2 = W.u.dyn.cinert[b0 + 2][k], c1 = W.u.dyn.cinert[b0 + 1][k] + c2, c0 = W.u.dyn.cinert[b0][k] + c1;
     W.u.dyn.crb[b0 + 2][k] = c2; W.u.dyn.crb[b0 + 1][k] = c1; W.u.dyn.crb[b0][k] = c0;
   }
   wave_barrier();
-  if (lane < 10) W.u.dyn.crb[0][lane] = W.u.dyn.cinert[0][lane] + W.u.dyn.crb[1][lane] + W.u.dyn.crb[4][lane] + W.u.dyn.crb[7][lane] + W.u.dyn.crb[10][lane];
+  { const int l10 = lane < 10 ? lane : 9; W.u.dyn.crb[0][l10] = W.u.dyn.cinert[0][l10] + W.u.dyn.crb[1][l10] + W.u.dyn.crb[4][l10] + W.u.dyn.crb[7][l10] + W.u.dyn.crb[10][l10]; }
   wave_barrier();
 
   GQ_TICK(2); GQ_SUB(W, 1, 4);
@@ -614,15 +627,14 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     static_assert(sizeof(WaveMem::Mc) == 108 * 4 && offsetof(WaveMem, Mb) == offsetof(WaveMem, Mc) + sizeof(WaveMem::Mc), "S3 writes Mc | Mb as one flat array");
     float* M0 = &W.Mc[0][0];
 #pragma unroll
-    for (int p = 0; p < 3; p++) {
-      if (p < 2 || lane < 144 - 2 * GQ_WAVE) {
-        const int ent = s3e[p], dd = ent & 0xff, sa = (ent >> 8) & 0xff, bd = (ent >> 16) & 0xff;
-        float buf[6];
-        mul_inert(buf, W.u.dyn.crb[bd], W.cdof[dd]);
-        const float* sv = W.cdof[sa];
-        const float v = sv[0] * buf[0] + sv[1] * buf[1] + sv[2] * buf[2] + sv[3] * buf[3] + sv[4] * buf[4] + sv[5] * buf[5];
-        M0[lane + GQ_WAVE * p] = (ent >> 24) ? v + s3a[p] : 0.0f;
-      }
+    for (int p = 0; p < 3; p++) { /* (the table's slots past entry 143 repeat entry 143: mirror lanes) */
+      const int ent = s3e[p], dd = ent & 0xff, sa = (ent >> 8) & 0xff, bd = (ent >> 16) & 0xff;
+      float buf[6];
+      mul_inert(buf, W.u.dyn.crb[bd], W.cdof[dd]);
+      const float* sv = W.cdof[sa];
+      const float v = sv[0] * buf[0] + sv[1] * buf[1] + sv[2] * buf[2] + sv[3] * buf[3] + sv[4] * buf[4] + sv[5] * buf[5];
+      const int e = lane + GQ_WAVE * p;
+      M0[e < 143 ? e : 143] = (ent >> 24) ? v + s3a[p] : 0.0f;
     }
   }
   wave_barrier();
@@ -659,7 +671,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   }
   const GQ_MODEL float* vx_p = K.vx; const GQ_MODEL float* vy_p = K.vy; const GQ_MODEL float* vz_p = K.vz;
   /* ================================================================ S5: velocity stage (mj_comVel, mj_rne) */
-  if (lane < 4) {
+  { /* lane = leg, mirror lanes */
     /* base velocity and bias acceleration, recomputed per leg lane */
     float vb[6], ab[6];
     {
@@ -669,13 +681,12 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       st3(vb, ww); st3(vb + 3, vl);
       V3 al = cross(vl, ww);
       ab[0] = ab[1] = ab[2] = 0.0f; ab[3] = al.x; ab[4] = al.y; ab[5] = al.z - K.gravity_z;
-      if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) { W.u.dyn.cvel[0][k] = vb[k]; W.u.dyn.cacc[0][k] = ab[k]; }
-      }
+      for (int k = 0; k < 6; k++) { W.u.dyn.cvel[0][k] = vb[k]; W.u.dyn.cacc[0][k] = ab[k]; } /* (every lane: same words, same values) */
     }
+#pragma unroll
     for (int i = 0; i < 3; i++) {
-      const int b = 1 + 3 * lane + i, d = 6 + 3 * lane + i;
+      const int b = 1 + 3 * lq + i, d = 6 + 3 * lq + i;
       float cd[6];
       cross_motion(cd, vb, W.cdof[d]);
       float qd = W.qvel[d];
@@ -684,29 +695,38 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     }
   }
   wave_barrier();
-  if (lane < GQ_NB) {
+  { /* lane = body, mirror lanes */
     float t1[6], t2[6], f[6];
-    mul_inert(t1, W.u.dyn.cinert[lane], W.u.dyn.cacc[lane]);
-    mul_inert(t2, W.u.dyn.cinert[lane], W.u.dyn.cvel[lane]);
-    cross_force(f, W.u.dyn.cvel[lane], t2);
+    mul_inert(t1, W.u.dyn.cinert[lb], W.u.dyn.cacc[lb]);
+    mul_inert(t2, W.u.dyn.cinert[lb], W.u.dyn.cvel[lb]);
+    cross_force(f, W.u.dyn.cvel[lb], t2);
 #pragma unroll
-    for (int k = 0; k < 6; k++) W.u.dyn.cfrc[lane][k] = f[k] + t1[k];
+    for (int k = 0; k < 6; k++) W.u.dyn.cfrc[lb][k] = f[k] + t1[k];
   }
   wave_barrier();
-  if (lane < 24) { /* accumulate up the legs */
-    const int leg = lane / 6, k = lane % 6, b0 = 1 + 3 * leg;
+  { /* accumulate up the legs: lane = (leg, component), mirror lanes; the sums are read first, written after a barrier */
+    const int l24 = lane < 24 ? lane : 23;
+    const int leg = l24 / 6, k = l24 % 6, b0 = 1 + 3 * leg;
     float f2 = W.u.dyn.cfrc[b0 + 2][k], f1 = W.u.dyn.cfrc[b0 + 1][k] + f2, f0 = W.u.dyn.cfrc[b0][k] + f1;
+    wave_barrier();
     W.u.dyn.cfrc[b0 + 1][k] = f1; W.u.dyn.cfrc[b0][k] = f0;
   }
   wave_barrier();
-  if (lane < 6) W.u.dyn.cfrc[0][lane] += W.u.dyn.cfrc[1][lane] + W.u.dyn.cfrc[4][lane] + W.u.dyn.cfrc[7][lane] + W.u.dyn.cfrc[10][lane];
+  {
+    const int l6 = lane < 6 ? lane : 5;
+    const float fb = W.u.dyn.cfrc[0][l6] + (W.u.dyn.cfrc[1][l6] + W.u.dyn.cfrc[4][l6] + W.u.dyn.cfrc[7][l6] + W.u.dyn.cfrc[10][l6]);
+    wave_barrier();
+    W.u.dyn.cfrc[0][l6] = fb;
+  }
   wave_barrier();
-  if (lane < GQ_NVD) {
-    const float* s = W.cdof[lane];
-    const float* f = W.u.dyn.cfrc[dof_body(lane)];
+  { /* lane = dof, mirror lanes */
+    const float* s = W.cdof[ld];
+    const float* f = W.u.dyn.cfrc[dof_body(ld)];
     float bias = s[0] * f[0] + s[1] * f[1] + s[2] * f[2] + s[3] * f[3] + s[4] * f[4] + s[5] * f[5];
-    W.bias[lane] = bias;
-    W.smooth[lane] -= bias; /* passive + actuation + applied were put there right after S0 */
+    const float sm_new = W.smooth[ld] - bias; /* passive + actuation + applied were put there right after S0 */
+    wave_barrier();
+    W.bias[ld] = bias;
+    W.smooth[ld] = sm_new;
   }
 
   GQ_TICK(5); GQ_SUB(W, 1, 6);
@@ -802,14 +822,15 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     /* joint limits: lane j < 12 owns hinge j (lower side first, then upper) */
     bool lim_lo = false, lim_hi = false;
     float dlo = 0.0f, dhi = 0.0f;
-    if (lane < GQ_NJ && lim_on) {
-      const float q = W.qj[lane];
+    {
+      const float q = W.qj[lj];
       dlo = q - lim_lo_; dhi = lim_hi_ - q;
-      lim_lo = dlo < lim_mg; lim_hi = dhi < lim_mg;
+      const bool mine = lane < GQ_NJ && lim_on != 0;
+      lim_lo = mine && dlo < lim_mg; lim_hi = mine && dhi < lim_mg;
     }
     const uint64_t mlo = ballot(lim_lo), mhi = ballot(lim_hi);
     int nl = popc64(mlo) + popc64(mhi);
-    {
+    if (nl > 0) { /* wave-uniform */
       int at = popc64(mlo & lt) + popc64(mhi & lt);
       if (lim_lo && at < GQ_NJ) { W.u2.c.lim_jnt[at] = lane; W.u2.c.lim_side[at] = 1.0f; W.u2.c.lim_dist[at] = dlo; at++; }
       if (lim_hi && at < GQ_NJ) { W.u2.c.lim_jnt[at] = lane; W.u2.c.lim_side[at] = -1.0f; W.u2.c.lim_dist[at] = dhi; }
@@ -831,8 +852,10 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     const float fg = (code < 4 && mu_env >= 0.0f) ? mu_env : fgeom;
     const float mu = fmaxf(1e-5f, fric_rule == 0 ? fmaxf(ff, fg) : (fric_rule == 1 ? ff : fg)); /* mjMINMU */
     int nfit = 0;
+    const bool multi = ballot(tk[1] || tk[2] || tk[3]) != 0; /* wave-uniform: some item touches at a point other than its first (primitive geoms only) */
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+      if (k > 0 && !multi) break;
       if (tk[k]) { /* the lane's j-th contact in MuJoCo's order: j = touching candidates placed before this one */
         int j = 0;
 #pragma unroll
@@ -853,8 +876,8 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       }
     }
     const int tot = bcast(wave_incl_scan(nfit | ((nfit * need) << 8)), 63);
-    if (lane == GQ_WAVE - 1) W.ndrop = (incl & 0xff) - (tot & 0xff); /* lane 63's inclusive sum = every touching candidate of the floor pass */
-    if (lane == 0) {
+    { /* (every lane stores the same words) */
+      W.ndrop = (bcast(incl, 63) & 0xff) - (tot & 0xff); /* lane 63's inclusive sum = every touching candidate of the floor pass */
       W.ncon = tot & 0xff; W.nlim = nl; W.nefc = C.nfl + nl + (tot >> 8); W.invalid = invalid;
       W.foot_touch = ftm;
     }
@@ -1234,7 +1257,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   if constexpr (SOLVER == 1) {
     /* qacc and qfrc_constraint (= M (qacc - qacc_smooth)) come out of the Newton solve; only the Euler system
      * (M + h D) qacc_int = qfrc_smooth + qfrc_constraint is left */
-    if (lane < GQ_NVD) W.act[lane] = W.smooth[lane] + W.qfrc_c[lane];
+    W.act[ld] = W.smooth[ld] + W.qfrc_c[ld];
     wave_barrier();
     solve_tree_stored(GQ_EULER_FLEG(W), GQ_EULER_FBASE(W), W.act, W.qacc_int); /* factor of M + h diag(damping): left in LDS by the solver's first elimination */
   } else {
@@ -1316,27 +1339,27 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   /* mj_checkAcc: a non-finite or absurd acceleration (|qacc| >= 1e10, MuJoCo's mjMAXVAL) means the simulation diverged.
    * MuJoCo resets the data and warns; here the env is frozen for this step (zero acceleration) and flagged terminated +
    * truncated, so that an auto-resetting batch re-spawns it and a NaN never reaches the next step */
-  const bool diverged = ballot(lane < GQ_NVD && !(fabsf(W.qacc[lane]) < 1e10f && fabsf(W.qacc_int[lane]) < 1e10f)) != 0;
+  const float qa_raw = W.qacc[ld], qi_raw = W.qacc_int[ld]; /* lane = dof, mirror lanes */
+  const bool diverged = ballot(!(fabsf(qa_raw) < 1e10f && fabsf(qi_raw) < 1e10f)) != 0;
   /* semi-implicit Euler (mj_Euler): velocity with the damped system, then positions with the new velocity */
   float vnew = 0.0f;
-  if (lane < GQ_NVD) {
-    if (diverged) { W.qacc[lane] = 0.0f; W.qacc_int[lane] = 0.0f; }
-    vnew = W.qvel[lane] + h * W.qacc_int[lane];
-    if (!(fabsf(vnew) < 1e10f)) vnew = 0.0f;
-    gptr(e_qvel)[(size_t)env * 18 + lane] = vnew;
-    gptr(e_qacc)[(size_t)env * 18 + lane] = W.qacc[lane];
-    gptr(e_warm)[(size_t)env * 18 + lane] = W.qacc[lane];
+  {
+    const float qa = diverged ? 0.0f : qa_raw, qi = diverged ? 0.0f : qi_raw;
+    if (diverged) { W.qacc[ld] = 0.0f; W.qacc_int[ld] = 0.0f; } /* wave-uniform, rare */
+    vnew = W.qvel[ld] + h * qi;
+    vnew = fabsf(vnew) < 1e10f ? vnew : 0.0f;
+    gptr(e_qvel)[(size_t)env * 18 + ld] = vnew;
+    gptr(e_qacc)[(size_t)env * 18 + ld] = qa;
+    gptr(e_warm)[(size_t)env * 18 + ld] = qa;
   }
   /* base x,y stay in f64 (uniform: every lane reads the same two words) and never enter fp32 arithmetic; they wait
    * in LDS since S0, so they do not occupy registers across the solver */
   const double bx_d = W.bxy[0], by_d = W.bxy[1];
   wave_barrier();
-  if (lane < GQ_NVD) W.qvel[lane] = vnew; /* new qvel; old one is not needed any more */
+  W.qvel[ld] = vnew; /* new qvel; old one is not needed any more */
   wave_barrier();
   /* positions */
   const double bxn_d = bx_d + (double)h * (double)W.qvel[0], byn_d = by_d + (double)h * (double)W.qvel[1];
-  if (lane == 0) gptr(e_qpos)[(size_t)env * 19 + 0] = bxn_d;
-  if (lane == 1) gptr(e_qpos)[(size_t)env * 19 + 1] = byn_d;
   const float znew = W.basez + h * W.qvel[2];
   Q4 qn;
   {
@@ -1356,15 +1379,13 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     }
     qn = qnormalize(qn);
   }
-  if (lane == 2) gptr(e_qpos)[(size_t)env * 19 + 2] = (double)znew;
-  if (lane >= 3 && lane < 7) {
-    float qc = lane == 3 ? qn.w : (lane == 4 ? qn.x : (lane == 5 ? qn.y : qn.z));
-    gptr(e_qpos)[(size_t)env * 19 + lane] = (double)qc;
-  }
-  float qjn = 0.0f;
-  if (lane >= 7 && lane < 19) {
-    qjn = W.qj[lane - 7] + h * W.qvel[lane - 1];
-    gptr(e_qpos)[(size_t)env * 19 + lane] = (double)qjn;
+  /* the qpos row: lane = column (mirror lanes), ONE store - base x, y (f64), z, the quaternion, the joint angles picked by selects */
+  const int l19 = lane < 19 ? lane : 18, jq = l19 < 7 ? 0 : l19 - 7;
+  const float qjn = W.qj[jq] + h * W.qvel[6 + jq];
+  const float qcol = l19 < 3 ? znew : (l19 == 3 ? qn.w : (l19 == 4 ? qn.x : (l19 == 5 ? qn.y : (l19 == 6 ? qn.z : qjn)))); /* columns 2 .. 18 */
+  {
+    const double qd = l19 == 0 ? bxn_d : (l19 == 1 ? byn_d : (double)qcol);
+    gptr(e_qpos)[(size_t)env * 19 + l19] = qd;
   }
 
   GQ_TICK(11); GQ_SUB(W, 2, 6); /* integration + state stores */
@@ -1374,10 +1395,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   V3 vlin = v3(W.qvel[0], W.qvel[1], W.qvel[2]), wloc = v3(W.qvel[3], W.qvel[4], W.qvel[5]);
   float* ob = W.u.obs;
   /* observables nobody asked for are not computed (obs_need: groups of canonical scalars the output layout refers to) */
-  if (lane == 0) {
-    ob[OB_QPOS] = (float)bxn_d; ob[OB_QPOS + 1] = (float)byn_d; ob[OB_QPOS + 2] = znew;
-    ob[OB_QPOS + 3] = qn.w; ob[OB_QPOS + 4] = qn.x; ob[OB_QPOS + 5] = qn.y; ob[OB_QPOS + 6] = qn.z;
-  }
+  ob[OB_QPOS + l19] = l19 == 0 ? (float)bxn_d : (l19 == 1 ? (float)byn_d : qcol); /* the same row in fp32: one store */
   if (obs_need & GQ_NEED_BASE) {
   /* scipy as_euler('xyz') of the new orientation */
   float sy = fminf(fmaxf(-Rn[6], -1.0f), 1.0f);
@@ -1392,7 +1410,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   V3 tl = v3(cyaw * cmdl.x - syaw * cmdl.y, syaw * cmdl.x + cyaw * cmdl.y, cmdl.z);
   V3 ta = v3(0.0f, 0.0f, W.cmd[3]);
   V3 acc3 = v3(W.qacc[0], W.qacc[1], W.qacc[2]);
-  if (lane == 0) {
+  { /* (every lane stores the same words: the values are wave-uniform) */
     ob[OB_BASE_POS] = (float)bxn_d; ob[OB_BASE_POS + 1] = (float)byn_d; ob[OB_BASE_POS + 2] = znew;
     st3(ob + OB_LIN_VEL, vlin); st3(ob + OB_LIN_VEL_ERR, tl - vlin); st3(ob + OB_LIN_ACC, acc3);
     V3 ww = matvec(Rn, wloc);
@@ -1408,9 +1426,9 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   }
   }
   GQ_SUB(W, 2, 7); /* base observables */
-  if (lane < GQ_NVD) ob[OB_QVEL + lane] = W.qvel[lane];
-  if (lane < 12) { ob[OB_TAU + lane] = W.ctrl[lane]; ob[OB_QVEL_JS + lane] = W.qvel[6 + lane]; }
-  if (lane >= 7 && lane < 19) { ob[OB_QPOS + lane] = qjn; ob[OB_QPOS_JS + lane - 7] = qjn; }
+  ob[OB_QVEL + ld] = W.qvel[ld];
+  ob[OB_TAU + lj] = W.ctrl[lj]; ob[OB_QVEL_JS + lj] = W.qvel[6 + lj];
+  ob[OB_QPOS_JS + jq] = qjn;
   /* kinetic energy 1/2 v'Mv and work (M qacc).v with the OLD mass matrix, NEW velocity, qacc of this step */
   if (obs_need & GQ_NEED_ENERGY) {
     float ke_part = 0.0f, wk_part = 0.0f;
@@ -1422,33 +1440,36 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       const float* M0 = &W.Mc[0][0];
 #pragma unroll
       for (int p = 0; p < 3; p++) {
-        if (p < 2 || lane < 144 - 2 * GQ_WAVE) {
-          const int ent = s3k[p], dd = ent & 0xff, sa = (ent >> 8) & 0xff;
-          const float coef = (ent >> 24) ? ((p < 2 && (p == 0 || lane < 108 - GQ_WAVE) && dd != sa) ? 1.0f : 0.5f) : 0.0f;
-          ke_part += coef * M0[lane + GQ_WAVE * p] * W.qvel[dd] * W.qvel[sa];
-        }
+        const int ent = s3k[p], dd = ent & 0xff, sa = (ent >> 8) & 0xff, e = lane + GQ_WAVE * p;
+        const bool counts = (p < 2 || lane < 144 - 2 * GQ_WAVE) && (ent >> 24) != 0; /* (the table's slots past entry 143 repeat it) */
+        const float coef = counts ? ((p < 2 && (p == 0 || lane < 108 - GQ_WAVE) && dd != sa) ? 1.0f : 0.5f) : 0.0f;
+        ke_part += coef * M0[e < 143 ? e : 143] * W.qvel[dd] * W.qvel[sa];
       }
-      if (lane < GQ_NVD) wk_part = diverged ? 0.0f : W.act[lane] * W.qvel[lane]; /* (a frozen env: qacc was zeroed) */
+      wk_part = (lane < GQ_NVD && !diverged) ? W.act[ld] * W.qvel[ld] : 0.0f; /* (a frozen env: qacc was zeroed) */
     } else if (lane < GQ_NVD) {
       const float mv = mul_m_row(W, W.qvel, lane), ma = mul_m_row(W, W.qacc, lane);
       ke_part = 0.5f * W.qvel[lane] * mv; wk_part = ma * W.qvel[lane];
     }
     float ke = wave_sum(ke_part), wk = wave_sum(wk_part);
-    if (lane == 0) { ob[OB_KE] = ke; ob[OB_WORK] = wk; }
+    ob[OB_KE] = ke; ob[OB_WORK] = wk;
   }
   GQ_SUB(W, 2, 8); /* joint observables + energy */
   /* feet: lane k < 4 = foot k in FL FR RL RR order */
-  if ((obs_need & (GQ_NEED_FEET | GQ_NEED_CONTACT)) && lane < 4) {
+  if (obs_need & (GQ_NEED_FEET | GQ_NEED_CONTACT)) { /* wave-uniform; lane = foot, mirror lanes */
     const int leg = FRec.leg, body = 3 + 3 * leg;
-    V3 pw = ld3(W.foot_world[lane]); /* relative to the OLD base x/y */
+    V3 pw = ld3(W.foot_world[lq]); /* relative to the OLD base x/y */
     /* spatial velocity of the calf with old cdof and new qvel (J_old * qvel_new) */
     float sv[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
     for (int d = 0; d < 6; d++)
 #pragma unroll
       for (int k = 0; k < 6; k++) sv[k] += W.cdof[d][k] * W.qvel[d];
-    for (int d = 6 + 3 * leg; d < 9 + 3 * leg; d++)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int d = 6 + 3 * leg + i;
 #pragma unroll
       for (int k = 0; k < 6; k++) sv[k] += W.cdof[d][k] * W.qvel[d];
+    }
     V3 fv = ld3(sv + 3) + cross(ld3(sv), pw - v3(0.0f, 0.0f, W.basez));
     /* world position of the foot: old base x/y + relative.  feet_pos:base uses the NEW base pose (quirk B3) */
     V3 pworld = v3((float)(bx_d + (double)pw.x), (float)(by_d + (double)pw.y), pw.z);
@@ -1458,40 +1479,44 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
      * and calf link geom alike) sets the state and adds its force */
     V3 cf = v3(0.0f, 0.0f, 0.0f);
     float cs = 0.0f;
-    for (int c = 0; c < ((obs_need & GQ_NEED_CONTACT) ? ncon : 0); c++) {
-      if (W.con_body[c] != body) continue;
-      cs = 1.0f;
-      const int r0 = W.con_row[c];
-      float fn, ft1 = 0.0f, ft2 = 0.0f; /* contact-frame force: mj_contactForce */
-      if (W.con_dim[c] == 1) fn = W.force[r0];
-      else if constexpr (CONE) { fn = W.force[r0]; ft1 = W.force[r0 + 1]; ft2 = W.force[r0 + 2]; }
-      else { /* mju_decodePyramid */
-        const float f0 = W.force[r0], f1 = W.force[r0 + 1], f2 = W.force[r0 + 2], f3 = W.force[r0 + 3], mu = W.con_mu[c];
-        fn = f0 + f1 + f2 + f3; ft1 = mu * (f0 - f1); ft2 = mu * (f2 - f3);
+    for (int c = 0; c < ((obs_need & GQ_NEED_CONTACT) ? ncon : 0); c++) { /* wave-uniform trip count; the contact's words are wave-uniform
+                                                                            * reads, the foot's share is a select (no divergent branch) */
+      const bool mine = W.con_body[c] == body;
+      const int r0 = W.con_row[c], dimc = W.con_dim[c];
+      float fn, ft1, ft2; /* contact-frame force: mj_contactForce */
+      if constexpr (CONE) {
+        const float f0 = W.force[r0], f1 = W.force[r0 + 1 < 63 ? r0 + 1 : 63], f2 = W.force[r0 + 2 < 63 ? r0 + 2 : 63];
+        fn = f0; ft1 = dimc == 1 ? 0.0f : f1; ft2 = dimc == 1 ? 0.0f : f2;
+      } else { /* mju_decodePyramid */
+        const float f0 = W.force[r0], f1 = W.force[r0 + 1 < 63 ? r0 + 1 : 63], f2 = W.force[r0 + 2 < 63 ? r0 + 2 : 63], f3 = W.force[r0 + 3 < 63 ? r0 + 3 : 63], mu = W.con_mu[c];
+        fn = dimc == 1 ? f0 : f0 + f1 + f2 + f3; ft1 = dimc == 1 ? 0.0f : mu * (f0 - f1); ft2 = dimc == 1 ? 0.0f : mu * (f2 - f3);
       }
-      bool own_frame = false;
-      if constexpr (GEN) own_frame = GQ_BX_WCLS(W)[c] != -1;
-      if (own_frame) { /* frame' * f with the contact's own frame */
+      int wcls = -1;
+      if constexpr (GEN) wcls = uniform(GQ_BX_WCLS(W)[c]);
+      V3 add;
+      if (wcls != -1) { /* wave-uniform: frame' * f with the contact's own frame */
         const V3 cn = ld3(GQ_BX_CONNRM(W) + 3 * c);
         V3 ct1, ct2;
         make_frame(cn, ct1, ct2);
-        cf = cf + fn * cn + ft1 * ct1 + ft2 * ct2;
+        add = fn * cn + ft1 * ct1 + ft2 * ct2;
       } else { /* floor: n = z, t1 = (cos, sin, 0), t2 = (-sin, cos, 0) */
         const float t1c = W.con_t1[c][0], t1s = W.con_t1[c][1];
-        cf = cf + v3(ft1 * t1c - ft2 * t1s, ft1 * t1s + ft2 * t1c, fn);
+        add = v3(ft1 * t1c - ft2 * t1s, ft1 * t1s + ft2 * t1c, fn);
       }
+      cs = mine ? 1.0f : cs;
+      cf = v3(mine ? cf.x + add.x : cf.x, mine ? cf.y + add.y : cf.y, mine ? cf.z + add.z : cf.z);
     }
-    if ((W.foot_touch >> lane) & 1) cs = 1.0f; /* contact detected but dropped by the row budget */
+    if ((W.foot_touch >> lq) & 1) cs = 1.0f; /* contact detected but dropped by the row budget */
     /* slot of this foot in legs_order-dependent observables is resolved by obs_map; canonical order = FL FR RL RR */
-    st3(ob + OB_FEET_POS + 3 * lane, pworld);
-    st3(ob + OB_FEET_POS_B + 3 * lane, matTvec(Rn, prel_new));
-    st3(ob + OB_FEET_VEL + 3 * lane, fv);
-    st3(ob + OB_FEET_VEL_REL + 3 * lane, fvr);
-    st3(ob + OB_FEET_VEL_B + 3 * lane, matTvec(Rn, fv));
-    st3(ob + OB_FEET_VEL_REL_B + 3 * lane, matTvec(Rn, fvr));
-    ob[OB_CONTACT_STATE + lane] = cs;
-    st3(ob + OB_CONTACT_F + 3 * lane, cf);
-    st3(ob + OB_CONTACT_F_B + 3 * lane, matTvec(Rn, cf));
+    st3(ob + OB_FEET_POS + 3 * lq, pworld);
+    st3(ob + OB_FEET_POS_B + 3 * lq, matTvec(Rn, prel_new));
+    st3(ob + OB_FEET_VEL + 3 * lq, fv);
+    st3(ob + OB_FEET_VEL_REL + 3 * lq, fvr);
+    st3(ob + OB_FEET_VEL_B + 3 * lq, matTvec(Rn, fv));
+    st3(ob + OB_FEET_VEL_REL_B + 3 * lq, matTvec(Rn, fvr));
+    ob[OB_CONTACT_STATE + lq] = cs;
+    st3(ob + OB_CONTACT_F + 3 * lq, cf);
+    st3(ob + OB_CONTACT_F_B + 3 * lq, matTvec(Rn, cf));
   }
   wave_barrier();
   GQ_SUB(W, 2, 9); /* feet + contact forces */
@@ -1516,13 +1541,13 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       const int o = g == 0 ? OB_IMU_ACC : OB_IMU_GYRO;
       ob[o + ax] = W.warm[lane] + bias + noise; ob[o + 3 + ax] = noise; ob[o + 6 + ax] = bias;
     }
-  } else if (lane < 18) ob[OB_IMU_ACC + lane] = 0.0f;
+  } else ob[OB_IMU_ACC + ld] = 0.0f;
   /* termination (quadruped_env.py:283-285): non-foot contact with the ground, or base outside the terrain */
   int terminated = 0;
   {
     const bool oob = bxn_d > tlim0 || bxn_d < tlim1 || byn_d > tlim2 || byn_d < tlim3;
     terminated = W.invalid || oob || diverged;
-    if (lane == 0) {
+    { /* (every lane stores the same words) */
       if (pass == 0) { /* the flags of the user's step survive an in-kernel auto-reset */
         gptr(e_inval)[env] = (uint8_t)W.invalid;
         gptr(e_term)[env] = (uint8_t)terminated;
