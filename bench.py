@@ -58,6 +58,26 @@ def pmc_traffic():
         return None, None
 
 
+def valu_issue(kernel_ms: float, waves_per_simd: int = 4):
+    """VALU issue fraction of the headline launch ("report achieved HBM fraction and VALU utilisation"):
+    VALU instructions per wave from the last committed rocprofv3 --pmc SQ_INSTS_VALU pass (profiles/latest_sq.json) x the
+    waves resident per SIMD x the issue cycles of a wave64 VALU instruction (2 on the SIMD-32 datapath for fp32 - MI355X_MICROARCH.md; 4
+    on CDNA3's SIMD-16), over the launch's cycles at the 2.4 GHz peak clock.  Same source-hash staleness check as `traffic`."""
+    p = ROOT / 'profiles' / 'latest_sq.json'
+    try:
+        d = json.loads(p.read_text())
+        now = kernel_source_hash()
+        per_wave = d['valu_per_wave']
+        cyc = per_wave * waves_per_simd * 2
+        return {'valu_insts_per_wave': per_wave, 'waves_per_simd': waves_per_simd, 'issue_cycles_per_inst': 2, 'clock_ghz': 2.4,
+                'busy_us': cyc / 2.4e3, 'frac': cyc / 2.4e3 / (kernel_ms * 1e3),
+                'active_lanes_per_valu': d.get('active_lanes_per_valu'),
+                'source': {'profile': d.get('profile'), 'kernel_src_sha16': d.get('kernel_src_sha16'), 'current_kernel_src_sha16': now,
+                           'stale': d.get('kernel_src_sha16') != now}}
+    except Exception:
+        return None
+
+
 def kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
@@ -89,7 +109,8 @@ def cpu_baseline(seconds_budget: float = 15.0, all_cores: bool = True):
     out = {'value': done / t_used, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
            'sample': f'{done} steps of 1 mini_cheetah env on flat, 50*N(0,1) torques, ALL_OBS assembled each step, '
                      f'reset to the start state on termination; C fp64 restatement of mj_step with the Newton solver '
-                     f'(MuJoCo itself is not installable here), {os.cpu_count()} host cores present, 1 used'}
+                     f'(MuJoCo itself is not installable here; gcc -O3 -march=x86-64-v2, see oracle/Makefile - portable across the build and the GPU box, '
+                     f'so conservative for this CPU next to -march=native), {os.cpu_count()} host cores present, 1 used'}
     if all_cores:
         try:
             out['all_cores'] = cpu_baseline_all_cores()
@@ -129,6 +150,68 @@ def cpu_baseline_all_cores(seconds_budget: float = 6.0):
     total, tmax = sum(r[0] for r in res), max(r[1] for r in res)
     return {'value': total / tmax, 'unit': 'env-steps/s', 'cores': cores,
             'sample': f'{cores} processes x 1 env each, {total} env-steps in {tmax:.1f} s (slowest worker), same workload as the 1-core figure'}
+
+
+def config_line(QuadrupedEnv, robot, scene, n, device, pool, imu=False, heightmap=False, steps=400, warmup=100):
+    """One BASELINE.json config timed like the headline (untimed warm-up, K steps between two synchronisations, HIP events
+    around every EVENT_STRIDE-th step-kernel launch), reported as a secondary of the default run: configs[2..4]."""
+    obs_names = tuple(QuadrupedEnv.ALL_OBS)
+    sensors = sensors_kwargs = None
+    if imu:
+        from gym_quadruped_amd.sensors import IMU
+        names = {'hyqreal1': ('Body_Acc', 'Body_Gyro')}.get(robot, ('imu_acc', 'imu_gyro'))
+        sensors, sensors_kwargs = (IMU,), (dict(accel_name=names[0], gyro_name=names[1], imu_site_name='imu', accel_noise=0.01, gyro_noise=0.01,
+                                               accel_bias_rate=0.01, gyro_bias_rate=0.01, seed=1),)
+        obs_names = obs_names + IMU.ALL_OBS
+    t_build = time.perf_counter()
+    env = QuadrupedEnv(robot, state_obs_names=obs_names, scene=scene, num_envs=n, device=device, sensors=sensors, sensors_kwargs=sensors_kwargs,
+                       auto_reset='next_step', solver='newton', solver_iterations=100, solver_tolerance=1e-8, seed=1000)
+    env.reset(random=True)
+    hm = None
+    if heightmap:
+        from gym_quadruped_amd.sensors import HeightMap
+        hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)
+        yaw0 = torch.zeros(n, device=device)
+
+    def one(i, ev=None):
+        env._profile_events = ev
+        o = env.step(pool[i % 64])[0]
+        if hm is not None:
+            hm.update_height_map(env.qpos[:, 0:3], yaw=o['base_ori_euler_xyz'][:, 2] if 'base_ori_euler_xyz' in o else yaw0)
+    for i in range(warmup):
+        one(i)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % EVENT_STRIDE == 0 else None for i in range(steps)]
+    torch.cuda.synchronize(device)
+    t_build = time.perf_counter() - t_build
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i, ev[i])
+    env._profile_events = None
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    kernel_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in ev if p is not None]))
+    b = algorithmic_bytes_per_env_step(env._obs_dim)
+    out = {'value': n * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': warmup, 'kernel_ms': kernel_ms,
+           'obs_dim': env._obs_dim, 'bytes_per_env_step': b, 'achieved_gbs': n * b / (kernel_ms * 1e-3) / 1e9,
+           'frac': n * b / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           'workload': f'{robot} {scene}, {n} envs, ALL_OBS' + (' + IMU (6 observables)' if imu else '') + (' + 5x5 HeightMap every step (its ray kernel is inside ms_per_step, not kernel_ms)' if heightmap else '')
+                       + ', newton <=100 it tol 1e-8, self-collision on, auto-reset next_step',
+           'state_finite': bool(torch.isfinite(env.qpos).all() and torch.isfinite(env.qvel).all()), 'setup_s': t_build}
+    env.close()
+    return out
+
+
+def config_lines(QuadrupedEnv, n, device, pool):
+    """BASELINE.json configs[2..4] on this one GPU (config 4 = one 4096-env shard of its 8)."""
+    out = {}
+    for key, kw in (('cfg3_aliengo_perlin', dict(robot='aliengo', scene='perlin')),
+                    ('cfg4_go2_flat_one_shard', dict(robot='go2', scene='flat')),
+                    ('cfg5_hyqreal1_boxes_imu_heightmap', dict(robot='hyqreal1', scene='random_boxes', imu=True, heightmap=True))):
+        try:
+            out[key] = config_line(QuadrupedEnv, n=n, device=device, pool=pool, **kw)
+        except Exception as e:  # noqa: BLE001 - a reported extra: the headline line must still be printed
+            out[key] = {'error': f'{type(e).__name__}: {e}'}
+    return out
 
 
 def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
@@ -184,7 +267,8 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
     # under the benchmark's random actions, so the figures compare with the headline; without noise the robots stand on four feet - a
     # different, heavier contact workload (see DESIGN.md section 3 for the like-for-like comparison with the same actions played open loop)
     K = 512
-    for key, kw in (('closed_loop_inline', dict(mode='inline', noise_sigma=50.0)), ('closed_loop_mailbox', dict(mode='mailbox', noise_sigma=50.0)),
+    # gq_rollout_closed evaluates the policy inside the Newton step kernels only: with --solver pgs the block is skipped (GQ_EINVAL otherwise)
+    for key, kw in () if args.solver != 'newton' else (('closed_loop_inline', dict(mode='inline', noise_sigma=50.0)), ('closed_loop_mailbox', dict(mode='mailbox', noise_sigma=50.0)),
                     ('closed_loop_inline_standing', dict(mode='inline', noise_sigma=0.0))):
         env.rollout_closed_loop(256, 25.0, 0.8, **kw)
         torch.cuda.synchronize(device)
@@ -375,6 +459,8 @@ def main():
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary and args.robot == 'mini_cheetah' and args.scene == 'flat':
         secondary = secondary_lines(QuadrupedEnv, n, device, pool, args)
+        if args.solver == 'newton' and args.obs == 'all' and n == ENVS_PER_GPU:
+            secondary.update(config_lines(QuadrupedEnv, n, device, pool))
     if rank == 0:
         total_envs = shard.global_envs
         value = aggregate_throughput([dt] * world, args.steps, n)   # dt is already the max over ranks
@@ -398,6 +484,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic[0], 'traffic_source': traffic[1], 'kernel': 'gq::step_kernel',
                          'kernel_ms': kernel_ms, 'bytes_per_env_step': bytes_step,
+                         'valu_issue': valu_issue(kernel_ms) if headline else None,
                          'note': 'algorithmic bytes / HIP-event kernel time; the step is latency/VALU bound, not HBM bound'},
         }
         if steady is not None:

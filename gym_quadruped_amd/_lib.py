@@ -35,9 +35,9 @@ def lib():
     if not hasattr(L, 'gq_struct_sizes') or L.gq_version() != GQ_ABI_VERSION:
         raise GqError(f'{LIB_PATH} implements ABI {L.gq_version()}, this binding expects {GQ_ABI_VERSION}: rebuild the library '
                       f'(make -C gym_quadruped_amd/csrc)')
-    sizes = (C.c_int32 * 6)()
+    sizes = (C.c_int32 * 8)()
     L.gq_struct_sizes(sizes)
-    mirror = [C.sizeof(t) for t in (GqModelDesc, GqState, GqObsOut, GqResetCfg, GqResampleCfg, GqImuCfg)]
+    mirror = [C.sizeof(t) for t in (GqModelDesc, GqState, GqObsOut, GqResetCfg, GqResampleCfg, GqImuCfg, GqPolicyPd, GqMailboxView)]
     if list(sizes) != mirror:
         raise GqError(f'struct layouts differ between {LIB_PATH} {list(sizes)} and gym_quadruped_amd/cabi.py {mirror}')
     L.gq_model_create.argtypes = [C.POINTER(GqModelDesc), C.c_int, C.POINTER(C.c_void_p)]

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gq.h"
@@ -108,10 +109,11 @@ extern "C" {
 
 const char* gq_last_error(void) { return g_err; }
 int gq_version(void) { return GQ_ABI_VERSION; }
-int gq_struct_sizes(int32_t out[6]) {
+int gq_struct_sizes(int32_t out[8]) {
   if (!out) { SET_ERR("gq_struct_sizes: null argument"); return GQ_EINVAL; }
   out[0] = (int32_t)sizeof(GqModelDesc); out[1] = (int32_t)sizeof(GqState); out[2] = (int32_t)sizeof(GqObsOut);
   out[3] = (int32_t)sizeof(GqResetCfg); out[4] = (int32_t)sizeof(GqResampleCfg); out[5] = (int32_t)sizeof(GqImuCfg);
+  out[6] = (int32_t)sizeof(GqPolicyPd); out[7] = (int32_t)sizeof(GqMailboxView);
   return GQ_OK;
 }
 int gq_obs_dim(int obs_id) { return gq_obs_dim_host(obs_id); }
@@ -197,17 +199,27 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   return GQ_OK;
 }
 
+/* releases whatever mailbox_setup has allocated so far (every pointer of the block starts out null: GqBatch is value-initialised) */
+static void mailbox_free(GqBatch* b) {
+  auto& m = b->mb;
+  hipFree(m.host.act); hipFree(m.host.steps_done); hipFree(m.host.issued); hipFree(m.host.q_items); hipFree(m.host.q_ctr); hipFree(m.host.status);
+  hipFree(m.dev); hipFree(m.policy_dev);
+  if (m.staging) hipHostFree(m.staging);
+  if (m.alive) hipHostFree(m.alive);
+  if (m.status_host) hipHostFree(m.status_host);
+  if (m.stream) hipStreamDestroy(m.stream);
+  if (m.fork) hipEventDestroy(m.fork);
+  if (m.join) hipEventDestroy(m.join);
+  std::memset(&m, 0, sizeof m);
+}
+
 int gq_batch_destroy(GqBatch* b) {
   if (!b) return GQ_OK;
   DeviceGuard guard(b->model->device);
   hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->lift_pending); hipFree(b->load_hint); hipFree(b->dev_args);
   if (b->staging) hipHostFree(b->staging);
   if (b->batch_staging) hipHostFree(b->batch_staging);
-  if (b->mb.ready) {
-    hipFree(b->mb.host.act); hipFree(b->mb.host.steps_done); hipFree(b->mb.host.issued); hipFree(b->mb.host.q_items); hipFree(b->mb.host.q_ctr);
-    hipFree(b->mb.host.status); hipFree(b->mb.dev); hipFree(b->mb.policy_dev); hipHostFree(b->mb.staging); hipHostFree(b->mb.alive); hipHostFree(b->mb.status_host);
-    hipStreamDestroy(b->mb.stream); hipEventDestroy(b->mb.fork); hipEventDestroy(b->mb.join);
-  }
+  mailbox_free(b);
   for (int i = 0; i < b->n_shard_streams; i++) { hipStreamDestroy(b->shard_stream[i]); hipEventDestroy(b->shard_event[i]); }
   if (b->n_shard_streams) hipEventDestroy(b->fork_event);
   if (b->debug) hipFree(b->debug);
@@ -445,8 +457,14 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
 }
 
 /* mailboxes, queues and the policy stream of a batch; the XCD census of the device (one probe launch) */
+static int mailbox_setup_impl(GqBatch* b);
 static int mailbox_setup(GqBatch* b) {
   if (b->mb.ready) return GQ_OK;
+  const int rc = mailbox_setup_impl(b);
+  if (rc != GQ_OK) mailbox_free(b); /* a failed setup keeps nothing: the next call starts from scratch */
+  return rc;
+}
+static int mailbox_setup_impl(GqBatch* b) {
   const int N = b->host.n_envs;
   gq::MailboxDev& h = b->mb.host;
   std::memset(&h, 0, sizeof h);
@@ -484,7 +502,8 @@ static int mailbox_setup(GqBatch* b) {
   return GQ_OK;
 }
 
-/* experiment hook (not declared in gq.h): copy the XCD census words of the last closed rollout to the host */
+#ifdef GQ_MB_DEBUG
+/* experiment hook of -DGQ_MB_DEBUG builds (tools/closed_loop_debug.py; not part of the ABI): copy the XCD census words of the last closed rollout to the host */
 int gq_mailbox_census(GqBatch* b, int32_t* out_host) {
   if (!b || !b->mb.ready) return GQ_EINVAL;
   DeviceGuard guard(b->model->device);
@@ -492,6 +511,7 @@ int gq_mailbox_census(GqBatch* b, int32_t* out_host) {
   HIP_TRY(hipMemcpy(out_host, b->mb.host.issued + b->host.n_envs, sizeof(int32_t) * (size_t)b->host.n_envs, hipMemcpyDeviceToHost));
   return GQ_OK;
 }
+#endif
 
 int gq_mailbox_get(GqBatch* b, GqMailboxView* out) {
   if (!b || !out) { SET_ERR("gq_mailbox_get: null argument"); return GQ_EINVAL; }
@@ -521,6 +541,10 @@ int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, i
   if (n_steps == 0) return GQ_OK;
   const int N = b->host.n_envs, od = b->host.obs_dim;
   gq::MailboxDev& h = b->mb.host;
+  /* queue tickets are 32-bit: the env-steps that pass through one queue must stay below 2^31 (items carry env + 1 in 24 bits) */
+  if (N >= (1 << 24) || (int64_t)((N + h.nq - 1) / h.nq) * (int64_t)n_steps >= ((int64_t)1 << 31) - 65536) {
+    SET_ERR("gq_rollout_closed: %d envs x %d steps over %d queues overflows the 32-bit ticket counters: split the rollout", N, n_steps, h.nq); return GQ_EINVAL;
+  }
   gq::PolicyPdDev P{};
   if (pd) { /* the columns of the joint angles / velocities in this batch's observation row */
     for (int j = 0; j < 12; j++) {
@@ -553,12 +577,16 @@ int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, i
     HIP_TRY(hipGetLastError());
     return GQ_OK;
   }
-  if (step_waves <= 0) step_waves = N; /* more workgroups than free slots is harmless: the late ones find the queues drained */
+  if (step_waves <= 0) step_waves = N; /* more workgroups than free slots (or than envs) is harmless: pop tickets that run ahead of the pushes
+                                        * wait on lap-tagged slots, the late ones find the queues drained */
   if (step_waves < 4 * h.nq) step_waves = 4 * h.nq; /* a wavefront pops from ITS XCD's queue only: every XCD needs stepping wavefronts, also for a batch of
                                                       * one env (workgroups are dealt round-robin over the XCDs; the surplus finds its queue empty and leaves) */
   h.n_steps = n_steps; h.obs_seq = obs_seq; h.act_seq = act_seq;
   h.timeout_ticks = (int64_t)((timeout_s > 0.0 ? timeout_s : 5.0) * 1e8);
-  { const char* fl = getenv("GQ_MB_FLAGS"); h.flags = fl ? atoi(fl) : 0; }
+  h.flags = 0;
+#ifdef GQ_MB_DEBUG
+  { const char* fl = getenv("GQ_MB_FLAGS"); h.flags = fl ? atoi(fl) : 0; } /* fence / census experiments (tools/closed_loop_debug.py) */
+#endif
   /* fresh rollout state, ordered on the caller's stream */
   HIP_TRY(hipMemsetAsync(h.steps_done, 0, sizeof(int32_t) * (size_t)N, stream));
   HIP_TRY(hipMemsetAsync(h.issued, 0, sizeof(int32_t) * 2 * (size_t)N, stream));
@@ -582,11 +610,13 @@ int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, i
     HIP_TRY(hipEventRecord(b->mb.join, b->mb.stream));
     const auto t0 = std::chrono::steady_clock::now();
     while (*(volatile int32_t*)b->mb.alive < policy_waves) {
+      std::this_thread::yield();
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
         /* it cannot start: tell it to leave as soon as it does, and report */
-        int32_t one = 3;
-        (void)hipMemcpyAsync(h.status, &one, sizeof one, hipMemcpyHostToDevice, stream);
-        (void)hipStreamWaitEvent(stream, b->mb.join, 0);
+        b->mb.status_host[0] = 3; /* pinned: the source of an asynchronous copy must outlive this frame */
+        (void)hipMemcpyAsync(h.status, b->mb.status_host, sizeof(int32_t), hipMemcpyHostToDevice, stream);
+        (void)hipStreamSynchronize(stream);
+        (void)hipStreamSynchronize(b->mb.stream); /* the policy kernel has left (or never ran): nothing of this call touches `alive` later */
         SET_ERR("gq_rollout_closed: the policy kernel did not become resident within 2 s (%d of %d workgroups)", (int)*(volatile int32_t*)b->mb.alive, policy_waves);
         return GQ_EDEVICE;
       }

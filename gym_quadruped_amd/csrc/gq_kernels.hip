@@ -9,6 +9,18 @@
 #include <gq_device.h>
 #include "gq_step_body.h"
 
+/* Parallel build (csrc/Makefile): this file is compiled once per PART, each translation unit instantiating one group of step-kernel
+ * variants (-DGQ_PART=k; the variants are 60 large, fully inlined kernels - one unit took 7.5 minutes, the parts build side by side in
+ * about one).  GQ_PART undefined: everything in one unit (tools/dev_build.sh development builds).  Part GQ_PART_MISC holds the
+ * non-template kernels, the launch entry points and the dispatch over the parts. */
+#ifndef GQ_PART
+#define GQ_PART (-1)
+#endif
+#define GQ_PART_MISC 18
+#define GQ_IN_MISC (GQ_PART < 0 || GQ_PART == GQ_PART_MISC)
+constexpr int gq_step_part(int S, int M, bool C, bool B) { return ((S == 0 ? 0 : (C ? 2 : 1)) * 3 + M) * 2 + (B ? 1 : 0); } /* 0 .. 17 */
+constexpr int gq_mailbox_part(bool C, bool B) { return 19 + (C ? 2 : 0) + (B ? 1 : 0); }                                   /* 19 .. 22 */
+
 namespace gq {
 
 /* joint-space PD law of the closed-loop rollouts, every operation rounded on its own (the elementwise torch expression
@@ -106,8 +118,8 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
 #endif
   const GQ_MODEL MailboxDev& MB = *mptr(MBp);
   const int q = MB.xcc_queue[xcc_id()];
-  const int N = MB.n_envs, nq = MB.nq, qmask = MB.qcap - 1;
-  const int total = ((N - q + nq - 1) / nq) * MB.n_steps; /* env-steps that will ever pass through this queue */
+  const int N = MB.n_envs, nq = MB.nq, qmask = MB.qcap - 1, qshift = __builtin_ctz(MB.qcap);
+  const int total = ((N - q + nq - 1) / nq) * MB.n_steps; /* env-steps that will ever pass through this queue (< 2^31: checked by gq_rollout_closed) */
   int32_t* const head = MB.q_ctr + (size_t)(3 * q) * GQ_MB_QSTRIDE;
   int32_t* const items = MB.q_items + (size_t)q * MB.qcap;
   int played = 0;
@@ -117,19 +129,24 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket >= total) break;
     int32_t* const slot = items + (ticket & qmask);
+    /* an item carries the LAP of its push ticket (bits 24..30 = (s / qcap) mod 128): tickets may run ahead of the pushes by the number
+     * of resident step wavefronts, which can exceed qcap for a small batch - ticket t and ticket t + qcap then wait on the same slot,
+     * and each must take the item of ITS lap only (an env stepped by two wavefronts at once otherwise).  Nothing is cleared: the
+     * slot is simply overwritten one lap later, and a lap's item is at most one lap old when its ticket reads it. */
+    const int want = (ticket >> qshift) & 0x7f;
     int item;
     const long long t0 = wall_clock64();
     for (int spin = 0;; spin++) { /* the ticket's env is pushed as soon as the policy has its action */
       item = __builtin_amdgcn_readfirstlane(ld_pub(slot));
-      if (item != 0) break;
+      if ((item & 0xffffff) != 0 && (item >> 24) == want) break;
       nap();
       if ((spin & 31) == 31) {
-        if (ld_pub(MB.status) != 0) return;
-        if (wall_clock64() - t0 > MB.timeout_ticks) { if (lane_id() == 0) { st_pub(MB.status + 1, ticket); st_pub(MB.status, 1); } return; }
+        bool leave = ld_pub(MB.status) != 0;
+        if (!leave && wall_clock64() - t0 > MB.timeout_ticks) { if (lane_id() == 0) { st_pub(MB.status + 1, ticket); st_pub(MB.status, 1); } leave = true; }
+        if (leave) { if (lane_id() == 0 && played) add_pub(MB.status + 2, played); return; }
       }
     }
-    if (lane_id() == 0) st_pub(slot, 0); /* the slot is free for the push that comes qcap tickets later */
-    const int env = item - 1;
+    const int env = (item & 0xffffff) - 1;
     adopt_fence();
     if (MB.flags & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     /* the env's step index is only needed to place the row in obs_seq: otherwise that round trip is not taken */
@@ -161,6 +178,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
   if (lane_id() == 0 && played) add_pub(MB.status + 2, played);
 }
 
+#if GQ_IN_MISC
 /* the built-in policy of the closed-loop rollout.  A policy wavefront serves envs of ITS XCD's queue only (lane = env, strided over the
  * policy wavefronts that landed on the XCD): observation row, action row, count and queue slot of an env are written and read
  * through one L2, like the env's state rows - no hand-off of the rollout depends on coherence between two XCDs' L2s, and none
@@ -168,7 +186,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
 __global__ void __launch_bounds__(GQ_WAVE) policy_pd_kernel(const MailboxDev* __restrict__ MBp, const PolicyPdDev* __restrict__ Pp, const float* __restrict__ obs, const int od) {
   const GQ_MODEL MailboxDev& MB = *mptr(MBp);
   const GQ_MODEL PolicyPdDev& P = *mptr(Pp);
-  const int lane = (int)threadIdx.x, nq = MB.nq, q = MB.xcc_queue[xcc_id()], qmask = MB.qcap - 1;
+  const int lane = (int)threadIdx.x, nq = MB.nq, q = MB.xcc_queue[xcc_id()], qmask = MB.qcap - 1, qshift = __builtin_ctz(MB.qcap);
   const int N = MB.n_envs, K = MB.n_steps, P_all = (int)gridDim.x;
   int rank = 0;
   if (lane == 0) rank = add_pub(MB.q_ctr + (size_t)(3 * q + 2) * GQ_MB_QSTRIDE, 1);
@@ -217,7 +235,7 @@ __global__ void __launch_bounds__(GQ_WAVE) policy_pd_kernel(const MailboxDev* __
       }
       publish_fence();
       if (MB.flags & 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      st_pub(items + (s & qmask), e + 1); /* the item - after the action is in place */
+      st_pub(items + (s & qmask), (((s >> qshift) & 0x7f) << 24) | (e + 1)); /* the item (lap of its ticket | env + 1) - after the action is in place */
       MB.issued[e] = k + 1;
       progress = true;
     }
@@ -234,6 +252,7 @@ __global__ void xcc_probe_kernel(int32_t* mask) {
   if (threadIdx.x == 0) atomicOr(mask, 1 << xcc_id());
 }
 
+#endif /* GQ_IN_MISC */
 template <bool BOXES>
 __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB) reset_kernel(ResetArgs a, const int n_envs) {
   const int widx = wave_index();
@@ -247,6 +266,7 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB) reset_kernel(ResetArgs a, co
   reset_wave<BOXES>(a, W);
 }
 
+#if GQ_IN_MISC
 /* HeightMap rays: one wavefront per env, lane = cell (strided when the grid has more than 64).  Scene = the floor plane z = 0
  * plus the static world boxes (mj_ray against static geoms, heightmap.py:90-99): the nearest hit of the vertical ray with any
  * box (slab test in the box frame).  The env's whole grid lies within a circle around `center`: lane = box first picks the
@@ -455,13 +475,16 @@ __global__ void ray_kernel(const GQ_GLOBAL GqDevModel* model, const double* orig
   if (geom_out) geom_out[idx] = geom;
 }
 
+#endif /* GQ_IN_MISC */
 }  // namespace gq
 
+#if GQ_IN_MISC
 extern "C" void gq_launch_heightmap(const GQ_GLOBAL GqDevModel* model, const double* center, int center_stride, const float* yaw, int yaw_stride, int n_envs, int rows, int cols,
                                     float dist_x, float dist_y, float* out, hipStream_t stream) {
   hipLaunchKernelGGL(gq::heightmap_kernel, dim3(n_envs), dim3(GQ_WAVE), 0, stream, model, center, center_stride, yaw, yaw_stride, n_envs, rows, cols, dist_x, dist_y, out);
 }
 
+#endif /* GQ_IN_MISC */
 /* Development builds (tools/dev_build.sh: -DGQ_DEV_ONLY=<0|1>, cone = 0 pyramidal / 1 elliptic) instantiate only the flat-scene
  * self-collision Newton variants (production + instrumented) - a 15 s build for A/B timing of kernel experiments through
  * GQ_LIBGQ_PATH; any other launch aborts.  The product library is built without the macro and carries every variant. */
@@ -472,7 +495,8 @@ extern "C" void gq_launch_heightmap(const GQ_GLOBAL GqDevModel* model, const dou
 #define GQ_DEV_CUTS 0 /* -DGQ_DEV_CUTS=1: the development build also carries the stage-cut variant (tools/stage_cuts.py) */
 #endif
 template <int S, int M, bool C, bool B, bool SF, bool P = true>
-static void launch_variant(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, hipStream_t stream) {
+static bool launch_variant(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, hipStream_t stream) {
+  if constexpr (GQ_PART >= 0 && gq_step_part(S, M, C, B) != GQ_PART) return false; else
 #ifdef GQ_DEV_ONLY
   if constexpr (!(S == 1 && (M != 2 || GQ_DEV_CUTS) && B == (GQ_DEV_BOXES != 0) && (!B || P == (GQ_DEV_BOXES == 2)) && SF && C == (GQ_DEV_ONLY != 0))) { fprintf(stderr, "libgq development build: kernel variant solver=%d mode=%d cone=%d boxes=%d self=%d not compiled in\n", S, M, int(C), int(B), int(SF)); abort(); } else
 #endif
@@ -482,30 +506,57 @@ static void launch_variant(const gq::FusedArgs* dev_args, const gq::StepCall* c,
     if constexpr (M == 0) {
       if (c->n_steps > 1 || c->policy) { /* persistent rollout (also a one-step one with the policy inline: only this variant evaluates it): production kernel only */
         hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF, P, true>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
-        return;
+        return true;
       }
     }
     call.n_steps = 1;
     hipLaunchKernelGGL((gq::step_kernel<S, M, C, B, SF, P>), dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, dev_args, call);
+    return true;
   }
 }
 
-extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, int self, hipStream_t stream) {
+/* the run-time choice among the variants of THIS translation unit; false: the variant lives in another part */
+static bool dispatch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, int self, hipStream_t stream) {
   /* 0: production; 1: debug record + stage timers; 2: stage cut (GQ_STOP_STAGE / gq_debug_stop_stage) - the early returns
    * of the cut cost the production kernel ~8 % when merely compiled in, hence a variant of their own.
    * Scene variants: flat (no world geoms beyond the floor), flat + robot self-collision, world boxes / height field (always
    * with the self-collision stage compiled in; a model without pairs skips it at run time). */
   const int mode = c->debug != nullptr ? 1 : (c->stop_stage != 0 ? 2 : 0);
-#define GQ_LAUNCH(S, M, C) do { if (boxes == 2) launch_variant<S, M, C, true, true, true>(dev_args, c, n_envs, stream); \
-                                else if (boxes) launch_variant<S, M, C, true, true, false>(dev_args, c, n_envs, stream); \
-                                else if (self) launch_variant<S, M, C, false, true>(dev_args, c, n_envs, stream); \
-                                else launch_variant<S, M, C, false, false>(dev_args, c, n_envs, stream); } while (0)
-#define GQ_LAUNCH_MODE(S, C) do { if (mode == 1) GQ_LAUNCH(S, 1, C); else if (mode == 2) GQ_LAUNCH(S, 2, C); else GQ_LAUNCH(S, 0, C); } while (0)
-  if (solver == 1 && cone) GQ_LAUNCH_MODE(1, true);
-  else if (solver == 1) GQ_LAUNCH_MODE(1, false);
-  else GQ_LAUNCH_MODE(0, false); /* PGS: pyramidal cones only (gq_model_create rejects elliptic cones with solver 0) */
+#define GQ_LAUNCH(S, M, C) (boxes == 2 ? launch_variant<S, M, C, true, true, true>(dev_args, c, n_envs, stream) \
+                            : boxes ? launch_variant<S, M, C, true, true, false>(dev_args, c, n_envs, stream) \
+                            : self ? launch_variant<S, M, C, false, true>(dev_args, c, n_envs, stream) \
+                            : launch_variant<S, M, C, false, false>(dev_args, c, n_envs, stream))
+#define GQ_LAUNCH_MODE(S, C) (mode == 1 ? GQ_LAUNCH(S, 1, C) : mode == 2 ? GQ_LAUNCH(S, 2, C) : GQ_LAUNCH(S, 0, C))
+  if (solver == 1 && cone) return GQ_LAUNCH_MODE(1, true);
+  if (solver == 1) return GQ_LAUNCH_MODE(1, false);
+  return GQ_LAUNCH_MODE(0, false); /* PGS: pyramidal cones only (gq_model_create rejects elliptic cones with solver 0) */
 #undef GQ_LAUNCH_MODE
 #undef GQ_LAUNCH
+}
+#define GQ_CAT2(a, b) a##b
+#define GQ_CAT(a, b) GQ_CAT2(a, b)
+#if GQ_PART >= 0 && GQ_PART < GQ_PART_MISC
+extern "C" bool GQ_CAT(gq_launch_step_p, GQ_PART)(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, int self, hipStream_t stream) {
+  return dispatch_step(dev_args, c, n_envs, solver, cone, boxes, self, stream);
+}
+#endif
+#if GQ_IN_MISC
+#if GQ_PART >= 0
+#define GQ_P(k) extern "C" bool gq_launch_step_p##k(const gq::FusedArgs*, const gq::StepCall*, int, int, int, int, int, hipStream_t);
+GQ_P(0) GQ_P(1) GQ_P(2) GQ_P(3) GQ_P(4) GQ_P(5) GQ_P(6) GQ_P(7) GQ_P(8) GQ_P(9) GQ_P(10) GQ_P(11) GQ_P(12) GQ_P(13) GQ_P(14) GQ_P(15) GQ_P(16) GQ_P(17)
+#undef GQ_P
+#endif
+extern "C" void gq_launch_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, int n_envs, int solver, int cone, int boxes, int self, hipStream_t stream) {
+#if GQ_PART >= 0
+  static bool (*const part[18])(const gq::FusedArgs*, const gq::StepCall*, int, int, int, int, int, hipStream_t) = {
+    gq_launch_step_p0, gq_launch_step_p1, gq_launch_step_p2, gq_launch_step_p3, gq_launch_step_p4, gq_launch_step_p5, gq_launch_step_p6, gq_launch_step_p7, gq_launch_step_p8,
+    gq_launch_step_p9, gq_launch_step_p10, gq_launch_step_p11, gq_launch_step_p12, gq_launch_step_p13, gq_launch_step_p14, gq_launch_step_p15, gq_launch_step_p16, gq_launch_step_p17};
+  const int mode = c->debug != nullptr ? 1 : (c->stop_stage != 0 ? 2 : 0);
+  const int k = gq_step_part(solver == 1 ? 1 : 0, mode, solver == 1 && cone, boxes != 0);
+  if (!part[k](dev_args, c, n_envs, solver, cone, boxes, self, stream)) { fprintf(stderr, "libgq: step-kernel part %d does not hold solver=%d mode=%d cone=%d boxes=%d self=%d\n", k, solver, mode, cone, boxes, self); abort(); }
+#else
+  dispatch_step(dev_args, c, n_envs, solver, cone, boxes, self, stream);
+#endif
 }
 extern "C" void gq_launch_xcc_probe(int32_t* mask, hipStream_t stream) {
   hipLaunchKernelGGL(gq::xcc_probe_kernel, dim3(4096), dim3(GQ_WAVE), 0, stream, mask);
@@ -513,26 +564,48 @@ extern "C" void gq_launch_xcc_probe(int32_t* mask, hipStream_t stream) {
 extern "C" void gq_launch_policy_pd(const gq::MailboxDev* mb, const gq::PolicyPdDev* pd, const float* obs, int od, int waves, hipStream_t stream) {
   hipLaunchKernelGGL(gq::policy_pd_kernel, dim3(waves), dim3(GQ_WAVE), 0, stream, mb, pd, obs, od);
 }
-/* returns 0 if the scene / solver combination has no mailbox variant compiled in */
-extern "C" int gq_launch_mailbox_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, const gq::MailboxDev* mb, int waves, int solver, int cone, int boxes, int self, hipStream_t stream) {
+#endif /* GQ_IN_MISC */
+/* mailbox variants of this translation unit (parts 19 .. 22: pyramidal / elliptic x flat / world geoms) */
+template <bool C, bool B, bool SF, bool P>
+static bool launch_mailbox_variant(const gq::FusedArgs* dev_args, const gq::StepCall* c, const gq::MailboxDev* mb, int waves, hipStream_t stream) {
+  if constexpr (GQ_PART >= 0 && gq_mailbox_part(C, B) != GQ_PART) return false;
+  else { hipLaunchKernelGGL((gq::mailbox_step_kernel<1, C, B, SF, P>), dim3(waves), dim3(GQ_WAVE), 0, stream, dev_args, *c, mb); return true; }
+}
+static bool dispatch_mailbox(const gq::FusedArgs* dev_args, const gq::StepCall* c, const gq::MailboxDev* mb, int waves, int cone, int boxes, int self, hipStream_t stream) {
 #if GQ_WPB != 1
-  return 0;
+  return false;
+#elif defined(GQ_DEV_ONLY)
+  if (!(!boxes && self && cone == (GQ_DEV_ONLY != 0))) return false;
+  return launch_mailbox_variant<(GQ_DEV_ONLY != 0), false, true, true>(dev_args, c, mb, waves, stream);
 #else
-#ifdef GQ_DEV_ONLY
-  if (!(solver == 1 && !boxes && self && cone == (GQ_DEV_ONLY != 0))) return 0;
-#endif
-  if (solver != 1) return 0;
-#define GQ_MB_LAUNCH(C, B, SF, P) hipLaunchKernelGGL((gq::mailbox_step_kernel<1, C, B, SF, P>), dim3(waves), dim3(GQ_WAVE), 0, stream, dev_args, *c, mb)
-#ifdef GQ_DEV_ONLY
-  GQ_MB_LAUNCH((GQ_DEV_ONLY != 0), false, true, true);
-#else
-#define GQ_MB_SCENE(C) do { if (boxes == 2) GQ_MB_LAUNCH(C, true, true, true); else if (boxes) GQ_MB_LAUNCH(C, true, true, false); \
-                            else if (self) GQ_MB_LAUNCH(C, false, true, true); else GQ_MB_LAUNCH(C, false, false, true); } while (0)
-  if (cone) GQ_MB_SCENE(true); else GQ_MB_SCENE(false);
+#define GQ_MB_SCENE(C) (boxes == 2 ? launch_mailbox_variant<C, true, true, true>(dev_args, c, mb, waves, stream) \
+                        : boxes ? launch_mailbox_variant<C, true, true, false>(dev_args, c, mb, waves, stream) \
+                        : self ? launch_mailbox_variant<C, false, true, true>(dev_args, c, mb, waves, stream) \
+                        : launch_mailbox_variant<C, false, false, true>(dev_args, c, mb, waves, stream))
+  return cone ? GQ_MB_SCENE(true) : GQ_MB_SCENE(false);
 #undef GQ_MB_SCENE
 #endif
-#undef GQ_MB_LAUNCH
-  return 1;
+}
+#if GQ_PART > GQ_PART_MISC
+extern "C" bool GQ_CAT(gq_launch_mailbox_p, GQ_PART)(const gq::FusedArgs* dev_args, const gq::StepCall* c, const gq::MailboxDev* mb, int waves, int cone, int boxes, int self, hipStream_t stream) {
+  return dispatch_mailbox(dev_args, c, mb, waves, cone, boxes, self, stream);
+}
+#endif
+#if GQ_IN_MISC
+#if GQ_PART >= 0
+#define GQ_P(k) extern "C" bool gq_launch_mailbox_p##k(const gq::FusedArgs*, const gq::StepCall*, const gq::MailboxDev*, int, int, int, int, hipStream_t);
+GQ_P(19) GQ_P(20) GQ_P(21) GQ_P(22)
+#undef GQ_P
+#endif
+/* returns 0 if the scene / solver combination has no mailbox variant compiled in */
+extern "C" int gq_launch_mailbox_step(const gq::FusedArgs* dev_args, const gq::StepCall* c, const gq::MailboxDev* mb, int waves, int solver, int cone, int boxes, int self, hipStream_t stream) {
+  if (solver != 1) return 0;
+#if GQ_PART >= 0
+  static bool (*const part[4])(const gq::FusedArgs*, const gq::StepCall*, const gq::MailboxDev*, int, int, int, int, hipStream_t) = {
+    gq_launch_mailbox_p19, gq_launch_mailbox_p20, gq_launch_mailbox_p21, gq_launch_mailbox_p22};
+  return part[gq_mailbox_part(cone != 0, boxes != 0) - 19](dev_args, c, mb, waves, cone, boxes, self, stream) ? 1 : 0;
+#else
+  return dispatch_mailbox(dev_args, c, mb, waves, cone, boxes, self, stream) ? 1 : 0;
 #endif
 }
 extern "C" void gq_launch_jac(const GqDevModel* model, const double* qpos, int body, const double* point, float* jacp, float* jacr, int n_envs, hipStream_t stream) {
@@ -545,3 +618,4 @@ extern "C" void gq_launch_reset(const gq::ResetArgs* a, int n_envs, int boxes, h
   if (boxes) hipLaunchKernelGGL(gq::reset_kernel<true>, dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, *a, n_envs);
   else hipLaunchKernelGGL(gq::reset_kernel<false>, dim3((n_envs + GQ_WPB - 1) / GQ_WPB), dim3(GQ_WAVE * GQ_WPB), 0, stream, *a, n_envs);
 }
+#endif /* GQ_IN_MISC */

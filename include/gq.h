@@ -59,7 +59,7 @@ extern "C" {
  * that crosses the boundary.  History: 100 round 1; 300 = GqModelDesc.struct_size + the self-collision / geom_type tables,
  * GqObsOut.step_num_prev, strided HeightMap views, the round-3 entry points; 400 = the closed-loop persistent rollout
  * (gq_rollout_closed, gq_mailbox_get), GqObsOut.contacts_dropped. */
-#define GQ_ABI_VERSION 400
+#define GQ_ABI_VERSION 500
 
 typedef struct GqModelDesc {
   int32_t struct_size; /* = sizeof(GqModelDesc) of the caller's header; gq_model_create refuses any other value */
@@ -246,9 +246,9 @@ enum GqObsId {
 
 const char* gq_last_error(void);
 int gq_version(void);   /* GQ_ABI_VERSION of the library build */
-/* sizeof of the structs that cross this boundary, in the library's build: out[0..5] = GqModelDesc, GqState, GqObsOut,
- * GqResetCfg, GqResampleCfg, GqImuCfg.  A binding whose mirror of one of them differs must not call the library. */
-int gq_struct_sizes(int32_t out[6]);
+/* sizeof of the structs that cross this boundary, in the library's build: out[0..7] = GqModelDesc, GqState, GqObsOut,
+ * GqResetCfg, GqResampleCfg, GqImuCfg, GqPolicyPd, GqMailboxView.  A binding whose mirror of one of them differs must not call the library. */
+int gq_struct_sizes(int32_t out[8]);
 
 /* dimension of observable `id` (19,18,12,... as configure_observation_space, quadruped_utils.py:235-325) */
 int gq_obs_dim(int obs_id);
@@ -350,7 +350,10 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
  *   policy side   for each env e, for k = 0 .. n_steps - 1:  wait until steps_done[e] >= k (the observation row of e after k steps
  *                 is in GqObsOut.obs, written through to device-coherent memory); write the 12 torques to action[e][0..12);
  *                 then push e onto ready queue  e % n_queues:  s = atomic_add(counters[(3 q + 1) * counter_stride], 1);
- *                 items[q * queue_capacity + (s & (queue_capacity - 1))] = e + 1   (device-scope stores, the item last);
+ *                 items[q * queue_capacity + (s & (queue_capacity - 1))] = (((s / queue_capacity) & 127) << 24) | (e + 1)
+ *                 (device-scope stores, the item last; the lap number of the push ticket rides in bits 24..30, so that pop tickets that
+ *                 run more than queue_capacity ahead of the pushes - many resident step wavefronts, few envs - each take the item of
+ *                 their own lap; N <= 2^24 - 1 envs, N / n_queues * n_steps < 2^31 tickets per queue);
  *   step side     the wavefronts of ONE launch pop tickets from the queue of their XCD, play one QuadrupedEnv.step() of the popped
  *                 env each (mj_step, observation / termination epilogue, next-step auto-reset exactly as gq_step), publish the
  *                 observation row and steps_done[e] = k + 1, and pop again until all N * n_steps env-steps are claimed.
@@ -365,13 +368,15 @@ int gq_rollout(GqBatch* b, const float* ctrl_seq, int n_steps, int shards, GqSta
  * wavefront that writes env e's action must run on the XCD of queue e % n_queues (GqMailboxView.xcc_queue maps HW_REG_XCC_ID to
  * queues) - action row, observation row and counters of an env then meet in ONE L2, like the env's state rows, and device-scope
  * (sc1) accesses + a wait for the stores are all the ordering needed.  A producer on another XCD should be paired with device-scope
- * fences (environment GQ_MB_FLAGS: 1 release on the policy side, 2 acquire on the stepping side; measured cost of the latter 14 %).
+ * fences (a -DGQ_MB_DEBUG build of the library reads them from the environment - GQ_MB_FLAGS: 1 release on the policy side, 2 acquire on
+ * the stepping side; measured cost of the latter 14 % - the product build compiles the switches to 0).
  * mode GQ_CLOSED_INLINE: the built-in policy is evaluated by the wavefront that steps the env, right where the observation row is
  * written (the persistent kernel of gq_rollout(shards = 0) with the action derived instead of read): the turn-around of an action
  * is zero instead of two trips through device memory, which matters when there are no more envs than wavefront slots - every env
  * then waits out its own policy latency (measured at 4096 envs: DESIGN.md).  Mailbox mode is the general mechanism: any policy
  * that can run as a resident kernel; its latency hides behind other envs' steps once there are more envs than slots.
- * step_waves: workgroups of the step launch (0 = one per env; more than the device can hold at once is harmless).
+ * step_waves: workgroups of the step launch (0 = one per env; more than the device can hold at once, or than there are envs, is harmless:
+ * the surplus waits on lap-tagged queue slots or finds its queue drained).
  * obs_seq / act_seq: device [K][N][obs_dim] / [K][N][12] f32 records of every observation row / action, or NULL.
  * Needs the Newton solver, next-step auto-reset (or none) and the production kernel (no inspection record / stage cut).
  * Asynchronous on hip_stream except for one synchronisation at the start (mailbox reset, policy residency). */

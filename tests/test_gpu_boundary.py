@@ -220,3 +220,23 @@ def test_gq_full_mass_is_mj_fullM_of_the_last_forward_pass():
         assert np.abs(Mg[e] - Mo).max() < 1e-4 * np.abs(Mo).max(), e
         assert np.abs(Mg[e] - Mg[e].T).max() < 1e-6 * np.abs(Mo).max() and np.linalg.eigvalsh(Mg[e].astype(np.float64)).min() > 0
     assert L.gq_full_mass(env._hbatch, n + 1, M.data_ptr(), stream) != 0      # more envs than the record covers
+
+
+def test_integration_stub_runs():
+    """INTEGRATION.md's binding stub (the ctypes a reference maintainer would write), executed as written against the built
+    library on the GPU: create, reset, step, auto-reset step, destroy - and the tensors it leaves are a stepped batch."""
+    import os
+    from pathlib import Path
+    from test_host_and_abi import integration_stub_text
+    root = Path(__file__).resolve().parents[1]
+    ns = {'__name__': 'integration_stub'}
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        exec(compile(integration_stub_text(), 'INTEGRATION.md', 'exec'), ns)
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    assert ns['D'] == 73 and bool(torch.isfinite(ns['obs']).all()) and bool(torch.isfinite(ns['qpos']).all())
+    assert int(ns['step_num'].min()) >= 1 and float(ns['qpos'][:, 2].min()) > 0.0 and not bool(ns['lift_failed'].any())
+    assert float(ns['obs'][:, 37:49].abs().max()) > 1.0   # tau_ctrl_setpoint columns carry the 50 * N(0, 1) torques (clamped to ctrlrange)

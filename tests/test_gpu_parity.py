@@ -496,8 +496,9 @@ def test_box_scenes_rollout_and_step_parity(robot, scene):
     env.enable_debug(n)
     obs, rew, term, trunc, info = env.step(act)
     torch.cuda.synchronize()
-    dbg = env.debug_internals(n, ['qacc', 'nefc'])
+    dbg = env.debug_internals(n, ['qacc', 'nefc', 'ncon', 'efc_J', 'efc_R', 'efc_aref'])
     o = Oracle(marshalled(robot, solver=1, iterations=100, tolerance=1e-12, boxes=env.scene_desc['boxes'], terrain_limits=lim))
+    dropped, tg, ig = info['contacts_dropped'].cpu().numpy(), term.cpu().numpy(), info['invalid_contacts'].cpu().numpy()
     a = act.cpu().numpy()
     qv = env.qvel.cpu().numpy()
     nbox = 0
@@ -506,12 +507,17 @@ def test_box_scenes_rollout_and_step_parity(robot, scene):
         if pend[e]:
             continue   # this env spent the step on its reset
         o.set_state(q0[e], v0[e], w0[e], np.zeros(18), 0.0, float(fr[e])); o.step(a[e].astype(np.float64))
-        if tally.classify(e, o, dbg[e]['nefc'][0]) != 'ok':
+        cls = tally.classify(e, o, dbg[e]['nefc'][0])
+        if cls == 'budget':   # the kernel's rows are the oracle's first rows, the flags the oracle's, and the caller is told what was cut
+            tally.check_budget_prefix(e, o, dbg[e]['nefc'][0], dbg[e]['efc_J'], dbg[e]['efc_R'], dbg[e]['efc_aref'], (tg[e], ig[e]))
+            assert int(dropped[e]) == o.ncon - int(dbg[e]['ncon'][0]) > 0, (e, int(dropped[e]), o.ncon, int(dbg[e]['ncon'][0]))
+        if cls != 'ok':
             continue
+        assert int(dropped[e]) == 0, (e, int(dropped[e]))
         nbox += int((np.abs(o.contact_frame[:, 0, 2] - 1.0) > 1e-9).sum() + (np.abs(o.contact_pos[:, 2]) > 5e-3).sum()) if o.ncon else 0
         assert np.abs(dbg[e]['qacc'] - o.qacc).max() < 3e-4 * max(1.0, np.abs(o.qacc).max()), e
         assert np.abs(qv[e] - o.qvel).max() < 1e-3
-    tally.finish(f'box scene one-step parity {robot} {scene}', min_checked=0.7, max_tie=0.15, max_budget=0.25)
+    tally.finish(f'box scene one-step parity {robot} {scene}', min_checked=0.7, max_tie=0.15, max_budget=0.1)
     assert nbox > 0
 
 
@@ -716,8 +722,9 @@ def test_perlin_scene_contract_and_parity(robot):
     env.enable_debug(n)
     obs, rew, term, trunc, info = env.step(act)
     torch.cuda.synchronize()
-    dbg = env.debug_internals(n, ['qacc', 'nefc'])
+    dbg = env.debug_internals(n, ['qacc', 'nefc', 'ncon', 'efc_J', 'efc_R', 'efc_aref'])
     o = Oracle(marshalled(robot, solver=1, iterations=100, tolerance=1e-12, hfield=hf, terrain_limits=lim))
+    dropped, tg, ig = info['contacts_dropped'].cpu().numpy(), term.cpu().numpy(), info['invalid_contacts'].cpu().numpy()
     a = act.cpu().numpy()
     qv = env.qvel.cpu().numpy()
     nhf = 0
@@ -726,12 +733,17 @@ def test_perlin_scene_contract_and_parity(robot):
         if pend[e]:
             continue
         o.set_state(q0[e], v0[e], w0[e], np.zeros(18), 0.0, float(fr[e])); o.step(a[e].astype(np.float64))
-        if tally.classify(e, o, dbg[e]['nefc'][0]) != 'ok':
+        cls = tally.classify(e, o, dbg[e]['nefc'][0])
+        if cls == 'budget':   # the kernel's rows are the oracle's first rows, the flags the oracle's, and the caller is told what was cut
+            tally.check_budget_prefix(e, o, dbg[e]['nefc'][0], dbg[e]['efc_J'], dbg[e]['efc_R'], dbg[e]['efc_aref'], (tg[e], ig[e]))
+            assert int(dropped[e]) == o.ncon - int(dbg[e]['ncon'][0]) > 0, (e, int(dropped[e]), o.ncon, int(dbg[e]['ncon'][0]))
+        if cls != 'ok':
             continue
+        assert int(dropped[e]) == 0, (e, int(dropped[e]))
         nhf += int((np.abs(o.contact_frame[:, 0, 2] - 1.0) > 1e-9).sum()) if o.ncon else 0
         assert np.abs(dbg[e]['qacc'] - o.qacc).max() < 3e-4 * max(1.0, np.abs(o.qacc).max()), e
         assert np.abs(qv[e] - o.qvel).max() < 1e-3
-    tally.finish(f'perlin one-step parity {robot}', min_checked=0.7, max_tie=0.15, max_budget=0.25)
+    tally.finish(f'perlin one-step parity {robot}', min_checked=0.7, max_tie=0.15, max_budget=0.1)
     assert nhf > n // 4, nhf
     # HeightMap: vertical rays against the same surface
     hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)

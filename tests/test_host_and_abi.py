@@ -80,15 +80,77 @@ def test_cabi_library_exports_every_declared_symbol():
 
 
 def test_ctypes_struct_layout_matches_header():
-    """sizeof of the ctypes mirrors must equal what the C compiler sees (guards against field drift)."""
-    from gym_quadruped_amd.cabi import GqModelDesc, GqObsOut, GqResetCfg, GqState
-    src = '#include <stdio.h>\n#include "gq.h"\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(GqModelDesc),sizeof(GqState),sizeof(GqObsOut),sizeof(GqResetCfg));return 0;}'
+    """sizeof of the ctypes mirrors must equal what the C compiler sees (guards against field drift) - every struct that
+    crosses the boundary, in the order of gq_struct_sizes."""
+    from gym_quadruped_amd.cabi import GqImuCfg, GqMailboxView, GqModelDesc, GqObsOut, GqPolicyPd, GqResampleCfg, GqResetCfg, GqState
+    names = ['GqModelDesc', 'GqState', 'GqObsOut', 'GqResetCfg', 'GqResampleCfg', 'GqImuCfg', 'GqPolicyPd', 'GqMailboxView']
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gq.h"\nint main(){printf("' + '%zu ' * len(names) + '%zu\\n",' + ','.join(f'sizeof({n})' for n in names)
+           + ',offsetof(GqPolicyPd, noise_seed));return 0;}')
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         (Path(d) / 'a.c').write_text(src)
         subprocess.run(['gcc', '-I', str(ROOT / 'include'), str(Path(d) / 'a.c'), '-o', str(Path(d) / 'a')], check=True)
         out = subprocess.run([str(Path(d) / 'a')], check=True, capture_output=True, text=True).stdout.split()
-    assert [int(x) for x in out] == [ctypes.sizeof(GqModelDesc), ctypes.sizeof(GqState), ctypes.sizeof(GqObsOut), ctypes.sizeof(GqResetCfg)]
+    mirror = [GqModelDesc, GqState, GqObsOut, GqResetCfg, GqResampleCfg, GqImuCfg, GqPolicyPd, GqMailboxView]
+    assert [int(x) for x in out[:-1]] == [ctypes.sizeof(t) for t in mirror]
+    assert int(out[-1]) == GqPolicyPd.noise_seed.offset   # the 8-byte-aligned word after 37 floats
+    # ... and the built library reports the same eight numbers (what _lib.lib() refuses a stale build with)
+    from gym_quadruped_amd import _lib
+    L = ctypes.CDLL(str(_lib.LIB_PATH))
+    sizes = (ctypes.c_int32 * 8)()
+    assert L.gq_struct_sizes(sizes) == 0 and list(sizes) == [ctypes.sizeof(t) for t in mirror]
+
+
+def integration_stub_text():
+    """The first fenced python block of INTEGRATION.md section 2: the binding a reference maintainer would write."""
+    text = (ROOT / 'INTEGRATION.md').read_text()
+    a = text.index('```python\n', text.index('## 2. The stub')) + len('```python\n')
+    return text[a:text.index('\n```', a)]
+
+
+class _TypeCheckedLib:
+    """Stands in for ctypes.CDLL on a machine without a GPU: calls that need no device go to the real library, every
+    other call is checked against the argument table gym_quadruped_amd/_lib.py declares for it (count and convertibility
+    of each argument - what ctypes itself would refuse) and answered with GQ_OK."""
+
+    def __init__(self, real):
+        self._real = real
+        self.calls = []
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if name in ('gq_version', 'gq_struct_sizes', 'gq_last_error', 'gq_obs_dim'):
+            return fn
+
+        def call(*args):
+            assert fn.argtypes is not None, f'{name}: no argument table in _lib.py'
+            assert len(args) == len(fn.argtypes), f'{name}: {len(args)} arguments, the ABI takes {len(fn.argtypes)}'
+            for k, (a, t) in enumerate(zip(args, fn.argtypes)):
+                try:
+                    t.from_param(a)
+                except (TypeError, ctypes.ArgumentError) as e:
+                    raise AssertionError(f'{name}: argument {k} ({type(a).__name__}) is not a {t.__name__}: {e}')
+                if isinstance(a, ctypes.Structure):
+                    assert type(a) is t, f'{name}: argument {k} is a {type(a).__name__}, the ABI takes {t.__name__} by value'
+            self.calls.append(name)
+            if name == 'gq_batch_obs_dim':
+                return 19 + 18 + 12 + 12 + 12
+            return 0
+        return call
+
+
+def test_integration_stub_text_matches_the_abi(monkeypatch):
+    """INTEGRATION.md's stub, executed as written (device = cpu tensors; device calls type-checked, not run): the ABI
+    version it asserts, the struct sizes it compares, every struct constructor and every call's argument list."""
+    from gym_quadruped_amd import _lib
+    real = _lib.lib()
+    proxy = _TypeCheckedLib(real)
+    monkeypatch.setattr(ctypes, 'CDLL', lambda path, *a, **k: proxy)
+    monkeypatch.chdir(ROOT)
+    text = integration_stub_text()
+    assert "N, dev = 64, 'cuda'" in text
+    exec(compile(text.replace("N, dev = 64, 'cuda'", "N, dev = 64, 'cpu'"), 'INTEGRATION.md', 'exec'), {'__name__': 'integration_stub'})
+    assert proxy.calls == ['gq_model_create', 'gq_batch_create', 'gq_batch_obs_dim', 'gq_reset', 'gq_step', 'gq_step', 'gq_batch_destroy', 'gq_model_destroy']
 
 
 def test_env_fails_loudly_without_gpu_or_library():

@@ -10,8 +10,8 @@ def kernel_stats(db, out_md, title, bench_json=None):
         f.write('| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n')
         for n, calls, tot, avg, p in rows[:8]:
             f.write(f'| {n.split("(")[0][:70]} | {calls} | {tot:.1f} | {avg:.2f} | {p:.2f} |\n')
-        r = list(c.execute("select name, vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x, avg(duration), count(*), min(duration), max(duration) from kernels where name like 'void gq::%' or name like 'gq::%' group by name"))
-        f.write('\nlibgq kernels (ns):\n\n| kernel | vgpr | sgpr | lds B | scratch B | grid | wg | avg ns | n | min ns | max ns |\n|---|---|---|---|---|---|---|---|---|---|---|\n')
+        r = list(c.execute("select name, lds_size, scratch_size, grid_x, workgroup_x, avg(duration), count(*), min(duration), max(duration) from kernels where name like 'void gq::%' or name like 'gq::%' group by name"))
+        f.write('\nlibgq kernels (ns; register counts: the compiler\'s table in profiles/rNN_kernel_resources.md - rocprofv3\'s vgpr column is the allocation granule, not the use):\n\n| kernel | lds B | scratch B | grid | wg | avg ns | n | min ns | max ns |\n|---|---|---|---|---|---|---|---|---|\n')
         for x in r:
             f.write('| ' + x[0].split('(')[0] + ' | ' + ' | '.join(str(int(v)) for v in x[1:]) + ' |\n')
         if bench_json and Path(bench_json).exists():
@@ -69,6 +69,14 @@ def sq(dirs, out_md, n_envs):
             f.write(f'| {k} | {m:.0f} | {m / n_envs:.1f} | {n} |\n')
         g = lambda k: tot.get(k, (0, 0))[0]
         if g('SQ_WAVE_CYCLES'):
+            sha = None
+            for d in dirs:
+                h = Path(d).parent / 'kernel_src_sha16.txt'
+                if h.exists():
+                    sha = h.read_text().strip() or None
+            print(json.dumps({'valu_per_wave': g('SQ_INSTS_VALU') / n_envs, 'salu_per_wave': g('SQ_INSTS_SALU') / n_envs, 'lds_per_wave': g('SQ_INSTS_LDS') / n_envs,
+                              'active_lanes_per_valu': (g('SQ_THREAD_CYCLES_VALU') / g('SQ_INSTS_VALU')) if g('SQ_INSTS_VALU') and g('SQ_THREAD_CYCLES_VALU') else None,
+                              'wave_cycles': 4 * g('SQ_WAVE_CYCLES') / n_envs, 'kernel_src_sha16': sha, 'profile': str(out_md)}))
             f.write(f'\nper wave: {g("SQ_INSTS_VALU")/n_envs:.0f} VALU, {g("SQ_INSTS_SALU")/n_envs:.0f} SALU, {g("SQ_INSTS_LDS")/n_envs:.0f} LDS, '
                     f'{(g("SQ_INSTS_VMEM_RD")+g("SQ_INSTS_VMEM_WR"))/n_envs:.0f} VMEM instructions over {4*g("SQ_WAVE_CYCLES")/n_envs:.0f} cycles of wave lifetime; '
                     f'VALU busy {g("SQ_ACTIVE_INST_VALU")/g("SQ_WAVE_CYCLES")*100:.0f} % of a wave\'s lifetime (x4 resident waves per SIMD), '

@@ -6,7 +6,12 @@ T=$1; R=${2:-r02}; PO=${PROFILES_OUT:-profiles}; mkdir -p $PO
 P=gpurun_out/prof_$T
 python tools/profile_summary.py stats $P/stats/stats_results.db $PO/${R}_kernel_stats.md "$R kernel stats: python bench.py --no-cpu-baseline --no-secondary --steps 2000 --warmup 200 (mini_cheetah flat, 4096 envs, Newton, self-collision on)" $P/bench_stats.json
 python tools/profile_summary.py pmc $P/pmc_1,$P/pmc_2 $PO/${R}_hbm_counters.md 4096 1735 > $PO/latest_traffic.json
-python tools/profile_summary.py sq $P/pmc_3,$P/pmc_4,$P/pmc_5,$P/pmc_6,$P/pmc_7,$P/pmc_8 $PO/${R}_sq_counters.md 4096
+python tools/profile_summary.py sq $P/pmc_3,$P/pmc_4,$P/pmc_5,$P/pmc_6,$P/pmc_7,$P/pmc_8 $PO/${R}_sq_counters.md 4096 > $PO/latest_sq.json
+# raw rocprofv3 --stats CSVs (small) are kept beside the summaries
+RAW=$PO/raw_${R}; mkdir -p $RAW
+for t in "" _noself _cfg3 _cfg4 _cfg5; do
+  for f in gpurun_out/prof_${T}$t/stats/*kernel_stats.csv gpurun_out/prof_${T}$t/stats/*domain_stats.csv; do [ -f "$f" ] && cp "$f" $RAW/headline${t}_$(basename $f); done
+done
 for t in noself cfg3 cfg4 cfg5; do
   Q=gpurun_out/prof_${T}_$t
   python tools/profile_summary.py stats $Q/stats/stats_results.db $PO/${R}_kernel_stats_$t.md "$R kernel stats: bench.py --no-cpu-baseline --no-secondary $(cut -d' ' -f5- $Q/command.txt) --steps 2000 --warmup 200" $Q/bench_stats.json

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline --no-secondary $*"
 echo "$BENCH" > $OUT/command.txt
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH --steps 2000 --warmup 200 > $OUT/bench_stats.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $OUT/stats -o stats -- $BENCH --steps 2000 --warmup 200 > $OUT/bench_stats.json 2> $OUT/stats.log
 if [ "$PMC" = "pmc" ]; then
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT" \
