@@ -87,18 +87,17 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
   WaveCtx C;
   int hint = load_rows<SOLVER>(A->s, c, W, env, pass == 0, C);
   bool respawn = c.auto_reset == 2 && C.pend; /* wave-uniform */
-  /* the reset's own step after an explicit gq_reset: the reset kernel left word whether the lift loop is still due */
-  int lift = c.first_pass ? C.lift : 0;
+  /* (the reset's own step after an explicit gq_reset: the reset kernel left word whether the lift loop is still due - load_rows put it in W.lift_due) */
   if constexpr (PERSIST) if (c.policy) pd_inline(*mptr(c.policy), A->s, c, W, env, kstep, !respawn); /* wave-uniform */
   for (;;) { /* one call site each for reset_wave / step_wave: both are large and fully inlined */
     if (respawn) {
       wave_priority(3); /* reset + step in one launch: this wave is the longest of its SIMD */
       wave_barrier();   /* the rows just staged in LDS are dead: reset_wave reuses the region */
-      lift = reset_wave<BOXES, PRIM>(A->r, W, c.env0);
+      reset_wave<BOXES, PRIM>(A->r, W, c.env0);
       pass = c.auto_reset;
-      hint = load_rows<SOLVER>(A->s, c, W, env, false, C);
+      hint = load_rows<SOLVER>(A->s, c, W, env, false, C, true);
     }
-    const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF, PRIM>(A->s, c, W, pass, lift, hint, C, t_entry);
+    const int term = step_wave<SOLVER, MODE, CONE, BOXES, SELF, PRIM>(A->s, c, W, pass, hint, C, t_entry);
     if (pass != 0 || c.auto_reset != 1 || !term) break;
     respawn = true;
   }
@@ -156,7 +155,7 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
     ck.ctrl = MB.act;
     ck.obs_seq = MB.obs_seq ? MB.obs_seq + (size_t)k * N * mptr(A->s.batch)->obs_dim : nullptr;
     const StepCall& c = ck;
-    int pass = 0, lift = 0;
+    int pass = 0;
     if ((MB.flags & 32) && lane_id() == 0) add_pub(MB.issued + N + env, 1 << (4 * xcc_id())); /* experiment: which XCDs ever stepped this env (nibble counters, <= 15 steps) */
     WaveCtx C;
     int hint = load_rows<SOLVER, true>(A->s, c, W, env, true, C);
@@ -164,11 +163,11 @@ __global__ void __launch_bounds__(GQ_WAVE, 4) mailbox_step_kernel(const FusedArg
     if (respawn) {
       wave_priority(3);
       wave_barrier();
-      lift = reset_wave<BOXES, PRIM, true>(A->r, W, c.env0);
+      reset_wave<BOXES, PRIM, true>(A->r, W, c.env0);
       pass = c.auto_reset;
-      hint = load_rows<SOLVER, true>(A->s, c, W, env, false, C);
+      hint = load_rows<SOLVER, true>(A->s, c, W, env, false, C, true);
     }
-    step_wave<SOLVER, 0, CONE, BOXES, SELF, PRIM, true>(A->s, c, W, pass, lift, hint, C);
+    step_wave<SOLVER, 0, CONE, BOXES, SELF, PRIM, true>(A->s, c, W, pass, hint, C);
     publish_fence(); /* state rows are in this XCD's L2, the observation row has been written through */
     if (MB.flags & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane_id() == 0) add_pub(MB.steps_done + env, 1);

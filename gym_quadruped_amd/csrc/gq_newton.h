@@ -599,6 +599,16 @@ __device__ __forceinline__ int row_piece(int rtype, float y, float R, float flos
   return (rtype != ROW_NONE && y < 0.0f) ? 1 : 0;
 }
 
+/* cost s_i(y) of one row at residual y (mj_constraintUpdate), branch-free: unilateral rows D min(y, 0)^2 / 2; friction-loss rows the
+ * Huber function - quadratic inside |y| < R floss, linear outside */
+__device__ __forceinline__ float row_cost(int rtype, float y, float R, float D, float floss) {
+  const bool fr = rtype == ROW_FRICTION;
+  const float lim = R * floss, ay = fabsf(y);
+  const float quad = 0.5f * D * y * y;
+  const float hub = ay < lim ? quad : floss * (ay - 0.5f * lim);
+  return fr ? hub : ((rtype != ROW_NONE && y < 0.0f) ? quad : 0.0f);
+}
+
 /* derivative pieces of one row along the search direction (first and second derivative of s_i(y + alpha*v)) */
 __device__ __forceinline__ void row_dd(int rtype, float y, float v, float R, float D, float floss, float& d1, float& d2) {
   /* selects, no branches: the line search evaluates this once per trial, and a lone tail wavefront pays 10-20 cycles for every divergent
@@ -754,6 +764,7 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
   }
   /* md = M (qacc - qacc_smooth) = M qacc - qfrc_smooth, advanced with the iterate; zero at the starting point */
   float gnorm2_prev = 0.0f, pred_prev = 1.0f;
+  bool prev_unit = false; /* the previous step was a unit step taken because it lowered the cost (see the line search) */
   for (;; iter++) {
     /* a wave that needs many iterations decides when the launch ends: it moves ahead of the waves it shares the SIMD with */
     /* elliptic-cone models run 2.6 iterations on average and up to 14: with the pyramidal rule (priority 3 from the third iteration on) half of
@@ -805,7 +816,9 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
     if (scale * fast_sqrt(gnorm2) < m.tolerance) { exit_code = 3; break; }
     /* fp32 floor (GqModelDesc.noise_floor): the gradient is a difference of two vectors; once it is down at their
      * round-off a further Newton step only chases noise */
-    if (iter > 0 && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(lane < GQ_NVD ? gterm : 0.0f)) { exit_code = 4; break; }
+    /* (not straight after a unit step taken on its cost decrease: rows changed piece there, and the iterate it leaves has not been through
+     * a step on its own pieces yet - a hyqreal2 pose lying on the floor reached this ratio three such steps into an eight-iteration solve) */
+    if (iter > 0 && !prev_unit && m.noise_floor > 0.0f && gnorm2 <= m.noise_floor * m.noise_floor * wave_sum(lane < GQ_NVD ? gterm : 0.0f)) { exit_code = 4; break; }
     /* stagnation at working precision: close to the solution (the last step promised less than 1e-6, scaled like
      * `tolerance`) Newton's gradient collapses from one iterate to the next; one that did not even halve is rounding noise
      * of the stiff rows' residuals (elliptic models, impratio 100: the iterates then cycle between neighbouring fp32
@@ -1008,11 +1021,31 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
     if constexpr (!CONE) full_step = ballot(row_piece(rtype, y, rR, rfloss) != row_piece(rtype, y + v, rR, rfloss)) == 0;
     NW_T(5);
     if constexpr (DBG) if (tdbg && lane == 0 && full_step) tdbg[30] += 1.0f;
-    if (full_step) { alpha = 1.0f; first_try = true; }
-    else {
     /* phi'(alpha) = sum over lanes of (s.Mdq + alpha s.Ms) [dof lanes] + d1(alpha) [row lanes]: the quadratic part rides
      * in the same reduction as the rows' derivatives */
     const float p1 = lane < GQ_NVD ? search[ld] * md : 0.0f, p2 = lane < GQ_NVD ? search[ld] * ms : 0.0f;
+    /* The unit step is taken whenever it LOWERS the cost (one reduction: phi(1) - phi(0) = s.Mdq + s.Ms / 2 + the rows' cost changes),
+     * without a search for the minimiser along the direction.  The minimiser of the strictly convex problem does not depend on the step rule,
+     * only the path to it does: over 20 000 benchmark-like steps of the fp64 restatement (tools/newton_start_experiment.py, GQO_LS_MODE=1)
+     * the unit step lowers the cost in 96.8 % of the iterations and the iteration count FALLS (mean 1.346 -> 1.321, three or more iterations
+     * 1 623 -> 1 159 of 20 000) against the exact line search - across the kink of a row that changes piece, the exact minimiser along the
+     * direction is no better a place to linearise again than the Newton point.  What it removes is the search itself: two wave reductions
+     * and five branches per trial, 5 - 22 trials in the waves that end a launch (profiles/r05_lone_wave_stages256.txt).  When the unit step
+     * does not lower the cost (3 % of the iterations) the safeguarded search below runs as before. */
+    float dphi = 0.0f; /* phi(1) - phi(0) when the unit step was taken on that evidence */
+    bool unit_step = false;
+    /* (elliptic models keep the search: the rule holds for any convex cost - 89 % / 82 % of the iterations of go2 / hyqreal1 in the fp64
+     * restatement - but in fp32 the stiff cone rows (impratio 100) make the sign of a small cost difference noise: tried, the iteration counts
+     * rose by 25 % in the emulator and the go2 benchmark fell from 26.0 to 8.6 M with the extra registers spilled) */
+    if constexpr (!CONE) if (!full_step) { /* wave-uniform */
+      const float dc = row_cost(rtype, y + v, rR, rD, rfloss) - row_cost(rtype, y, rR, rD, rfloss);
+      dphi = wave_sum(p1 + 0.5f * p2 + dc);
+      unit_step = dphi < 0.0f;
+      if constexpr (DBG) if (tdbg && lane == 0 && unit_step) tdbg[30] += 1.0f;
+    }
+    if (full_step) { alpha = 1.0f; first_try = true; }
+    else if (unit_step) alpha = 1.0f;
+    else {
     float d1, d2;
     row_dd(rtype, y, v, rR, rD, rfloss, d1, d2);
     /* elliptic contacts: along the line T(alpha)^2 = TT + 2 alpha UV + alpha^2 VV and N(alpha) = N + alpha N1, so three
@@ -1103,7 +1136,9 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
     wave_barrier();
     NW_T(6);
     /* improvement of this step from the line-search model (exact for a quadratic phi): phi(0) - phi(alpha) = -g0 alpha / 2 */
-    const float pred = scale * (-0.5f * g0 * alpha);
+    /* (a unit step taken on its cost decrease: the decrease itself - MuJoCo's own `improvement`) */
+    const float pred = unit_step ? scale * (-dphi) : scale * (-0.5f * g0 * alpha);
+    prev_unit = unit_step;
     if constexpr (CONE) pred_prev = pred;
     const bool small_step = pred < m.tolerance || tiny_step;
     if ((first_try && ballot(moved) == 0) || small_step) {

@@ -397,7 +397,7 @@ template <class M> __device__ __forceinline__ GqDevLinkRec link_fetch(const M& m
  * qfrc_applied waits in W.smooth (the actuation block adds the rest to it), the clock in W.force[0] (free until the solver).
  * user_ctrl: the caller's actions (pass 0); resets step with zero control. */
 template <int SOLVER, bool PUB = false> /* PUB: the control row is a mailbox another wavefront wrote while this kernel runs (ld_pub) */
-__device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call, WaveMem& W, const int env, const bool user_ctrl, WaveCtx& C) {
+__device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call, WaveMem& W, const int env, const bool user_ctrl, WaveCtx& C, const bool after_respawn = false) {
   const int lane = lane_id();
   /* ---- 1: pointers */
   const GqDevModel* model = a.model; const GqDevBatch* batch = a.batch;
@@ -448,6 +448,9 @@ __device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call
   if (lane < 12) W.ctrl[lane] = ct;
   if (lane < 4) W.cmd[lane] = cm;
   if (lane == 0) { W.mu_env = mu; W.step_old = sn; W.force[0] = tm; }
+  /* whether the reset's lift loop is due in this step's S6 waits in LDS (carried in a register across the re-spawn branch it was spilled to
+   * scratch memory): from the reset kernel's flag here, from reset_wave itself after an in-kernel re-spawn */
+  if (!after_respawn && lane == 0) GQ_LIFT_DUE(W) = first_pass ? lift : 0;
   C.pend = uniform(pend); C.lift = uniform(lift);
   hint = uniform(hint);
 #if GQ_TICKSET == 3
@@ -472,7 +475,7 @@ __device__ __forceinline__ int load_rows(const StepArgs& a, const StepCall& call
  * in, it cost them 17 % (registers spilled across the box loop). */
 template <int SOLVER, int MODE, bool CONE, bool BOXES, bool SELF, bool PRIM, bool PUB = false> /* PUB: the observation row is published to a
                                                                                                    * concurrently running reader (st_pub) */
-__device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int lift, const int hint, const WaveCtx& C, const long long t_entry = 0) {
+__device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call, WaveMem& W, const int pass, const int hint, const WaveCtx& C, const long long t_entry = 0) {
   /* lane / env are made opaque so that per-lane address arithmetic is not hoisted out of the (rarely taken) second
    * pass loop of the kernel and kept live - that hoisting alone cost > 250 spilled VGPRs */
   int lane_o = lane_id(), env_o = wave_index() + uniform(call.env0);
@@ -759,7 +762,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
 #pragma unroll
     for (int q = 0; q < 5; q++) solimp[q] = IT.solimp[q];
   }
-  if (lift) { /* wave-uniform; only set on scenes without world boxes / height field */
+  if (uniform(GQ_LIFT_DUE(W))) { /* wave-uniform; only set on scenes without world boxes / height field */
     /* the reference lifts by 1.1 max |contact.dist| over EVERY contact of the calf bodies with the ground (feet_contact_state
      * lists them all, quadruped_env.py:378-385) until none is left */
     float dz = 0.0f;
@@ -1848,6 +1851,7 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
     if (a.friction_next)
       gptr(a.friction_next)[env] = c.friction_range[0] + (c.friction_range[1] - c.friction_range[0]) * u_fric;
   }
+  GQ_LIFT_DUE(W) = lift_due; /* (every lane: the same word) step_wave's S6 reads it */
   return lift_due;
 }
 

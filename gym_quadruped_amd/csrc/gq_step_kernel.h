@@ -148,7 +148,7 @@ enum {
 
 enum { ROW_NONE = 0, ROW_FRICTION = 1, ROW_LIMIT = 2, ROW_CONTACT1 = 3, ROW_PYRAMID = 4, ROW_ELLIPTIC = 5 };
 
-/* ------------------------------------------------------------------ per-wave LDS working set (10 196 B: 16 waves per CU fit the 160 KB)
+/* ------------------------------------------------------------------ per-wave LDS working set (10 240 B, all of it used: 16 waves per CU fit the 160 KB)
  * `u` overlays three regions with disjoint lifetimes: the spatial-dynamics scratch (S1-S5), the half-batch of
  * B = M^-1 J' rows while the dual operator is built (S8), and the observation row (S11). */
 struct WaveDyn {
@@ -211,6 +211,10 @@ struct WaveMem {
     float obs[256];
   } u;
 };
+static_assert(sizeof(WaveMem) <= 10240 || GQ_TICKSET != 0, "16 one-wave workgroups per CU need <= 10 240 B of LDS each: WaveMem is full, a new field must reuse a dead one");
+/* S0 .. S6: whether the reset's lift loop is due in this step's S6, as an int in force[1] (free until the solver, like the clock in force[0];
+ * carried in a register from the prologue across the re-spawn branch it was spilled to scratch memory, and WaveMem has no byte to spare) */
+#define GQ_LIFT_DUE(W) (reinterpret_cast<int32_t*>(&(W).force[1])[0])
 
 /* ------------------------------------------------------------------ small math */
 struct V3 { float x, y, z; };

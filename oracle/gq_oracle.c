@@ -1526,6 +1526,19 @@ static void gqo_sol_newton(GqOracle* o, int maxiter, double tol) {
       q2 += 0.5 * search[i] * Mv[i];
     }
     if (has_cone) { /* elliptic contacts: phi is convex and C1 but not piecewise quadratic -> safeguarded Newton on phi' */
+      { /* experiment knob GQO_LS_MODE = 1 (see below): the full Newton step whenever it lowers the cost */
+        static int lsmode_c = -1;
+        static long n_full = 0, n_fall = 0;
+        if (lsmode_c < 0) { const char* e = getenv("GQO_LS_MODE"); lsmode_c = e ? atoi(e) : 0; }
+        if (lsmode_c == 1) {
+          double trial[NV];
+          for (int i = 0; i < NV; i++) trial[i] = qacc[i] + search[i];
+          const int okf = primal_cost(o, trial, NULL) < primal_cost(o, qacc, NULL);
+          if (okf) n_full++; else n_fall++;
+          if (getenv("GQO_LS_STATS") && ((n_full + n_fall) % 5000) == 0) fprintf(stderr, "ls mode 1 (cone): %ld full steps accepted, %ld fell back to the search\n", n_full, n_fall);
+          if (okf) { memcpy(qacc, trial, sizeof qacc); continue; }
+        }
+      }
       double lo = 0, hi = -1, alpha = 0, g0 = 0;
       int ok = 0;
       for (int it = 0; it < 200; it++) {
@@ -1589,7 +1602,11 @@ static void gqo_sol_newton(GqOracle* o, int maxiter, double tol) {
       if (lsmode == 1) {
         double trial[NV];
         for (int i = 0; i < NV; i++) trial[i] = qacc[i] + search[i];
-        if (primal_cost(o, trial, NULL) < primal_cost(o, qacc, NULL)) { memcpy(qacc, trial, sizeof qacc); continue; }
+        static long n_full = 0, n_fall = 0;
+        const int okf = primal_cost(o, trial, NULL) < primal_cost(o, qacc, NULL);
+        if (okf) n_full++; else n_fall++;
+        if (getenv("GQO_LS_STATS") && ((n_full + n_fall) % 5000) == 0) fprintf(stderr, "ls mode 1: %ld full steps accepted, %ld fell back to the exact search\n", n_full, n_fall);
+        if (okf) { memcpy(qacc, trial, sizeof qacc); continue; }
       }
     }
     if (d1 >= 0) { alpha = 0; found = 1; }

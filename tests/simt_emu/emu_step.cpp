@@ -67,25 +67,24 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
       for (int g = 0; g < M.nlg; g++) prims = prims || M.lg[g].ptype == 2 || M.lg[g].ptype == 3 || M.lg[g].ptype == 6;
       int hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, pass == 0, C) : gq::load_rows<0>(f.s, call, W, e, pass == 0, C);
       bool respawn = call.auto_reset == 2 && C.pend;
-      int lift = call.first_pass ? C.lift : 0;
       for (;;) {
         if (respawn) {
           gq::wave_barrier();
-          lift = boxes ? (prims ? gq::reset_wave<true, true>(f.r, W) : gq::reset_wave<true, false>(f.r, W)) : gq::reset_wave<false>(f.r, W);
+          boxes ? (prims ? gq::reset_wave<true, true>(f.r, W) : gq::reset_wave<true, false>(f.r, W)) : gq::reset_wave<false>(f.r, W);
           pass = call.auto_reset;
-          hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, false, C) : gq::load_rows<0>(f.s, call, W, e, false, C);
+          hint = M.solver == 1 ? gq::load_rows<1>(f.s, call, W, e, false, C, true) : gq::load_rows<0>(f.s, call, W, e, false, C, true);
         }
         int term;
         if (M.solver != 1) { /* PGS (pyramidal cones only) */
-          if (boxes && prims) term = gq::step_wave<0, 1, false, true, true, true>(f.s, call, W, pass, lift, hint, C);
-          else if (boxes) term = gq::step_wave<0, 1, false, true, true, false>(f.s, call, W, pass, lift, hint, C);
-          else if (self) term = gq::step_wave<0, 1, false, false, true, true>(f.s, call, W, pass, lift, hint, C);
-          else term = gq::step_wave<0, 1, false, false, false, true>(f.s, call, W, pass, lift, hint, C);
+          if (boxes && prims) term = gq::step_wave<0, 1, false, true, true, true>(f.s, call, W, pass, hint, C);
+          else if (boxes) term = gq::step_wave<0, 1, false, true, true, false>(f.s, call, W, pass, hint, C);
+          else if (self) term = gq::step_wave<0, 1, false, false, true, true>(f.s, call, W, pass, hint, C);
+          else term = gq::step_wave<0, 1, false, false, false, true>(f.s, call, W, pass, hint, C);
         }
-        else if (boxes && prims) term = M.cone ? gq::step_wave<1, 1, true, true, true, true>(f.s, call, W, pass, lift, hint, C) : gq::step_wave<1, 1, false, true, true, true>(f.s, call, W, pass, lift, hint, C);
-        else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true, true, false>(f.s, call, W, pass, lift, hint, C) : gq::step_wave<1, 1, false, true, true, false>(f.s, call, W, pass, lift, hint, C);
-        else if (self) term = M.cone ? gq::step_wave<1, 1, true, false, true, true>(f.s, call, W, pass, lift, hint, C) : gq::step_wave<1, 1, false, false, true, true>(f.s, call, W, pass, lift, hint, C);
-        else term = M.cone ? gq::step_wave<1, 1, true, false, false, true>(f.s, call, W, pass, lift, hint, C) : gq::step_wave<1, 1, false, false, false, true>(f.s, call, W, pass, lift, hint, C);
+        else if (boxes && prims) term = M.cone ? gq::step_wave<1, 1, true, true, true, true>(f.s, call, W, pass, hint, C) : gq::step_wave<1, 1, false, true, true, true>(f.s, call, W, pass, hint, C);
+        else if (boxes) term = M.cone ? gq::step_wave<1, 1, true, true, true, false>(f.s, call, W, pass, hint, C) : gq::step_wave<1, 1, false, true, true, false>(f.s, call, W, pass, hint, C);
+        else if (self) term = M.cone ? gq::step_wave<1, 1, true, false, true, true>(f.s, call, W, pass, hint, C) : gq::step_wave<1, 1, false, false, true, true>(f.s, call, W, pass, hint, C);
+        else term = M.cone ? gq::step_wave<1, 1, true, false, false, true>(f.s, call, W, pass, hint, C) : gq::step_wave<1, 1, false, false, false, true>(f.s, call, W, pass, hint, C);
         if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
       }
