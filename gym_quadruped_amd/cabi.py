@@ -56,6 +56,7 @@ class GqModelDesc(C.Structure):
         ('hfield_solmix', C.c_double), ('hfield_solref', C.c_double * 2), ('hfield_solimp', C.c_double * 5),
         ('hfield_condim', C.c_int32), ('hfield_priority', C.c_int32),
         ('nselfpair', C.c_int32), ('selfpair_geom1', _I), ('selfpair_geom2', _I), ('geom_capsule', _D), ('geom_type', _I),
+        ('plane_grid', C.c_int32), ('plane_vert_pos', _D), ('plane_mask', _I),
     ]
 
 
@@ -115,6 +116,167 @@ LEG_NAMES = ['FL', 'FR', 'RL', 'RR']
 SOLVER_PGS, SOLVER_NEWTON = 0, 1
 
 
+PLANE_GRID = 8   # cube-map cells per face edge of the plane-support tables (6 * 8 * 8 = 384 direction cells)
+
+
+def plane_cell_tables(grid=PLANE_GRID):
+    """Unit centre and angular radius of every cube-map cell (face = dominant axis and its sign, then a grid x grid raster over the
+    other two coordinates divided by the dominant one): cell index = ((axis * 2 + negative) * grid + iu) * grid + iv - the
+    formula the kernel evaluates (csrc/gq_step_body.h stage_collision_scan)."""
+    cen, rad = np.zeros((6 * grid * grid, 3)), np.zeros(6 * grid * grid)
+    for m in range(3):
+        o = [k for k in range(3) if k != m]
+        for sgn in range(2):
+            for iu in range(grid):
+                for iv in range(grid):
+                    pts = []
+                    for du in (0.0, 0.5, 1.0):
+                        for dv in (0.0, 0.5, 1.0):
+                            q = np.zeros(3)
+                            q[m] = 1.0 if sgn == 0 else -1.0
+                            q[o[0]], q[o[1]] = (iu + du) / grid * 2 - 1, (iv + dv) / grid * 2 - 1
+                            pts.append(q / np.linalg.norm(q))
+                    pts = np.asarray(pts)
+                    idx = ((m * 2 + sgn) * grid + iu) * grid + iv
+                    cen[idx] = pts[4]
+                    rad[idx] = np.arccos(np.clip((pts @ pts[4]).min(), -1.0, 1.0))   # the corners are the farthest points of a cell
+    return cen, rad
+
+
+def plane_cell_of(d, grid=PLANE_GRID):
+    """Cell of direction d (numpy restatement of the kernel's formula; tests)."""
+    a = np.abs(d)
+    m = 0 if (a[0] >= a[1] and a[0] >= a[2]) else (1 if a[1] >= a[2] else 2)
+    o = [k for k in range(3) if k != m]
+    iu = min(int((d[o[0]] / a[m] + 1.0) * 0.5 * grid), grid - 1)
+    iv = min(int((d[o[1]] / a[m] + 1.0) * 0.5 * grid), grid - 1)
+    return ((m * 2 + (0 if d[m] > 0 else 1)) * grid + iu) * grid + iv
+
+
+def _clip(poly, a, b, c):
+    """Sutherland-Hodgman: the part of the convex polygon poly [(u, v)] with a + b u + c v >= 0."""
+    out = []
+    n = len(poly)
+    for i in range(n):
+        p, q = poly[i], poly[(i + 1) % n]
+        fp, fq = a + b * p[0] + c * p[1], a + b * q[0] + c * q[1]
+        if fp >= 0:
+            out.append(p)
+        if (fp >= 0) != (fq >= 0):
+            t = fp / (fp - fq)
+            out.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+    return out
+
+
+def _cone_cells(V, hull, adj, grid, slack):
+    """[cells][vertices] bool: the cube-map cells the normal cone of every hull vertex reaches.  Vertex v supports direction d iff
+    (V[v] - V[w]) . d >= 0 for every hull neighbour w; on a cube face (dominant coordinate +-1, the other two = (u, v)) these are
+    half-planes in (u, v), the cone's trace is their intersection with the face square - a small convex polygon - and the cells its
+    bounding box overlaps are marked (a superset of the cells it meets).  A vertex qhull did not report (no facets) reaches every cell."""
+    n = len(V)
+    nb = [set() for _ in range(n)]
+    for simp in hull.simplices:
+        for i in simp:
+            nb[i].update(int(j) for j in simp if j != i)
+    out = np.zeros((6 * grid * grid, n), dtype=bool)
+    scale = np.abs(V).max() + 1e-12
+    for v in range(n):
+        if not adj[v]:
+            out[:, v] = True
+            continue
+        E = (V[v][None, :] - V[sorted(nb[v])]) / scale            # rows e: e . d >= 0
+        for m in range(3):
+            o = [k for k in range(3) if k != m]
+            for sgn in range(2):
+                dm = 1.0 if sgn == 0 else -1.0
+                poly = [(-1.0, -1.0), (1.0, -1.0), (1.0, 1.0), (-1.0, 1.0)]
+                for e in E:
+                    poly = _clip(poly, e[m] * dm + 1e-9, e[o[0]], e[o[1]])   # (+1e-9: the cone a hair wider - conservative)
+                    if not poly:
+                        break
+                if not poly:
+                    continue
+                P = np.asarray(poly)
+                lo, hi = P.min(0) - slack, P.max(0) + slack
+                iu0, iu1 = max(int(np.floor((lo[0] + 1) * 0.5 * grid)), 0), min(int(np.floor((hi[0] + 1) * 0.5 * grid)), grid - 1)
+                iv0, iv1 = max(int(np.floor((lo[1] + 1) * 0.5 * grid)), 0), min(int(np.floor((hi[1] + 1) * 0.5 * grid)), grid - 1)
+                base = (m * 2 + sgn) * grid
+                for iu in range(iu0, iu1 + 1):
+                    out[(base + iu) * grid + iv0:(base + iu) * grid + iv1 + 1, v] = True
+    return out
+
+
+_PLANE_CACHE = {}
+
+
+def plane_support_tables(md: ModelDesc, grid=PLANE_GRID, chunk=64, wide_deg=45.0, slack=2e-3):
+    key = (hash(np.asarray(md.vert_pos, dtype=np.float64).tobytes()), tuple(int(x) for x in md.cloud_vertnum), grid, chunk, wide_deg, slack)
+    if key not in _PLANE_CACHE:
+        _PLANE_CACHE[key] = _plane_support_tables(md, grid, chunk, wide_deg, slack)
+    return _PLANE_CACHE[key]
+
+
+def _plane_support_tables(md: ModelDesc, grid, chunk, wide_deg, slack):
+    """Acceleration structure of the hull-versus-plane narrow phase (mjc_PlaneConvex's support vertex = the vertex deepest along the
+    plane normal): per hull cloud of more than one 64-vertex chunk, (i) its vertices in DIRECTION order - sorted by the cube-map cell
+    of the mean of the outward normals of the hull facets around the vertex, vertices with a wide normal cone last - so that a chunk
+    of consecutive vertices answers a patch of directions, and (ii) per direction cell a bit mask of the chunks that can hold the
+    support vertex of SOME direction in the cell.  A vertex is the support vertex for exactly the directions inside the cone spanned
+    by the normals of its facets; the mask keeps a chunk when the cap around one of its vertices' cones (axis = mean normal,
+    half-angle = the widest facet normal) comes within the cell's own cap - a superset of the exact answer, so the kernel's scan of
+    the masked chunks finds the same vertex as a scan of the whole cloud (tests/test_host_and_abi.py).  Position-sorted chunks
+    (sort_cloud_vertices, used against world boxes and the height field) cannot answer this query for a link LYING on the floor: every
+    slab along its axis is equally deep, all 8 - 11 chunks of every geom were scanned - 18 k cycles for exactly the waves that end a
+    launch.  Returns (plane_vert_pos [nvert][3] f64, plane_mask [ncloud][6 grid^2] int32)."""
+    from scipy.spatial import ConvexHull
+    cen, rad = plane_cell_tables(grid)
+    vert = np.array(md.vert_pos, dtype=np.float64, copy=True)
+    ncl = len(md.cloud_vertnum)
+    masks = np.ones((ncl, 6 * grid * grid), dtype=np.int32)
+    for cl in range(ncl):
+        n, a = int(md.cloud_vertnum[cl]), int(md.cloud_vertadr[cl])
+        if n <= chunk:
+            continue
+        V = vert[a:a + n].copy()
+        try:
+            hull = ConvexHull(V)
+        except Exception:   # a degenerate cloud: every chunk is scanned, the order stays
+            masks[cl] = (1 << ((n + chunk - 1) // chunk)) - 1
+            continue
+        N = hull.equations[:, :3]
+        adj = [[] for _ in range(n)]
+        for f, simp in enumerate(hull.simplices):
+            for v in simp:
+                adj[v].append(f)
+        ax, th = np.zeros((n, 3)), np.full(n, np.pi)
+        ctr = V.mean(0)
+        for v in range(n):
+            if adj[v]:
+                mean = N[adj[v]].sum(0)
+                nrm = np.linalg.norm(mean)
+                if nrm > 1e-9:
+                    ax[v] = mean / nrm
+                    th[v] = np.arccos(np.clip((N[adj[v]] @ ax[v]).min(), -1.0, 1.0))
+                    continue
+            # not reported as a hull vertex (qhull merged it into a facet) or a degenerate fan: may be the support vertex of any direction
+            out = V[v] - ctr
+            ax[v] = out / max(np.linalg.norm(out), 1e-12)
+        wide = th > np.radians(wide_deg)
+        key = np.array([plane_cell_of(ax[v], grid) for v in range(n)], dtype=np.int64) + wide * (10 * 6 * grid * grid)
+        order = np.argsort(key, kind='stable')
+        vert[a:a + n] = V[order]
+        chunk_of = np.empty(n, dtype=np.int64)
+        chunk_of[order] = np.arange(n) // chunk
+        ang = np.arccos(np.clip(cen @ ax.T, -1.0, 1.0))                    # [cells][vertices]
+        touch = ang <= th[None, :] + rad[:, None] + slack
+        touch &= _cone_cells(V, hull, adj, grid, slack)                     # two supersets of the exact answer: so is their intersection
+        m = np.zeros(6 * grid * grid, dtype=np.int64)
+        for k in range((n + chunk - 1) // chunk):
+            m |= (touch[:, chunk_of == k].any(1).astype(np.int64) << k)
+        masks[cl] = m.astype(np.int32)
+    return vert, masks
+
+
 class MarshalledModel:
     """Owns the numpy buffers a GqModelDesc points into (keep alive for as long as the struct is in use)."""
 
@@ -151,7 +313,7 @@ class MarshalledModel:
         d.nselfpair = int(len(pairs))
         self.self_pairs = pairs
         for name, ctype in GqModelDesc._fields_:
-            if ctype in (_I, _D):
+            if ctype in (_I, _D) and not name.startswith('plane_'):   # (the optional plane tables are filled below)
                 src = q0 if name == 'qpos0' else (box_arrays[name] if name in box_arrays else getattr(md, name))
                 arr = np.ascontiguousarray(src, dtype=np.int32 if ctype is _I else np.float64)
                 if arr.size == 0:
@@ -193,6 +355,14 @@ class MarshalledModel:
             d.hfield_solref = (C.c_double * 2)(*hg['solref'])
             d.hfield_solimp = (C.c_double * 5)(*hg['solimp'])
             d.hfield_condim, d.hfield_priority = hg['condim'], hg['priority']
+        # hull-versus-plane support tables (optional in the C-ABI: NULL = every chunk of a cloud is scanned)
+        if nvert > 0 and any(int(c) > 64 for c in md.cloud_vertnum):
+            pv, pm = plane_support_tables(md)
+            pv, pm = np.ascontiguousarray(pv, dtype=np.float64), np.ascontiguousarray(pm, dtype=np.int32)
+            self._keep += [pv, pm]
+            d.plane_grid = PLANE_GRID
+            d.plane_vert_pos = pv.ctypes.data_as(_D)
+            d.plane_mask = pm.ctypes.data_as(_I)
         self.desc = d
 
 

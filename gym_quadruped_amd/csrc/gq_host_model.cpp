@@ -248,6 +248,24 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
   vx->clear(); vy->clear(); vz->clear();
   for (int i = 0; i < d->nvert; i++) { vx->push_back((float)d->vert_pos[3 * i]); vy->push_back((float)d->vert_pos[3 * i + 1]); vz->push_back((float)d->vert_pos[3 * i + 2]); }
   if (vx->empty()) { vx->push_back(0); vy->push_back(0); vz->push_back(0); }
+  /* plane tables (optional): the direction-ordered copy of the clouds, then per cloud of more than one chunk its cell masks (as floats:
+   * a mask of <= 16 chunk bits is an integer a float holds exactly) */
+  const bool plane_tables = d->plane_grid > 0 && d->plane_vert_pos && d->plane_mask;
+  if (d->plane_grid < 0 || d->plane_grid > 16) FAIL("plane_grid %d out of range (0 .. 16)", d->plane_grid);
+  M.plane_grid = plane_tables ? d->plane_grid : 0;
+  int plane_base = 0;
+  std::vector<int> cloud_pmask(d->ncloud > 0 ? d->ncloud : 0, -1);
+  if (plane_tables) {
+    plane_base = (int)vx->size();
+    for (int i = 0; i < d->nvert; i++) { vx->push_back((float)d->plane_vert_pos[3 * i]); vy->push_back((float)d->plane_vert_pos[3 * i + 1]); vz->push_back((float)d->plane_vert_pos[3 * i + 2]); }
+    const int ncell = 6 * d->plane_grid * d->plane_grid;
+    for (int cl = 0; cl < d->ncloud; cl++) {
+      if (d->cloud_vertnum[cl] <= 64) continue;
+      if (d->cloud_vertnum[cl] > 16 * 64) FAIL("cloud %d: %d vertices - the plane masks hold 16 chunks of 64", cl, d->cloud_vertnum[cl]);
+      cloud_pmask[cl] = (int)vx->size();
+      for (int c = 0; c < ncell; c++) { vx->push_back((float)(d->plane_mask[(size_t)cl * ncell + c] & 0xffff)); vy->push_back(0.0f); vz->push_back(0.0f); }
+    }
+  }
   M.nlg = 0;
   int nitem = 0;
   for (int g = 0; g < d->ngeom; g++) {
@@ -262,6 +280,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     if (M.nlg >= GQ_MAXLG) FAIL("more than %d link collision geoms", GQ_MAXLG);
     GqDevGeom& G = M.lg[M.nlg++];
     G.body = b - 1; G.cloud_adr = d->cloud_vertadr[cl]; G.cloud_num = d->cloud_vertnum[cl]; G.radius = (float)d->cloud_radius[cl];
+    G.plane_adr = plane_base + G.cloud_adr; G.pmask_adr = cloud_pmask[cl];
     double R[9]; quat2mat(d->geom_quat + 4 * g, R);
     for (int i = 0; i < 3; i++) G.pos[i] = (float)d->geom_pos[3 * g + i];
     for (int i = 0; i < 9; i++) G.mat[i] = (float)R[i];

@@ -29,6 +29,9 @@ struct GqDevGeom {          /* a robot collision geom that is not a foot sphere 
   int32_t flat_adr;         /* small clouds (<= GQ_FLAT_MAXV vertices): first slot in GqDevModel::flat_*, else -1 */
   int32_t chunk_adr;        /* clouds of more than one 64-vertex chunk: index (into the vertex arrays) of the chunk boxes -
                              * entry 2k = centre, 2k + 1 = half extents of vertices [64k, 64k + 64) in the geom frame; else -1 */
+  int32_t plane_adr;        /* floor pass (stage_collision_scan): first vertex of the cloud's DIRECTION-ordered copy in the vertex arrays
+                             * (= cloud_adr when the model came without plane tables) */
+  int32_t pmask_adr;        /* ... and the index (vertex array x) of its per-direction-cell chunk masks, stored as floats; -1: scan every chunk */
   float radius;             /* inflation (capsule) */
   /* plane narrow phase (MuJoCo's mjraw_Plane* routines, evaluated by ONE lane): 0 = hull cloud, support vertex found by the
    * 64-lane scan (mjc_PlaneConvex's first point); 2 sphere; 3 capsule: psize = (radius, half length); 5 cylinder: psize =
@@ -91,6 +94,7 @@ struct alignas(16) GqDevLimRec { int32_t limited; float lo, hi, margin; }; /* la
 struct GqDevModel {
   float timestep, gravity_z, impratio, meaninertia, tolerance, noise_floor;
   int32_t iterations, cone, nlg, nfl, solver;
+  int32_t plane_grid;            /* cube-map cells per face edge of the plane tables (GqDevGeom::pmask_adr), 0: none */
   /* copies of the wave-uniform scalars S5 - S9 read, next to the ones above: the step kernel fetches all of them with two wide scalar
    * loads (StepConsts) instead of one load per field scattered over the struct */
   int32_t hot_foot_leg[4], hot_nsp, hot_self_cut;

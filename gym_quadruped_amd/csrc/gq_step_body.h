@@ -93,12 +93,11 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
     V3 c = ld3(W.xpos[b]) + matvec(W.xmat[b], ld3(FR.pos));
     st3(W.foot_world[lane < 4 ? lane : 3], c);
   }
-  /* link geoms.  Phase 1, lane = geom: plane normal in the geom frame and the OBB lower bound of the cloud.
-   * Phase 2, lane = (surviving geom, 64-vertex chunk of its cloud), four geoms x 16 chunks per pass: lower bound of the chunk's
-   * box (host table behind the vertex arrays; clouds are sorted along their principal axis, so chunks are compact slabs) - a
-   * chunk that cannot come within the contact margin holds no contact and cannot hold the deepest vertex of a geom in contact.
-   * Phase 3, wave-uniform loop over the surviving geoms: wave-wide scan of the surviving chunks (usually one or two of up to
-   * eleven) for the deepest vertex; a geom without surviving chunk makes no contact (distance 1e30).
+  /* link geoms.  Phase 1, lane = geom: plane normal in the geom frame, the OBB lower bound of the cloud, and - for a geom that may
+   * touch - the mask of the 64-vertex chunks of its DIRECTION-ordered cloud that can hold the support vertex of that normal (one word
+   * of the geom's cube-map table).
+   * Phase 3, wave-uniform loop over the surviving geoms: wave-wide scan of the masked chunks (two or three of up to eleven) for the
+   * deepest vertex.
    * Phase 4, lane = geom again: the winner's world position.
    * The scan is a chain of memory round trips - a robot lying on the floor has ten geoms to scan and is also the env whose
    * Newton solve ends the launch - so a geom's table addresses come from its phase-1 lane (ds_bpermute / v_readlane), not
@@ -108,7 +107,7 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
   V3 ng = v3(0.0f, 0.0f, 0.0f);
   float d0 = 0.0f, gmargin = 0.0f, gradius = 0.0f;
   bool needs = false;
-  int cadr = 0, cnum = 0, chk = -1;
+  int cadr = 0, cnum = 0, cmask0 = 0;
   if (nlg > 0) { /* wave-uniform; lane = geom, mirror lanes (they never join the scan: `needs` is masked) */
     const int lg_ = lane < nlg ? lane : nlg - 1;
     const GQ_MODEL GqDevGeom& G = m.lg[lg_];
@@ -121,43 +120,30 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
     const float lower = d0 + dot(ng, ld3(G.aabb_c)) - (fabsf(ng.x) * G.aabb_h[0] + fabsf(ng.y) * G.aabb_h[1] + fabsf(ng.z) * G.aabb_h[2]) - gradius;
     const bool calf = G.body > 0 && (G.body - 1) % 3 == 2;
     needs = lane < nlg && G.ptype == 0 && lower < gmargin && (!calf_only || calf); /* primitive geoms are evaluated lane-locally (floor_candidates) */
-    cadr = G.cloud_adr; cnum = G.cloud_num; chk = G.chunk_adr;
+    cadr = G.plane_adr; cnum = G.cloud_num; /* the DIRECTION-ordered copy of the cloud */
+    { /* which chunks can hold the support vertex of direction -n_g: the geom's mask table, one word per cube-map cell of the direction
+       * (host: cabi.plane_support_tables; no table: every chunk) */
+      const int pm = G.pmask_adr, gridn = m.plane_grid;
+      const float ax_ = fabsf(ng.x), ay_ = fabsf(ng.y), az_ = fabsf(ng.z);
+      const int mx_ = (ax_ >= ay_ && ax_ >= az_) ? 0 : (ay_ >= az_ ? 1 : 2);
+      const float dm = -(mx_ == 0 ? ng.x : (mx_ == 1 ? ng.y : ng.z));
+      const float o0 = -(mx_ == 0 ? ng.y : ng.x), o1 = -(mx_ == 2 ? ng.y : ng.z);
+      const float inv = fast_rcp(fmaxf(fabsf(dm), 0.5f)); /* (the dominant component of a unit vector is >= 0.577) */
+      const float hg = 0.5f * (float)gridn;
+      const int iu = imin(imax((int)((o0 * inv + 1.0f) * hg), 0), gridn - 1), iv = imin(imax((int)((o1 * inv + 1.0f) * hg), 0), gridn - 1);
+      const int cell = ((mx_ * 2 + (dm > 0.0f ? 0 : 1)) * gridn + iu) * gridn + iv;
+      const float mw = vx[pm >= 0 ? pm + cell : 0]; /* (unconditional load, clamped address) */
+      const int nchunk = (cnum + GQ_WAVE - 1) / GQ_WAVE;
+      cmask0 = pm >= 0 ? (int)mw : ((1 << nchunk) - 1);
+    }
     W.u2.c.lg_dist[lg_] = 1e30f; /* (a geom that is scanned gets its distance from phase 3) */
   }
   uint64_t todo = ballot(needs);
   if (todo) { /* wave-uniform */
-    /* phase 2: chunk masks, 16 bits per geom, kept by the geom's own lane */
-    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    int cmask = 0;
-    {
-      const int nsurv = popc64(todo);
-      const int rank = popc64(todo & lt); /* of a surviving geom lane */
-      for (int q0 = 0; q0 < nsurv; q0 += 4) { /* wave-uniform */
-        /* the (q0 + lane / 16)-th surviving geom: select by rank (lanes with needs publish rank -> lane through a ballot search) */
-        const int want = q0 + (lane >> 4);
-        int g = 0;
-        { /* position of the want-th set bit of todo (<= 38 geoms: a short wave-uniform walk, lane-local compare) */
-          uint64_t t = todo;
-          int r = 0;
-          while (t) { const int b = ffs64(t); t &= t - 1; if (r == want) g = b; r++; }
-        }
-        const bool have = want < nsurv;
-        const int c = lane & 15;
-        const int gcn = shfl_idx(cnum, g), gck = shfl_idx(chk, g);
-        const float gx = shfl_idx(ng.x, g), gy = shfl_idx(ng.y, g), gz = shfl_idx(ng.z, g), gd = shfl_idx(d0, g), gm = shfl_idx(gmargin, g), gr = shfl_idx(gradius, g);
-        const int nchunk = (gcn + GQ_WAVE - 1) / GQ_WAVE;
-        bool keep = have && c < nchunk;
-        if (keep && gck >= 0) {
-          const int ia = gck + 2 * c;
-          const V3 cc = v3(vx[ia], vy[ia], vz[ia]), hh = v3(vx[ia + 1], vy[ia + 1], vz[ia + 1]);
-          const float lb = gd + gx * cc.x + gy * cc.y + gz * cc.z - (fabsf(gx) * hh.x + fabsf(gy) * hh.y + fabsf(gz) * hh.z) - gr;
-          keep = lb < gm + 1e-5f;
-        }
-        const uint64_t km = ballot(keep);
-        /* hand the 16-bit group to the geom's lane */
-        if (needs && rank >= q0 && rank < q0 + 4) cmask = (int)((km >> (16 * (rank - q0))) & 0xffffull);
-      }
-    }
+    /* (phase 2 - chunk masks from the boxes of position-sorted chunks, one memory round trip per four geoms - is gone: the masks come
+     * from the direction table in phase 1.  A link lying on the floor has every slab along its axis equally deep: all 8 - 11 chunks of
+     * each of its ten geoms were scanned, 18 k cycles for exactly the waves that end a launch; by direction it is two or three) */
+    const int cmask = needs ? cmask0 : 0;
     /* phase 3 */
     float px[4], py[4], pz[4];
     for (;;) { /* one trip per geom */

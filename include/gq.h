@@ -58,7 +58,8 @@ extern "C" {
  * before its first call (gym_quadruped_amd/_lib.py does), and gq_struct_sizes() lets it check its own mirror of every struct
  * that crosses the boundary.  History: 100 round 1; 300 = GqModelDesc.struct_size + the self-collision / geom_type tables,
  * GqObsOut.step_num_prev, strided HeightMap views, the round-3 entry points; 400 = the closed-loop persistent rollout
- * (gq_rollout_closed, gq_mailbox_get), GqObsOut.contacts_dropped. */
+ * (gq_rollout_closed, gq_mailbox_get), GqObsOut.contacts_dropped; 500 = lap-tagged mailbox queue items, gq_struct_sizes(out[8]),
+ * GqModelDesc.plane_* (optional). */
 #define GQ_ABI_VERSION 500
 
 typedef struct GqModelDesc {
@@ -197,6 +198,17 @@ typedef struct GqModelDesc {
    * It also selects the exact pair routines for sphere / capsule / box geoms against world boxes and against each other.
    * NULL: spheres and capsules are recognised by their clouds (1 / 2 vertices), everything else is a hull. */
   const int32_t* geom_type;      /* [ngeom] */
+  /* OPTIONAL acceleration structure of the hull-versus-plane narrow phase (mjc_PlaneConvex's support vertex: the hull vertex deepest
+   * along the plane normal); plane_grid = 0 / NULL pointers: every 64-vertex chunk of a cloud is scanned.
+   * plane_vert_pos: the clouds' vertices once more, every cloud (same cloud_vertadr / cloud_vertnum) in DIRECTION order, so that a chunk
+   * of 64 consecutive vertices answers a patch of directions.  plane_mask: per cloud and per cell of a cube map of the unit sphere
+   * (cell = ((axis * 2 + negative) * G + iu) * G + iv: dominant axis of the direction and its sign, then the other two coordinates
+   * divided by the dominant one, rastered G x G over [-1, 1]^2), bit k is set when chunk k may hold the support vertex of SOME
+   * direction in the cell - a superset is fine, a missing bit is a missed contact.  gym_quadruped_amd/cabi.py plane_support_tables
+   * builds both from the hulls' facet normals. */
+  int32_t plane_grid;            /* G (<= 16), 0: no tables */
+  const double* plane_vert_pos;  /* [nvert][3] */
+  const int32_t* plane_mask;     /* [ncloud][6 G G] */
 } GqModelDesc;
 
 typedef struct GqModel GqModel;

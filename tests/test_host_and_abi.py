@@ -304,3 +304,51 @@ def test_cloud_vertices_are_sorted_into_compact_chunks():
             assert n < 4 * CLOUD_CHUNK or chunk_ext < 0.35 * ext, (stem, c, chunk_ext, ext)     # a typical chunk spans a fraction of the hull's long axis
                                                                          # (hull vertices crowd at the ends: the chunk across the sparse middle is long)
         assert big >= 3
+
+
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'hyqreal1', 'spot'])
+def test_plane_support_tables_never_hide_the_support_vertex(robot):
+    """cabi.plane_support_tables (the optional GqModelDesc.plane_* acceleration structure of the hull-versus-plane narrow phase): the
+    direction-ordered copy of every cloud holds the same vertices, and for 20 000 random directions per hull the chunk of the support
+    vertex (brute force over the whole cloud) is in the mask of the direction's cube-map cell - a missing bit would be a missed
+    contact.  Also: the masks do prune (fewer than half of the chunks on average) and directions on cell borders / cube edges
+    (where the kernel's fp32 cell index may differ from this f64 one) are covered by both neighbours."""
+    from gym_quadruped_amd.cabi import PLANE_GRID, plane_cell_of, plane_support_tables
+    from gym_quadruped_amd.mjcf import load_compiled
+    from gym_quadruped_amd.robot_cfgs import get_robot_config
+    md = load_compiled(Path(get_robot_config(robot).mjcf_filename).stem)
+    pv, pm = plane_support_tables(md)
+    assert pv.shape == np.asarray(md.vert_pos).shape and pm.shape == (len(md.cloud_vertnum), 6 * PLANE_GRID ** 2)
+    rng = np.random.default_rng(4)
+    seen = 0
+    for cl in range(len(md.cloud_vertnum)):
+        n, a = int(md.cloud_vertnum[cl]), int(md.cloud_vertadr[cl])
+        V = pv[a:a + n]
+        assert sorted(map(tuple, V)) == sorted(map(tuple, np.asarray(md.vert_pos, dtype=np.float64)[a:a + n]))
+        if n <= 64:
+            assert np.array_equal(V, np.asarray(md.vert_pos, dtype=np.float64)[a:a + n]) and (pm[cl] == 1).all()
+            continue
+        seen += 1
+        nch = (n + 63) // 64
+        dirs = rng.normal(size=(20000, 3))
+        # directions on cell borders and cube edges: snap one or two raster coordinates to a grid line
+        snap = dirs[:4000] / np.abs(dirs[:4000]).max(1)[:, None]
+        k = rng.integers(0, 3, 4000)
+        line = np.round((snap[np.arange(4000), k] + 1) * 0.5 * PLANE_GRID) / PLANE_GRID * 2 - 1
+        snap[np.arange(4000), k] = np.where(np.abs(snap[np.arange(4000), k]) < 1, line, snap[np.arange(4000), k])
+        dirs[:4000] = snap
+        dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+        kept = 0
+        for d in dirs:
+            depth = V @ d
+            sup = int(np.argmax(depth))
+            cells = {plane_cell_of(d), plane_cell_of((d * (1 + 1e-6 * rng.normal(size=3))).astype(np.float32).astype(np.float64))}
+            for c in cells:
+                mk = int(pm[cl][c])
+                kept += bin(mk).count('1') / len(cells)
+                assert 0 < mk < (1 << nch)
+                if not (mk >> (sup // 64)) & 1:   # only an exact tie with a vertex of a kept chunk may take its place
+                    best = max(depth[64 * q:64 * q + 64].max() for q in range(nch) if (mk >> q) & 1)
+                    assert best >= depth[sup] - 1e-12, (robot, cl, d)
+        assert kept / len(dirs) < (0.5 * nch if nch >= 4 else nch)   # (a cloud of two or three chunks has little to prune)
+    assert seen >= 1
