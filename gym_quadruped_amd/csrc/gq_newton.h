@@ -1010,7 +1010,9 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
 #pragma unroll
       for (int k = 0; k < GQ_NVD; k++) v += J[k] * search[k];
     }
-    const float ms = mul_m_row(W, search, ld);
+    /* (elliptic variants: the row's LDS addresses are derived again from an opaque lane index every iteration - hoisted out of the loop
+     * they were kept in scratch memory and reloaded here, four loads and their wait per iteration) */
+    const float ms = mul_m_row(W, search, CONE ? opaque_lane(ld) : ld);
     float alpha = 0.0f, lo = 0.0f, hi = -1.0f; /* hi < 0: no upper bracket yet */
     bool first_try = false;
     float g0 = 0.0f, UV = 0.0f, VV = 0.0f, N1 = 0.0f;

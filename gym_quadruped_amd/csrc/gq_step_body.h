@@ -643,10 +643,20 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
    * the foot record) and per wave (StepConsts: scalar loads, pinned) - one batch in front of the velocity stage */
   const FootRec FRec = foot_fetch(m, lane);
   const int l12_ = lane < GQ_NJ ? lane : GQ_NJ - 1, l18_ = lane < GQ_NVD ? lane : GQ_NVD - 1;
-  const int lim_on = m.lim_rec[l12_].limited; const float lim_lo_ = m.lim_rec[l12_].lo, lim_hi_ = m.lim_rec[l12_].hi, lim_mg = m.lim_rec[l12_].margin;
-  const int flr_dof = m.fl_row[l18_].dof; const float flr_R = m.fl_row[l18_].R, flr_B = m.fl_row[l18_].B, flr_floss = m.fl_row[l18_].floss;
-  int hent_pre[2];
-  if constexpr (SOLVER == 1) { hent_pre[0] = m.newton_hent[0][lane]; hent_pre[1] = m.newton_hent[1][lane]; } else { hent_pre[0] = hent_pre[1] = 0; }
+  /* (elliptic variants fetch these where they are used: their solver needs the registers, and what is prefetched here was spilled to scratch
+   * memory on the way - 92 bytes per lane after the early-fetch rework of round 5, 28 before it) */
+  constexpr bool EARLY = !CONE;
+#define GQ_FETCH_LIM() do { lim_on = m.lim_rec[l12_].limited; lim_lo_ = m.lim_rec[l12_].lo; lim_hi_ = m.lim_rec[l12_].hi; lim_mg = m.lim_rec[l12_].margin; } while (0)
+#define GQ_FETCH_FLR() do { flr_dof = m.fl_row[l18_].dof; flr_R = m.fl_row[l18_].R; flr_B = m.fl_row[l18_].B; flr_floss = m.fl_row[l18_].floss; } while (0)
+#define GQ_FETCH_HENT() do { if constexpr (SOLVER == 1) { hent_pre[0] = m.newton_hent[0][lane]; hent_pre[1] = m.newton_hent[1][lane]; } else { hent_pre[0] = hent_pre[1] = 0; } } while (0)
+  int lim_on = 0, flr_dof = 0, hent_pre[2] = {0, 0};
+  float lim_lo_ = 0.0f, lim_hi_ = 0.0f, lim_mg = 0.0f, flr_R = 0.0f, flr_B = 0.0f, flr_floss = 0.0f;
+  if constexpr (EARLY) { GQ_FETCH_LIM(); GQ_FETCH_FLR(); GQ_FETCH_HENT(); }
+  /* (the late fetches go through closures: the same statements written in line left the elliptic variants with 60 instead of 48 bytes of scratch -
+   * the register allocator's outcome on these kernels is that sensitive; the pyramidal variants keep the in-line form they were tuned with) */
+  auto fetch_lim = [&]() { GQ_FETCH_LIM(); };
+  auto fetch_flr = [&]() { GQ_FETCH_FLR(); };
+  auto fetch_hent = [&]() { GQ_FETCH_HENT(); };
   StepConsts K;
   {
     int fl0 = m.hot_foot_leg[0], fl1 = m.hot_foot_leg[1], fl2 = m.hot_foot_leg[2], fl3 = m.hot_foot_leg[3], its = m.iterations, nsp = m.hot_nsp, scut = m.hot_self_cut;
@@ -811,6 +821,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     /* joint limits: lane j < 12 owns hinge j (lower side first, then upper) */
     bool lim_lo = false, lim_hi = false;
     float dlo = 0.0f, dhi = 0.0f;
+    if constexpr (!EARLY) fetch_lim();
     {
       const float q = W.qj[lj];
       dlo = q - lim_lo_; dhi = lim_hi_ - q;
@@ -908,6 +919,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   float jsgn = 0.0f;
   bool jcon = false;
   V3 dir = v3(0.0f, 0.0f, 0.0f), w = v3(0.0f, 0.0f, 0.0f);
+  if constexpr (!EARLY) fetch_flr();
   if (lane < nfl) {
     rtype = ROW_FRICTION; rfloss = flr_floss; flR = flr_R; flB = flr_B;
     jd = flr_dof; jsgn = 1.0f;
@@ -1121,6 +1133,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     wave_barrier(); /* the J rows are in LDS (S7, over the dead u.dyn) for the Hessian assembly */
     GQ_TICK(8);
     const EllRow ell = {ecode, er0, efri, emu, fast_rcp(eR0)};
+    if constexpr (!EARLY) fetch_hent();
     /* a contact between two different legs couples them in the Hessian M + J'DJ, which then no longer has M's tree
      * sparsity: such an env takes the dense Newton step */
     const bool xrow = SELF && internal && jleg1 >= 0 && jleg >= 0 && jleg1 != jleg && K.self_cut != 3;
@@ -1306,8 +1319,10 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   int omap[4], s3k[3];
 #pragma unroll
   for (int i = 0; i < 4; i++) { const int k = lane + GQ_WAVE * i; omap[i] = k < od ? Bt.obs_map[k] : 0; }
+  int lane_s3 = lane;
+  if constexpr (CONE) opaque(lane_s3); /* (a fresh load through an opaque index: otherwise S3's copy of the same words is kept - in scratch memory - across the solver) */
 #pragma unroll
-  for (int p = 0; p < 3; p++) s3k[p] = (SOLVER == 1 && (obs_need & GQ_NEED_ENERGY)) ? m.s3_ent[p][lane] : 0; /* the energy sums walk M's stored entries */
+  for (int p = 0; p < 3; p++) s3k[p] = (SOLVER == 1 && (obs_need & GQ_NEED_ENERGY)) ? m.s3_ent[p][lane_s3] : 0; /* the energy sums walk M's stored entries */
   /* IMU ground truth (mj_sensorAcc / mj_sensorVel of this forward pass: OLD pose and velocity, this step's qacc).
    * accelerometer = site-frame acceleration of the site point minus gravity; gyro = site-frame angular velocity */
   const bool imu_on = e_imu_bias != nullptr && imu_en;
@@ -1429,7 +1444,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
       const float* M0 = &W.Mc[0][0];
 #pragma unroll
       for (int p = 0; p < 3; p++) {
-        const int ent = s3k[p], dd = ent & 0xff, sa = (ent >> 8) & 0xff, e = lane + GQ_WAVE * p;
+        const int ent = s3k[p], dd = ent & 0xff, sa = (ent >> 8) & 0xff, e = lane_s3 + GQ_WAVE * p; /* (opaque in the elliptic variants: S3's copy of this address was kept in scratch) */
         const bool counts = (p < 2 || lane < 144 - 2 * GQ_WAVE) && (ent >> 24) != 0; /* (the table's slots past entry 143 repeat it) */
         const float coef = counts ? ((p < 2 && (p == 0 || lane < 108 - GQ_WAVE) && dd != sa) ? 1.0f : 0.5f) : 0.0f;
         ke_part += coef * M0[e < 143 ? e : 143] * W.qvel[dd] * W.qvel[sa];
