@@ -1036,9 +1036,11 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
      * does not lower the cost (3 % of the iterations) the safeguarded search below runs as before. */
     float dphi = 0.0f; /* phi(1) - phi(0) when the unit step was taken on that evidence */
     bool unit_step = false;
-    /* (elliptic models keep the search: the rule holds for any convex cost - 89 % / 82 % of the iterations of go2 / hyqreal1 in the fp64
-     * restatement - but in fp32 the stiff cone rows (impratio 100) make the sign of a small cost difference noise: tried, the iteration counts
-     * rose by 25 % in the emulator and the go2 benchmark fell from 26.0 to 8.6 M with the extra registers spilled) */
+    /* (elliptic models keep the search.  The rule holds for any convex cost - the unit step lowers it in 89 % / 82 % of the iterations of go2 /
+     * hyqreal1 in the fp64 restatement - and it was tried twice: as here (go2 26.0 -> 8.6 M: fp32 noise in the sign of small cost differences of
+     * the stiff cone rows, and the extra registers spilled), and as an Armijo test phi(1) - phi(0) <= 1e-4 phi'(0) riding as a fourth reduction
+     * in the search's first pass (mean solver time -8 %, but the iteration histogram grows a tail - 16 instead of 12 iterations at the end,
+     * three times as many envs at 8 - 11 - and the launch lasts as long as its slowest wave: go2 27.2 -> 24.0 M, hyqreal1 31.1 -> 29.1 M)) */
     if constexpr (!CONE) if (!full_step) { /* wave-uniform */
       const float dc = row_cost(rtype, y + v, rR, rD, rfloss) - row_cost(rtype, y, rR, rD, rfloss);
       dphi = wave_sum(p1 + 0.5f * p2 + dc);
