@@ -750,9 +750,9 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
     const int slot = (hent[pass] >> 16) & 0xff;
     hbase[pass] = (&W.Mc[0][0])[slot];
   }
-  long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = (DBG && tdbg) ? cycles() : 0;
+  uint32_t tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = (DBG && tdbg) ? (uint32_t)cycles() : 0u; /* (32-bit: wave-uniform counters of the instrumented variant, half the registers) */
   if constexpr (DBG) if (tdbg && lane == 0) { tdbg[29] = 0.0f; tdbg[30] = 0.0f; } /* line-search trials, full-step shortcuts */
-#define NW_T(i) do { if constexpr (DBG) if (tdbg) { const long long tn = cycles(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+#define NW_T(i) do { if constexpr (DBG) if (tdbg) { const uint32_t tn = (uint32_t)cycles(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
   NW_T(0);
   /* residual y = J qacc - aref and Ma-terms are evaluated once, then advanced incrementally along the search
    * direction (y += alpha J s, M dq += alpha M s), as mj_solNewton does */
