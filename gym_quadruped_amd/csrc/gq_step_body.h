@@ -1664,6 +1664,9 @@ enum { RN_QPOS = 0, RN_QVEL = 12, RN_X = 24, RN_Y = 25, RN_ROLL = 26, RN_PITCH =
        RN_YAWDOT = 30, RN_FRICTION = 31, RN_VEL_INTERVAL = 32 };
 
 #define GQ_LIFT_RULE_ITERS 4
+#ifndef GQ_LIFT_CAP
+#define GQ_LIFT_CAP 100 /* iteration cap of the lift loop (the reference raises RuntimeError at 100); development builds lower it to measure what the loop costs */
+#endif
 template <bool BOXES, bool PRIM = true, bool PUB = false>
 __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const int env0 = 0) {
   int lane_o = lane_id(), env_o = wave_index() + uniform(env0);
@@ -1766,7 +1769,7 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
       V3 calf_c; float calf_r;
       item_sphere(W, m, true, calf_c, calf_r);
       const PrimLane PLL = prim_lane(W, m, item_fetch(m, lane < 4 + m.nlg ? lane : 0), PRIM && lane < 4 + m.nlg, PRIM); /* lane = position in con_order, as box_item_scan expects */
-      for (int it = 0; it <= 100; it++) {
+      for (int it = 0; it <= GQ_LIFT_CAP; it++) {
         float pen = floor_pen(dz);
         float clear = 0.0f; /* lift that takes the touching item above the box altogether */
         uint64_t cand[2];
@@ -1811,7 +1814,7 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
         }
         pen = wave_max(pen);
         failed = pen > 0.0f;
-        if (!failed || it == 100) break;
+        if (!failed || it == GQ_LIFT_CAP) break;
 #ifdef GQ_EMU_TRACE
         if (lane == 0 && getenv("GQ_EMU_TRACE")) printf("lift it %d dz %.4f pen %.5f cand %d\n", it, (double)dz, (double)pen, popc64(cand[0]) + popc64(cand[1]));
 #endif
