@@ -645,7 +645,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   const int l12_ = lane < GQ_NJ ? lane : GQ_NJ - 1, l18_ = lane < GQ_NVD ? lane : GQ_NVD - 1;
   /* (elliptic variants fetch these where they are used: their solver needs the registers, and what is prefetched here was spilled to scratch
    * memory on the way - 92 bytes per lane after the early-fetch rework of round 5, 28 before it) */
-  constexpr bool EARLY = !CONE;
+  constexpr bool EARLY = !CONE && !(BOXES && PRIM); /* (the world-geom variants of the primitive-geom robots: 44 bytes of scratch with the early fetch, see below) */
 #define GQ_FETCH_LIM() do { lim_on = m.lim_rec[l12_].limited; lim_lo_ = m.lim_rec[l12_].lo; lim_hi_ = m.lim_rec[l12_].hi; lim_mg = m.lim_rec[l12_].margin; } while (0)
 #define GQ_FETCH_FLR() do { flr_dof = m.fl_row[l18_].dof; flr_R = m.fl_row[l18_].R; flr_B = m.fl_row[l18_].B; flr_floss = m.fl_row[l18_].floss; } while (0)
 #define GQ_FETCH_HENT() do { if constexpr (SOLVER == 1) { hent_pre[0] = m.newton_hent[0][lane]; hent_pre[1] = m.newton_hent[1][lane]; } else { hent_pre[0] = hent_pre[1] = 0; } } while (0)
@@ -1139,7 +1139,9 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
     const bool xrow = SELF && internal && jleg1 >= 0 && jleg >= 0 && jleg1 != jleg && K.self_cut != 3;
     const bool xleg = SELF && ballot(xrow) != 0;
     if constexpr (DBG && SELF) if (timing && lane == 0) call.debug[(size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER + 31] = (float)(uniform(W.nself) + (xleg ? 100 : 0));
-    const float fN = newton_solve<DBG, CONE>(W, K, Drec.fl_row, hent_pre, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
+    int fl_row_nw = Drec.fl_row;
+    if constexpr (!EARLY) { int l_ = ld; opaque(l_); fl_row_nw = m.dof_rec[l_].fl_row; } /* (a fresh load instead of a register kept - spilled - since the kernel's first lines) */
+    const float fN = newton_solve<DBG, CONE>(W, K, fl_row_nw, hent_pre, rtype, rR, raref, rfloss, nefc, nfl, nfl + nlim, iter,
                                   timing ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_TIMER : nullptr, ell, prio_hint, xrow,
                                   xleg ? uniform(W.con_row[ncon - uniform(W.nself)]) : -1);
     /* a coupled-leg Newton step (Sherman-Morrison / dense) is the most expensive thing a wave can do, and leg-leg contacts
@@ -1320,7 +1322,7 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
 #pragma unroll
   for (int i = 0; i < 4; i++) { const int k = lane + GQ_WAVE * i; omap[i] = k < od ? Bt.obs_map[k] : 0; }
   int lane_s3 = lane;
-  if constexpr (CONE) opaque(lane_s3); /* (a fresh load through an opaque index: otherwise S3's copy of the same words is kept - in scratch memory - across the solver) */
+  if constexpr (!EARLY) opaque(lane_s3); /* (a fresh load through an opaque index: otherwise S3's copy of the same words is kept - in scratch memory - across the solver) */
 #pragma unroll
   for (int p = 0; p < 3; p++) s3k[p] = (SOLVER == 1 && (obs_need & GQ_NEED_ENERGY)) ? m.s3_ent[p][lane_s3] : 0; /* the energy sums walk M's stored entries */
   /* IMU ground truth (mj_sensorAcc / mj_sensorVel of this forward pass: OLD pose and velocity, this step's qacc).
