@@ -352,7 +352,9 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline() if world == 1 else cpu_baseline(seconds_budget=10.0, all_cores=False)
     dist = None
-    if world > 1:
+    # GQ_BENCH_FORCE_DIST=1 (tests/test_gpu_boundary.py): a ONE-rank torchrun launch also goes through the process-group path - the RCCL
+    # initialisation, the barriers around the timed region and the MAX all-reduce of the N > 1 protocol - on a one-GPU box
+    if world > 1 or os.environ.get('GQ_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')

@@ -240,3 +240,20 @@ def test_integration_stub_runs():
     assert ns['D'] == 73 and bool(torch.isfinite(ns['obs']).all()) and bool(torch.isfinite(ns['qpos']).all())
     assert int(ns['step_num'].min()) >= 1 and float(ns['qpos'][:, 2].min()) > 0.0 and not bool(ns['lift_failed'].any())
     assert float(ns['obs'][:, 37:49].abs().max()) > 1.0   # tau_ctrl_setpoint columns carry the 50 * N(0, 1) torques (clamped to ctrlrange)
+
+
+def test_bench_process_group_path_initialises_rccl_on_one_rank():
+    """bench.py's N > 1 protocol - init_process_group('nccl') = RCCL, barrier + synchronize around the timed region, MAX all-reduce of
+    the ranks' times, destroy - executed with ONE rank under torch.distributed.run (the boxes this suite runs on have one GPU; the
+    two-rank form of the same protocol runs on gloo in tests/test_sharding_gloo.py): the line it prints is a valid bench line."""
+    import json, os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, GQ_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29541',
+                        str(root / 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-secondary'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['steps'] == 20 and d['scaling'] == 'weak' and d['value'] > 1e7 and d['config']['state_finite']
