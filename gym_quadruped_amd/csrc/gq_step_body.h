@@ -1726,6 +1726,9 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
   wave_barrier();
   float dz = 0.0f;
   int failed = 0;
+#ifdef GQ_RESET_STAMPS /* development probe (tools/reset_probe.py): cycle stamps of this function, left in the env's qfrc_applied row */
+  const long long rs_t0 = cycles(); long long rs_t1 = rs_t0, rs_t2 = rs_t0; int rs_iters = 0, rs_scans = 0, rs_cand = 0;
+#endif
   /* scenes without world boxes / height field: the lift loop runs inside the reset's own mj_step (step_wave, S6) on that
    * step's kinematics and collision scan - this function only writes the spawn state and says that a lift is due */
   const bool flat_scene = !BOXES || (m.nbox == 0 && m.hf_nrow == 0); /* BOXES variants also serve flat scenes with robot self-collision */
@@ -1770,12 +1773,18 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
        * every box still touched (boxes are convex: the pose above them is free) - a handful of scans instead of 100. */
       V3 calf_c; float calf_r;
       item_sphere(W, m, true, calf_c, calf_r);
+#ifdef GQ_RESET_STAMPS
+      rs_t1 = cycles();
+#endif
       const PrimLane PLL = prim_lane(W, m, item_fetch(m, lane < 4 + m.nlg ? lane : 0), PRIM && lane < 4 + m.nlg, PRIM); /* lane = position in con_order, as box_item_scan expects */
       for (int it = 0; it <= GQ_LIFT_CAP; it++) {
         float pen = floor_pen(dz);
         float clear = 0.0f; /* lift that takes the touching item above the box altogether */
         uint64_t cand[2];
         box_candidates(W, m, spawn_x, spawn_y, dz, cand, calf_c, calf_r); /* around the lifted base; calf items only */
+#ifdef GQ_RESET_STAMPS
+        rs_iters++; rs_cand = imax(rs_cand, popc64(cand[0]) + popc64(cand[1])); rs_scans += popc64(cand[0]) + popc64(cand[1]);
+#endif
         for (int half = 0; half < 2; half++) {
           uint64_t todo = cand[half];
           while (todo) { /* wave-uniform */
@@ -1824,6 +1833,9 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
       }
     }
   }
+#ifdef GQ_RESET_STAMPS
+  rs_t2 = cycles();
+#endif
   if (lane < 19) gptr(a.qpos)[(size_t)env * 19 + lane] = lane == 2 ? q + (double)dz : q;
   if (lane < 18) {
     gptr(a.qvel)[(size_t)env * 18 + lane] = qv;
@@ -1831,6 +1843,10 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
     gptr(a.warm)[(size_t)env * 18 + lane] = 0.0f;
     if (a.applied) gptr(a.applied)[(size_t)env * 18 + lane] = 0.0f;
   }
+#ifdef GQ_RESET_STAMPS
+  if (lane == 0 && a.applied) { GQ_GLOBAL float* S = gptr(a.applied) + (size_t)env * 18 + 6;
+    S[0] = 1e-9f * (float)(rs_t1 - rs_t0); S[1] = 1e-9f * (float)(rs_t2 - rs_t1); S[2] = 1e-9f * (float)rs_iters; S[3] = 1e-9f * (float)rs_scans; S[4] = 1e-9f * (float)rs_cand; }
+#endif
   if (lane == 0) {
     gptr(a.time)[env] = 0.0f;
     gptr(a.step_num)[env] = -1; /* the reset's own mj_step brings it to 0 (:332, :397) */
