@@ -312,6 +312,22 @@ __device__ inline V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c, bool& interior)
 }
 /* sphere (centre p relative to the reference corner, radius r) against the height field: signed distance, normal,
  * false if nothing within `reach` of the surface.  Triangles of the cells under the sphere's footprint (+ reach) are visited. */
+/* one triangle of the scan below: the sphere's signed distance to it and the normal, false if the triangle has no say */
+__device__ __forceinline__ bool sphere_hf_triangle(const GQ_MODEL GqDevModel& m, const GQ_MODEL float* H, HfRef ref, V3 p, float r, int cc, int rr, int up, float& dd, V3& nn) {
+  HfTri t;
+  if (!hf_cell_triangle(m, H, ref, cc, rr, up, t)) return false;
+  const float side = dot(p - t.a, t.n);
+  bool inside;
+  const V3 q = closest_on_triangle(p, t.a, t.b, t.c, inside);
+  if (inside) { dd = side - r; nn = t.n; return true; } /* over (or under) the face: distance along its normal, whatever the sign */
+  if (side < 0.0f) return false;                        /* below the plane and outside the column: a neighbour's business */
+  const V3 d = p - q;
+  const float l2 = dot(d, d);
+  if (!(l2 > 1e-12f)) return false;
+  const float inv = fast_rsqrt(l2);
+  dd = l2 * inv - r; nn = inv * d;
+  return true;
+}
 __device__ inline bool sphere_hfield(const GQ_MODEL GqDevModel& m, const GQ_MODEL float* H, HfRef ref, V3 p, float r, float reach, float& dist, V3& n) {
   const float R = r + reach;
   const int c0 = (int)floorf((p.x - R) * m.hf_inv_dx), c1 = (int)floorf((p.x + R) * m.hf_inv_dx);
@@ -320,22 +336,8 @@ __device__ inline bool sphere_hfield(const GQ_MODEL GqDevModel& m, const GQ_MODE
   for (int rr = r0; rr <= r1; rr++)
     for (int cc = c0; cc <= c1; cc++)
       for (int up = 0; up < 2; up++) {
-        HfTri t;
-        if (!hf_cell_triangle(m, H, ref, cc, rr, up, t)) continue;
-        const float side = dot(p - t.a, t.n);
-        bool inside;
-        const V3 q = closest_on_triangle(p, t.a, t.b, t.c, inside);
         float dd; V3 nn;
-        if (inside) { dd = side - r; nn = t.n; } /* over (or under) the face: distance along its normal, whatever the sign */
-        else {
-          if (side < 0.0f) continue;             /* below the plane and outside the column: a neighbour's business */
-          const V3 d = p - q;
-          const float l2 = dot(d, d);
-          if (!(l2 > 1e-12f)) continue;
-          const float inv = fast_rsqrt(l2);
-          dd = l2 * inv - r; nn = inv * d;
-        }
-        if (dd < dist) { dist = dd; n = nn; }
+        if (sphere_hf_triangle(m, H, ref, p, r, cc, rr, up, dd, nn) && dd < dist) { dist = dd; n = nn; }
       }
   return dist < reach;
 }
@@ -353,26 +355,23 @@ __device__ inline bool hfield_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m
                    (float)((double)m.hf_pos[1] - (double)m.hf_sy + (double)ref.rb * (double)m.hf_dy - by), m.hf_pos[2] - zoff);
   const int nlg = m.nlg, cls = m.hf_cls;
   /* phase A, lane = link geom / foot: bounding sphere above the surface?  (surface within rho of a point rises at most maxslope * rho) */
-  bool needs = false, foot_near = false;
-  if (lane < nlg && rg >= 0.0f) {
-    const V3 cl = cg - hp;
+  /* (lanes 60-63 take the feet - GQ_MAXLG < 60 -: ONE pass through the elevation loads for geoms and feet - they were two, a memory round trip each) */
+  bool needs = false;
+  {
+    const bool isfoot = lane >= 60, isgeom = lane < nlg && rg >= 0.0f;
+    const int fk = isfoot ? lane - 60 : 0;
+    const V3 cl = (isfoot ? ld3(W.foot_world[fk]) : cg) - hp;
+    const float rb = isfoot ? m.foot_radius[fk] : rg;
     HfTri t;
-    if (hf_triangle_under(m, H, ref, cl.x, cl.y, t)) {
+    if ((isfoot || isgeom) && hf_triangle_under(m, H, ref, cl.x, cl.y, t)) {
       const float hc = t.a.z - (t.n.x * (cl.x - t.a.x) + t.n.y * (cl.y - t.a.y)) / t.n.z;
-      needs = cl.z - rg - (hc + m.hf_maxslope * rg) < m.boxmix[cls][4 + lane].margin;
+      needs = cl.z - rb - (hc + m.hf_maxslope * rb) < m.boxmix[cls][isfoot ? fk : 4 + lane].margin;
     }
   }
   if (lane < nlg && !needs) W.u2.c.lg_dist[lane] = 1e30f;
-  if (lane < 4) {
-    const V3 cl = ld3(W.foot_world[lane]) - hp;
-    HfTri t;
-    if (hf_triangle_under(m, H, ref, cl.x, cl.y, t)) {
-      const float hc = t.a.z - (t.n.x * (cl.x - t.a.x) + t.n.y * (cl.y - t.a.y)) / t.n.z, rf = m.foot_radius[lane];
-      foot_near = cl.z - rf - (hc + m.hf_maxslope * rf) < m.boxmix[cls][lane].margin;
-    }
-  }
-  uint64_t todo = ballot(needs);
-  const uint64_t feet = ballot(foot_near);
+  const uint64_t near_all = ballot(needs);
+  uint64_t todo = near_all & ((1ull << 60) - 1ull);
+  const uint64_t feet = near_all >> 60;
   dist = 1e30f; nrm = v3(0.0f, 0.0f, 1.0f); pt = v3(0.0f, 0.0f, 0.0f);
   if ((todo | feet) == 0) return false;
   if (m.self_cut == 10) return false; /* profiling aid (GQ_SELF_CUT): 10 stop after the bounding tests, 11 no flattened pass, 12 no serial scans, 13 no foot narrow phase */
@@ -463,11 +462,51 @@ __device__ inline bool hfield_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m
     }
   }
   wave_barrier();
+  /* the feet: a sphere against the triangles of the cells under its footprint (sphere_hfield).  A footprint of a few centimetres on cells of
+   * tens of centimetres covers one cell, two or four when it straddles a grid line: lane = (foot, cell of the 2 x 2 block, triangle) evaluates
+   * the <= 8 triangles of every near foot at once - one pass through the elevation loads instead of up to eight dependent ones on the foot's lane,
+   * which all four feet walked in lockstep (the longest footprint set the trip count) - and the foot takes the first of the nearest in the
+   * serial scan's order (rows, columns, lower / upper triangle).  A footprint over more than 2 x 2 cells (a fine grid): the serial scan. */
+  bool feet_par = false;
+  float fdd = 1e30f;
+  V3 fnn = v3(0.0f, 0.0f, 1.0f);
+  if (feet != 0 && m.self_cut != 13) { /* wave-uniform */
+    const int fk = (lane >> 3) & 3, k = lane & 7;
+    const bool live = lane < 32 && ((feet >> fk) & 1ull);
+    const V3 p = ld3(W.foot_world[fk]) - hp;
+    const float r = m.foot_radius[fk], R = r + fmaxf(m.boxmix[cls][fk].margin, 0.0f) + 1e-4f;
+    const int c0 = (int)floorf((p.x - R) * m.hf_inv_dx), c1 = (int)floorf((p.x + R) * m.hf_inv_dx);
+    const int r0 = (int)floorf((p.y - R) * m.hf_inv_dy), r1 = (int)floorf((p.y + R) * m.hf_inv_dy);
+    feet_par = ballot(live && (c1 - c0 > 1 || r1 - r0 > 1)) == 0;
+    if (feet_par) {
+      const int cc = c0 + ((k >> 1) & 1), rr = r0 + ((k >> 2) & 1);
+      float dd; V3 nn;
+      if (live && cc <= c1 && rr <= r1 && sphere_hf_triangle(m, H, ref, p, r, cc, rr, k & 1, dd, nn)) { fdd = dd; fnn = nn; }
+      float* S = W.force; /* scratch, as in the flattened pass */
+      S[lane] = fdd;
+      wave_barrier();
+    }
+  }
   /* phase C, lane = collision item */
+  int src = lane;
+  float fbest = 1e30f;
+  const int code = lane < 4 + nlg ? (int)m.con_order[lane] : 4;
+  const bool myfoot = code < 4 && ((feet >> code) & 1ull) && m.self_cut != 13;
+  if (feet_par && myfoot) {
+    const float* S = W.force + 8 * code;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const float dk = S[k]; if (dk < fbest) { fbest = dk; src = 8 * code + k; } }
+  }
+  if (feet_par) { /* wave-uniform: the winner's normal */
+    const V3 n = v3(shfl_idx(fnn.x, src), shfl_idx(fnn.y, src), shfl_idx(fnn.z, src));
+    if (myfoot && fbest < fmaxf(m.boxmix[cls][code].margin, 0.0f) + 1e-4f) {
+      dist = fbest; nrm = n; pt = ld3(W.foot_world[code]) - (m.foot_radius[code] + 0.5f * fbest) * n;
+    }
+    wave_barrier(); /* W.force is scratch no longer */
+  }
   if (lane < 4 + nlg) {
-    const int code = m.con_order[lane];
     if (code < 4) {
-      if (((feet >> code) & 1) && m.self_cut != 13) {
+      if (myfoot && !feet_par) {
         V3 n; float d;
         if (sphere_hfield(m, H, ref, ld3(W.foot_world[code]) - hp, m.foot_radius[code], fmaxf(m.boxmix[cls][code].margin, 0.0f) + 1e-4f, d, n)) {
           dist = d; nrm = n; pt = ld3(W.foot_world[code]) - (m.foot_radius[code] + 0.5f * d) * n;

@@ -74,6 +74,13 @@ def stage_times(n=4096, iters=100, tol=1e-8, solver='newton', robot='mini_cheeta
             if sel.sum():
                 print(f'    {nm:32s}: {sel.sum():5d} waves, niter mean {nit[sel].mean():.2f} max {nit[sel].max():.0f}, nefc mean {ne[sel].mean():.1f}, total {T[sel, 13].mean():8.0f} cycles, '
                       f'S6b {(T[sel, 6] - T[sel, 14]).mean():6.0f} S7 {(T[sel, 7] - T[sel, 6]).mean():6.0f} solver {(T[sel, 9] - T[sel, 8]).mean():7.0f}; per iteration: hessian {T[sel, 19].sum() / nit[sel].sum():6.0f} solve {T[sel, 20].sum() / nit[sel].sum():6.0f}')
+        dn = T[:, 26] > 0
+        if dn.sum():   # dense steps: how many cross-leg rows were active (what a low-rank correction of the tree solve would have to carry)
+            kmax = T[dn, 24].astype(int)
+            print(f'    dense steps: {int(T[:, 26].sum())} in {dn.sum()} waves (+ {int(T[:, 27].sum())} Sherman-Morrison steps); active cross-leg rows in a dense step, '
+                  f'largest per wave: ' + ' '.join(f'{k}:{c}' for k, c in enumerate(np.bincount(kmax)) if c))
+            slow = np.argsort(-T[:, 13])[:64]
+            print('    among the 64 slowest waves: largest active cross-leg row count per wave ' + ' '.join(f'{k}:{c}' for k, c in enumerate(np.bincount(T[slow, 24].astype(int))) if c) + f'; dense steps {int(T[slow, 26].sum())}, SM steps {int(T[slow, 27].sum())}')
         for k in range(2, int(nit.max()) + 1):
             sel = nit == k
             if sel.sum():
