@@ -119,7 +119,7 @@ __device__ inline void item_sphere(const WaveMem& W, const GQ_MODEL GqDevModel& 
 /* PL: what is kept of the item record of lane `it` (prim_lane); H: the item's contact candidates with box b - one for a foot
  * sphere or a hull / cylinder cloud (its deepest inflated vertex), up to 2 / 4 for the robot's sphere / capsule / box geoms
  * (exact pair routines, gq_pairs.h).  PRIM false: the model has no such geom and the routines are not compiled in. */
-template <bool PRIM>
+template <bool PRIM, int BATCH = 2 /* chunks whose vertex loads go out together (below) */>
 __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, int b,
                                      double bx, double by, float zoff, V3 cg, float rg, const PrimLane& PL, PairHit& H) {
   float dist; V3 nrm, pt;
@@ -190,17 +190,28 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
       }
       chunks = ballot(keep);
     }
-    while (chunks) { /* wave-uniform */
-      const int v0 = GQ_WAVE * ffs64(chunks);
-      chunks &= chunks - 1;
-      const int i = G.cloud_adr + v0 + lane;
-      const bool in = v0 + lane < G.cloud_num;
-      const int ii = in ? i : G.cloud_adr;
-      const V3 v = v3(vx[ii], vy[ii], vz[ii]);
-      const V3 c = t + matvec(A, v);
-      V3 n;
-      const float dv = sphere_box(c, bs, G.radius, n);
-      if (in && dv < best) { best = dv; bn = n; bc = c; }
+    while (chunks) { /* wave-uniform: the vertex loads of up to BATCH chunks go out together - one memory round trip, not one per chunk (two:
+                      * hyqreal1 random_boxes 24.5 -> 25.0 M, three or four: 24.9 / 24.7; the pyramidal hull robots keep one - mini_cheetah
+                      * random_boxes 30.9 against 30.7 with two) */
+      int v0[BATCH];
+      V3 vv[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; u++) { v0[u] = chunks ? GQ_WAVE * ffs64(chunks) : -1; chunks &= chunks - 1; }
+#pragma unroll
+      for (int u = 0; u < BATCH; u++)
+        if (v0[u] >= 0) { /* wave-uniform */
+          const int ii = v0[u] + lane < G.cloud_num ? G.cloud_adr + v0[u] + lane : G.cloud_adr;
+          vv[u] = v3(vx[ii], vy[ii], vz[ii]);
+        }
+#pragma unroll
+      for (int u = 0; u < BATCH; u++)
+        if (v0[u] >= 0) {
+          const bool in = v0[u] + lane < G.cloud_num;
+          const V3 c = t + matvec(A, vv[u]);
+          V3 n;
+          const float dv = sphere_box(c, bs, G.radius, n);
+          if (in && dv < best) { best = dv; bn = n; bc = c; }
+        }
     }
     const float wmin = wave_min(best);
     const int who = ffs64(ballot(best == wmin));
@@ -914,7 +925,7 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
       PairHit H;
       const float* sph = GQ_BX_ISPH(W) + 4 * opaque_lane(lane < GQ_MAXLG ? lane : 0);
       const V3 cg = ld3(sph); const float rg = sph[3];
-      if (!box_item_scan<PRIM>(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, PL, H)) continue;
+      if (!box_item_scan<PRIM, CONE ? 2 : 1>(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, PL, H)) continue;
       append_world_contacts<CONE, PRIM>(W, m, m.box[b].cls, mu_env, H, S);
       wave_barrier();
     }
