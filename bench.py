@@ -170,14 +170,20 @@ def config_line(QuadrupedEnv, robot, scene, n, device, pool, imu=False, heightma
     hm = None
     if heightmap:
         from gym_quadruped_amd.sensors import HeightMap
-        hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)
+        # the map follows the base (what examples/aliengo_with_heightmap.py does by hand after every step): the step kernel casts the rays
+        # (gq_batch_set_heightmap); GQ_BENCH_HM_SEPARATE=1 measures the separate ray kernel behind every step instead
+        hm_follow = scene != 'flat' and os.environ.get('GQ_BENCH_HM_SEPARATE', '0') != '1'
+        hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env, follow_base=hm_follow)
         yaw0 = torch.zeros(n, device=device)
 
     def one(i, ev=None):
         env._profile_events = ev
         o = env.step(pool[i % 64])[0]
         if hm is not None:
-            hm.update_height_map(env.qpos[:, 0:3], yaw=o['base_ori_euler_xyz'][:, 2] if 'base_ori_euler_xyz' in o else yaw0)
+            if hm.follow_base:
+                hm.update_height_map()
+            else:
+                hm.update_height_map(env.qpos[:, 0:3], yaw=o['base_ori_euler_xyz'][:, 2] if 'base_ori_euler_xyz' in o else yaw0)
     for i in range(warmup):
         one(i)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % EVENT_STRIDE == 0 else None for i in range(steps)]
@@ -194,7 +200,7 @@ def config_line(QuadrupedEnv, robot, scene, n, device, pool, imu=False, heightma
     out = {'value': n * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': warmup, 'kernel_ms': kernel_ms,
            'obs_dim': env._obs_dim, 'bytes_per_env_step': b, 'achieved_gbs': n * b / (kernel_ms * 1e-3) / 1e9,
            'frac': n * b / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           'workload': f'{robot} {scene}, {n} envs, ALL_OBS' + (' + IMU (6 observables)' if imu else '') + (' + 5x5 HeightMap every step (its ray kernel is inside ms_per_step, not kernel_ms)' if heightmap else '')
+           'workload': f'{robot} {scene}, {n} envs, ALL_OBS' + (' + IMU (6 observables)' if imu else '') + ((' + 5x5 HeightMap that follows the base, its rays cast by the step kernel every step' if hm.follow_base else ' + 5x5 HeightMap every step (its ray kernel is inside ms_per_step, not kernel_ms)') if heightmap else '')
                        + ', newton <=100 it tol 1e-8, self-collision on, auto-reset next_step',
            'state_finite': bool(torch.isfinite(env.qpos).all() and torch.isfinite(env.qvel).all()), 'setup_s': t_build}
     env.close()
@@ -411,8 +417,15 @@ def main():
     hm = None
     if args.heightmap:   # examples/aliengo_with_heightmap.py:25
         from gym_quadruped_amd.sensors import HeightMap
-        hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env)
+        hm_follow = args.scene != 'flat' and os.environ.get('GQ_BENCH_HM_SEPARATE', '0') != '1'   # (see config_line)
+        hm = HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=env.mjModel, mj_data=env, follow_base=hm_follow)
         yaw0 = torch.zeros(n, device=device)
+
+    def update_hm(o_i):
+        if hm.follow_base:
+            hm.update_height_map()
+        else:
+            hm.update_height_map(env.qpos[:, 0:3], yaw=o_i['base_ori_euler_xyz'][:, 2] if 'base_ori_euler_xyz' in o_i else yaw0)
     for i in range(args.warmup):
         env.step(pool[i % 64])
     # timed region: exactly K steps bracketed by barrier + synchronize
@@ -428,7 +441,7 @@ def main():
         env._profile_events = ev[i]  # HIP events around the step-kernel launch on the launch stream
         o_i = env.step(pool[i % 64])[0]
         if hm is not None:
-            hm.update_height_map(env.qpos[:, 0:3], yaw=o_i['base_ori_euler_xyz'][:, 2] if 'base_ori_euler_xyz' in o_i else yaw0)
+            update_hm(o_i)
     env._profile_events = None
     barrier()
     dt = time.perf_counter() - t0
@@ -447,7 +460,7 @@ def main():
         for i in range(STEADY_STEPS):
             o_i = env.step(pool[i % 64])[0]
             if hm is not None:
-                hm.update_height_map(env.qpos[:, 0:3], yaw=o_i['base_ori_euler_xyz'][:, 2] if 'base_ori_euler_xyz' in o_i else yaw0)
+                update_hm(o_i)
         barrier()
         dts = time.perf_counter() - t1
         if dist is not None:
@@ -480,7 +493,7 @@ def main():
             'config': {'workload': f'{args.robot} {args.scene}, {n} envs/GPU, random-action rollout (50*N(0,1) torques), '
                                    f'{"ALL_OBS" if args.obs == "all" else "_DEFAULT_OBS"} ({env._obs_dim} scalars), '
                                    f'auto-reset on termination ({env.auto_reset_mode}), sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8, robot self-collision {"off" if args.no_self_collision or args.solver == "pgs" else "on"}'
-                                   + (', IMU plug-in' if args.imu else '') + (', 5x5 HeightMap every step' if args.heightmap else ''),
+                                   + (', IMU plug-in' if args.imu else '') + ((', 5x5 HeightMap following the base (rays cast by the step kernel)' if hm.follow_base else ', 5x5 HeightMap every step') if args.heightmap else ''),
                        'envs_per_gpu': n, 'total_envs': total_envs, 'parallelism': f'env-shards x{world} (no collectives)',
                        'state_finite': finite},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

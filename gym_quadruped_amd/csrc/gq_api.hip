@@ -79,6 +79,7 @@ struct GqBatch {
   bool batch_dirty;
   bool shadow_valid;
   float* imu_bias;      /* caller-owned device [N][6], set by gq_batch_set_imu */
+  float* heightmap;     /* caller-owned device [N][rows * cols][3], set by gq_batch_set_heightmap (NULL: off) */
   hipStream_t shard_stream[8]; hipEvent_t shard_event[8]; hipEvent_t fork_event; int n_shard_streams; /* gq_rollout */
   int32_t* h9;          /* caller-owned device [N][6] resampling counters, set by gq_batch_set_resampling */
   float* ext_dist;      /* caller-owned device [N][6] */
@@ -237,6 +238,17 @@ int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state) {
   return GQ_OK;
 }
 
+int gq_batch_set_heightmap(GqBatch* b, int rows, int cols, float dist_x, float dist_y, float* out) {
+  if (!b) { SET_ERR("gq_batch_set_heightmap: null batch"); return GQ_EINVAL; }
+  if (!out) { b->heightmap = nullptr; b->host.hm_rows = b->host.hm_cols = 0; b->batch_dirty = true; return GQ_OK; }
+  if (rows <= 0 || cols <= 0 || rows * cols > 4096 || !(dist_x > 0.0f) || !(dist_y > 0.0f)) { SET_ERR("gq_batch_set_heightmap: bad grid (%d x %d cells of %g x %g m)", rows, cols, (double)dist_x, (double)dist_y); return GQ_EINVAL; }
+  if (scene_variant(b->model) == 0) { SET_ERR("gq_batch_set_heightmap: the scene has no world boxes / height field - every ray ends on the floor plane; use gq_heightmap"); return GQ_EINVAL; }
+  b->heightmap = out;
+  b->host.hm_rows = rows; b->host.hm_cols = cols; b->host.hm_dx = dist_x; b->host.hm_dy = dist_y;
+  b->batch_dirty = true; /* uploaded by the next launch, stream-ordered (ensure_args) */
+  return GQ_OK;
+}
+
 int gq_batch_set_resampling(GqBatch* b, const GqResampleCfg* cfg, const GqResetCfg* cmd_cfg, int32_t* counters, float* ext_dist) {
   if (!b) { SET_ERR("gq_batch_set_resampling: null batch"); return GQ_EINVAL; }
   GqDevBatch& h = b->host;
@@ -306,7 +318,7 @@ static void fill_step_args(gq::StepArgs* a, GqBatch* b, const GqState& st, const
   a->qpos = st.qpos; a->qvel = st.qvel; a->qacc = st.qacc; a->warm = st.qacc_warmstart;
   a->applied = st.qfrc_applied; a->time = st.time; a->friction = st.friction; a->cmd = st.cmd;
   a->friction_next = b->friction_next; a->pending = b->pending; a->load_hint = b->load_hint;
-  a->imu_bias = b->imu_bias;
+  a->imu_bias = b->imu_bias; a->heightmap = b->heightmap;
   a->h9 = b->h9; a->ext_dist = b->ext_dist;
   a->dyn = b->dyn_out; a->contacts = b->con_out;
   a->lift_failed = lift_failed; a->lift_pending = b->lift_pending;

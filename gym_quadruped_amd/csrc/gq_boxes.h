@@ -26,6 +26,10 @@ namespace gq {
 /* bounding spheres of the link geoms' clouds (item_sphere), [GQ_MAXLG][4]: parked in the (idle until S7) J block behind the region the
  * kinematics scratch and the self-collision tables use, and re-read per world box - four registers less across the box loop */
 #define GQ_BX_ISPH(W) (&(W).u.B[40][0])
+/* oriented bounding boxes of the link geoms' clouds in kernel coordinates, [GQ_MAXLG][GQ_BX_OBBW]: centre, the three half-axis vectors, the geom's
+ * radius (stage_box_contacts writes them once per step; rows 0 - 27 of the J block, free until the self-collision pass behind the box loop) */
+#define GQ_BX_OBBW 13
+#define GQ_BX_OBB(W) (&(W).u.B[0][0])
 
 /* sphere of radius r centred at c (box frame) against a box of half extents s: signed distance, outward normal n (box frame) */
 __device__ __forceinline__ float sphere_box(V3 c, V3 s, float r, V3& n) {
@@ -98,6 +102,26 @@ __device__ inline void box_candidates(const WaveMem& W, const GQ_MODEL GqDevMode
   }
 }
 
+/* oriented bounding box of link geom `lane`'s cloud (geom-frame AABB) in kernel coordinates -> GQ_BX_OBB (box independent: once per step / reset;
+ * the caller's barrier comes before the first box_item_scan<.., OBB = true>) */
+__device__ inline void item_obb_store(WaveMem& W, const GQ_MODEL GqDevModel& m) {
+  const int lane = lane_id();
+  if (lane < m.nlg) {
+    const GQ_MODEL GqDevGeom& G = m.lg[lane];
+    const float* Rb = W.xmat[G.body];
+    float RbRg[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) RbRg[3 * i + j] = Rb[3 * i] * G.mat[j] + Rb[3 * i + 1] * G.mat[3 + j] + Rb[3 * i + 2] * G.mat[6 + j];
+    float* O = GQ_BX_OBB(W) + GQ_BX_OBBW * lane;
+    st3(O, ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos)) + matvec(RbRg, ld3(G.aabb_c)));
+#pragma unroll
+    for (int j = 0; j < 3; j++) st3(O + 3 + 3 * j, G.aabb_h[j] * v3(RbRg[j], RbRg[3 + j], RbRg[6 + j]));
+    O[12] = G.radius;
+  }
+}
+
 /* Collision items against box b (wave-uniform): after the call lane `it` (position in con_order) holds the signed distance,
  * world normal and contact point (midway between the surfaces) of its item; false (and no barrier) when nothing is near.
  * (cg, rg): item_sphere of the lane's link geom.  zoff: extra height of the robot (lift loop). */
@@ -119,7 +143,7 @@ __device__ inline void item_sphere(const WaveMem& W, const GQ_MODEL GqDevModel& 
 /* PL: what is kept of the item record of lane `it` (prim_lane); H: the item's contact candidates with box b - one for a foot
  * sphere or a hull / cylinder cloud (its deepest inflated vertex), up to 2 / 4 for the robot's sphere / capsule / box geoms
  * (exact pair routines, gq_pairs.h).  PRIM false: the model has no such geom and the routines are not compiled in. */
-template <bool PRIM, int BATCH = 2 /* chunks whose vertex loads go out together (below) */>
+template <bool PRIM, int BATCH = 2 /* chunks whose vertex loads go out together (below) */, bool OBB = false /* GQ_BX_OBB holds the geoms' boxes */>
 __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, int b,
                                      double bx, double by, float zoff, V3 cg, float rg, const PrimLane& PL, PairHit& H) {
   float dist; V3 nrm, pt;
@@ -132,7 +156,19 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
   bool needs = false;
   if (lane < nlg) {
     V3 nn; /* bounding sphere of the cloud against the box itself */
-    needs = rg >= 0.0f && PL.cloud && sphere_box(matTvec(B.mat, cg - bp), bs, rg, nn) < m.boxmix[B.cls][4 + lane].margin;
+    const float marg = m.boxmix[B.cls][4 + lane].margin;
+    needs = rg >= 0.0f && PL.cloud && sphere_box(matTvec(B.mat, cg - bp), bs, rg, nn) < marg;
+    if constexpr (OBB) if (needs) {
+      /* the sphere of a long thin link is loose: half of the (geom, box) pairs it lets through have no vertex near the box, and each costs the
+       * transform, the chunk-box fetch and its round trip before that is known.  The cloud's box (geom-frame AABB, taken to kernel coordinates
+       * once per step) against the world box, separating along the world box's axes: gap_i = |c_i| - s_i - sum_j |e_j . b_i| */
+      const float* O = GQ_BX_OBB(W) + GQ_BX_OBBW * lane;
+      const V3 c = matTvec(B.mat, ld3(O) - bp);
+      const V3 e0 = matTvec(B.mat, ld3(O + 3)), e1 = matTvec(B.mat, ld3(O + 6)), e2 = matTvec(B.mat, ld3(O + 9));
+      const V3 ee = v3(fabsf(e0.x) + fabsf(e1.x) + fabsf(e2.x), fabsf(e0.y) + fabsf(e1.y) + fabsf(e2.y), fabsf(e0.z) + fabsf(e1.z) + fabsf(e2.z));
+      const V3 gap = v3(fmaxf(0.0f, fabsf(c.x) - bs.x - ee.x), fmaxf(0.0f, fabsf(c.y) - bs.y - ee.y), fmaxf(0.0f, fabsf(c.z) - bs.z - ee.z));
+      needs = sqrtf(dot(gap, gap)) - O[12] < marg + 1e-5f;
+    }
     if (!needs) W.u2.c.lg_dist[lane] = 1e30f;
   }
   uint64_t todo = ballot(needs);
@@ -914,6 +950,7 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
     item_sphere(W, m, false, cg, rg);
     box_candidates(W, m, bx, by, 0.0f, cand, cg, rg);
     if (lane < GQ_MAXLG) { st3(GQ_BX_ISPH(W) + 4 * lane, cg); GQ_BX_ISPH(W)[4 * lane + 3] = rg; }
+    if constexpr (!PRIM) item_obb_store(W, m); /* hull robots: the clouds' oriented boxes for box_item_scan's second bounding test */
   }
   wave_barrier();
 #pragma unroll 1
@@ -925,7 +962,7 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
       PairHit H;
       const float* sph = GQ_BX_ISPH(W) + 4 * opaque_lane(lane < GQ_MAXLG ? lane : 0);
       const V3 cg = ld3(sph); const float rg = sph[3];
-      if (!box_item_scan<PRIM, CONE ? 2 : 1>(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, PL, H)) continue;
+      if (!box_item_scan<PRIM, CONE ? 2 : 1, !PRIM>(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, PL, H)) continue;
       append_world_contacts<CONE, PRIM>(W, m, m.box[b].cls, mu_env, H, S);
       wave_barrier();
     }

@@ -273,74 +273,9 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB) reset_kernel(ResetArgs a, co
  * thread per ray looping over the 100 boxes of random_boxes took 21.7 us per step of config 5). */
 __global__ void __launch_bounds__(GQ_WAVE) heightmap_kernel(const GQ_GLOBAL GqDevModel* model, const double* center, int center_stride, const float* yaw, int yaw_stride, int n_envs, int rows, int cols,
                                  float dist_x, float dist_y, float* out) {
-  const int env = (int)blockIdx.x, lane = (int)threadIdx.x, cells = rows * cols;
+  const int env = (int)blockIdx.x;
   center += (size_t)env * center_stride; yaw += (size_t)env * yaw_stride; /* row strides in elements: views of qpos / the observation row work in place */
-  const int nbox = model->nbox;
-  uint64_t cand[2] = {0, 0};
-  {
-    const double gx = center[0], gy = center[1];
-    const float reach = sqrtf((0.5f * rows + 1.0f) * dist_x * (0.5f * rows + 1.0f) * dist_x + (0.5f * cols + 1.0f) * dist_y * (0.5f * cols + 1.0f) * dist_y);
-    for (int half = 0; half < 2 && half * GQ_WAVE < nbox; half++) {
-      const int b = half * GQ_WAVE + lane;
-      bool near = false;
-      if (b < nbox) {
-        const GQ_GLOBAL GqDevBox& B = model->box[b];
-        const double ox = gx - (double)B.pos[0], oy = gy - (double)B.pos[1], rr = (double)B.rad + (double)reach;
-        near = ox * ox + oy * oy <= rr * rr;
-      }
-      cand[half] = ballot(near);
-    }
-  }
-  for (int cell = lane; cell < cells; cell += GQ_WAVE) {
-  const int idx = env * cells + cell, i = cell / cols, j = cell % cols;
-  const float c_rows = (rows % 2 == 0) ? 0.5f * rows : 0.5f * (rows - 1), c_cols = (cols % 2 == 0) ? 0.5f * cols : 0.5f * (cols - 1);
-  const float off_r = (rows % 2 == 0) ? -0.5f * dist_x : 0.0f, off_c = (cols % 2 == 0) ? -0.5f * dist_y : 0.0f;
-  const float ox = dist_x * (c_rows - (float)i) + off_r, oy = dist_y * (c_cols - (float)j) + off_c;
-  const float cy = cosf(yaw[0]), sy = sinf(yaw[0]);
-  /* offset in the world frame: R_W2H^T [ox, oy], R_W2H = [[c, s], [-s, c]] */
-  const double px = center[0] + (double)(cy * ox - sy * oy);
-  const double py = center[1] + (double)(sy * ox + cy * oy);
-  const double pz = center[2] + 0.6 - 0.07;
-  /* mj_ray along -z against the floor plane: distance = pz (ray starts above the floor), hit = origin - z * dist */
-  double dist = pz > 0.0 ? pz : -1.0;   /* mj_ray returns -1 when nothing is hit */
-  for (int half = 0; half < 2; half++)
-  for (uint64_t todo = cand[half]; todo; todo &= todo - 1) { /* wave-uniform */
-    const int b = half * GQ_WAVE + ffs64(todo);
-    const GQ_GLOBAL GqDevBox& B = model->box[b];
-    const double ox = px - (double)B.pos[0], oy = py - (double)B.pos[1], oz = pz - (double)B.pos[2];
-    if (ox * ox + oy * oy > (double)(B.rad * B.rad)) continue; /* the vertical ray misses the bounding sphere */
-    /* origin and direction (0, 0, -1) in the box frame */
-    double tin = 0.0, tout = 1e30;
-    bool hit = true;
-    for (int k = 0; k < 3 && hit; k++) {
-      const double ol = (double)B.mat[k] * ox + (double)B.mat[3 + k] * oy + (double)B.mat[6 + k] * oz, dl = -(double)B.mat[6 + k];
-      const double s = (double)B.size[k];
-      if (fabs(dl) < 1e-12) { hit = fabs(ol) <= s; continue; }
-      double t0 = (-s - ol) / dl, t1 = (s - ol) / dl;
-      if (t0 > t1) { const double tt = t0; t0 = t1; t1 = tt; }
-      if (t0 > tin) tin = t0;
-      if (t1 < tout) tout = t1;
-      hit = tin <= tout;
-    }
-    if (hit && tout >= 0.0 && (dist < 0.0 || tin < dist)) dist = tin;
-  }
-  if (model->hf_nrow > 0) { /* height field: the vertical ray meets the triangle under (px, py) */
-    const GQ_GLOBAL GqDevModel& M = *model;
-    const float x = (float)(px - (double)M.hf_pos[0]), y = (float)(py - (double)M.hf_pos[1]);
-    const float fx = (x + M.hf_sx) * M.hf_inv_dx, fy = (y + M.hf_sy) * M.hf_inv_dy;
-    if (fx >= 0.0f && fy >= 0.0f && fx <= (float)(M.hf_ncol - 1) && fy <= (float)(M.hf_nrow - 1)) {
-      const int nc = M.hf_ncol, c = min((int)fx, nc - 2), r = min((int)fy, M.hf_nrow - 2);
-      const float u = fx - (float)c, v = fy - (float)r;
-      const float* H = M.hf_data;
-      const float h00 = H[r * nc + c], h10 = H[r * nc + c + 1], h01 = H[(r + 1) * nc + c], h11 = H[(r + 1) * nc + c + 1];
-      const float h = u + v <= 1.0f ? h00 + u * (h10 - h00) + v * (h01 - h00) : h11 + (1.0f - u) * (h01 - h11) + (1.0f - v) * (h10 - h11);
-      const double top = (double)M.hf_pos[2] + (double)h, t = pz - top;
-      if (t >= 0.0 && (dist < 0.0 || t < dist)) dist = t;
-    }
-  }
-  float* o = out + (size_t)idx * 3;
-  o[0] = (float)px; o[1] = (float)py; o[2] = (float)(pz - dist);
-  }
+  heightmap_rays(*model, center[0], center[1], center[2], cosf(yaw[0]), sinf(yaw[0]), rows, cols, dist_x, dist_y, out + (size_t)env * rows * cols * 3);
 }
 
 /* mj_jac for one world point per env (include/gq.h gq_jac): kinematics of the env's pose, then lane = dof writes its

@@ -209,6 +209,9 @@ struct GqDevBatch {            /* per-batch constants */
   float imu_pos[3], imu_mat[9];
   float imu_acc_noise, imu_gyro_noise, imu_acc_bias_rate, imu_gyro_bias_rate;
   uint32_t imu_seed_lo, imu_seed_hi;
+  /* HeightMap that follows the base (gq_batch_set_heightmap; 0 rows: off) */
+  int32_t hm_rows, hm_cols;
+  float hm_dx, hm_dy;
   /* in-episode resampling of the velocity command / disturbance wrench (gq_batch_set_resampling; 0 = off) */
   int32_t rs_cmd_reset, rs_dist_reset, rs_env_id_offset;
   int32_t rs_dist_kind[6];

@@ -7,6 +7,7 @@
 #include "gq_step_kernel.h"
 #include "gq_newton.h"
 #include "gq_boxes.h"
+#include "gq_heightmap.h"
 
 namespace gq {
 
@@ -1623,6 +1624,19 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   }
   GQ_SUB(W, 2, 11); /* gather */
   wave_barrier(); /* the obs row overlays u: finish reading it before a second pass reuses the region */
+  /* HeightMap that follows the base (gq_batch_set_heightmap): the sensor's rays from the NEW base pose and heading, cast by the env's own
+   * wavefront here instead of by a kernel of their own behind every step (config 5: 9.4 us + a launch boundary per step).  World-geom variants
+   * only; on a flat scene the host keeps launching heightmap_kernel (a ray hits the floor: nothing to fuse). */
+#ifndef GQ_NO_FUSED_HM /* (development builds: A/B of the epilogue's cost in the variants that carry it) */
+  if constexpr (BOXES) if (a.heightmap) { /* wave-uniform */
+    const GQ_MODEL GqDevBatch& B = Bt;
+    float syaw, cyaw; /* heading as scipy's as_euler('xyz')[2] of the new orientation takes it (S11): atan2(R10, R00), at the gimbal pole atan2(-R01, R11) */
+    if (fabsf(Rn[6]) < 0.9999999f) { syaw = Rn[3]; cyaw = Rn[0]; } else { syaw = -Rn[1]; cyaw = Rn[4]; }
+    const float hyp2 = syaw * syaw + cyaw * cyaw, inv = hyp2 > 0.0f ? fast_rsqrt(hyp2) : 0.0f;
+    syaw *= inv; cyaw = hyp2 > 0.0f ? cyaw * inv : 1.0f;
+    heightmap_rays(m, bxn_d, byn_d, (double)znew, cyaw, syaw, B.hm_rows, B.hm_cols, B.hm_dx, B.hm_dy, a.heightmap + (size_t)env * (size_t)(B.hm_rows * B.hm_cols) * 3);
+  }
+#endif
   /* in-episode resampling (quadruped_env.py:292-305): the user's step only; a redraw acts from the next step on */
   if (pass == 0 && e_h9) resample_wave<PUB>(a, env);
   GQ_SUB(W, 2, 12); /* resampling */
@@ -1777,6 +1791,7 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
       rs_t1 = cycles();
 #endif
       const PrimLane PLL = prim_lane(W, m, item_fetch(m, lane < 4 + m.nlg ? lane : 0), PRIM && lane < 4 + m.nlg, PRIM); /* lane = position in con_order, as box_item_scan expects */
+      if constexpr (!PRIM) { item_obb_store(W, m); wave_barrier(); } /* (the spawn pose's boxes; a lift moves the world boxes down - zoff - not the robot) */
       for (int it = 0; it <= GQ_LIFT_CAP; it++) {
         float pen = floor_pen(dz);
         float clear = 0.0f; /* lift that takes the touching item above the box altogether */
@@ -1791,7 +1806,7 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
             const int b = half * GQ_WAVE + ffs64(todo);
             todo &= todo - 1;
             PairHit BH;
-            if (!box_item_scan<PRIM>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, PLL, BH)) continue;
+            if (!box_item_scan<PRIM, 2, !PRIM>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, PLL, BH)) continue;
             if (lane < 4 + m.nlg) {
               const int code = m.con_order[lane];
               const bool calf = code < 4 || (m.lg[code - 4].body > 0 && (m.lg[code - 4].body - 1) % 3 == 2);

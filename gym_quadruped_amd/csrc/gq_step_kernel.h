@@ -61,6 +61,7 @@ struct StepArgs {
   float* ext_dist;        /* [N][6] current disturbance wrench, may be NULL */
   float* dyn;             /* [N][GQ_DYN_STRIDE] dynamics rows (gq_batch_set_outputs), may be NULL */
   float* contacts;        /* [N][GQ_CON_STRIDE] contact rows, may be NULL */
+  float* heightmap;       /* [N][rows * cols][3] hit points of the HeightMap that follows the base (gq_batch_set_heightmap), may be NULL */
   int32_t n_envs;
 };
 struct StepCall {

@@ -150,6 +150,7 @@ class QuadrupedEnv(AccessorsMixin):
         self._extra_names = tuple(n for n in _ALL_OBS if n not in self.state_obs_names) if accessors else ()
         self._all_ids = list(self._obs_ids) + obs_ids_from_names(self._extra_names)
         self._launches = 0
+        self._hm_fresh = False   # a HeightMap(follow_base=True) holds the rays of the CURRENT state (written by the last step's kernel)
 
         # device state: one tensor per field, env-major rows
         N, dev = self.num_envs, self.device
@@ -298,6 +299,7 @@ class QuadrupedEnv(AccessorsMixin):
         if ev is not None:
             ev[1].record()
         self._launches += 1
+        self._hm_fresh = True
         self._note_step()
         for sensor in self.sensors:  # reference :273-274 (kernel-side sensors: no-op)
             sensor.step()
@@ -329,6 +331,7 @@ class QuadrupedEnv(AccessorsMixin):
         if obs_out is not None and (tuple(obs_out.shape) != (K, self.num_envs, self._obs_dim) or obs_out.dtype != torch.float32 or not obs_out.is_contiguous()):
             raise ValueError(f'obs_out must be a contiguous float32 tensor of shape {(K, self.num_envs, self._obs_dim)}')
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._hm_fresh = False
         _lib.check(self._L.gq_rollout(self._hbatch, a.data_ptr(), K, int(shards), self._st, self._out, self._auto_cfg, self._episode.data_ptr(),
                                       self._lift_failed.data_ptr(), None if obs_out is None else obs_out.data_ptr(), stream), 'gq_rollout')
         self._last_action = a[K - 1]
@@ -376,6 +379,7 @@ class QuadrupedEnv(AccessorsMixin):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if mode not in ('inline', 'mailbox'):
             raise ValueError("mode must be 'inline' or 'mailbox'")
+        self._hm_fresh = False
         _lib.check(self._L.gq_rollout_closed(self._hbatch, K, int(mode == 'inline'), C.byref(pd), int(policy_waves), int(step_waves), float(timeout_s), self._st, self._out,
                                              self._auto_cfg, self._episode.data_ptr(), self._lift_failed.data_ptr(),
                                              None if obs_seq is None else obs_seq.data_ptr(), None if act_seq is None else act_seq.data_ptr(), stream),
@@ -432,6 +436,7 @@ class QuadrupedEnv(AccessorsMixin):
     def _reset_masked(self, mask, random, options, qpos=None, qvel=None):
         """One ``gq_reset`` call = state write (+ lift loop) and the reset's own ``mj_step`` for the masked envs."""
         options = {} if options is None else options
+        self._hm_fresh = False
         cfg = self._reset_cfg
         cfg.random = int(bool(random))
         cfg.q_pos_amp = float(options.get('angle_sweep', 20 * math.pi / 180))
@@ -556,6 +561,7 @@ class QuadrupedEnv(AccessorsMixin):
     _LEGACY_H9 = {'_steps_after_vel': 0, '_steps_before_vel': 1, '_steps_after_dist': 3, '_steps_before_dist': 4}
 
     def load_state_dict(self, d):
+        self._hm_fresh = False
         for k, v in d.items():
             if k in self._LEGACY_H9:  # checkpoints written before the resampling counters moved into one [N, 6] tensor
                 self._h9[:, self._LEGACY_H9[k]].copy_(torch.as_tensor(v, device=self.device).to(torch.int32))

@@ -14,12 +14,22 @@ from .. import _lib
 
 
 class HeightMap:
-    def __init__(self, num_rows, num_cols, dist_x, dist_y, mj_model, mj_data):
+    def __init__(self, num_rows, num_cols, dist_x, dist_y, mj_model, mj_data, follow_base: bool = False):
+        """``follow_base=True`` (extension; scenes with world boxes or a height field): the map is the one the reference's examples
+        keep - ``update_height_map(qpos[0:3], yaw=base_ori_euler_xyz[2])`` after every step (examples/aliengo_with_heightmap.py) - and
+        the STEP KERNEL casts its rays (``gq_batch_set_heightmap``): ``update_height_map()`` without arguments then returns what the last
+        ``env.step`` wrote, with no kernel and no launch boundary of its own (9.4 us per step of BASELINE config 5).  After a reset, a rollout
+        or a restored state it launches the ray kernel once, with the same centre and heading."""
         self.mj_model, self.mj_data = mj_model, mj_data   # mj_data: the batched env
         env = mj_data
         self.num_rows, self.num_cols, self.dist_x, self.dist_y = int(num_rows), int(num_cols), float(dist_x), float(dist_y)
         self.sensor_data_matrix = torch.zeros(env.num_envs, self.num_rows, self.num_cols, 1, 3, dtype=torch.float32, device=env.device)
         self.data = None
+        self.follow_base = bool(follow_base)
+        if self.follow_base:
+            _lib.check(_lib.lib().gq_batch_set_heightmap(env._hbatch, self.num_rows, self.num_cols, self.dist_x, self.dist_y,
+                                                         self.sensor_data_matrix.data_ptr()), 'gq_batch_set_heightmap')
+            env._hm_fresh = False
 
     def create_sensor_matrix(self, center, yaw=0.0):
         """center: [N,3] (e.g. env.qpos[:, 0:3]); yaw: [N] or float.  Returns [N, rows, cols, 1, 3] hit points."""
@@ -37,6 +47,31 @@ class HeightMap:
                                                    self.dist_x, self.dist_y, self.sensor_data_matrix.data_ptr(), stream), 'gq_heightmap_strided')
         return self.sensor_data_matrix
 
-    def update_height_map(self, center, yaw=0.0):
+    def update_height_map(self, center=None, yaw=0.0):
+        if center is None:
+            if not self.follow_base:
+                raise ValueError('update_height_map() without a centre needs HeightMap(..., follow_base=True)')
+            env = self.mj_data
+            if env._hm_fresh:   # the last env.step wrote it
+                self.data = self.sensor_data_matrix
+                return self.data
+            q = env.qpos
+            w, x, y, z = q[:, 3].float(), q[:, 4].float(), q[:, 5].float(), q[:, 6].float()
+            center, yaw = q[:, 0:3], torch.atan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z))
+            self.data = self.create_sensor_matrix(center, yaw)
+            env._hm_fresh = True    # (until the state changes again)
+            return self.data
         self.data = self.create_sensor_matrix(center, yaw)
         return self.data
+
+    def close(self):
+        """Detach from the step kernel (``follow_base``): call before the tensor is dropped while the env lives on."""
+        if self.follow_base and getattr(self.mj_data, '_hbatch', None):
+            _lib.check(_lib.lib().gq_batch_set_heightmap(self.mj_data._hbatch, 0, 0, 0.0, 0.0, None), 'gq_batch_set_heightmap')
+            self.follow_base = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -289,6 +289,16 @@ typedef struct GqImuCfg {
 } GqImuCfg;
 int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state);
 
+/* HeightMap that follows the base (sensors/heightmap.py:17-221 as examples/aliengo_with_heightmap.py uses it: update_height_map(qpos[0:3],
+ * yaw = base_ori_euler_xyz[2]) after every step).  From the next gq_step on, the step kernel itself casts the rows x cols rays of every env it
+ * steps - grid centred on the NEW base position, heading = yaw of the new base orientation (scipy as_euler('xyz')[2], as the observation row
+ * holds it) - and writes the hit points to out, device [N][rows * cols][3] (caller-owned; cell order and ray geometry as gq_heightmap): no
+ * kernel and no launch boundary of its own behind the step.  An env the step's mask leaves out keeps its rows.  Scenes with world boxes or a
+ * height field only (GQ_EINVAL on a flat scene: gq_heightmap there).  out = NULL switches it off.  gq_reset does not cast rays: after a reset
+ * the caller launches gq_heightmap once (the Python HeightMap does).  No reference counterpart as a call: the reference casts mj_ray per cell
+ * from Python. */
+int gq_batch_set_heightmap(GqBatch* b, int rows, int cols, float dist_x, float dist_y, float* out);
+
 /* reset configuration: the knobs of QuadrupedEnv.reset / _sample_ref_vel / _set_ground_friction */
 typedef struct GqResetCfg {
   uint64_t seed;            /* key of the counter-based device RNG (Philox4x32-10; counter = draw, episode, env) */

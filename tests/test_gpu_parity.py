@@ -553,6 +553,46 @@ def test_heightmap_rays_hit_world_boxes():
     assert nhit > 0
 
 
+@pytest.mark.parametrize('robot,scene', [('hyqreal1', 'random_boxes'), ('aliengo', 'perlin'), ('aliengo', 'random_boxes')])
+def test_heightmap_following_the_base_equals_the_ray_kernel(robot, scene):
+    """HeightMap(follow_base=True): the step kernel casts the rays of the map centred on the new base position with the new heading
+    (gq_batch_set_heightmap).  Every step it must hold what the separate ray kernel returns for update_height_map(qpos[0:3],
+    yaw=base_ori_euler_xyz[2]) - the call the reference's examples make after env.step - re-spawning envs included; after a reset the
+    argument-less update launches the ray kernel itself; a flat scene refuses the fused form."""
+    from gym_quadruped_amd import _lib
+    from gym_quadruped_amd.quadruped_env import QuadrupedEnv
+    from gym_quadruped_amd.sensors import HeightMap
+    n = 384
+    env = QuadrupedEnv(robot, scene=scene, state_obs_names=('qpos', 'base_ori_euler_xyz'), num_envs=n, solver='newton', auto_reset='next_step', seed=4)
+    obs = env.reset(random=True)
+    fused = HeightMap(num_rows=5, num_cols=7, dist_x=0.1, dist_y=0.08, mj_model=env.mjModel, mj_data=env, follow_base=True)
+    plain = HeightMap(num_rows=5, num_cols=7, dist_x=0.1, dist_y=0.08, mj_model=env.mjModel, mj_data=env)
+    a0 = fused.update_height_map().clone()                      # after a reset: the ray kernel, centre / heading taken from qpos
+    b0 = plain.update_height_map(env.qpos[:, 0:3], yaw=obs['base_ori_euler_xyz'][:, 2]).clone()
+    assert torch.allclose(a0, b0, atol=2e-5), float((a0 - b0).abs().max())
+    g = torch.Generator(device='cuda:0').manual_seed(1)
+    on_geom = 0
+    for k in range(80):
+        obs, _, term, _, _ = env.step(torch.randn(n, 12, generator=g, device='cuda:0') * 60)
+        a = fused.update_height_map()                           # no launch: written by the step
+        b = plain.update_height_map(env.qpos[:, 0:3], yaw=obs['base_ori_euler_xyz'][:, 2])
+        if k % 8 == 7:
+            assert torch.allclose(a, b, atol=2e-5), (k, float((a - b).abs().max()))
+            on_geom += int((b[..., 2] > 1e-3).sum())
+    assert on_geom > 0 and int(env._episode.max()) > 1          # rays land on the scene's geoms; envs re-spawned on the way
+    obs = env.reset(random=True)
+    assert not env._hm_fresh
+    a1 = fused.update_height_map().clone()
+    b1 = plain.update_height_map(env.qpos[:, 0:3], yaw=obs['base_ori_euler_xyz'][:, 2])
+    assert torch.allclose(a1, b1, atol=2e-5)
+    fused.close()
+    env.step(torch.zeros(n, 12, device='cuda:0'))               # detached: the step no longer writes the map
+    torch.cuda.synchronize()
+    flat = QuadrupedEnv(robot, scene='flat', state_obs_names=('qpos',), num_envs=8)
+    with pytest.raises(_lib.GqError):
+        HeightMap(num_rows=5, num_cols=5, dist_x=0.1, dist_y=0.1, mj_model=flat.mjModel, mj_data=flat, follow_base=True)
+
+
 def test_baseline_config5_hyqreal1_boxes_imu_heightmap():
     """BASELINE.json configs[4]: hyqreal1 on random_boxes with the IMU plug-in and a 5x5 HeightMap, the full observation
     pipeline (ALL_OBS + 6 IMU observables): reset, a short auto-resetting rollout, everything finite and shaped."""
