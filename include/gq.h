@@ -59,8 +59,8 @@ extern "C" {
  * that crosses the boundary.  History: 100 round 1; 300 = GqModelDesc.struct_size + the self-collision / geom_type tables,
  * GqObsOut.step_num_prev, strided HeightMap views, the round-3 entry points; 400 = the closed-loop persistent rollout
  * (gq_rollout_closed, gq_mailbox_get), GqObsOut.contacts_dropped; 500 = lap-tagged mailbox queue items, gq_struct_sizes(out[8]),
- * GqModelDesc.plane_* (optional). */
-#define GQ_ABI_VERSION 500
+ * GqModelDesc.plane_* (optional); 510 = gq_batch_set_heightmap (no struct changed). */
+#define GQ_ABI_VERSION 510
 
 typedef struct GqModelDesc {
   int32_t struct_size; /* = sizeof(GqModelDesc) of the caller's header; gq_model_create refuses any other value */
