@@ -742,6 +742,15 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
       near[half] = ballot(nr);
     }
   }
+  /* lane = pass: does any body pair of the pass's 64 geom pairs come near?  (one load per lane, in flight with the spheres above) */
+  /* (elliptic variants only - go2 372 pairs +0.7 %, go1 655 pairs +0.8 %; in the pyramidal ones the test cost what it saved: b2 -0.2 %,
+   * and the headline's code, 90 pairs and never a skipped pass, moved by -0.3 % with it) */
+  uint64_t live_pass = ~0ull;
+  if constexpr (CONE) if (nsp > 2 * GQ_WAVE) {
+    const int np = (nsp + GQ_WAVE - 1) / GQ_WAVE, lp = lane < np ? lane : 0;
+    const uint64_t pb0 = m.sp_pass_bp[lp][0], pb1 = m.sp_pass_bp[lp][1];
+    live_pass = ballot(lane < np && ((near[0] & pb0) | (near[1] & pb1)) != 0);
+  }
   if (K.self_cut == 1) { wave_barrier(); return; }
   wave_barrier();
   GQ_SUB(W, 1, 10); /* proxy end points */
@@ -752,6 +761,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
   int ncand = 0;
 #pragma unroll 1
   for (int p0 = 0; p0 < nsp; p0 += GQ_WAVE) {
+    if constexpr (CONE) if (!((live_pass >> (p0 / GQ_WAVE)) & 1ull)) continue; /* wave-uniform: every body pair of this pass is far apart */
     const int p = p0 + lane;
     bool cand;
     { /* branch-free: lanes past the last pair test pair 0 (the prefetch's fall-back) and are masked */

@@ -494,6 +494,8 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       if (S.mix.margin > M.self_margin) M.self_margin = S.mix.margin;
     }
     M.nsp = d->nselfpair;
+    for (int k = 0; k < (GQ_MAXSP + 63) / 64; k++) M.sp_pass_bp[k][0] = M.sp_pass_bp[k][1] = 0;
+    for (int q = 0; q < M.nsp; q++) M.sp_pass_bp[q / 64][(M.sp[q].bp >> 6) & 1] |= 1ull << (M.sp[q].bp & 63);
   }
   /* height field: scalars here, the elevations themselves through gq_hfield_heights (the caller owns their memory) */
   M.hf_nrow = 0; M.hf_ncol = 0; M.hf_cls = 0; M.hf_data = nullptr;

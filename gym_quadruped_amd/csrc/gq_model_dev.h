@@ -164,6 +164,8 @@ struct GqDevModel {
   float item_bsph[4 + GQ_MAXLG][4];        /* bounding sphere of the item's TRUE shape where it is a primitive (else of its proxy capsule): centre (body frame), radius */
   GqDevBodyPair bp[GQ_MAXBP];
   GqDevSelfPair sp[GQ_MAXSP];
+  uint64_t sp_pass_bp[(GQ_MAXSP + 63) / 64][2]; /* body pairs (bit = index into bp) that own a geom pair of pass k (64 pairs per pass): a pass none of whose
+                                                 * body pairs is near is skipped whole - its record loads included */
   /* height field of the scene (0 rows: none): elevations in metres relative to hf_pos[2], row r <-> y, column c <-> x */
   int32_t hf_nrow, hf_ncol, hf_cls; /* hf_cls: its contact-parameter class in boxmix / boxcls_friction */
   float hf_pos[3], hf_sx, hf_sy, hf_dx, hf_dy, hf_inv_dx, hf_inv_dy;
