@@ -241,7 +241,7 @@ int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state) {
 int gq_batch_set_heightmap(GqBatch* b, int rows, int cols, float dist_x, float dist_y, float* out) {
   if (!b) { SET_ERR("gq_batch_set_heightmap: null batch"); return GQ_EINVAL; }
   if (!out) { b->heightmap = nullptr; b->host.hm_rows = b->host.hm_cols = 0; b->batch_dirty = true; return GQ_OK; }
-  if (rows <= 0 || cols <= 0 || rows * cols > 4096 || !(dist_x > 0.0f) || !(dist_y > 0.0f)) { SET_ERR("gq_batch_set_heightmap: bad grid (%d x %d cells of %g x %g m)", rows, cols, (double)dist_x, (double)dist_y); return GQ_EINVAL; }
+  if (rows <= 0 || cols <= 0 || rows > 4096 || cols > 4096 || rows * cols > 4096 || !(dist_x > 0.0f) || !(dist_y > 0.0f)) { SET_ERR("gq_batch_set_heightmap: bad grid (%d x %d cells of %g x %g m)", rows, cols, (double)dist_x, (double)dist_y); return GQ_EINVAL; }
   if (scene_variant(b->model) == 0) { SET_ERR("gq_batch_set_heightmap: the scene has no world boxes / height field - every ray ends on the floor plane; use gq_heightmap"); return GQ_EINVAL; }
   b->heightmap = out;
   b->host.hm_rows = rows; b->host.hm_cols = cols; b->host.hm_dx = dist_x; b->host.hm_dy = dist_y;
