@@ -12,7 +12,7 @@ import numpy as np
 from .mjcf import ModelDesc
 
 GQ_NLEG = 4
-GQ_ABI_VERSION = 510   # include/gq.h
+GQ_ABI_VERSION = 600   # include/gq.h
 # optional extra output rows of the step kernel (include/gq.h gq_batch_set_outputs)
 GQ_DYN = dict(MC=0, MB=108, BIAS=144, XPOS=162, XMAT=201, FOOT=318, STRIDE=336)
 GQ_CON_MAX, GQ_CON_REC = 12, 24
@@ -57,6 +57,7 @@ class GqModelDesc(C.Structure):
         ('hfield_condim', C.c_int32), ('hfield_priority', C.c_int32),
         ('nselfpair', C.c_int32), ('selfpair_geom1', _I), ('selfpair_geom2', _I), ('geom_capsule', _D), ('geom_type', _I),
         ('plane_grid', C.c_int32), ('plane_vert_pos', _D), ('plane_mask', _I),
+        ('nadj', C.c_int32), ('vert_adjadr', _I), ('vert_adjnum', _I), ('vert_adj', _I), ('plane_order', _I),
     ]
 
 
@@ -233,8 +234,10 @@ def _plane_support_tables(md: ModelDesc, grid, chunk, wide_deg, slack):
     vert = np.array(md.vert_pos, dtype=np.float64, copy=True)
     ncl = len(md.cloud_vertnum)
     masks = np.ones((ncl, 6 * grid * grid), dtype=np.int32)
+    perm = np.zeros(len(vert), dtype=np.int32)
     for cl in range(ncl):
         n, a = int(md.cloud_vertnum[cl]), int(md.cloud_vertadr[cl])
+        perm[a:a + n] = np.arange(n)
         if n <= chunk:
             continue
         V = vert[a:a + n].copy()
@@ -265,6 +268,7 @@ def _plane_support_tables(md: ModelDesc, grid, chunk, wide_deg, slack):
         key = np.array([plane_cell_of(ax[v], grid) for v in range(n)], dtype=np.int64) + wide * (10 * 6 * grid * grid)
         order = np.argsort(key, kind='stable')
         vert[a:a + n] = V[order]
+        perm[a:a + n] = order
         chunk_of = np.empty(n, dtype=np.int64)
         chunk_of[order] = np.arange(n) // chunk
         ang = np.arccos(np.clip(cen @ ax.T, -1.0, 1.0))                    # [cells][vertices]
@@ -274,7 +278,48 @@ def _plane_support_tables(md: ModelDesc, grid, chunk, wide_deg, slack):
         for k in range((n + chunk - 1) // chunk):
             m |= (touch[:, chunk_of == k].any(1).astype(np.int64) << k)
         masks[cl] = m.astype(np.int32)
-    return vert, masks
+    return vert, masks, perm
+
+
+_GRAPH_CACHE = {}
+GEOM_MESH = 7
+
+
+def hull_graphs_enabled(md: ModelDesc) -> bool:
+    return any(int(md.geom_cloudid[g]) >= 0 and int(md.geom_type[g]) == GEOM_MESH and int(md.geom_bodyid[g]) > 0 for g in range(md.ngeom))
+
+
+def hull_graphs(md: ModelDesc):
+    """Edge graphs of the mesh clouds' convex hulls (MuJoCo's ``mesh_graph``, which mjc_PlaneConvex walks: quadruped_env.py:271 ->
+    mj_step -> mj_collision): per vertex of ``vert_pos`` the cloud-local indices of the vertices it shares a hull edge with, ascending.
+    Returns (vert_adjadr [nvert], vert_adjnum [nvert], vert_adj [nadj]) int32; vertices of clouds no mesh geom uses have no neighbours.
+    The hull is scipy's (qhull, triangulated facets), so a planar polygonal facet contributes its fan's diagonals as edges too."""
+    key = (hash(np.asarray(md.vert_pos, dtype=np.float64).tobytes()), tuple(int(x) for x in md.cloud_vertnum), tuple(int(x) for x in md.geom_type),
+           tuple(int(x) for x in md.geom_cloudid))
+    if key in _GRAPH_CACHE:
+        return _GRAPH_CACHE[key]
+    from scipy.spatial import ConvexHull
+    nvert = int(md.vert_pos.shape[0])
+    adr, num, adj = np.zeros(nvert, np.int32), np.zeros(nvert, np.int32), []
+    mesh_clouds = {int(md.geom_cloudid[g]) for g in range(md.ngeom) if int(md.geom_cloudid[g]) >= 0 and int(md.geom_type[g]) == GEOM_MESH}
+    for cl in sorted(mesh_clouds):
+        n, a = int(md.cloud_vertnum[cl]), int(md.cloud_vertadr[cl])
+        if n < 4:
+            continue
+        try:
+            hull = ConvexHull(np.asarray(md.vert_pos[a:a + n], dtype=np.float64))
+        except Exception:   # a flat cloud has no hull graph: support vertex only
+            continue
+        nb = [set() for _ in range(n)]
+        for simp in hull.simplices:
+            for i in simp:
+                nb[int(i)].update(int(j) for j in simp if j != i)
+        for v in range(n):
+            adr[a + v], num[a + v] = len(adj), len(nb[v])
+            adj.extend(sorted(nb[v]))
+    out = (adr, num, np.asarray(adj if adj else [0], dtype=np.int32))
+    _GRAPH_CACHE[key] = out
+    return out
 
 
 class MarshalledModel:
@@ -282,7 +327,7 @@ class MarshalledModel:
 
     def __init__(self, md: ModelDesc, *, qpos0=None, feet_geom_names=None, terrain_limits=(1e4, -1e4, 1e4, -1e4),
                  timestep=None, solver=SOLVER_PGS, iterations=100, tolerance=1e-8, floor=None,
-                 noise_floor=0.0, boxes=None, hfield=None, self_collision=None):
+                 noise_floor=0.0, boxes=None, hfield=None, self_collision=None, mesh_graph=True):
         self.md = md
         self._keep = []
         d = GqModelDesc()
@@ -313,7 +358,7 @@ class MarshalledModel:
         d.nselfpair = int(len(pairs))
         self.self_pairs = pairs
         for name, ctype in GqModelDesc._fields_:
-            if ctype in (_I, _D) and not name.startswith('plane_'):   # (the optional plane tables are filled below)
+            if ctype in (_I, _D) and not name.startswith('plane_') and not name.startswith('vert_adj'):   # (the optional tables are filled below)
                 src = q0 if name == 'qpos0' else (box_arrays[name] if name in box_arrays else getattr(md, name))
                 arr = np.ascontiguousarray(src, dtype=np.int32 if ctype is _I else np.float64)
                 if arr.size == 0:
@@ -357,12 +402,20 @@ class MarshalledModel:
             d.hfield_condim, d.hfield_priority = hg['condim'], hg['priority']
         # hull-versus-plane support tables (optional in the C-ABI: NULL = every chunk of a cloud is scanned)
         if nvert > 0 and any(int(c) > 64 for c in md.cloud_vertnum):
-            pv, pm = plane_support_tables(md)
-            pv, pm = np.ascontiguousarray(pv, dtype=np.float64), np.ascontiguousarray(pm, dtype=np.int32)
-            self._keep += [pv, pm]
+            pv, pm, po = plane_support_tables(md)
+            pv, pm, po = np.ascontiguousarray(pv, dtype=np.float64), np.ascontiguousarray(pm, dtype=np.int32), np.ascontiguousarray(po, dtype=np.int32)
+            self._keep += [pv, pm, po]
             d.plane_grid = PLANE_GRID
             d.plane_vert_pos = pv.ctypes.data_as(_D)
             d.plane_mask = pm.ctypes.data_as(_I)
+            d.plane_order = po.ctypes.data_as(_I)
+        # hull graphs of the mesh clouds (optional in the C-ABI: NULL = a mesh meets a plane at its support vertex only)
+        if nvert > 0 and mesh_graph and hull_graphs_enabled(md):
+            ga, gn, gl = hull_graphs(md)
+            ga, gn, gl = np.ascontiguousarray(ga, dtype=np.int32), np.ascontiguousarray(gn, dtype=np.int32), np.ascontiguousarray(gl, dtype=np.int32)
+            self._keep += [ga, gn, gl]
+            d.nadj = int(gn.sum())
+            d.vert_adjadr, d.vert_adjnum, d.vert_adj = ga.ctypes.data_as(_I), gn.ctypes.data_as(_I), gl.ctypes.data_as(_I)
         self.desc = d
 
 

@@ -59,8 +59,9 @@ extern "C" {
  * that crosses the boundary.  History: 100 round 1; 300 = GqModelDesc.struct_size + the self-collision / geom_type tables,
  * GqObsOut.step_num_prev, strided HeightMap views, the round-3 entry points; 400 = the closed-loop persistent rollout
  * (gq_rollout_closed, gq_mailbox_get), GqObsOut.contacts_dropped; 500 = lap-tagged mailbox queue items, gq_struct_sizes(out[8]),
- * GqModelDesc.plane_* (optional); 510 = gq_batch_set_heightmap (no struct changed). */
-#define GQ_ABI_VERSION 510
+ * GqModelDesc.plane_* (optional); 510 = gq_batch_set_heightmap (no struct changed); 600 = GqModelDesc.vert_adj* / plane_order (hull
+ * graphs: multi-point mesh-plane contacts), the general convex narrow phase (GJK / EPA) behind the same tables. */
+#define GQ_ABI_VERSION 600
 
 typedef struct GqModelDesc {
   int32_t struct_size; /* = sizeof(GqModelDesc) of the caller's header; gq_model_create refuses any other value */
@@ -209,6 +210,17 @@ typedef struct GqModelDesc {
   int32_t plane_grid;            /* G (<= 16), 0: no tables */
   const double* plane_vert_pos;  /* [nvert][3] */
   const int32_t* plane_mask;     /* [ncloud][6 G G] */
+  /* OPTIONAL hull graphs of the mesh clouds (MuJoCo's mesh_graph): the edges of the convex hull, per vertex the list of the vertices it
+   * shares an edge with (cloud-LOCAL indices, ascending).  mjc_PlaneConvex walks them: after the support vertex of a mesh against a
+   * plane, the neighbours within the margin become contacts too, until the pair has three (csrc/gq_step_body.h stage_collision_scan,
+   * oracle/gq_oracle.c gqo_collision).  vert_adjnum = 0 for the vertices of clouds that are not meshes; NULL pointers: support vertex
+   * only.  plane_order (with plane_vert_pos): cloud-local index, in vert_pos, of every vertex of the direction-ordered copy.
+   * gym_quadruped_amd/cabi.py hull_graphs builds them with scipy.spatial.ConvexHull. */
+  int32_t nadj;
+  const int32_t* vert_adjadr;    /* [nvert] first entry of the vertex's list in vert_adj */
+  const int32_t* vert_adjnum;    /* [nvert] */
+  const int32_t* vert_adj;       /* [nadj] */
+  const int32_t* plane_order;    /* [nvert] */
 } GqModelDesc;
 
 typedef struct GqModel GqModel;

@@ -1,0 +1,338 @@
+/*
+ * gq_convex.h - convex narrow phase of the CPU oracle (TEST INFRASTRUCTURE ONLY, included by gq_oracle.c).
+ *
+ * What MuJoCo's general convex routine mjc_Convex computes for a pair of convex geoms (engine_collision_convex.c: the native
+ * GJK / EPA pipeline of MuJoCo 3.x, one contact per pair with multiccd off - the default): the signed distance of the two
+ * shapes (positive: separation, negative: minus the penetration depth = the length of the minimum translation that
+ * separates them), the contact normal from geom 1 to geom 2 along that translation, and the point midway between the two
+ * witness points.  Restated from the published algorithms (Gilbert-Johnson-Keerthi distance; van den Bergen's expanding
+ * polytope), not from MuJoCo's source, which is not under /root/reference: PARITY UNPINNED like the rest of mj_step.
+ * Pinned geometrically instead - tests/test_oracle_invariants.py holds depth / distance, normal and witness points to the
+ * exact Minkowski-difference hull of the two vertex sets (scipy.spatial.ConvexHull).
+ *
+ * Shapes are polytopes given by their vertices (a mesh geom's convex hull, a box geom's corners, a cylinder's two 16-gon
+ * rims, a sphere's centre, a capsule's two end points) plus a radius that inflates them (spheres, capsules), or a box given
+ * analytically (world boxes).  GJK / EPA run on the un-inflated cores; the radii are taken off the distance afterwards.
+ * The step kernel (gym_quadruped_amd/csrc/gq_convex.h) runs the same iteration with one support query per wavefront scan.
+ */
+#pragma once
+#include <math.h>
+#include <string.h>
+
+#define CVX_GJK_MAXIT 48
+#define CVX_EPA_MAXIT 28   /* the kernel holds one polytope face per lane: 4 + 2 * 28 <= 64 */
+#define CVX_EPA_MAXF (4 + 2 * CVX_EPA_MAXIT + 4)
+#define CVX_EPA_MAXV (4 + CVX_EPA_MAXIT + 2)
+
+typedef struct {
+  int box;              /* 1: analytic box (centre t, axes = columns of R, half extents h); 0: vertex cloud V[nv] in the frame (R, t) */
+  const double* V; int nv;
+  double R[9], t[3], h[3];
+  double r;             /* inflation radius */
+} Cvx;
+
+typedef struct { double w[3], a[3]; int ia, ib; } CvxPt; /* point of A - B, its witness on A (the one on B is a - w), vertex ids */
+
+static inline double cvx_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cvx_cross(double* r, const double* a, const double* b) {
+  r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* support point of the core in world direction d: the first vertex (lowest index) that maximises the projection; a box
+ * corner takes +h on an exactly perpendicular axis */
+static int cvx_support(const Cvx* s, const double* d, double* p) {
+  double dl[3];
+  for (int k = 0; k < 3; k++) dl[k] = s->R[k] * d[0] + s->R[3 + k] * d[1] + s->R[6 + k] * d[2];
+  double q[3];
+  int id = 0;
+  if (s->box) {
+    for (int k = 0; k < 3; k++) { const int neg = dl[k] < 0; q[k] = neg ? -s->h[k] : s->h[k]; id |= neg << k; }
+  } else {
+    double best = -1e300;
+    for (int v = 0; v < s->nv; v++) {
+      const double pr = cvx_dot(dl, s->V + 3 * v);
+      if (pr > best) { best = pr; id = v; }
+    }
+    memcpy(q, s->V + 3 * id, sizeof q);
+  }
+  for (int k = 0; k < 3; k++) p[k] = s->t[k] + s->R[3 * k] * q[0] + s->R[3 * k + 1] * q[1] + s->R[3 * k + 2] * q[2];
+  return id;
+}
+static void cvx_minkowski(const Cvx* A, const Cvx* B, const double* d, CvxPt* out) {
+  double b[3], nd[3] = {-d[0], -d[1], -d[2]};
+  out->ia = cvx_support(A, d, out->a);
+  out->ib = cvx_support(B, nd, b);
+  for (int k = 0; k < 3; k++) out->w[k] = out->a[k] - b[k];
+}
+
+/* closest point of the segment / triangle to the origin as barycentric weights (Ericson, Real-Time Collision Detection 5.1) */
+static void cvx_seg(const double* p0, const double* p1, double* lam) {
+  double e[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+  const double ee = cvx_dot(e, e), t = ee > 0 ? -cvx_dot(p0, e) / ee : 0.0;
+  const double tc = t <= 0 ? 0.0 : (t >= 1 ? 1.0 : t);
+  lam[0] = 1 - tc; lam[1] = tc;
+}
+static void cvx_tri(const double* a, const double* b, const double* c, double* lam) {
+  double ab[3], ac[3];
+  for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; }
+  const double d1 = -cvx_dot(ab, a), d2 = -cvx_dot(ac, a);
+  lam[0] = lam[1] = lam[2] = 0;
+  if (d1 <= 0 && d2 <= 0) { lam[0] = 1; return; }
+  const double d3 = -cvx_dot(ab, b), d4 = -cvx_dot(ac, b);
+  if (d3 >= 0 && d4 <= d3) { lam[1] = 1; return; }
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); lam[0] = 1 - v; lam[1] = v; return; }
+  const double d5 = -cvx_dot(ab, c), d6 = -cvx_dot(ac, c);
+  if (d6 >= 0 && d5 <= d6) { lam[2] = 1; return; }
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); lam[0] = 1 - w; lam[2] = w; return; }
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); lam[1] = 1 - w; lam[2] = w; return; }
+  const double den = 1.0 / (va + vb + vc);
+  lam[1] = vb * den; lam[2] = vc * den; lam[0] = 1 - lam[1] - lam[2];
+}
+
+/* closest point of the simplex S[0..n) to the origin: weights lam[0..n) (zero for the vertices the point does not need), the point
+ * v; returns 1 when a tetrahedron encloses the origin (then lam / v are not set) */
+static int cvx_simplex(const CvxPt* S, int n, double* lam, double* v) {
+  lam[0] = lam[1] = lam[2] = lam[3] = 0;
+  if (n == 1) lam[0] = 1;
+  else if (n == 2) cvx_seg(S[0].w, S[1].w, lam);
+  else if (n == 3) cvx_tri(S[0].w, S[1].w, S[2].w, lam);
+  else {
+    static const int F[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}}; /* face, opposite vertex */
+    double best = 1e300;
+    int any = 0;
+    for (int f = 0; f < 4; f++) {
+      const double* a = S[F[f][0]].w; const double* b = S[F[f][1]].w; const double* c = S[F[f][2]].w; const double* o = S[F[f][3]].w;
+      double ab[3], ac[3], ao[3], nf[3];
+      for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; ao[k] = o[k] - a[k]; }
+      cvx_cross(nf, ab, ac);
+      const double so = cvx_dot(nf, ao), sz = -cvx_dot(nf, a);
+      /* the origin lies beyond this face (on the side away from the opposite vertex); a flat tetrahedron (so = 0) counts as beyond */
+      if ((so > 0 && sz < 0) || (so < 0 && sz > 0) || so == 0) {
+        double l3[3], p[3];
+        cvx_tri(a, b, c, l3);
+        for (int k = 0; k < 3; k++) p[k] = l3[0] * a[k] + l3[1] * b[k] + l3[2] * c[k];
+        const double pp = cvx_dot(p, p);
+        if (pp < best) {
+          best = pp; any = 1;
+          lam[0] = lam[1] = lam[2] = lam[3] = 0;
+          lam[F[f][0]] = l3[0]; lam[F[f][1]] = l3[1]; lam[F[f][2]] = l3[2];
+        }
+      }
+    }
+    if (!any) return 1;
+  }
+  for (int k = 0; k < 3; k++) {
+    v[k] = 0;
+    for (int i = 0; i < n; i++) v[k] += lam[i] * S[i].w[k];
+  }
+  return 0;
+}
+
+typedef struct { int v[3], adj[3]; double n[3], d; int alive; } CvxFace;
+static void cvx_face_plane(const CvxPt* P, CvxFace* f) {
+  const double* a = P[f->v[0]].w; const double* b = P[f->v[1]].w; const double* c = P[f->v[2]].w;
+  double ab[3], ac[3], n[3];
+  for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; }
+  cvx_cross(n, ab, ac);
+  const double l2 = cvx_dot(n, n);
+  if (l2 > 1e-60) { const double inv = 1.0 / sqrt(l2); for (int k = 0; k < 3; k++) f->n[k] = n[k] * inv; f->d = cvx_dot(f->n, a); }
+  else { f->n[0] = f->n[1] = 0; f->n[2] = 1; f->d = 1e300; } /* a sliver: kept for the topology, never the closest face */
+}
+
+/* GJK + EPA on the cores of A and B.  reach: contacts farther apart than this (core to core) are of no interest.
+ * Returns 0: no contact within reach; 1: cores apart, *dist > 0; 2: cores overlap, *dist < 0.  n: unit normal from A to B;
+ * pa / pb: witness points on the two cores.  niter (optional): GJK and EPA iteration counts. */
+static int cvx_gjk_epa(const Cvx* A, const Cvx* B, double reach, double tol_rel, double tol_epa, double* dist, double* n, double* pa, double* pb, int* niter) {
+  CvxPt S[4], P[CVX_EPA_MAXV];
+  int ns = 0;
+  double v[3], lam[4] = {1, 0, 0, 0}, d0[3] = {B->t[0] - A->t[0], B->t[1] - A->t[1], B->t[2] - A->t[2]};
+  if (cvx_dot(d0, d0) < 1e-24) { d0[0] = 1; d0[1] = 0; d0[2] = 0; }
+  cvx_minkowski(A, B, d0, &S[0]);
+  ns = 1;
+  memcpy(v, S[0].w, sizeof v);
+  int enclosed = 0, it;
+  if (niter) niter[0] = niter[1] = 0;
+  for (it = 0; it < CVX_GJK_MAXIT; it++) {
+    const double vv = cvx_dot(v, v);
+    if (vv < 1e-28) { enclosed = 1; break; } /* the origin lies ON the simplex: touching cores */
+    double dir[3] = {-v[0], -v[1], -v[2]};
+    CvxPt w;
+    cvx_minkowski(A, B, dir, &w);
+    const double vw = cvx_dot(v, w.w);
+    if (vw > 0 && vw * vw > reach * reach * vv) return 0; /* the plane through w normal to v separates the cores by more than reach */
+    int dup = 0;
+    for (int i = 0; i < ns; i++) dup |= (S[i].ia == w.ia && S[i].ib == w.ib);
+    if (dup || vv - vw <= tol_rel * (vv + sqrt(vv * cvx_dot(w.w, w.w)))) break; /* v is the closest point (to the round-off of the two products) */
+    S[ns++] = w;
+    if (cvx_simplex(S, ns, lam, v)) { enclosed = 1; break; }
+    int m = 0;
+    for (int i = 0; i < ns; i++) if (lam[i] > 0) { S[m] = S[i]; lam[m] = lam[i]; m++; }
+    ns = m;
+  }
+  if (niter) niter[0] = it;
+  if (!enclosed) {
+    const double len = sqrt(cvx_dot(v, v));
+    if (len > reach) return 0;
+    for (int k = 0; k < 3; k++) {
+      n[k] = -v[k] / len; pa[k] = 0;
+      for (int i = 0; i < ns; i++) pa[k] += lam[i] * S[i].a[k];
+      pb[k] = pa[k] - v[k];
+    }
+    *dist = len;
+    return 1;
+  }
+  /* ---- the cores overlap: expanding polytope.  First a tetrahedron around the origin */
+  if (ns < 4) { /* touching or degenerate simplex: blow it up with supports along directions the simplex does not span */
+    static const double ax[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int tries = 0; tries < 12 && ns < 4; tries++) {
+      double dir[3];
+      if (ns == 1) { const int k = tries % 3; for (int q = 0; q < 3; q++) dir[q] = (tries < 3 ? 1 : -1) * ax[k][q]; }
+      else if (ns == 2) {
+        double e[3] = {S[1].w[0] - S[0].w[0], S[1].w[1] - S[0].w[1], S[1].w[2] - S[0].w[2]};
+        const int k = tries % 3;
+        cvx_cross(dir, e, ax[k]);
+        if (tries >= 3 && tries < 6) for (int q = 0; q < 3; q++) dir[q] = -dir[q];
+      } else {
+        double e1[3], e2[3];
+        for (int q = 0; q < 3; q++) { e1[q] = S[1].w[q] - S[0].w[q]; e2[q] = S[2].w[q] - S[0].w[q]; }
+        cvx_cross(dir, e1, e2);
+        if (tries & 1) for (int q = 0; q < 3; q++) dir[q] = -dir[q];
+      }
+      if (cvx_dot(dir, dir) < 1e-30) continue;
+      CvxPt w;
+      cvx_minkowski(A, B, dir, &w);
+      int dup = 0;
+      for (int i = 0; i < ns; i++) dup |= (S[i].ia == w.ia && S[i].ib == w.ib);
+      if (dup) continue;
+      /* the new point must add a dimension */
+      if (ns == 2) {
+        double e[3], f[3], c[3];
+        for (int q = 0; q < 3; q++) { e[q] = S[1].w[q] - S[0].w[q]; f[q] = w.w[q] - S[0].w[q]; }
+        cvx_cross(c, e, f);
+        if (cvx_dot(c, c) < 1e-24 * cvx_dot(e, e)) continue;
+      } else if (ns == 3) {
+        double e1[3], e2[3], c[3], f[3];
+        for (int q = 0; q < 3; q++) { e1[q] = S[1].w[q] - S[0].w[q]; e2[q] = S[2].w[q] - S[0].w[q]; f[q] = w.w[q] - S[0].w[q]; }
+        cvx_cross(c, e1, e2);
+        const double vol = cvx_dot(c, f);
+        if (vol * vol < 1e-24 * cvx_dot(c, c)) continue;
+      } else if (ns == 1) {
+        double f[3] = {w.w[0] - S[0].w[0], w.w[1] - S[0].w[1], w.w[2] - S[0].w[2]};
+        if (cvx_dot(f, f) < 1e-24) continue;
+      }
+      S[ns++] = w;
+    }
+    if (ns < 4) return 0; /* flat Minkowski difference (both shapes degenerate): no volume to penetrate */
+  }
+  int nv = 4, nf = 4;
+  CvxFace Fc[CVX_EPA_MAXF];
+  for (int i = 0; i < 4; i++) P[i] = S[i];
+  {
+    static const int T[4][3] = {{0, 1, 2}, {0, 3, 1}, {0, 2, 3}, {1, 3, 2}};
+    static const int Ad[4][3] = {{1, 3, 2}, {2, 3, 0}, {0, 3, 1}, {1, 2, 0}}; /* face across edge v[e] -> v[e + 1] */
+    for (int f = 0; f < 4; f++) {
+      for (int e = 0; e < 3; e++) { Fc[f].v[e] = T[f][e]; Fc[f].adj[e] = Ad[f][e]; }
+      Fc[f].alive = 1;
+      cvx_face_plane(P, &Fc[f]);
+    }
+    /* orientation: the four windings above are consistent; all are turned when face 0 looks at vertex 3 */
+    const double s = cvx_dot(Fc[0].n, P[3].w) - Fc[0].d;
+    if (s > 0)
+      for (int f = 0; f < 4; f++) {
+        int t = Fc[f].v[1]; Fc[f].v[1] = Fc[f].v[2]; Fc[f].v[2] = t;
+        t = Fc[f].adj[0]; Fc[f].adj[0] = Fc[f].adj[2]; Fc[f].adj[2] = t;
+        cvx_face_plane(P, &Fc[f]);
+      }
+  }
+  int best = 0, eit;
+  for (eit = 0;; eit++) {
+    double dmin = 1e300;
+    best = -1;
+    for (int f = 0; f < nf; f++) if (Fc[f].alive && Fc[f].d < dmin) { dmin = Fc[f].d; best = f; }
+    if (best < 0) return 0;
+    if (eit >= CVX_EPA_MAXIT) break;
+    CvxPt w;
+    cvx_minkowski(A, B, Fc[best].n, &w);
+    int dup = 0;
+    for (int i = 0; i < nv; i++) dup |= (P[i].ia == w.ia && P[i].ib == w.ib);
+#ifdef CVX_DEBUG
+    printf("epa it %d best %d dmin %.6g support %.6g dup %d nv %d nf %d ids %d %d\n", eit, best, dmin, cvx_dot(w.w, Fc[best].n), dup, nv, nf, w.ia, w.ib);
+#endif
+    if (dup || cvx_dot(w.w, Fc[best].n) - dmin <= tol_epa) break; /* the face lies on the boundary of A - B */
+    /* the faces that see w - the CONNECTED patch around the closest face (a face that is coplanar with w to round-off may test either
+     * way; a patch grown through shared edges has one rim) - go, and a fan around w closes the hole */
+    int vis[CVX_EPA_MAXF], grew = 1;
+    for (int f = 0; f < nf; f++) vis[f] = 0;
+    vis[best] = 1;
+    while (grew) {
+      grew = 0;
+      for (int f = 0; f < nf; f++) {
+        if (vis[f] || !Fc[f].alive || !(Fc[f].d < 1e299) || !(cvx_dot(Fc[f].n, w.w) - Fc[f].d > 0.5 * tol_epa)) continue;
+        if (vis[Fc[f].adj[0]] || vis[Fc[f].adj[1]] || vis[Fc[f].adj[2]]) { vis[f] = 1; grew = 1; }
+      }
+    }
+    int he[3 * CVX_EPA_MAXF][3], nh = 0; /* rim edges a -> b (the winding of the face that goes) and the face g that stays behind them */
+    for (int f = 0; f < nf; f++) {
+      if (!vis[f]) continue;
+      for (int e = 0; e < 3; e++)
+        if (!vis[Fc[f].adj[e]]) { he[nh][0] = Fc[f].v[e]; he[nh][1] = Fc[f].v[(e + 1) % 3]; he[nh][2] = Fc[f].adj[e]; nh++; }
+    }
+    for (int f = 0; f < nf; f++) if (vis[f]) Fc[f].alive = 0;
+    P[nv] = w;
+    /* new faces (a, b, w) take the lowest free slots, rim edges in (face, edge) order - the kernel's lane assignment */
+    int slot_of[3 * CVX_EPA_MAXF], slot = 0, made = 0;
+    for (int e = 0; e < nh; e++) {
+      while (slot < nf && Fc[slot].alive) slot++;
+      if (slot >= CVX_EPA_MAXF) break;
+      if (slot >= nf) nf = slot + 1;
+      slot_of[e] = slot;
+      Fc[slot].v[0] = he[e][0]; Fc[slot].v[1] = he[e][1]; Fc[slot].v[2] = nv; Fc[slot].alive = 1;
+      cvx_face_plane(P, &Fc[slot]);
+      slot++; made++;
+    }
+    for (int e = 0; e < made; e++) { /* neighbours: the face behind the rim edge, the fan face that starts where this one ends, the one that ends where it starts */
+      CvxFace* F = &Fc[slot_of[e]];
+      const int g = he[e][2];
+      F->adj[0] = g;
+      for (int q = 0; q < 3; q++) if (Fc[g].v[q] == he[e][1] && Fc[g].v[(q + 1) % 3] == he[e][0]) Fc[g].adj[q] = slot_of[e];
+      F->adj[1] = F->adj[2] = slot_of[e];
+      for (int k = made - 1; k >= 0; k--) { if (he[k][0] == he[e][1]) F->adj[1] = slot_of[k]; if (he[k][1] == he[e][0]) F->adj[2] = slot_of[k]; }
+    }
+    nv++;
+  }
+  if (niter) niter[1] = eit;
+  /* the closest face: its plane's foot point, split over the face's vertices */
+  {
+    const CvxFace* f = &Fc[best];
+    const double* a = P[f->v[0]].w; const double* b = P[f->v[1]].w; const double* c = P[f->v[2]].w;
+    double l3[3], fa[3], fb[3], fc[3];
+    const double dd = f->d < 1e299 ? f->d : 0.0;
+    for (int k = 0; k < 3; k++) { fa[k] = a[k] - dd * f->n[k]; fb[k] = b[k] - dd * f->n[k]; fc[k] = c[k] - dd * f->n[k]; }
+    cvx_tri(fa, fb, fc, l3); /* (the foot point falls inside the face when it is a face of A - B; clamped otherwise) */
+    for (int k = 0; k < 3; k++) {
+      n[k] = f->n[k];
+      pa[k] = l3[0] * P[f->v[0]].a[k] + l3[1] * P[f->v[1]].a[k] + l3[2] * P[f->v[2]].a[k];
+      pb[k] = pa[k] - dd * f->n[k];
+    }
+    *dist = -dd;
+  }
+  return 2;
+}
+
+/* one contact of a convex pair: signed distance of the inflated shapes, normal A -> B, point midway between the surfaces */
+static int cvx_pair(const Cvx* A, const Cvx* B, double margin, double* dist, double* nrm, double* pos, int* niter) {
+  double n[3], pa[3], pb[3], dc;
+  const int rc = cvx_gjk_epa(A, B, margin + A->r + B->r, 1e-13, 1e-10, &dc, n, pa, pb, niter);
+  if (!rc) return 0;
+  const double d = dc - A->r - B->r;
+  if (d >= margin) return 0;
+  for (int k = 0; k < 3; k++) {
+    nrm[k] = n[k];
+    pos[k] = 0.5 * ((pa[k] + A->r * n[k]) + (pb[k] - B->r * n[k]));
+  }
+  *dist = d;
+  return 1;
+}

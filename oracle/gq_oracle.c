@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include "gq.h"
+#include "gq_convex.h"
 
 #define NQ 19
 #define NV 18
@@ -823,6 +824,20 @@ int gqo_test_box_box(const double* ca, const double* Ra, const double* ha, const
   return n;
 }
 
+/* test hook (tests/test_oracle_invariants.py): the convex routine on two shapes - clouds (h = NULL) or analytic boxes (V = NULL).
+ * out: dist, pos[3], nrm[3], GJK iterations, EPA iterations */
+int gqo_test_convex(const double* VA, int na, const double* hA, const double* RA, const double* tA, double rA,
+                    const double* VB, int nb, const double* hB, const double* RB, const double* tB, double rB, double margin, double* out) {
+  Cvx A, B;
+  memset(&A, 0, sizeof A); memset(&B, 0, sizeof B);
+  A.box = VA == NULL; A.V = VA; A.nv = na; A.r = rA; memcpy(A.R, RA, sizeof A.R); memcpy(A.t, tA, sizeof A.t); if (hA) memcpy(A.h, hA, sizeof A.h);
+  B.box = VB == NULL; B.V = VB; B.nv = nb; B.r = rB; memcpy(B.R, RB, sizeof B.R); memcpy(B.t, tB, sizeof B.t); if (hB) memcpy(B.h, hB, sizeof B.h);
+  int it[2] = {0, 0};
+  const int rc = cvx_pair(&A, &B, margin, out, out + 4, out + 1, it);
+  out[7] = it[0]; out[8] = it[1];
+  return rc;
+}
+
 /* a robot collision geom as a primitive for the pair routines: 1 sphere / capsule (world end points, radius), 2 box (world
  * centre, axes, half sizes), 0 anything else (cylinders, hulls: capsule proxy / vertex cloud) */
 typedef struct { int kind; double p0[3], p1[3], r, c[3], R[9], h[3]; } Prim;
@@ -918,11 +933,12 @@ static void gqo_collision(GqOracle* o) {
       }
     } else { /* sphere: exact; mesh (and anything else): the support vertex of the cloud */
       double best = 1e300, second = 1e300, bw[3] = {0, 0, 0};
+      int vbest = 0;
       for (int v = 0; v < nv; v++) {
         double w[3];
         mulmatvec3(w, gm, V + 3 * v);
         const double dv = w[2] + gp[2] - r;
-        if (dv < best) { second = best; best = dv; for (int k = 0; k < 3; k++) bw[k] = w[k] + gp[k]; }
+        if (dv < best) { second = best; best = dv; vbest = v; for (int k = 0; k < 3; k++) bw[k] = w[k] + gp[k]; }
         else if (dv < second) second = dv;
       }
       if (best < margin) {
@@ -930,6 +946,24 @@ static void gqo_collision(GqOracle* o) {
         for (int k = 0; k < 3; k++) ppos[0][k] = bw[k] - normal[k] * (r + 0.5 * best);
         np = 1;
         tiegap = second - best;
+        /* mjc_PlaneConvex, mesh geoms: after the support vertex, the vertices the hull graph joins to it are tried in the graph's
+         * order and those within the margin become contacts too, until the pair has three (GqModelDesc.vert_adj*: the hull's edge
+         * graph; neighbours by ascending vertex index) */
+        if (m->vert_adjnum && m->vert_adjadr && m->vert_adj) {
+          const int va = m->cloud_vertadr[cl] + vbest;
+          for (int q = 0; q < m->vert_adjnum[va] && np < 3; q++) {
+            const int u = m->vert_adj[m->vert_adjadr[va] + q];
+            double w[3];
+            mulmatvec3(w, gm, V + 3 * u);
+            const double du = w[2] + gp[2] - r;
+            if (fabs(du - margin) < tiegap) tiegap = fabs(du - margin);
+            if (du >= margin) continue;
+            pdist[np] = du;
+            for (int k = 0; k < 3; k++) ppos[np][k] = w[k] + gp[k] - normal[k] * (r + 0.5 * du);
+            np++;
+          }
+          /* a tie for the support vertex changes the whole manifold, a neighbour at the margin changes its size: both are 'tie' envs */
+        }
       }
     }
     for (int q = 0; q < np && o->ncon < NCON; q++) {
@@ -968,6 +1002,21 @@ static void gqo_collision(GqOracle* o) {
           set_frame(c, pts[q].nrm, NULL);
           contact_param(o, w, g, c);
         }
+        continue;
+      }
+      if (!is_foot(m, g)) { /* hull / cylinder clouds: MuJoCo's general convex routine (mjc_Convex), one contact per pair - gq_convex.h */
+        Cvx A, B;
+        memset(&A, 0, sizeof A); memset(&B, 0, sizeof B);
+        A.box = 1; memcpy(A.R, bm, sizeof A.R); memcpy(A.t, bp, sizeof A.t); memcpy(A.h, bs, sizeof A.h);
+        B.V = m->vert_pos + 3 * m->cloud_vertadr[cl]; B.nv = m->cloud_vertnum[cl]; B.r = r;
+        memcpy(B.R, o->geom_xmat[g], sizeof B.R); memcpy(B.t, o->geom_xpos[g], sizeof B.t);
+        double dist, nrm[3], pos[3];
+        if (!cvx_pair(&A, &B, margin, &dist, nrm, pos, NULL)) continue;
+        Contact* c = &o->contact[o->ncon++];
+        c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = dist; c->tiegap = 1.0;
+        memcpy(c->pos, pos, sizeof c->pos);
+        set_frame(c, nrm, NULL);
+        contact_param(o, w, g, c);
         continue;
       }
       double best = 1e300, second = 1e300, bn[3] = {0, 0, 1}, bv[3] = {0, 0, 0};
@@ -1057,6 +1106,32 @@ static void gqo_collision(GqOracle* o) {
           set_frame(c, nrm, NULL);
           contact_param_pair(o, g1, g2, c);
         }
+        continue;
+      }
+    }
+    {
+      Prim P1, P2;
+      prim_of_geom(o, g1, &P1); prim_of_geom(o, g2, &P2);
+      if (P1.kind != 1 || P2.kind != 1) { /* a hull / cylinder (or a box against one): mjc_Convex on the two clouds, one contact - gq_convex.h */
+        const int c1 = m->geom_cloudid[g1], c2 = m->geom_cloudid[g2];
+        const double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+        { /* bounding spheres (mj_collision's broad phase) */
+          double dc[3] = {o->geom_xpos[g2][0] - o->geom_xpos[g1][0], o->geom_xpos[g2][1] - o->geom_xpos[g1][1], o->geom_xpos[g2][2] - o->geom_xpos[g1][2]};
+          if (sqrt(dot3(dc, dc)) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue;
+        }
+        Cvx A, B;
+        memset(&A, 0, sizeof A); memset(&B, 0, sizeof B);
+        A.V = m->vert_pos + 3 * m->cloud_vertadr[c1]; A.nv = m->cloud_vertnum[c1]; A.r = m->cloud_radius[c1];
+        memcpy(A.R, o->geom_xmat[g1], sizeof A.R); memcpy(A.t, o->geom_xpos[g1], sizeof A.t);
+        B.V = m->vert_pos + 3 * m->cloud_vertadr[c2]; B.nv = m->cloud_vertnum[c2]; B.r = m->cloud_radius[c2];
+        memcpy(B.R, o->geom_xmat[g2], sizeof B.R); memcpy(B.t, o->geom_xpos[g2], sizeof B.t);
+        double dist, nrm[3], pos[3];
+        if (!cvx_pair(&A, &B, margin, &dist, nrm, pos, NULL)) continue;
+        Contact* c = &o->contact[o->ncon++];
+        c->geom = g2; c->body = b2; c->geom1 = g1; c->body1 = b1; c->dist = dist; c->tiegap = 1.0;
+        memcpy(c->pos, pos, sizeof c->pos);
+        set_frame(c, nrm, NULL);
+        contact_param_pair(o, g1, g2, c);
         continue;
       }
     }

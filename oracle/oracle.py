@@ -18,8 +18,8 @@ _LIB = None
 
 def build(force=False):
     so = _HERE / 'libgq_oracle.so'
-    src = _HERE / 'gq_oracle.c'
-    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+    srcs = [_HERE / 'gq_oracle.c', _HERE / 'gq_convex.h', _HERE.parent / 'include' / 'gq.h']
+    if force or not so.exists() or so.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
         subprocess.run(['make', '-C', str(_HERE), '-B' if force else '-s'], check=True, capture_output=True)
     return so
 

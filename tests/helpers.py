@@ -30,7 +30,7 @@ DBG_SIZE = _o
 
 
 def marshalled(robot='mini_cheetah', solver=0, iterations=100, tolerance=1e-8, timestep=0.002,
-               terrain_limits=(1e4, -1e4, 1e4, -1e4), noise_floor=0.0, boxes=None, hfield=None, self_collision=None):
+               terrain_limits=(1e4, -1e4, 1e4, -1e4), noise_floor=0.0, boxes=None, hfield=None, self_collision=None, mesh_graph=True):
     cfg = get_robot_config(robot)
     md = load_compiled(Path(cfg.mjcf_filename).stem)
     qpos0 = md.qpos0.copy()
@@ -38,7 +38,7 @@ def marshalled(robot='mini_cheetah', solver=0, iterations=100, tolerance=1e-8, t
         qpos0[7:] = np.asarray(cfg.qpos0_js, dtype=np.float64)
     return MarshalledModel(md, qpos0=qpos0, feet_geom_names=cfg.feet_geom_names, terrain_limits=terrain_limits,
                            timestep=timestep, solver=solver, iterations=iterations, tolerance=tolerance,
-                           noise_floor=noise_floor, boxes=boxes, hfield=hfield, self_collision=self_collision)
+                           noise_floor=noise_floor, boxes=boxes, hfield=hfield, self_collision=self_collision, mesh_graph=mesh_graph)
 
 
 def random_states(md, n, rng, z_range=(0.18, 0.45), contact_bias=True):

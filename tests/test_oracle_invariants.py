@@ -88,7 +88,7 @@ def test_static_stance_carries_the_weight(robot):
         o.step(np.zeros(12))
     fn = []
     for _ in range(200):   # the unactuated robot may still be creeping: average the normal force
-        o.step(np.zeros(12)); fn.append(o.contact_force[:, 0].sum())
+        o.step(np.zeros(12)); fn.append(o.contact_force[:o.ncon, 0][o.contact_geom1[:o.ncon] < 0].sum())   # (contacts with the WORLD: robot-robot forces are internal)
     assert np.abs(o.qvel).max() < 1.0
     assert abs(np.mean(fn) - md.total_mass * 9.81) < 0.03 * md.total_mass * 9.81
 
@@ -286,8 +286,9 @@ def test_flat_height_field_is_a_raised_floor(robot):
     """A height field with constant elevation H under the robot must give exactly the dynamics of the floor plane H lower
     (sphere-triangle and vertex-plane distances degenerate to the plane's, normal +z, default geom parameters)."""
     H = 1.37
-    mmF = marshalled(robot, solver=1, iterations=100, tolerance=1e-12)
-    mmH = marshalled(robot, solver=1, iterations=100, tolerance=1e-12, hfield=_plane_hfield(H))
+    # (mesh_graph off: a mesh keeps ONE contact with the height field, so the floor side is held to its support vertex as well)
+    mmF = marshalled(robot, solver=1, iterations=100, tolerance=1e-12, mesh_graph=False)
+    mmH = marshalled(robot, solver=1, iterations=100, tolerance=1e-12, hfield=_plane_hfield(H), mesh_graph=False)
     oF, oH = Oracle(mmF), Oracle(mmH)
     rng = np.random.default_rng(19)
     hip = float(mmF.desc.key_qpos[2])
@@ -568,3 +569,268 @@ def test_box_box_routine_properties():
                 faces += 1
                 np.testing.assert_allclose(np.sort(d), np.sort(np.full(4, d[0])), atol=2e-3)      # four bottom corners at (nearly) one depth
     assert flat > 100 and faces >= 0.8 * flat
+
+
+# ------------------------------------------------------------------ convex narrow phase (oracle/gq_convex.h: GJK + EPA)
+def _cvx_lib():
+    import ctypes as C
+    from oracle.oracle import lib
+    L = lib()
+    L.gqo_test_convex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double] * 2 + [C.c_double, C.c_void_p]
+    return L
+
+
+def convex_oracle(VA, hA, RA, tA, rA, VB, hB, RB, tB, rB, margin):
+    """(found, dist, pos, nrm, gjk iterations, epa iterations) of the oracle's convex routine; V = None: an analytic box of half extents h."""
+    import ctypes as C
+    L = _cvx_lib()
+    arrs = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (VA, hA, RA, tA, VB, hB, RB, tB)]
+    p = [None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrs]
+    out = np.zeros(9)
+    rc = L.gqo_test_convex(p[0], 0 if arrs[0] is None else len(arrs[0]), p[1], p[2], p[3], float(rA),
+                           p[4], 0 if arrs[4] is None else len(arrs[4]), p[5], p[6], p[7], float(rB), float(margin), out.ctypes.data_as(C.c_void_p))
+    return rc, out[0], out[1:4].copy(), out[4:7].copy(), int(out[7]), int(out[8])
+
+
+def _closest_on_triangle_to_origin(a, b, c):
+    ab, ac = b - a, c - a
+    d1, d2 = -(ab @ a), -(ac @ a)
+    if d1 <= 0 and d2 <= 0:
+        return a
+    d3, d4 = -(ab @ b), -(ac @ b)
+    if d3 >= 0 and d4 <= d3:
+        return b
+    vc = d1 * d4 - d3 * d2
+    if vc <= 0 and d1 >= 0 and d3 <= 0:
+        return a + d1 / (d1 - d3) * ab
+    d5, d6 = -(ab @ c), -(ac @ c)
+    if d6 >= 0 and d5 <= d6:
+        return c
+    vb = d5 * d2 - d1 * d6
+    if vb <= 0 and d2 >= 0 and d6 <= 0:
+        return a + d2 / (d2 - d6) * ac
+    va = d3 * d6 - d5 * d4
+    if va <= 0 and d4 - d3 >= 0 and d5 - d6 >= 0:
+        return b + (d4 - d3) / ((d4 - d3) + (d5 - d6)) * (c - b)
+    den = 1.0 / (va + vb + vc)
+    return a + ab * vb * den + ac * vc * den
+
+
+def minkowski_truth(WA, WB):
+    """Exact signed distance and separating direction of two polytopes given by their world vertices, by brute force: the convex hull of
+    ALL pairwise differences a - b (scipy / qhull).  Origin inside: -(distance to the nearest facet plane) = minus the penetration depth
+    (the shortest translation that separates the shapes), normal = that facet's; outside: the distance to the nearest point of the
+    nearest facet, normal towards the origin."""
+    from scipy.spatial import ConvexHull
+    D = (WA[:, None, :] - WB[None, :, :]).reshape(-1, 3)
+    h = ConvexHull(D)
+    if np.all(h.equations[:, 3] <= 0):
+        k = int(np.argmax(h.equations[:, 3]))
+        return float(h.equations[k, 3]), h.equations[k, :3].copy(), float(np.sort(h.equations[:, 3])[-1] - np.unique(np.round(h.equations[:, 3], 12))[-2] if len(np.unique(np.round(h.equations[:, 3], 12))) > 1 else 1.0)
+    best, bq = 1e300, None
+    for s in h.simplices:
+        q = _closest_on_triangle_to_origin(*D[s])
+        if q @ q < best:
+            best, bq = q @ q, q
+    d = float(np.sqrt(best))
+    return d, -bq / d, 1.0
+
+
+def _box_corners(h):
+    return np.array([[sx * h[0], sy * h[1], sz * h[2]] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)], dtype=np.float64)
+
+
+def _support(W, n):
+    return float((W @ n).max())
+
+
+def _check_convex_against_truth(VA, hA, RA, tA, rA, VB, hB, RB, tB, rB, margin, tol=1e-9, ang_tol_deg=1e-3):
+    WA = (_box_corners(hA) if VA is None else VA) @ RA.T + tA
+    WB = (_box_corners(hB) if VB is None else VB) @ RB.T + tB
+    d, n, gap = minkowski_truth(WA, WB)
+    dd = d - rA - rB
+    rc, dist, pos, nrm, git, eit = convex_oracle(VA, hA, RA, tA, rA, VB, hB, RB, tB, rB, margin)
+    if dd >= margin + 1e-9:
+        assert rc == 0
+        return None
+    if dd >= margin - 1e-9:
+        return None
+    assert rc == 1
+    assert abs(dist - dd) < tol, (dist, dd)
+    # depth / distance is the support-function gap along the reported normal: h_A(n) + h_B(-n) = -dist_core
+    assert abs(_support(WA, nrm) + _support(WB, -nrm) + (dist + rA + rB)) < 10 * tol
+    if gap > 1e-6:   # the separating direction is unique unless two facets of A - B are equally near
+        ang = np.degrees(np.arccos(np.clip(nrm @ n, -1, 1)))
+        assert ang < ang_tol_deg, (ang, dist, dd)
+    # the contact point lies midway between the two surfaces: half the (signed) distance from A's support plane along the normal
+    sa = _support(WA, nrm) + rA
+    assert abs(pos @ nrm - (sa + 0.5 * dist)) < 10 * tol
+    # ... and inside both shapes' slabs in every facet direction of the other (a point of the overlap region / the gap's mid-plane)
+    return dist, git, eit
+
+
+def test_convex_routine_against_the_minkowski_hull_random_polytopes():
+    """mjc_Convex as restated in oracle/gq_convex.h (GJK distance, EPA penetration) against brute force: random polytopes of 4 - 60
+    vertices, pairs of clouds and cloud - analytic box, separated within the margin, touching and overlapping up to the full size of the
+    shapes, with and without an inflation radius.  Distance / depth to 1e-9 m, normal to 1e-3 degree."""
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(0)
+    n_contact, its = 0, []
+    for trial in range(400):
+        VA = rng.normal(size=(rng.integers(4, 60), 3)) * rng.uniform(0.02, 0.15, size=3)
+        if trial % 2 == 0:
+            VB, hB = None, rng.uniform(0.05, 0.5, size=3)
+        else:
+            VB, hB = rng.normal(size=(rng.integers(4, 60), 3)) * rng.uniform(0.02, 0.15, size=3), None
+        RA, RB = (Rot.random(random_state=int(rng.integers(1 << 30))).as_matrix() for _ in range(2))
+        tB = rng.normal(size=3) * rng.choice([0.05, 0.15, 0.3, 0.6])
+        r = _check_convex_against_truth(VA, None, RA, np.zeros(3), float(rng.choice([0.0, 0.01])), VB, hB, RB, tB, 0.0, margin=0.02)
+        if r is not None:
+            n_contact += 1; its.append(r[1:])
+    its = np.asarray(its)
+    assert n_contact > 150 and its[:, 0].max() <= 12 and its[:, 1].max() <= 24, (n_contact, its.max(0))
+
+
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'hyqreal1', 'spot', 'go1'])
+def test_convex_routine_on_the_robots_own_hulls(robot):
+    """The same pin on the geometry the step sees: every mesh / cylinder cloud of the robot against a world box (analytic) and against
+    another of the robot's clouds, at random relative poses from 2 cm apart to 3 cm deep."""
+    from scipy.spatial.transform import Rotation as Rot
+    md = marshalled(robot, solver=1).md
+    clouds = [c for c in range(len(md.cloud_vertnum)) if md.cloud_vertnum[c] >= 8]
+    assert clouds
+    rng = np.random.default_rng(5)
+    n_contact = n_deep = 0
+    for trial in range(100):
+        ca = clouds[trial % len(clouds)]
+        VA = md.vert_pos[md.cloud_vertadr[ca]:md.cloud_vertadr[ca] + md.cloud_vertnum[ca]]
+        if trial % 2 == 0:
+            VB, hB = None, rng.uniform(0.1, 0.6, size=3)
+        else:
+            cb = clouds[int(rng.integers(len(clouds)))]
+            VB, hB = md.vert_pos[md.cloud_vertadr[cb]:md.cloud_vertadr[cb] + md.cloud_vertnum[cb]], None
+        RA, RB = (Rot.random(random_state=int(rng.integers(1 << 30))).as_matrix() for _ in range(2))
+        WA = VA @ RA.T
+        WB0 = (_box_corners(hB) if VB is None else VB) @ RB.T
+        # place B 5 cm away along a random direction, then move it in along the (oracle's) separating direction until the shapes are
+        # `want` apart - or, want < 0, overlap by at most that much; the final configuration is judged by brute force below
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        want = rng.uniform(-0.03, 0.012)
+        tB = u * (_support(WA, u) + _support(WB0, -u) + 0.05)
+        rc0, d0, _, n0, _, _ = convex_oracle(VA, None, RA, np.zeros(3), 0.0, VB, hB, RB, tB, 0.0, 10.0)
+        assert rc0 == 1 and d0 >= 0.05 - 1e-9
+        tB = tB - (d0 - want) * n0
+        r = _check_convex_against_truth(VA, None, RA, np.zeros(3), 0.0, VB, hB, RB, tB, 0.0, margin=0.01, tol=1e-9)
+        if r is not None:
+            n_contact += 1; n_deep += r[0] < -1e-3
+    assert n_contact >= 60 and n_deep >= 30, (n_contact, n_deep)
+
+
+def test_convex_routine_degenerate_configurations():
+    """Aligned boxes face to face (the separating direction is a whole facet: depth and normal are unique, the point is not), a box
+    corner on a face, exactly touching shapes (distance 0), a capsule core (2 vertices + radius) through a box, a sphere core (1 vertex)
+    inside a hull, nested shapes."""
+    I = np.eye(3)
+    cube = _box_corners([0.1, 0.1, 0.1])
+    # face to face, 2 mm deep, both as cloud - cloud and as box - cloud
+    for VA, hA in ((cube, None), (None, np.array([0.1, 0.1, 0.1]))):
+        rc, dist, pos, nrm, _, _ = convex_oracle(VA, hA, I, np.zeros(3), 0.0, cube, None, I, np.array([0.0, 0.0, 0.198]), 0.0, 0.001)
+        assert rc == 1 and abs(dist + 0.002) < 1e-12 and np.allclose(nrm, [0, 0, 1], atol=1e-9) and abs(pos[2] - 0.099) < 1e-9
+        assert abs(pos[0]) <= 0.1 + 1e-9 and abs(pos[1]) <= 0.1 + 1e-9
+    # exactly touching (distance 0 < margin): a contact with dist 0 and the face normal
+    rc, dist, pos, nrm, _, _ = convex_oracle(cube, None, I, np.zeros(3), 0.0, cube, None, I, np.array([0.0, 0.0, 0.2]), 0.0, 0.001)
+    assert rc == 1 and abs(dist) < 1e-12 and abs(abs(nrm[2]) - 1) < 1e-6
+    # separated by exactly the margin: no contact
+    rc = convex_oracle(cube, None, I, np.zeros(3), 0.0, cube, None, I, np.array([0.0, 0.0, 0.2011]), 0.0, 0.001)[0]
+    assert rc == 0
+    # a corner of a rotated cube 1 mm into the top face of a big analytic box
+    from scipy.spatial.transform import Rotation as Rot
+    R = Rot.from_euler('xyz', [np.arctan(np.sqrt(2)), 0, np.pi / 4]).as_matrix() @ Rot.from_euler('z', 0.3).as_matrix()
+    low = (cube @ R.T)[:, 2].min()
+    rc, dist, pos, nrm, _, _ = convex_oracle(None, np.array([1.0, 1.0, 0.5]), I, np.zeros(3), 0.0, cube, None, R, np.array([0.1, -0.2, 0.5 - low - 0.001]), 0.0, 0.001)
+    assert rc == 1 and abs(dist + 0.001) < 1e-12 and np.allclose(nrm, [0, 0, 1], atol=1e-9) and abs(pos[2] - 0.4995) < 1e-9
+    # capsule core through a box: depth = radius + distance of the axis to the nearest face
+    seg = np.array([[0.0, 0.0, -0.3], [0.0, 0.0, 0.3]])
+    Ry = Rot.from_euler('y', np.pi / 2).as_matrix()
+    rc, dist, pos, nrm, _, _ = convex_oracle(None, np.array([0.2, 0.2, 0.05]), I, np.zeros(3), 0.0, seg, None, Ry, np.array([0.0, 0.0, 0.03]), 0.02, 0.0)
+    assert rc == 1 and abs(dist + (0.02 + 0.02)) < 1e-12 and np.allclose(nrm, [0, 0, 1], atol=1e-9)
+    # sphere core inside a hull: leaves through the nearest facet
+    rc, dist, pos, nrm, _, _ = convex_oracle(cube, None, I, np.zeros(3), 0.0, np.zeros((1, 3)), None, I, np.array([0.07, 0.01, -0.02]), 0.01, 0.0)
+    assert rc == 1 and abs(dist + (0.03 + 0.01)) < 1e-12 and np.allclose(nrm, [1, 0, 0], atol=1e-9)
+    # nested: a small cube at the centre of a big one - six equally near facets, any of them is a valid answer
+    rc, dist, pos, nrm, _, _ = convex_oracle(_box_corners([0.5, 0.5, 0.5]), None, I, np.zeros(3), 0.0, cube, None, I, np.zeros(3), 0.0, 0.0)
+    assert rc == 1 and abs(dist + 0.6) < 1e-12 and abs(np.abs(nrm).max() - 1) < 1e-9
+
+
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'hyqreal1', 'spot'])
+def test_mesh_plane_manifold_follows_the_hull_graph(robot):
+    """mjc_PlaneConvex as restated in gqo_collision: the first contact of a mesh geom with the floor is the hull's support vertex (the
+    lowest vertex, brute force), the others are neighbours of that vertex in the hull's edge graph that lie within the margin, in the
+    graph's order, at most three in all; every contact point lies on the vertical through its vertex, midway to the floor."""
+    from gym_quadruped_amd.cabi import hull_graphs
+    mm = marshalled(robot, solver=1, self_collision=False)
+    md, o = mm.md, Oracle(mm)
+    adr, num, adj = hull_graphs(md)
+    rng = np.random.default_rng(23)
+    hip = float(mm.desc.key_qpos[2])
+    Q = _lying_states(md, 200, rng, (0.02, 0.5 * hip))
+    n_multi = n_geom = 0
+    for q in Q:
+        o.set_state(q, np.zeros(18), np.zeros(18), np.zeros(18)); o.forward(np.zeros(12), stage=1)
+        if not o.ncon:
+            continue
+        geoms, dist, pos = o.get('contact_geom').astype(int), o.get('contact_dist'), o.contact_pos
+        gx, gm = o.geom_xpos, o.geom_xmat
+        for g in np.unique(geoms):
+            if int(md.geom_type[g]) != 7:
+                continue
+            idx = np.nonzero(geoms == g)[0]
+            assert 1 <= len(idx) <= 3 and np.all(np.diff(idx) == 1)
+            cl = md.geom_cloudid[g]
+            a = int(md.cloud_vertadr[cl])
+            V = md.vert_pos[a:a + md.cloud_vertnum[cl]]
+            W = V @ gm[g].T + gx[g]
+            margin = max(float(md.geom_margin[g]), 0.0)
+            v0 = int(np.argmin(W[:, 2]))
+            assert abs(dist[idx[0]] - W[v0, 2]) < 1e-12
+            nb = [int(u) for u in adj[adr[a + v0]:adr[a + v0] + num[a + v0]]]
+            assert nb == sorted(nb) and v0 not in nb
+            expect = [v0] + [u for u in nb if W[u, 2] < margin][:2]
+            assert len(idx) == len(expect)
+            for c, u in zip(idx, expect):
+                np.testing.assert_allclose(pos[c], [W[u, 0], W[u, 1], 0.5 * W[u, 2]], atol=1e-12)
+                assert abs(dist[c] - W[u, 2]) < 1e-12
+            n_geom += 1; n_multi += len(idx) > 1
+    assert n_geom > 100 and n_multi > 20, (n_geom, n_multi)
+
+
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'hyqreal1', 'spot'])
+def test_hull_graph_is_the_edge_graph_of_the_hull(robot):
+    """cabi.hull_graphs: symmetric, no self loops, every vertex of a mesh cloud has at least three neighbours, and a vertex is the
+    support vertex of a direction exactly when none of its neighbours is higher along it (local = global maximum on a convex polytope:
+    the property mjc_PlaneConvex's neighbour walk relies on)."""
+    from gym_quadruped_amd.cabi import hull_graphs
+    md = marshalled(robot, solver=1).md
+    adr, num, adj = hull_graphs(md)
+    rng = np.random.default_rng(3)
+    meshes = {int(md.geom_cloudid[g]) for g in range(md.ngeom) if md.geom_cloudid[g] >= 0 and md.geom_type[g] == 7}
+    assert meshes
+    for cl in meshes:
+        a, n = int(md.cloud_vertadr[cl]), int(md.cloud_vertnum[cl])
+        V = md.vert_pos[a:a + n]
+        nb = [set(int(u) for u in adj[adr[a + v]:adr[a + v] + num[a + v]]) for v in range(n)]
+        assert all(len(s) >= 3 and v not in s for v, s in enumerate(nb))
+        assert all(v in nb[u] for v, s in enumerate(nb) for u in s)
+        for _ in range(200):
+            d = rng.normal(size=3)
+            pr = V @ d
+            v = int(np.argmax(pr))
+            assert all(pr[u] <= pr[v] for u in nb[v])
+            # hill climbing from a random start ends on the support vertex
+            w = int(rng.integers(n))
+            for _ in range(n):
+                u = max(nb[w], key=lambda k: pr[k])
+                if pr[u] <= pr[w]:
+                    break
+                w = u
+            assert pr[w] >= pr[v] - 1e-12
