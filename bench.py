@@ -82,7 +82,7 @@ def kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     # the DEVICE side of the step kernel (and the flags it is built with): the host API / model lowering do not move its traffic
-    for name in ('Makefile', 'gq_boxes.h', 'gq_device.h', 'gq_heightmap.h', 'gq_kernels.hip', 'gq_model_dev.h', 'gq_newton.h', 'gq_pairs.h', 'gq_step_body.h', 'gq_step_kernel.h'):
+    for name in ('Makefile', 'gq_boxes.h', 'gq_convex.h', 'gq_device.h', 'gq_heightmap.h', 'gq_kernels.hip', 'gq_model_dev.h', 'gq_newton.h', 'gq_pairs.h', 'gq_step_body.h', 'gq_step_kernel.h'):
         h.update((ROOT / 'gym_quadruped_amd' / 'csrc' / name).read_bytes())
     return h.hexdigest()[:16]
 

@@ -16,6 +16,7 @@
 #pragma once
 #include "gq_step_kernel.h"
 #include "gq_pairs.h"
+#include "gq_convex.h"
 
 namespace gq {
 
@@ -30,6 +31,14 @@ namespace gq {
  * radius (stage_box_contacts writes them once per step; rows 0 - 27 of the J block, free until the self-collision pass behind the box loop) */
 #define GQ_BX_OBBW 13
 #define GQ_BX_OBB(W) (&(W).u.B[0][0])
+/* scratch of the convex routine (gq_convex.h): the two shape descriptors + the result in the factor block behind GQ_BX_WCLS (48 words, both
+ * phases); its polytope (200 words) in rows 28 - 39 of the J block during the world-box loop (between the clouds' boxes and GQ_BX_ISPH) and in
+ * rows 38 - 49 during the self-collision pass (behind its end-point table and pair list; GQ_BX_ISPH / GQ_BX_PSPH are dead by then) */
+#define GQ_CVX_SHP(W) ((LdsF)&(W).F[0][44])
+#define GQ_CVX_POLY_BOX(W) ((LdsF)&(W).u.B[28][0])
+#define GQ_CVX_POLY_SELF(W) ((LdsF)&(W).u.B[38][0])
+static_assert(GQ_BX_OBBW * GQ_MAXLG <= 28 * GQ_NVD && 28 * GQ_NVD + GQ_CVX_POLY_WORDS <= 40 * GQ_NVD && 38 * GQ_NVD + GQ_CVX_POLY_WORDS <= 64 * GQ_NVD && 44 + GQ_CVX_SHP_WORDS <= GQ_FACTOR_SIZE,
+              "scratch of the convex routine");
 
 /* sphere of radius r centred at c (box frame) against a box of half extents s: signed distance, outward normal n (box frame) */
 __device__ __forceinline__ float sphere_box(V3 c, V3 s, float r, V3& n) {
@@ -190,75 +199,35 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
     dist = 1e30f; nrm = v3(0.0f, 0.0f, 1.0f); pt = v3(0.0f, 0.0f, 0.0f);
     if ((todo | ballot(foot_near) | ballot(prim_near)) == 0) return false;
   }
-  while (todo) { /* wave-uniform */
+  if (todo) { /* wave-uniform: the world box as shape A of the convex routine (mjc_Convex: box = geom 1, the normal points out of it) */
+    CvxShape A;
+    A.kind = 1; A.adr = 0; A.num = 0; A.pm = -1; A.t = bp; A.h = bs; A.r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) A.R[i] = B.mat[i];
+    wave_barrier();
+    cvx_shape_store(GQ_CVX_SHP(W), A);
+  }
+  while (todo) { /* wave-uniform: one hull / cylinder cloud against the box - GJK + EPA on the wavefront (gq_convex.h) */
     const int g = ffs64(todo);
     todo &= todo - 1;
     const GQ_MODEL GqDevGeom& G = m.lg[g];
     const float* Rb = W.xmat[G.body];
-    /* vertex -> box frame: p = A v + t, A = Bmat' Rb Rg, t = Bmat' (xpos + Rb gpos - bpos) */
-    float RbRg[9], A[9];
+    CvxShape S;
+    S.kind = 0; S.adr = G.plane_adr; S.num = G.cloud_num; S.pm = G.pmask_adr; S.r = G.radius; S.h = v3(0.0f, 0.0f, 0.0f);
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = 0; j < 3; j++) RbRg[3 * i + j] = Rb[3 * i] * G.mat[j] + Rb[3 * i + 1] * G.mat[3 + j] + Rb[3 * i + 2] * G.mat[6 + j];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) A[3 * i + j] = B.mat[i] * RbRg[j] + B.mat[3 + i] * RbRg[3 + j] + B.mat[6 + i] * RbRg[6 + j];
-    const V3 og = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos)) - bp;
-    const V3 t = matTvec(B.mat, og);
-    float best = 1e30f;
-    V3 bn = v3(0.0f, 0.0f, 1.0f), bc = v3(0.0f, 0.0f, 0.0f);
-    /* large clouds (hull meshes of several hundred vertices): lane = 64-vertex chunk, its box (geom frame, host table) taken
-     * into the box frame and held against the world box; only chunks that can come within the contact margin are scanned.
-     * A vertex farther than the margin makes no contact and lifts nothing, so the result is the full scan's. */
-    uint64_t chunks = 1;
-    if (G.chunk_adr >= 0) { /* wave-uniform */
-      const int nchunk = (G.cloud_num + GQ_WAVE - 1) / GQ_WAVE;
-      bool keep = false;
-      if (lane < nchunk) {
-        const int ia = G.chunk_adr + 2 * lane;
-        const V3 cc = t + matvec(A, v3(vx[ia], vy[ia], vz[ia])), hh = v3(vx[ia + 1], vy[ia + 1], vz[ia + 1]);
-        const V3 ee = v3(fabsf(A[0]) * hh.x + fabsf(A[1]) * hh.y + fabsf(A[2]) * hh.z, fabsf(A[3]) * hh.x + fabsf(A[4]) * hh.y + fabsf(A[5]) * hh.z,
-                         fabsf(A[6]) * hh.x + fabsf(A[7]) * hh.y + fabsf(A[8]) * hh.z);
-        const V3 gap = v3(fmaxf(0.0f, fabsf(cc.x) - bs.x - ee.x), fmaxf(0.0f, fabsf(cc.y) - bs.y - ee.y), fmaxf(0.0f, fabsf(cc.z) - bs.z - ee.z));
-        keep = sqrtf(dot(gap, gap)) - G.radius < m.boxmix[B.cls][4 + g].margin + 1e-5f;
-      }
-      chunks = ballot(keep);
-    }
-    while (chunks) { /* wave-uniform: the vertex loads of up to BATCH chunks go out together - one memory round trip, not one per chunk (two:
-                      * hyqreal1 random_boxes 24.5 -> 25.0 M, three or four: 24.9 / 24.7; the pyramidal hull robots keep one - mini_cheetah
-                      * random_boxes 30.9 against 30.7 with two) */
-      int v0[BATCH];
-      V3 vv[BATCH];
-#pragma unroll
-      for (int u = 0; u < BATCH; u++) { v0[u] = chunks ? GQ_WAVE * ffs64(chunks) : -1; chunks &= chunks - 1; }
-#pragma unroll
-      for (int u = 0; u < BATCH; u++)
-        if (v0[u] >= 0) { /* wave-uniform */
-          const int ii = v0[u] + lane < G.cloud_num ? G.cloud_adr + v0[u] + lane : G.cloud_adr;
-          vv[u] = v3(vx[ii], vy[ii], vz[ii]);
-        }
-#pragma unroll
-      for (int u = 0; u < BATCH; u++)
-        if (v0[u] >= 0) {
-          const bool in = v0[u] + lane < G.cloud_num;
-          const V3 c = t + matvec(A, vv[u]);
-          V3 n;
-          const float dv = sphere_box(c, bs, G.radius, n);
-          if (in && dv < best) { best = dv; bn = n; bc = c; }
-        }
-    }
-    const float wmin = wave_min(best);
-    const int who = ffs64(ballot(best == wmin));
-    const V3 n_l = v3(bcast(bn.x, who), bcast(bn.y, who), bcast(bn.z, who));
-    const V3 c_l = v3(bcast(bc.x, who), bcast(bc.y, who), bcast(bc.z, who));
+      for (int j = 0; j < 3; j++) S.R[3 * i + j] = Rb[3 * i] * G.mat[j] + Rb[3 * i + 1] * G.mat[3 + j] + Rb[3 * i + 2] * G.mat[6 + j];
+    S.t = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos));
+    wave_barrier();
+    cvx_shape_store(GQ_CVX_SHP(W) + GQ_CVX_SHAPE_WORDS, S);
+    wave_barrier();
+    const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_BOX(W), vx, vy, vz, m.plane_grid, m.boxmix[B.cls][4 + g].margin);
     if (lane == 0) {
-      const V3 n_w = matvec(B.mat, n_l);
-      const V3 v_w = bp + matvec(B.mat, c_l);
-      W.u2.c.lg_dist[g] = wmin;
-      st3(W.u2.c.lg_pt[g], v_w - (G.radius + 0.5f * wmin) * n_w);
-      st3(GQ_BX_LGNRM(W) + 3 * g, n_w);
+      LdsCF out = GQ_CVX_SHP(W) + 2 * GQ_CVX_SHAPE_WORDS;
+      W.u2.c.lg_dist[g] = hit ? out[0] : 1e30f;
+      st3(GQ_BX_LGNRM(W) + 3 * g, ld3(out + 1));
+      st3(W.u2.c.lg_pt[g], ld3(out + 4));
     }
   }
   wave_barrier();
@@ -705,6 +674,48 @@ __device__ __forceinline__ SelfPrefetch self_prefetch(const GQ_MODEL GqDevModel&
   return P;
 }
 
+/* a collision item as a shape of the convex routine (wave-uniform): feet and sphere / capsule geoms are their cores (the world end points of
+ * the self-collision table + radius), everything else is its vertex cloud in the geom's frame */
+__device__ inline void self_item_shape(const WaveMem& W, const GQ_MODEL GqDevModel& m, const int it, const float* k, LdsF dst) {
+  CvxShape S;
+  const int pt = it < 4 ? 2 : m.lg[it - 4].ptype;
+  if (pt == 2 || pt == 3) {
+    S.kind = 2; S.adr = 0; S.num = 2; S.pm = -1; S.t = ld3(k); S.h = ld3(k + 3); S.r = k[6];
+#pragma unroll
+    for (int i = 0; i < 9; i++) S.R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+  } else {
+    const GQ_MODEL GqDevGeom& G = m.lg[it - 4];
+    const float* Rb = W.xmat[G.body];
+    S.kind = 0; S.adr = G.plane_adr; S.num = G.cloud_num; S.pm = G.pmask_adr; S.r = G.radius; S.h = v3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) S.R[3 * i + j] = Rb[3 * i] * G.mat[j] + Rb[3 * i + 1] * G.mat[3 + j] + Rb[3 * i + 2] * G.mat[6 + j];
+    S.t = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos));
+  }
+  cvx_shape_store(dst, S);
+}
+/* ... and its oriented bounding box for the mid phase (ONE lane): the cloud's geom-frame box grown by the radius; a core's world-axis box */
+__device__ inline void self_item_obb(const WaveMem& W, const GQ_MODEL GqDevModel& m, const int it, const float* k, V3& c, float* R, V3& h) {
+  const int pt = it < 4 ? 2 : m.lg[it - 4].ptype;
+  if (pt == 2 || pt == 3) {
+    const V3 p0 = ld3(k), p1 = ld3(k + 3);
+    c = 0.5f * (p0 + p1);
+    h = v3(0.5f * fabsf(p1.x - p0.x) + k[6], 0.5f * fabsf(p1.y - p0.y) + k[6], 0.5f * fabsf(p1.z - p0.z) + k[6]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+  } else {
+    const GQ_MODEL GqDevGeom& G = m.lg[it - 4];
+    const float* Rb = W.xmat[G.body];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) R[3 * i + j] = Rb[3 * i] * G.mat[j] + Rb[3 * i + 1] * G.mat[3 + j] + Rb[3 * i + 2] * G.mat[6 + j];
+    c = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos)) + matvec(R, ld3(G.aabb_c));
+    h = v3(G.aabb_h[0] + G.radius, G.aabb_h[1] + G.radius, G.aabb_h[2] + G.radius);
+  }
+}
+
 template <bool CONE, bool PRIM = true>
 __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre, const StepConsts& K, const int nlg) {
   constexpr int NP = PRIM ? 4 : 1; /* points per pair: only the exact pair routines return more than one */
@@ -793,6 +804,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     PairHit H;
     H.n = 0;
     int it1 = 0, it2 = 0;
+    bool cvx = false;
     if (cand) {
       const GQ_MODEL GqDevSelfPair& Pp = m.sp[p];
       it1 = Pp.it1; it2 = Pp.it2;
@@ -809,6 +821,11 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
           const V3 nrm = fast_rcp(len) * d;
           H.n = 1; H.dist[0] = dist; H.nrm[0] = nrm; H.pos[0] = c1 + (k1[6] + 0.5f * dist) * nrm;
         }
+      } else if (kind == 4) { /* a hull / cylinder is involved: the convex routine, one pair at a time below - here its mid phase, the two shapes' oriented boxes */
+        V3 c1, h1, c2, h2; float R1[9], R2[9];
+        self_item_obb(W, m, it1, k1, c1, R1, h1);
+        self_item_obb(W, m, it2, k2, c2, R2, h2);
+        cvx = !obb_apart(c1, R1, h1, c2, R2, h2, marg);
       } else if constexpr (PRIM) { /* a box is involved: exact routines (gq_pairs.h); the box of kind 1 / 3 is item 1, of kind 2 item 2 */
         const int ib = kind == 2 ? it2 : it1;
         bool continue_pair = true;
@@ -842,6 +859,23 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
 #pragma unroll
             for (int k = 0; k < 2; k++) H.nrm[k] = -1.0f * H.nrm[k];
           }
+        }
+      }
+    }
+    { /* the convex pairs that passed their mid phase, one after the other on the whole wavefront (gq_convex.h) */
+      uint64_t cm = ballot(cvx);
+      while (cm) { /* wave-uniform */
+        const int j = ffs64(cm);
+        cm &= cm - 1;
+        const int pj = bcast(p, j), i1 = bcast(it1, j), i2 = bcast(it2, j);
+        wave_barrier();
+        self_item_shape(W, m, i1, cw[i1], GQ_CVX_SHP(W));
+        self_item_shape(W, m, i2, cw[i2], GQ_CVX_SHP(W) + GQ_CVX_SHAPE_WORDS);
+        wave_barrier();
+        const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_SELF(W), K.vx, K.vy, K.vz, m.plane_grid, m.sp[pj].mix.margin);
+        if (hit && lane == j) {
+          LdsCF out = GQ_CVX_SHP(W) + 2 * GQ_CVX_SHAPE_WORDS;
+          H.n = 1; H.dist[0] = out[0]; H.nrm[0] = ld3(out + 1); H.pos[0] = ld3(out + 4);
         }
       }
     }
@@ -960,7 +994,7 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
     item_sphere(W, m, false, cg, rg);
     box_candidates(W, m, bx, by, 0.0f, cand, cg, rg);
     if (lane < GQ_MAXLG) { st3(GQ_BX_ISPH(W) + 4 * lane, cg); GQ_BX_ISPH(W)[4 * lane + 3] = rg; }
-    if constexpr (!PRIM) item_obb_store(W, m); /* hull robots: the clouds' oriented boxes for box_item_scan's second bounding test */
+    item_obb_store(W, m); /* the clouds' oriented boxes for box_item_scan's second bounding test */
   }
   wave_barrier();
 #pragma unroll 1
@@ -972,7 +1006,7 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
       PairHit H;
       const float* sph = GQ_BX_ISPH(W) + 4 * opaque_lane(lane < GQ_MAXLG ? lane : 0);
       const V3 cg = ld3(sph); const float rg = sph[3];
-      if (!box_item_scan<PRIM, CONE ? 2 : 1, !PRIM>(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, PL, H)) continue;
+      if (!box_item_scan<PRIM, 1, true>(W, m, vx, vy, vz, b, bx, by, 0.0f, cg, rg, PL, H)) continue;
       append_world_contacts<CONE, PRIM>(W, m, m.box[b].cls, mu_env, H, S);
       wave_barrier();
     }

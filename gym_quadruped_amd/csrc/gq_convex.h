@@ -1,0 +1,525 @@
+/*
+ * gq_convex.h - the general convex narrow phase of the step kernel: what MuJoCo's mjc_Convex computes for a pair of convex geoms
+ * (mj_collision inside mj_step, quadruped_env.py:271) - signed distance / penetration depth, the normal of the minimum translation
+ * and the point midway between the two witness points, ONE contact per pair (multiccd is off by default) - for the robot's mesh hulls
+ * and cylinders against the world boxes of a scene and against each other.  GJK for the distance of the un-inflated cores, the
+ * expanding polytope algorithm when they overlap; restated step for step in oracle/gq_convex.h (fp64), which is pinned against the
+ * exact Minkowski-difference hull (tests/test_oracle_invariants.py).
+ *
+ * One wavefront works on one pair:
+ *   support query   lane = vertex: the masked 64-vertex chunks of the hull's DIRECTION-ordered copy (the cube-map table of the plane
+ *                   narrow phase, GqDevGeom::pmask_adr: ~2 of up to 11 chunks hold the support vertex of a direction), DPP wave-max, the
+ *                   winner's coordinates by v_readlane; world boxes and sphere / capsule cores answer analytically
+ *   GJK simplex     wave-uniform arithmetic (<= 4 points kept in LDS)
+ *   EPA polytope    lane = face (<= 4 + 2 x 24 faces): closest face by DPP wave-min; the faces that see the new vertex grow as a
+ *                   connected patch by ballots over the faces' neighbour words; rim edges ranked by one wave prefix scan; the fan's
+ *                   faces take the freed lanes
+ * Scratch: 200 words of the idle J block (polytope vertices, face neighbours, rim list) and 48 of the idle factor block (the two
+ * shape descriptors, the result) - the caller says where, see gq_boxes.h.
+ */
+#pragma once
+#include "gq_step_kernel.h"
+
+namespace gq {
+
+#define GQ_CVX_GJK_MAXIT 32
+#define GQ_CVX_EPA_MAXIT 24
+#define GQ_CVX_MAXV 28                 /* polytope vertices: 4 + one per EPA iteration */
+#define GQ_CVX_MAXRIM 24
+#define GQ_CVX_POLY_WORDS (4 * GQ_CVX_MAXV + 64 + GQ_CVX_MAXRIM)  /* 200 */
+#define GQ_CVX_SHAPE_WORDS 20
+#define GQ_CVX_SHP_WORDS (2 * GQ_CVX_SHAPE_WORDS + 8)
+#define GQ_CVX_TOL_GJK 1e-6f           /* relative, on v.v - v.w */
+#define GQ_CVX_TOL_EPA 1e-8f           /* metres: a face whose support point lies no farther out is a face of A - B (the round-off of fp32 coordinates about the base is 6e-8; the usual exit is exact - the support vertex is already a vertex of the polytope) */
+
+/* a shape as the routine sees it (wave-uniform, in LDS): kind 0 vertex cloud [adr, adr + num) of the vertex arrays in the frame (R, t),
+ * pm = index of its direction-cell chunk masks or -1; kind 1 box, centre t, axes = columns of R, half extents h; kind 2 segment t .. h
+ * (capsule / sphere core, world end points).  r: the radius that inflates the core. */
+struct CvxShape { int kind, adr, num, pm; float R[9]; V3 t, h; float r; };
+/* the routine is a function of its own (one copy per kernel, two call sites): its scratch pointers carry the LDS address space in their
+ * type, or every access through them would be a FLAT instruction */
+typedef GQ_LDS float* LdsF;
+typedef const GQ_LDS float* LdsCF;
+typedef GQ_LDS int32_t* LdsI;
+typedef const GQ_LDS int32_t* LdsCI;
+__device__ __forceinline__ void st3l(LdsF p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ void cvx_shape_store(LdsF S, const CvxShape& s) { /* (every lane stores the same words) */
+  LdsI I = (LdsI)S;
+  I[0] = s.kind; I[1] = s.adr; I[2] = s.num; I[3] = s.pm;
+#pragma unroll
+  for (int i = 0; i < 9; i++) S[4 + i] = s.R[i];
+  st3l(S + 13, s.t); st3l(S + 16, s.h); S[19] = s.r;
+}
+
+struct CvxSup { V3 p; int id; };
+/* support point of the core of shape S in world direction d (wave-uniform in, wave-uniform out) */
+__device__ inline CvxSup cvx_support(LdsCF S, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const int grid, const V3 d) {
+  LdsCI I = (LdsCI)S;
+  const int kind = uniform(I[0]);
+  CvxSup o;
+  if (kind == 2) {
+    const V3 p0 = ld3(S + 13), p1 = ld3(S + 16);
+    const bool far = dot(d, p1 - p0) > 0.0f;
+    o.p = far ? p1 : p0; o.id = far ? 1 : 0;
+    return o;
+  }
+  LdsCF R = S + 4;
+  const V3 dl = matTvec(R, d), t = ld3(S + 13);
+  if (kind == 1) {
+    const V3 h = ld3(S + 16);
+    const V3 q = v3(dl.x < 0.0f ? -h.x : h.x, dl.y < 0.0f ? -h.y : h.y, dl.z < 0.0f ? -h.z : h.z);
+    o.id = (dl.x < 0.0f ? 1 : 0) | (dl.y < 0.0f ? 2 : 0) | (dl.z < 0.0f ? 4 : 0);
+    o.p = t + matvec(R, q);
+    return o;
+  }
+  const int lane = lane_id();
+  const int adr = uniform(I[1]), num = uniform(I[2]), pm = uniform(I[3]);
+  int cm = (1 << ((num + GQ_WAVE - 1) / GQ_WAVE)) - 1;
+  if (pm >= 0) { /* wave-uniform: the chunks that can hold the support vertex of dl (the cell formula of stage_collision_scan) */
+    const float ax_ = fabsf(dl.x), ay_ = fabsf(dl.y), az_ = fabsf(dl.z);
+    const int mx_ = (ax_ >= ay_ && ax_ >= az_) ? 0 : (ay_ >= az_ ? 1 : 2);
+    const float dm = mx_ == 0 ? dl.x : (mx_ == 1 ? dl.y : dl.z);
+    const float o0 = mx_ == 0 ? dl.y : dl.x, o1 = mx_ == 2 ? dl.y : dl.z;
+    const float inv = fast_rcp(fmaxf(fabsf(dm), 1e-30f));
+    const float hg = 0.5f * (float)grid;
+    const int iu = imin(imax((int)((o0 * inv + 1.0f) * hg), 0), grid - 1), iv = imin(imax((int)((o1 * inv + 1.0f) * hg), 0), grid - 1);
+    const int cell = ((mx_ * 2 + (dm > 0.0f ? 0 : 1)) * grid + iu) * grid + iv;
+    cm = uniform((int)vx[pm + cell]);
+  }
+  const int last = adr + num - 1;
+  float best = -3e38f;
+  V3 bp = v3(0.0f, 0.0f, 0.0f);
+  int bi = adr;
+  while (cm) { /* wave-uniform: up to four chunks with their twelve loads in flight together; lanes past the end re-read the last vertex */
+    int cu[4];
+    float px[4], py[4], pz[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { cu[u] = cm ? __builtin_ctz(cm) : -1; cm &= cm - 1; }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (cu[u] >= 0) {
+        const int i = adr + cu[u] * GQ_WAVE + lane, ii = i < last ? i : last;
+        px[u] = vx[ii]; py[u] = vy[ii]; pz[u] = vz[ii];
+      }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (cu[u] >= 0) {
+        const int i = adr + cu[u] * GQ_WAVE + lane, ii = i < last ? i : last;
+        const float pr = dl.x * px[u] + dl.y * py[u] + dl.z * pz[u];
+        if (pr > best) { best = pr; bp = v3(px[u], py[u], pz[u]); bi = ii; }
+      }
+  }
+  const float wmax = wave_max(best);
+  const int who = ffs64(ballot(best == wmax));
+  const V3 q = v3(bcast(bp.x, who), bcast(bp.y, who), bcast(bp.z, who));
+  o.id = bcast(bi, who) - adr;
+  o.p = t + matvec(R, q);
+  return o;
+}
+/* support point of A - B in direction d: w = s_A(d) - s_B(-d) and the packed vertex ids (one copy of the scan code per kernel) */
+struct CvxMink { V3 w; int id; };
+__device__
+#ifndef GQ_CVX_INLINE
+__attribute__((noinline))
+#endif
+CvxMink cvx_minkowski(LdsCF SA, LdsCF SB, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const int grid, const V3 d) {
+  const CvxSup a = cvx_support(SA, vx, vy, vz, grid, d), b = cvx_support(SB, vx, vy, vz, grid, -1.0f * d);
+  CvxMink o;
+  o.w = a.p - b.p; o.id = a.id | (b.id << 16);
+  return o;
+}
+/* the point of shape S that cvx_support returned with `id` */
+__device__ inline V3 cvx_point(LdsCF S, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const int id) {
+  LdsCI I = (LdsCI)S;
+  const int kind = uniform(I[0]);
+  if (kind == 2) return id ? ld3(S + 16) : ld3(S + 13);
+  LdsCF R = S + 4;
+  const V3 t = ld3(S + 13);
+  if (kind == 1) {
+    const V3 h = ld3(S + 16);
+    return t + matvec(R, v3((id & 1) ? -h.x : h.x, (id & 2) ? -h.y : h.y, (id & 4) ? -h.z : h.z));
+  }
+  const int i = uniform(I[1]) + id;
+  return t + matvec(R, v3(vx[i], vy[i], vz[i]));
+}
+
+/* closest point of a segment / triangle to the origin as barycentric weights (Ericson 5.1.2 / 5.1.5; oracle cvx_seg / cvx_tri).
+ * In DOUBLE precision on fp32 points: a simplex of A - B is routinely a sliver - two vertices of a mesh a few millimetres apart
+ * against a corner of a world box a metre away - and the weights of the nearest point are ratios of differences of products of its
+ * edge vectors; in fp32 the point came out 1.3e-4 m off on such a sliver (a tenth of the contact margin) and GJK stalled there.
+ * The arithmetic is wave-uniform and a few dozen operations per iteration; gfx950 issues v_fma_f64 at the fp32 rate. */
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 d3(V3 a) { D3 r = {(double)a.x, (double)a.y, (double)a.z}; return r; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { D3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 cross(D3 a, D3 b) { D3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; return r; }
+__device__ __forceinline__ void cvx_seg(D3 p0, D3 p1, double* lam) {
+  const D3 e = p1 - p0;
+  const double ee = dot(e, e), t = ee > 0.0 ? -dot(p0, e) / ee : 0.0;
+  const double tc = t <= 0.0 ? 0.0 : (t >= 1.0 ? 1.0 : t);
+  lam[0] = 1.0 - tc; lam[1] = tc;
+}
+__device__ inline void cvx_tri(D3 a, D3 b, D3 c, double* lam) {
+  const D3 ab = b - a, ac = c - a;
+  const double d1 = -dot(ab, a), d2 = -dot(ac, a);
+  lam[0] = lam[1] = lam[2] = 0.0;
+  if (d1 <= 0.0 && d2 <= 0.0) { lam[0] = 1.0; return; }
+  const double d3_ = -dot(ab, b), d4 = -dot(ac, b);
+  if (d3_ >= 0.0 && d4 <= d3_) { lam[1] = 1.0; return; }
+  const double vc = d1 * d4 - d3_ * d2;
+  if (vc <= 0.0 && d1 >= 0.0 && d3_ <= 0.0) { const double v = d1 / (d1 - d3_); lam[0] = 1.0 - v; lam[1] = v; return; }
+  const double d5 = -dot(ab, c), d6 = -dot(ac, c);
+  if (d6 >= 0.0 && d5 <= d6) { lam[2] = 1.0; return; }
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { const double w = d2 / (d2 - d6); lam[0] = 1.0 - w; lam[2] = w; return; }
+  const double va = d3_ * d6 - d5 * d4;
+  if (va <= 0.0 && (d4 - d3_) >= 0.0 && (d5 - d6) >= 0.0) { const double w = (d4 - d3_) / ((d4 - d3_) + (d5 - d6)); lam[1] = 1.0 - w; lam[2] = w; return; }
+  const double den = 1.0 / (va + vb + vc);
+  lam[1] = vb * den; lam[2] = vc * den; lam[0] = 1.0 - lam[1] - lam[2];
+}
+__device__ __forceinline__ V3 cvx_comb(const double* l, D3 a, D3 b, D3 c) {
+  return v3((float)(l[0] * a.x + l[1] * b.x + l[2] * c.x), (float)(l[0] * a.y + l[1] * b.y + l[2] * c.y), (float)(l[0] * a.z + l[1] * b.z + l[2] * c.z));
+}
+
+/* polytope vertex k in the scratch: w (3 words), ids (ia | ib << 16) */
+#define GQ_CVX_PW(P, k) ld3((P) + 4 * (k))
+#define GQ_CVX_PID(P, k) (((LdsCI)(P))[4 * (k) + 3])
+
+/* closest point of the simplex P[0..n) to the origin: weights lam (zero where a vertex is not needed), the point v; true when a
+ * tetrahedron encloses the origin (oracle cvx_simplex) */
+__device__ inline bool cvx_simplex(LdsCF P, const int n, float* lam, V3& v) {
+  lam[0] = lam[1] = lam[2] = lam[3] = 0.0f;
+  const V3 f0 = GQ_CVX_PW(P, 0);
+  if (n == 1) { lam[0] = 1.0f; v = f0; return false; }
+  const D3 p0 = d3(f0), p1 = d3(GQ_CVX_PW(P, 1));
+  if (n == 2) { double l2[3]; cvx_seg(p0, p1, l2); l2[2] = 0.0; lam[0] = (float)l2[0]; lam[1] = (float)l2[1]; v = cvx_comb(l2, p0, p1, p1); return false; }
+  const D3 p2 = d3(GQ_CVX_PW(P, 2));
+  if (n == 3) { double l3[3]; cvx_tri(p0, p1, p2, l3); lam[0] = (float)l3[0]; lam[1] = (float)l3[1]; lam[2] = (float)l3[2]; v = cvx_comb(l3, p0, p1, p2); return false; }
+  const D3 p3 = d3(GQ_CVX_PW(P, 3));
+  double best = 1e300;
+  bool any = false;
+#pragma unroll 1
+  for (int f = 0; f < 4; f++) { /* faces (0,1,2 | 3), (0,1,3 | 2), (0,2,3 | 1), (1,2,3 | 0) */
+    const D3 a = f == 3 ? p1 : p0, b = f < 2 ? p1 : p2, c = f == 0 ? p2 : p3, o = f == 0 ? p3 : (f == 1 ? p2 : (f == 2 ? p1 : p0));
+    const D3 nf = cross(b - a, c - a);
+    const double so = dot(nf, o - a), sz = -dot(nf, a);
+    if ((so > 0.0 && sz < 0.0) || (so < 0.0 && sz > 0.0) || so == 0.0) { /* the origin lies beyond this face */
+      double l3[3];
+      cvx_tri(a, b, c, l3);
+      const V3 p = cvx_comb(l3, a, b, c);
+      const double pp = (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z;
+      if (pp < best) {
+        best = pp; any = true; v = p;
+        const int ia = f == 3 ? 1 : 0, ib = f < 2 ? 1 : 2, ic = f == 0 ? 2 : 3;
+        lam[0] = lam[1] = lam[2] = lam[3] = 0.0f;
+        lam[ia] = (float)l3[0]; lam[ib] = (float)l3[1]; lam[ic] = (float)l3[2];
+      }
+    }
+  }
+  return !any;
+}
+
+/* unit normal and offset of the polytope face (a, b, c); a sliver (edges parallel to 1e-5) gets the offset 1e30: kept for the topology,
+ * never the closest face (oracle cvx_face_plane) */
+__device__ __forceinline__ void cvx_face_plane(V3 a, V3 b, V3 c, V3& n, float& d) {
+  /* (double precision: the vertices of A - B lie up to a metre from the origin - a corner of a world box - while the offset wanted is
+   * millimetres to 1e-6; an fp32 cross product of a thin face tilts its normal by 1e-3 and moves the offset by 1e-5) */
+  const D3 A = d3(a), ab = d3(b) - A, ac = d3(c) - A, x = cross(ab, ac);
+  const double l2 = dot(x, x);
+  if (l2 > 1e-10 * dot(ab, ab) * dot(ac, ac) && l2 > 1e-60) {
+    const double inv = 1.0 / sqrt(l2);
+    n = v3((float)(x.x * inv), (float)(x.y * inv), (float)(x.z * inv));
+    d = (float)(dot(x, A) * inv);
+  } else { n = v3(0.0f, 0.0f, 1.0f); d = 1e30f; }
+}
+
+/* One convex pair.  shp: the two shape descriptors (A, B: GQ_CVX_SHAPE_WORDS each), then the result - dist, normal A -> B (3), point (3);
+ * poly: GQ_CVX_POLY_WORDS words of scratch.  Returns true when the inflated shapes are closer than margin.  Wave-uniform. */
+__device__
+#ifndef GQ_CVX_INLINE
+__attribute__((noinline))
+#endif
+bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const int grid, const float margin) {
+  const int lane = lane_id();
+  LdsCF SA = shp; LdsCF SB = shp + GQ_CVX_SHAPE_WORDS;
+  LdsF out = shp + 2 * GQ_CVX_SHAPE_WORDS;
+  LdsF P = poly;
+  LdsI PI = (LdsI)poly;
+  LdsI ADJ = PI + 4 * GQ_CVX_MAXV;
+  LdsI RIM = ADJ + 64;
+  const float rA = SA[19], rB = SB[19], reach = margin + rA + rB;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  /* ---- GJK */
+  V3 v;
+  float lam[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+  int ns = 1;
+  {
+    V3 d0 = (uniform(((LdsCI)SB)[0]) == 2 ? 0.5f * (ld3(SB + 13) + ld3(SB + 16)) : ld3(SB + 13)) -
+            (uniform(((LdsCI)SA)[0]) == 2 ? 0.5f * (ld3(SA + 13) + ld3(SA + 16)) : ld3(SA + 13));
+    if (dot(d0, d0) < 1e-24f) d0 = v3(1.0f, 0.0f, 0.0f);
+    const CvxMink s0 = cvx_minkowski(SA, SB, vx, vy, vz, grid, d0);
+    v = s0.w;
+    wave_barrier();
+    st3l(P, v); PI[3] = s0.id;
+    wave_barrier();
+  }
+  bool enclosed = false;
+#pragma unroll 1
+  for (int it = 0; it < GQ_CVX_GJK_MAXIT; it++) {
+    const float vv = dot(v, v);
+    if (vv < 1e-24f) { enclosed = true; break; } /* the origin lies on the simplex: touching cores */
+    const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, grid, -1.0f * v);
+    const V3 w = sw.w;
+    const float vw = dot(v, w);
+    if (vw > 0.0f && vw * vw > reach * reach * vv) return false; /* the cores are farther apart than anything of interest */
+    const int wid = sw.id;
+    bool dup = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) dup = dup || (i < ns && GQ_CVX_PID(P, i) == wid);
+#ifdef GQ_EMU_TRACE
+    if (lane == 0 && getenv("GQ_CVX_TRACE")) printf("gjk it %d ns %d vv %.9g vw %.9g dup %d wid %x\n", it, ns, (double)vv, (double)vw, (int)dup, wid);
+#endif
+    if (dup || vv - vw <= GQ_CVX_TOL_GJK * (vv + fast_sqrt(vv * dot(w, w)))) break; /* v is the closest point */
+    wave_barrier();
+    st3l(P + 4 * ns, w); PI[4 * ns + 3] = wid;
+    ns++;
+    wave_barrier();
+#ifdef GQ_EMU_TRACE
+    if (lane == 0 && getenv("GQ_CVX_TRACE") && it >= 6 && it <= 8) for (int i = 0; i < ns; i++) printf("   S[%d] = %.9g %.9g %.9g id %x\n", i, (double)P[4 * i], (double)P[4 * i + 1], (double)P[4 * i + 2], GQ_CVX_PID(P, i));
+#endif
+    if (cvx_simplex(P, ns, lam, v)) { enclosed = true; break; }
+#ifdef GQ_EMU_TRACE
+    if (lane == 0 && getenv("GQ_CVX_TRACE") && it >= 6 && it <= 8) printf("   lam %.9g %.9g %.9g %.9g v %.9g %.9g %.9g\n", (double)lam[0], (double)lam[1], (double)lam[2], (double)lam[3], (double)v.x, (double)v.y, (double)v.z);
+#endif
+    /* keep the vertices that carry the point (wave-uniform data: every lane moves the same words) */
+    V3 kw[4]; int kid[4]; float kl[4]; int m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { kw[i] = v3(0.0f, 0.0f, 0.0f); kid[i] = 0; kl[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i < ns && lam[i] > 0.0f) {
+        const V3 pw = GQ_CVX_PW(P, i); const int pid = GQ_CVX_PID(P, i);
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (q == m) { kw[q] = pw; kid[q] = pid; kl[q] = lam[i]; }
+        m++;
+      }
+    wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (q < m) { st3l(P + 4 * q, kw[q]); PI[4 * q + 3] = kid[q]; lam[q] = kl[q]; } else lam[q] = 0.0f;
+    ns = m;
+    wave_barrier();
+  }
+  if (!enclosed) {
+    const float len = fast_sqrt(dot(v, v));
+    const float dist = len - rA - rB;
+    if (!(dist < margin)) return false;
+    const V3 n = fast_rcp(len) * (-1.0f * v);
+    V3 pa = v3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i < ns && lam[i] > 0.0f) pa = pa + lam[i] * cvx_point(SA, vx, vy, vz, GQ_CVX_PID(P, i) & 0xffff);
+    const V3 pb = pa - v;
+    const V3 pos = 0.5f * ((pa + rA * n) + (pb - rB * n));
+    wave_barrier();
+    out[0] = dist; st3l(out + 1, n); st3l(out + 4, pos);
+    wave_barrier();
+    return true;
+  }
+  /* ---- the cores overlap.  A tetrahedron around the origin first: a touching / degenerate simplex is blown up with supports along
+   * directions it does not span (oracle: same order of attempts) */
+  if (ns < 4) {
+#pragma unroll 1
+    for (int tries = 0; tries < 12 && ns < 4; tries++) {
+      V3 dir;
+      const V3 p0 = GQ_CVX_PW(P, 0);
+      const int k = tries % 3;
+      const V3 axk = v3(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
+      if (ns == 1) dir = tries < 3 ? axk : -1.0f * axk;
+      else if (ns == 2) { dir = cross(GQ_CVX_PW(P, 1) - p0, axk); if (tries >= 3 && tries < 6) dir = -1.0f * dir; }
+      else { dir = cross(GQ_CVX_PW(P, 1) - p0, GQ_CVX_PW(P, 2) - p0); if (tries & 1) dir = -1.0f * dir; }
+      if (dot(dir, dir) < 1e-30f) continue;
+      const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, grid, dir);
+      const V3 w = sw.w;
+      const int wid = sw.id;
+      bool dup = false;
+#pragma unroll
+      for (int i = 0; i < 4; i++) dup = dup || (i < ns && GQ_CVX_PID(P, i) == wid);
+      if (dup) continue;
+      const V3 f = w - p0;
+      if (ns == 1) { if (dot(f, f) < 1e-20f) continue; }
+      else if (ns == 2) { const V3 e = GQ_CVX_PW(P, 1) - p0, c = cross(e, f); if (dot(c, c) < 1e-12f * dot(e, e) * dot(f, f)) continue; }
+      else { const V3 c = cross(GQ_CVX_PW(P, 1) - p0, GQ_CVX_PW(P, 2) - p0); const float vol = dot(c, f); if (vol * vol < 1e-12f * dot(c, c) * dot(f, f)) continue; }
+      wave_barrier();
+      st3l(P + 4 * ns, w); PI[4 * ns + 3] = wid;
+      ns++;
+      wave_barrier();
+    }
+    if (ns < 4) return false; /* a flat Minkowski difference: no volume to penetrate */
+  }
+  /* ---- EPA, lane = face */
+  int fv = 0;                    /* v0 | v1 << 8 | v2 << 16 */
+  V3 fn = v3(0.0f, 0.0f, 1.0f);
+  float fd = 3e38f;
+  bool alive = false;
+  {
+    /* faces (0,1,2), (0,3,1), (0,2,3), (1,3,2) and the face across each of their edges; all four are turned when face 0 looks at vertex 3 */
+    const V3 q0 = GQ_CVX_PW(P, 0), q1 = GQ_CVX_PW(P, 1), q2 = GQ_CVX_PW(P, 2), q3 = GQ_CVX_PW(P, 3);
+    V3 n0; float dd0;
+    cvx_face_plane(q0, q1, q2, n0, dd0);
+    const bool turn = dot(n0, q3) - dd0 > 0.0f;
+    const int l4 = lane & 3;
+    const int t0 = l4 == 3 ? 1 : 0, t1 = l4 == 0 ? 1 : (l4 == 2 ? 2 : 3), t2 = l4 == 0 ? 2 : (l4 == 1 ? 1 : (l4 == 2 ? 3 : 2));
+    const int a0 = l4 == 0 ? 1 : (l4 == 1 ? 2 : (l4 == 2 ? 0 : 1)), a1 = l4 == 3 ? 2 : 3, a2 = l4 == 0 ? 2 : (l4 == 1 ? 0 : (l4 == 2 ? 1 : 0));
+    const int u1 = turn ? t2 : t1, u2 = turn ? t1 : t2;
+    fv = t0 | (u1 << 8) | (u2 << 16);
+    alive = lane < 4;
+    cvx_face_plane(GQ_CVX_PW(P, t0), GQ_CVX_PW(P, u1), GQ_CVX_PW(P, u2), fn, fd);
+    wave_barrier();
+    ADJ[lane] = lane < 4 ? ((turn ? a2 : a0) | (a1 << 8) | ((turn ? a0 : a2) << 16)) : 0;
+    wave_barrier();
+  }
+  int nv = 4, best = 0;
+#pragma unroll 1
+  for (int eit = 0;; eit++) {
+    const float dmin = wave_min(alive ? fd : 3e38f);
+    const uint64_t bm = ballot(alive && fd == dmin);
+    if (bm == 0) return false;
+    best = ffs64(bm);
+    if (eit >= GQ_CVX_EPA_MAXIT || nv >= GQ_CVX_MAXV) break;
+    const V3 nb = v3(bcast(fn.x, best), bcast(fn.y, best), bcast(fn.z, best));
+    const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, grid, nb);
+    const V3 w = sw.w;
+    const int wid = sw.id;
+    const bool dup = ballot(lane < nv && GQ_CVX_PID(P, lane < nv ? lane : 0) == wid) != 0;
+#ifdef GQ_EMU_TRACE
+    if (lane == 0 && getenv("GQ_CVX_TRACE")) printf("epa it %d best %d dmin %.9g sup %.9g dup %d nv %d wid %x\n", eit, best, (double)dmin, (double)dot(w, nb), (int)dup, nv, wid);
+#endif
+    if (dup || dot(w, nb) - dmin <= GQ_CVX_TOL_EPA) break; /* the face lies on the boundary of A - B */
+    /* the connected patch of faces that see w, grown from the closest one through shared edges */
+    const bool cand = alive && fd < 1e29f && dot(fn, w) - fd > 0.5f * GQ_CVX_TOL_EPA;
+    const int adj = ADJ[lane];
+    const int j0 = adj & 0xff, j1 = (adj >> 8) & 0xff, j2 = (adj >> 16) & 0xff;
+    uint64_t vis = 1ull << best;
+    for (;;) {
+      const bool in = cand && !((vis >> lane) & 1ull) && (((vis >> j0) | (vis >> j1) | (vis >> j2)) & 1ull);
+      const uint64_t add = ballot(in);
+      if (!add) break;
+      vis |= add;
+    }
+    const bool mine = (vis >> lane) & 1ull;
+    const bool r0 = mine && !((vis >> j0) & 1ull), r1 = mine && !((vis >> j1) & 1ull), r2 = mine && !((vis >> j2) & 1ull);
+    const int cnt = (r0 ? 1 : 0) + (r1 ? 1 : 0) + (r2 ? 1 : 0);
+    const int incl = wave_incl_scan(cnt);
+    const int nh = bcast(incl, 63);
+    if (nh > GQ_CVX_MAXRIM) break; /* (a rim of more than 24 edges: the polytope has outgrown the scratch; the closest face so far is the answer) */
+    {
+      int at = incl - cnt;
+      const int f0 = fv & 0xff, f1 = (fv >> 8) & 0xff, f2 = (fv >> 16) & 0xff;
+      if (r0) RIM[at++] = f0 | (f1 << 8) | (j0 << 16);
+      if (r1) RIM[at++] = f1 | (f2 << 8) | (j1 << 16);
+      if (r2) RIM[at++] = f2 | (f0 << 8) | (j2 << 16);
+    }
+    alive = alive && !mine;
+    st3l(P + 4 * nv, w); PI[4 * nv + 3] = wid; /* (every lane: the same words) */
+    wave_barrier();
+    /* the fan: new face k = rim edge k + the new vertex, on the k-th free lane */
+    const uint64_t freem = ballot(!alive);
+    const int rank = popc64(freem & lt);
+    const bool take = !alive && rank < nh;
+    int ea = 0, eb = 0, eg = 0;
+    if (take) {
+      const int e = RIM[rank];
+      ea = e & 0xff; eb = (e >> 8) & 0xff; eg = (e >> 16) & 0xff;
+    }
+    wave_barrier();
+    if (take) RIM[rank] = ea | (eb << 8) | (eg << 16) | (lane << 24);
+    const int gfv = shfl_idx(fv, take ? eg : lane); /* the face behind the rim edge: its vertices (it is not in the patch: its lane keeps them) */
+    wave_barrier();
+    if (take) {
+      fv = ea | (eb << 8) | (nv << 16);
+      cvx_face_plane(GQ_CVX_PW(P, ea), GQ_CVX_PW(P, eb), w, fn, fd);
+      alive = true;
+      int n1 = lane, n2 = lane;
+      bool s1 = false, s2 = false;
+      for (int k = 0; k < nh; k++) { /* (per-lane trip count is wave-uniform; no cross-lane primitive inside) */
+        const int e = RIM[k], ka = e & 0xff, kb = (e >> 8) & 0xff, ks = (e >> 24) & 0xff;
+        if (!s1 && ka == eb) { n1 = ks; s1 = true; }
+        if (!s2 && kb == ea) { n2 = ks; s2 = true; }
+      }
+      ADJ[lane] = eg | (n1 << 8) | (n2 << 16);
+      /* the face behind the rim edge now borders this one: its edge b -> a */
+      const int g0 = gfv & 0xff, g1 = (gfv >> 8) & 0xff, g2 = (gfv >> 16) & 0xff;
+      const int q = (g0 == eb && g1 == ea) ? 0 : ((g1 == eb && g2 == ea) ? 1 : 2);
+      ((GQ_LDS uint8_t*)ADJ)[4 * eg + q] = (uint8_t)lane;
+    }
+    nv++;
+    wave_barrier();
+  }
+  /* the closest face: the foot point of its plane, split over the face's vertices.  A facet of A - B with more than three vertices (edge
+   * against edge: a parallelogram) is several coplanar triangles of equal offset - the one that CONTAINS the foot point carries the
+   * witness points: among the faces within the tolerance of the smallest offset (lane = face), the one whose nearest point is nearest */
+  {
+    const float dsel = wave_min(alive ? fd : 3e38f);
+    float q2 = 3e38f;
+    if (alive && fd <= dsel + 10.0f * GQ_CVX_TOL_EPA) {
+      const D3 a = d3(GQ_CVX_PW(P, fv & 0xff)), b = d3(GQ_CVX_PW(P, (fv >> 8) & 0xff)), c = d3(GQ_CVX_PW(P, (fv >> 16) & 0xff));
+      double l3[3];
+      cvx_tri(a, b, c, l3);
+      const V3 q = cvx_comb(l3, a, b, c);
+      q2 = dot(q, q);
+    }
+    const float q2min = wave_min(q2);
+    const uint64_t sel = ballot(q2 == q2min && q2 < 3e38f);
+    if (sel) best = ffs64(sel);
+  }
+  {
+    const int bf = bcast(fv, best);
+    const V3 n = v3(bcast(fn.x, best), bcast(fn.y, best), bcast(fn.z, best));
+    const float dbest = bcast(fd, best);
+    const float dd = dbest < 1e29f ? dbest : 0.0f;
+    const int i0 = bf & 0xff, i1 = (bf >> 8) & 0xff, i2 = (bf >> 16) & 0xff;
+    double l3[3];
+    const D3 foot = d3(dd * n);
+    cvx_tri(d3(GQ_CVX_PW(P, i0)) - foot, d3(GQ_CVX_PW(P, i1)) - foot, d3(GQ_CVX_PW(P, i2)) - foot, l3);
+    const V3 pa = (float)l3[0] * cvx_point(SA, vx, vy, vz, GQ_CVX_PID(P, i0) & 0xffff) + (float)l3[1] * cvx_point(SA, vx, vy, vz, GQ_CVX_PID(P, i1) & 0xffff) +
+                  (float)l3[2] * cvx_point(SA, vx, vy, vz, GQ_CVX_PID(P, i2) & 0xffff);
+    const V3 pb = pa - dd * n;
+    const float dist = -dd - rA - rB;
+    if (!(dist < margin)) return false;
+    wave_barrier();
+    out[0] = dist; st3l(out + 1, n); st3l(out + 4, 0.5f * ((pa + rA * n) + (pb - rB * n)));
+    wave_barrier();
+    return true;
+  }
+}
+
+/* mid phase of a convex pair, ONE lane: two oriented boxes (centre, axes = columns of R, half extents) are held apart by more than
+ * `reach` along one of the 15 separating-axis candidates (oracle obb_apart) - then so are the hulls inside them */
+__device__ inline bool obb_apart(V3 ca, const float* Ra, V3 ha, V3 cb, const float* Rb, V3 hb, float reach) {
+  float C[3][3], AC[3][3], t[3];
+  const V3 d = cb - ca;
+  const float hA[3] = {ha.x, ha.y, ha.z}, hB[3] = {hb.x, hb.y, hb.z};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    t[i] = Ra[i] * d.x + Ra[3 + i] * d.y + Ra[6 + i] * d.z;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { C[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]; AC[i][j] = fabsf(C[i][j]) + 1e-6f; }
+  }
+  bool apart = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) apart = apart || fabsf(t[i]) - (hA[i] + hB[0] * AC[i][0] + hB[1] * AC[i][1] + hB[2] * AC[i][2]) > reach;
+#pragma unroll
+  for (int j = 0; j < 3; j++) apart = apart || fabsf(t[0] * C[0][j] + t[1] * C[1][j] + t[2] * C[2][j]) - (hB[j] + hA[0] * AC[0][j] + hA[1] * AC[1][j] + hA[2] * AC[2][j]) > reach;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const float len2 = 1.0f - C[i][j] * C[i][j];
+      const float sep = fabsf(t[i2] * C[i1][j] - t[i1] * C[i2][j]) - (hA[i1] * AC[i2][j] + hA[i2] * AC[i1][j] + hB[j1] * AC[i][j2] + hB[j2] * AC[i][j1]);
+      apart = apart || (len2 >= 1e-4f && sep > reach * fast_sqrt(len2));
+    }
+  return apart;
+}
+
+}  // namespace gq

@@ -17,6 +17,8 @@
  * address space, so that its loads are invariant - scalar loads where the address is uniform, free to be hoisted above
  * stores and to be merged where the same word is read twice. */
 #define GQ_MODEL __attribute__((address_space(4)))
+/* LDS (the per-wave working set): for pointers that cross a function boundary (gq_convex.h) */
+#define GQ_LDS __attribute__((address_space(3)))
 
 namespace gq {
 

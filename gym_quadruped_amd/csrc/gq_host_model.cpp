@@ -266,6 +266,36 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       for (int c = 0; c < ncell; c++) { vx->push_back((float)(d->plane_mask[(size_t)cl * ncell + c] & 0xffff)); vy->push_back(0.0f); vz->push_back(0.0f); }
     }
   }
+  /* hull graphs (optional): per cloud with a graph, one record per vertex of the DIRECTION-ordered copy - x = first entry of its neighbour
+   * list, y = the list's length - and the lists themselves: the neighbours' COORDINATES (geom frame) in ascending order of their index in
+   * vert_pos, so that the floor pass reaches the support vertex's neighbours with one record load and one coordinate load */
+  std::vector<int> cloud_nbr(d->ncloud > 0 ? d->ncloud : 0, -1);
+  if (d->vert_adjadr && d->vert_adjnum && d->vert_adj && d->nadj > 0) {
+    for (int cl = 0; cl < d->ncloud; cl++) {
+      const int a = d->cloud_vertadr[cl], n = d->cloud_vertnum[cl];
+      int total = 0;
+      for (int v = 0; v < n; v++) total += d->vert_adjnum[a + v];
+      if (!total) continue;
+      const int rec = (int)vx->size(), lists = rec + n;
+      if ((size_t)lists + (size_t)total >= (1u << 24)) FAIL("hull graph tables exceed the 2^24 entries a float index can address");
+      cloud_nbr[cl] = rec;
+      vx->resize((size_t)lists + total, 0.0f); vy->resize((size_t)lists + total, 0.0f); vz->resize((size_t)lists + total, 0.0f);
+      int at = lists;
+      for (int i = 0; i < n; i++) { /* i: position in the direction-ordered copy; v: the same vertex in vert_pos */
+        const int v = (plane_tables && d->plane_order) ? d->plane_order[a + i] : i;
+        if (v < 0 || v >= n) FAIL("plane_order[%d] = %d is not a vertex of cloud %d", a + i, v, cl);
+        const int cnt = d->vert_adjnum[a + v], first = d->vert_adjadr[a + v];
+        if (cnt < 0 || first < 0 || first + cnt > d->nadj) FAIL("hull graph of vertex %d runs outside vert_adj", a + v);
+        (*vx)[rec + i] = (float)at; (*vy)[rec + i] = (float)cnt;
+        for (int q = 0; q < cnt; q++) {
+          const int u = d->vert_adj[first + q];
+          if (u < 0 || u >= n) FAIL("vert_adj entry %d of vertex %d is not a vertex of its cloud", u, a + v);
+          (*vx)[at] = (float)d->vert_pos[3 * (a + u)]; (*vy)[at] = (float)d->vert_pos[3 * (a + u) + 1]; (*vz)[at] = (float)d->vert_pos[3 * (a + u) + 2];
+          at++;
+        }
+      }
+    }
+  }
   M.nlg = 0;
   int nitem = 0;
   for (int g = 0; g < d->ngeom; g++) {
@@ -280,7 +310,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     if (M.nlg >= GQ_MAXLG) FAIL("more than %d link collision geoms", GQ_MAXLG);
     GqDevGeom& G = M.lg[M.nlg++];
     G.body = b - 1; G.cloud_adr = d->cloud_vertadr[cl]; G.cloud_num = d->cloud_vertnum[cl]; G.radius = (float)d->cloud_radius[cl];
-    G.plane_adr = plane_base + G.cloud_adr; G.pmask_adr = cloud_pmask[cl];
+    G.plane_adr = plane_base + G.cloud_adr; G.pmask_adr = cloud_pmask[cl]; G.nbr_adr = cloud_nbr[cl];
     double R[9]; quat2mat(d->geom_quat + 4 * g, R);
     for (int i = 0; i < 3; i++) G.pos[i] = (float)d->geom_pos[3 * g + i];
     for (int i = 0; i < 9; i++) G.mat[i] = (float)R[i];
@@ -436,6 +466,10 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
         const GqDevGeom& G = M.lg[it - 4];
         for (int i = 0; i < 3; i++) c[i] = G.pos[i];
         r = std::sqrt((double)G.psize[0] * G.psize[0] + (double)G.psize[1] * G.psize[1] + (double)G.psize[2] * G.psize[2]);
+      } else if (it >= 4 && M.lg[it - 4].ptype != 2 && M.lg[it - 4].ptype != 3) { /* hull / cylinder cloud (convex routine): the sphere around its box */
+        const GqDevGeom& G = M.lg[it - 4];
+        for (int i = 0; i < 3; i++) c[i] = G.pos[i] + G.mat[3 * i] * G.aabb_c[0] + G.mat[3 * i + 1] * G.aabb_c[1] + G.mat[3 * i + 2] * G.aabb_c[2];
+        r = std::sqrt((double)G.aabb_h[0] * G.aabb_h[0] + (double)G.aabb_h[1] * G.aabb_h[1] + (double)G.aabb_h[2] * G.aabb_h[2]) + G.radius;
       }
       for (int i = 0; i < 3; i++) M.item_bsph[it][i] = (float)c[i];
       M.item_bsph[it][3] = (float)(r * 1.0001 + 1e-6);
@@ -449,7 +483,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       for (int i = 0; i < 3; i++) c[i] /= n;
       for (int it = 0; it < 4 + M.nlg; it++)
         if (M.item_body[it] == b) {
-          if (it >= 4 && M.lg[it - 4].ptype == 6) { /* a box: its own bounding sphere */
+          if (it >= 4 && M.lg[it - 4].ptype != 2 && M.lg[it - 4].ptype != 3) { /* a box, hull or cylinder: its own bounding sphere */
             double s = 0;
             for (int i = 0; i < 3; i++) { const double t = M.item_bsph[it][i] - c[i]; s += t * t; }
             r = std::fmax(r, std::sqrt(s) + M.item_bsph[it][3]);
@@ -480,10 +514,11 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       if (++P.count > 64) FAIL("more than 64 geom pairs between two bodies");
       GqDevSelfPair& S = M.sp[p];
       S.it1 = item_of_geom[g1]; S.it2 = item_of_geom[g2]; S.bp = M.nbp - 1;
-      { /* pair routine: a box against a sphere / capsule / box is exact (gq_pairs.h); everything else goes by capsule proxies */
+      { /* pair routine: a box against a sphere / capsule / box is exact (gq_pairs.h), two spheres / capsules by their axes' closest points; a
+         * hull or cylinder with anything goes through the convex routine (gq_convex.h: kind 4) */
         auto prim = [&](int it) { if (it < 4) return 1; const int pt = M.lg[it - 4].ptype; return pt == 6 ? 2 : ((pt == 2 || pt == 3) ? 1 : 0); };
         const int k1 = prim(S.it1), k2 = prim(S.it2);
-        S.kind = (k1 == 2 && k2 == 2) ? 3 : ((k1 == 2 && k2 == 1) ? 1 : ((k1 == 1 && k2 == 2) ? 2 : 0));
+        S.kind = (k1 == 0 || k2 == 0) ? 4 : ((k1 == 2 && k2 == 2) ? 3 : ((k1 == 2 && k2 == 1) ? 1 : ((k1 == 1 && k2 == 2) ? 2 : 0)));
       }
       WorldGeom w{d->geom_condim[g1], d->geom_priority[g1], d->geom_solmix[g1], d->geom_margin[g1], d->geom_gap[g1], d->geom_solref + 2 * g1, d->geom_solimp + 5 * g1};
       Mixed mx = mix_with(d, w, g2);

@@ -32,6 +32,9 @@ struct GqDevGeom {          /* a robot collision geom that is not a foot sphere 
   int32_t plane_adr;        /* floor pass (stage_collision_scan): first vertex of the cloud's DIRECTION-ordered copy in the vertex arrays
                              * (= cloud_adr when the model came without plane tables) */
   int32_t pmask_adr;        /* ... and the index (vertex array x) of its per-direction-cell chunk masks, stored as floats; -1: scan every chunk */
+  int32_t nbr_adr;          /* mesh geoms: index (vertex arrays) of the hull-graph records of the DIRECTION-ordered copy - entry i: x = first entry of vertex i's
+                             * neighbour list (an index into the vertex arrays, where the neighbours' COORDINATES stand, ascending hull-table index), y = its
+                             * length; -1: no graph (support vertex only) */
   float radius;             /* inflation (capsule) */
   /* plane narrow phase (MuJoCo's mjraw_Plane* routines, evaluated by ONE lane): 0 = hull cloud, support vertex found by the
    * 64-lane scan (mjc_PlaneConvex's first point); 2 sphere; 3 capsule: psize = (radius, half length); 5 cylinder: psize =
@@ -57,7 +60,7 @@ struct GqDevBox { float pos[3], mat[9], size[3], rad; int32_t cls; };
 /* robot self-collision (mj_collision between two bodies of the robot): body pairs for the broad phase, geom pairs with
  * their mixed contact parameters for the narrow phase (capsule proxies, gym_quadruped_amd/selfcol.py) */
 struct GqDevBodyPair { int32_t b1, b2, first, count; };   /* kernel body indices (0 = base), range of geom pairs */
-struct GqDevSelfPair { int32_t it1, it2, bp, kind; GqDevMix mix; }; /* kind: 0 capsule proxies (segment-segment), 1 box (item 1) - sphere / capsule (item 2), 2 sphere / capsule - box, 3 box - box (gq_pairs.h) */ /* collision items (k < 4 foot k, else 4 + link geom); mix.rule: 0 max, 1 item1, 2 item2 */ /* mat: columns = box axes in the world; rad: bounding sphere */
+struct GqDevSelfPair { int32_t it1, it2, bp, kind; GqDevMix mix; }; /* kind: 0 two sphere / capsule cores (segment-segment), 1 box (item 1) - sphere / capsule (item 2), 2 sphere / capsule - box, 3 box - box (gq_pairs.h), 4 a hull / cylinder is involved (gq_convex.h) */ /* collision items (k < 4 foot k, else 4 + link geom); mix.rule: 0 max, 1 item1, 2 item2 */ /* mat: columns = box axes in the world; rad: bounding sphere */
 
 /* Everything lane `it` of the floor pass (S6: lane = collision item in MuJoCo's contact order) needs about its item, as ONE
  * contiguous 128-byte record: a single batch of loads, issued a stage early (the indirection con_order -> lg[] -> fields was two

@@ -79,6 +79,11 @@ __device__ inline Q4 stage_kinematics(WaveMem& W, const GqDevLinkRec L) { /* (by
 
 /* S6 (mj_collision, floor plane z = 0): foot sphere centres and, per link geom, the deepest cloud vertex.
  * calf_only restricts the scan to geoms of the calf bodies (reset lift loop, quadruped_env.py:376-388). */
+/* floor pass scratch in the J block (idle between S5 and the world-box / self-collision passes of S6): per link geom up to two further
+ * contact points of a mesh with the floor (geom-frame point, distance; 1e30: none) and the support vertex's index in its cloud */
+#define GQ_FLR_XTRA(W) (&(W).u.B[0][0])                                   /* [GQ_MAXLG][2][4] */
+#define GQ_FLR_WIDX(W) (reinterpret_cast<int32_t*>(&(W).u.B[17][0]))      /* [GQ_MAXLG] */
+static_assert(8 * GQ_MAXLG <= 17 * GQ_NVD && GQ_MAXLG <= 3 * GQ_NVD, "floor pass scratch");
 struct FootRec { int leg; float pos[3]; }; /* lane = foot: its leg and the sphere centre in the calf frame (fetched a stage early by the caller) */
 template <class M> __device__ __forceinline__ FootRec foot_fetch(const M& m, const int lane) {
   const int k = lane < 4 ? lane : 3;
@@ -138,6 +143,7 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
       cmask0 = pm >= 0 ? (int)mw : ((1 << nchunk) - 1);
     }
     W.u2.c.lg_dist[lg_] = 1e30f; /* (a geom that is scanned gets its distance from phase 3) */
+    GQ_FLR_XTRA(W)[8 * lg_ + 3] = 1e30f; GQ_FLR_XTRA(W)[8 * lg_ + 7] = 1e30f; /* (... and its further contact points from phase 5) */
   }
   uint64_t todo = ballot(needs);
   if (todo) { /* wave-uniform */
@@ -155,6 +161,7 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
       int cm = bcast(cmask, g);
       float best = 1e30f;
       V3 bp = v3(0.0f, 0.0f, 0.0f);
+      int bi = 0;
       while (cm) { /* wave-uniform: up to 4 chunks with all 12 loads in flight together; lanes past the end re-read the last vertex */
         int cu[4];
 #pragma unroll
@@ -170,22 +177,52 @@ __device__ inline void stage_collision_scan(WaveMem& W, const GQ_MODEL GqDevMode
         for (int u = 0; u < 4; u++)
           if (cu[u] >= 0) {
             const float dv = gx * px[u] + gy * py[u] + gz * pz[u];
-            if (dv < best) { best = dv; bp = v3(px[u], py[u], pz[u]); } /* (a re-read last vertex never wins a tie: strict <) */
+            const int i = adr + cu[u] * GQ_WAVE + lane;
+            if (dv < best) { best = dv; bp = v3(px[u], py[u], pz[u]); bi = (i < last ? i : last) - adr; } /* (a re-read last vertex never wins a tie: strict <) */
           }
       }
       const float wmin = wave_min(best);
       const int who = ffs64(ballot(best == wmin));
-      if (lane == who) { W.u2.c.lg_dist[g] = wmin; st3(W.u2.c.lg_pt[g], bp); } /* geom-frame vertex for now; 1e30: no chunk in reach */
+      if (lane == who) { W.u2.c.lg_dist[g] = wmin; st3(W.u2.c.lg_pt[g], bp); GQ_FLR_WIDX(W)[g] = bi; } /* geom-frame vertex for now; 1e30: no chunk in reach */
       if (!todo) break;
     }
     wave_barrier();
+    int nb_adr = 0, nb_cnt = 0;
     if (needs) { /* phase 4, lane = geom */
       const GQ_MODEL GqDevGeom& G = m.lg[lane];
       const float* Rb = W.xmat[G.body];
       const float raw = W.u2.c.lg_dist[lane];
       const V3 vb = ld3(G.pos) + matvec(G.mat, ld3(W.u2.c.lg_pt[lane]));
-      W.u2.c.lg_dist[lane] = raw < 1e29f ? raw + d0 - gradius : 1e30f;
+      const float dist = raw < 1e29f ? raw + d0 - gradius : 1e30f;
+      W.u2.c.lg_dist[lane] = dist;
       st3(W.u2.c.lg_pt[lane], ld3(W.xpos[G.body]) + matvec(Rb, vb));
+      /* mjc_PlaneConvex's neighbour walk: a mesh that touches brings the hull-graph neighbours of its support vertex (the record of the
+       * winner: first entry and length of its list in the vertex arrays) */
+      if (dist < gmargin && G.nbr_adr >= 0) {
+        const int r = G.nbr_adr + GQ_FLR_WIDX(W)[lane];
+        nb_adr = (int)vx[r]; nb_cnt = (int)vy[r];
+      }
+    }
+    /* phase 5, one trip per touching mesh, lane = neighbour (list order = ascending vertex index of the hull table): the first two inside
+     * the margin join the support vertex - geom-frame coordinates and distance go to GQ_FLR_XTRA, floor_candidates takes them to the world */
+    uint64_t walk = ballot(nb_cnt > 0);
+    while (walk) { /* wave-uniform */
+      const int g = ffs64(walk);
+      walk &= walk - 1;
+      const int a0 = bcast(nb_adr, g), cnt = imin(bcast(nb_cnt, g), GQ_WAVE);
+      const float gx = bcast(ng.x, g), gy = bcast(ng.y, g), gz = bcast(ng.z, g), off = bcast(d0 - gradius, g), mg = bcast(gmargin, g);
+      const int i = a0 + (lane < cnt ? lane : 0);
+      const V3 p = v3(vx[i], vy[i], vz[i]);
+      const float dk = gx * p.x + gy * p.y + gz * p.z + off;
+      uint64_t in = ballot(lane < cnt && dk < mg);
+      float* X = GQ_FLR_XTRA(W) + 8 * g;
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int who = in ? ffs64(in) : -1;
+        in &= in - 1;
+        if (lane == who) { st3(X + 4 * q, p); X[4 * q + 3] = dk; }
+        if (who < 0 && lane == 0) X[4 * q + 3] = 1e30f;
+      }
     }
   }
   wave_barrier();
@@ -213,7 +250,19 @@ __device__ inline void floor_candidates(const WaveMem& W, const ItemRegs& G, Flo
     C.n = 1; C.r = G.radius; C.pt[0] = ld3(W.foot_world[G.code]); C.dist[0] = C.pt[0].z - C.r;
     return;
   }
-  if (ptype == 0) { const int g = G.code - 4; C.n = 1; C.r = G.radius; C.pt[0] = ld3(W.u2.c.lg_pt[g]); C.dist[0] = W.u2.c.lg_dist[g]; return; }
+  if (ptype == 0) { /* hull: the support vertex, then up to two of its hull-graph neighbours (stage_collision_scan phase 5) */
+    const int g = G.code - 4;
+    C.n = 1; C.r = G.radius; C.pt[0] = ld3(W.u2.c.lg_pt[g]); C.dist[0] = W.u2.c.lg_dist[g];
+    const float* X = GQ_FLR_XTRA(W) + 8 * g;
+    const float d1 = X[3], d2 = X[7];
+    if (d1 < 1e29f) { /* (rare: only a mesh that touches has them) */
+      const float* Rb = W.xmat[G.body];
+      const V3 o = ld3(W.xpos[G.body]) + matvec(Rb, G.pos);
+      C.pt[1] = o + matvec(Rb, matvec(G.mat, ld3(X))); C.dist[1] = d1; C.n = 2;
+      if (d2 < 1e29f) { C.pt[2] = o + matvec(Rb, matvec(G.mat, ld3(X + 4))); C.dist[2] = d2; C.n = 3; }
+    }
+    return;
+  }
   const float* Rb = W.xmat[G.body];
   const V3 c = ld3(W.xpos[G.body]) + matvec(Rb, G.pos);
   float A[9]; /* geom frame in the world: Rb Rg */
@@ -1791,7 +1840,7 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
       rs_t1 = cycles();
 #endif
       const PrimLane PLL = prim_lane(W, m, item_fetch(m, lane < 4 + m.nlg ? lane : 0), PRIM && lane < 4 + m.nlg, PRIM); /* lane = position in con_order, as box_item_scan expects */
-      if constexpr (!PRIM) { item_obb_store(W, m); wave_barrier(); } /* (the spawn pose's boxes; a lift moves the world boxes down - zoff - not the robot) */
+      { item_obb_store(W, m); wave_barrier(); } /* (the spawn pose's boxes; a lift moves the world boxes down - zoff - not the robot) */
       for (int it = 0; it <= GQ_LIFT_CAP; it++) {
         float pen = floor_pen(dz);
         float clear = 0.0f; /* lift that takes the touching item above the box altogether */
@@ -1806,7 +1855,7 @@ __device__ __forceinline__ int reset_wave(const ResetArgs& a, WaveMem& W, const 
             const int b = half * GQ_WAVE + ffs64(todo);
             todo &= todo - 1;
             PairHit BH;
-            if (!box_item_scan<PRIM, 2, !PRIM>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, PLL, BH)) continue;
+            if (!box_item_scan<PRIM, 1, true>(W, m, mptr(a.vx), mptr(a.vy), mptr(a.vz), b, spawn_x, spawn_y, dz, calf_c, calf_r, PLL, BH)) continue;
             if (lane < 4 + m.nlg) {
               const int code = m.con_order[lane];
               const bool calf = code < 4 || (m.lg[code - 4].body > 0 && (m.lg[code - 4].body - 1) % 3 == 2);

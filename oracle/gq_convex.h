@@ -19,8 +19,9 @@
 #include <math.h>
 #include <string.h>
 
-#define CVX_GJK_MAXIT 48
-#define CVX_EPA_MAXIT 28   /* the kernel holds one polytope face per lane: 4 + 2 * 28 <= 64 */
+#define CVX_GJK_MAXIT 32   /* the kernel's caps (csrc/gq_convex.h): the same iteration cut at the same place gives the same answer */
+#define CVX_EPA_MAXIT 24   /* the kernel holds one polytope face per lane (4 + 2 * 24 <= 64) and 28 polytope vertices in its scratch */
+#define CVX_EPA_MAXRIM 24  /* ... and a rim of at most 24 edges */
 #define CVX_EPA_MAXF (4 + 2 * CVX_EPA_MAXIT + 4)
 #define CVX_EPA_MAXV (4 + CVX_EPA_MAXIT + 2)
 
@@ -138,7 +139,7 @@ static void cvx_face_plane(const CvxPt* P, CvxFace* f) {
   for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; }
   cvx_cross(n, ab, ac);
   const double l2 = cvx_dot(n, n);
-  if (l2 > 1e-60) { const double inv = 1.0 / sqrt(l2); for (int k = 0; k < 3; k++) f->n[k] = n[k] * inv; f->d = cvx_dot(f->n, a); }
+  if (l2 > 1e-10 * cvx_dot(ab, ab) * cvx_dot(ac, ac) && l2 > 1e-300) { const double inv = 1.0 / sqrt(l2); for (int k = 0; k < 3; k++) f->n[k] = n[k] * inv; f->d = cvx_dot(f->n, a); }
   else { f->n[0] = f->n[1] = 0; f->n[2] = 1; f->d = 1e300; } /* a sliver: kept for the topology, never the closest face */
 }
 
@@ -280,6 +281,7 @@ static int cvx_gjk_epa(const Cvx* A, const Cvx* B, double reach, double tol_rel,
       for (int e = 0; e < 3; e++)
         if (!vis[Fc[f].adj[e]]) { he[nh][0] = Fc[f].v[e]; he[nh][1] = Fc[f].v[(e + 1) % 3]; he[nh][2] = Fc[f].adj[e]; nh++; }
     }
+    if (nh > CVX_EPA_MAXRIM) break; /* (the kernel's rim list is full: the closest face so far is the answer) */
     for (int f = 0; f < nf; f++) if (vis[f]) Fc[f].alive = 0;
     P[nv] = w;
     /* new faces (a, b, w) take the lowest free slots, rim edges in (face, edge) order - the kernel's lane assignment */
@@ -304,7 +306,21 @@ static int cvx_gjk_epa(const Cvx* A, const Cvx* B, double reach, double tol_rel,
     nv++;
   }
   if (niter) niter[1] = eit;
-  /* the closest face: its plane's foot point, split over the face's vertices */
+  /* the closest face: its plane's foot point, split over the face's vertices.  A facet of A - B with more than three vertices (edge
+   * against edge: a parallelogram) is several coplanar triangles of equal offset - the one that CONTAINS the foot point carries the
+   * witness points: among the faces within the tolerance of the smallest offset, the one whose nearest point is nearest */
+  {
+    double dsel = 1e300, q2min = 1e300;
+    for (int f = 0; f < nf; f++) if (Fc[f].alive && Fc[f].d < dsel) dsel = Fc[f].d;
+    for (int f = 0; f < nf; f++) {
+      if (!Fc[f].alive || !(Fc[f].d <= dsel + 10 * tol_epa)) continue;
+      double l3[3], q[3];
+      cvx_tri(P[Fc[f].v[0]].w, P[Fc[f].v[1]].w, P[Fc[f].v[2]].w, l3);
+      for (int k = 0; k < 3; k++) q[k] = l3[0] * P[Fc[f].v[0]].w[k] + l3[1] * P[Fc[f].v[1]].w[k] + l3[2] * P[Fc[f].v[2]].w[k];
+      const double q2 = cvx_dot(q, q);
+      if (q2 < q2min) { q2min = q2; best = f; }
+    }
+  }
   {
     const CvxFace* f = &Fc[best];
     const double* a = P[f->v[0]].w; const double* b = P[f->v[1]].w; const double* c = P[f->v[2]].w;

@@ -85,6 +85,7 @@ typedef struct GqOracle {
   /* IMU site on the base body + last mj_sensorAcc / mj_sensorVel readings (noise-free) */
   double imu_pos[3], imu_quat[4], imu_acc[3], imu_gyro[3];
   int warning; /* bad qpos/qvel/qacc seen (mj_checkPos/Vel/Acc) */
+  double cloud_aabb[64][6]; int cloud_aabb_ok[64]; /* geom-frame box of every cloud (centre, half extents): mid phase of the convex pairs */
 } GqOracle;
 
 /* ------------------------------------------------------------------ small vector helpers */
@@ -824,6 +825,92 @@ int gqo_test_box_box(const double* ca, const double* Ra, const double* ha, const
   return n;
 }
 
+/* counters of the convex routine's work (tools/convex_census.py): calls, contacts, GJK iterations, EPA runs, EPA iterations; not thread-safe */
+static long long g_cvx_stat[12];
+void gqo_cvx_stats(long long* out, int reset) { if (out) memcpy(out, g_cvx_stat, sizeof g_cvx_stat); if (reset) memset(g_cvx_stat, 0, sizeof g_cvx_stat); }
+/* test diagnostics (Contact.tiegap): is the contact POINT of a convex pair determined?  Depth and normal of the minimum translation are
+ * unique, but where two faces, a face and an edge or two parallel edges meet, every point of their overlap is a valid witness and the
+ * polytope's last triangle - i.e. the iteration path, which round-off steers - picks one.  Dimension of the support sets along +-n
+ * (vertices within 1e-7 of the support planes): ambiguous when they add up to three or more, or are two parallel edges. */
+static int cvx_support_set(const Cvx* s, const double* d, double axis[3]) {
+  double best = -1e300, W[8][3], first[3] = {0, 0, 0}, far2 = 0;
+  const int nv = s->box ? 8 : s->nv;
+  int cnt = 0;
+  axis[0] = axis[1] = axis[2] = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (int v = 0; v < nv; v++) {
+      double q[3], w[3];
+      if (s->box) { for (int k = 0; k < 3; k++) q[k] = ((v >> k) & 1) ? -s->h[k] : s->h[k]; } else memcpy(q, s->V + 3 * v, sizeof q);
+      for (int k = 0; k < 3; k++) w[k] = s->t[k] + s->R[3 * k] * q[0] + s->R[3 * k + 1] * q[1] + s->R[3 * k + 2] * q[2];
+      const double pr = cvx_dot(w, d);
+      if (pass == 0) { if (pr > best) best = pr; continue; }
+      if (pr < best - 1e-7) continue;
+      if (cnt == 0) memcpy(first, w, sizeof first);
+      else { const double e[3] = {w[0] - first[0], w[1] - first[1], w[2] - first[2]}; const double l2 = cvx_dot(e, e); if (l2 > far2) { far2 = l2; memcpy(axis, e, sizeof e); } }
+      if (cnt < 8) memcpy(W[cnt], w, sizeof w);
+      cnt++;
+    }
+  if (cnt <= 1 || far2 < 1e-16) return 0;
+  /* more than an edge: some support vertex off the line through the first one along `axis` */
+  for (int i = 1; i < (cnt < 8 ? cnt : 8); i++) {
+    const double e[3] = {W[i][0] - first[0], W[i][1] - first[1], W[i][2] - first[2]};
+    double c[3];
+    cvx_cross(c, e, axis);
+    if (cvx_dot(c, c) > 1e-14 * far2) return 2;
+  }
+  return cnt > 8 ? 2 : 1;
+}
+static double cvx_point_tie(const Cvx* A, const Cvx* B, const double* n) {
+  double ea[3], eb[3], nn[3] = {-n[0], -n[1], -n[2]};
+  const int da = cvx_support_set(A, n, ea), db = cvx_support_set(B, nn, eb);
+  if (da + db >= 3) return 0.0;
+  if (da == 1 && db == 1) { double c[3]; cvx_cross(c, ea, eb); if (cvx_dot(c, c) < 1e-8 * cvx_dot(ea, ea) * cvx_dot(eb, eb)) return 0.0; }
+  return 1.0;
+}
+static int g_cvx_capped; /* the last pair ran into an iteration cap: its answer is the iteration's state there, not the converged one (test diagnostics) */
+static int cvx_pair_counted(const Cvx* A, const Cvx* B, double margin, double* dist, double* nrm, double* pos, int self) {
+  int it[2] = {0, 0};
+  const int rc = cvx_pair(A, B, margin, dist, nrm, pos, it);
+  long long* s = g_cvx_stat + (self ? 4 : 0);
+  s[0] += 1; s[1] += rc; s[2] += it[0]; s[3] += it[1];
+  g_cvx_capped = rc && (it[1] >= CVX_EPA_MAXIT || it[0] >= CVX_GJK_MAXIT);
+  g_cvx_stat[9] += g_cvx_capped;
+  return rc;
+}
+
+/* mid phase of a convex pair: the clouds' geom-frame boxes, taken to the world, are held apart by more than `reach` along one of the
+ * 15 separating-axis candidates -> the hulls inside them are too (conservative: never hides a contact).  What the kernel's lane = pair
+ * pass does in front of its wave-serial GJK (csrc/gq_convex.h obb_apart). */
+static const double* cloud_box(GqOracle* o, int cl) {
+  const GqModelDesc* m = &o->d;
+  if (cl < 64 && !o->cloud_aabb_ok[cl]) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int v = 0; v < m->cloud_vertnum[cl]; v++)
+      for (int k = 0; k < 3; k++) { const double c = m->vert_pos[3 * (m->cloud_vertadr[cl] + v) + k]; if (c < lo[k]) lo[k] = c; if (c > hi[k]) hi[k] = c; }
+    for (int k = 0; k < 3; k++) { o->cloud_aabb[cl][k] = 0.5 * (lo[k] + hi[k]); o->cloud_aabb[cl][3 + k] = 0.5 * (hi[k] - lo[k]) * 1.0001 + 1e-7; }
+    o->cloud_aabb_ok[cl] = 1;
+  }
+  return o->cloud_aabb[cl < 64 ? cl : 63];
+}
+static int obb_apart(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb, double reach) {
+  double C[3][3], AC[3][3], t[3], d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+  for (int i = 0; i < 3; i++) {
+    t[i] = Ra[i] * d[0] + Ra[3 + i] * d[1] + Ra[6 + i] * d[2];
+    for (int j = 0; j < 3; j++) { C[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]; AC[i][j] = fabs(C[i][j]) + 1e-9; }
+  }
+  for (int i = 0; i < 3; i++) if (fabs(t[i]) - (ha[i] + hb[0] * AC[i][0] + hb[1] * AC[i][1] + hb[2] * AC[i][2]) > reach) return 1;
+  for (int j = 0; j < 3; j++) if (fabs(t[0] * C[0][j] + t[1] * C[1][j] + t[2] * C[2][j]) - (hb[j] + ha[0] * AC[0][j] + ha[1] * AC[1][j] + ha[2] * AC[2][j]) > reach) return 1;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double len2 = 1.0 - C[i][j] * C[i][j]; /* |a_i x b_j|^2 */
+      if (len2 < 1e-6) continue;                    /* nearly parallel edges: the face axes decide */
+      const double sep = fabs(t[i2] * C[i1][j] - t[i1] * C[i2][j]) - (ha[i1] * AC[i2][j] + ha[i2] * AC[i1][j] + hb[j1] * AC[i][j2] + hb[j2] * AC[i][j1]);
+      if (sep > reach * sqrt(len2)) return 1;
+    }
+  return 0;
+}
+
 /* test hook (tests/test_oracle_invariants.py): the convex routine on two shapes - clouds (h = NULL) or analytic boxes (V = NULL).
  * out: dist, pos[3], nrm[3], GJK iterations, EPA iterations */
 int gqo_test_convex(const double* VA, int na, const double* hA, const double* RA, const double* tA, double rA,
@@ -1011,9 +1098,9 @@ static void gqo_collision(GqOracle* o) {
         B.V = m->vert_pos + 3 * m->cloud_vertadr[cl]; B.nv = m->cloud_vertnum[cl]; B.r = r;
         memcpy(B.R, o->geom_xmat[g], sizeof B.R); memcpy(B.t, o->geom_xpos[g], sizeof B.t);
         double dist, nrm[3], pos[3];
-        if (!cvx_pair(&A, &B, margin, &dist, nrm, pos, NULL)) continue;
+        if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 0)) continue;
         Contact* c = &o->contact[o->ncon++];
-        c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = dist; c->tiegap = 1.0;
+        c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = dist; c->tiegap = g_cvx_capped ? 0.0 : cvx_point_tie(&A, &B, nrm);
         memcpy(c->pos, pos, sizeof c->pos);
         set_frame(c, nrm, NULL);
         contact_param(o, w, g, c);
@@ -1119,6 +1206,14 @@ static void gqo_collision(GqOracle* o) {
           double dc[3] = {o->geom_xpos[g2][0] - o->geom_xpos[g1][0], o->geom_xpos[g2][1] - o->geom_xpos[g1][1], o->geom_xpos[g2][2] - o->geom_xpos[g1][2]};
           if (sqrt(dot3(dc, dc)) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue;
         }
+        { /* mid phase: the clouds' oriented boxes */
+          const double* b1x = cloud_box(o, c1); const double* b2x = cloud_box(o, c2);
+          double w1[3], w2[3];
+          mulmatvec3(w1, o->geom_xmat[g1], b1x); mulmatvec3(w2, o->geom_xmat[g2], b2x);
+          for (int k = 0; k < 3; k++) { w1[k] += o->geom_xpos[g1][k]; w2[k] += o->geom_xpos[g2][k]; }
+          g_cvx_stat[8] += 1;
+          if (obb_apart(w1, o->geom_xmat[g1], b1x + 3, w2, o->geom_xmat[g2], b2x + 3, margin + m->cloud_radius[c1] + m->cloud_radius[c2])) continue;
+        }
         Cvx A, B;
         memset(&A, 0, sizeof A); memset(&B, 0, sizeof B);
         A.V = m->vert_pos + 3 * m->cloud_vertadr[c1]; A.nv = m->cloud_vertnum[c1]; A.r = m->cloud_radius[c1];
@@ -1126,9 +1221,9 @@ static void gqo_collision(GqOracle* o) {
         B.V = m->vert_pos + 3 * m->cloud_vertadr[c2]; B.nv = m->cloud_vertnum[c2]; B.r = m->cloud_radius[c2];
         memcpy(B.R, o->geom_xmat[g2], sizeof B.R); memcpy(B.t, o->geom_xpos[g2], sizeof B.t);
         double dist, nrm[3], pos[3];
-        if (!cvx_pair(&A, &B, margin, &dist, nrm, pos, NULL)) continue;
+        if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 1)) continue;
         Contact* c = &o->contact[o->ncon++];
-        c->geom = g2; c->body = b2; c->geom1 = g1; c->body1 = b1; c->dist = dist; c->tiegap = 1.0;
+        c->geom = g2; c->body = b2; c->geom1 = g1; c->body1 = b1; c->dist = dist; c->tiegap = g_cvx_capped ? 0.0 : cvx_point_tie(&A, &B, nrm);
         memcpy(c->pos, pos, sizeof c->pos);
         set_frame(c, nrm, NULL);
         contact_param_pair(o, g1, g2, c);

@@ -133,3 +133,26 @@ extern "C" int emu_box_box(const float* ca, const float* Ra, const float* ha, co
   for (int q = 0; q < H.n; q++) { out[7 * q] = H.dist[q]; out[7 * q + 1] = H.pos[q].x; out[7 * q + 2] = H.pos[q].y; out[7 * q + 3] = H.pos[q].z; out[7 * q + 4] = gq::hit_nrm(H, q).x; out[7 * q + 5] = gq::hit_nrm(H, q).y; out[7 * q + 6] = gq::hit_nrm(H, q).z; }
   return H.n;
 }
+/* the kernel's convex routine (csrc/gq_convex.h: GJK + EPA, one wavefront per pair) called directly on two shapes - vertex clouds (h = NULL)
+ * or analytic boxes (V = NULL) - for a side-by-side with the oracle's restatement: out = dist, pos[3], nrm[3] */
+extern "C" int emu_convex(const float* VA, int na, const float* hA, const float* RA, const float* tA, float rA,
+                          const float* VB, int nb, const float* hB, const float* RB, const float* tB, float rB, float margin, float* out) {
+  std::vector<float> vx, vy, vz;
+  for (int i = 0; i < na; i++) { vx.push_back(VA[3 * i]); vy.push_back(VA[3 * i + 1]); vz.push_back(VA[3 * i + 2]); }
+  for (int i = 0; i < nb; i++) { vx.push_back(VB[3 * i]); vy.push_back(VB[3 * i + 1]); vz.push_back(VB[3 * i + 2]); }
+  if (vx.empty()) { vx.push_back(0); vy.push_back(0); vz.push_back(0); }
+  static float shp[GQ_CVX_SHP_WORDS], poly[GQ_CVX_POLY_WORDS];
+  int hit = 0;
+  emu_run_wave(0, 1, [&]() {
+    gq::CvxShape A, B;
+    A.kind = VA ? 0 : 1; A.adr = 0; A.num = na; A.pm = -1; A.r = rA; A.t = gq::v3(tA[0], tA[1], tA[2]); A.h = hA ? gq::v3(hA[0], hA[1], hA[2]) : gq::v3(0, 0, 0);
+    B.kind = VB ? 0 : 1; B.adr = na; B.num = nb; B.pm = -1; B.r = rB; B.t = gq::v3(tB[0], tB[1], tB[2]); B.h = hB ? gq::v3(hB[0], hB[1], hB[2]) : gq::v3(0, 0, 0);
+    for (int i = 0; i < 9; i++) { A.R[i] = RA[i]; B.R[i] = RB[i]; }
+    gq::cvx_shape_store(shp, A); gq::cvx_shape_store(shp + GQ_CVX_SHAPE_WORDS, B);
+    gq::wave_barrier();
+    const bool h = gq::cvx_pair_wave(shp, poly, vx.data(), vy.data(), vz.data(), 0, margin);
+    if (gq::lane_id() == 0) hit = h ? 1 : 0;
+  });
+  if (hit) { const float* o = shp + 2 * GQ_CVX_SHAPE_WORDS; out[0] = o[0]; out[1] = o[4]; out[2] = o[5]; out[3] = o[6]; out[4] = o[1]; out[5] = o[2]; out[6] = o[3]; }
+  return hit;
+}

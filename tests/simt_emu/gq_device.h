@@ -17,6 +17,7 @@
 #define GQ_WAVE 64
 #define GQ_GLOBAL
 #define GQ_MODEL
+#define GQ_LDS
 #define __global__
 #define __device__
 #define __host__

@@ -1,0 +1,60 @@
+"""How much work the convex narrow phase (oracle/gq_convex.h: GJK + EPA) and the mesh-plane manifold add on benchmark-like states:
+N envs of the CPU oracle under 50 N(0,1) N.m random torques with re-spawn on termination (the headline workload's state distribution,
+scaled down).  Prints per env-step: convex-routine calls that pass the bounding spheres, contacts, GJK / EPA iterations, the contact
+count histogram and the share of env-steps over the kernel's 12-contact capacity.  TEST / MEASUREMENT AID (uses the oracle)."""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
+from helpers import marshalled, random_states   # noqa: E402
+from oracle.oracle import Oracle, lib           # noqa: E402
+
+
+def main(robot='mini_cheetah', n_envs=48, n_steps=250, boxes=None):
+    mm = marshalled(robot, solver=1, iterations=100, tolerance=1e-8, boxes=boxes)
+    md = mm.md
+    L = lib()
+    L.gqo_cvx_stats.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(0)
+    hip = float(mm.desc.key_qpos[2])
+    stats = np.zeros(12, dtype=np.int64)
+    L.gqo_cvx_stats(None, 1)
+    ncon_hist = np.zeros(64, dtype=np.int64)
+    nself_tot = nsteps = nterm = 0
+    for e in range(n_envs):
+        o = Oracle(mm)
+        q, v = random_states(md, 1, rng, z_range=(1.0 * hip, 1.2 * hip))
+        o.set_state(q[0], 0 * v[0], np.zeros(18), np.zeros(18))
+        for k in range(n_steps):
+            o.step(50.0 * rng.normal(size=12))
+            n = int(o.ncon)
+            ncon_hist[min(n, 63)] += 1
+            g1 = o.get('contact_geom1')[:n]
+            nself_tot += int((g1 >= 0).sum())
+            nsteps += 1
+            bodies = md.geom_bodyid[o.get('contact_geom')[:n].astype(int)]
+            world = g1 < 0
+            if np.any(world & ((bodies < 2) | ((bodies - 2) % 3 != 2))):   # a non-calf body on the ground: the env terminates and re-spawns
+                nterm += 1
+                q, v = random_states(md, 1, rng, z_range=(1.0 * hip, 1.2 * hip))
+                o.set_state(q[0], 0 * v[0], np.zeros(18), np.zeros(18))
+    L.gqo_cvx_stats(stats.ctypes.data_as(C.c_void_p), 1)
+    print(f'{robot}: {nsteps} env-steps, {nterm} terminations, self contacts / step {nself_tot / nsteps:.3f}')
+    print(f"  self pairs past the bounding spheres / step {stats[8] / nsteps:.2f}")
+    for name, s in (("world boxes", stats[:4]), ("self pairs", stats[4:8])):
+        calls = max(int(s[0]), 1)
+        print(f'  {name}: convex calls / step {s[0] / nsteps:.3f}, contacts / call {s[1] / calls:.3f}, GJK its / call {s[2] / calls:.2f}, EPA its / contact {s[3] / max(int(s[1]), 1):.2f}')
+    print(f'  convex contacts that ran into an iteration cap: {stats[9]} of {stats[1] + stats[5]}')
+    tot = ncon_hist.sum()
+    print('  contacts per env-step: mean %.2f, > 12: %.2f %%, histogram %s' % ((ncon_hist * np.arange(64)).sum() / tot, 100 * ncon_hist[13:].sum() / tot,
+                                                                          ' '.join(f'{k}:{100 * c / tot:.1f}' for k, c in enumerate(ncon_hist) if c)))
+
+
+if __name__ == '__main__':
+    main(*(sys.argv[1:2] or ['mini_cheetah']))
