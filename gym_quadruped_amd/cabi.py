@@ -57,7 +57,7 @@ class GqModelDesc(C.Structure):
         ('hfield_condim', C.c_int32), ('hfield_priority', C.c_int32),
         ('nselfpair', C.c_int32), ('selfpair_geom1', _I), ('selfpair_geom2', _I), ('geom_capsule', _D), ('geom_type', _I),
         ('plane_grid', C.c_int32), ('plane_vert_pos', _D), ('plane_mask', _I),
-        ('nadj', C.c_int32), ('vert_adjadr', _I), ('vert_adjnum', _I), ('vert_adj', _I), ('plane_order', _I),
+        ('nadj', C.c_int32), ('vert_adjadr', _I), ('vert_adjnum', _I), ('vert_adj', _I), ('plane_order', _I), ('plane_cap', _D),
     ]
 
 
@@ -235,6 +235,7 @@ def _plane_support_tables(md: ModelDesc, grid, chunk, wide_deg, slack):
     ncl = len(md.cloud_vertnum)
     masks = np.ones((ncl, 6 * grid * grid), dtype=np.int32)
     perm = np.zeros(len(vert), dtype=np.int32)
+    caps = np.zeros((ncl, 16, 4)); caps[:, :, 3] = -2.0
     for cl in range(ncl):
         n, a = int(md.cloud_vertnum[cl]), int(md.cloud_vertadr[cl])
         perm[a:a + n] = np.arange(n)
@@ -278,7 +279,16 @@ def _plane_support_tables(md: ModelDesc, grid, chunk, wide_deg, slack):
         for k in range((n + chunk - 1) // chunk):
             m |= (touch[:, chunk_of == k].any(1).astype(np.int64) << k)
         masks[cl] = m.astype(np.int32)
-    return vert, masks, perm
+        for k in range((n + chunk - 1) // chunk):
+            mem = np.nonzero(chunk_of == k)[0]
+            a_k = ax[mem].sum(0)
+            if np.linalg.norm(a_k) < 1e-9 or np.any(th[mem] >= np.pi - 1e-9):
+                continue   # a vertex that may support any direction: the chunk is always scanned
+            a_k /= np.linalg.norm(a_k)
+            half = float(np.max(np.arccos(np.clip(ax[mem] @ a_k, -1.0, 1.0)) + th[mem])) + slack
+            if half < np.pi:
+                caps[cl, k, :3], caps[cl, k, 3] = a_k, np.cos(half)
+    return vert, masks, perm, caps
 
 
 _GRAPH_CACHE = {}
@@ -402,9 +412,10 @@ class MarshalledModel:
             d.hfield_condim, d.hfield_priority = hg['condim'], hg['priority']
         # hull-versus-plane support tables (optional in the C-ABI: NULL = every chunk of a cloud is scanned)
         if nvert > 0 and any(int(c) > 64 for c in md.cloud_vertnum):
-            pv, pm, po = plane_support_tables(md)
-            pv, pm, po = np.ascontiguousarray(pv, dtype=np.float64), np.ascontiguousarray(pm, dtype=np.int32), np.ascontiguousarray(po, dtype=np.int32)
-            self._keep += [pv, pm, po]
+            pv, pm, po, pc = plane_support_tables(md)
+            pv, pm, po, pc = np.ascontiguousarray(pv, dtype=np.float64), np.ascontiguousarray(pm, dtype=np.int32), np.ascontiguousarray(po, dtype=np.int32), np.ascontiguousarray(pc, dtype=np.float64)
+            self._keep += [pv, pm, po, pc]
+            d.plane_cap = pc.ctypes.data_as(_D)
             d.plane_grid = PLANE_GRID
             d.plane_vert_pos = pv.ctypes.data_as(_D)
             d.plane_mask = pm.ctypes.data_as(_I)

@@ -213,7 +213,7 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
     const GQ_MODEL GqDevGeom& G = m.lg[g];
     const float* Rb = W.xmat[G.body];
     CvxShape S;
-    S.kind = 0; S.adr = G.plane_adr; S.num = G.cloud_num; S.pm = G.pmask_adr; S.r = G.radius; S.h = v3(0.0f, 0.0f, 0.0f);
+    S.kind = 0; S.adr = G.plane_adr; S.num = G.cloud_num; S.pm = G.cap_adr; S.r = G.radius; S.h = v3(0.0f, 0.0f, 0.0f);
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -222,7 +222,7 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
     wave_barrier();
     cvx_shape_store(GQ_CVX_SHP(W) + GQ_CVX_SHAPE_WORDS, S);
     wave_barrier();
-    const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_BOX(W), vx, vy, vz, m.plane_grid, m.boxmix[B.cls][4 + g].margin);
+    const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_BOX(W), vx, vy, vz, m.boxmix[B.cls][4 + g].margin);
     if (lane == 0) {
       LdsCF out = GQ_CVX_SHP(W) + 2 * GQ_CVX_SHAPE_WORDS;
       W.u2.c.lg_dist[g] = hit ? out[0] : 1e30f;
@@ -686,7 +686,7 @@ __device__ inline void self_item_shape(const WaveMem& W, const GQ_MODEL GqDevMod
   } else {
     const GQ_MODEL GqDevGeom& G = m.lg[it - 4];
     const float* Rb = W.xmat[G.body];
-    S.kind = 0; S.adr = G.plane_adr; S.num = G.cloud_num; S.pm = G.pmask_adr; S.r = G.radius; S.h = v3(0.0f, 0.0f, 0.0f);
+    S.kind = 0; S.adr = G.plane_adr; S.num = G.cloud_num; S.pm = G.cap_adr; S.r = G.radius; S.h = v3(0.0f, 0.0f, 0.0f);
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -872,7 +872,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         self_item_shape(W, m, i1, cw[i1], GQ_CVX_SHP(W));
         self_item_shape(W, m, i2, cw[i2], GQ_CVX_SHP(W) + GQ_CVX_SHAPE_WORDS);
         wave_barrier();
-        const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_SELF(W), K.vx, K.vy, K.vz, m.plane_grid, m.sp[pj].mix.margin);
+        const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_SELF(W), K.vx, K.vy, K.vz, m.sp[pj].mix.margin);
         if (hit && lane == j) {
           LdsCF out = GQ_CVX_SHP(W) + 2 * GQ_CVX_SHAPE_WORDS;
           H.n = 1; H.dist[0] = out[0]; H.nrm[0] = ld3(out + 1); H.pos[0] = ld3(out + 4);

@@ -22,6 +22,14 @@
 
 namespace gq {
 
+/* The routine is INLINED into the kernel: as a function of its own (one copy of the code, two call sites) its register need is not bounded by
+ * the kernel's __launch_bounds__ - the step kernels that call it were allocated 165 VGPRs, two waves per SIMD instead of four, and a 4 096-env
+ * batch was no longer co-resident (launch time x 3).  -DGQ_CVX_CALL keeps the call for experiments. */
+#ifdef GQ_CVX_CALL
+#define GQ_CVX_FN __device__ __attribute__((noinline))
+#else
+#define GQ_CVX_FN __device__ __forceinline__
+#endif
 #define GQ_CVX_GJK_MAXIT 32
 #define GQ_CVX_EPA_MAXIT 24
 #define GQ_CVX_MAXV 28                 /* polytope vertices: 4 + one per EPA iteration */
@@ -33,7 +41,7 @@ namespace gq {
 #define GQ_CVX_TOL_EPA 1e-8f           /* metres: a face whose support point lies no farther out is a face of A - B (the round-off of fp32 coordinates about the base is 6e-8; the usual exit is exact - the support vertex is already a vertex of the polytope) */
 
 /* a shape as the routine sees it (wave-uniform, in LDS): kind 0 vertex cloud [adr, adr + num) of the vertex arrays in the frame (R, t),
- * pm = index of its direction-cell chunk masks or -1; kind 1 box, centre t, axes = columns of R, half extents h; kind 2 segment t .. h
+ * pm = index of its chunk caps in the vertex arrays (GqDevGeom::cap_adr) or -1; kind 1 box, centre t, axes = columns of R, half extents h; kind 2 segment t .. h
  * (capsule / sphere core, world end points).  r: the radius that inflates the core. */
 struct CvxShape { int kind, adr, num, pm; float R[9]; V3 t, h; float r; };
 /* the routine is a function of its own (one copy per kernel, two call sites): its scratch pointers carry the LDS address space in their
@@ -51,81 +59,104 @@ __device__ __forceinline__ void cvx_shape_store(LdsF S, const CvxShape& s) { /* 
   st3l(S + 13, s.t); st3l(S + 16, s.h); S[19] = s.r;
 }
 
-struct CvxSup { V3 p; int id; };
-/* support point of the core of shape S in world direction d (wave-uniform in, wave-uniform out) */
-__device__ inline CvxSup cvx_support(LdsCF S, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const int grid, const V3 d) {
-  LdsCI I = (LdsCI)S;
-  const int kind = uniform(I[0]);
-  CvxSup o;
-  if (kind == 2) {
-    const V3 p0 = ld3(S + 13), p1 = ld3(S + 16);
-    const bool far = dot(d, p1 - p0) > 0.0f;
-    o.p = far ? p1 : p0; o.id = far ? 1 : 0;
-    return o;
-  }
-  LdsCF R = S + 4;
-  const V3 dl = matTvec(R, d), t = ld3(S + 13);
-  if (kind == 1) {
-    const V3 h = ld3(S + 16);
-    const V3 q = v3(dl.x < 0.0f ? -h.x : h.x, dl.y < 0.0f ? -h.y : h.y, dl.z < 0.0f ? -h.z : h.z);
-    o.id = (dl.x < 0.0f ? 1 : 0) | (dl.y < 0.0f ? 2 : 0) | (dl.z < 0.0f ? 4 : 0);
-    o.p = t + matvec(R, q);
-    return o;
-  }
+/* per-lane copy of the two shapes' chunk caps (lane k < 16: chunk k of A, lane 16 + k: chunk k of B): the support vertex of direction d
+ * can only lie in a chunk whose cap - axis, cosine of the half angle; host: cabi.plane_support_tables, the enclosing cap of the normal
+ * cones of the chunk's vertices in the DIRECTION-ordered copy - contains d.  One load per pair, at the start of the routine: a support
+ * query then costs ONE memory round trip (the vertex loads of both shapes' chunks, issued together) instead of a table word and then the
+ * vertices, per shape one after the other - the pair routine is a chain of such queries and nothing else */
+struct CvxCaps { V3 ax; float cs; };
+__device__ inline CvxCaps cvx_caps_fetch(LdsCF SA, LdsCF SB, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz) {
   const int lane = lane_id();
-  const int adr = uniform(I[1]), num = uniform(I[2]), pm = uniform(I[3]);
-  int cm = (1 << ((num + GQ_WAVE - 1) / GQ_WAVE)) - 1;
-  if (pm >= 0) { /* wave-uniform: the chunks that can hold the support vertex of dl (the cell formula of stage_collision_scan) */
-    const float ax_ = fabsf(dl.x), ay_ = fabsf(dl.y), az_ = fabsf(dl.z);
-    const int mx_ = (ax_ >= ay_ && ax_ >= az_) ? 0 : (ay_ >= az_ ? 1 : 2);
-    const float dm = mx_ == 0 ? dl.x : (mx_ == 1 ? dl.y : dl.z);
-    const float o0 = mx_ == 0 ? dl.y : dl.x, o1 = mx_ == 2 ? dl.y : dl.z;
-    const float inv = fast_rcp(fmaxf(fabsf(dm), 1e-30f));
-    const float hg = 0.5f * (float)grid;
-    const int iu = imin(imax((int)((o0 * inv + 1.0f) * hg), 0), grid - 1), iv = imin(imax((int)((o1 * inv + 1.0f) * hg), 0), grid - 1);
-    const int cell = ((mx_ * 2 + (dm > 0.0f ? 0 : 1)) * grid + iu) * grid + iv;
-    cm = uniform((int)vx[pm + cell]);
+  LdsCI IA = (LdsCI)SA; LdsCI IB = (LdsCI)SB;
+  const int k = lane & 15;
+  const int capA = uniform(IA[3]), capB = uniform(IB[3]);
+  const int c = lane < 16 ? capA : capB;
+  CvxCaps o;
+  o.ax = v3(0.0f, 0.0f, 0.0f); o.cs = -2.0f; /* no caps: every chunk passes */
+  if (lane < 32 && c >= 0) { o.ax = v3(vx[c + k], vy[c + k], vz[c + k]); o.cs = vx[c + 16 + k]; }
+  return o;
+}
+
+/* support point of A - B in world direction d: w = s_A(d) - s_B(-d) and the packed vertex ids (ia | ib << 16).  Clouds: lane = vertex
+ * over the chunks their caps let through, the loads of BOTH shapes in flight together, DPP wave-max, the winners' coordinates by v_readlane;
+ * boxes and segments answer analytically.  (One copy of this code per kernel.) */
+struct CvxMink { V3 w; int id; };
+GQ_CVX_FN CvxMink cvx_minkowski(LdsCF SA, LdsCF SB, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const V3 d, const CvxCaps caps) {
+  const int lane = lane_id();
+  LdsCI IA = (LdsCI)SA; LdsCI IB = (LdsCI)SB;
+  const int kA = uniform(IA[0]), kB = uniform(IB[0]);
+  const V3 dlA = matTvec(SA + 4, d), dlB = matTvec(SB + 4, -1.0f * d);
+  int cmA = 0, cmB = 0, adrA = 0, adrB = 0, lastA = 0, lastB = 0;
+  if (kA == 0 || kB == 0) { /* wave-uniform */
+    const V3 mine = lane < 16 ? dlA : dlB;
+    const float inv = fast_rsqrt(fmaxf(dot(mine, mine), 1e-30f));
+    const uint64_t pass = ballot(inv * dot(mine, caps.ax) >= caps.cs - 1e-4f);
+    if (kA == 0) { adrA = uniform(IA[1]); const int n = uniform(IA[2]); lastA = adrA + n - 1; cmA = (int)(pass & 0xffffull) & ((1 << ((n + GQ_WAVE - 1) / GQ_WAVE)) - 1); }
+    if (kB == 0) { adrB = uniform(IB[1]); const int n = uniform(IB[2]); lastB = adrB + n - 1; cmB = (int)((pass >> 16) & 0xffffull) & ((1 << ((n + GQ_WAVE - 1) / GQ_WAVE)) - 1); }
   }
-  const int last = adr + num - 1;
-  float best = -3e38f;
-  V3 bp = v3(0.0f, 0.0f, 0.0f);
-  int bi = adr;
-  while (cm) { /* wave-uniform: up to four chunks with their twelve loads in flight together; lanes past the end re-read the last vertex */
-    int cu[4];
-    float px[4], py[4], pz[4];
+  float bestA = -3e38f, bestB = -3e38f;
+  V3 pA = v3(0.0f, 0.0f, 0.0f), pB = v3(0.0f, 0.0f, 0.0f);
+  int iA = adrA, iB = adrB;
+  while (cmA | cmB) { /* wave-uniform: up to three chunks of each shape per trip, their loads in flight together; lanes past the end re-read the last vertex */
+    int cu[6];
+    float px[6], py[6], pz[6];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { cu[u] = cm ? __builtin_ctz(cm) : -1; cm &= cm - 1; }
+    for (int u = 0; u < 3; u++) { cu[u] = cmA ? __builtin_ctz(cmA) : -1; cmA &= cmA - 1; }
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 3; u < 6; u++) { cu[u] = cmB ? __builtin_ctz(cmB) : -1; cmB &= cmB - 1; }
+#pragma unroll
+    for (int u = 0; u < 6; u++)
       if (cu[u] >= 0) {
-        const int i = adr + cu[u] * GQ_WAVE + lane, ii = i < last ? i : last;
+        const int i = (u < 3 ? adrA : adrB) + cu[u] * GQ_WAVE + lane, last = u < 3 ? lastA : lastB, ii = i < last ? i : last;
         px[u] = vx[ii]; py[u] = vy[ii]; pz[u] = vz[ii];
       }
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 3; u++)
       if (cu[u] >= 0) {
-        const int i = adr + cu[u] * GQ_WAVE + lane, ii = i < last ? i : last;
-        const float pr = dl.x * px[u] + dl.y * py[u] + dl.z * pz[u];
-        if (pr > best) { best = pr; bp = v3(px[u], py[u], pz[u]); bi = ii; }
+        const int i = adrA + cu[u] * GQ_WAVE + lane, ii = i < lastA ? i : lastA;
+        const float pr = dlA.x * px[u] + dlA.y * py[u] + dlA.z * pz[u];
+        if (pr > bestA) { bestA = pr; pA = v3(px[u], py[u], pz[u]); iA = ii; }
+      }
+#pragma unroll
+    for (int u = 3; u < 6; u++)
+      if (cu[u] >= 0) {
+        const int i = adrB + cu[u] * GQ_WAVE + lane, ii = i < lastB ? i : lastB;
+        const float pr = dlB.x * px[u] + dlB.y * py[u] + dlB.z * pz[u];
+        if (pr > bestB) { bestB = pr; pB = v3(px[u], py[u], pz[u]); iB = ii; }
       }
   }
-  const float wmax = wave_max(best);
-  const int who = ffs64(ballot(best == wmax));
-  const V3 q = v3(bcast(bp.x, who), bcast(bp.y, who), bcast(bp.z, who));
-  o.id = bcast(bi, who) - adr;
-  o.p = t + matvec(R, q);
-  return o;
-}
-/* support point of A - B in direction d: w = s_A(d) - s_B(-d) and the packed vertex ids (one copy of the scan code per kernel) */
-struct CvxMink { V3 w; int id; };
-__device__
-#ifndef GQ_CVX_INLINE
-__attribute__((noinline))
-#endif
-CvxMink cvx_minkowski(LdsCF SA, LdsCF SB, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const int grid, const V3 d) {
-  const CvxSup a = cvx_support(SA, vx, vy, vz, grid, d), b = cvx_support(SB, vx, vy, vz, grid, -1.0f * d);
+  V3 a, b;
+  int ida, idb;
+  if (kA == 0) {
+    const float wmax = wave_max(bestA);
+    const int who = ffs64(ballot(bestA == wmax));
+    a = ld3(SA + 13) + matvec(SA + 4, v3(bcast(pA.x, who), bcast(pA.y, who), bcast(pA.z, who)));
+    ida = bcast(iA, who) - adrA;
+  } else if (kA == 1) {
+    const V3 h = ld3(SA + 16);
+    ida = (dlA.x < 0.0f ? 1 : 0) | (dlA.y < 0.0f ? 2 : 0) | (dlA.z < 0.0f ? 4 : 0);
+    a = ld3(SA + 13) + matvec(SA + 4, v3(dlA.x < 0.0f ? -h.x : h.x, dlA.y < 0.0f ? -h.y : h.y, dlA.z < 0.0f ? -h.z : h.z));
+  } else {
+    const V3 p0 = ld3(SA + 13), p1 = ld3(SA + 16);
+    const bool far = dot(d, p1 - p0) > 0.0f;
+    a = far ? p1 : p0; ida = far ? 1 : 0;
+  }
+  if (kB == 0) {
+    const float wmax = wave_max(bestB);
+    const int who = ffs64(ballot(bestB == wmax));
+    b = ld3(SB + 13) + matvec(SB + 4, v3(bcast(pB.x, who), bcast(pB.y, who), bcast(pB.z, who)));
+    idb = bcast(iB, who) - adrB;
+  } else if (kB == 1) {
+    const V3 h = ld3(SB + 16);
+    idb = (dlB.x < 0.0f ? 1 : 0) | (dlB.y < 0.0f ? 2 : 0) | (dlB.z < 0.0f ? 4 : 0);
+    b = ld3(SB + 13) + matvec(SB + 4, v3(dlB.x < 0.0f ? -h.x : h.x, dlB.y < 0.0f ? -h.y : h.y, dlB.z < 0.0f ? -h.z : h.z));
+  } else {
+    const V3 p0 = ld3(SB + 13), p1 = ld3(SB + 16);
+    const bool far = dot(d, p1 - p0) < 0.0f;
+    b = far ? p1 : p0; idb = far ? 1 : 0;
+  }
   CvxMink o;
-  o.w = a.p - b.p; o.id = a.id | (b.id << 16);
+  o.w = a - b; o.id = ida | (idb << 16);
   return o;
 }
 /* the point of shape S that cvx_support returned with `id` */
@@ -235,11 +266,7 @@ __device__ __forceinline__ void cvx_face_plane(V3 a, V3 b, V3 c, V3& n, float& d
 
 /* One convex pair.  shp: the two shape descriptors (A, B: GQ_CVX_SHAPE_WORDS each), then the result - dist, normal A -> B (3), point (3);
  * poly: GQ_CVX_POLY_WORDS words of scratch.  Returns true when the inflated shapes are closer than margin.  Wave-uniform. */
-__device__
-#ifndef GQ_CVX_INLINE
-__attribute__((noinline))
-#endif
-bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const int grid, const float margin) {
+GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const float margin) {
   const int lane = lane_id();
   LdsCF SA = shp; LdsCF SB = shp + GQ_CVX_SHAPE_WORDS;
   LdsF out = shp + 2 * GQ_CVX_SHAPE_WORDS;
@@ -249,6 +276,7 @@ bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL
   LdsI RIM = ADJ + 64;
   const float rA = SA[19], rB = SB[19], reach = margin + rA + rB;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const CvxCaps caps = cvx_caps_fetch(SA, SB, vx, vy, vz);
   /* ---- GJK */
   V3 v;
   float lam[4] = {1.0f, 0.0f, 0.0f, 0.0f};
@@ -257,8 +285,9 @@ bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL
     V3 d0 = (uniform(((LdsCI)SB)[0]) == 2 ? 0.5f * (ld3(SB + 13) + ld3(SB + 16)) : ld3(SB + 13)) -
             (uniform(((LdsCI)SA)[0]) == 2 ? 0.5f * (ld3(SA + 13) + ld3(SA + 16)) : ld3(SA + 13));
     if (dot(d0, d0) < 1e-24f) d0 = v3(1.0f, 0.0f, 0.0f);
-    const CvxMink s0 = cvx_minkowski(SA, SB, vx, vy, vz, grid, d0);
+    const CvxMink s0 = cvx_minkowski(SA, SB, vx, vy, vz, d0, caps);
     v = s0.w;
+    if (-dot(v, d0) > reach * fast_sqrt(dot(d0, d0))) return false; /* the first direction already separates the cores by more than reach */
     wave_barrier();
     st3l(P, v); PI[3] = s0.id;
     wave_barrier();
@@ -268,7 +297,7 @@ bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL
   for (int it = 0; it < GQ_CVX_GJK_MAXIT; it++) {
     const float vv = dot(v, v);
     if (vv < 1e-24f) { enclosed = true; break; } /* the origin lies on the simplex: touching cores */
-    const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, grid, -1.0f * v);
+    const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, -1.0f * v, caps);
     const V3 w = sw.w;
     const float vw = dot(v, w);
     if (vw > 0.0f && vw * vw > reach * reach * vv) return false; /* the cores are farther apart than anything of interest */
@@ -338,7 +367,7 @@ bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL
       else if (ns == 2) { dir = cross(GQ_CVX_PW(P, 1) - p0, axk); if (tries >= 3 && tries < 6) dir = -1.0f * dir; }
       else { dir = cross(GQ_CVX_PW(P, 1) - p0, GQ_CVX_PW(P, 2) - p0); if (tries & 1) dir = -1.0f * dir; }
       if (dot(dir, dir) < 1e-30f) continue;
-      const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, grid, dir);
+      const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, dir, caps);
       const V3 w = sw.w;
       const int wid = sw.id;
       bool dup = false;
@@ -387,7 +416,7 @@ bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL
     best = ffs64(bm);
     if (eit >= GQ_CVX_EPA_MAXIT || nv >= GQ_CVX_MAXV) break;
     const V3 nb = v3(bcast(fn.x, best), bcast(fn.y, best), bcast(fn.z, best));
-    const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, grid, nb);
+    const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, nb, caps);
     const V3 w = sw.w;
     const int wid = sw.id;
     const bool dup = ballot(lane < nv && GQ_CVX_PID(P, lane < nv ? lane : 0) == wid) != 0;

@@ -254,7 +254,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
   if (d->plane_grid < 0 || d->plane_grid > 16) FAIL("plane_grid %d out of range (0 .. 16)", d->plane_grid);
   M.plane_grid = plane_tables ? d->plane_grid : 0;
   int plane_base = 0;
-  std::vector<int> cloud_pmask(d->ncloud > 0 ? d->ncloud : 0, -1);
+  std::vector<int> cloud_pmask(d->ncloud > 0 ? d->ncloud : 0, -1), cloud_cap(d->ncloud > 0 ? d->ncloud : 0, -1);
   if (plane_tables) {
     plane_base = (int)vx->size();
     for (int i = 0; i < d->nvert; i++) { vx->push_back((float)d->plane_vert_pos[3 * i]); vy->push_back((float)d->plane_vert_pos[3 * i + 1]); vz->push_back((float)d->plane_vert_pos[3 * i + 2]); }
@@ -264,6 +264,12 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       if (d->cloud_vertnum[cl] > 16 * 64) FAIL("cloud %d: %d vertices - the plane masks hold 16 chunks of 64", cl, d->cloud_vertnum[cl]);
       cloud_pmask[cl] = (int)vx->size();
       for (int c = 0; c < ncell; c++) { vx->push_back((float)(d->plane_mask[(size_t)cl * ncell + c] & 0xffff)); vy->push_back(0.0f); vz->push_back(0.0f); }
+      if (d->plane_cap) { /* chunk caps: 16 axes, then 16 cosines */
+        cloud_cap[cl] = (int)vx->size();
+        const double* Cp = d->plane_cap + (size_t)cl * 64;
+        for (int k = 0; k < 16; k++) { vx->push_back((float)Cp[4 * k]); vy->push_back((float)Cp[4 * k + 1]); vz->push_back((float)Cp[4 * k + 2]); }
+        for (int k = 0; k < 16; k++) { vx->push_back((float)(Cp[4 * k + 3] <= -1.5 ? -2.0 : Cp[4 * k + 3] - 1e-6)); vy->push_back(0.0f); vz->push_back(0.0f); }
+      }
     }
   }
   /* hull graphs (optional): per cloud with a graph, one record per vertex of the DIRECTION-ordered copy - x = first entry of its neighbour
@@ -310,7 +316,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     if (M.nlg >= GQ_MAXLG) FAIL("more than %d link collision geoms", GQ_MAXLG);
     GqDevGeom& G = M.lg[M.nlg++];
     G.body = b - 1; G.cloud_adr = d->cloud_vertadr[cl]; G.cloud_num = d->cloud_vertnum[cl]; G.radius = (float)d->cloud_radius[cl];
-    G.plane_adr = plane_base + G.cloud_adr; G.pmask_adr = cloud_pmask[cl]; G.nbr_adr = cloud_nbr[cl];
+    G.plane_adr = plane_base + G.cloud_adr; G.pmask_adr = cloud_pmask[cl]; G.cap_adr = cloud_cap[cl]; G.nbr_adr = cloud_nbr[cl];
     double R[9]; quat2mat(d->geom_quat + 4 * g, R);
     for (int i = 0; i < 3; i++) G.pos[i] = (float)d->geom_pos[3 * g + i];
     for (int i = 0; i < 9; i++) G.mat[i] = (float)R[i];

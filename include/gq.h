@@ -221,6 +221,10 @@ typedef struct GqModelDesc {
   const int32_t* vert_adjnum;    /* [nvert] */
   const int32_t* vert_adj;       /* [nadj] */
   const int32_t* plane_order;    /* [nvert] */
+  /* OPTIONAL (with plane_vert_pos): per cloud and per 64-vertex chunk of its direction-ordered copy a cap of directions - unit axis (geom
+   * frame), cosine of the half angle - containing every direction one of the chunk's vertices supports; cos = -2: the chunk is always
+   * scanned.  The convex routine (csrc/gq_convex.h) takes its support vertices from the chunks whose cap contains the query direction. */
+  const double* plane_cap;       /* [ncloud][16][4] */
 } GqModelDesc;
 
 typedef struct GqModel GqModel;

@@ -146,16 +146,18 @@ static void cvx_face_plane(const CvxPt* P, CvxFace* f) {
 /* GJK + EPA on the cores of A and B.  reach: contacts farther apart than this (core to core) are of no interest.
  * Returns 0: no contact within reach; 1: cores apart, *dist > 0; 2: cores overlap, *dist < 0.  n: unit normal from A to B;
  * pa / pb: witness points on the two cores.  niter (optional): GJK and EPA iteration counts. */
-static int cvx_gjk_epa(const Cvx* A, const Cvx* B, double reach, double tol_rel, double tol_epa, double* dist, double* n, double* pa, double* pb, int* niter) {
+static int cvx_gjk_epa(const Cvx* A, const Cvx* B, double reach, double tol_rel, double tol_epa, double* dist, double* n, double* pa, double* pb, int* niter, const double* hint) {
   CvxPt S[4], P[CVX_EPA_MAXV];
   int ns = 0;
   double v[3], lam[4] = {1, 0, 0, 0}, d0[3] = {B->t[0] - A->t[0], B->t[1] - A->t[1], B->t[2] - A->t[2]};
+  if (hint) memcpy(d0, hint, sizeof d0); /* the mid phase's best separating-axis candidate, from A to B (gq_oracle.c obb_apart) */
   if (cvx_dot(d0, d0) < 1e-24) { d0[0] = 1; d0[1] = 0; d0[2] = 0; }
   cvx_minkowski(A, B, d0, &S[0]);
+  if (niter) niter[0] = niter[1] = 0;
+  if (-cvx_dot(S[0].w, d0) > reach * sqrt(cvx_dot(d0, d0))) return 0; /* the first direction already separates the cores by more than reach */
   ns = 1;
   memcpy(v, S[0].w, sizeof v);
   int enclosed = 0, it;
-  if (niter) niter[0] = niter[1] = 0;
   for (it = 0; it < CVX_GJK_MAXIT; it++) {
     const double vv = cvx_dot(v, v);
     if (vv < 1e-28) { enclosed = 1; break; } /* the origin lies ON the simplex: touching cores */
@@ -339,9 +341,9 @@ static int cvx_gjk_epa(const Cvx* A, const Cvx* B, double reach, double tol_rel,
 }
 
 /* one contact of a convex pair: signed distance of the inflated shapes, normal A -> B, point midway between the surfaces */
-static int cvx_pair(const Cvx* A, const Cvx* B, double margin, double* dist, double* nrm, double* pos, int* niter) {
+static int cvx_pair(const Cvx* A, const Cvx* B, double margin, double* dist, double* nrm, double* pos, int* niter, const double* hint) {
   double n[3], pa[3], pb[3], dc;
-  const int rc = cvx_gjk_epa(A, B, margin + A->r + B->r, 1e-13, 1e-10, &dc, n, pa, pb, niter);
+  const int rc = cvx_gjk_epa(A, B, margin + A->r + B->r, 1e-13, 1e-10, &dc, n, pa, pb, niter, hint);
   if (!rc) return 0;
   const double d = dc - A->r - B->r;
   if (d >= margin) return 0;

@@ -868,9 +868,9 @@ static double cvx_point_tie(const Cvx* A, const Cvx* B, const double* n) {
   return 1.0;
 }
 static int g_cvx_capped; /* the last pair ran into an iteration cap: its answer is the iteration's state there, not the converged one (test diagnostics) */
-static int cvx_pair_counted(const Cvx* A, const Cvx* B, double margin, double* dist, double* nrm, double* pos, int self) {
+static int cvx_pair_counted(const Cvx* A, const Cvx* B, double margin, double* dist, double* nrm, double* pos, int self, const double* hint) {
   int it[2] = {0, 0};
-  const int rc = cvx_pair(A, B, margin, dist, nrm, pos, it);
+  const int rc = cvx_pair(A, B, margin, dist, nrm, pos, it, hint);
   long long* s = g_cvx_stat + (self ? 4 : 0);
   s[0] += 1; s[1] += rc; s[2] += it[0]; s[3] += it[1];
   g_cvx_capped = rc && (it[1] >= CVX_EPA_MAXIT || it[0] >= CVX_GJK_MAXIT);
@@ -892,23 +892,45 @@ static const double* cloud_box(GqOracle* o, int cl) {
   }
   return o->cloud_aabb[cl < 64 ? cl : 63];
 }
-static int obb_apart(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb, double reach) {
+static int obb_apart(const double* ca, const double* Ra, const double* ha, const double* cb, const double* Rb, const double* hb, double reach, double* axis) {
   double C[3][3], AC[3][3], t[3], d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
   for (int i = 0; i < 3; i++) {
     t[i] = Ra[i] * d[0] + Ra[3 + i] * d[1] + Ra[6 + i] * d[2];
     for (int j = 0; j < 3; j++) { C[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]; AC[i][j] = fabs(C[i][j]) + 1e-9; }
   }
-  for (int i = 0; i < 3; i++) if (fabs(t[i]) - (ha[i] + hb[0] * AC[i][0] + hb[1] * AC[i][1] + hb[2] * AC[i][2]) > reach) return 1;
-  for (int j = 0; j < 3; j++) if (fabs(t[0] * C[0][j] + t[1] * C[1][j] + t[2] * C[2][j]) - (hb[j] + ha[0] * AC[0][j] + ha[1] * AC[1][j] + ha[2] * AC[2][j]) > reach) return 1;
+  /* the candidate with the largest gap (first of equals, in this order) is GJK's first search direction, turned to point from A to B */
+  double best = -1e300;
+  int apart = 0;
+  axis[0] = d[0]; axis[1] = d[1]; axis[2] = d[2];
+  for (int i = 0; i < 3; i++) {
+    const double gap = fabs(t[i]) - (ha[i] + hb[0] * AC[i][0] + hb[1] * AC[i][1] + hb[2] * AC[i][2]);
+    if (gap > reach) apart = 1;
+    if (gap > best) { best = gap; const double sg = t[i] < 0 ? -1 : 1; for (int k = 0; k < 3; k++) axis[k] = sg * Ra[3 * k + i]; }
+  }
+  for (int j = 0; j < 3; j++) {
+    const double tj = t[0] * C[0][j] + t[1] * C[1][j] + t[2] * C[2][j];
+    const double gap = fabs(tj) - (hb[j] + ha[0] * AC[0][j] + ha[1] * AC[1][j] + ha[2] * AC[2][j]);
+    if (gap > reach) apart = 1;
+    if (gap > best) { best = gap; const double sg = tj < 0 ? -1 : 1; for (int k = 0; k < 3; k++) axis[k] = sg * Rb[3 * k + j]; }
+  }
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
       const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
       const double len2 = 1.0 - C[i][j] * C[i][j]; /* |a_i x b_j|^2 */
-      if (len2 < 1e-6) continue;                    /* nearly parallel edges: the face axes decide */
-      const double sep = fabs(t[i2] * C[i1][j] - t[i1] * C[i2][j]) - (ha[i1] * AC[i2][j] + ha[i2] * AC[i1][j] + hb[j1] * AC[i][j2] + hb[j2] * AC[i][j1]);
-      if (sep > reach * sqrt(len2)) return 1;
+      if (len2 < 1e-4) continue;                    /* nearly parallel edges: the face axes decide */
+      const double len = sqrt(len2), tp = t[i2] * C[i1][j] - t[i1] * C[i2][j];
+      const double gap = (fabs(tp) - (ha[i1] * AC[i2][j] + ha[i2] * AC[i1][j] + hb[j1] * AC[i][j2] + hb[j2] * AC[i][j1])) / len;
+      if (gap > reach) apart = 1;
+      if (gap > best) {
+        best = gap;
+        const double ai[3] = {Ra[i], Ra[3 + i], Ra[6 + i]}, bj[3] = {Rb[j], Rb[3 + j], Rb[6 + j]};
+        double c[3];
+        cross3(c, ai, bj);
+        const double sg = dot3(c, d) < 0 ? -1 : 1;
+        for (int k = 0; k < 3; k++) axis[k] = sg * c[k] / len;
+      }
     }
-  return 0;
+  return apart;
 }
 
 /* test hook (tests/test_oracle_invariants.py): the convex routine on two shapes - clouds (h = NULL) or analytic boxes (V = NULL).
@@ -920,7 +942,7 @@ int gqo_test_convex(const double* VA, int na, const double* hA, const double* RA
   A.box = VA == NULL; A.V = VA; A.nv = na; A.r = rA; memcpy(A.R, RA, sizeof A.R); memcpy(A.t, tA, sizeof A.t); if (hA) memcpy(A.h, hA, sizeof A.h);
   B.box = VB == NULL; B.V = VB; B.nv = nb; B.r = rB; memcpy(B.R, RB, sizeof B.R); memcpy(B.t, tB, sizeof B.t); if (hB) memcpy(B.h, hB, sizeof B.h);
   int it[2] = {0, 0};
-  const int rc = cvx_pair(&A, &B, margin, out, out + 4, out + 1, it);
+  const int rc = cvx_pair(&A, &B, margin, out, out + 4, out + 1, it, NULL);
   out[7] = it[0]; out[8] = it[1];
   return rc;
 }
@@ -1098,7 +1120,7 @@ static void gqo_collision(GqOracle* o) {
         B.V = m->vert_pos + 3 * m->cloud_vertadr[cl]; B.nv = m->cloud_vertnum[cl]; B.r = r;
         memcpy(B.R, o->geom_xmat[g], sizeof B.R); memcpy(B.t, o->geom_xpos[g], sizeof B.t);
         double dist, nrm[3], pos[3];
-        if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 0)) continue;
+        if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 0, NULL)) continue;
         Contact* c = &o->contact[o->ncon++];
         c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = dist; c->tiegap = g_cvx_capped ? 0.0 : cvx_point_tie(&A, &B, nrm);
         memcpy(c->pos, pos, sizeof c->pos);
@@ -1206,13 +1228,14 @@ static void gqo_collision(GqOracle* o) {
           double dc[3] = {o->geom_xpos[g2][0] - o->geom_xpos[g1][0], o->geom_xpos[g2][1] - o->geom_xpos[g1][1], o->geom_xpos[g2][2] - o->geom_xpos[g1][2]};
           if (sqrt(dot3(dc, dc)) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue;
         }
+        double hint[3];
         { /* mid phase: the clouds' oriented boxes */
           const double* b1x = cloud_box(o, c1); const double* b2x = cloud_box(o, c2);
           double w1[3], w2[3];
           mulmatvec3(w1, o->geom_xmat[g1], b1x); mulmatvec3(w2, o->geom_xmat[g2], b2x);
           for (int k = 0; k < 3; k++) { w1[k] += o->geom_xpos[g1][k]; w2[k] += o->geom_xpos[g2][k]; }
           g_cvx_stat[8] += 1;
-          if (obb_apart(w1, o->geom_xmat[g1], b1x + 3, w2, o->geom_xmat[g2], b2x + 3, margin + m->cloud_radius[c1] + m->cloud_radius[c2])) continue;
+          if (obb_apart(w1, o->geom_xmat[g1], b1x + 3, w2, o->geom_xmat[g2], b2x + 3, margin + m->cloud_radius[c1] + m->cloud_radius[c2], hint)) continue;
         }
         Cvx A, B;
         memset(&A, 0, sizeof A); memset(&B, 0, sizeof B);
@@ -1221,7 +1244,8 @@ static void gqo_collision(GqOracle* o) {
         B.V = m->vert_pos + 3 * m->cloud_vertadr[c2]; B.nv = m->cloud_vertnum[c2]; B.r = m->cloud_radius[c2];
         memcpy(B.R, o->geom_xmat[g2], sizeof B.R); memcpy(B.t, o->geom_xpos[g2], sizeof B.t);
         double dist, nrm[3], pos[3];
-        if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 1)) continue;
+        (void)hint; /* (the mid phase's best axis as GJK's first direction was tried: boxes that overlap are not separated along their own axes, the hulls inside them hardly ever are) */
+        if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 1, NULL)) continue;
         Contact* c = &o->contact[o->ncon++];
         c->geom = g2; c->body = b2; c->geom1 = g1; c->body1 = b1; c->dist = dist; c->tiegap = g_cvx_capped ? 0.0 : cvx_point_tie(&A, &B, nrm);
         memcpy(c->pos, pos, sizeof c->pos);

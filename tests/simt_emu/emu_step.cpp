@@ -150,7 +150,7 @@ extern "C" int emu_convex(const float* VA, int na, const float* hA, const float*
     for (int i = 0; i < 9; i++) { A.R[i] = RA[i]; B.R[i] = RB[i]; }
     gq::cvx_shape_store(shp, A); gq::cvx_shape_store(shp + GQ_CVX_SHAPE_WORDS, B);
     gq::wave_barrier();
-    const bool h = gq::cvx_pair_wave(shp, poly, vx.data(), vy.data(), vz.data(), 0, margin);
+    const bool h = gq::cvx_pair_wave(shp, poly, vx.data(), vy.data(), vz.data(), margin);
     if (gq::lane_id() == 0) hit = h ? 1 : 0;
   });
   if (hit) { const float* o = shp + 2 * GQ_CVX_SHAPE_WORDS; out[0] = o[0]; out[1] = o[4]; out[2] = o[5]; out[3] = o[6]; out[4] = o[1]; out[5] = o[2]; out[6] = o[3]; }

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import budgeted_states, ALL_OBS, ParityTally, marshalled, random_states, self_contact_states, split_obs, tally_note
+from helpers import budgeted_states, oracle_fits_row_budget, ALL_OBS, ParityTally, marshalled, random_states, self_contact_states, split_obs, tally_note
 
 pytestmark = pytest.mark.gpu
 
@@ -61,6 +61,10 @@ def test_step_matches_oracle_stagewise():
         if o.ncon and o.get('contact_tiegap').min() < 3e-7:
             n_tie += 1
             assert np.all(np.isfinite(qvel_g[e])) and np.abs(qvel_g[e] - o.qvel).max() < 0.05
+            continue
+        if not oracle_fits_row_budget(o, False):   # a robot pressed into the floor: its mesh manifolds exceed the kernel's 12 contacts / 63 rows (the budget tests hold those to the prefix rule)
+            if e < ndbg:
+                assert int(dbg[e]['nefc'][0]) < o.nefc
             continue
         if e < ndbg:
             d = dbg[e]

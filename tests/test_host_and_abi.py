@@ -317,7 +317,7 @@ def test_plane_support_tables_never_hide_the_support_vertex(robot):
     from gym_quadruped_amd.mjcf import load_compiled
     from gym_quadruped_amd.robot_cfgs import get_robot_config
     md = load_compiled(Path(get_robot_config(robot).mjcf_filename).stem)
-    pv, pm, _ = plane_support_tables(md)
+    pv, pm, _, _ = plane_support_tables(md)
     assert pv.shape == np.asarray(md.vert_pos).shape and pm.shape == (len(md.cloud_vertnum), 6 * PLANE_GRID ** 2)
     rng = np.random.default_rng(4)
     seen = 0

@@ -668,7 +668,18 @@ def _check_convex_against_truth(VA, hA, RA, tA, rA, VB, hB, RB, tB, rB, margin, 
     # the contact point lies midway between the two surfaces: half the (signed) distance from A's support plane along the normal
     sa = _support(WA, nrm) + rA
     assert abs(pos @ nrm - (sa + 0.5 * dist)) < 10 * tol
-    # ... and inside both shapes' slabs in every facet direction of the other (a point of the overlap region / the gap's mid-plane)
+    # ... between two WITNESS points: pos -+ dist / 2 along the normal are points of the two inflated surfaces, i.e. taken back by the
+    # radii they lie in the cores (inside every facet plane of the shapes' own hulls)
+    from scipy.spatial import ConvexHull
+    for W, q in ((WA, pos - (0.5 * dist + rA) * nrm), (WB, pos + (0.5 * dist + rB) * nrm)):
+        if len(W) >= 4 and np.linalg.matrix_rank(W - W[0], tol=1e-9) == 3:
+            eq = ConvexHull(W).equations
+            assert (eq[:, :3] @ q + eq[:, 3]).max() < 1e-7, 'witness point outside its shape'
+        elif len(W) == 2:
+            t = np.clip((q - W[0]) @ (W[1] - W[0]) / ((W[1] - W[0]) @ (W[1] - W[0])), 0, 1)
+            assert np.linalg.norm(W[0] + t * (W[1] - W[0]) - q) < 1e-7
+        elif len(W) == 1:
+            assert np.linalg.norm(W[0] - q) < 1e-7
     return dist, git, eit
 
 
