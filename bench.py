@@ -224,9 +224,11 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
     """Short runs of the same workload with (i) the reference's default observation set (73 scalars, SURVEY.md 8d
     "secondary") and (ii) the PGS solver the north-star names; same timing discipline, reported next to the headline."""
     out = {}
-    for key, obs_names, solver in (('default_obs', QuadrupedEnv._DEFAULT_OBS, args.solver), ('pgs', tuple(QuadrupedEnv.ALL_OBS), 'pgs')):
+    for key, obs_names, solver, sc in (('default_obs', QuadrupedEnv._DEFAULT_OBS, args.solver, _self_collision(args)), ('pgs', tuple(QuadrupedEnv.ALL_OBS), 'pgs', None),
+                                       ('self_collision_capsule_proxies', tuple(QuadrupedEnv.ALL_OBS), args.solver, 'capsule'),
+                                       ('self_collision_off', tuple(QuadrupedEnv.ALL_OBS), args.solver, False)):
         env = QuadrupedEnv('mini_cheetah', state_obs_names=obs_names, scene='flat', num_envs=n, device=device, auto_reset='next_step',
-                           solver=solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000)
+                           solver=solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000, self_collision=sc)
         env.reset(random=True)
         for i in range(warmup):
             env.step(pool[i % 64])
@@ -237,7 +239,11 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         out[key] = {'value': n * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps,
-                    'obs_dim': env._obs_dim, 'solver': solver, 'bytes_per_env_step': algorithmic_bytes_per_env_step(env._obs_dim)}
+                    'obs_dim': env._obs_dim, 'solver': solver, 'bytes_per_env_step': algorithmic_bytes_per_env_step(env._obs_dim),
+                    'self_collision': env._mm.self_collision}
+        if key == 'self_collision_capsule_proxies':
+            out[key]['note'] = ('the headline workload with the capsule proxies of rounds 2 - 5 in place of the convex routine for robot-robot pairs that involve a mesh '
+                                '(QuadrupedEnv(self_collision="capsule")): an approximation - such a contact is found late, by the gap between hull and capsule')
         env.close()
     # the same workload as an OPEN-LOOP rollout (QuadrupedEnv.rollout / gq_rollout): 2 shards of envs on 2 HIP streams, no
     # cross-env barrier between steps - what a random-action / dataset-recording rollout can use and a policy loop cannot.
@@ -245,7 +251,7 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
     # overlapping launches share the SIMDs, so each still lasts as long as its slowest wave under full contention, and more
     # than two queues serialise
     env = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), scene='flat', num_envs=n, device=device, auto_reset='next_step',
-                       solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000, self_collision=False if args.no_self_collision else None)
+                       solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000, self_collision=_self_collision(args))
     env.reset(random=True)
     acts = torch.stack(pool)                       # [64, n, 12]
     for _ in range(4):
@@ -300,7 +306,7 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
         with torch.cuda.stream(st):
             e = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), scene='flat', num_envs=n, device=device, auto_reset='next_step',
                              solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000 + k, env_id_offset=k * n,
-                             self_collision=False if args.no_self_collision else None)
+                             self_collision=_self_collision(args))
             e.reset(random=True)
         envs.append(e); streams.append(st)
     torch.cuda.synchronize(device)
@@ -321,6 +327,13 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
     return out
 
 
+def _self_collision(args):
+    """QuadrupedEnv(self_collision=...) of the command line: None = the default (on with the Newton solver, mesh pairs by the convex routine)."""
+    if args.no_self_collision or args.self_collision == 'off':
+        return False
+    return 'capsule' if args.self_collision == 'capsule' else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -336,6 +349,9 @@ def main():
     ap.add_argument('--scene', default='flat', help="headline metric: flat; box scenes (random_boxes, stairs, ...) for the secondary configs")
     ap.add_argument('--robot', default='mini_cheetah', help='headline metric: mini_cheetah; other registry robots for the secondary configs')
     ap.add_argument('--no-self-collision', action='store_true', help='switch robot self-collision off (MuJoCo default and default here: on)')
+    ap.add_argument('--self-collision', choices=['convex', 'capsule', 'off'], default='convex',
+                    help="robot-robot pairs with a mesh / cylinder: 'convex' = MuJoCo's general convex routine on the hulls (default, the headline), "
+                         "'capsule' = capsule proxies in their place (approximation), 'off' = no robot-robot contacts")
     ap.add_argument('--imu', action='store_true', help='BASELINE config 5: IMU plug-in (6 observables; robots that expose accelerometer + gyro sensors)')
     ap.add_argument('--heightmap', action='store_true', help='BASELINE config 5: a 5x5 HeightMap @ 0.1 m updated every step')
     ap.add_argument('--dist-backend', default='nccl', help=argparse.SUPPRESS)   # test hook: 'gloo' together with GQ_BENCH_SHARE_DEVICE=1 runs the
@@ -390,7 +406,7 @@ def main():
         obs_names = obs_names + IMU.ALL_OBS
     env = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device, sensors=sensors, sensors_kwargs=sensors_kwargs,
                        auto_reset=False if (args.no_auto_reset or args.auto_reset == 'off') else args.auto_reset, solver=args.solver, solver_iterations=100, solver_tolerance=1e-8,
-                       seed=1000, env_id_offset=shard.env_offset, self_collision=False if args.no_self_collision else None)  # shards: disjoint global env ids -> disjoint RNG counters
+                       seed=1000, env_id_offset=shard.env_offset, self_collision=_self_collision(args))  # shards: disjoint global env ids -> disjoint RNG counters
     env.reset(random=True)
     g = torch.Generator(device=device).manual_seed(rank)
     pool = [torch.randn(n, 12, generator=g, device=device) * 50 for _ in range(64)]
@@ -407,7 +423,7 @@ def main():
     # clocks and caches as a --steps 2000 one; the measured env then does exactly --warmup untimed steps
     scratch = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device, sensors=sensors, sensors_kwargs=sensors_kwargs,
                            auto_reset='next_step', solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=999,
-                           self_collision=False if args.no_self_collision else None)
+                           self_collision=_self_collision(args))
     scratch.reset(random=True)
     for i in range(DEVICE_WARMUP_STEPS):
         scratch.step(pool[i % 64])
@@ -483,7 +499,7 @@ def main():
         achieved = n * bytes_step / (kernel_ms * 1e-3) / 1e9
         # the committed counter passes were taken on the headline workload: replayed for that workload only
         headline = (args.robot == 'mini_cheetah' and args.scene == 'flat' and args.solver == 'newton' and args.obs == 'all' and n == ENVS_PER_GPU
-                    and not args.no_self_collision and not args.imu and not args.heightmap and args.auto_reset == 'next_step' and not args.no_auto_reset)
+                    and _self_collision(args) is None and not args.imu and not args.heightmap and args.auto_reset == 'next_step' and not args.no_auto_reset)
         traffic = pmc_traffic() if headline else (None, {'note': 'HBM counters are committed for the headline workload only (profiles/rNN_hbm_counters.md)'})
         out = {
             'metric': 'env-steps/sec (batched)', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world,
@@ -492,7 +508,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'{args.robot} {args.scene}, {n} envs/GPU, random-action rollout (50*N(0,1) torques), '
                                    f'{"ALL_OBS" if args.obs == "all" else "_DEFAULT_OBS"} ({env._obs_dim} scalars), '
-                                   f'auto-reset on termination ({env.auto_reset_mode}), sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8, robot self-collision {"off" if args.no_self_collision or args.solver == "pgs" else "on"}'
+                                   f'auto-reset on termination ({env.auto_reset_mode}), sim_dt 0.002, {args.solver} solver <=100 it tol 1e-8, robot self-collision {"off" if _self_collision(args) is False or args.solver == "pgs" else ("on (mesh pairs: capsule proxies)" if _self_collision(args) == "capsule" else "on (mesh pairs: GJK / EPA on the hulls, as mjc_Convex)")}'
                                    + (', IMU plug-in' if args.imu else '') + ((', 5x5 HeightMap following the base (rays cast by the step kernel)' if hm.follow_base else ', 5x5 HeightMap every step') if args.heightmap else ''),
                        'envs_per_gpu': n, 'total_envs': total_envs, 'parallelism': f'env-shards x{world} (no collectives)',
                        'state_finite': finite},

@@ -57,7 +57,7 @@ class GqModelDesc(C.Structure):
         ('hfield_condim', C.c_int32), ('hfield_priority', C.c_int32),
         ('nselfpair', C.c_int32), ('selfpair_geom1', _I), ('selfpair_geom2', _I), ('geom_capsule', _D), ('geom_type', _I),
         ('plane_grid', C.c_int32), ('plane_vert_pos', _D), ('plane_mask', _I),
-        ('nadj', C.c_int32), ('vert_adjadr', _I), ('vert_adjnum', _I), ('vert_adj', _I), ('plane_order', _I), ('plane_cap', _D),
+        ('nadj', C.c_int32), ('vert_adjadr', _I), ('vert_adjnum', _I), ('vert_adj', _I), ('plane_order', _I), ('plane_cap', _D), ('self_convex', C.c_int32),
     ]
 
 
@@ -363,6 +363,10 @@ class MarshalledModel:
         from .selfcol import geom_capsules, self_pairs
         if self_collision is None:   # MuJoCo's behaviour (robot geoms collide with each other) wherever the solver supports it
             self_collision = int(solver) == SOLVER_NEWTON
+        if self_collision not in (True, False, 'convex', 'capsule'):
+            raise ValueError("self_collision must be True / 'convex' (MuJoCo's mesh-mesh routine), 'capsule' (capsule proxies for mesh / cylinder geoms) or False")
+        d.self_convex = 0 if self_collision == 'capsule' else 1
+        self.self_collision = 'off' if not self_collision else ('capsule' if self_collision == 'capsule' else 'convex')
         pairs = self_pairs(md) if self_collision else np.zeros((0, 2), np.int32)
         box_arrays.update(selfpair_geom1=pairs[:, 0], selfpair_geom2=pairs[:, 1], geom_capsule=geom_capsules(md))
         d.nselfpair = int(len(pairs))

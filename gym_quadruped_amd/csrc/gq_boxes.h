@@ -864,6 +864,8 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     }
     { /* the convex pairs that passed their mid phase, one after the other on the whole wavefront (gq_convex.h) */
       uint64_t cm = ballot(cvx);
+      if (K.self_cut == 5) cm = 0;        /* profiling aid: the mid phase without the convex routine */
+      if (K.self_cut == 6) cm &= cm - 1;  /* ... and without the first pair that reaches it */
       while (cm) { /* wave-uniform */
         const int j = ffs64(cm);
         cm &= cm - 1;

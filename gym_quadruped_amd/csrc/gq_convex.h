@@ -184,6 +184,12 @@ __device__ __forceinline__ D3 d3(V3 a) { D3 r = {(double)a.x, (double)a.y, (doub
 __device__ __forceinline__ D3 operator-(D3 a, D3 b) { D3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
 __device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ D3 cross(D3 a, D3 b) { D3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; return r; }
+__device__ __forceinline__ double bcastd(double v, int src) { /* v_readlane of both halves */
+  struct I2 { int x, y; };
+  I2 u = __builtin_bit_cast(I2, v);
+  u.x = bcast(u.x, src); u.y = bcast(u.y, src);
+  return __builtin_bit_cast(double, u);
+}
 __device__ __forceinline__ void cvx_seg(D3 p0, D3 p1, double* lam) {
   const D3 e = p1 - p0;
   const double ee = dot(e, e), t = ee > 0.0 ? -dot(p0, e) / ee : 0.0;
@@ -227,27 +233,30 @@ __device__ inline bool cvx_simplex(LdsCF P, const int n, float* lam, V3& v) {
   const D3 p2 = d3(GQ_CVX_PW(P, 2));
   if (n == 3) { double l3[3]; cvx_tri(p0, p1, p2, l3); lam[0] = (float)l3[0]; lam[1] = (float)l3[1]; lam[2] = (float)l3[2]; v = cvx_comb(l3, p0, p1, p2); return false; }
   const D3 p3 = d3(GQ_CVX_PW(P, 3));
+  /* the tetrahedron, lane f & 3 = face f: (0,1,2 | 3), (0,1,3 | 2), (0,2,3 | 1), (1,2,3 | 0) - the four faces side by side instead of one
+   * after the other on every lane (the fp64 triangle routine is ~100 dependent instructions, and this is the iteration's critical path);
+   * the nearest of the faces the origin lies beyond wins, the first of equals in face order like the oracle's loop */
+  const int f = lane_id() & 3;
+  const D3 a = f == 3 ? p1 : p0, b = f < 2 ? p1 : p2, c = f == 0 ? p2 : p3, o = f == 0 ? p3 : (f == 1 ? p2 : (f == 2 ? p1 : p0));
+  const D3 nf = cross(b - a, c - a);
+  const double so = dot(nf, o - a), sz = -dot(nf, a);
+  const bool beyond = (so > 0.0 && sz < 0.0) || (so < 0.0 && sz > 0.0) || so == 0.0;
+  double l3[3];
+  cvx_tri(a, b, c, l3);
+  const V3 p = cvx_comb(l3, a, b, c);
+  const double pp = beyond ? (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z : 1e300;
   double best = 1e300;
-  bool any = false;
-#pragma unroll 1
-  for (int f = 0; f < 4; f++) { /* faces (0,1,2 | 3), (0,1,3 | 2), (0,2,3 | 1), (1,2,3 | 0) */
-    const D3 a = f == 3 ? p1 : p0, b = f < 2 ? p1 : p2, c = f == 0 ? p2 : p3, o = f == 0 ? p3 : (f == 1 ? p2 : (f == 2 ? p1 : p0));
-    const D3 nf = cross(b - a, c - a);
-    const double so = dot(nf, o - a), sz = -dot(nf, a);
-    if ((so > 0.0 && sz < 0.0) || (so < 0.0 && sz > 0.0) || so == 0.0) { /* the origin lies beyond this face */
-      double l3[3];
-      cvx_tri(a, b, c, l3);
-      const V3 p = cvx_comb(l3, a, b, c);
-      const double pp = (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z;
-      if (pp < best) {
-        best = pp; any = true; v = p;
-        const int ia = f == 3 ? 1 : 0, ib = f < 2 ? 1 : 2, ic = f == 0 ? 2 : 3;
-        lam[0] = lam[1] = lam[2] = lam[3] = 0.0f;
-        lam[ia] = (float)l3[0]; lam[ib] = (float)l3[1]; lam[ic] = (float)l3[2];
-      }
-    }
-  }
-  return !any;
+  int fb = -1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const double ppk = bcastd(pp, k); if (ppk < best) { best = ppk; fb = k; } }
+  if (fb < 0) return true; /* the origin is beyond no face: enclosed */
+  v = v3(bcast(p.x, fb), bcast(p.y, fb), bcast(p.z, fb));
+  const float w0 = (float)bcastd(l3[0], fb), w1 = (float)bcastd(l3[1], fb), w2 = (float)bcastd(l3[2], fb);
+  lam[0] = fb == 3 ? 0.0f : w0;
+  lam[1] = fb < 2 ? w1 : (fb == 3 ? w0 : 0.0f);
+  lam[2] = fb == 0 ? w2 : (fb == 1 ? 0.0f : w1);
+  lam[3] = fb == 0 ? 0.0f : w2;
+  return false;
 }
 
 /* unit normal and offset of the polytope face (a, b, c); a sliver (edges parallel to 1e-5) gets the offset 1e30: kept for the topology,
@@ -354,6 +363,9 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     wave_barrier();
     return true;
   }
+#ifdef GQ_CVX_STATS
+  ((LdsI)out)[7] = 0;
+#endif
   /* ---- the cores overlap.  A tetrahedron around the origin first: a touching / degenerate simplex is blown up with supports along
    * directions it does not span (oracle: same order of attempts) */
   if (ns < 4) {
@@ -484,6 +496,9 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     nv++;
     wave_barrier();
   }
+#ifdef GQ_CVX_STATS
+  ((LdsI)out)[7] = nv - 4;
+#endif
   /* the closest face: the foot point of its plane, split over the face's vertices.  A facet of A - B with more than three vertices (edge
    * against edge: a parallelogram) is several coplanar triangles of equal offset - the one that CONTAINS the foot point carries the
    * witness points: among the faces within the tolerance of the smallest offset (lane = face), the one whose nearest point is nearest */

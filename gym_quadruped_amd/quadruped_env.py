@@ -83,7 +83,7 @@ class QuadrupedEnv(AccessorsMixin):
         mjcf_path: str | None = None,
         env_id_offset: int = 0,
         accessors: bool = False,
-        self_collision: bool | None = None,
+        self_collision: bool | str | None = None,   # None / True / "convex": MuJoCo's behaviour, mesh pairs through the convex routine; "capsule": capsule proxies for mesh / cylinder pairs (faster, approximate); False: off
     ):
         self._save_hyperparameters(constructor_params=locals().copy())
         log.info(f'Initializing {robot} environment with scene {scene}.')

@@ -867,12 +867,14 @@ static double cvx_point_tie(const Cvx* A, const Cvx* B, const double* n) {
   if (da == 1 && db == 1) { double c[3]; cvx_cross(c, ea, eb); if (cvx_dot(c, c) < 1e-8 * cvx_dot(ea, ea) * cvx_dot(eb, eb)) return 0.0; }
   return 1.0;
 }
+static int g_cvx_last_queries;
 static int g_cvx_capped; /* the last pair ran into an iteration cap: its answer is the iteration's state there, not the converged one (test diagnostics) */
 static int cvx_pair_counted(const Cvx* A, const Cvx* B, double margin, double* dist, double* nrm, double* pos, int self, const double* hint) {
   int it[2] = {0, 0};
   const int rc = cvx_pair(A, B, margin, dist, nrm, pos, it, hint);
   long long* s = g_cvx_stat + (self ? 4 : 0);
   s[0] += 1; s[1] += rc; s[2] += it[0]; s[3] += it[1];
+  g_cvx_last_queries = 1 + it[0] + it[1];
   g_cvx_capped = rc && (it[1] >= CVX_EPA_MAXIT || it[0] >= CVX_GJK_MAXIT);
   g_cvx_stat[9] += g_cvx_capped;
   return rc;
@@ -1122,7 +1124,7 @@ static void gqo_collision(GqOracle* o) {
         double dist, nrm[3], pos[3];
         if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 0, NULL)) continue;
         Contact* c = &o->contact[o->ncon++];
-        c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = dist; c->tiegap = g_cvx_capped ? 0.0 : cvx_point_tie(&A, &B, nrm);
+        c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = dist; c->tiegap = g_cvx_capped ? 0.0 : (cvx_point_tie(&A, &B, nrm) > 0 ? 1.0 : -1.0); /* -1: depth and normal are determined, the contact POINT is not */
         memcpy(c->pos, pos, sizeof c->pos);
         set_frame(c, nrm, NULL);
         contact_param(o, w, g, c);
@@ -1221,7 +1223,7 @@ static void gqo_collision(GqOracle* o) {
     {
       Prim P1, P2;
       prim_of_geom(o, g1, &P1); prim_of_geom(o, g2, &P2);
-      if (P1.kind != 1 || P2.kind != 1) { /* a hull / cylinder (or a box against one): mjc_Convex on the two clouds, one contact - gq_convex.h */
+      if ((P1.kind != 1 || P2.kind != 1) && m->self_convex) { /* a hull / cylinder (or a box against one): mjc_Convex on the two clouds, one contact - gq_convex.h (self_convex = 0: the capsule proxies below) */
         const int c1 = m->geom_cloudid[g1], c2 = m->geom_cloudid[g2];
         const double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
         { /* bounding spheres (mj_collision's broad phase) */
@@ -1245,9 +1247,12 @@ static void gqo_collision(GqOracle* o) {
         memcpy(B.R, o->geom_xmat[g2], sizeof B.R); memcpy(B.t, o->geom_xpos[g2], sizeof B.t);
         double dist, nrm[3], pos[3];
         (void)hint; /* (the mid phase's best axis as GJK's first direction was tried: boxes that overlap are not separated along their own axes, the hulls inside them hardly ever are) */
-        if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 1, NULL)) continue;
+        const int full_before = o->ncon >= 12;
+        const int hit_ = cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 1, NULL);
+        if (full_before) g_cvx_stat[10] += g_cvx_last_queries; /* census: support queries spent on pairs behind the kernel's 12-contact capacity */
+        if (!hit_) continue;
         Contact* c = &o->contact[o->ncon++];
-        c->geom = g2; c->body = b2; c->geom1 = g1; c->body1 = b1; c->dist = dist; c->tiegap = g_cvx_capped ? 0.0 : cvx_point_tie(&A, &B, nrm);
+        c->geom = g2; c->body = b2; c->geom1 = g1; c->body1 = b1; c->dist = dist; c->tiegap = g_cvx_capped ? 0.0 : (cvx_point_tie(&A, &B, nrm) > 0 ? 1.0 : -1.0); /* -1: depth and normal are determined, the contact POINT is not */
         memcpy(c->pos, pos, sizeof c->pos);
         set_frame(c, nrm, NULL);
         contact_param_pair(o, g1, g2, c);

@@ -194,7 +194,16 @@ class ParityTally:
 
     def classify(self, e, o, nefc_kernel):
         self.n += 1
-        if o.ncon and o.get('contact_tiegap').min() < self.tie_threshold:
+        gaps = o.get('contact_tiegap') if o.ncon else np.ones(1)
+        if gaps.min() < self.tie_threshold:
+            if (gaps[gaps < self.tie_threshold] == -1.0).all():
+                # convex contacts whose POINT is not determined (two faces, a face and an edge, parallel edges: every point of the overlap is a
+                # valid witness and the polytope's last triangle picks one - gq_oracle.c cvx_point_tie): depth, normal and therefore the number
+                # of rows ARE determined and are held to the oracle's; J / forces / qacc of the env are out of reach like a tie's
+                self.point = getattr(self, 'point', 0) + 1
+                if oracle_fits_self_budget(o, self.cone):
+                    assert int(nefc_kernel) == o.nefc, (e, 'rows of an env with an undetermined contact point', int(nefc_kernel), o.nefc)
+                return 'tie'
             self.tie += 1          # two hull vertices of (numerically) equal depth: fp32 / fp64 may pick either
             return 'tie'
         if not oracle_fits_self_budget(o, self.cone):
@@ -227,7 +236,7 @@ class ParityTally:
         self.budget_prefix_checked = getattr(self, 'budget_prefix_checked', 0) + 1
 
     def report(self, what):
-        msg = (f'{what}: {self.n} envs, {self.checked} compared, {self.tie} deepest-vertex ties, {self.budget} over the row '
+        msg = (f'{what}: {self.n} envs, {self.checked} compared, {self.tie} deepest-vertex ties, {getattr(self, "point", 0)} with an undetermined contact point (rows held to the oracle), {self.budget} over the row '
                f'budget ({getattr(self, "budget_prefix_checked", 0)} of them held to the prefix rule), {len(self.mismatch)} MISMATCHED {self.mismatch[:8]}')
         tally_note(msg)
         return msg
@@ -235,7 +244,8 @@ class ParityTally:
     def finish(self, what, min_checked, max_tie, max_budget):
         msg = self.report(what)
         assert not self.mismatch, msg
-        assert self.checked >= min_checked * self.n and self.tie <= max_tie * self.n and self.budget <= max_budget * self.n, msg
+        nd = self.n - getattr(self, 'point', 0)   # the shares are taken among the envs whose contacts are all determined
+        assert self.checked >= min_checked * nd and self.tie <= max_tie * self.n and self.budget <= max_budget * self.n and nd >= 0.3 * self.n, msg
 
 
 def oracle_reset_lift(o, q0, v0, hip_height):

@@ -832,3 +832,29 @@ def test_convex_routine_kernel_equals_oracle(robot):
         if min(da, db) == 1 or (da == 2 and db == 2):
             assert np.linalg.norm(pk - pos) < 2e-5, (trial, pk, pos, da, db)
     assert n >= 80 and deep >= 30 and capped <= 0.05 * n, (n, deep, capped)
+
+
+def test_capsule_proxy_mode_matches_oracle():
+    """QuadrupedEnv(self_collision='capsule') / GqModelDesc.self_convex = 0: robot-robot pairs that involve a mesh go through the capsule proxies
+    of geom_capsule instead of the convex routine, in kernel and oracle alike (the approximate, fast mode: DESIGN.md section 3)."""
+    n = 10
+    mm = marshalled('mini_cheetah', solver=1, iterations=100, tolerance=1e-10, noise_floor=0.0, self_collision='capsule')
+    o = Oracle(marshalled('mini_cheetah', solver=1, iterations=100, tolerance=1e-12, self_collision='capsule'))
+    assert mm.desc.self_convex == 0 and mm.self_collision == 'capsule'
+    rng = np.random.default_rng(7)
+    qpos, qvel = self_contact_states(mm.md, n, rng, o, want_cross=True)
+    qvel = qvel.astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 20).astype(np.float32)
+    st = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), debug_envs=n, friction=np.full(n, 0.7, np.float32))
+    nchecked = 0
+    for e in range(n):
+        o.set_state(qpos[e], qvel[e], np.zeros(18), np.zeros(18), 0.0, 0.7); o.step(ctrl[e].astype(np.float64))
+        rec = st['debug'][e]
+        if not oracle_fits_self_budget(o, False) or o.get('contact_tiegap').min() < 3e-7:
+            continue
+        nchecked += 1
+        ne = o.nefc
+        assert int(dbg(rec, 'nefc')[0]) == ne and int(dbg(rec, 'ncon')[0]) == o.ncon
+        np.testing.assert_allclose(dbg(rec, 'efc_J').reshape(64, 18)[:ne], o.efc_J, rtol=2e-4, atol=2e-5)
+        assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 2e-4 * max(1.0, np.abs(o.qacc).max())
+    assert nchecked >= n // 2

@@ -26,7 +26,7 @@ def main(robot='mini_cheetah', n_envs=48, n_steps=250, boxes=None):
     stats = np.zeros(12, dtype=np.int64)
     L.gqo_cvx_stats(None, 1)
     ncon_hist = np.zeros(64, dtype=np.int64)
-    call_hist, work_hist = np.zeros(64, dtype=np.int64), np.zeros(256, dtype=np.int64)
+    call_hist, work_hist, work2_hist = np.zeros(64, dtype=np.int64), np.zeros(256, dtype=np.int64), np.zeros(256, dtype=np.int64)
     prev = np.zeros(12, dtype=np.int64)
     nself_tot = nsteps = nterm = 0
     for e in range(n_envs):
@@ -38,7 +38,8 @@ def main(robot='mini_cheetah', n_envs=48, n_steps=250, boxes=None):
             L.gqo_cvx_stats(stats.ctypes.data_as(C.c_void_p), 0)
             d = stats - prev; prev = stats.copy()
             call_hist[min(int(d[0] + d[4]), 63)] += 1
-            work_hist[min(int(d[0] + d[4] + d[2] + d[6] + d[3] + d[7]), 255)] += 1   # Minkowski support queries of the env-step: one per call + one per GJK / EPA iteration
+            work_hist[min(int(d[0] + d[4] + d[2] + d[6] + d[3] + d[7]), 255)] += 1
+            work2_hist[min(int(d[0] + d[4] + d[2] + d[6] + d[3] + d[7] - d[10]), 255)] += 1   # Minkowski support queries of the env-step: one per call + one per GJK / EPA iteration
             n = int(o.ncon)
             ncon_hist[min(n, 63)] += 1
             g1 = o.get('contact_geom1')[:n]
@@ -61,6 +62,8 @@ def main(robot='mini_cheetah', n_envs=48, n_steps=250, boxes=None):
     print('  convex calls per env-step: ' + ' '.join(f'>={k}:{100 * cs[k]:.2f}%' for k in (1, 2, 3, 4, 6, 8, 12) if cs[k] > 0))
     ws = np.cumsum(work_hist[::-1])[::-1] / work_hist.sum()
     print('  support queries per env-step: ' + ' '.join(f'>={k}:{100 * ws[k]:.2f}%' for k in (1, 4, 8, 16, 32, 64, 128) if ws[k] > 0), 'max', int(np.nonzero(work_hist)[0].max()))
+    ws2 = np.cumsum(work2_hist[::-1])[::-1] / work2_hist.sum()
+    print('  ... without the pairs behind a full 12-contact list: ' + ' '.join(f'>={k}:{100 * ws2[k]:.2f}%' for k in (1, 4, 8, 16, 32, 64, 128) if ws2[k] > 0), 'max', int(np.nonzero(work2_hist)[0].max()))
     tot = ncon_hist.sum()
     print('  contacts per env-step: mean %.2f, > 12: %.2f %%, histogram %s' % ((ncon_hist * np.arange(64)).sum() / tot, 100 * ncon_hist[13:].sum() / tot,
                                                                           ' '.join(f'{k}:{100 * c / tot:.1f}' for k, c in enumerate(ncon_hist) if c)))
