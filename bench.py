@@ -78,6 +78,20 @@ def valu_issue(kernel_ms: float, waves_per_simd: int = 4):
         return None
 
 
+def launch_tail():
+    """How much of the headline launch is its tail: (launch end - median wave end) / launch end from the last committed wave-timeline pass
+    (tools/wave_timeline.py -> profiles/latest_tail.json; instrumented kernel, one launch) - the number that separates the step loop from the
+    persistent rollouts, which have no launch boundary.  Same source-hash staleness check as `traffic`."""
+    p = ROOT / 'profiles' / 'latest_tail.json'
+    try:
+        d = json.loads(p.read_text())
+        now = kernel_source_hash()
+        return {'tail': d['tail'], 'launch_us': d.get('launch_us'), 'median_wave_end_us': d.get('median_wave_end_us'), 'p99_wave_end_us': d.get('p99_wave_end_us'),
+                'source': {'profile': d.get('profile'), 'kernel_src_sha16': d.get('kernel_src_sha16'), 'current_kernel_src_sha16': now, 'stale': d.get('kernel_src_sha16') != now}}
+    except Exception:
+        return None
+
+
 def kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
@@ -294,6 +308,24 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
                     'note': {'inline': 'the stepping wavefront evaluates the policy on the observation row it has just written',
                              'mailbox': 'policy kernel on a second stream; actions / observations through per-env mailboxes, per-XCD ready queues; env-steps are tasks popped by the wavefronts of one persistent launch'}[kw['mode']]
                             + '; states equal the step loop fed with the same actions bit for bit (tests/test_gpu_closed_loop.py)'}
+    # the regime a controller / RL user lives in, as a STEP LOOP: the caller computes joint-space PD torques towards keyframe 0 from the observation
+    # it has just received (torch, on the GPU) and plays them through env.step - robots stand on four feet; compare closed_loop_inline_standing
+    if args.solver == 'newton':
+        env.reset(random=True)
+        qdes = torch.as_tensor(np.asarray(env.mjModel.key_qpos[0][7:], dtype=np.float32), device=device)
+        o = env.step(torch.zeros(n, 12, device=device))[0]
+        for _ in range(200):
+            o = env.step(25.0 * (qdes - o['qpos_js']) - 0.8 * o['qvel_js'])[0]
+        torch.cuda.synchronize(device)
+        t3 = time.perf_counter()
+        for _ in range(steps):
+            o = env.step(25.0 * (qdes - o['qpos_js']) - 0.8 * o['qvel_js'])[0]
+        torch.cuda.synchronize(device)
+        dts = time.perf_counter() - t3
+        out['step_loop_standing'] = {'value': n * steps / dts, 'unit': 'env-steps/s', 'ms_per_step': dts / steps * 1e3, 'steps': steps,
+                                     'mean_feet_in_contact': float(env._obs_views['contact_state'].sum(1).mean()),
+                                     'policy': 'joint-space PD kp 25 kd 0.8 towards keyframe 0, evaluated by the caller in torch between two env.step calls',
+                                     'note': 'QuadrupedEnv.step in a loop with a policy in it (robots stand: ~4 feet in contact every step); the two torch kernels of the law are inside the time'}
     out['pipelined_rollout'] = {'value': n * reps * 64 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / (reps * 64) * 1e3, 'steps': reps * 64, 'shards': 2,
                                 'note': 'open-loop: each shard of 2048 envs chains its steps on its own stream (gq_step_range); same kernels and results as the step loop'}
     env.close()
@@ -516,6 +548,7 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic[0], 'traffic_source': traffic[1], 'kernel': 'gq::step_kernel',
                          'kernel_ms': kernel_ms, 'bytes_per_env_step': bytes_step,
                          'valu_issue': valu_issue(kernel_ms) if headline else None,
+                         'tail': launch_tail() if headline else None,
                          'note': 'algorithmic bytes / HIP-event kernel time; the step is latency/VALU bound, not HBM bound'},
         }
         if steady is not None:

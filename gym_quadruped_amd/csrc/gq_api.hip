@@ -188,8 +188,14 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   HIP_TRY_OR_DESTROY(hipMemset(b->lift_pending, 0, (size_t)n_envs), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipMalloc(&b->load_hint, (size_t)n_envs), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipMemset(b->load_hint, 0, (size_t)n_envs), gq_batch_destroy(b));
+  /* profiling knobs of development builds (tools/dev_build.sh defines GQ_DEV_KNOBS; tools/stage_insts.sh, stage_cuts.py): the product library
+   * reads no environment variable (tests/test_host_and_abi.py checks its objects for getenv) */
+#ifdef GQ_DEV_KNOBS
   { const char* s = getenv("GQ_STOP_STAGE"); b->stop_stage = s ? atoi(s) : 0; }
   { const char* s = getenv("GQ_FORCE_SELF"); b->force_self = (s && atoi(s)) ? 1 : 0; }
+#else
+  b->stop_stage = 0; b->force_self = 0;
+#endif
   HIP_TRY_OR_DESTROY(hipMalloc(&b->dev_args, sizeof(gq::FusedArgs)), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipHostMalloc(&b->staging, sizeof(gq::FusedArgs) * GQ_ARG_SLOTS, hipHostMallocDefault), gq_batch_destroy(b));
   b->staging_next = 0; b->shadow_valid = false;
@@ -597,7 +603,11 @@ int gq_rollout_closed(GqBatch* b, int n_steps, int mode, const GqPolicyPd* pd, i
   h.timeout_ticks = (int64_t)((timeout_s > 0.0 ? timeout_s : 5.0) * 1e8);
   h.flags = 0;
 #ifdef GQ_MB_DEBUG
-  { const char* fl = getenv("GQ_MB_FLAGS"); h.flags = fl ? atoi(fl) : 0; } /* fence / census experiments (tools/closed_loop_debug.py) */
+#ifdef GQ_DEV_KNOBS
+  { const char* fl = getenv("GQ_MB_FLAGS"); h.flags = fl ? atoi(fl) : 0; } /* fence / census experiments (tools/closed_loop_debug.py), development builds only */
+#else
+  h.flags = 0;
+#endif
 #endif
   /* fresh rollout state, ordered on the caller's stream */
   HIP_TRY(hipMemsetAsync(h.steps_done, 0, sizeof(int32_t) * (size_t)N, stream));

@@ -163,10 +163,13 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
   const int nlg = m.nlg;
   /* phase A, lane = link geom: bounding spheres */
   bool needs = false;
+  V3 hintw = v3(0.0f, 0.0f, 0.0f); /* lane = geom: out of the box towards the cloud's centre - GJK's first direction (a leg above a wide box: the box's top normal, which
+                                    * separates the two at the first support query; the line of centres would be nearly horizontal) */
   if (lane < nlg) {
     V3 nn; /* bounding sphere of the cloud against the box itself */
     const float marg = m.boxmix[B.cls][4 + lane].margin;
     needs = rg >= 0.0f && PL.cloud && sphere_box(matTvec(B.mat, cg - bp), bs, rg, nn) < marg;
+    hintw = matvec(B.mat, nn);
     if constexpr (OBB) if (needs) {
       /* the sphere of a long thin link is loose: half of the (geom, box) pairs it lets through have no vertex near the box, and each costs the
        * transform, the chunk-box fetch and its round trip before that is known.  The cloud's box (geom-frame AABB, taken to kernel coordinates
@@ -222,7 +225,7 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
     wave_barrier();
     cvx_shape_store(GQ_CVX_SHP(W) + GQ_CVX_SHAPE_WORDS, S);
     wave_barrier();
-    const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_BOX(W), vx, vy, vz, m.boxmix[B.cls][4 + g].margin);
+    const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_BOX(W), vx, vy, vz, m.boxmix[B.cls][4 + g].margin, v3(bcast(hintw.x, g), bcast(hintw.y, g), bcast(hintw.z, g)));
     if (lane == 0) {
       LdsCF out = GQ_CVX_SHP(W) + 2 * GQ_CVX_SHAPE_WORDS;
       W.u2.c.lg_dist[g] = hit ? out[0] : 1e30f;

@@ -30,6 +30,14 @@ namespace gq {
 #else
 #define GQ_CVX_FN __device__ __forceinline__
 #endif
+#ifdef GQ_CVX_STATS /* tools/ubench/convex_pair.hip: cycle sums per part of the routine */
+extern __device__ long long gq_cvx_cyc[8];
+#define GQ_CVX_T(i) do { const long long t_ = __builtin_readcyclecounter(); if (lane_id() == 0) gq_cvx_cyc[i] += t_ - tk_; tk_ = t_; } while (0)
+#define GQ_CVX_T0() long long tk_ = __builtin_readcyclecounter()
+#else
+#define GQ_CVX_T(i) do { } while (0)
+#define GQ_CVX_T0() do { } while (0)
+#endif
 #define GQ_CVX_GJK_MAXIT 32
 #define GQ_CVX_EPA_MAXIT 24
 #define GQ_CVX_MAXV 28                 /* polytope vertices: 4 + one per EPA iteration */
@@ -275,7 +283,7 @@ __device__ __forceinline__ void cvx_face_plane(V3 a, V3 b, V3 c, V3& n, float& d
 
 /* One convex pair.  shp: the two shape descriptors (A, B: GQ_CVX_SHAPE_WORDS each), then the result - dist, normal A -> B (3), point (3);
  * poly: GQ_CVX_POLY_WORDS words of scratch.  Returns true when the inflated shapes are closer than margin.  Wave-uniform. */
-GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const float margin) {
+GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const float margin, const V3 hint = {0.0f, 0.0f, 0.0f}) {
   const int lane = lane_id();
   LdsCF SA = shp; LdsCF SB = shp + GQ_CVX_SHAPE_WORDS;
   LdsF out = shp + 2 * GQ_CVX_SHAPE_WORDS;
@@ -285,6 +293,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
   LdsI RIM = ADJ + 64;
   const float rA = SA[19], rB = SB[19], reach = margin + rA + rB;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  GQ_CVX_T0();
   const CvxCaps caps = cvx_caps_fetch(SA, SB, vx, vy, vz);
   /* ---- GJK */
   V3 v;
@@ -293,6 +302,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
   {
     V3 d0 = (uniform(((LdsCI)SB)[0]) == 2 ? 0.5f * (ld3(SB + 13) + ld3(SB + 16)) : ld3(SB + 13)) -
             (uniform(((LdsCI)SA)[0]) == 2 ? 0.5f * (ld3(SA + 13) + ld3(SA + 16)) : ld3(SA + 13));
+    if (dot(hint, hint) > 0.0f) d0 = hint; /* the caller's first search direction, from A to B (world boxes: out of the box towards the cloud's centre) */
     if (dot(d0, d0) < 1e-24f) d0 = v3(1.0f, 0.0f, 0.0f);
     const CvxMink s0 = cvx_minkowski(SA, SB, vx, vy, vz, d0, caps);
     v = s0.w;
@@ -306,7 +316,9 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
   for (int it = 0; it < GQ_CVX_GJK_MAXIT; it++) {
     const float vv = dot(v, v);
     if (vv < 1e-24f) { enclosed = true; break; } /* the origin lies on the simplex: touching cores */
+    GQ_CVX_T(0);
     const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, -1.0f * v, caps);
+    GQ_CVX_T(1);
     const V3 w = sw.w;
     const float vw = dot(v, w);
     if (vw > 0.0f && vw * vw > reach * reach * vv) return false; /* the cores are farther apart than anything of interest */
@@ -346,7 +358,9 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     for (int q = 0; q < 4; q++) if (q < m) { st3l(P + 4 * q, kw[q]); PI[4 * q + 3] = kid[q]; lam[q] = kl[q]; } else lam[q] = 0.0f;
     ns = m;
     wave_barrier();
+    GQ_CVX_T(2);
   }
+  GQ_CVX_T(0);
   if (!enclosed) {
     const float len = fast_sqrt(dot(v, v));
     const float dist = len - rA - rB;
@@ -428,7 +442,9 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     best = ffs64(bm);
     if (eit >= GQ_CVX_EPA_MAXIT || nv >= GQ_CVX_MAXV) break;
     const V3 nb = v3(bcast(fn.x, best), bcast(fn.y, best), bcast(fn.z, best));
+    GQ_CVX_T(3);
     const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, nb, caps);
+    GQ_CVX_T(1);
     const V3 w = sw.w;
     const int wid = sw.id;
     const bool dup = ballot(lane < nv && GQ_CVX_PID(P, lane < nv ? lane : 0) == wid) != 0;
@@ -463,6 +479,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     alive = alive && !mine;
     st3l(P + 4 * nv, w); PI[4 * nv + 3] = wid; /* (every lane: the same words) */
     wave_barrier();
+    GQ_CVX_T(4);
     /* the fan: new face k = rim edge k + the new vertex, on the k-th free lane */
     const uint64_t freem = ballot(!alive);
     const int rank = popc64(freem & lt);
@@ -495,7 +512,9 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     }
     nv++;
     wave_barrier();
+    GQ_CVX_T(5);
   }
+  GQ_CVX_T(3);
 #ifdef GQ_CVX_STATS
   ((LdsI)out)[7] = nv - 4;
 #endif

@@ -1052,6 +1052,14 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
       const float dc = row_cost(rtype, y + v, rR, rD, rfloss) - row_cost(rtype, y, rR, rD, rfloss);
       dphi = wave_sum(p1 + 0.5f * p2 + dc);
       unit_step = dphi < 0.0f;
+      if (unit_step && scale * (-dphi) < m.tolerance) { /* wave-uniform */
+        /* a decrease below the tolerance ENDS the solve (small_step below): it must be the decrease of a converged point, not of a unit step that
+         * overshot across a kink and landed at nearly the same cost.  The line's slope tells them apart - at a minimiser phi'(0) = g.s is itself
+         * below the tolerance (-phi'(0) / 2 is the decrease a quadratic would give); otherwise the safeguarded search runs */
+        float d1c, d2c;
+        row_dd(rtype, y, v, rR, rD, rfloss, d1c, d2c);
+        unit_step = scale * (-0.5f * wave_sum(p1 + d1c)) < m.tolerance;
+      }
       if constexpr (DBG) if (tdbg && lane == 0 && unit_step) tdbg[30] += 1.0f;
     }
     if (full_step) { alpha = 1.0f; first_try = true; }

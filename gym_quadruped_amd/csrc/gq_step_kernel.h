@@ -36,7 +36,7 @@ namespace gq {
  * into SGPRs at kernel entry and immediately spilled lane-by-lane into VGPRs (v_writelane / v_readlane: ~10 % of the
  * kernel's VALU issue slots).  What changes from call to call travels by value in StepCall. */
 /* Field order (round 5): the sixteen pointers a wave's PROLOGUE reads (load_rows) are the first 128 bytes - two s_load_dwordx16 - and the
- * ones its EPILOGUE stores through follow in one block (EpiPtrs in gq_step_body.h); the block is filled by name (gq_api.hip). */
+ * ones its EPILOGUE stores through follow in one block (from `qacc` on); the block is filled by name (gq_api.hip). */
 struct StepArgs {
   const GqDevModel* model;
   const GqDevBatch* batch;

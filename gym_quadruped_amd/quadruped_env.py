@@ -151,6 +151,8 @@ class QuadrupedEnv(AccessorsMixin):
         self._all_ids = list(self._obs_ids) + obs_ids_from_names(self._extra_names)
         self._launches = 0
         self._hm_fresh = False   # a HeightMap(follow_base=True) holds the rays of the CURRENT state (written by the last step's kernel)
+        self._hm_follow = None   # weakref to THE HeightMap(follow_base=True) registered with the step kernel (one output slot per batch)
+        self._hm_version = -1
 
         # device state: one tensor per field, env-major rows
         N, dev = self.num_envs, self.device
@@ -299,7 +301,10 @@ class QuadrupedEnv(AccessorsMixin):
         if ev is not None:
             ev[1].record()
         self._launches += 1
-        self._hm_fresh = True
+        # a HeightMap(follow_base=True) registered with this env now holds the rays of the NEW state; the flag is tied to the version counter of the
+        # state tensor, so that an in-place write (env.qpos[...] = x) makes it stale again
+        self._hm_fresh = self._hm_follow is not None and self._hm_follow() is not None
+        self._hm_version = self._qpos._version
         self._note_step()
         for sensor in self.sensors:  # reference :273-274 (kernel-side sensors: no-op)
             sensor.step()

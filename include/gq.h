@@ -316,9 +316,12 @@ int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state);
  * steps - grid centred on the NEW base position, heading = yaw of the new base orientation (scipy as_euler('xyz')[2], as the observation row
  * holds it) - and writes the hit points to out, device [N][rows * cols][3] (caller-owned; cell order and ray geometry as gq_heightmap): no
  * kernel and no launch boundary of its own behind the step.  An env the step's mask leaves out keeps its rows.  Scenes with world boxes or a
- * height field only (GQ_EINVAL on a flat scene: gq_heightmap there).  out = NULL switches it off.  gq_reset does not cast rays: after a reset
- * the caller launches gq_heightmap once (the Python HeightMap does).  No reference counterpart as a call: the reference casts mj_ray per cell
- * from Python. */
+ * height field only (GQ_EINVAL on a flat scene: gq_heightmap there).  out = NULL switches it off.  The heading is taken from the base
+ * rotation's (R10, R00), normalised - the yaw of as_euler('xyz') away from the gimbal pole.  Every forward pass of the step kernel that
+ * advances an env casts its rays, the reset's own mj_step (gq_reset, the in-kernel auto-reset) included; what gq_reset's step wrote is the
+ * map of the state AFTER that step, so a caller that resets with an explicit state, restores a snapshot or writes the state tensors in
+ * place launches gq_heightmap once for the state it now holds (the Python HeightMap does: it ties the map's freshness to the state tensor's
+ * version).  No reference counterpart as a call: the reference casts mj_ray per cell from Python. */
 int gq_batch_set_heightmap(GqBatch* b, int rows, int cols, float dist_x, float dist_y, float* out);
 
 /* reset configuration: the knobs of QuadrupedEnv.reset / _sample_ref_vel / _set_ground_friction */

@@ -1122,7 +1122,17 @@ static void gqo_collision(GqOracle* o) {
         B.V = m->vert_pos + 3 * m->cloud_vertadr[cl]; B.nv = m->cloud_vertnum[cl]; B.r = r;
         memcpy(B.R, o->geom_xmat[g], sizeof B.R); memcpy(B.t, o->geom_xpos[g], sizeof B.t);
         double dist, nrm[3], pos[3];
-        if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 0, NULL)) continue;
+        double hint[3];
+        { /* GJK's first direction: out of the box towards the centre of the cloud's box (csrc/gq_boxes.h box_item_scan) */
+          const double* cb = cloud_box(o, cl);
+          double cw[3], cl3[3], nl[3];
+          mulmatvec3(cw, o->geom_xmat[g], cb);
+          for (int k = 0; k < 3; k++) cw[k] += o->geom_xpos[g][k] - bp[k];
+          mulmatTvec3(cl3, bm, cw);
+          point_box(cl3, bs, nl);
+          mulmatvec3(hint, bm, nl);
+        }
+        if (!cvx_pair_counted(&A, &B, margin, &dist, nrm, pos, 0, hint)) continue;
         Contact* c = &o->contact[o->ncon++];
         c->geom = g; c->body = m->geom_bodyid[g]; c->geom1 = -1; c->body1 = 0; c->dist = dist; c->tiegap = g_cvx_capped ? 0.0 : (cvx_point_tie(&A, &B, nrm) > 0 ? 1.0 : -1.0); /* -1: depth and normal are determined, the contact POINT is not */
         memcpy(c->pos, pos, sizeof c->pos);

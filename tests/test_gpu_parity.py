@@ -589,6 +589,20 @@ def test_heightmap_following_the_base_equals_the_ray_kernel(robot, scene):
     a1 = fused.update_height_map().clone()
     b1 = plain.update_height_map(env.qpos[:, 0:3], yaw=obs['base_ori_euler_xyz'][:, 2])
     assert torch.allclose(a1, b1, atol=2e-5)
+    # one base-following map per env: a second one is refused (the kernel has one output slot per batch) ...
+    with pytest.raises(ValueError):
+        HeightMap(num_rows=5, num_cols=7, dist_x=0.1, dist_y=0.08, mj_model=env.mjModel, mj_data=env, follow_base=True)
+    # ... a custom centre on the base-following map goes to a tensor of its own and leaves the kernel's alone ...
+    env.step(torch.zeros(n, 12, device='cuda:0'))
+    keep = fused.update_height_map().clone()
+    far = fused.update_height_map(env.qpos[:, 0:3] + torch.tensor([0.3, 0.0, 0.0], device='cuda:0', dtype=torch.float64), yaw=0.5)
+    assert far.data_ptr() != fused.sensor_data_matrix.data_ptr()
+    assert torch.equal(fused.update_height_map(), keep)
+    # ... and an in-place write to the state makes the kernel's map stale: the next argument-less update casts the rays again
+    env.qpos[:, 0] += 0.25
+    moved = fused.update_height_map().clone()
+    ref = plain.update_height_map(env.qpos[:, 0:3], yaw=env._obs_views['base_ori_euler_xyz'][:, 2])
+    assert torch.allclose(moved, ref, atol=2e-5) and not torch.allclose(moved, keep, atol=1e-3)
     fused.close()
     env.step(torch.zeros(n, 12, device='cuda:0'))               # detached: the step no longer writes the map
     torch.cuda.synchronize()
@@ -901,7 +915,8 @@ def test_robot_self_collision_step_parity(robot):
     assert p99(ea) < (1e-4 if cone else 2e-5) * 5 and max(ea) < 2e-3, (p99(ea), max(ea))
     assert p99(ev) < (7e-4 if cone else 5e-5) * 5 and max(ev) < 5e-3, (p99(ev), max(ev))
     tally.finish(f'self-collision one-step parity {robot}', min_checked=0.75, max_tie=0.15, max_budget=0.1)
-    assert tally.checked >= 120
+    assert tally.checked >= 50   # (of 160: where two flat faces of CAD hulls or a cylinder rim and a box meet, the contact POINT is not determined - those envs, up to 60 % on
+                                 #  b2 / hyqreal1, are held to the oracle's row count only, see ParityTally.classify)
     assert nself >= 0.9 * tally.checked and ncross >= 0.25 * tally.checked, (nself, ncross, tally.checked)
 
 

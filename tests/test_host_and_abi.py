@@ -352,3 +352,28 @@ def test_plane_support_tables_never_hide_the_support_vertex(robot):
                     assert best >= depth[sup] - 1e-12, (robot, cl, d)
         assert kept / len(dirs) < (0.5 * nch if nch >= 4 else nch)   # (a cloud of two or three chunks has little to prune)
     assert seen >= 1
+
+
+def test_product_library_reads_no_environment_variable():
+    """The profiling knobs (GQ_STOP_STAGE, GQ_FORCE_SELF, GQ_SELF_CUT, GQ_MB_FLAGS) belong to development builds (tools/dev_build.sh,
+    -DGQ_DEV_KNOBS): the product sources call getenv only under that macro or under the emulator's trace macro, and the built library has no
+    undefined reference to getenv."""
+    import re
+    import subprocess
+    from gym_quadruped_amd import _lib
+    csrc = Path(_lib.__file__).parent / 'csrc'
+    for f in sorted(csrc.glob('*.h')) + sorted(csrc.glob('*.hip')) + sorted(csrc.glob('*.cpp')):
+        guard = []
+        for ln in f.read_text().splitlines():
+            t = ln.strip()
+            if t.startswith('#if'):
+                guard.append(t)
+            elif t.startswith('#else') and guard:
+                guard[-1] = '#else of ' + guard[-1]
+            elif t.startswith('#endif') and guard:
+                guard.pop()
+            if re.search(r'\bgetenv\s*\(', ln) and not t.startswith(('/*', '*', '//')):
+                assert any(g.startswith(('#ifdef GQ_DEV_KNOBS', '#ifdef GQ_EMU_TRACE')) for g in guard), f'{f.name}: getenv outside GQ_DEV_KNOBS / GQ_EMU_TRACE: {t[:80]}'
+    if _lib.LIB_PATH.exists():
+        und = subprocess.run(['nm', '-D', '--undefined-only', str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+        assert 'getenv' not in und, 'libgq.so imports getenv'

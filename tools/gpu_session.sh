@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the GQ_STOP_STAGE / GQ_SELF_CUT / GQ_FORCE_SELF knobs used below exist in DEVELOPMENT builds only - tools/dev_build.sh, -DGQ_DEV_KNOBS, selected with
+# GQ_LIBGQ_PATH; the product library reads no environment variable)
 # One GPU-box session (via gpurun): everything writes under gpurun_out/<tag>/.   Usage: tools/gpu_session.sh <tag> [parts...]
 # parts: probe tests perf bench profiles
 set -u

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the GQ_STOP_STAGE / GQ_SELF_CUT / GQ_FORCE_SELF knobs used below exist in DEVELOPMENT builds only - tools/dev_build.sh, -DGQ_DEV_KNOBS, selected with
+# GQ_LIBGQ_PATH; the product library reads no environment variable)
 # Dynamic instruction counts per stage (runs on the GPU box): the step kernel is cut short after stage marker k
 # (GQ_STOP_STAGE) and SQ_INSTS_VALU / SALU / LDS + SQ_WAVE_CYCLES are collected per cut; differences between
 # consecutive cuts are the stage costs.  Markers in execution order: 1 2 3 4 5 14 6 7 8 9 10 11 12 13 (0 = full).

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <vector>
 #include <random>
+namespace gq { __device__ long long gq_cvx_cyc[8]; }
 #include "gq_convex.h"
 
 #define REP 8
@@ -96,6 +97,8 @@ int main() {
     if (res[4 * p] < 0) { cs += cyc[p]; is += res[4 * p + 1]; nc++; }
   }
   printf("%d penetrating pairs (%d vertices per hull, every chunk scanned): mean %.0f cycles per pair, %.1f EPA iterations -> %.0f cycles per EPA iteration (GJK not separated out)\n", nc, NV, cs / nc, is / nc, cs / is);
+  { long long c[8]; hipMemcpyFromSymbol(c, HIP_SYMBOL(gq::gq_cvx_cyc), sizeof c);
+    printf("cycle shares over all pairs and repeats: GJK glue %lld, support queries %lld, simplex + reduce %lld, EPA select/dup %lld, EPA patch + rim %lld, EPA fan + planes %lld\n", c[0], c[1], c[2], c[3], c[4], c[5]); }
   hipLaunchKernelGGL(k_pieces, dim3(1), dim3(64), 0, 0, dvx, dvy, dvz, dsh, dres, dcyc);
   hipLaunchKernelGGL(k_pieces, dim3(1), dim3(64), 0, 0, dvx, dvy, dvz, dsh, dres, dcyc);
   hipMemcpy(cyc.data(), dcyc, 3 * 8, hipMemcpyDeviceToHost);

@@ -47,3 +47,15 @@ print('last waves to finish (end us | start | niter nefc pending | co-resident w
 for e in last:
     co = np.where(slot == slot[e])[0]
     print(f'  env {e:5d}: {t1[e]:6.1f} | {t0[e]:5.1f} | {nit[e]} {int(d[e]["nefc"][0]):2d} {int(pend[e])} hint {hint[e]} self {int(T[e, 31])} | ' + ' '.join(f'{nit[c]}{"r" if pend[c] else ""}h{hint[c]}@{t1[c]:.0f}' for c in co if c != e))
+
+# the launch's tail as one number (bench.py roofline.tail replays it from profiles/latest_tail.json, with the kernel-source hash it was taken on):
+# the share of the launch during which the median wave has already finished, instrumented variant, one launch of the headline workload
+import json, os
+import bench
+tail = {'tail': float((t1.max() - np.median(t1)) / t1.max()), 'launch_us': float(t1.max()), 'median_wave_end_us': float(np.median(t1)), 'p99_wave_end_us': float(np.percentile(t1, 99)),
+        'kernel_src_sha16': bench.kernel_source_hash(), 'workload': f'{robot} {scene}, {n} envs, instrumented step kernel, launch 301 of a random-action rollout',
+        'profile': 'profiles/r06_wave_timeline.txt'}
+print('tail json:', json.dumps(tail))
+if robot == 'mini_cheetah' and scene == 'flat' and selfcol is None and n == 4096:
+    os.makedirs(ROOT / 'gpurun_out', exist_ok=True)
+    (ROOT / 'gpurun_out' / 'latest_tail.json').write_text(json.dumps(tail))
