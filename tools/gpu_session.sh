@@ -36,7 +36,8 @@ for p in $PARTS; do
             timeout 600 python tools/perf_probe.py stages 4096 > $OUT/stages4096.txt 2>&1;;
     selfcut) for c in 0 2 4; do GQ_SELF_CUT=$c timeout 600 python bench.py --no-cpu-baseline --no-secondary > $OUT/bench_selfcut$c.json 2> $OUT/bench_selfcut$c.err; python -c "import json; d=json.load(open('$OUT/bench_selfcut$c.json')); print('self cut $c', round(d['value']/1e6,2), 'M', round(d['roofline']['kernel_ms']*1e3,1), 'us kernel')"; done;;
     timeline) timeout 600 python tools/wave_timeline.py 4096 > $OUT/wave_timeline.txt 2>&1
-              timeout 600 python tools/wave_timeline.py 4096 mini_cheetah noself > $OUT/wave_timeline_noself.txt 2>&1;;
+              timeout 600 python tools/wave_timeline.py 4096 mini_cheetah noself > $OUT/wave_timeline_noself.txt 2>&1
+              cp gpurun_out/latest_tail.json $OUT/ 2>/dev/null;;
     robots) for r in go2 aliengo hyqreal1; do
               timeout 600 python tools/wave_timeline.py 4096 $r > $OUT/wave_timeline_$r.txt 2>&1
               timeout 600 python tools/wave_timeline.py 4096 $r noself > $OUT/wave_timeline_${r}_noself.txt 2>&1
@@ -47,9 +48,11 @@ for p in $PARTS; do
             timeout 600 python tools/stage_cuts.py 4096 aliengo > $OUT/stage_cuts4096_aliengo.txt 2>&1
             timeout 900 python tools/niter_hist.py mini_cheetah aliengo go2 hyqreal1 go1 b2 2>&1 | grep -v amdgpu.ids > $OUT/niter_hist.txt
             (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o /tmp/fma_issue fma_issue.hip && /tmp/fma_issue) > $OUT/ubench_fma_issue.txt 2>&1;;
+    convex) (hipcc --offload-arch=gfx950 -O3 -std=c++17 -Igym_quadruped_amd/csrc -Iinclude -DGQ_CVX_STATS -o /tmp/convex_pair tools/ubench/convex_pair.hip && /tmp/convex_pair) > $OUT/ubench_convex_pair.txt 2>&1;;
     nscan) timeout 900 python tools/nscan.py > $OUT/nscan.txt 2>&1;;
     profiles) timeout 1500 bash tools/run_profiles.sh $TAG pmc > $OUT/run_profiles.txt 2>&1
               timeout 600 bash tools/run_profiles.sh ${TAG}_noself nopmc --no-self-collision >> $OUT/run_profiles.txt 2>&1
+              timeout 600 bash tools/run_profiles.sh ${TAG}_capsule nopmc --self-collision capsule >> $OUT/run_profiles.txt 2>&1
               timeout 600 bash tools/run_profiles.sh ${TAG}_cfg3 nopmc --robot aliengo --scene perlin >> $OUT/run_profiles.txt 2>&1
               timeout 600 bash tools/run_profiles.sh ${TAG}_cfg4 nopmc --robot go2 >> $OUT/run_profiles.txt 2>&1
               timeout 900 bash tools/run_profiles.sh ${TAG}_cfg5 nopmc --robot hyqreal1 --scene random_boxes --imu --heightmap >> $OUT/run_profiles.txt 2>&1;;

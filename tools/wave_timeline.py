@@ -9,7 +9,7 @@ from gym_quadruped_amd.quadruped_env import QuadrupedEnv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 robot = sys.argv[2] if len(sys.argv) > 2 else 'mini_cheetah'
-selfcol = None if (len(sys.argv) <= 3 or sys.argv[3] != 'noself') else False
+selfcol = None if (len(sys.argv) <= 3 or sys.argv[3] not in ('noself', 'capsule')) else (False if sys.argv[3] == 'noself' else 'capsule')
 scene = sys.argv[4] if len(sys.argv) > 4 else 'flat'
 env = QuadrupedEnv(robot, scene=scene, state_obs_names=tuple(QuadrupedEnv.ALL_OBS), num_envs=n, auto_reset='next_step', seed=1, self_collision=selfcol)
 env.reset(random=True)
