@@ -38,6 +38,9 @@ extern __device__ long long gq_cvx_cyc[8];
 #define GQ_CVX_T(i) do { } while (0)
 #define GQ_CVX_T0() do { } while (0)
 #endif
+#ifndef GQ_CVX_BATCH
+#define GQ_CVX_BATCH 2  /* chunks per shape whose vertex loads go out together (three: 18 registers of loads in flight, spilled by the kernels that inline the routine) */
+#endif
 #define GQ_CVX_GJK_MAXIT 32
 #define GQ_CVX_EPA_MAXIT 24
 #define GQ_CVX_MAXV 28                 /* polytope vertices: 4 + one per EPA iteration */
@@ -105,28 +108,28 @@ GQ_CVX_FN CvxMink cvx_minkowski(LdsCF SA, LdsCF SB, const GQ_MODEL float* vx, co
   float bestA = -3e38f, bestB = -3e38f;
   V3 pA = v3(0.0f, 0.0f, 0.0f), pB = v3(0.0f, 0.0f, 0.0f);
   int iA = adrA, iB = adrB;
-  while (cmA | cmB) { /* wave-uniform: up to three chunks of each shape per trip, their loads in flight together; lanes past the end re-read the last vertex */
-    int cu[6];
-    float px[6], py[6], pz[6];
+  while (cmA | cmB) { /* wave-uniform: up to GQ_CVX_BATCH chunks of each shape per trip, their loads in flight together; lanes past the end re-read the last vertex */
+    int cu[2 * GQ_CVX_BATCH];
+    float px[2 * GQ_CVX_BATCH], py[2 * GQ_CVX_BATCH], pz[2 * GQ_CVX_BATCH];
 #pragma unroll
-    for (int u = 0; u < 3; u++) { cu[u] = cmA ? __builtin_ctz(cmA) : -1; cmA &= cmA - 1; }
+    for (int u = 0; u < GQ_CVX_BATCH; u++) { cu[u] = cmA ? __builtin_ctz(cmA) : -1; cmA &= cmA - 1; }
 #pragma unroll
-    for (int u = 3; u < 6; u++) { cu[u] = cmB ? __builtin_ctz(cmB) : -1; cmB &= cmB - 1; }
+    for (int u = GQ_CVX_BATCH; u < 2 * GQ_CVX_BATCH; u++) { cu[u] = cmB ? __builtin_ctz(cmB) : -1; cmB &= cmB - 1; }
 #pragma unroll
-    for (int u = 0; u < 6; u++)
+    for (int u = 0; u < 2 * GQ_CVX_BATCH; u++)
       if (cu[u] >= 0) {
-        const int i = (u < 3 ? adrA : adrB) + cu[u] * GQ_WAVE + lane, last = u < 3 ? lastA : lastB, ii = i < last ? i : last;
+        const int i = (u < GQ_CVX_BATCH ? adrA : adrB) + cu[u] * GQ_WAVE + lane, last = u < GQ_CVX_BATCH ? lastA : lastB, ii = i < last ? i : last;
         px[u] = vx[ii]; py[u] = vy[ii]; pz[u] = vz[ii];
       }
 #pragma unroll
-    for (int u = 0; u < 3; u++)
+    for (int u = 0; u < GQ_CVX_BATCH; u++)
       if (cu[u] >= 0) {
         const int i = adrA + cu[u] * GQ_WAVE + lane, ii = i < lastA ? i : lastA;
         const float pr = dlA.x * px[u] + dlA.y * py[u] + dlA.z * pz[u];
         if (pr > bestA) { bestA = pr; pA = v3(px[u], py[u], pz[u]); iA = ii; }
       }
 #pragma unroll
-    for (int u = 3; u < 6; u++)
+    for (int u = GQ_CVX_BATCH; u < 2 * GQ_CVX_BATCH; u++)
       if (cu[u] >= 0) {
         const int i = adrB + cu[u] * GQ_WAVE + lane, ii = i < lastB ? i : lastB;
         const float pr = dlB.x * px[u] + dlB.y * py[u] + dlB.z * pz[u];

@@ -751,7 +751,7 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
     hbase[pass] = (&W.Mc[0][0])[slot];
   }
   uint32_t tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = (DBG && tdbg) ? (uint32_t)cycles() : 0u; /* (32-bit: wave-uniform counters of the instrumented variant, half the registers) */
-  if constexpr (DBG) if (tdbg && lane == 0) { tdbg[29] = 0.0f; tdbg[30] = 0.0f; tdbg[24] = 0.0f; tdbg[26] = 0.0f; tdbg[27] = 0.0f; } /* line-search trials, full-step shortcuts; largest count of active cross-leg rows in a dense step, dense steps, Sherman-Morrison steps */
+  if constexpr (DBG) if (tdbg && lane == 0) { tdbg[29] = 0.0f; tdbg[30] = 0.0f; tdbg[0] = 0.0f; } /* line-search trials, full-step shortcuts; slot 0 (no stage stamp uses it): largest count of active cross-leg rows in a dense step + 64 x dense steps + 4096 x Sherman-Morrison steps (slots 24 - 28 are the wave's clocks / hardware slot / priority, written at the start of step_wave) */
 #define NW_T(i) do { if constexpr (DBG) if (tdbg) { const uint32_t tn = (uint32_t)cycles(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
   NW_T(0);
   /* residual y = J qacc - aref and Ma-terms are evaluated once, then advanced incrementally along the search
@@ -844,8 +844,9 @@ __device__ inline float newton_solve(WaveMem& W, const StepConsts& m, const int 
     if constexpr (DBG) if (tdbg && xl) { /* wave-uniform */
       const float kx = (float)popc64(ballot(xrow && (wact != 0.0f || (CONE && zone == 2))));
       if (lane == 0) {
-        if (xsm) tdbg[27] += 1.0f;
-        else { tdbg[24] = fmaxf(tdbg[24], kx); tdbg[26] += 1.0f; }
+        const int w0 = (int)tdbg[0];
+        if (xsm) tdbg[0] = (float)(w0 + 4096);
+        else tdbg[0] = (float)((w0 & ~63) + 64 + imax(w0 & 63, imin((int)kx, 63)));
       }
     }
     const float xw = xsm ? bcast(wact, xr) : 0.0f;

@@ -74,6 +74,7 @@ def stage_times(n=4096, iters=100, tol=1e-8, solver='newton', robot='mini_cheeta
             if sel.sum():
                 print(f'    {nm:32s}: {sel.sum():5d} waves, niter mean {nit[sel].mean():.2f} max {nit[sel].max():.0f}, nefc mean {ne[sel].mean():.1f}, total {T[sel, 13].mean():8.0f} cycles, '
                       f'S6b {(T[sel, 6] - T[sel, 14]).mean():6.0f} S7 {(T[sel, 7] - T[sel, 6]).mean():6.0f} solver {(T[sel, 9] - T[sel, 8]).mean():7.0f}; per iteration: hessian {T[sel, 19].sum() / nit[sel].sum():6.0f} solve {T[sel, 20].sum() / nit[sel].sum():6.0f}')
+        W0 = T[:, 0].astype(int); T = T.copy(); T[:, 24], T[:, 26], T[:, 27] = W0 & 63, (W0 >> 6) & 63, W0 >> 12   # the dense-step census, packed in slot 0 (gq_newton.h)
         dn = T[:, 26] > 0
         if dn.sum():   # dense steps: how many cross-leg rows were active (what a low-rank correction of the tree solve would have to carry)
             kmax = T[dn, 24].astype(int)
