@@ -96,7 +96,7 @@ def kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     # the DEVICE side of the step kernel (and the flags it is built with): the host API / model lowering do not move its traffic
-    for name in ('Makefile', 'gq_boxes.h', 'gq_convex.h', 'gq_device.h', 'gq_heightmap.h', 'gq_kernels.hip', 'gq_model_dev.h', 'gq_newton.h', 'gq_pairs.h', 'gq_step_body.h', 'gq_step_kernel.h'):
+    for name in ('Makefile', 'gq_boxes.h', 'gq_convex.h', 'gq_device.h', 'gq_exchange.h', 'gq_heightmap.h', 'gq_kernels.hip', 'gq_model_dev.h', 'gq_newton.h', 'gq_pairs.h', 'gq_step_body.h', 'gq_step_kernel.h'):
         h.update((ROOT / 'gym_quadruped_amd' / 'csrc' / name).read_bytes())
     return h.hexdigest()[:16]
 
@@ -239,10 +239,12 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
     "secondary") and (ii) the PGS solver the north-star names; same timing discipline, reported next to the headline."""
     out = {}
     for key, obs_names, solver, sc in (('default_obs', QuadrupedEnv._DEFAULT_OBS, args.solver, _self_collision(args)), ('pgs', tuple(QuadrupedEnv.ALL_OBS), 'pgs', None),
+                                       ('pair_exchange_off', tuple(QuadrupedEnv.ALL_OBS), args.solver, None),
                                        ('self_collision_capsule_proxies', tuple(QuadrupedEnv.ALL_OBS), args.solver, 'capsule'),
                                        ('self_collision_off', tuple(QuadrupedEnv.ALL_OBS), args.solver, False)):
         env = QuadrupedEnv('mini_cheetah', state_obs_names=obs_names, scene='flat', num_envs=n, device=device, auto_reset='next_step',
-                           solver=solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000, self_collision=sc)
+                           solver=solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000, self_collision=sc,
+                           pair_exchange=(key != 'pair_exchange_off' and not args.no_pair_exchange))
         env.reset(random=True)
         for i in range(warmup):
             env.step(pool[i % 64])
@@ -255,6 +257,9 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
         out[key] = {'value': n * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps,
                     'obs_dim': env._obs_dim, 'solver': solver, 'bytes_per_env_step': algorithmic_bytes_per_env_step(env._obs_dim),
                     'self_collision': env._mm.self_collision}
+        if key == 'pair_exchange_off':
+            out[key]['note'] = ('the headline workload with every env computing its own convex pairs (QuadrupedEnv(pair_exchange=False)): the launch then lasts as long as '
+                                'its most entangled robot - csrc/gq_exchange.h; results are bit-identical')
         if key == 'self_collision_capsule_proxies':
             out[key]['note'] = ('the headline workload with the capsule proxies of rounds 2 - 5 in place of the convex routine for robot-robot pairs that involve a mesh '
                                 '(QuadrupedEnv(self_collision="capsule")): an approximation - such a contact is found late, by the gap between hull and capsule')
@@ -265,7 +270,7 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
     # overlapping launches share the SIMDs, so each still lasts as long as its slowest wave under full contention, and more
     # than two queues serialise
     env = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), scene='flat', num_envs=n, device=device, auto_reset='next_step',
-                       solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000, self_collision=_self_collision(args))
+                       solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000, self_collision=_self_collision(args), pair_exchange=not args.no_pair_exchange)
     env.reset(random=True)
     acts = torch.stack(pool)                       # [64, n, 12]
     for _ in range(4):
@@ -338,7 +343,7 @@ def secondary_lines(QuadrupedEnv, n, device, pool, args, steps=400, warmup=100):
         with torch.cuda.stream(st):
             e = QuadrupedEnv('mini_cheetah', state_obs_names=tuple(QuadrupedEnv.ALL_OBS), scene='flat', num_envs=n, device=device, auto_reset='next_step',
                              solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=1000 + k, env_id_offset=k * n,
-                             self_collision=_self_collision(args))
+                             self_collision=_self_collision(args), pair_exchange=not args.no_pair_exchange)
             e.reset(random=True)
         envs.append(e); streams.append(st)
     torch.cuda.synchronize(device)
@@ -380,6 +385,7 @@ def main():
     ap.add_argument('--solver', choices=['newton', 'pgs'], default='newton')
     ap.add_argument('--scene', default='flat', help="headline metric: flat; box scenes (random_boxes, stairs, ...) for the secondary configs")
     ap.add_argument('--robot', default='mini_cheetah', help='headline metric: mini_cheetah; other registry robots for the secondary configs')
+    ap.add_argument('--no-pair-exchange', action='store_true', help='every env computes its own convex self pairs (default: shared with idle wavefronts of the launch, csrc/gq_exchange.h)')
     ap.add_argument('--no-self-collision', action='store_true', help='switch robot self-collision off (MuJoCo default and default here: on)')
     ap.add_argument('--self-collision', choices=['convex', 'capsule', 'off'], default='convex',
                     help="robot-robot pairs with a mesh / cylinder: 'convex' = MuJoCo's general convex routine on the hulls (default, the headline), "
@@ -438,7 +444,7 @@ def main():
         obs_names = obs_names + IMU.ALL_OBS
     env = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device, sensors=sensors, sensors_kwargs=sensors_kwargs,
                        auto_reset=False if (args.no_auto_reset or args.auto_reset == 'off') else args.auto_reset, solver=args.solver, solver_iterations=100, solver_tolerance=1e-8,
-                       seed=1000, env_id_offset=shard.env_offset, self_collision=_self_collision(args))  # shards: disjoint global env ids -> disjoint RNG counters
+                       seed=1000, env_id_offset=shard.env_offset, self_collision=_self_collision(args), pair_exchange=not args.no_pair_exchange)  # shards: disjoint global env ids -> disjoint RNG counters
     env.reset(random=True)
     g = torch.Generator(device=device).manual_seed(rank)
     pool = [torch.randn(n, 12, generator=g, device=device) * 50 for _ in range(64)]
@@ -455,7 +461,7 @@ def main():
     # clocks and caches as a --steps 2000 one; the measured env then does exactly --warmup untimed steps
     scratch = QuadrupedEnv(args.robot, state_obs_names=obs_names, scene=args.scene, num_envs=n, device=device, sensors=sensors, sensors_kwargs=sensors_kwargs,
                            auto_reset='next_step', solver=args.solver, solver_iterations=100, solver_tolerance=1e-8, seed=999,
-                           self_collision=_self_collision(args))
+                           self_collision=_self_collision(args), pair_exchange=not args.no_pair_exchange)
     scratch.reset(random=True)
     for i in range(DEVICE_WARMUP_STEPS):
         scratch.step(pool[i % 64])

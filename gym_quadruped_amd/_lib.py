@@ -14,7 +14,7 @@ import os
 LIB_PATH = Path(os.environ.get('GQ_LIBGQ_PATH', Path(__file__).parent / 'libgq.so'))
 
 EXPORTS = ['gq_last_error', 'gq_version', 'gq_struct_sizes', 'gq_obs_dim', 'gq_model_create', 'gq_model_destroy', 'gq_batch_create',
-           'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_batch_set_imu', 'gq_batch_set_heightmap', 'gq_batch_set_pending', 'gq_batch_set_resampling', 'gq_heightmap', 'gq_heightmap_strided', 'gq_step_range', 'gq_batch_bind', 'gq_rollout', 'gq_rollout_closed', 'gq_rollout_closed_status', 'gq_mailbox_get', 'gq_jac', 'gq_ray', 'gq_forward', 'gq_full_mass', 'gq_batch_set_outputs', 'gq_contact_force', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get', 'gq_debug_device_buffer', 'gq_debug_field', 'gq_debug_stop_stage']
+           'gq_batch_destroy', 'gq_batch_obs_dim', 'gq_batch_set_imu', 'gq_batch_set_heightmap', 'gq_batch_set_pair_exchange', 'gq_batch_set_pending', 'gq_batch_set_resampling', 'gq_heightmap', 'gq_heightmap_strided', 'gq_step_range', 'gq_batch_bind', 'gq_rollout', 'gq_rollout_closed', 'gq_rollout_closed_status', 'gq_mailbox_get', 'gq_jac', 'gq_ray', 'gq_forward', 'gq_full_mass', 'gq_batch_set_outputs', 'gq_contact_force', 'gq_step', 'gq_reset', 'gq_debug_enable', 'gq_debug_get', 'gq_debug_device_buffer', 'gq_debug_field', 'gq_debug_stop_stage']
 
 
 class GqError(RuntimeError):
@@ -47,6 +47,7 @@ def lib():
     L.gq_batch_obs_dim.argtypes = [C.c_void_p]
     L.gq_batch_set_imu.argtypes = [C.c_void_p, C.POINTER(GqImuCfg), C.c_void_p]
     L.gq_batch_set_heightmap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    L.gq_batch_set_pair_exchange.argtypes = [C.c_void_p, C.c_int]
     L.gq_batch_set_resampling.argtypes = [C.c_void_p, C.POINTER(GqResampleCfg), C.POINTER(GqResetCfg), C.c_void_p, C.c_void_p]
     L.gq_batch_set_pending.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.gq_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, GqState, GqObsOut, C.POINTER(GqResetCfg), C.c_void_p,

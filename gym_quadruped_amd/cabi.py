@@ -12,7 +12,7 @@ import numpy as np
 from .mjcf import ModelDesc
 
 GQ_NLEG = 4
-GQ_ABI_VERSION = 600   # include/gq.h
+GQ_ABI_VERSION = 610   # include/gq.h
 # optional extra output rows of the step kernel (include/gq.h gq_batch_set_outputs)
 GQ_DYN = dict(MC=0, MB=108, BIAS=144, XPOS=162, XMAT=201, FOOT=318, STRIDE=336)
 GQ_CON_MAX, GQ_CON_REC = 12, 24

@@ -64,6 +64,8 @@ struct GqBatch {
   uint8_t* pending;     /* device [N]: next-step auto-reset flags */
   uint8_t* lift_pending;/* device [N]: reset kernel -> the reset's own step: lift loop still due */
   uint8_t* load_hint;   /* device [N]: per-env solver load of the previous step (scheduling hint of the step kernel) */
+  int32_t* xq;          /* device: convex pair exchange (gq_exchange.h) - models with convex self pairs only, else NULL */
+  int xq_slots; bool xq_on;
   int stop_stage;       /* profiling aid: GQ_STOP_STAGE at batch creation */
   int force_self;       /* profiling aid: GQ_FORCE_SELF=1 runs the self-collision kernel variant even for a model without pairs */
   /* argument block of step_kernel: device copy, host shadow of what the device holds, pinned staging ring for the
@@ -188,6 +190,18 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
   HIP_TRY_OR_DESTROY(hipMemset(b->lift_pending, 0, (size_t)n_envs), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipMalloc(&b->load_hint, (size_t)n_envs), gq_batch_destroy(b));
   HIP_TRY_OR_DESTROY(hipMemset(b->load_hint, 0, (size_t)n_envs), gq_batch_destroy(b));
+  if (m->host.ncvx_self > 0) { /* the pair exchange: two slots per env, rounded up to a power of two (an env publishes what it has beyond its first pair - 0.45 pairs
+                                * per env-step on the benchmark's states: the table stays sparse, which is what its hashing wants) */
+    int slots = 256;
+    while (slots < 2 * n_envs && slots < (1 << 21)) slots <<= 1;
+    const size_t words = (size_t)slots * (1 + GQ_XQ_ITEM);
+    HIP_TRY_OR_DESTROY(hipMalloc(&b->xq, words * sizeof(int32_t)), gq_batch_destroy(b));
+    HIP_TRY_OR_DESTROY(hipMemset(b->xq, 0, words * sizeof(int32_t)), gq_batch_destroy(b));
+    b->xq_slots = slots;
+    b->xq_on = true;
+    b->host.xq = b->xq; b->host.xq_slots = slots;
+    HIP_TRY_OR_DESTROY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice), gq_batch_destroy(b));
+  }
   /* profiling knobs of development builds (tools/dev_build.sh defines GQ_DEV_KNOBS; tools/stage_insts.sh, stage_cuts.py): the product library
    * reads no environment variable (tests/test_host_and_abi.py checks its objects for getenv) */
 #ifdef GQ_DEV_KNOBS
@@ -223,7 +237,7 @@ static void mailbox_free(GqBatch* b) {
 int gq_batch_destroy(GqBatch* b) {
   if (!b) return GQ_OK;
   DeviceGuard guard(b->model->device);
-  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->lift_pending); hipFree(b->load_hint); hipFree(b->dev_args);
+  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->lift_pending); hipFree(b->load_hint); hipFree(b->xq); hipFree(b->dev_args);
   if (b->staging) hipHostFree(b->staging);
   if (b->batch_staging) hipHostFree(b->batch_staging);
   mailbox_free(b);
@@ -240,6 +254,15 @@ int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state) {
   if (!b || !cfg || !bias_state) { SET_ERR("gq_batch_set_imu: null argument"); return GQ_EINVAL; }
   gq_fill_imu(&b->host, cfg);
   b->imu_bias = bias_state;
+  b->batch_dirty = true; /* uploaded by the next launch, stream-ordered (ensure_args) */
+  return GQ_OK;
+}
+
+int gq_batch_set_pair_exchange(GqBatch* b, int on) {
+  if (!b) { SET_ERR("gq_batch_set_pair_exchange: null batch"); return GQ_EINVAL; }
+  if (on && !b->xq) { SET_ERR("gq_batch_set_pair_exchange: the model has no convex self pairs - nothing to exchange"); return GQ_EINVAL; }
+  b->xq_on = on != 0;
+  b->host.xq = b->xq_on ? b->xq : nullptr; b->host.xq_slots = b->xq_on ? b->xq_slots : 0;
   b->batch_dirty = true; /* uploaded by the next launch, stream-ordered (ensure_args) */
   return GQ_OK;
 }
@@ -759,7 +782,7 @@ static const struct { const char* name; int off, n; } kDbg[] = {
     {"efc_J", GQ_DBG_EFC_J, 64 * 18}, {"efc_aref", GQ_DBG_EFC_AREF, 64}, {"efc_R", GQ_DBG_EFC_R, 64},
     {"efc_b", GQ_DBG_EFC_B, 64}, {"efc_force", GQ_DBG_EFC_FORCE, 64}, {"efc_type", GQ_DBG_EFC_TYPE, 64},
     {"contact_dist", GQ_DBG_CON_DIST, GQ_MAXCON}, {"contact_geom", GQ_DBG_CON_GEOM, GQ_MAXCON},
-    {"foot_pos", GQ_DBG_FOOT_POS, 12}, {"qacc", GQ_DBG_QACC, 18}, {"timer", GQ_DBG_TIMER, 32}, {"record", 0, GQ_DBG_SIZE}};
+    {"foot_pos", GQ_DBG_FOOT_POS, 12}, {"qacc", GQ_DBG_QACC, 18}, {"timer", GQ_DBG_TIMER, 32}, {"xq", GQ_DBG_XQ, 16}, {"record", 0, GQ_DBG_SIZE}};
 
 int gq_debug_stop_stage(GqBatch* b, int stage) {
   if (!b) { SET_ERR("gq_debug_stop_stage: null batch"); return GQ_EINVAL; }

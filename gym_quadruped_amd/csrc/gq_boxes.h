@@ -17,6 +17,7 @@
 #include "gq_step_kernel.h"
 #include "gq_pairs.h"
 #include "gq_convex.h"
+#include "gq_exchange.h"
 
 namespace gq {
 
@@ -720,7 +721,7 @@ __device__ inline void self_item_obb(const WaveMem& W, const GQ_MODEL GqDevModel
 }
 
 template <bool CONE, bool PRIM = true>
-__device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre, const StepConsts& K, const int nlg) {
+__device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr) {
   constexpr int NP = PRIM ? 4 : 1; /* points per pair: only the exact pair routines return more than one */
   const int lane = lane_id();
   const int nsp = K.nsp;
@@ -797,11 +798,12 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     ncand += popc64(cm);
   }
   GQ_SUB(W, 1, 11); /* pair cull */
-  if (ncand == 0 || K.self_cut == 2) return;
+  if (K.self_cut == 2 || (ncand == 0 && Bt.xq == nullptr)) return;
   if (ncand > 2 * GQ_WAVE) ncand = 2 * GQ_WAVE; /* more than 128 close pairs: the robot is a knot; the row budget is long spent */
   wave_barrier();
+  const int npass = ncand > 0 ? ncand : 1; /* (a batch with a pair exchange: an env without a candidate still passes by the convex block once - it may have time for others, gq_exchange.h) */
 #pragma unroll 1
-  for (int c0 = 0; c0 < ncand; c0 += GQ_WAVE) { /* pass B, lane = candidate pair */
+  for (int c0 = 0; c0 < npass; c0 += GQ_WAVE) { /* pass B, lane = candidate pair */
     const bool cand = c0 + lane < ncand;
     const int p = cand ? list[c0 + lane] : 0;
     PairHit H;
@@ -865,22 +867,110 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         }
       }
     }
-    { /* the convex pairs that passed their mid phase, one after the other on the whole wavefront (gq_convex.h) */
+    { /* the convex pairs that passed their mid phase, one after the other on the whole wavefront (gq_convex.h) - or, when the batch has a
+       * pair exchange and this env several pairs, shared with wavefronts that have time (gq_exchange.h).  ONE call site of the routine
+       * serves the pairs computed here and the published pairs taken back. */
       uint64_t cm = ballot(cvx);
       if (K.self_cut == 5) cm = 0;        /* profiling aid: the mid phase without the convex routine */
       if (K.self_cut == 6) cm &= cm - 1;  /* ... and without the first pair that reaches it */
-      while (cm) { /* wave-uniform */
-        const int j = ffs64(cm);
-        cm &= cm - 1;
-        const int pj = bcast(p, j), i1 = bcast(it1, j), i2 = bcast(it2, j);
+      Xq X; X.q = Bt.xq; X.slots = Bt.xq_slots;
+      uint64_t local = cm, own = 0; /* pairs to run here / published */
+      int myslot = -1;              /* lane = pair: the slot it reserved */
+      long long t_wait = -1;
+      /* an env without convex work of its own has 40 us to spare before the launch's entangled envs are through: it lingers here for a few
+       * microseconds - if its group of the table has seen pairs lately - and takes what gets published meanwhile */
+      bool linger = X.q != nullptr && cm == 0 && c0 + GQ_WAVE >= npass;
+      long long t_linger = -1;
+#define GQ_XSTAT(i, v) do { if (xdbg && lane == 0) xdbg[i] = (float)(v); } while (0)
+#define GQ_XTIME(i) GQ_XSTAT(i, wall_clock64() & 0xFFFFF)
+      int x_back = 0, x_help = 0; long long x_ticks = 0, x_t0 = 0; bool x_ld = false;
+      if (cm) GQ_XSTAT(0, popc64(cm));
+      if (X.q != nullptr && (cm & (cm - 1)) != 0) { /* two pairs or more: keep the first, publish the others - at once, helpers come by only so often */
+        const uint64_t rest = cm & (cm - 1);
+        if ((rest >> lane) & 1ull) myslot = xq_reserve(X, wave_index(), lane);
+        own = ballot(myslot >= 0);
+        local = cm & ~own; /* (no free slot among a pair's candidates: it stays here) */
+        for (uint64_t r = own; r;) {
+          const int jj = ffs64(r); r &= r - 1;
+          const int pj = bcast(p, jj), i1 = bcast(it1, jj), i2 = bcast(it2, jj), sj = bcast(myslot, jj);
+          wave_barrier();
+          self_item_shape(W, m, i1, cw[i1], GQ_CVX_SHP(W));
+          self_item_shape(W, m, i2, cw[i2], GQ_CVX_SHP(W) + GQ_CVX_SHAPE_WORDS);
+          wave_barrier();
+          xq_put(X, sj, GQ_CVX_SHP(W), m.sp[pj].mix.margin);
+        }
+        publish_fence();
+        if (myslot >= 0) xq_ready(X, myslot);
+        GQ_XSTAT(1, popc64(own)); GQ_XTIME(2);
+      }
+#pragma unroll 1
+      for (;;) { /* wave-uniform */
+        int j = -1, slot = -1;
+        if (local) { j = ffs64(local); local &= local - 1; }
+        else if (own) { /* the pairs kept here are done: watch the published ones */
+          if (xdbg && !x_ld) { GQ_XTIME(3); x_ld = true; }
+          const int s = myslot >= 0 ? ld_pub(xq_state(X, myslot)) : XQ_DONE;
+          const uint64_t ready = ballot(s == XQ_READY), busy = ballot(s == XQ_CLAIMED);
+          if (ready) { /* nobody has taken it yet: take it back */
+            j = ffs64(ready);
+            slot = bcast(myslot, j);
+            if (!xq_claim(X, slot)) continue; /* a helper was faster */
+            j = -1; x_back++;
+          } else if (busy) {
+            if (t_wait < 0) t_wait = wall_clock64();
+            if (wall_clock64() - t_wait < GQ_XQ_OWNER_TICKS) { nap(); continue; }
+            /* (never seen) a helper holds the pair for milliseconds: compute it here; its slot is left behind, results are not read from it */
+            j = ffs64(busy);
+            own &= ~(1ull << j);
+            if (lane == j) myslot = -1;
+          } else break; /* all DONE */
+        } else if (linger) {
+          int hot;
+          slot = xq_scan(X, wave_index(), hot);
+          if (slot >= 0) {
+            if (!xq_claim(X, slot)) continue;
+            if (xdbg) { if (x_help == 0) GQ_XTIME(7); x_help++; x_t0 = wall_clock64(); }
+            xq_mark_hot(X, wave_index());
+            if (t_linger < 0) t_linger = wall_clock64();
+          } else {
+            const long long now = wall_clock64();
+            if (t_linger < 0) { /* first look: nothing there - stay only if the group was busy within the last millisecond */
+              t_linger = now;
+              if (!xq_is_hot(hot, now)) break;
+            }
+            if (now - t_linger > GQ_XQ_LINGER_TICKS) break;
+            nap();
+            continue;
+          }
+        } else break;
+        float marg;
         wave_barrier();
-        self_item_shape(W, m, i1, cw[i1], GQ_CVX_SHP(W));
-        self_item_shape(W, m, i2, cw[i2], GQ_CVX_SHP(W) + GQ_CVX_SHAPE_WORDS);
+        if (j >= 0) {
+          const int pj = bcast(p, j), i1 = bcast(it1, j), i2 = bcast(it2, j);
+          self_item_shape(W, m, i1, cw[i1], GQ_CVX_SHP(W));
+          self_item_shape(W, m, i2, cw[i2], GQ_CVX_SHP(W) + GQ_CVX_SHAPE_WORDS);
+          marg = m.sp[pj].mix.margin;
+        } else xq_get(X, slot, GQ_CVX_SHP(W), marg);
         wave_barrier();
-        const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_SELF(W), K.vx, K.vy, K.vz, m.sp[pj].mix.margin);
-        if (hit && lane == j) {
-          LdsCF out = GQ_CVX_SHP(W) + 2 * GQ_CVX_SHAPE_WORDS;
-          H.n = 1; H.dist[0] = out[0]; H.nrm[0] = ld3(out + 1); H.pos[0] = ld3(out + 4);
+        const bool hit = cvx_pair_wave(GQ_CVX_SHP(W), GQ_CVX_POLY_SELF(W), K.vx, K.vy, K.vz, marg);
+        LdsCF out = GQ_CVX_SHP(W) + 2 * GQ_CVX_SHAPE_WORDS;
+        if (j >= 0) {
+          if (hit && lane == j) { H.n = 1; H.dist[0] = out[0]; H.nrm[0] = ld3(out + 1); H.pos[0] = ld3(out + 4); }
+        } else {
+          wave_barrier(); xq_done(X, slot, hit, out);
+          if (xdbg && linger) x_ticks += wall_clock64() - x_t0;
+          if (linger && wall_clock64() - t_linger > GQ_XQ_LINGER_TICKS) linger = false;
+        }
+      }
+      if (xdbg) { if (own) { GQ_XTIME(4); GQ_XSTAT(5, x_back); } if (x_help) { GQ_XSTAT(6, x_help); GQ_XSTAT(8, x_ticks); } if (cm == 0 && X.q) GQ_XTIME(9); }
+      if (own) { /* collect, and give the slots back */
+        if (myslot >= 0) {
+          const int32_t* it = xq_item(X, myslot);
+          if (ld_pub(it + GQ_XQ_RES) != 0) {
+            const float* r = reinterpret_cast<const float*>(it) + GQ_XQ_RES;
+            H.n = 1; H.dist[0] = ld_pub(r + 1); H.nrm[0] = v3(ld_pub(r + 2), ld_pub(r + 3), ld_pub(r + 4)); H.pos[0] = v3(ld_pub(r + 5), ld_pub(r + 6), ld_pub(r + 7));
+          }
+          st_pub(xq_state(X, myslot), XQ_FREE); /* (the loads above have returned: H is used below) */
         }
       }
     }
@@ -956,7 +1046,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
 /* S6 for a scene without world boxes / height field but with robot self-collision: general frames for the floor
  * contacts the floor pass left in W, then the robot-robot contacts.  Ends with a barrier. */
 template <bool CONE>
-__device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre, const StepConsts& K, const int nlg) {
+__device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr) {
   const int lane = lane_id();
   WorldAppend S;
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = 0; S.reserve = 0; S.nself = 0; S.ndrop = uniform(W.ndrop);
@@ -968,7 +1058,7 @@ __device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL G
   }
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
-  append_self_contacts<CONE>(W, m, mu_env, S, pre, K, nlg);
+  append_self_contacts<CONE>(W, m, mu_env, S, pre, K, nlg, Bt, xdbg);
   { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; W.ndrop = S.ndrop; } /* (every lane: the same words) */
   wave_barrier();
 }
@@ -979,7 +1069,7 @@ __device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL G
  * materialised in scratch memory, 200 bytes per lane) */
 template <bool CONE, bool SELF, bool PRIM>
 __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
-                                          double bx, double by, float mu_env, const SelfPrefetch& pre, const ItemRegs& IT, const StepConsts& K, const int nlg) {
+                                          double bx, double by, float mu_env, const SelfPrefetch& pre, const ItemRegs& IT, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr) {
   const int lane = lane_id();
   const PrimLane PL = prim_lane(W, m, IT, PRIM && lane < 4 + m.nlg, PRIM); /* all the box loop keeps of the item record */
   WorldAppend S;
@@ -1030,7 +1120,7 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
   if constexpr (SELF) {
     (void)pre;
     const SelfPrefetch pre_now = self_prefetch(m, nlg, K.nsp); /* not prefetched in front of the box loop: it would sit in registers (or scratch) across it */
-    append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre_now, K, nlg);
+    append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre_now, K, nlg, Bt, xdbg);
   }
   if (lane == 0) {
     W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself; W.ndrop = S.ndrop;

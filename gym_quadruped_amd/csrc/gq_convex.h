@@ -92,18 +92,32 @@ __device__ inline CvxCaps cvx_caps_fetch(LdsCF SA, LdsCF SB, const GQ_MODEL floa
  * over the chunks their caps let through, the loads of BOTH shapes in flight together, DPP wave-max, the winners' coordinates by v_readlane;
  * boxes and segments answer analytically.  (One copy of this code per kernel.) */
 struct CvxMink { V3 w; int id; };
-GQ_CVX_FN CvxMink cvx_minkowski(LdsCF SA, LdsCF SB, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const V3 d, const CvxCaps caps) {
-  const int lane = lane_id();
+/* the two shapes' descriptors in registers for the length of the routine (wave-uniform values): a query read them from LDS - 40 words, their
+ * latency in front of every one of the ten to twenty queries of a pair */
+struct CvxRegs { int kA, kB, adrA, adrB, lastA, lastB, chA, chB; LdsCF RA, RB, tA_, tB_, hA_, hB_; };
+__device__ __forceinline__ CvxRegs cvx_regs(LdsCF SA, LdsCF SB) {
   LdsCI IA = (LdsCI)SA; LdsCI IB = (LdsCI)SB;
-  const int kA = uniform(IA[0]), kB = uniform(IB[0]);
-  const V3 dlA = matTvec(SA + 4, d), dlB = matTvec(SB + 4, -1.0f * d);
-  int cmA = 0, cmB = 0, adrA = 0, adrB = 0, lastA = 0, lastB = 0;
+  CvxRegs G;
+  G.kA = uniform(IA[0]); G.kB = uniform(IB[0]);
+  G.adrA = uniform(IA[1]); G.adrB = uniform(IB[1]);
+  const int nA = uniform(IA[2]), nB = uniform(IB[2]);
+  G.lastA = G.adrA + nA - 1; G.lastB = G.adrB + nB - 1;
+  G.chA = (1 << ((nA + GQ_WAVE - 1) / GQ_WAVE)) - 1; G.chB = (1 << ((nB + GQ_WAVE - 1) / GQ_WAVE)) - 1;
+  G.RA = SA + 4; G.RB = SB + 4; G.tA_ = SA + 13; G.tB_ = SB + 13; G.hA_ = SA + 16; G.hB_ = SB + 16;
+  return G;
+}
+GQ_CVX_FN CvxMink cvx_minkowski(const CvxRegs& G, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const V3 d, const CvxCaps caps) {
+  const int lane = lane_id();
+  const int kA = G.kA, kB = G.kB;
+  const V3 dlA = matTvec(G.RA, d), dlB = matTvec(G.RB, -1.0f * d);
+  int cmA = 0, cmB = 0;
+  const int adrA = G.adrA, adrB = G.adrB, lastA = G.lastA, lastB = G.lastB;
   if (kA == 0 || kB == 0) { /* wave-uniform */
     const V3 mine = lane < 16 ? dlA : dlB;
     const float inv = fast_rsqrt(fmaxf(dot(mine, mine), 1e-30f));
     const uint64_t pass = ballot(inv * dot(mine, caps.ax) >= caps.cs - 1e-4f);
-    if (kA == 0) { adrA = uniform(IA[1]); const int n = uniform(IA[2]); lastA = adrA + n - 1; cmA = (int)(pass & 0xffffull) & ((1 << ((n + GQ_WAVE - 1) / GQ_WAVE)) - 1); }
-    if (kB == 0) { adrB = uniform(IB[1]); const int n = uniform(IB[2]); lastB = adrB + n - 1; cmB = (int)((pass >> 16) & 0xffffull) & ((1 << ((n + GQ_WAVE - 1) / GQ_WAVE)) - 1); }
+    if (kA == 0) cmA = (int)(pass & 0xffffull) & G.chA;
+    if (kB == 0) cmB = (int)((pass >> 16) & 0xffffull) & G.chB;
   }
   float bestA = -3e38f, bestB = -3e38f;
   V3 pA = v3(0.0f, 0.0f, 0.0f), pB = v3(0.0f, 0.0f, 0.0f);
@@ -141,28 +155,28 @@ GQ_CVX_FN CvxMink cvx_minkowski(LdsCF SA, LdsCF SB, const GQ_MODEL float* vx, co
   if (kA == 0) {
     const float wmax = wave_max(bestA);
     const int who = ffs64(ballot(bestA == wmax));
-    a = ld3(SA + 13) + matvec(SA + 4, v3(bcast(pA.x, who), bcast(pA.y, who), bcast(pA.z, who)));
+    a = ld3(G.tA_) + matvec(G.RA, v3(bcast(pA.x, who), bcast(pA.y, who), bcast(pA.z, who)));
     ida = bcast(iA, who) - adrA;
   } else if (kA == 1) {
-    const V3 h = ld3(SA + 16);
+    const V3 h = ld3(G.hA_);
     ida = (dlA.x < 0.0f ? 1 : 0) | (dlA.y < 0.0f ? 2 : 0) | (dlA.z < 0.0f ? 4 : 0);
-    a = ld3(SA + 13) + matvec(SA + 4, v3(dlA.x < 0.0f ? -h.x : h.x, dlA.y < 0.0f ? -h.y : h.y, dlA.z < 0.0f ? -h.z : h.z));
+    a = ld3(G.tA_) + matvec(G.RA, v3(dlA.x < 0.0f ? -h.x : h.x, dlA.y < 0.0f ? -h.y : h.y, dlA.z < 0.0f ? -h.z : h.z));
   } else {
-    const V3 p0 = ld3(SA + 13), p1 = ld3(SA + 16);
+    const V3 p0 = ld3(G.tA_), p1 = ld3(G.hA_);
     const bool far = dot(d, p1 - p0) > 0.0f;
     a = far ? p1 : p0; ida = far ? 1 : 0;
   }
   if (kB == 0) {
     const float wmax = wave_max(bestB);
     const int who = ffs64(ballot(bestB == wmax));
-    b = ld3(SB + 13) + matvec(SB + 4, v3(bcast(pB.x, who), bcast(pB.y, who), bcast(pB.z, who)));
+    b = ld3(G.tB_) + matvec(G.RB, v3(bcast(pB.x, who), bcast(pB.y, who), bcast(pB.z, who)));
     idb = bcast(iB, who) - adrB;
   } else if (kB == 1) {
-    const V3 h = ld3(SB + 16);
+    const V3 h = ld3(G.hB_);
     idb = (dlB.x < 0.0f ? 1 : 0) | (dlB.y < 0.0f ? 2 : 0) | (dlB.z < 0.0f ? 4 : 0);
-    b = ld3(SB + 13) + matvec(SB + 4, v3(dlB.x < 0.0f ? -h.x : h.x, dlB.y < 0.0f ? -h.y : h.y, dlB.z < 0.0f ? -h.z : h.z));
+    b = ld3(G.tB_) + matvec(G.RB, v3(dlB.x < 0.0f ? -h.x : h.x, dlB.y < 0.0f ? -h.y : h.y, dlB.z < 0.0f ? -h.z : h.z));
   } else {
-    const V3 p0 = ld3(SB + 13), p1 = ld3(SB + 16);
+    const V3 p0 = ld3(G.tB_), p1 = ld3(G.hB_);
     const bool far = dot(d, p1 - p0) < 0.0f;
     b = far ? p1 : p0; idb = far ? 1 : 0;
   }
@@ -278,7 +292,9 @@ __device__ __forceinline__ void cvx_face_plane(V3 a, V3 b, V3 c, V3& n, float& d
   const D3 A = d3(a), ab = d3(b) - A, ac = d3(c) - A, x = cross(ab, ac);
   const double l2 = dot(x, x);
   if (l2 > 1e-10 * dot(ab, ab) * dot(ac, ac) && l2 > 1e-60) {
-    const double inv = 1.0 / sqrt(l2);
+    double inv;
+    if (l2 > 1e-30) { const double r = (double)fast_rsqrt((float)l2); inv = r * (1.5 - 0.5 * l2 * r * r); } /* v_rsq_f32 + one Newton step in fp64 (1e-14): fp64 sqrt and division are dozens of instructions each */
+    else inv = 1.0 / sqrt(l2);
     n = v3((float)(x.x * inv), (float)(x.y * inv), (float)(x.z * inv));
     d = (float)(dot(x, A) * inv);
   } else { n = v3(0.0f, 0.0f, 1.0f); d = 1e30f; }
@@ -298,6 +314,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   GQ_CVX_T0();
   const CvxCaps caps = cvx_caps_fetch(SA, SB, vx, vy, vz);
+  const CvxRegs G = cvx_regs(SA, SB);
   /* ---- GJK */
   V3 v;
   float lam[4] = {1.0f, 0.0f, 0.0f, 0.0f};
@@ -307,7 +324,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
             (uniform(((LdsCI)SA)[0]) == 2 ? 0.5f * (ld3(SA + 13) + ld3(SA + 16)) : ld3(SA + 13));
     if (dot(hint, hint) > 0.0f) d0 = hint; /* the caller's first search direction, from A to B (world boxes: out of the box towards the cloud's centre) */
     if (dot(d0, d0) < 1e-24f) d0 = v3(1.0f, 0.0f, 0.0f);
-    const CvxMink s0 = cvx_minkowski(SA, SB, vx, vy, vz, d0, caps);
+    const CvxMink s0 = cvx_minkowski(G, vx, vy, vz, d0, caps);
     v = s0.w;
     if (-dot(v, d0) > reach * fast_sqrt(dot(d0, d0))) return false; /* the first direction already separates the cores by more than reach */
     wave_barrier();
@@ -320,7 +337,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     const float vv = dot(v, v);
     if (vv < 1e-24f) { enclosed = true; break; } /* the origin lies on the simplex: touching cores */
     GQ_CVX_T(0);
-    const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, -1.0f * v, caps);
+    const CvxMink sw = cvx_minkowski(G, vx, vy, vz, -1.0f * v, caps);
     GQ_CVX_T(1);
     const V3 w = sw.w;
     const float vw = dot(v, w);
@@ -396,7 +413,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
       else if (ns == 2) { dir = cross(GQ_CVX_PW(P, 1) - p0, axk); if (tries >= 3 && tries < 6) dir = -1.0f * dir; }
       else { dir = cross(GQ_CVX_PW(P, 1) - p0, GQ_CVX_PW(P, 2) - p0); if (tries & 1) dir = -1.0f * dir; }
       if (dot(dir, dir) < 1e-30f) continue;
-      const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, dir, caps);
+      const CvxMink sw = cvx_minkowski(G, vx, vy, vz, dir, caps);
       const V3 w = sw.w;
       const int wid = sw.id;
       bool dup = false;
@@ -446,7 +463,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     if (eit >= GQ_CVX_EPA_MAXIT || nv >= GQ_CVX_MAXV) break;
     const V3 nb = v3(bcast(fn.x, best), bcast(fn.y, best), bcast(fn.z, best));
     GQ_CVX_T(3);
-    const CvxMink sw = cvx_minkowski(SA, SB, vx, vy, vz, nb, caps);
+    const CvxMink sw = cvx_minkowski(G, vx, vy, vz, nb, caps);
     GQ_CVX_T(1);
     const V3 w = sw.w;
     const int wid = sw.id;

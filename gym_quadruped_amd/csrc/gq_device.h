@@ -70,6 +70,7 @@ __device__ __forceinline__ int shfl_xor(int v, int m) { return __shfl_xor(v, m, 
 
 /* a value the program knows to be wave-uniform but the compiler does not (e.g. read from LDS): v_readfirstlane */
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniformf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 /* read lane `src` (per-lane index) - ds_bpermute_b32 */
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, GQ_WAVE); }
@@ -180,6 +181,7 @@ template <bool PUB, class T> __device__ __forceinline__ T ldv(const T* p) {
   else return *(const GQ_GLOBAL T*)p;
 }
 __device__ __forceinline__ int add_pub(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool cas_pub(int32_t* p, int expect, int v) { return __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void publish_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* compiler: no store sinks below */
   __builtin_amdgcn_s_waitcnt(0x0F70);                    /* vmcnt(0): every store of this wave has reached its L2 / memory */

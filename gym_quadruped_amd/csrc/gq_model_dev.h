@@ -161,6 +161,7 @@ struct GqDevModel {
   GqDevBox box[GQ_MAXBOX];
   /* robot self-collision */
   int32_t nbp, nsp;
+  int32_t ncvx_self;                       /* self pairs that go through the convex routine (kind 4): a batch of such a model gets a pair exchange (gq_exchange.h) */
   int32_t self_cut;                        /* profiling aid (env GQ_SELF_CUT): 1 stop after the end points, 2 after the first pass, 3 no dense / Sherman-Morrison step */
   float self_margin;                       /* largest detection margin among the pairs (broad-phase slack) */
   float body_sph[GQ_NB][4];                /* bounding sphere of the body's proxy capsules: centre (body frame), radius */
@@ -219,6 +220,9 @@ struct GqDevBatch {            /* per-batch constants */
   /* HeightMap that follows the base (gq_batch_set_heightmap; 0 rows: off) */
   int32_t hm_rows, hm_cols;
   float hm_dx, hm_dy;
+  /* convex pair exchange (gq_exchange.h; gq_batch_set_pair_exchange): the batch's table and its number of slots, NULL / 0: none.  Read where
+   * it is used - held in registers across the step it cost the headline kernel 100 bytes of scratch per lane */
+  int32_t* xq; int32_t xq_slots;
   /* in-episode resampling of the velocity command / disturbance wrench (gq_batch_set_resampling; 0 = off) */
   int32_t rs_cmd_reset, rs_dist_reset, rs_env_id_offset;
   int32_t rs_dist_kind[6];
@@ -250,4 +254,8 @@ struct GqDevBatch {            /* per-batch constants */
 #define GQ_DBG_FOOT_POS (GQ_DBG_CON_GEOM + GQ_MAXCON)
 #define GQ_DBG_QACC (GQ_DBG_FOOT_POS + 12)
 #define GQ_DBG_TIMER (GQ_DBG_QACC + 18) /* 16 stage time stamps, shader cycles relative to kernel entry */
-#define GQ_DBG_SIZE (GQ_DBG_TIMER + 32) /* 0-15 stage stamps, 16-23 Newton sub-stage cycle sums */
+#define GQ_DBG_XQ (GQ_DBG_TIMER + 32)   /* 0-15 stage stamps, 16-23 Newton sub-stage cycle sums */
+/* the wave's part in the convex pair exchange (gq_exchange.h), times in 100 MHz ticks & 0xFFFFF like timer[24]: 0 convex pairs past the mid
+ * phase, 1 published, 2 time the pairs were READY, 3 time the pairs kept here were done, 4 time every published pair was DONE, 5 pairs taken
+ * back, 6 pairs computed for others at the convex block, 7 time of the first of them, 8 ticks spent on them, 9 time the lingering ended */
+#define GQ_DBG_SIZE (GQ_DBG_XQ + 16)

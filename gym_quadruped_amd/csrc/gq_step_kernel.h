@@ -64,6 +64,10 @@ struct StepArgs {
   float* heightmap;       /* [N][rows * cols][3] hit points of the HeightMap that follows the base (gq_batch_set_heightmap), may be NULL */
   int32_t n_envs;
 };
+/* layout of the convex pair exchange (gq_exchange.h), int32 words: [slots] state words, then [slots][GQ_XQ_ITEM] items */
+#define GQ_XQ_ITEM 64
+#define GQ_XQ_MARGIN 40
+#define GQ_XQ_RES 48 /* hit, dist, normal (3), point (3) */
 struct StepCall {
   const float* ctrl;    /* [N][nu] or NULL (zero control) */
   const uint8_t* mask;  /* [N] or NULL */

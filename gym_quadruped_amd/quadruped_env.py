@@ -84,6 +84,7 @@ class QuadrupedEnv(AccessorsMixin):
         env_id_offset: int = 0,
         accessors: bool = False,
         self_collision: bool | str | None = None,   # None / True / "convex": MuJoCo's behaviour, mesh pairs through the convex routine; "capsule": capsule proxies for mesh / cylinder pairs (faster, approximate); False: off
+        pair_exchange: bool = True,   # convex self pairs of an entangled env are shared with idle wavefronts of the launch (csrc/gq_exchange.h): same results, shorter launches; False: every env keeps its pairs
     ):
         self._save_hyperparameters(constructor_params=locals().copy())
         log.info(f'Initializing {robot} environment with scene {scene}.')
@@ -207,6 +208,8 @@ class QuadrupedEnv(AccessorsMixin):
         self._hbatch = C.c_void_p()
         _lib.check(L.gq_batch_create(self._hmodel, N, ids.ctypes.data, len(ids), lo.ctypes.data, C.byref(self._hbatch)), 'gq_batch_create')
         assert L.gq_batch_obs_dim(self._hbatch) == self._obs_dim
+        if not pair_exchange and self._mm.self_collision == 'convex':
+            L.gq_batch_set_pair_exchange(self._hbatch, 0)   # (a model without convex self pairs has no exchange to switch off)
         self._st = GqState(self._qpos.data_ptr(), self._qvel.data_ptr(), self._qacc.data_ptr(), self._warm.data_ptr(),
                            self._applied.data_ptr(), self._time.data_ptr(), self._friction.data_ptr(), self._cmd.data_ptr())
         self._out = GqObsOut(self._obs_buf.data_ptr(), self._reward.data_ptr(), self._terminated.data_ptr(),

@@ -60,8 +60,9 @@ extern "C" {
  * GqObsOut.step_num_prev, strided HeightMap views, the round-3 entry points; 400 = the closed-loop persistent rollout
  * (gq_rollout_closed, gq_mailbox_get), GqObsOut.contacts_dropped; 500 = lap-tagged mailbox queue items, gq_struct_sizes(out[8]),
  * GqModelDesc.plane_* (optional); 510 = gq_batch_set_heightmap (no struct changed); 600 = GqModelDesc.vert_adj* / plane_order (hull
- * graphs: multi-point mesh-plane contacts), the general convex narrow phase (GJK / EPA) behind the same tables. */
-#define GQ_ABI_VERSION 600
+ * graphs: multi-point mesh-plane contacts), the general convex narrow phase (GJK / EPA) behind the same tables; 610 = gq_batch_set_pair_exchange
+ * (no struct changed). */
+#define GQ_ABI_VERSION 610
 
 typedef struct GqModelDesc {
   int32_t struct_size; /* = sizeof(GqModelDesc) of the caller's header; gq_model_create refuses any other value */
@@ -323,6 +324,14 @@ int gq_batch_set_imu(GqBatch* b, const GqImuCfg* cfg, float* bias_state);
  * place launches gq_heightmap once for the state it now holds (the Python HeightMap does: it ties the map's freshness to the state tensor's
  * version).  No reference counterpart as a call: the reference casts mj_ray per cell from Python. */
 int gq_batch_set_heightmap(GqBatch* b, int rows, int cols, float dist_x, float dist_y, float* out);
+
+/* The convex pair exchange of a batch (gym_quadruped_amd/csrc/gq_exchange.h): in a full-batch launch (gq_step, the persistent gq_rollout) an env
+ * with several hull pairs in reach hands all but one of them to wavefronts of the same launch that have finished their own env - the launch
+ * no longer lasts as long as its most entangled robot.  Results are bit-identical either way (a pair's contact does not depend on which
+ * wavefront computes it).  On by default for a model with convex self pairs (GqModelDesc.self_convex); on = 0 switches it off (A/B
+ * measurements, tests), on = 1 back on.  Returns GQ_OK, or GQ_EINVAL for a model without such pairs when on = 1.  No reference counterpart
+ * (MuJoCo's narrow phase is serial per mjData). */
+int gq_batch_set_pair_exchange(GqBatch* b, int on);
 
 /* reset configuration: the knobs of QuadrupedEnv.reset / _sample_ref_vel / _set_ground_friction */
 typedef struct GqResetCfg {

@@ -827,6 +827,8 @@ int gqo_test_box_box(const double* ca, const double* Ra, const double* ha, const
 
 /* counters of the convex routine's work (tools/convex_census.py): calls, contacts, GJK iterations, EPA runs, EPA iterations; not thread-safe */
 static long long g_cvx_stat[12];
+static long long g_cvx_hist[2][64]; /* census: calls by GJK iterations / contacts by EPA iterations */
+void gqo_cvx_hist(long long* out, int reset) { if (out) memcpy(out, g_cvx_hist, sizeof g_cvx_hist); if (reset) memset(g_cvx_hist, 0, sizeof g_cvx_hist); }
 void gqo_cvx_stats(long long* out, int reset) { if (out) memcpy(out, g_cvx_stat, sizeof g_cvx_stat); if (reset) memset(g_cvx_stat, 0, sizeof g_cvx_stat); }
 /* test diagnostics (Contact.tiegap): is the contact POINT of a convex pair determined?  Depth and normal of the minimum translation are
  * unique, but where two faces, a face and an edge or two parallel edges meet, every point of their overlap is a valid witness and the
@@ -875,6 +877,7 @@ static int cvx_pair_counted(const Cvx* A, const Cvx* B, double margin, double* d
   long long* s = g_cvx_stat + (self ? 4 : 0);
   s[0] += 1; s[1] += rc; s[2] += it[0]; s[3] += it[1];
   g_cvx_last_queries = 1 + it[0] + it[1];
+  g_cvx_hist[0][it[0] < 63 ? it[0] : 63]++; if (rc && it[1] > 0) g_cvx_hist[1][it[1] < 63 ? it[1] : 63]++;
   g_cvx_capped = rc && (it[1] >= CVX_EPA_MAXIT || it[0] >= CVX_GJK_MAXIT);
   g_cvx_stat[9] += g_cvx_capped;
   return rc;

@@ -23,7 +23,7 @@ _o = 0
 for _name, _n in [('M', 324), ('qfrc_bias', 18), ('qfrc_smooth', 18), ('qacc_smooth', 18), ('qfrc_constraint', 18),
                   ('xpos', 39), ('xmat', 117), ('nefc', 1), ('ncon', 1), ('niter', 1), ('efc_J', 64 * 18),
                   ('efc_aref', 64), ('efc_R', 64), ('efc_b', 64), ('efc_force', 64), ('efc_type', 64),
-                  ('contact_dist', 12), ('contact_geom', 12), ('foot_pos', 12), ('qacc', 18), ('timer', 32)]:
+                  ('contact_dist', 12), ('contact_geom', 12), ('foot_pos', 12), ('qacc', 18), ('timer', 32), ('xq', 16)]:
     DBG[_name] = (_o, _n)
     _o += _n
 DBG_SIZE = _o

@@ -19,6 +19,12 @@ static void emu_fill_cfg(gq::ResetCfgDev* d, const GqResetCfg* cfg) {
   d->env_id_offset = cfg->env_id_offset;
 }
 
+/* the convex pair exchange (gq_exchange.h) under emulation: wavefronts run one after the other, so an owner ends up claiming its own items -
+ * every queue operation is exercised, concurrency is not (tests/test_gpu_parity.py compares exchange on / off on the device) */
+static int g_emu_xq_on = 0;
+extern "C" void emu_set_exchange(int on) { g_emu_xq_on = on; }
+extern "C" void emu_exchange_stats(int* out) { out[0] = gq::g_emu_cas_ok; out[1] = out[2] = out[3] = 0; }
+
 /* same control flow as gq::step_kernel (csrc/gq_kernels.hip) */
 extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_ids, int n_obs, const int32_t* legs_order,
                         const float* ctrl, const uint8_t* mask, double* qpos, float* qvel, float* qacc, float* warm,
@@ -49,6 +55,12 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
   gq::StepCall call{};
   call.ctrl = ctrl; call.mask = mask; call.debug = debug;
   call.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; call.first_pass = first_pass;
+  static std::vector<int32_t> xq;
+  if (g_emu_xq_on && M.ncvx_self > 0) {
+    const int slots = 256;
+    if (xq.empty()) xq.assign((size_t)slots * (1 + GQ_XQ_ITEM), 0);
+    B.xq = xq.data(); B.xq_slots = slots;
+  }
   if (auto_reset) {
     gq::ResetArgs& r = f.r;
     r.model = &M; r.vx = vx.data(); r.vy = vy.data(); r.vz = vz.data();
@@ -87,6 +99,12 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
         else term = M.cone ? gq::step_wave<1, 1, true, false, false, true>(f.s, call, W, pass, hint, C) : gq::step_wave<1, 1, false, false, false, true>(f.s, call, W, pass, hint, C);
         if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
+      }
+      if (B.xq && self) { /* as step_kernel's tail */
+        gq::wave_barrier();
+        using namespace gq;
+        Xq X; X.q = B.xq; X.slots = B.xq_slots;
+        xq_help(X, e, GQ_CVX_SHP(W), GQ_CVX_POLY_SELF(W), f.s.vx, f.s.vy, f.s.vz);
       }
     });
   }

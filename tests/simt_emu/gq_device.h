@@ -53,6 +53,7 @@ static inline int shfl_xor(int v, int m) { const uint32_t* s = exchange((uint32_
 static inline float shfl_idx(float v, int src) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r; memcpy(&r, &s[src & 63], 4); return r; }
 static inline int shfl_idx(int v, int src) { const uint32_t* s = exchange((uint32_t)v); return (int)s[src & 63]; }
 static inline int uniform(int v) { return v; }
+static inline float uniformf(float v) { return v; }
 static inline uint64_t ballot(bool p) { const uint32_t* s = exchange(p ? 1u : 0u); uint64_t m = 0; for (int i = 0; i < 64; i++) m |= (uint64_t)(s[i] & 1) << i; return m; }
 static inline float wave_sum(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = 0; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r += t; } return r; }
 static inline float wave_min(float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t* s = exchange(u); float r = INFINITY; for (int i = 0; i < 64; i++) { float t; memcpy(&t, &s[i], 4); r = std::min(r, t); } return r; }
@@ -73,9 +74,14 @@ static inline int ld_pub(const int32_t* p) { return *p; }
 static inline float ld_pub(const float* p) { return *p; }
 static inline void st_pub(int32_t* p, int v) { *p = v; }
 static inline void st_pub(float* p, float v) { *p = v; }
+static inline int add_pub(int32_t* p, int v) { const int o = *p; *p = o + v; return o; }
+inline int g_emu_cas_ok = 0; /* successful compare-and-swaps (the pair exchange: reservations + claims) */
+static inline bool cas_pub(int32_t* p, int expect, int v) { if (*p != expect) return false; *p = v; g_emu_cas_ok++; return true; }
+static inline void publish_fence() {}
+static inline void nap() {}
 static inline void sched_fence() {}
 static inline long long cycles() { return 0; }
-static inline long long wall_clock64() { return 0; }
+static inline long long wall_clock64() { static long long t = 0; return t += 100; } /* a microsecond per look: the pair exchange's waits (gq_exchange.h) end */
 static inline void wave_priority(int) {}
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }

@@ -995,3 +995,29 @@ def test_step_parity_on_benchmark_rollout_states(robot, scene):
     # measured on MI355X (profiles/r03_parity_tallies.txt): 0 of 160 over the row budget for every robot on flat; ties only on
     # hull robots.  A regression that drops contacts shows up as budget / mismatch counts far above these bounds.
     tally.finish(f'benchmark-state one-step parity {robot} {scene}', min_checked=0.85, max_tie=0.12, max_budget=0.03)
+
+
+@pytest.mark.parametrize('mode', ['step', 'rollout'])
+def test_pair_exchange_is_bit_identical(mode):
+    """The convex pair exchange (csrc/gq_exchange.h): wavefronts of one launch compute each other's hull pairs.  4096 mini_cheetah envs under
+    random torques without auto-reset - robots fall, fold up and stay that way: the state distribution with the most entangled envs -
+    stepped with the exchange on and off end in bit-identical states, through the step loop and through the persistent rollout (one launch:
+    slots are reserved, freed and reused step after step).  The heavy launches also have to END: nothing in the protocol may wait for ever."""
+    n, steps = 4096, 300
+    g = torch.Generator(device='cuda:0').manual_seed(5)
+    acts = torch.randn(steps, n, 12, generator=g, device='cuda:0') * 40
+    out = []
+    for on in (True, False):
+        env = _make_env(n, obs=('qpos', 'qvel'), iters=100, tol=1e-8, solver='newton', auto_reset=False, pair_exchange=on)
+        assert env._mm.self_collision == 'convex'
+        env.reset(random=True)
+        if mode == 'step':
+            for k in range(steps):
+                env.step(acts[k])
+        else:
+            env.rollout(acts, shards=0)
+        torch.cuda.synchronize()
+        out.append((env.qpos.clone(), env.qvel.clone(), env._contacts_dropped.clone()))
+        env.close()
+    assert torch.isfinite(out[0][0]).all()
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])

@@ -1,6 +1,7 @@
 """The UNMODIFIED HIP kernel bodies (csrc/gq_step_body.h) executed by the host SIMT emulator (tests/simt_emu) against
 the CPU oracle: same parity contract as tests/test_gpu_parity.py, runnable without a GPU."""
 from pathlib import Path
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -858,3 +859,36 @@ def test_capsule_proxy_mode_matches_oracle():
         np.testing.assert_allclose(dbg(rec, 'efc_J').reshape(64, 18)[:ne], o.efc_J, rtol=2e-4, atol=2e-5)
         assert np.abs(dbg(rec, 'qacc') - o.qacc).max() < 2e-4 * max(1.0, np.abs(o.qacc).max())
     assert nchecked >= n // 2
+
+
+@pytest.mark.parametrize('robot', ['mini_cheetah', 'hyqreal1'])
+def test_pair_exchange_changes_nothing(robot):
+    """The convex pair exchange (csrc/gq_exchange.h): an env with several hull pairs in reach probes them, publishes all but the first
+    undecided one to the batch's queue, claims items back and collects the results - the step it produces is bit-identical to the one
+    without the exchange, and items do pass through the queue.  (Under emulation the wavefronts run one after the other: the owner claims
+    its own items - every queue operation, no concurrency; the device test in test_gpu_parity.py covers that.)"""
+    from helpers import emu_lib
+    n = 12
+    mm = marshalled(robot, solver=1, iterations=100, tolerance=1e-10, noise_floor=0.0)
+    o = Oracle(marshalled(robot, solver=1, iterations=100, tolerance=1e-12))
+    rng = np.random.default_rng(11)
+    qpos, qvel = self_contact_states(mm.md, n, rng, o, want_cross=True)
+    qvel = qvel.astype(np.float32)
+    ctrl = (rng.normal(0, 1, (n, 12)) * 20).astype(np.float32)
+    L = emu_lib()
+    L.emu_set_exchange(0)
+    a = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), debug_envs=n)
+    stats0 = (C.c_int * 4)(); L.emu_exchange_stats(stats0)
+    L.emu_set_exchange(1)
+    try:
+        b = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), debug_envs=n)
+        c = emu_step(mm, ctrl, qpos.copy(), qvel.copy(), debug_envs=n)   # a second launch: the last leaver rewound the queue, new epoch
+    finally:
+        L.emu_set_exchange(0)
+    stats = (C.c_int * 4)(); L.emu_exchange_stats(stats)
+    assert stats[0] - stats0[0] > 0, 'no env published a pair: the test does not reach the exchange'
+    for k in ('qpos', 'qvel', 'warm', 'obs'):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+    for e in range(n):
+        for f in ('ncon', 'nefc', 'efc_J', 'efc_aref', 'contact_dist', 'contact_geom', 'qacc'):
+            assert np.array_equal(dbg(a['debug'][e], f), dbg(b['debug'][e], f)), (e, f)

@@ -57,6 +57,12 @@ def main(robot='mini_cheetah', n_envs=48, n_steps=250, boxes=None):
     for name, s in (("world boxes", stats[:4]), ("self pairs", stats[4:8])):
         calls = max(int(s[0]), 1)
         print(f'  {name}: convex calls / step {s[0] / nsteps:.3f}, contacts / call {s[1] / calls:.3f}, GJK its / call {s[2] / calls:.2f}, EPA its / contact {s[3] / max(int(s[1]), 1):.2f}')
+    hist = np.zeros((2, 64), dtype=np.int64)
+    L.gqo_cvx_hist.argtypes = [C.c_void_p, C.c_int]
+    L.gqo_cvx_hist(hist.ctypes.data_as(C.c_void_p), 1)
+    for nm, h in (('GJK iterations per call', hist[0]), ('EPA iterations per contact', hist[1])):
+        tot = max(int(h.sum()), 1); cum = np.cumsum(h[::-1])[::-1]
+        print(f'  {nm}: ' + ' '.join(f'>={k}:{100.0 * cum[k] / tot:.1f}%' for k in (1, 2, 4, 6, 8, 12, 16, 20, 24, 32) if cum[k]) + f'  max {np.nonzero(h)[0].max() if h.sum() else 0}')
     print(f'  convex contacts that ran into an iteration cap: {stats[9]} of {stats[1] + stats[5]}')
     cs = np.cumsum(call_hist[::-1])[::-1] / call_hist.sum()
     print('  convex calls per env-step: ' + ' '.join(f'>={k}:{100 * cs[k]:.2f}%' for k in (1, 2, 3, 4, 6, 8, 12) if cs[k] > 0))

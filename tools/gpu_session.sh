@@ -48,7 +48,7 @@ for p in $PARTS; do
             timeout 600 python tools/stage_cuts.py 4096 aliengo > $OUT/stage_cuts4096_aliengo.txt 2>&1
             timeout 900 python tools/niter_hist.py mini_cheetah aliengo go2 hyqreal1 go1 b2 2>&1 | grep -v amdgpu.ids > $OUT/niter_hist.txt
             (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o /tmp/fma_issue fma_issue.hip && /tmp/fma_issue) > $OUT/ubench_fma_issue.txt 2>&1;;
-    convex) (hipcc --offload-arch=gfx950 -O3 -std=c++17 -Igym_quadruped_amd/csrc -Iinclude -DGQ_CVX_STATS -o /tmp/convex_pair tools/ubench/convex_pair.hip && /tmp/convex_pair) > $OUT/ubench_convex_pair.txt 2>&1;;
+    convex) (hipcc --offload-arch=gfx950 -O3 -std=c++17 -Igym_quadruped_amd/csrc -Iinclude -DGQ_CVX_STATS -Wno-unused-result -o /tmp/convex_pair tools/ubench/convex_pair.hip 2>/dev/null && /tmp/convex_pair) > $OUT/ubench_convex_pair.txt 2>&1;;
     nscan) timeout 900 python tools/nscan.py > $OUT/nscan.txt 2>&1;;
     profiles) timeout 1500 bash tools/run_profiles.sh $TAG pmc > $OUT/run_profiles.txt 2>&1
               timeout 600 bash tools/run_profiles.sh ${TAG}_noself nopmc --no-self-collision >> $OUT/run_profiles.txt 2>&1

@@ -32,11 +32,12 @@ __global__ void __launch_bounds__(64) k_pieces(const float* vx, const float* vy,
   if (lane < 2 * GQ_CVX_SHAPE_WORDS) shp[lane] = shapes[lane];
   __syncthreads();
   const gq::CvxCaps caps = gq::cvx_caps_fetch((gq::LdsCF)shp, (gq::LdsCF)(shp + 20), (const GQ_MODEL float*)vx, (const GQ_MODEL float*)vy, (const GQ_MODEL float*)vz);
+  const gq::CvxRegs G = gq::cvx_regs((gq::LdsCF)shp, (gq::LdsCF)(shp + 20));
   gq::V3 d = gq::v3(0.3f, 0.2f, 1.0f);
   long long t0 = __builtin_readcyclecounter();
 #pragma unroll 1
   for (int k = 0; k < 64; k++) {
-    const gq::CvxMink m = gq::cvx_minkowski((gq::LdsCF)shp, (gq::LdsCF)(shp + 20), (const GQ_MODEL float*)vx, (const GQ_MODEL float*)vy, (const GQ_MODEL float*)vz, d, caps);
+    const gq::CvxMink m = gq::cvx_minkowski(G, (const GQ_MODEL float*)vx, (const GQ_MODEL float*)vy, (const GQ_MODEL float*)vz, d, caps);
     d = gq::v3(m.w.y + 0.1f, m.w.z - 0.3f, m.w.x + 0.2f);
   }
   long long t1 = __builtin_readcyclecounter();

@@ -18,7 +18,7 @@ for i in range(300): env.step(torch.randn(n, 12, generator=g, device='cuda') * 5
 env.enable_debug(n)
 pend = env._terminated.clone().cpu().numpy().astype(bool) if hasattr(env, '_terminated') else np.zeros(n, bool)
 env.step(torch.randn(n, 12, generator=g, device='cuda') * 50); torch.cuda.synchronize()
-d = env.debug_internals(n, ['timer', 'niter', 'nefc'])
+d = env.debug_internals(n, ['timer', 'niter', 'nefc', 'xq'])
 T = np.stack([x['timer'] for x in d]); nit = np.array([x['niter'][0] for x in d]).astype(int)
 t0 = T[:, 24]; t1 = T[:, 25]
 base = t0.min()
@@ -42,11 +42,25 @@ for nm, sel in (('no robot-robot contact', (ns == 0) & ~pend), ('robot-robot con
     if sel.sum(): print(f'  {nm:50s}: {sel.sum():5d} waves, niter mean {nit[sel].mean():.2f} max {nit[sel].max()}, lifetime mean {dur[sel].mean():6.1f} p99 {np.percentile(dur[sel], 99):6.1f} max {dur[sel].max():6.1f} us, end max {t1[sel].max():6.1f}')
 busy = np.array([((t0 <= t) & (t1 > t)).sum() for t in np.arange(0, t1.max(), 2.0)])
 print('resident waves every 2 us:', busy.tolist())
+# the convex pair exchange as each wave saw it (debug record 'xq', csrc/gq_model_dev.h GQ_DBG_XQ)
+XQ = np.stack([x['xq'] for x in d])
+rel = lambda col: ((XQ[:, col] - (T[:, 24] - 0)) % (1 << 20)) / 100.0      # us since the wave's start
+own = XQ[:, 1] > 0; hlp = XQ[:, 6] > 0; lin = (XQ[:, 9] > 0)
+if own.sum():
+    print(f'pair exchange: {int((XQ[:, 0] > 0).sum())} envs with convex pairs past the mid phase ({XQ[:, 0].sum():.0f} pairs, max {XQ[:, 0].max():.0f}), {own.sum()} of them published {XQ[own, 1].sum():.0f} (max {XQ[own, 1].max():.0f}), took back {XQ[own, 5].sum():.0f};')
+    print(f'  owners, us since their start: pairs READY p50 {np.median(rel(2)[own]):.1f} p99 {np.percentile(rel(2)[own], 99):.1f}; own pairs done p50 {np.median(rel(3)[own]):.1f} p99 {np.percentile(rel(3)[own], 99):.1f}; all DONE p50 {np.median(rel(4)[own]):.1f} p90 {np.percentile(rel(4)[own], 90):.1f} p99 {np.percentile(rel(4)[own], 99):.1f} max {rel(4)[own].max():.1f}')
+if hlp.sum():
+    per = XQ[hlp, 8] / np.maximum(XQ[hlp, 6], 1) / 100.0
+    print(f'  {lin.sum()} envs lingered at the convex block (end p50 {np.median(rel(9)[lin]):.1f} p99 {np.percentile(rel(9)[lin], 99):.1f} us since start); {hlp.sum()} of them computed {XQ[hlp, 6].sum():.0f} pairs for others (max {XQ[hlp, 6].max():.0f}), first claim p50 {np.median(rel(7)[hlp]):.1f} p99 {np.percentile(rel(7)[hlp], 99):.1f} us; us per pair p50 {np.median(per):.1f} p90 {np.percentile(per, 90):.1f} max {per.max():.1f}')
 last = np.argsort(-t1)[:12]
 print('last waves to finish (end us | start | niter nefc pending | co-resident waves on the SIMD: their niter):')
 for e in last:
     co = np.where(slot == slot[e])[0]
     print(f'  env {e:5d}: {t1[e]:6.1f} | {t0[e]:5.1f} | {nit[e]} {int(d[e]["nefc"][0]):2d} {int(pend[e])} hint {hint[e]} self {int(T[e, 31])} | ' + ' '.join(f'{nit[c]}{"r" if pend[c] else ""}h{hint[c]}@{t1[c]:.0f}' for c in co if c != e))
+    # stage ends of this wave in us from its start (stage stamps are shader cycles; scaled by the wave's own wall time / cycle count)
+    sc = (t1[e] - t0[e]) / max(T[e, 13], 1.0)
+    print(f'             exchange: pairs {XQ[e, 0]:.0f} published {XQ[e, 1]:.0f} READY@{rel(2)[e] if XQ[e, 1] else 0:.0f} own done@{rel(3)[e] if XQ[e, 1] else 0:.0f} all DONE@{rel(4)[e] if XQ[e, 1] else 0:.0f} back {XQ[e, 5]:.0f} | helped {XQ[e, 6]:.0f} first@{rel(7)[e] if XQ[e, 6] else 0:.0f} us spent {XQ[e, 8] / 100:.0f} linger end@{rel(9)[e] if XQ[e, 9] else 0:.0f}')
+    print('             stage ends (us from wave start): ' + ' '.join(f'{nm} {T[e, k] * sc:.0f}' for nm, k in (('kin', 5), ('floor', 14), ('collide', 6), ('rows', 7), ('pre', 8), ('solve', 9), ('euler', 10), ('integ', 11), ('obs', 12), ('end', 13))))
 
 # the launch's tail as one number (bench.py roofline.tail replays it from profiles/latest_tail.json, with the kernel-source hash it was taken on):
 # the share of the launch during which the median wave has already finished, instrumented variant, one launch of the headline workload
