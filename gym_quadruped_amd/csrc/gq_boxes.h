@@ -726,6 +726,13 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
   const int lane = lane_id();
   const int nsp = K.nsp;
   if (nsp == 0) return;
+#ifdef GQ_XQ_OFF /* experiment builds: the pair exchange compiled out */
+  int32_t* const xq_tab = nullptr; const int xq_slots = 0; const int xq_act = 0; (void)Bt;
+#else
+  int32_t* const xq_tab = Bt.xq; const int xq_slots = Bt.xq_slots; /* (fetched here: the scalar loads return behind the end points and the pair cull) */
+  int xq_act = 0; /* the time word of this wavefront's window, fetched here (lane 31's word of a whole-window load would do: one word is enough) so that its latency passes behind the end points and the pair cull */
+  if (xq_tab) { Xq X0; X0.q = xq_tab; X0.slots = xq_slots; xq_act = ld_pub(xq_time_word(X0, xq_window(X0, wave_index()))); }
+#endif
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   /* world end points of every item's proxy capsule, once: lane = collision item; scratch in the J block, which is free
    * until S7 (the spatial-dynamics scratch it overlays is dead since S5) */
@@ -798,7 +805,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     ncand += popc64(cm);
   }
   GQ_SUB(W, 1, 11); /* pair cull */
-  if (K.self_cut == 2 || (ncand == 0 && Bt.xq == nullptr)) return;
+  if (K.self_cut == 2 || (ncand == 0 && (xq_tab == nullptr || !xq_is_hot(xq_act, wall_clock64())))) return;
   if (ncand > 2 * GQ_WAVE) ncand = 2 * GQ_WAVE; /* more than 128 close pairs: the robot is a knot; the row budget is long spent */
   wave_barrier();
   const int npass = ncand > 0 ? ncand : 1; /* (a batch with a pair exchange: an env without a candidate still passes by the convex block once - it may have time for others, gq_exchange.h) */
@@ -873,14 +880,13 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
       uint64_t cm = ballot(cvx);
       if (K.self_cut == 5) cm = 0;        /* profiling aid: the mid phase without the convex routine */
       if (K.self_cut == 6) cm &= cm - 1;  /* ... and without the first pair that reaches it */
-      Xq X; X.q = Bt.xq; X.slots = Bt.xq_slots;
+      Xq X; X.q = xq_tab; X.slots = xq_slots;
       uint64_t local = cm, own = 0; /* pairs to run here / published */
       int myslot = -1;              /* lane = pair: the slot it reserved */
-      long long t_wait = -1;
       /* an env without convex work of its own has 40 us to spare before the launch's entangled envs are through: it lingers here for a few
        * microseconds - if its group of the table has seen pairs lately - and takes what gets published meanwhile */
-      bool linger = X.q != nullptr && cm == 0 && c0 + GQ_WAVE >= npass;
-      long long t_linger = -1;
+      bool linger = X.q != nullptr && cm == 0 && c0 + GQ_WAVE >= npass && xq_is_hot(xq_act, wall_clock64());
+      int t_ref = 0; bool t_set = false; /* start of the wait in progress, 100 MHz ticks (low word): an owner's deadline or the lingering */
 #define GQ_XSTAT(i, v) do { if (xdbg && lane == 0) xdbg[i] = (float)(v); } while (0)
 #define GQ_XTIME(i) GQ_XSTAT(i, wall_clock64() & 0xFFFFF)
       int x_back = 0, x_help = 0; long long x_ticks = 0, x_t0 = 0; bool x_ld = false;
@@ -900,7 +906,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
           xq_put(X, sj, GQ_CVX_SHP(W), m.sp[pj].mix.margin);
         }
         publish_fence();
-        if (myslot >= 0) xq_ready(X, myslot);
+        if (myslot >= 0) { xq_ready(X, myslot); xq_mark_active(X, myslot); }
         GQ_XSTAT(1, popc64(own)); GQ_XTIME(2);
       }
 #pragma unroll 1
@@ -917,28 +923,21 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
             if (!xq_claim(X, slot)) continue; /* a helper was faster */
             j = -1; x_back++;
           } else if (busy) {
-            if (t_wait < 0) t_wait = wall_clock64();
-            if (wall_clock64() - t_wait < GQ_XQ_OWNER_TICKS) { nap(); continue; }
+            if (!t_set) { t_ref = (int)wall_clock64(); t_set = true; }
+            if ((int)wall_clock64() - t_ref < GQ_XQ_OWNER_TICKS) { nap(); continue; }
             /* (never seen) a helper holds the pair for milliseconds: compute it here; its slot is left behind, results are not read from it */
             j = ffs64(busy);
             own &= ~(1ull << j);
             if (lane == j) myslot = -1;
           } else break; /* all DONE */
         } else if (linger) {
-          int hot;
-          slot = xq_scan(X, wave_index(), hot);
+          if (!t_set) { t_ref = (int)wall_clock64(); t_set = true; }
+          slot = xq_scan(X, wave_index());
           if (slot >= 0) {
             if (!xq_claim(X, slot)) continue;
             if (xdbg) { if (x_help == 0) GQ_XTIME(7); x_help++; x_t0 = wall_clock64(); }
-            xq_mark_hot(X, wave_index());
-            if (t_linger < 0) t_linger = wall_clock64();
           } else {
-            const long long now = wall_clock64();
-            if (t_linger < 0) { /* first look: nothing there - stay only if the group was busy within the last millisecond */
-              t_linger = now;
-              if (!xq_is_hot(hot, now)) break;
-            }
-            if (now - t_linger > GQ_XQ_LINGER_TICKS) break;
+            if ((int)wall_clock64() - t_ref > GQ_XQ_LINGER_TICKS) break;
             nap();
             continue;
           }
@@ -959,7 +958,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         } else {
           wave_barrier(); xq_done(X, slot, hit, out);
           if (xdbg && linger) x_ticks += wall_clock64() - x_t0;
-          if (linger && wall_clock64() - t_linger > GQ_XQ_LINGER_TICKS) linger = false;
+          if (linger && (int)wall_clock64() - t_ref > GQ_XQ_LINGER_TICKS) linger = false;
         }
       }
       if (xdbg) { if (own) { GQ_XTIME(4); GQ_XSTAT(5, x_back); } if (x_help) { GQ_XSTAT(6, x_help); GQ_XSTAT(8, x_ticks); } if (cm == 0 && X.q) GQ_XTIME(9); }

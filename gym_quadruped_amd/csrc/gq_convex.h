@@ -509,21 +509,25 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
       const int e = RIM[rank];
       ea = e & 0xff; eb = (e >> 8) & 0xff; eg = (e >> 16) & 0xff;
     }
-    wave_barrier();
-    if (take) RIM[rank] = ea | (eb << 8) | (eg << 16) | (lane << 24);
     const int gfv = shfl_idx(fv, take ? eg : lane); /* the face behind the rim edge: its vertices (it is not in the patch: its lane keeps them) */
+    /* the fan's own neighbours: the new face whose rim edge starts where this one's ends, and the one whose edge ends where this one's
+     * starts - first match in rim order = lane order of the taking lanes (v_readlane per rim edge: the loop over the LDS list it replaces
+     * was a dependent LDS read per edge) */
+    int n1 = lane, n2 = lane;
+    {
+      bool s1 = false, s2 = false;
+      for (uint64_t tm = ballot(take); tm;) { /* wave-uniform */
+        const int src = ffs64(tm); tm &= tm - 1;
+        const int ka = bcast(ea, src), kb = bcast(eb, src);
+        if (!s1 && ka == eb) { n1 = src; s1 = true; }
+        if (!s2 && kb == ea) { n2 = src; s2 = true; }
+      }
+    }
     wave_barrier();
     if (take) {
       fv = ea | (eb << 8) | (nv << 16);
       cvx_face_plane(GQ_CVX_PW(P, ea), GQ_CVX_PW(P, eb), w, fn, fd);
       alive = true;
-      int n1 = lane, n2 = lane;
-      bool s1 = false, s2 = false;
-      for (int k = 0; k < nh; k++) { /* (per-lane trip count is wave-uniform; no cross-lane primitive inside) */
-        const int e = RIM[k], ka = e & 0xff, kb = (e >> 8) & 0xff, ks = (e >> 24) & 0xff;
-        if (!s1 && ka == eb) { n1 = ks; s1 = true; }
-        if (!s2 && kb == ea) { n2 = ks; s2 = true; }
-      }
       ADJ[lane] = eg | (n1 << 8) | (n2 << 16);
       /* the face behind the rim edge now borders this one: its edge b -> a */
       const int g0 = gfv & 0xff, g1 = (gfv >> 8) & 0xff, g2 = (gfv >> 16) & 0xff;

@@ -105,11 +105,6 @@ __global__ void __launch_bounds__(GQ_WAVE * GQ_WPB, 4) step_kernel(const FusedAr
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); /* the next step reads the rows this one stored (same wave, same addresses) */
   wave_barrier();
   }
-  if constexpr (SELF) if (mptr(A->s.batch)->xq) { /* the env's rows are stored: lend a hand with the convex pairs other envs have published (gq_exchange.h) */
-    wave_barrier();
-    Xq X; X.q = mptr(A->s.batch)->xq; X.slots = mptr(A->s.batch)->xq_slots;
-    xq_help(X, env, GQ_CVX_SHP(W), GQ_CVX_POLY_SELF(W), mptr(A->s.vx), mptr(A->s.vy), mptr(A->s.vz));
-  }
 }
 
 /* Closed-loop persistent rollout, the stepping side (protocol: gq_step_kernel.h MailboxDev).  grid = any number of one-wave workgroups:

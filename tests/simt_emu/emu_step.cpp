@@ -100,12 +100,6 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
         if (pass != 0 || call.auto_reset != 1 || !term) break;
         respawn = true;
       }
-      if (B.xq && self) { /* as step_kernel's tail */
-        gq::wave_barrier();
-        using namespace gq;
-        Xq X; X.q = B.xq; X.slots = B.xq_slots;
-        xq_help(X, e, GQ_CVX_SHP(W), GQ_CVX_POLY_SELF(W), f.s.vx, f.s.vy, f.s.vz);
-      }
     });
   }
   return B.obs_dim;

@@ -311,14 +311,15 @@ def test_plane_support_tables_never_hide_the_support_vertex(robot):
     """cabi.plane_support_tables (the optional GqModelDesc.plane_* acceleration structure of the hull-versus-plane narrow phase): the
     direction-ordered copy of every cloud holds the same vertices, and for 20 000 random directions per hull the chunk of the support
     vertex (brute force over the whole cloud) is in the mask of the direction's cube-map cell - a missing bit would be a missed
-    contact.  Also: the masks do prune (fewer than half of the chunks on average) and directions on cell borders / cube edges
+    contact - and in the chunks its caps keep (the convex routine's selection).  Also: the masks do prune (fewer than half of the chunks on average) and directions on cell borders / cube edges
     (where the kernel's fp32 cell index may differ from this f64 one) are covered by both neighbours."""
     from gym_quadruped_amd.cabi import PLANE_GRID, plane_cell_of, plane_support_tables
     from gym_quadruped_amd.mjcf import load_compiled
     from gym_quadruped_amd.robot_cfgs import get_robot_config
     md = load_compiled(Path(get_robot_config(robot).mjcf_filename).stem)
-    pv, pm, _, _ = plane_support_tables(md)
+    pv, pm, _, caps = plane_support_tables(md)
     assert pv.shape == np.asarray(md.vert_pos).shape and pm.shape == (len(md.cloud_vertnum), 6 * PLANE_GRID ** 2)
+    cap_kept = cap_chunks = 0
     rng = np.random.default_rng(4)
     seen = 0
     for cl in range(len(md.cloud_vertnum)):
@@ -339,6 +340,18 @@ def test_plane_support_tables_never_hide_the_support_vertex(robot):
         dirs[:4000] = snap
         dirs /= np.linalg.norm(dirs, axis=1)[:, None]
         kept = 0
+        # the chunks' caps (the convex routine picks the chunks of a support query by them, csrc/gq_convex.h cvx_minkowski: kept when
+        # cos(direction, axis) >= cosine - 1e-4): the support vertex's chunk is kept, or an exact tie in a kept one takes its place
+        D = V @ dirs.T                                                  # [vertex][direction]
+        sup_all = D.argmax(0)
+        keep = (caps[cl, :nch, :3] @ dirs.T >= caps[cl, :nch, 3][:, None] - 1e-4)   # [chunk][direction]
+        assert keep.any(0).all()
+        miss = np.nonzero(~keep[sup_all // 64, np.arange(len(dirs))])[0]
+        for i in miss:
+            best = max(D[64 * q:64 * q + 64, i].max() for q in range(nch) if keep[q, i])
+            assert best >= D[sup_all[i], i] - 1e-12, (robot, cl, dirs[i])
+        if nch >= 5:   # (a cloud of two to four chunks has little to prune)
+            cap_kept += keep.sum() / len(dirs); cap_chunks += nch
         for d in dirs:
             depth = V @ d
             sup = int(np.argmax(depth))
@@ -352,6 +365,7 @@ def test_plane_support_tables_never_hide_the_support_vertex(robot):
                     assert best >= depth[sup] - 1e-12, (robot, cl, d)
         assert kept / len(dirs) < (0.5 * nch if nch >= 4 else nch)   # (a cloud of two or three chunks has little to prune)
     assert seen >= 1
+    assert cap_chunks == 0 or cap_kept < 0.5 * cap_chunks, (cap_kept, cap_chunks)   # the caps do prune (patch-ordered chunks: rounds 4 - 5's cell-ordered strips kept 5 of 8)
 
 
 def test_product_library_reads_no_environment_variable():

@@ -1,13 +1,11 @@
 #!/bin/bash
-# A/B/C... of several libgq builds in one GPU session (interleaved rounds): tools/ab_multi.sh "<lib1> <lib2> ..." [bench args...]
-# Each lib is first held to the benchmark-state parity test (0 mismatches against the oracle), then timed.
+# A/B/C... of several development builds of libgq (tools/dev_build.sh -> ab/*.so) in one GPU session, interleaved, 2 rounds.
+# Usage: tools/ab_multi.sh "<lib1.so lib2.so ...>" "<bench args of case 1>" ["<bench args of case 2>" ...]
 LIBS=$1; shift
-ROOT=${GRAFT_REPO_ROOT:-$PWD}
-for lib in $LIBS; do
-  GQ_TALLY_FILE=/dev/null GQ_LIBGQ_PATH=$ROOT/ab/$lib.so timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "benchmark_rollout_states and mini_cheetah" 2>&1 | tail -1 | sed "s/^/parity $lib: /"
-done
-for round in 1 2 3; do
-  for lib in $LIBS; do
-    GQ_LIBGQ_PATH=$ROOT/ab/$lib.so timeout 300 python bench.py --no-cpu-baseline --no-secondary --steps 1500 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', '$*', round(d['value']/1e6,2), 'M', round(d['roofline']['kernel_ms']*1e3,1), 'us')"
+for round in 1 2; do
+  for args in "$@"; do
+    for lib in $LIBS; do
+      GQ_LIBGQ_PATH=$PWD/$lib python bench.py --no-cpu-baseline --no-secondary --steps 1000 $args 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', '[$args]', round(d['value']/1e6,2), 'M', round(d['roofline']['kernel_ms']*1e3,1), 'us')"
+    done
   done
 done
