@@ -12,7 +12,7 @@ import numpy as np
 from .mjcf import ModelDesc
 
 GQ_NLEG = 4
-GQ_ABI_VERSION = 610   # include/gq.h
+GQ_ABI_VERSION = 620   # include/gq.h
 # optional extra output rows of the step kernel (include/gq.h gq_batch_set_outputs)
 GQ_DYN = dict(MC=0, MB=108, BIAS=144, XPOS=162, XMAT=201, FOOT=318, STRIDE=336)
 GQ_CON_MAX, GQ_CON_REC = 12, 24
@@ -57,7 +57,7 @@ class GqModelDesc(C.Structure):
         ('hfield_condim', C.c_int32), ('hfield_priority', C.c_int32),
         ('nselfpair', C.c_int32), ('selfpair_geom1', _I), ('selfpair_geom2', _I), ('geom_capsule', _D), ('geom_type', _I),
         ('plane_grid', C.c_int32), ('plane_vert_pos', _D), ('plane_mask', _I),
-        ('nadj', C.c_int32), ('vert_adjadr', _I), ('vert_adjnum', _I), ('vert_adj', _I), ('plane_order', _I), ('plane_cap', _D), ('self_convex', C.c_int32),
+        ('nadj', C.c_int32), ('vert_adjadr', _I), ('vert_adjnum', _I), ('vert_adj', _I), ('plane_order', _I), ('plane_cap', _D), ('support_grid', _D), ('self_convex', C.c_int32),
     ]
 
 
@@ -215,6 +215,37 @@ def plane_support_tables(md: ModelDesc, grid=PLANE_GRID, chunk=64, wide_deg=45.0
     if key not in _PLANE_CACHE:
         _PLANE_CACHE[key] = _plane_support_tables(md, grid, chunk, wide_deg, slack)
     return _PLANE_CACHE[key]
+
+
+SUPPORT_GRID = 8   # cells per edge of a cube-map face (include/gq.h GqModelDesc.support_grid: 9 x 9 nodes per face)
+
+
+def support_grid_nodes(grid=SUPPORT_GRID):
+    """The 6 * (grid + 1)^2 node directions of GqModelDesc.support_grid, NOT normalised: face f of +x, -x, +y, -y, +z, -z, node (i, j)."""
+    t = -1.0 + 2.0 * np.arange(grid + 1) / grid
+    U = np.zeros((6, grid + 1, grid + 1, 3))
+    for f in range(6):
+        major, sign = f // 2, 1.0 - 2.0 * (f % 2)
+        oa, ob = [k for k in range(3) if k != major]
+        U[f, :, :, major] = sign
+        U[f, :, :, oa] = t[:, None]
+        U[f, :, :, ob] = t[None, :]
+    return U
+
+
+def support_grids(md: ModelDesc, grid=SUPPORT_GRID):
+    """GqModelDesc.support_grid: per cloud its support function at the cube-map nodes, rounded UP (the kernel evaluates the bilinear blend in
+    fp32: a relative 1e-6 and an absolute micrometre on top keep the blend an upper bound).  [ncloud][6][grid+1][grid+1] float64."""
+    V = np.asarray(md.vert_pos, dtype=np.float64)
+    U = support_grid_nodes(grid).reshape(-1, 3)
+    out = np.zeros((len(md.cloud_vertnum), 6, grid + 1, grid + 1))
+    for cl in range(len(md.cloud_vertnum)):
+        n, a = int(md.cloud_vertnum[cl]), int(md.cloud_vertadr[cl])
+        if n == 0:
+            continue
+        h = (V[a:a + n] @ U.T).max(0)
+        out[cl] = (h + 1e-6 * np.abs(h) + 1e-6).reshape(6, grid + 1, grid + 1)
+    return out
 
 
 def _patch_order(ax, ids, chunk):
@@ -406,7 +437,7 @@ class MarshalledModel:
         d.nselfpair = int(len(pairs))
         self.self_pairs = pairs
         for name, ctype in GqModelDesc._fields_:
-            if ctype in (_I, _D) and not name.startswith('plane_') and not name.startswith('vert_adj'):   # (the optional tables are filled below)
+            if ctype in (_I, _D) and not name.startswith('plane_') and not name.startswith('vert_adj') and name != 'support_grid':   # (the optional tables are filled below)
                 src = q0 if name == 'qpos0' else (box_arrays[name] if name in box_arrays else getattr(md, name))
                 arr = np.ascontiguousarray(src, dtype=np.int32 if ctype is _I else np.float64)
                 if arr.size == 0:
@@ -458,6 +489,11 @@ class MarshalledModel:
             d.plane_vert_pos = pv.ctypes.data_as(_D)
             d.plane_mask = pm.ctypes.data_as(_I)
             d.plane_order = po.ctypes.data_as(_I)
+        # support-function grids of the clouds (optional: NULL = every hull pair past the oriented boxes goes to the convex routine)
+        if nvert > 0:
+            sg = np.ascontiguousarray(support_grids(md), dtype=np.float64)
+            self._keep.append(sg)
+            d.support_grid = sg.ctypes.data_as(_D)
         # hull graphs of the mesh clouds (optional in the C-ABI: NULL = a mesh meets a plane at its support vertex only)
         if nvert > 0 and mesh_graph and hull_graphs_enabled(md):
             ga, gn, gl = hull_graphs(md)

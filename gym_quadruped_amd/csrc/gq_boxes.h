@@ -182,6 +182,24 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
       const V3 gap = v3(fmaxf(0.0f, fabsf(c.x) - bs.x - ee.x), fmaxf(0.0f, fabsf(c.y) - bs.y - ee.y), fmaxf(0.0f, fabsf(c.z) - bs.z - ee.z));
       needs = sqrtf(dot(gap, gap)) - O[12] < marg + 1e-5f;
     }
+    if (needs) { /* third test, still ONE lane: the hull itself (its support-function grid, cvx_hgrid) against the box along the direction GJK would
+                  * try first - nine in ten (geom, box) pairs that pass the boxes' test end at that query of the wave-serial routine (hyqreal1 over a box
+                  * field: 31 of them per env-step, tools/convex_census.py) */
+      const GQ_MODEL GqDevGeom& G = m.lg[lane];
+      if (G.hgrid_adr >= 0 && dot(hintw, hintw) > 0.25f) {
+        const float* Rb = W.xmat[G.body];
+        float Rg[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) Rg[3 * i + j] = Rb[3 * i] * G.mat[j] + Rb[3 * i + 1] * G.mat[3 + j] + Rb[3 * i + 2] * G.mat[6 + j];
+        const V3 tg = ld3(W.xpos[G.body]) + matvec(Rb, ld3(G.pos));
+        const V3 d = hintw, dl = matTvec(Rg, -1.0f * d), db = matTvec(B.mat, d);
+        const float hB = -dot(tg, d) + cvx_hgrid(vx, G.hgrid_adr, dl);                                    /* max over the hull of v . (-d) */
+        const float hA = dot(bp, d) + bs.x * fabsf(db.x) + bs.y * fabsf(db.y) + bs.z * fabsf(db.z);          /* max over the box of v . d */
+        if (-hA - hB > (marg + G.radius + 1e-5f) * fast_sqrt(dot(d, d))) needs = false;
+      }
+    }
     if (!needs) W.u2.c.lg_dist[lane] = 1e30f;
   }
   uint64_t todo = ballot(needs);
@@ -720,6 +738,28 @@ __device__ inline void self_item_obb(const WaveMem& W, const GQ_MODEL GqDevModel
   }
 }
 
+/* third mid-phase test of a convex self pair, ONE lane: the two shapes along the line of their origins (the direction GJK tries first) - a
+ * hull by the upper bound of its support function (cvx_hgrid), a sphere / capsule core exactly.  true: farther apart than margin + radii,
+ * the pair needs no support query (three in four of the pairs that pass the oriented boxes end at the routine's first one). */
+__device__ inline bool self_hulls_apart(const WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, int it1, const float* k1, const float* R1,
+                                        int it2, const float* k2, const float* R2, float marg) {
+  V3 t[2]; float r[2]; int adr[2]; bool seg[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int it = s ? it2 : it1; const float* k = s ? k2 : k1;
+    const int pt = it < 4 ? 2 : m.lg[it - 4].ptype;
+    seg[s] = pt == 2 || pt == 3;
+    if (seg[s]) { t[s] = 0.5f * (ld3(k) + ld3(k + 3)); r[s] = k[6]; adr[s] = -1; }
+    else { const GQ_MODEL GqDevGeom& G = m.lg[it - 4]; t[s] = ld3(W.xpos[G.body]) + matvec(W.xmat[G.body], ld3(G.pos)); r[s] = G.radius; adr[s] = G.hgrid_adr; if (adr[s] < 0) return false; }
+  }
+  const V3 d = t[1] - t[0];
+  const float dd = dot(d, d);
+  if (!(dd > 1e-12f)) return false;
+  const float hA = seg[0] ? fmaxf(dot(ld3(k1), d), dot(ld3(k1 + 3), d)) : dot(t[0], d) + cvx_hgrid(vx, adr[0], matTvec(R1, d));                 /* max over A of v . d */
+  const float hB = seg[1] ? fmaxf(-dot(ld3(k2), d), -dot(ld3(k2 + 3), d)) : -dot(t[1], d) + cvx_hgrid(vx, adr[1], matTvec(R2, -1.0f * d));       /* max over B of v . (-d) */
+  return -hA - hB > (marg + r[0] + r[1] + 1e-5f) * fast_sqrt(dd);
+}
+
 template <bool CONE, bool PRIM = true>
 __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr) {
   constexpr int NP = PRIM ? 4 : 1; /* points per pair: only the exact pair routines return more than one */
@@ -727,11 +767,13 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
   const int nsp = K.nsp;
   if (nsp == 0) return;
 #ifdef GQ_XQ_OFF /* experiment builds: the pair exchange compiled out */
-  int32_t* const xq_tab = nullptr; const int xq_slots = 0; const int xq_act = 0; (void)Bt;
+  int32_t* const xq_tab = nullptr; const int xq_slots = 0; const int xq_pre = 0; (void)Bt;
 #else
   int32_t* const xq_tab = Bt.xq; const int xq_slots = Bt.xq_slots; /* (fetched here: the scalar loads return behind the end points and the pair cull) */
-  int xq_act = 0; /* the time word of this wavefront's window, fetched here (lane 31's word of a whole-window load would do: one word is enough) so that its latency passes behind the end points and the pair cull */
-  if (xq_tab) { Xq X0; X0.q = xq_tab; X0.slots = xq_slots; xq_act = ld_pub(xq_time_word(X0, xq_window(X0, wave_index()))); }
+  /* the first half of this wavefront's window of the table - its word 31: when a pair was last published into the window, its word 63: when
+   * an env without convex work (a potential helper) last passed by - fetched here, so that the latency passes behind the end points and the cull */
+  int xq_pre = 0;
+  if (xq_tab) { Xq X0; X0.q = xq_tab; X0.slots = xq_slots; xq_pre = ld_pub(xq_tab + xq_window(X0, wave_index()) + lane); }
 #endif
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   /* world end points of every item's proxy capsule, once: lane = collision item; scratch in the J block, which is free
@@ -805,7 +847,14 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
     ncand += popc64(cm);
   }
   GQ_SUB(W, 1, 11); /* pair cull */
-  if (K.self_cut == 2 || (ncand == 0 && (xq_tab == nullptr || !xq_is_hot(xq_act, wall_clock64())))) return;
+  const int xq_act = bcast(xq_pre, 31), xq_hlp = bcast(xq_pre, 63);
+  if (K.self_cut == 2) return;
+  if (ncand == 0) { /* nothing of its own to do here: leave word of that, and stay only if pairs have come this way lately */
+    if (xq_tab == nullptr) return;
+    Xq X0; X0.q = xq_tab; X0.slots = xq_slots;
+    xq_mark_helper(X0, wave_index(), xq_hlp);
+    if (!xq_is_hot(xq_act, wall_clock64())) return;
+  }
   if (ncand > 2 * GQ_WAVE) ncand = 2 * GQ_WAVE; /* more than 128 close pairs: the robot is a knot; the row budget is long spent */
   wave_barrier();
   const int npass = ncand > 0 ? ncand : 1; /* (a batch with a pair exchange: an env without a candidate still passes by the convex block once - it may have time for others, gq_exchange.h) */
@@ -838,6 +887,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         self_item_obb(W, m, it1, k1, c1, R1, h1);
         self_item_obb(W, m, it2, k2, c2, R2, h2);
         cvx = !obb_apart(c1, R1, h1, c2, R2, h2, marg);
+        if (cvx) cvx = !self_hulls_apart(W, m, K.vx, it1, k1, R1, it2, k2, R2, marg); /* the hulls themselves, by their support grids */
       } else if constexpr (PRIM) { /* a box is involved: exact routines (gq_pairs.h); the box of kind 1 / 3 is item 1, of kind 2 item 2 */
         const int ib = kind == 2 ? it2 : it1;
         bool continue_pair = true;
@@ -891,7 +941,8 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
 #define GQ_XTIME(i) GQ_XSTAT(i, wall_clock64() & 0xFFFFF)
       int x_back = 0, x_help = 0; long long x_ticks = 0, x_t0 = 0; bool x_ld = false;
       if (cm) GQ_XSTAT(0, popc64(cm));
-      if (X.q != nullptr && (cm & (cm - 1)) != 0) { /* two pairs or more: keep the first, publish the others - at once, helpers come by only so often */
+      if (X.q != nullptr && cm == 0 && ncand != 0 && c0 + GQ_WAVE >= npass) xq_mark_helper(X, wave_index(), xq_hlp);
+      if (X.q != nullptr && (cm & (cm - 1)) != 0 && xq_is_hot(xq_hlp, wall_clock64())) { /* two pairs or more - and envs with time on their hands around (hyqreal1 on boxes: every env has four or five pairs, publishing would be pure overhead): keep the first, publish the others - at once, helpers come by only so often */
         const uint64_t rest = cm & (cm - 1);
         if ((rest >> lane) & 1ull) myslot = xq_reserve(X, wave_index(), lane);
         own = ballot(myslot >= 0);

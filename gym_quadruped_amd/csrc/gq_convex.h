@@ -580,6 +580,26 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
   }
 }
 
+/* An UPPER bound of a cloud's support function h(d) = max over its vertices v of v . d, d in the geom frame (any length), ONE lane: the
+ * bilinear blend of the four nodes of d's cell in the cloud's cube-map table (GqModelDesc.support_grid, 6 x 9 x 9 values at vx[adr..]) -
+ * h is convex and positively homogeneous, the blend of a cell's corners bounds it from above, second order in the cell size.  With it a lane
+ * proves a pair of hulls apart along a direction - no contact within the margin - without the routine's wave-wide support query. */
+__device__ inline float cvx_hgrid(const GQ_MODEL float* vx, int adr, V3 d) {
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  int face; float mj, a, b;
+  if (ax >= ay && ax >= az) { face = d.x >= 0.0f ? 0 : 1; mj = ax; a = d.y; b = d.z; }
+  else if (ay >= az) { face = d.y >= 0.0f ? 2 : 3; mj = ay; a = d.x; b = d.z; }
+  else { face = d.z >= 0.0f ? 4 : 5; mj = az; a = d.x; b = d.y; }
+  if (!(mj > 1e-30f)) return 3e38f;
+  const float inv = fast_rcp(mj);
+  const float fa = fminf(fmaxf((a * inv + 1.0f) * 4.0f, 0.0f), 8.0f), fb = fminf(fmaxf((b * inv + 1.0f) * 4.0f, 0.0f), 8.0f);
+  const int ia = imin((int)fa, 7), ib = imin((int)fb, 7);
+  const float ta = fa - (float)ia, tb = fb - (float)ib;
+  const GQ_MODEL float* T = vx + adr + face * 81 + ia * 9 + ib;
+  const float h0 = T[0] + tb * (T[1] - T[0]), h1 = T[9] + tb * (T[10] - T[9]);
+  return mj * (h0 + ta * (h1 - h0)) + 2e-6f * mj; /* (fp32 blend: a hair on top) */
+}
+
 /* mid phase of a convex pair, ONE lane: two oriented boxes (centre, axes = columns of R, half extents) are held apart by more than
  * `reach` along one of the 15 separating-axis candidates (oracle obb_apart) - then so are the hulls inside them */
 __device__ inline bool obb_apart(V3 ca, const float* Ra, V3 ha, V3 cb, const float* Rb, V3 hb, float reach) {

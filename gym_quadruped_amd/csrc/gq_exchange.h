@@ -84,6 +84,12 @@ __device__ __forceinline__ int xq_time_units(long long ticks) { return (int)((ti
  * publishing lane.  (ONE such word for the whole table, read by every wavefront, was tried: 4096 device-coherent loads of one address
  * delayed the stage by 14 us - and a plain load never sees the update, each XCD's L2 keeps the line it fetched first.) */
 __device__ __forceinline__ int32_t* xq_time_word(const Xq& x, int slot) { return x.q + ((slot & ~127) | 31); }
+/* ... and its word 63: when an env without convex work last passed by the convex block - owners publish only while such envs are around.
+ * (Rewritten once a millisecond at most: hlp = the value the caller fetched.) */
+__device__ __forceinline__ void xq_mark_helper(const Xq& x, int widx, int hlp) {
+  const long long now = wall_clock64();
+  if (lane_id() == 0 && (hlp == 0 || ((xq_time_units(now) - hlp) & 0x3fffffff) > 6250)) st_pub(x.q + xq_window(x, widx) + 63, xq_time_units(now));
+}
 __device__ __forceinline__ void xq_mark_active(const Xq& x, int slot) { st_pub(xq_time_word(x, slot), xq_time_units(wall_clock64())); }
 __device__ __forceinline__ bool xq_is_hot(int word, long long now_ticks) { return word != 0 && ((xq_time_units(now_ticks) - word) & 0x3fffffff) < GQ_XQ_HOT_UNITS; }
 

@@ -272,6 +272,16 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       }
     }
   }
+  /* support grids (optional): 486 node values per cloud, in the x array */
+  std::vector<int> cloud_hgrid(d->ncloud > 0 ? d->ncloud : 0, -1);
+  if (d->support_grid) {
+    for (int cl = 0; cl < d->ncloud; cl++) {
+      if (d->cloud_vertnum[cl] < 3) continue; /* spheres and capsules answer analytically */
+      cloud_hgrid[cl] = (int)vx->size();
+      for (int k = 0; k < 486; k++) { vx->push_back((float)d->support_grid[(size_t)cl * 486 + k]); vy->push_back(0.0f); vz->push_back(0.0f); }
+      /* (float) rounds to nearest: the table's own margin - 1e-6 relative + 1 um - covers it */
+    }
+  }
   /* hull graphs (optional): per cloud with a graph, one record per vertex of the DIRECTION-ordered copy - x = first entry of its neighbour
    * list, y = the list's length - and the lists themselves: the neighbours' COORDINATES (geom frame) in ascending order of their index in
    * vert_pos, so that the floor pass reaches the support vertex's neighbours with one record load and one coordinate load */
@@ -316,7 +326,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
     if (M.nlg >= GQ_MAXLG) FAIL("more than %d link collision geoms", GQ_MAXLG);
     GqDevGeom& G = M.lg[M.nlg++];
     G.body = b - 1; G.cloud_adr = d->cloud_vertadr[cl]; G.cloud_num = d->cloud_vertnum[cl]; G.radius = (float)d->cloud_radius[cl];
-    G.plane_adr = plane_base + G.cloud_adr; G.pmask_adr = cloud_pmask[cl]; G.cap_adr = cloud_cap[cl]; G.nbr_adr = cloud_nbr[cl];
+    G.plane_adr = plane_base + G.cloud_adr; G.pmask_adr = cloud_pmask[cl]; G.cap_adr = cloud_cap[cl]; G.nbr_adr = cloud_nbr[cl]; G.hgrid_adr = cloud_hgrid[cl];
     double R[9]; quat2mat(d->geom_quat + 4 * g, R);
     for (int i = 0; i < 3; i++) G.pos[i] = (float)d->geom_pos[3 * g + i];
     for (int i = 0; i < 9; i++) G.mat[i] = (float)R[i];

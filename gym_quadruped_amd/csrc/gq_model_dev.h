@@ -34,6 +34,7 @@ struct GqDevGeom {          /* a robot collision geom that is not a foot sphere 
   int32_t pmask_adr;        /* ... and the index (vertex array x) of its per-direction-cell chunk masks, stored as floats; -1: scan every chunk */
   int32_t cap_adr;          /* clouds of more than one chunk with plane tables: index (vertex arrays) of the 16 chunk caps of the direction-ordered copy - entries
                              * 0..15: the unit axes, entries 16..31: x = cosine of the half angle (-2: always scanned); -1: none (gq_convex.h) */
+  int32_t hgrid_adr;        /* hull / cylinder clouds with a support grid (GqModelDesc.support_grid): index (vertex array x) of its 6 x 81 node values; -1: none */
   int32_t nbr_adr;          /* mesh geoms: index (vertex arrays) of the hull-graph records of the DIRECTION-ordered copy - entry i: x = first entry of vertex i's
                              * neighbour list (an index into the vertex arrays, where the neighbours' COORDINATES stand, ascending hull-table index), y = its
                              * length; -1: no graph (support vertex only) */

@@ -873,6 +873,12 @@ def test_pair_exchange_changes_nothing(robot):
     o = Oracle(marshalled(robot, solver=1, iterations=100, tolerance=1e-12))
     rng = np.random.default_rng(11)
     qpos, qvel = self_contact_states(mm.md, n, rng, o, want_cross=True)
+    # two envs in the key posture in front (one per window of the emulator's 256-slot table): envs without convex work of their own, whose
+    # passing by is what makes the entangled ones publish (gq_exchange.h: owners publish only while potential helpers are around)
+    q0, v0 = random_states(mm.md, 2, rng, z_range=(0.6, 0.7))
+    q0[:, 7:] = mm.md.key_qpos[0][7:]; q0[:, 3:7] = [1, 0, 0, 0]
+    qpos, qvel = np.concatenate([q0, qpos]), np.concatenate([0 * v0, qvel])
+    n += 2
     qvel = qvel.astype(np.float32)
     ctrl = (rng.normal(0, 1, (n, 12)) * 20).astype(np.float32)
     L = emu_lib()

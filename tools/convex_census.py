@@ -29,9 +29,15 @@ def main(robot='mini_cheetah', n_envs=48, n_steps=250, boxes=None):
     call_hist, work_hist, work2_hist = np.zeros(64, dtype=np.int64), np.zeros(256, dtype=np.int64), np.zeros(256, dtype=np.int64)
     prev = np.zeros(12, dtype=np.int64)
     nself_tot = nsteps = nterm = 0
+    def spawn():
+        q, v = random_states(md, 1, rng, z_range=(1.0 * hip, 1.2 * hip))
+        if boxes is not None:   # over the box field (tests/test_kernel_emulated.py test_world_boxes_step_matches_oracle)
+            q[0, 0] = rng.uniform(0.5 + 2 * hip, 0.5 + 10 * hip); q[0, 1] = rng.uniform(-3 + 2 * hip, -3 + 12 * hip); q[0, 2] += 0.25 * hip
+        return q, v
+
     for e in range(n_envs):
         o = Oracle(mm)
-        q, v = random_states(md, 1, rng, z_range=(1.0 * hip, 1.2 * hip))
+        q, v = spawn()
         o.set_state(q[0], 0 * v[0], np.zeros(18), np.zeros(18))
         for k in range(n_steps):
             o.step(50.0 * rng.normal(size=12))
@@ -49,7 +55,7 @@ def main(robot='mini_cheetah', n_envs=48, n_steps=250, boxes=None):
             world = g1 < 0
             if np.any(world & ((bodies < 2) | ((bodies - 2) % 3 != 2))):   # a non-calf body on the ground: the env terminates and re-spawns
                 nterm += 1
-                q, v = random_states(md, 1, rng, z_range=(1.0 * hip, 1.2 * hip))
+                q, v = spawn()
                 o.set_state(q[0], 0 * v[0], np.zeros(18), np.zeros(18))
     L.gqo_cvx_stats(stats.ctypes.data_as(C.c_void_p), 1)
     print(f'{robot}: {nsteps} env-steps, {nterm} terminations, self contacts / step {nself_tot / nsteps:.3f}')
@@ -76,4 +82,11 @@ def main(robot='mini_cheetah', n_envs=48, n_steps=250, boxes=None):
 
 
 if __name__ == '__main__':
-    main(*(sys.argv[1:2] or ['mini_cheetah']))
+    # usage: convex_census.py [robot] [boxes]   ('boxes': the random_boxes scene of BASELINE config 5, seed 0)
+    robot = sys.argv[1] if len(sys.argv) > 1 else 'mini_cheetah'
+    boxes = None
+    if len(sys.argv) > 2 and sys.argv[2] == 'boxes':
+        from gym_quadruped_amd.terrain import generate_terrain
+        from gym_quadruped_amd.robot_cfgs import get_robot_config
+        boxes = generate_terrain('random_boxes', float(get_robot_config(robot).hip_height), seed=10)[0]['boxes']
+    main(robot, n_envs=24 if boxes is not None else 48, n_steps=150 if boxes is not None else 250, boxes=boxes)
