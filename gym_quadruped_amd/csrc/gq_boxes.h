@@ -221,7 +221,7 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
     dist = 1e30f; nrm = v3(0.0f, 0.0f, 1.0f); pt = v3(0.0f, 0.0f, 0.0f);
     if ((todo | ballot(foot_near) | ballot(prim_near)) == 0) return false;
   }
-  if (todo) { /* wave-uniform: the world box as shape A of the convex routine (mjc_Convex: box = geom 1, the normal points out of it) */
+  if (__builtin_expect(todo != 0, 0)) { /* wave-uniform: the world box as shape A of the convex routine (mjc_Convex: box = geom 1, the normal points out of it) */
     CvxShape A;
     A.kind = 1; A.adr = 0; A.num = 0; A.pm = -1; A.t = bp; A.h = bs; A.r = 0.0f;
 #pragma unroll
@@ -229,7 +229,7 @@ __device__ inline bool box_item_scan(WaveMem& W, const GQ_MODEL GqDevModel& m, c
     wave_barrier();
     cvx_shape_store(GQ_CVX_SHP(W), A);
   }
-  while (todo) { /* wave-uniform: one hull / cylinder cloud against the box - GJK + EPA on the wavefront (gq_convex.h) */
+  while (__builtin_expect(todo != 0, 0)) { /* wave-uniform: one hull / cylinder cloud against the box - GJK + EPA on the wavefront (gq_convex.h) */
     const int g = ffs64(todo);
     todo &= todo - 1;
     const GQ_MODEL GqDevGeom& G = m.lg[g];
@@ -738,6 +738,9 @@ __device__ inline void self_item_obb(const WaveMem& W, const GQ_MODEL GqDevModel
   }
 }
 
+/* (a macro: __builtin_expect has to stand in the function that branches on it - the hint of an inlined helper is lowered away before the inlining) */
+#define GQ_COLD_HINT(c) (COLD ? __builtin_expect((long)(c), 0L) : (long)(c)) /* (the front end folds the constant arm away) */
+
 /* third mid-phase test of a convex self pair, ONE lane: the two shapes along the line of their origins (the direction GJK tries first) - a
  * hull by the upper bound of its support function (cvx_hgrid), a sphere / capsule core exactly.  true: farther apart than margin + radii,
  * the pair needs no support query (three in four of the pairs that pass the oriented boxes end at the routine's first one). */
@@ -760,7 +763,9 @@ __device__ inline bool self_hulls_apart(const WaveMem& W, const GQ_MODEL GqDevMo
   return -hA - hB > (marg + r[0] + r[1] + 1e-5f) * fast_sqrt(dd);
 }
 
-template <bool CONE, bool PRIM = true>
+/* COLD: tell the register allocator that the convex block is rarely entered (see there) - the world-box variants, whose robots mostly have no hull
+ * pair (aliengo perlin + 8 %), do; the flat-scene variants, whose launch on the headline workload IS the convex routine, do not (- 4 % with it) */
+template <bool CONE, bool PRIM = true, bool COLD = false>
 __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr) {
   constexpr int NP = PRIM ? 4 : 1; /* points per pair: only the exact pair routines return more than one */
   const int lane = lane_id();
@@ -942,7 +947,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
       int x_back = 0, x_help = 0; long long x_ticks = 0, x_t0 = 0; bool x_ld = false;
       if (cm) GQ_XSTAT(0, popc64(cm));
       if (X.q != nullptr && cm == 0 && ncand != 0 && c0 + GQ_WAVE >= npass) xq_mark_helper(X, wave_index(), xq_hlp);
-      if (X.q != nullptr && (cm & (cm - 1)) != 0 && xq_is_hot(xq_hlp, wall_clock64())) { /* two pairs or more - and envs with time on their hands around (hyqreal1 on boxes: every env has four or five pairs, publishing would be pure overhead): keep the first, publish the others - at once, helpers come by only so often */
+      if (GQ_COLD_HINT(X.q != nullptr && (cm & (cm - 1)) != 0 && xq_is_hot(xq_hlp, wall_clock64()))) { /* two pairs or more - and envs with time on their hands around (hyqreal1 on boxes: every env has four or five pairs, publishing would be pure overhead): keep the first, publish the others - at once, helpers come by only so often */
         const uint64_t rest = cm & (cm - 1);
         if ((rest >> lane) & 1ull) myslot = xq_reserve(X, wave_index(), lane);
         own = ballot(myslot >= 0);
@@ -960,6 +965,9 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         if (myslot >= 0) { xq_ready(X, myslot); xq_mark_active(X, myslot); }
         GQ_XSTAT(1, popc64(own)); GQ_XTIME(2);
       }
+      /* (marked unlikely for the register allocator's sake: block frequencies are its spill weights, and the routine's loops otherwise outweigh
+       * values that live across the whole step - they were spilled all over the kernel, 57 scratch instructions in gq_step_body.h alone) */
+      if (GQ_COLD_HINT(local != 0 || own != 0 || linger))
 #pragma unroll 1
       for (;;) { /* wave-uniform */
         int j = -1, slot = -1;
@@ -1170,7 +1178,7 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
   if constexpr (SELF) {
     (void)pre;
     const SelfPrefetch pre_now = self_prefetch(m, nlg, K.nsp); /* not prefetched in front of the box loop: it would sit in registers (or scratch) across it */
-    append_self_contacts<CONE, PRIM>(W, m, mu_env, S, pre_now, K, nlg, Bt, xdbg);
+    append_self_contacts<CONE, PRIM, true>(W, m, mu_env, S, pre_now, K, nlg, Bt, xdbg);
   }
   if (lane == 0) {
     W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself; W.ndrop = S.ndrop;
