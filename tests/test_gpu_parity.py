@@ -997,25 +997,28 @@ def test_step_parity_on_benchmark_rollout_states(robot, scene):
     tally.finish(f'benchmark-state one-step parity {robot} {scene}', min_checked=0.85, max_tie=0.12, max_budget=0.03)
 
 
-@pytest.mark.parametrize('mode', ['step', 'rollout'])
+@pytest.mark.parametrize('mode', ['step', 'rollout', 'spot_boxes', 'sharded'])
 def test_pair_exchange_is_bit_identical(mode):
     """The convex pair exchange (csrc/gq_exchange.h): wavefronts of one launch compute each other's hull pairs.  4096 mini_cheetah envs under
     random torques without auto-reset - robots fall, fold up and stay that way: the state distribution with the most entangled envs -
     stepped with the exchange on and off end in bit-identical states, through the step loop and through the persistent rollout (one launch:
-    slots are reserved, freed and reused step after step).  The heavy launches also have to END: nothing in the protocol may wait for ever."""
-    n, steps = 4096, 300
+    slots are reserved, freed and reused step after step).  The heavy launches also have to END: nothing in the protocol may wait for ever.
+    'spot_boxes': the world-box kernel variant (the convex block is compiled as an unlikely region there) with a mesh robot on random_boxes and
+    the in-kernel auto-reset; 'sharded': the pipelined rollout - two shards' launches overlap on two streams and share the batch's table."""
+    n, steps = (4096, 300) if mode in ('step', 'rollout') else (2048, 150)
+    kw = dict(robot='spot', scene='random_boxes', auto_reset='next_step') if mode == 'spot_boxes' else dict(auto_reset=False)
     g = torch.Generator(device='cuda:0').manual_seed(5)
     acts = torch.randn(steps, n, 12, generator=g, device='cuda:0') * 40
     out = []
     for on in (True, False):
-        env = _make_env(n, obs=('qpos', 'qvel'), iters=100, tol=1e-8, solver='newton', auto_reset=False, pair_exchange=on)
+        env = _make_env(n, obs=('qpos', 'qvel'), iters=100, tol=1e-8, solver='newton', pair_exchange=on, **kw)
         assert env._mm.self_collision == 'convex'
         env.reset(random=True)
-        if mode == 'step':
+        if mode in ('step', 'spot_boxes'):
             for k in range(steps):
                 env.step(acts[k])
         else:
-            env.rollout(acts, shards=0)
+            env.rollout(acts, shards=0 if mode == 'rollout' else 2)
         torch.cuda.synchronize()
         out.append((env.qpos.clone(), env.qvel.clone(), env._contacts_dropped.clone()))
         env.close()
