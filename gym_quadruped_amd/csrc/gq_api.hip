@@ -66,6 +66,7 @@ struct GqBatch {
   uint8_t* load_hint;   /* device [N]: per-env solver load of the previous step (scheduling hint of the step kernel) */
   int32_t* xq;          /* device: convex pair exchange (gq_exchange.h) - models with convex self pairs only, else NULL */
   int xq_slots; bool xq_on;
+  float* sepc;          /* device: separating-axis cache of the convex self pairs (GqDevBatch::sepc) */
   int stop_stage;       /* profiling aid: GQ_STOP_STAGE at batch creation */
   int force_self;       /* profiling aid: GQ_FORCE_SELF=1 runs the self-collision kernel variant even for a model without pairs */
   /* argument block of step_kernel: device copy, host shadow of what the device holds, pinned staging ring for the
@@ -200,6 +201,9 @@ int gq_batch_create(GqModel* m, int n_envs, const int32_t* obs_ids, int n_obs, c
     b->xq_slots = slots;
     b->xq_on = true;
     b->host.xq = b->xq; b->host.xq_slots = slots;
+    HIP_TRY_OR_DESTROY(hipMalloc(&b->sepc, (size_t)n_envs * m->host.ncvx_self * 3 * sizeof(float)), gq_batch_destroy(b));
+    HIP_TRY_OR_DESTROY(hipMemset(b->sepc, 0, (size_t)n_envs * m->host.ncvx_self * 3 * sizeof(float)), gq_batch_destroy(b));
+    b->host.sepc = b->sepc; b->host.sepc_stride = m->host.ncvx_self * 3;
     HIP_TRY_OR_DESTROY(hipMemcpy(b->dev, &b->host, sizeof(GqDevBatch), hipMemcpyHostToDevice), gq_batch_destroy(b));
   }
   /* profiling knobs of development builds (tools/dev_build.sh defines GQ_DEV_KNOBS; tools/stage_insts.sh, stage_cuts.py): the product library
@@ -237,7 +241,7 @@ static void mailbox_free(GqBatch* b) {
 int gq_batch_destroy(GqBatch* b) {
   if (!b) return GQ_OK;
   DeviceGuard guard(b->model->device);
-  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->lift_pending); hipFree(b->load_hint); hipFree(b->xq); hipFree(b->dev_args);
+  hipFree(b->dev); hipFree(b->friction_next); hipFree(b->pending); hipFree(b->lift_pending); hipFree(b->load_hint); hipFree(b->xq); hipFree(b->sepc); hipFree(b->dev_args);
   if (b->staging) hipHostFree(b->staging);
   if (b->batch_staging) hipHostFree(b->batch_staging);
   mailbox_free(b);

@@ -741,11 +741,20 @@ __device__ inline void self_item_obb(const WaveMem& W, const GQ_MODEL GqDevModel
 /* (a macro: __builtin_expect has to stand in the function that branches on it - the hint of an inlined helper is lowered away before the inlining) */
 #define GQ_COLD_HINT(c) (COLD ? __builtin_expect((long)(c), 0L) : (long)(c)) /* (the front end folds the constant arm away) */
 
+/* the direction along which a pair was found apart -> its row of the axis cache: unit length, base frame (ONE lane; 0 0 0: nothing to remember) */
+__device__ inline void sepc_store(const WaveMem& W, float* row, V3 d) {
+  const float dd = dot(d, d);
+  V3 b = v3(0.0f, 0.0f, 0.0f);
+  if (dd > 1e-24f) b = fast_rsqrt(dd) * matTvec(W.xmat[0], d);
+  row[0] = b.x; row[1] = b.y; row[2] = b.z;
+}
+
 /* third mid-phase test of a convex self pair, ONE lane: the two shapes along the line of their origins (the direction GJK tries first) - a
- * hull by the upper bound of its support function (cvx_hgrid), a sphere / capsule core exactly.  true: farther apart than margin + radii,
+ * hull by the upper bound of its support function (cvx_hgrid), a sphere / capsule core exactly - or along `dir` (the axis cache: the direction
+ * the pair was found apart along a step ago).  true: farther apart than margin + radii,
  * the pair needs no support query (three in four of the pairs that pass the oriented boxes end at the routine's first one). */
 __device__ inline bool self_hulls_apart(const WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, int it1, const float* k1, const float* R1,
-                                        int it2, const float* k2, const float* R2, float marg) {
+                                        int it2, const float* k2, const float* R2, float marg, bool use_dir = false, V3 dir = {0.0f, 0.0f, 0.0f}) {
   V3 t[2]; float r[2]; int adr[2]; bool seg[2];
 #pragma unroll
   for (int s = 0; s < 2; s++) {
@@ -755,7 +764,7 @@ __device__ inline bool self_hulls_apart(const WaveMem& W, const GQ_MODEL GqDevMo
     if (seg[s]) { t[s] = 0.5f * (ld3(k) + ld3(k + 3)); r[s] = k[6]; adr[s] = -1; }
     else { const GQ_MODEL GqDevGeom& G = m.lg[it - 4]; t[s] = ld3(W.xpos[G.body]) + matvec(W.xmat[G.body], ld3(G.pos)); r[s] = G.radius; adr[s] = G.hgrid_adr; if (adr[s] < 0) return false; }
   }
-  const V3 d = t[1] - t[0];
+  const V3 d = use_dir ? dir : t[1] - t[0];
   const float dd = dot(d, d);
   if (!(dd > 1e-12f)) return false;
   const float hA = seg[0] ? fmaxf(dot(ld3(k1), d), dot(ld3(k1 + 3), d)) : dot(t[0], d) + cvx_hgrid(vx, adr[0], matTvec(R1, d));                 /* max over A of v . d */
@@ -766,7 +775,7 @@ __device__ inline bool self_hulls_apart(const WaveMem& W, const GQ_MODEL GqDevMo
 /* COLD: tell the register allocator that the convex block is rarely entered (see there) - the world-box variants, whose robots mostly have no hull
  * pair (aliengo perlin + 8 %), do; the flat-scene variants, whose launch on the headline workload IS the convex routine, do not (- 4 % with it) */
 template <bool CONE, bool PRIM = true, bool COLD = false>
-__device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr) {
+__device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, WorldAppend& S, const SelfPrefetch& pre, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr, const int env = 0) {
   constexpr int NP = PRIM ? 4 : 1; /* points per pair: only the exact pair routines return more than one */
   const int lane = lane_id();
   const int nsp = K.nsp;
@@ -777,6 +786,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
   int32_t* const xq_tab = Bt.xq; const int xq_slots = Bt.xq_slots; /* (fetched here: the scalar loads return behind the end points and the pair cull) */
   /* the first half of this wavefront's window of the table - its word 31: when a pair was last published into the window, its word 63: when
    * an env without convex work (a potential helper) last passed by - fetched here, so that the latency passes behind the end points and the cull */
+  float* const sepc = Bt.sepc ? Bt.sepc + (size_t)env * Bt.sepc_stride : nullptr; /* this env's rows of the separating-axis cache */
   int xq_pre = 0;
   if (xq_tab) { Xq X0; X0.q = xq_tab; X0.slots = xq_slots; xq_pre = ld_pub(xq_tab + xq_window(X0, wave_index()) + lane); }
 #endif
@@ -893,6 +903,11 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         self_item_obb(W, m, it2, k2, c2, R2, h2);
         cvx = !obb_apart(c1, R1, h1, c2, R2, h2, marg);
         if (cvx) cvx = !self_hulls_apart(W, m, K.vx, it1, k1, R1, it2, k2, R2, marg); /* the hulls themselves, by their support grids */
+        if (cvx && sepc) { /* ... and along the direction that told them apart a step ago (two links a few centimetres apart for ever: hyqreal1's trunk and upper legs) */
+          const float* c = sepc + 3 * Pp.cidx;
+          const V3 dw = matvec(W.xmat[0], v3(c[0], c[1], c[2]));
+          if (dot(dw, dw) > 0.25f) cvx = !self_hulls_apart(W, m, K.vx, it1, k1, R1, it2, k2, R2, marg, true, dw);
+        }
       } else if constexpr (PRIM) { /* a box is involved: exact routines (gq_pairs.h); the box of kind 1 / 3 is item 1, of kind 2 item 2 */
         const int ib = kind == 2 ? it2 : it1;
         bool continue_pair = true;
@@ -1014,6 +1029,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
         LdsCF out = GQ_CVX_SHP(W) + 2 * GQ_CVX_SHAPE_WORDS;
         if (j >= 0) {
           if (hit && lane == j) { H.n = 1; H.dist[0] = out[0]; H.nrm[0] = ld3(out + 1); H.pos[0] = ld3(out + 4); }
+          if (!hit && lane == j && sepc) sepc_store(W, sepc + 3 * m.sp[p].cidx, ld3(out + 1));
         } else {
           wave_barrier(); xq_done(X, slot, hit, out);
           if (xdbg && linger) x_ticks += wall_clock64() - x_t0;
@@ -1028,6 +1044,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
             const float* r = reinterpret_cast<const float*>(it) + GQ_XQ_RES;
             H.n = 1; H.dist[0] = ld_pub(r + 1); H.nrm[0] = v3(ld_pub(r + 2), ld_pub(r + 3), ld_pub(r + 4)); H.pos[0] = v3(ld_pub(r + 5), ld_pub(r + 6), ld_pub(r + 7));
           }
+          else if (sepc) { const float* r = reinterpret_cast<const float*>(it) + GQ_XQ_RES; sepc_store(W, sepc + 3 * m.sp[p].cidx, v3(ld_pub(r + 2), ld_pub(r + 3), ld_pub(r + 4))); }
           st_pub(xq_state(X, myslot), XQ_FREE); /* (the loads above have returned: H is used below) */
         }
       }
@@ -1104,7 +1121,7 @@ __device__ inline void append_self_contacts(WaveMem& W, const GQ_MODEL GqDevMode
 /* S6 for a scene without world boxes / height field but with robot self-collision: general frames for the floor
  * contacts the floor pass left in W, then the robot-robot contacts.  Ends with a barrier. */
 template <bool CONE>
-__device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr) {
+__device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, float mu_env, const SelfPrefetch& pre, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr, const int env = 0) {
   const int lane = lane_id();
   WorldAppend S;
   S.ncon = uniform(W.ncon); S.rows = uniform(W.nefc); S.invalid = 0; S.reserve = 0; S.nself = 0; S.ndrop = uniform(W.ndrop);
@@ -1116,7 +1133,7 @@ __device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL G
   }
   if constexpr (CONE)
     for (int c = 0; c < ncon; c++) { const int d = uniform(W.con_dim[c]); S.reserve += d > 1 ? d - 1 : 0; }
-  append_self_contacts<CONE>(W, m, mu_env, S, pre, K, nlg, Bt, xdbg);
+  append_self_contacts<CONE>(W, m, mu_env, S, pre, K, nlg, Bt, xdbg, env);
   { W.ncon = S.ncon; W.nefc = S.rows; W.nself = S.nself; W.ndrop = S.ndrop; } /* (every lane: the same words) */
   wave_barrier();
 }
@@ -1127,7 +1144,7 @@ __device__ __forceinline__ void stage_self_contacts(WaveMem& W, const GQ_MODEL G
  * materialised in scratch memory, 200 bytes per lane) */
 template <bool CONE, bool SELF, bool PRIM>
 __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL GqDevModel& m, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz,
-                                          double bx, double by, float mu_env, const SelfPrefetch& pre, const ItemRegs& IT, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr) {
+                                          double bx, double by, float mu_env, const SelfPrefetch& pre, const ItemRegs& IT, const StepConsts& K, const int nlg, const GQ_MODEL GqDevBatch& Bt, float* xdbg = nullptr, const int env = 0) {
   const int lane = lane_id();
   const PrimLane PL = prim_lane(W, m, IT, PRIM && lane < 4 + m.nlg, PRIM); /* all the box loop keeps of the item record */
   WorldAppend S;
@@ -1178,7 +1195,7 @@ __device__ __forceinline__ void stage_box_contacts(WaveMem& W, const GQ_MODEL Gq
   if constexpr (SELF) {
     (void)pre;
     const SelfPrefetch pre_now = self_prefetch(m, nlg, K.nsp); /* not prefetched in front of the box loop: it would sit in registers (or scratch) across it */
-    append_self_contacts<CONE, PRIM, true>(W, m, mu_env, S, pre_now, K, nlg, Bt, xdbg);
+    append_self_contacts<CONE, PRIM, true>(W, m, mu_env, S, pre_now, K, nlg, Bt, xdbg, env);
   }
   if (lane == 0) {
     W.ncon = S.ncon; W.nefc = S.rows; W.invalid = S.invalid; W.nself = S.nself; W.ndrop = S.ndrop;

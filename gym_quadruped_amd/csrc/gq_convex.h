@@ -301,7 +301,8 @@ __device__ __forceinline__ void cvx_face_plane(V3 a, V3 b, V3 c, V3& n, float& d
 }
 
 /* One convex pair.  shp: the two shape descriptors (A, B: GQ_CVX_SHAPE_WORDS each), then the result - dist, normal A -> B (3), point (3);
- * poly: GQ_CVX_POLY_WORDS words of scratch.  Returns true when the inflated shapes are closer than margin.  Wave-uniform. */
+ * poly: GQ_CVX_POLY_WORDS words of scratch.  Returns true when the inflated shapes are closer than margin; false: result words 1..3 hold the
+ * separating direction it found (0 0 0 when it has none to offer).  Wave-uniform. */
 GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, const GQ_MODEL float* vy, const GQ_MODEL float* vz, const float margin, const V3 hint = {0.0f, 0.0f, 0.0f}) {
   const int lane = lane_id();
   LdsCF SA = shp; LdsCF SB = shp + GQ_CVX_SHAPE_WORDS;
@@ -311,6 +312,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
   LdsI ADJ = PI + 4 * GQ_CVX_MAXV;
   LdsI RIM = ADJ + 64;
   const float rA = SA[19], rB = SB[19], reach = margin + rA + rB;
+  st3l(out + 1, v3(0.0f, 0.0f, 0.0f)); /* a pair found APART leaves the direction (A -> B) that separates it by more than margin + radii here: the caller's axis cache */
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   GQ_CVX_T0();
   const CvxCaps caps = cvx_caps_fetch(SA, SB, vx, vy, vz);
@@ -326,7 +328,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     if (dot(d0, d0) < 1e-24f) d0 = v3(1.0f, 0.0f, 0.0f);
     const CvxMink s0 = cvx_minkowski(G, vx, vy, vz, d0, caps);
     v = s0.w;
-    if (-dot(v, d0) > reach * fast_sqrt(dot(d0, d0))) return false; /* the first direction already separates the cores by more than reach */
+    if (-dot(v, d0) > reach * fast_sqrt(dot(d0, d0))) { st3l(out + 1, d0); return false; } /* the first direction already separates the cores by more than reach */
     wave_barrier();
     st3l(P, v); PI[3] = s0.id;
     wave_barrier();
@@ -341,7 +343,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
     GQ_CVX_T(1);
     const V3 w = sw.w;
     const float vw = dot(v, w);
-    if (vw > 0.0f && vw * vw > reach * reach * vv) return false; /* the cores are farther apart than anything of interest */
+    if (vw > 0.0f && vw * vw > reach * reach * vv) { st3l(out + 1, -1.0f * v); return false; } /* the cores are farther apart than anything of interest */
     const int wid = sw.id;
     bool dup = false;
 #pragma unroll
@@ -384,7 +386,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
   if (!enclosed) {
     const float len = fast_sqrt(dot(v, v));
     const float dist = len - rA - rB;
-    if (!(dist < margin)) return false;
+    if (!(dist < margin)) { st3l(out + 1, -1.0f * v); return false; }
     const V3 n = fast_rcp(len) * (-1.0f * v);
     V3 pa = v3(0.0f, 0.0f, 0.0f);
 #pragma unroll

@@ -538,7 +538,7 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
          * hull or cylinder with anything goes through the convex routine (gq_convex.h: kind 4) */
         auto prim = [&](int it) { if (it < 4) return 1; const int pt = M.lg[it - 4].ptype; return pt == 6 ? 2 : ((pt == 2 || pt == 3) ? 1 : 0); };
         const int k1 = prim(S.it1), k2 = prim(S.it2);
-        if ((k1 == 0 || k2 == 0) && d->self_convex) M.ncvx_self++;
+        S.cidx = ((k1 == 0 || k2 == 0) && d->self_convex) ? M.ncvx_self++ : -1;
         S.kind = ((k1 == 0 || k2 == 0) && d->self_convex) ? 4 : ((k1 == 2 && k2 == 2) ? 3 : ((k1 == 2 && k2 == 1) ? 1 : ((k1 == 1 && k2 == 2) ? 2 : 0)));
       }
       WorldGeom w{d->geom_condim[g1], d->geom_priority[g1], d->geom_solmix[g1], d->geom_margin[g1], d->geom_gap[g1], d->geom_solref + 2 * g1, d->geom_solimp + 5 * g1};

@@ -63,7 +63,7 @@ struct GqDevBox { float pos[3], mat[9], size[3], rad; int32_t cls; };
 /* robot self-collision (mj_collision between two bodies of the robot): body pairs for the broad phase, geom pairs with
  * their mixed contact parameters for the narrow phase (capsule proxies, gym_quadruped_amd/selfcol.py) */
 struct GqDevBodyPair { int32_t b1, b2, first, count; };   /* kernel body indices (0 = base), range of geom pairs */
-struct GqDevSelfPair { int32_t it1, it2, bp, kind; GqDevMix mix; }; /* kind: 0 two sphere / capsule cores (segment-segment), 1 box (item 1) - sphere / capsule (item 2), 2 sphere / capsule - box, 3 box - box (gq_pairs.h), 4 a hull / cylinder is involved (gq_convex.h) */ /* collision items (k < 4 foot k, else 4 + link geom); mix.rule: 0 max, 1 item1, 2 item2 */ /* mat: columns = box axes in the world; rad: bounding sphere */
+struct GqDevSelfPair { int32_t it1, it2, bp, kind; GqDevMix mix; int32_t cidx; /* kind 4: the pair's row in the batch's axis cache (GqDevBatch::sepc) */ }; /* kind: 0 two sphere / capsule cores (segment-segment), 1 box (item 1) - sphere / capsule (item 2), 2 sphere / capsule - box, 3 box - box (gq_pairs.h), 4 a hull / cylinder is involved (gq_convex.h) */ /* collision items (k < 4 foot k, else 4 + link geom); mix.rule: 0 max, 1 item1, 2 item2 */ /* mat: columns = box axes in the world; rad: bounding sphere */
 
 /* Everything lane `it` of the floor pass (S6: lane = collision item in MuJoCo's contact order) needs about its item, as ONE
  * contiguous 128-byte record: a single batch of loads, issued a stage early (the indirection con_order -> lg[] -> fields was two
@@ -224,6 +224,10 @@ struct GqDevBatch {            /* per-batch constants */
   /* convex pair exchange (gq_exchange.h; gq_batch_set_pair_exchange): the batch's table and its number of slots, NULL / 0: none.  Read where
    * it is used - held in registers across the step it cost the headline kernel 100 bytes of scratch per lane */
   int32_t* xq; int32_t xq_slots;
+  /* separating-axis cache of the convex self pairs: [N][ncvx_self][3] floats, the direction (base frame, unit) along which the pair was last found
+   * apart - tried again next step with the hulls' support grids by ONE lane before the pair goes to the routine.  A verified direction is a
+   * certificate, an unverified one is ignored: the cache changes no result, resets and snapshots ignore it.  NULL: none */
+  float* sepc; int32_t sepc_stride;
   /* in-episode resampling of the velocity command / disturbance wrench (gq_batch_set_resampling; 0 = off) */
   int32_t rs_cmd_reset, rs_dist_reset, rs_env_id_offset;
   int32_t rs_dist_kind[6];

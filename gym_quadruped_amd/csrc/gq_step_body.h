@@ -937,10 +937,10 @@ __device__ __forceinline__ int step_wave(const StepArgs& a, const StepCall& call
   if constexpr (BOXES) {
     const double bx0 = W.bxy[0], by0 = W.bxy[1]; /* base x/y of this forward pass, f64 */
     const float mu_b = W.mu_env;
-    stage_box_contacts<CONE, SELF, PRIM>(W, m, vx_p, vy_p, vz_p, bx0, by0, mu_b, self_pre, IT, K, nlg, Bt, (DBG && timing) ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_XQ : nullptr);
+    stage_box_contacts<CONE, SELF, PRIM>(W, m, vx_p, vy_p, vz_p, bx0, by0, mu_b, self_pre, IT, K, nlg, Bt, (DBG && timing) ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_XQ : nullptr, env);
   } else if constexpr (SELF) {
     const float mu_b = W.mu_env;
-    stage_self_contacts<CONE>(W, m, mu_b, self_pre, K, nlg, Bt, (DBG && timing) ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_XQ : nullptr);
+    stage_self_contacts<CONE>(W, m, mu_b, self_pre, K, nlg, Bt, (DBG && timing) ? call.debug + (size_t)env * GQ_DBG_SIZE + GQ_DBG_XQ : nullptr, env);
   }
   const int nefc = uniform(W.nefc), ncon = uniform(W.ncon), nlim = uniform(W.nlim), nfl = C.nfl; /* SGPRs */
   if (timing) { /* body poses go to the debug record now: xmat's LDS is reused by the Newton solver */

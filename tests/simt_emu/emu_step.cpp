@@ -56,6 +56,11 @@ extern "C" int emu_step(const GqModelDesc* desc, int n_envs, const int32_t* obs_
   call.ctrl = ctrl; call.mask = mask; call.debug = debug;
   call.auto_reset = auto_reset ? (auto_reset->autoreset_next_step ? 2 : 1) : 0; call.first_pass = first_pass;
   static std::vector<int32_t> xq;
+  static std::vector<float> sepc; /* the separating-axis cache (GqDevBatch::sepc): kept across calls like the batch's own */
+  if (M.ncvx_self > 0) {
+    if (sepc.size() != (size_t)n_envs * M.ncvx_self * 3) sepc.assign((size_t)n_envs * M.ncvx_self * 3, 0.0f);
+    B.sepc = sepc.data(); B.sepc_stride = M.ncvx_self * 3;
+  }
   if (g_emu_xq_on && M.ncvx_self > 0) {
     const int slots = 256;
     if (xq.empty()) xq.assign((size_t)slots * (1 + GQ_XQ_ITEM), 0);
