@@ -165,7 +165,7 @@ static int cvx_gjk_epa(const Cvx* A, const Cvx* B, double reach, double tol_rel,
     CvxPt w;
     cvx_minkowski(A, B, dir, &w);
     const double vw = cvx_dot(v, w.w);
-    if (vw > 0 && vw * vw > reach * reach * vv) return 0; /* the plane through w normal to v separates the cores by more than reach */
+    if (vw > 0 && vw * vw > reach * reach * vv) { if (niter) niter[0] = it + 1; return 0; } /* the plane through w normal to v separates the cores by more than reach (census: it + 1 support queries after the first) */
     int dup = 0;
     for (int i = 0; i < ns; i++) dup |= (S[i].ia == w.ia && S[i].ib == w.ib);
     if (dup || vv - vw <= tol_rel * (vv + sqrt(vv * cvx_dot(w.w, w.w)))) break; /* v is the closest point (to the round-off of the two products) */
