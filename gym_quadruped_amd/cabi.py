@@ -12,7 +12,7 @@ import numpy as np
 from .mjcf import ModelDesc
 
 GQ_NLEG = 4
-GQ_ABI_VERSION = 620   # include/gq.h
+GQ_ABI_VERSION = 630   # include/gq.h
 # optional extra output rows of the step kernel (include/gq.h gq_batch_set_outputs)
 GQ_DYN = dict(MC=0, MB=108, BIAS=144, XPOS=162, XMAT=201, FOOT=318, STRIDE=336)
 GQ_CON_MAX, GQ_CON_REC = 12, 24
@@ -217,7 +217,7 @@ def plane_support_tables(md: ModelDesc, grid=PLANE_GRID, chunk=64, wide_deg=45.0
     return _PLANE_CACHE[key]
 
 
-SUPPORT_GRID = 8   # cells per edge of a cube-map face (include/gq.h GqModelDesc.support_grid: 9 x 9 nodes per face)
+SUPPORT_GRID = 16   # cells per edge of a cube-map face (include/gq.h GQ_SUPPORT_GRID: 17 x 17 nodes per face; 32 x 32 was measured: within the noise of 16 x 16)
 
 
 def support_grid_nodes(grid=SUPPORT_GRID):

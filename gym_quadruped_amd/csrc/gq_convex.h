@@ -583,7 +583,7 @@ GQ_CVX_FN bool cvx_pair_wave(LdsF shp, LdsF poly, const GQ_MODEL float* vx, cons
 }
 
 /* An UPPER bound of a cloud's support function h(d) = max over its vertices v of v . d, d in the geom frame (any length), ONE lane: the
- * bilinear blend of the four nodes of d's cell in the cloud's cube-map table (GqModelDesc.support_grid, 6 x 9 x 9 values at vx[adr..]) -
+ * bilinear blend of the four nodes of d's cell in the cloud's cube-map table (GqModelDesc.support_grid, 6 x 17 x 17 values at vx[adr..]) -
  * h is convex and positively homogeneous, the blend of a cell's corners bounds it from above, second order in the cell size.  With it a lane
  * proves a pair of hulls apart along a direction - no contact within the margin - without the routine's wave-wide support query. */
 __device__ inline float cvx_hgrid(const GQ_MODEL float* vx, int adr, V3 d) {
@@ -594,11 +594,12 @@ __device__ inline float cvx_hgrid(const GQ_MODEL float* vx, int adr, V3 d) {
   else { face = d.z >= 0.0f ? 4 : 5; mj = az; a = d.x; b = d.y; }
   if (!(mj > 1e-30f)) return 3e38f;
   const float inv = fast_rcp(mj);
-  const float fa = fminf(fmaxf((a * inv + 1.0f) * 4.0f, 0.0f), 8.0f), fb = fminf(fmaxf((b * inv + 1.0f) * 4.0f, 0.0f), 8.0f);
-  const int ia = imin((int)fa, 7), ib = imin((int)fb, 7);
+  constexpr int NG = GQ_SUPPORT_GRID, NN = NG + 1;
+  const float fa = fminf(fmaxf((a * inv + 1.0f) * (0.5f * NG), 0.0f), (float)NG), fb = fminf(fmaxf((b * inv + 1.0f) * (0.5f * NG), 0.0f), (float)NG);
+  const int ia = imin((int)fa, NG - 1), ib = imin((int)fb, NG - 1);
   const float ta = fa - (float)ia, tb = fb - (float)ib;
-  const GQ_MODEL float* T = vx + adr + face * 81 + ia * 9 + ib;
-  const float h0 = T[0] + tb * (T[1] - T[0]), h1 = T[9] + tb * (T[10] - T[9]);
+  const GQ_MODEL float* T = vx + adr + face * (NN * NN) + ia * NN + ib;
+  const float h0 = T[0] + tb * (T[1] - T[0]), h1 = T[NN] + tb * (T[NN + 1] - T[NN]);
   return mj * (h0 + ta * (h1 - h0)) + 2e-6f * mj; /* (fp32 blend: a hair on top) */
 }
 

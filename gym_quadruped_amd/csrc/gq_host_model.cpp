@@ -272,13 +272,15 @@ int gq_build_dev_model(const GqModelDesc* d, GqDevModel* out, std::vector<float>
       }
     }
   }
-  /* support grids (optional): 486 node values per cloud, in the x array */
+  /* support grids (optional): 6 (G + 1)^2 node values per cloud, in the x array */
   std::vector<int> cloud_hgrid(d->ncloud > 0 ? d->ncloud : 0, -1);
   if (d->support_grid) {
     for (int cl = 0; cl < d->ncloud; cl++) {
       if (d->cloud_vertnum[cl] < 3) continue; /* spheres and capsules answer analytically */
       cloud_hgrid[cl] = (int)vx->size();
-      for (int k = 0; k < 486; k++) { vx->push_back((float)d->support_grid[(size_t)cl * 486 + k]); vy->push_back(0.0f); vz->push_back(0.0f); }
+      static_assert(GQ_SUPPORT_GRID == 16, "include/gq.h and gq_model_dev.h must agree on the grid (cabi.SUPPORT_GRID too)");
+      const int nn = 6 * (GQ_SUPPORT_GRID + 1) * (GQ_SUPPORT_GRID + 1);
+      for (int k = 0; k < nn; k++) { vx->push_back((float)d->support_grid[(size_t)cl * nn + k]); vy->push_back(0.0f); vz->push_back(0.0f); }
       /* (float) rounds to nearest: the table's own margin - 1e-6 relative + 1 um - covers it */
     }
   }

@@ -34,7 +34,7 @@ struct GqDevGeom {          /* a robot collision geom that is not a foot sphere 
   int32_t pmask_adr;        /* ... and the index (vertex array x) of its per-direction-cell chunk masks, stored as floats; -1: scan every chunk */
   int32_t cap_adr;          /* clouds of more than one chunk with plane tables: index (vertex arrays) of the 16 chunk caps of the direction-ordered copy - entries
                              * 0..15: the unit axes, entries 16..31: x = cosine of the half angle (-2: always scanned); -1: none (gq_convex.h) */
-  int32_t hgrid_adr;        /* hull / cylinder clouds with a support grid (GqModelDesc.support_grid): index (vertex array x) of its 6 x 81 node values; -1: none */
+  int32_t hgrid_adr;        /* hull / cylinder clouds with a support grid (GqModelDesc.support_grid): index (vertex array x) of its 6 x 17 x 17 node values; -1: none */
   int32_t nbr_adr;          /* mesh geoms: index (vertex arrays) of the hull-graph records of the DIRECTION-ordered copy - entry i: x = first entry of vertex i's
                              * neighbour list (an index into the vertex arrays, where the neighbours' COORDINATES stand, ascending hull-table index), y = its
                              * length; -1: no graph (support vertex only) */
@@ -63,6 +63,9 @@ struct GqDevBox { float pos[3], mat[9], size[3], rad; int32_t cls; };
 /* robot self-collision (mj_collision between two bodies of the robot): body pairs for the broad phase, geom pairs with
  * their mixed contact parameters for the narrow phase (capsule proxies, gym_quadruped_amd/selfcol.py) */
 struct GqDevBodyPair { int32_t b1, b2, first, count; };   /* kernel body indices (0 = base), range of geom pairs */
+#ifndef GQ_SUPPORT_GRID
+#define GQ_SUPPORT_GRID 16 /* = include/gq.h (checked in gq_host_model.cpp): cells per edge of a cube-map face of the hulls' support grids */
+#endif
 struct GqDevSelfPair { int32_t it1, it2, bp, kind; GqDevMix mix; int32_t cidx; /* kind 4: the pair's row in the batch's axis cache (GqDevBatch::sepc) */ }; /* kind: 0 two sphere / capsule cores (segment-segment), 1 box (item 1) - sphere / capsule (item 2), 2 sphere / capsule - box, 3 box - box (gq_pairs.h), 4 a hull / cylinder is involved (gq_convex.h) */ /* collision items (k < 4 foot k, else 4 + link geom); mix.rule: 0 max, 1 item1, 2 item2 */ /* mat: columns = box axes in the world; rad: bounding sphere */
 
 /* Everything lane `it` of the floor pass (S6: lane = collision item in MuJoCo's contact order) needs about its item, as ONE

@@ -61,8 +61,11 @@ extern "C" {
  * (gq_rollout_closed, gq_mailbox_get), GqObsOut.contacts_dropped; 500 = lap-tagged mailbox queue items, gq_struct_sizes(out[8]),
  * GqModelDesc.plane_* (optional); 510 = gq_batch_set_heightmap (no struct changed); 600 = GqModelDesc.vert_adj* / plane_order (hull
  * graphs: multi-point mesh-plane contacts), the general convex narrow phase (GJK / EPA) behind the same tables; 610 = gq_batch_set_pair_exchange
- * (no struct changed); 620 = GqModelDesc.support_grid (optional). */
-#define GQ_ABI_VERSION 620
+ * (no struct changed); 620 = GqModelDesc.support_grid (optional); 630 = that grid 16 x 16 cells per face (was 8 x 8). */
+#define GQ_ABI_VERSION 630
+#ifndef GQ_SUPPORT_GRID
+#define GQ_SUPPORT_GRID 16 /* cells per edge of a cube-map face of GqModelDesc.support_grid */
+#endif
 
 typedef struct GqModelDesc {
   int32_t struct_size; /* = sizeof(GqModelDesc) of the caller's header; gq_model_create refuses any other value */
@@ -227,12 +230,12 @@ typedef struct GqModelDesc {
    * scanned.  The convex routine (csrc/gq_convex.h) takes its support vertices from the chunks whose cap contains the query direction. */
   const double* plane_cap;       /* [ncloud][16][4] */
   /* OPTIONAL: per cloud the support function h(u) = max over its vertices v of v . u (geom frame) at the nodes of a cube map - face f of
-   * +x, -x, +y, -y, +z, -z, node (i, j), i, j = 0..8: u = the face's axis with the two other coordinates (in x, y, z order) at -1 + i / 4
-   * and -1 + j / 4, NOT normalised.  h is convex and positively homogeneous, so the bilinear blend of a cell's four nodes is an UPPER bound
+   * +x, -x, +y, -y, +z, -z, node (i, j), i, j = 0..GQ_SUPPORT_GRID: u = the face's axis with the two other coordinates (in x, y, z order) at -1 + 2 i / GQ_SUPPORT_GRID
+   * and -1 + 2 j / GQ_SUPPORT_GRID, NOT normalised.  h is convex and positively homogeneous, so the bilinear blend of a cell's four nodes is an UPPER bound
    * of h inside the cell (second order in the cell size: millimetres on a robot link): a lane tells a hull pair apart - no contact within
    * the margin - without a support query of the convex routine (csrc/gq_convex.h cvx_hgrid).  NULL: every pair past the oriented boxes
    * goes to the routine.  Values must not be below the true maxima (gym_quadruped_amd/cabi.py support_grids rounds up). */
-  const double* support_grid;    /* [ncloud][6][9][9] */
+  const double* support_grid;    /* [ncloud][6][GQ_SUPPORT_GRID + 1][GQ_SUPPORT_GRID + 1] */
   /* Robot-robot pairs that involve a mesh or a cylinder: 1 = the general convex routine on the geoms' hulls (mjc_Convex: GJK distance, EPA
    * penetration - what MuJoCo computes; csrc/gq_convex.h), 0 = the capsules of geom_capsule in their place (an approximation that finds such a
    * contact late, by the gap between hull and capsule, and costs a closest-point computation of two segments instead of ten to twenty support

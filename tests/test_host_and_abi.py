@@ -413,7 +413,7 @@ def test_support_grid_blend_is_an_upper_bound_and_tight(robot):
             continue
         D = rng.normal(size=(20000, 3)) * rng.uniform(0.2, 3.0, (20000, 1))     # any length
         D[:3000] /= np.abs(D[:3000]).max(1)[:, None]                            # on cube edges / cell borders
-        D[:1000, 1] = np.round(D[:1000, 1] * 4) / 4
+        D[:1000, 1] = np.round(D[:1000, 1] * 8) / 8
         D = D.astype(f32)
         ad = np.abs(D)
         major = np.where((ad[:, 0] >= ad[:, 1]) & (ad[:, 0] >= ad[:, 2]), 0, np.where(ad[:, 1] >= ad[:, 2], 1, 2))
@@ -421,8 +421,9 @@ def test_support_grid_blend_is_an_upper_bound_and_tight(robot):
         mj = ad[idx, major]
         face = 2 * major + (D[idx, major] < 0)
         oa = np.where(major == 0, 1, 0); ob = np.where(major == 2, 1, 2)
-        fa = np.clip((D[idx, oa] / mj + f32(1)) * f32(4), 0, 8).astype(f32); fb = np.clip((D[idx, ob] / mj + f32(1)) * f32(4), 0, 8).astype(f32)
-        ia = np.minimum(fa.astype(np.int32), 7); ib = np.minimum(fb.astype(np.int32), 7)
+        from gym_quadruped_amd.cabi import SUPPORT_GRID as NG
+        fa = np.clip((D[idx, oa] / mj + f32(1)) * f32(0.5 * NG), 0, NG).astype(f32); fb = np.clip((D[idx, ob] / mj + f32(1)) * f32(0.5 * NG), 0, NG).astype(f32)
+        ia = np.minimum(fa.astype(np.int32), NG - 1); ib = np.minimum(fb.astype(np.int32), NG - 1)
         ta = (fa - ia).astype(f32); tb = (fb - ib).astype(f32)
         t00, t01, t10, t11 = T[cl, face, ia, ib], T[cl, face, ia, ib + 1], T[cl, face, ia + 1, ib], T[cl, face, ia + 1, ib + 1]
         h0 = t00 + tb * (t01 - t00); h1 = t10 + tb * (t11 - t10)
